@@ -1,0 +1,169 @@
+/* libmitofilter_hip.so -- C ABI of the MI355X-native MitoFlex read pre-filter.
+ *
+ * What this boundary replaces.  The reference has NO FFI on this path: its
+ * only interface is the subprocess CLI `assemble/fastfilter` invoked through
+ * `shell_call` (assemble/assemble_wrapper.py:317-345, utility/helper.py:35-86).
+ * That CLI contract is kept by mitoflex_amd/assemble/fastfilter (built from
+ * mitoflex_amd/csrc/fastfilter_main.cpp).  The functions below are the
+ * additional in-process boundary BASELINE.json's north_star asks for
+ * ("libmitofilter_hip.so + ctypes wrapper"), following the export set
+ * recommended in SURVEY.md section 8b.  Each entry point cites the reference
+ * site whose role it takes over; where the reference has none it says so.
+ *
+ * Conventions: plain C, caller-allocated buffers, opaque handles created and
+ * destroyed by the library, return 0 on success / negative MF_E_* on failure,
+ * never throws; mf_last_error() returns a thread-local message.  Safe for
+ * concurrent calls on different devices; one host thread per device.
+ *
+ * There is no CPU fallback in this library: every compute entry point runs
+ * HIP kernels on a gfx950 device and fails with MF_E_NO_DEVICE without one.
+ */
+#ifndef MITOFILTER_H
+#define MITOFILTER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_ABI_VERSION 1
+
+enum {
+    MF_OK = 0,
+    MF_E_ARG = -1,        /* bad argument */
+    MF_E_IO = -2,         /* cannot open / read / write a file */
+    MF_E_NOMEM = -3,
+    MF_E_HIP = -4,        /* a HIP call failed; see mf_last_error() */
+    MF_E_NO_DEVICE = -5,  /* no usable gfx950 device */
+    MF_E_FORMAT = -6      /* malformed input */
+};
+
+/* mf_filter modes */
+enum {
+    MF_MODE_SCREENED = 0,   /* s-mer screen kernel + exact kernel on candidates (default) */
+    MF_MODE_EXHAUSTIVE = 1  /* exact kernel on every read (no screen) */
+};
+
+/* pair rule for mf_filter_fastq_files */
+enum { MF_PAIR_EITHER = 0, MF_PAIR_BOTH = 1 };
+
+typedef struct mf_kmerset mf_kmerset; /* bait k-mer table (+ screen structures), replicated per device */
+typedef struct mf_reads mf_reads;     /* one packed read set resident in one device's HBM */
+
+typedef struct {
+    int32_t  k;            /* k-mer length, 11..63 */
+    int32_t  key_words;    /* 1 (k<=32) or 2 u64 per key */
+    uint64_t slots;        /* open-address table slots (pow2) */
+    uint64_t n_keys;       /* distinct canonical k-mers */
+    uint64_t n_windows;    /* sum over records of max(0, len-k+1) */
+    int32_t  screen_s;     /* s-mer length used by the screen, 0 = screen disabled */
+    int32_t  screen_stride;/* sample stride in bases */
+    uint32_t bloom_words;  /* LDS bit-table size in u32 words */
+    uint32_t smer_slots;   /* exact s-mer table slots */
+    uint64_t n_smers;      /* distinct s-mers (both strands) */
+} mf_kmerset_info_t;
+
+typedef struct {
+    uint64_t n_reads;
+    uint64_t total_bases;
+    uint64_t n_invalid;    /* invalid (non-ACGT) bases */
+    uint32_t uniform_len;  /* >0 when every read has this length */
+    int32_t  device;
+} mf_reads_info_t;
+
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_pass;
+    uint64_t n_candidates;   /* reads handed to the exact kernel (screened mode) */
+    float    ms_total;       /* hipEvent time, first launch -> last kernel end  */
+    float    ms_screen;      /* screen kernel only */
+    float    ms_exact;       /* exact kernel only */
+    uint64_t algorithmic_bytes; /* ceil(2*bases/8) + ceil(n_reads/8): SURVEY.md 8d byte model */
+} mf_filter_stats_t;
+
+/* ---- library ---------------------------------------------------------- */
+int         mf_abi_version(void);
+const char *mf_last_error(void);
+/* number of visible gfx950 devices (>=0) or MF_E_HIP */
+int         mf_device_count(void);
+int         mf_device_name(int device, char *buf, size_t buflen);
+/* hipDeviceSynchronize on `device` (bench.py's barrier bracket) */
+int         mf_device_synchronize(int device);
+
+/* ---- bait k-mer set (no reference counterpart:
+ * profile/MT_database is protein, findmitoscaf/findmitoscaf.py:57) --------
+ * Parses a NUCLEOTIDE FASTA on the host, then builds the canonical-k-mer
+ * open-address table and the screen structures with device kernels.  The
+ * table is byte-identical to the CPU oracle's (history-independent layout). */
+int mf_kmerset_build_from_fasta(const char *fasta_path, int k, int device, mf_kmerset **out);
+int mf_kmerset_build_from_text(const char *fasta_text, size_t len, int k, int device, mf_kmerset **out);
+int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info);
+/* copy the device table back: keys_out must hold slots*key_words u64 */
+int mf_kmerset_export(const mf_kmerset *ks, int device, uint64_t *keys_out, size_t n_u64);
+int mf_kmerset_free(mf_kmerset *ks);
+
+/* ---- packed reads (row B1).  Layout: dense little-endian 2-bit stream,
+ * base i in words[i>>4] bits [2*(i&15), +1]; invalid bases stored as 0 and
+ * listed ascending in npos (global base indices); offsets has n_reads+1 base
+ * offsets.  The FASTQ conventions (4-line records, CR stripped, partial tail
+ * dropped, .gz by extension) are the reference's: filter/filter_bin/src/
+ * main.rs:287-321, filter/filter_bin/src/helper.rs:14-31. ------------------ */
+int mf_reads_from_packed(const uint32_t *words, const uint64_t *offsets, uint64_t n_reads,
+                         const uint64_t *npos, uint64_t n_npos, int device, mf_reads **out);
+int mf_reads_from_fastq(const char *fastq_path, int device, mf_reads **out);
+/* Deterministic synthetic PE150-shaped read set generated straight into the
+ * packed layout (bench / large parity properties): n_reads
+ * reads of read_len bases, iid uniform background; a fraction mito_ppm/1e6 of
+ * reads is sampled from bait_text (random strand, sub_ppm/1e6 substitution
+ * error); n_read_ppm/1e6 of reads get invalid bases at rate n_base_ppm/1e6.
+ * host_words_out/host_npos_out (optional) receive malloc'd host copies that
+ * the caller frees with mf_free_host(). */
+int mf_reads_synth(uint64_t n_reads, uint32_t read_len, uint64_t seed,
+                   const char *bait_fasta_text, size_t bait_len,
+                   uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm,
+                   int device, mf_reads **out,
+                   uint32_t **host_words_out, uint64_t *host_n_words_out,
+                   uint64_t **host_npos_out, uint64_t *host_n_npos_out);
+void mf_free_host(void *p);
+int mf_reads_info(const mf_reads *r, mf_reads_info_t *info);
+int mf_reads_free(mf_reads *r);
+
+/* ---- the hot path (rows B2, B3, B4): k-mer extract -> canonicalise ->
+ * open-address probe -> hit threshold.  Inputs already resident in HBM.
+ * out_bits: host buffer of ceil(n_reads/32) u32, bit r set = read r passes
+ * (hits >= threshold, threshold >= 1).  hits_out: optional host buffer of
+ * n_reads u32 receiving the full hit count of every read (disables the
+ * early exit; parity/debug).  stats optional. */
+int mf_filter(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
+              uint32_t *out_bits, uint32_t *hits_out, mf_filter_stats_t *stats);
+
+/* Same, result left on the device (no D2H); for timing loops.  Runs `steps`
+ * passes back to back on the library's stream and reports per-pass averages
+ * measured with hipEvents on that stream. */
+int mf_filter_resident(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
+                       int steps, mf_filter_stats_t *stats);
+
+/* One-shot over host buffers (SURVEY.md 8b name): H2D, filter, D2H. */
+int mf_filter_packed(const mf_kmerset *ks, int device,
+                     const uint32_t *words, const uint64_t *offsets, uint64_t n_reads,
+                     const uint64_t *npos, uint64_t n_npos,
+                     uint32_t threshold, uint32_t *out_bits);
+
+/* ---- file level: what a MitoFlex stage calls.  Takes the place
+ * `bim.bwa_map` has in the reference (bim/bim.py:43-58: reads in, baited
+ * reads out as FASTQ) and is hooked ahead of `megahit_core buildlib`
+ * (assemble/assemble_wrapper.py:162-193).  fq2/out2 NULL = single end.
+ * Records are zipped like the reference's PE reader (filter/filter_bin/src/
+ * main.rs:214); survivors keep input order and are written header/seq/+/qual
+ * (main.rs:261-268).  Chunks of whole pairs are dealt to n_devices GPUs (one
+ * host thread each, no collective); ".gz" inputs/outputs by extension. */
+int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2,
+                          const char *out1, const char *out2,
+                          uint32_t threshold, int pair_mode, int n_devices,
+                          uint64_t *kept, uint64_t *total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MITOFILTER_H */

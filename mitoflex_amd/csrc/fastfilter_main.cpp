@@ -1,0 +1,404 @@
+// `fastfilter` drop-in for MitoFlex (installed as mitoflex_amd/assemble/fastfilter,
+// the path MEGAHIT.FAST_FILTER resolves: assemble/assemble_wrapper.py:105-108).
+//
+// Personality 1 -- the reference's contig filter, argument for argument and
+// quirk for quirk (assemble/fastfilter_src/src/main.rs:9-134, helper.rs:12-41):
+//     fastfilter -i IN -o OUT -l MIN,MAX (-d INT | -m INT)
+// stdout carries the kept count and nothing else (the caller does int(stdout),
+// assemble_wrapper.py:326-339); a Rust panic is mirrored as exit code 101, a
+// clap usage error as exit code 1.  This part is plain host C++: it is a
+// kB-MB text filter and the reference itself is single-threaded host code.
+//
+// Personality 2 -- the read pre-filter the north star adds (no reference
+// counterpart):
+//     fastfilter bait --bait BAIT.fa -k 31 [-t 1] --fq1 R1.fq [--fq2 R2.fq]
+//                     --out1 O1.fq [--out2 O2.fq] [--pair either|both] [--devices N]
+// which loads libmitofilter_hip.so (HIP kernels, gfx950) and prints the kept
+// read/pair count.  It has no CPU fallback: without the library or a GPU it
+// exits non-zero, which shell_call turns into a RuntimeError (helper.py:82-86).
+#include "../../include/mitofilter.h"
+
+#include <dlfcn.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------ error exits
+static void (*g_flush_on_panic)() = nullptr;   // BufWriter::drop flushes while the panic unwinds
+
+[[noreturn]] static void rust_panic(const std::string &msg)
+{   // mirrors `panic!`/`unwrap()` failures: message on stderr, exit code 101
+    if (g_flush_on_panic) { void (*f)() = g_flush_on_panic; g_flush_on_panic = nullptr; f(); }
+    fflush(stdout);
+    fprintf(stderr, "thread 'main' panicked at '%s'\n", msg.c_str());
+    exit(101);
+}
+
+static const char *USAGE = "USAGE:\n    fastfilter [OPTIONS] -i <PATH> -l <INT,INT> -o <PATH>\n\nFor more information try --help\n";
+
+[[noreturn]] static void clap_error(const std::string &msg)
+{   // clap 2.33 usage errors exit with code 1
+    fprintf(stderr, "error: %s\n\n%s", msg.c_str(), USAGE);
+    exit(1);
+}
+
+static void print_help()
+{
+    fputs("Length filter 0.1\nJunyu Li\nA simple filter for trimming intermediate contigs.\n\n"
+          "USAGE:\n    fastfilter [OPTIONS] -i <PATH> -l <INT,INT> -o <PATH>\n\n"
+          "FLAGS:\n    -h, --help       Prints help information\n    -V, --version    Prints version information\n\n"
+          "OPTIONS:\n"
+          "    -m <INT>            Use it to take only x sequence with highest depth.\n"
+          "    -d <INT>            min depth\n"
+          "    -i <PATH>           Input file path, accepts only one-line format\n"
+          "    -l <INT,INT>        required min and max length\n"
+          "    -o <PATH>           Output file path\n", stdout);
+}
+
+// ------------------------------------------------------------ Rust parsers
+// str::parse::<usize>: optional '+', then ASCII digits only, no overflow
+static bool parse_usize(const std::string &s, uint64_t &out)
+{
+    size_t i = 0;
+    if (i < s.size() && s[i] == '+') i++;
+    if (i >= s.size()) return false;
+    uint64_t v = 0;
+    for (; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        const uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    out = v;
+    return true;
+}
+
+// str::parse::<i32>: optional sign, digits, range checked
+static bool parse_i32(const std::string &s, int32_t &out)
+{
+    size_t i = 0; bool neg = false;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+    if (i >= s.size()) return false;
+    int64_t v = 0;
+    for (; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (s[i] - '0');
+        if (v > (int64_t)INT32_MAX + 1) return false;
+    }
+    if (neg) v = -v;
+    if (v < INT32_MIN || v > INT32_MAX) return false;
+    out = (int32_t)v;
+    return true;
+}
+
+// str::parse::<f32>: [sign] (digits [. digits] | . digits) [(e|E) [sign] digits], or inf / infinity / nan;
+// no surrounding whitespace, no hex.  Value correctly rounded to binary32 (strtof does the same).
+static bool parse_f32(const std::string &s, float &out)
+{
+    size_t i = 0, n = s.size();
+    if (i < n && (s[i] == '+' || s[i] == '-')) i++;
+    auto ieq = [&](const char *w) {
+        size_t L = strlen(w);
+        if (n - i != L) return false;
+        for (size_t j = 0; j < L; j++) if (tolower((unsigned char)s[i + j]) != w[j]) return false;
+        return true;
+    };
+    bool ok = false;
+    if (ieq("inf") || ieq("infinity") || ieq("nan")) ok = true;
+    else {
+        size_t j = i, nd = 0;
+        while (j < n && isdigit((unsigned char)s[j])) { j++; nd++; }
+        if (j < n && s[j] == '.') { j++; while (j < n && isdigit((unsigned char)s[j])) { j++; nd++; } }
+        if (nd > 0) {
+            if (j < n && (s[j] == 'e' || s[j] == 'E')) {
+                j++;
+                if (j < n && (s[j] == '+' || s[j] == '-')) j++;
+                size_t ne = 0;
+                while (j < n && isdigit((unsigned char)s[j])) { j++; ne++; }
+                ok = ne > 0 && j == n;
+            } else ok = j == n;
+        }
+    }
+    if (!ok) return false;
+    out = strtof(s.c_str(), nullptr);
+    return true;
+}
+
+static bool valid_utf8(const char *p, size_t n)
+{
+    const unsigned char *s = (const unsigned char *)p;
+    size_t i = 0;
+    while (i < n) {
+        unsigned char c = s[i];
+        if (c < 0x80) { i++; continue; }
+        int len; uint32_t cp, min;
+        if ((c & 0xE0) == 0xC0) { len = 2; cp = c & 0x1F; min = 0x80; }
+        else if ((c & 0xF0) == 0xE0) { len = 3; cp = c & 0x0F; min = 0x800; }
+        else if ((c & 0xF8) == 0xF0) { len = 4; cp = c & 0x07; min = 0x10000; }
+        else return false;
+        if (i + len > n) return false;
+        for (int k = 1; k < len; k++) { if ((s[i + k] & 0xC0) != 0x80) return false; cp = (cp << 6) | (s[i + k] & 0x3F); }
+        if (cp < min || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += len;
+    }
+    return true;
+}
+
+// title.split_whitespace()[2].split('=')[1].parse::<f32>().unwrap()   (main.rs:86-91 / :120-124)
+static float header_depth(const char *t, size_t n)
+{
+    // Unicode White_Space for the ASCII range: \t \n \v \f \r space (non-ASCII spaces are not produced by MEGAHIT)
+    std::vector<std::pair<size_t, size_t>> tok;
+    size_t i = 0;
+    auto ws = [](unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); };
+    while (i < n) {
+        while (i < n && ws((unsigned char)t[i])) i++;
+        size_t b = i;
+        while (i < n && !ws((unsigned char)t[i])) i++;
+        if (i > b) tok.emplace_back(b, i - b);
+        if (tok.size() == 3) break;
+    }
+    if (tok.size() < 3) rust_panic("index out of bounds: the len is " + std::to_string(tok.size()) + " but the index is 2");
+    std::string f(t + tok[2].first, tok[2].second);
+    size_t e1 = f.find('=');
+    if (e1 == std::string::npos) rust_panic("index out of bounds: the len is 1 but the index is 1");
+    size_t e2 = f.find('=', e1 + 1);
+    std::string val = f.substr(e1 + 1, e2 == std::string::npos ? std::string::npos : e2 - e1 - 1);
+    float v;
+    if (!parse_f32(val, v)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseFloatError { kind: Invalid }");
+    return v;
+}
+
+// ----------------------------------------------------------------- file IO
+static bool has_gz_ext(const std::string &path)
+{   // Path::extension() == Some("gz")  (helper.rs:19,34)
+    size_t slash = path.rfind('/');
+    std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    size_t dot = name.rfind('.');
+    return dot != std::string::npos && dot != 0 && name.substr(dot) == ".gz";
+}
+
+static void read_all(const std::string &path, std::string &data)
+{
+    if (has_gz_ext(path)) {
+        FILE *probe = fopen(path.c_str(), "rb");
+        if (!probe) rust_panic("Cannot open file " + path + "!");
+        fclose(probe);
+        gzFile g = gzopen(path.c_str(), "rb");
+        if (!g) rust_panic("Cannot open file " + path + "!");
+        gzbuffer(g, 128 * 1024);
+        char buf[1 << 16]; int n;
+        while ((n = gzread(g, buf, sizeof buf)) > 0) data.append(buf, (size_t)n);
+        const bool bad = n < 0;
+        gzclose(g);
+        if (bad) rust_panic("called `Result::unwrap()` on an `Err` value: Custom { kind: InvalidInput, error: \"corrupt deflate stream\" }");
+        return;
+    }
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) rust_panic("Cannot open file " + path + "!");
+    char buf[1 << 16]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+    fclose(f);
+}
+
+struct Writer {
+    bool gz = false; gzFile g = nullptr; FILE *f = nullptr; std::string buf;
+    void open(const std::string &path)
+    {
+        gz = has_gz_ext(path);
+        if (gz) { g = gzopen(path.c_str(), "wb6"); if (!g) rust_panic("Cannot open file " + path); }   // Compression::default() = level 6
+        else { f = fopen(path.c_str(), "wb"); if (!f) rust_panic("Cannot open file " + path); }
+        buf.reserve(128 * 1024);
+    }
+    void drain() { if (buf.empty()) return; if (gz) gzwrite(g, buf.data(), (unsigned)buf.size()); else fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    void line(const char *p, size_t n) { buf.append(p, n); buf.push_back('\n'); if (buf.size() >= 128 * 1024) drain(); }
+    void close() { drain(); if (gz && g) gzclose(g); if (f) fclose(f); g = nullptr; f = nullptr; }
+};
+
+struct Line { const char *p; size_t n; };
+// BufRead::lines(): split at '\n', drop one trailing '\r', final line may lack '\n', empty trailing piece not yielded
+static void split_lines(const std::string &data, std::vector<Line> &lines)
+{
+    const char *p = data.data(), *end = p + data.size();
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        size_t n = (size_t)(le - p);
+        if (n && p[n - 1] == '\r') n--;
+        lines.push_back(Line{p, n});
+        if (!nl) break;
+        p = nl + 1;
+    }
+}
+
+// ------------------------------------------------------------ contig filter
+static int contig_filter_main(int argc, char **argv)
+{
+    std::string v_l, v_d, v_i, v_o, v_m;
+    bool has_l = false, has_d = false, has_i = false, has_o = false, has_m = false;
+    for (int a = 1; a < argc; a++) {
+        std::string arg = argv[a];
+        if (arg == "-h" || arg == "--help") { print_help(); return 0; }
+        if (arg == "-V" || arg == "--version") { puts("Length filter 0.1"); return 0; }
+        if (arg.size() < 2 || arg[0] != '-' || arg[1] == '-')
+            clap_error("Found argument '" + arg + "' which wasn't expected, or isn't valid in this context");
+        const char o = arg[1];
+        if (o != 'l' && o != 'd' && o != 'i' && o != 'o' && o != 'm')
+            clap_error("Found argument '-" + std::string(1, o) + "' which wasn't expected, or isn't valid in this context");
+        std::string val;
+        if (arg.size() > 2) { val = arg.substr(2); if (val[0] == '=') val = val.substr(1); }
+        else {
+            if (a + 1 >= argc) clap_error("The argument '-" + std::string(1, o) + " <" + (o == 'i' || o == 'o' ? "PATH" : o == 'l' ? "INT,INT" : "INT") + ">' requires a value but none was supplied");
+            val = argv[++a];
+            if (!val.empty() && val[0] == '-' && val.size() > 1)
+                clap_error("Found argument '" + val + "' which wasn't expected, or isn't valid in this context");
+        }
+        bool *has = o == 'l' ? &has_l : o == 'd' ? &has_d : o == 'i' ? &has_i : o == 'o' ? &has_o : &has_m;
+        std::string *dst = o == 'l' ? &v_l : o == 'd' ? &v_d : o == 'i' ? &v_i : o == 'o' ? &v_o : &v_m;
+        if (*has) clap_error("The argument '-" + std::string(1, o) + "' was provided more than once, but cannot be used multiple times");
+        *has = true; *dst = val;
+    }
+    if (has_d && has_m) clap_error("The argument '-d <INT>' cannot be used with '-m <INT>'");
+    if (!has_i || !has_l || !has_o) {
+        std::string miss;
+        if (!has_i) miss += "\n    -i <PATH>";
+        if (!has_l) miss += "\n    -l <INT,INT>";
+        if (!has_o) miss += "\n    -o <PATH>";
+        clap_error("The following required arguments were not provided:" + miss);
+    }
+
+    // main.rs:57-67
+    std::vector<uint64_t> lengths;
+    {
+        size_t b = 0;
+        for (;;) {
+            size_t c = v_l.find(',', b);
+            std::string piece = v_l.substr(b, c == std::string::npos ? std::string::npos : c - b);
+            uint64_t v;
+            if (!parse_usize(piece, v)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
+            lengths.push_back(v);
+            if (c == std::string::npos) break;
+            b = c + 1;
+        }
+    }
+    if (lengths.size() != 2) { puts("Input length string not valid, please input INT,INT."); }
+    if (lengths.size() < 2) rust_panic("index out of bounds: the len is 1 but the index is 1");
+    const uint64_t min = lengths[0], max = lengths[1];
+
+    std::string data; read_all(v_i, data);       // main.rs:69
+    static Writer out; out.open(v_o);            // main.rs:70
+    g_flush_on_panic = [] { out.close(); };
+    std::vector<Line> lines; split_lines(data, lines);
+    uint64_t count = 0;
+
+    if (!has_m) {
+        // main.rs:74-105
+        if (!has_d) rust_panic("called `Option::unwrap()` on a `None` value");
+        int32_t depth;
+        if (!parse_i32(v_d, depth)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
+        for (size_t i = 0; i + 1 < lines.size(); i += 2) {
+            const Line &t = lines[i], &s = lines[i + 1];
+            if (!valid_utf8(t.p, t.n) || !valid_utf8(s.p, s.n)) { out.close(); rust_panic("called `Result::unwrap()` on an `Err` value: Custom { kind: InvalidData, error: \"stream did not contain valid UTF-8\" }"); }
+            if (t.n == 0 || t.p[0] != '>') continue;
+            if (depth != 0) {
+                const float seq_depth = header_depth(t.p, t.n);
+                if ((float)depth > seq_depth) continue;
+            }
+            const uint64_t length = (uint64_t)s.n - 1;            // wraps for an empty sequence, as the release binary does
+            if (length < min || length > max) continue;
+            out.line(t.p, t.n); out.line(s.p, s.n);
+            count++;
+        }
+    } else {
+        // main.rs:106-131
+        uint64_t max_count;
+        if (!parse_usize(v_m, max_count)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
+        for (const Line &l : lines)
+            if (!valid_utf8(l.p, l.n)) rust_panic("called `Result::unwrap()` on an `Err` value: Custom { kind: InvalidData, error: \"stream did not contain valid UTF-8\" }");
+        std::vector<std::pair<Line, Line>> seqs;
+        for (size_t i = 0; i + 1 < lines.size(); i += 2)
+            if (lines[i + 1].n <= max && lines[i + 1].n >= min) seqs.emplace_back(lines[i], lines[i + 1]);
+        // sort_by_cached_key with a unit key: stable no-op, but the key closure still
+        // runs (and can panic) for every element when there are at least two
+        if (seqs.size() >= 2) for (auto &p : seqs) (void)header_depth(p.first.p, p.first.n);
+        for (size_t j = seqs.size(); j-- > 0 && count < max_count;) {
+            out.line(seqs[j].first.p, seqs[j].first.n); out.line(seqs[j].second.p, seqs[j].second.n);
+            count++;
+        }
+    }
+    g_flush_on_panic = nullptr;
+    out.close();
+    printf("%llu\n", (unsigned long long)count);
+    return 0;
+}
+
+// ---------------------------------------------------------------- bait mode
+static std::string exe_dir()
+{
+    char buf[PATH_MAX]; ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
+    if (n <= 0) return ".";
+    buf[n] = 0;
+    std::string p(buf); size_t s = p.rfind('/');
+    return s == std::string::npos ? "." : p.substr(0, s);
+}
+
+static int bait_main(int argc, char **argv)
+{
+    std::string bait, fq1, fq2, out1, out2, pair = "either", libpath;
+    int k = 31, devices = 1; unsigned thr = 1;
+    for (int a = 2; a < argc; a++) {
+        std::string o = argv[a];
+        auto need = [&](const char *name) -> std::string {
+            if (a + 1 >= argc) { fprintf(stderr, "error: %s requires a value\n", name); exit(1); }
+            return argv[++a];
+        };
+        if (o == "--bait") bait = need("--bait");
+        else if (o == "--fq1") fq1 = need("--fq1");
+        else if (o == "--fq2") fq2 = need("--fq2");
+        else if (o == "--out1") out1 = need("--out1");
+        else if (o == "--out2") out2 = need("--out2");
+        else if (o == "--pair") pair = need("--pair");
+        else if (o == "--lib") libpath = need("--lib");
+        else if (o == "-k" || o == "--kmer") k = atoi(need("-k").c_str());
+        else if (o == "-t" || o == "--threshold") thr = (unsigned)strtoul(need("-t").c_str(), nullptr, 10);
+        else if (o == "--devices") devices = atoi(need("--devices").c_str());
+        else { fprintf(stderr, "error: unknown option '%s' for fastfilter bait\n", o.c_str()); return 1; }
+    }
+    if (bait.empty() || fq1.empty() || out1.empty() || (fq2.empty() != out2.empty()) || (pair != "either" && pair != "both")) {
+        fputs("usage: fastfilter bait --bait BAIT.fa [-k 31] [-t 1] --fq1 R1.fq [--fq2 R2.fq] --out1 O1.fq [--out2 O2.fq]"
+              " [--pair either|both] [--devices N]\n", stderr);
+        return 1;
+    }
+    if (libpath.empty()) libpath = exe_dir() + "/../libmitofilter_hip.so";
+    void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "error: cannot load %s: %s (the bait filter has no CPU fallback)\n", libpath.c_str(), dlerror()); return 2; }
+#define SYM(name) auto p_##name = (decltype(&name))dlsym(h, #name); if (!p_##name) { fprintf(stderr, "error: %s lacks symbol %s\n", libpath.c_str(), #name); return 2; }
+    SYM(mf_abi_version) SYM(mf_last_error) SYM(mf_kmerset_build_from_fasta) SYM(mf_filter_fastq_files) SYM(mf_kmerset_free)
+#undef SYM
+    if (p_mf_abi_version() != MF_ABI_VERSION) { fprintf(stderr, "error: ABI version mismatch\n"); return 2; }
+    mf_kmerset *ks = nullptr;
+    if (p_mf_kmerset_build_from_fasta(bait.c_str(), k, 0, &ks) != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 3; }
+    uint64_t kept = 0, total = 0;
+    int rc = p_mf_filter_fastq_files(ks, fq1.c_str(), fq2.empty() ? nullptr : fq2.c_str(), out1.c_str(),
+                                     out2.empty() ? nullptr : out2.c_str(), thr, pair == "both" ? MF_PAIR_BOTH : MF_PAIR_EITHER,
+                                     devices, &kept, &total);
+    if (rc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); p_mf_kmerset_free(ks); return 3; }
+    p_mf_kmerset_free(ks);
+    printf("%llu\n", (unsigned long long)kept);      // same stdout contract as the contig filter
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc >= 2 && strcmp(argv[1], "bait") == 0) return bait_main(argc, argv);
+    return contig_filter_main(argc, argv);
+}

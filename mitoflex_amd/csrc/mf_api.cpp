@@ -1,0 +1,552 @@
+// C ABI of libmitofilter_hip (include/mitofilter.h).  Host orchestration only:
+// device memory, one stream per device, kernel launches, hipEvent timing.
+// There is no CPU compute path in this file: without a gfx950 device every
+// compute entry point fails with MF_E_NO_DEVICE.
+#include "../../include/mitofilter.h"
+#include "mf_common.h"
+#include "mf_host.h"
+#include "mf_kernels.h"
+#include "mf_synth.h"
+
+#include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace mf;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string t_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    t_err = buf;
+    return code;
+}
+#define HIPCHK(call)                                                                                  \
+    do { hipError_t e_ = (call);                                                                      \
+         if (e_ != hipSuccess) return fail(MF_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// --------------------------------------------------------------- device ctx
+struct DevCtx { int device = -1; hipStream_t stream = nullptr; int n_cu = 0; };
+static std::mutex g_ctx_mu;
+static std::map<int, DevCtx> g_ctx;
+
+static int get_ctx(int device, DevCtx **out)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) { *out = &it->second; hipError_t e = hipSetDevice(device); if (e != hipSuccess) return fail(MF_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return MF_OK; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible (%s); libmitofilter_hip has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(MF_E_ARG, "device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MF_E_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    HIPCHK(hipSetDevice(device));
+    DevCtx c; c.device = device; c.n_cu = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    g_ctx[device] = c;
+    *out = &g_ctx[device];
+    return MF_OK;
+}
+
+// ------------------------------------------------------------------ kmerset
+struct DevTables {
+    uint64_t *keys = nullptr;
+    uint32_t *bloom = nullptr, *stab = nullptr;
+    KmerSetView view{};
+    uint64_t n_keys = 0, n_smers = 0;
+};
+struct mf_kmerset {
+    int k = 0, kw = 1;
+    BaitHost bait;
+    uint64_t n_windows = 0, slots = 0;
+    ScreenGeom geom{0, 0};
+    uint32_t bloom_log2w = 0, stab_slots = 0;
+    std::mutex mu;
+    std::map<int, DevTables> dev;
+};
+
+static uint32_t env_u32(const char *name, uint32_t dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
+static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
+{
+    std::lock_guard<std::mutex> lk(ks->mu);
+    auto it = ks->dev.find(device);
+    if (it != ks->dev.end()) { *out = &it->second; return MF_OK; }
+    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const BaitHost &B = ks->bait;
+    DevTables T;
+    uint32_t *d_words = nullptr; uint8_t *d_run = nullptr; uint32_t *d_pos = nullptr, *d_flag = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    HIPCHK(hipMalloc(&d_words, B.words.size() * 4));
+    HIPCHK(hipMalloc(&d_run, B.runlen.size()));
+    HIPCHK(hipMemcpyAsync(d_words, B.words.data(), B.words.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_run, B.runlen.data(), B.runlen.size(), hipMemcpyHostToDevice, st));
+    const size_t key_bytes = ks->slots * ks->kw * sizeof(uint64_t);
+    HIPCHK(hipMalloc(&T.keys, key_bytes));
+    HIPCHK(hipMemsetAsync(T.keys, 0xFF, key_bytes, st));
+    if (ks->kw == 2) {
+        if (B.total > 0xFFFFFFF0ull) return fail(MF_E_ARG, "bait longer than 2^32 bases is not supported for k > 32");
+        HIPCHK(hipMalloc(&d_pos, ks->slots * 4));
+        HIPCHK(hipMemsetAsync(d_pos, 0xFF, ks->slots * 4, st));
+    }
+    HIPCHK(hipMalloc(&d_flag, 4)); HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
+    HIPCHK(hipMalloc(&d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
+    BaitView bv{d_words, B.total, d_run};
+    HIPCHK(launch_build_table(bv, ks->k, ks->kw, T.keys, ks->slots, d_pos, st));
+    if (ks->geom.s) {
+        HIPCHK(hipMalloc(&T.bloom, sizeof(uint32_t) << ks->bloom_log2w));
+        HIPCHK(hipMemsetAsync(T.bloom, 0, sizeof(uint32_t) << ks->bloom_log2w, st));
+        HIPCHK(hipMalloc(&T.stab, (size_t)ks->stab_slots * 4));
+        HIPCHK(hipMemsetAsync(T.stab, 0xFF, (size_t)ks->stab_slots * 4, st));
+        HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, T.stab, ks->stab_slots, d_flag, st));
+    }
+    HIPCHK(launch_count_keys(T.keys, ks->slots, ks->kw, T.stab, T.stab ? ks->stab_slots : 0, d_cnt, st));
+    unsigned long long cnt[2] = {0, 0}; uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_words); hipFree(d_run); hipFree(d_pos); hipFree(d_flag); hipFree(d_cnt);
+    T.n_keys = cnt[0]; T.n_smers = cnt[1] + (flag ? 1 : 0);
+    KmerSetView &V = T.view;
+    V.k = ks->k; V.kw = ks->kw; V.slot_mask = ks->slots - 1; V.keys = T.keys;
+    V.s = ks->geom.s; V.stride = ks->geom.stride;
+    V.smask = ks->geom.s >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ks->geom.s)) - 1);
+    V.bloom_log2w = ks->bloom_log2w; V.bloom = T.bloom;
+    V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
+    ks->dev[device] = T;
+    *out = &ks->dev[device];
+    return MF_OK;
+}
+
+static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmerset **out)
+{
+    if (!out) return fail(MF_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (k < 11 || k > 63) return fail(MF_E_ARG, "k=%d out of range [11,63]", k);
+    mf_kmerset *ks = new (std::nothrow) mf_kmerset();
+    if (!ks) return fail(MF_E_NOMEM, "out of memory");
+    ks->k = k; ks->kw = k > 32 ? 2 : 1;
+    parse_bait_fasta(text, len, ks->bait);
+    ks->n_windows = ks->bait.n_windows(k);
+    ks->slots = table_slots_for(ks->n_windows);
+    ks->geom = screen_geom_for(k);
+    if (getenv("MF_NO_SCREEN")) ks->geom = ScreenGeom{0, 0};
+    if (ks->geom.s) {
+        const uint64_t bound = 2 * ks->bait.n_swindows(ks->geom.s);
+        uint32_t lg = 8;                                 // 1 KiB .. 128 KiB of LDS
+        while (lg < 15 && (1ull << lg) < bound) lg++;
+        ks->bloom_log2w = env_u32("MF_BLOOM_LOG2W", lg);
+        if (ks->bloom_log2w < 8) ks->bloom_log2w = 8;
+        if (ks->bloom_log2w > 15) ks->bloom_log2w = 15;
+        uint64_t ss = 1024; while (ss < 2 * bound) ss <<= 1;
+        if (ss > (1ull << 31)) { delete ks; return fail(MF_E_ARG, "bait too large for the s-mer screen table"); }
+        ks->stab_slots = (uint32_t)ss;
+    }
+    DevTables *T; int rc = build_on_device(ks, device, &T);
+    if (rc) { delete ks; return rc; }
+    *out = ks;
+    return MF_OK;
+}
+
+extern "C" {
+
+int mf_abi_version(void) { return MF_ABI_VERSION; }
+const char *mf_last_error(void) { return t_err.c_str(); }
+
+int mf_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return fail(MF_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int mf_device_name(int device, char *buf, size_t buflen)
+{
+    if (!buf || !buflen) return fail(MF_E_ARG, "bad buffer");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return MF_OK;
+}
+
+int mf_device_synchronize(int device)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return MF_OK;
+}
+
+int mf_kmerset_build_from_text(const char *text, size_t len, int k, int device, mf_kmerset **out)
+{
+    if (!text && len) return fail(MF_E_ARG, "fasta_text is NULL");
+    return kmerset_new(text ? text : "", len, k, device, out);
+}
+
+int mf_kmerset_build_from_fasta(const char *path, int k, int device, mf_kmerset **out)
+{
+    if (!path) return fail(MF_E_ARG, "fasta_path is NULL");
+    std::vector<char> buf; std::string err;
+    if (!slurp_file(path, buf, err)) return fail(MF_E_IO, "%s", err.c_str());
+    return kmerset_new(buf.data(), buf.size(), k, device, out);
+}
+
+int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info)
+{
+    if (!ks || !info) return fail(MF_E_ARG, "NULL argument");
+    memset(info, 0, sizeof *info);
+    info->k = ks->k; info->key_words = ks->kw; info->slots = ks->slots; info->n_windows = ks->n_windows;
+    info->screen_s = ks->geom.s; info->screen_stride = ks->geom.stride;
+    info->bloom_words = ks->geom.s ? (1u << ks->bloom_log2w) : 0; info->smer_slots = ks->stab_slots;
+    if (!ks->dev.empty()) { info->n_keys = ks->dev.begin()->second.n_keys; info->n_smers = ks->dev.begin()->second.n_smers; }
+    return MF_OK;
+}
+
+int mf_kmerset_export(const mf_kmerset *ks_, int device, uint64_t *keys_out, size_t n_u64)
+{
+    mf_kmerset *ks = const_cast<mf_kmerset *>(ks_);
+    if (!ks || !keys_out) return fail(MF_E_ARG, "NULL argument");
+    if (n_u64 < ks->slots * ks->kw) return fail(MF_E_ARG, "keys_out too small: need %llu u64", (unsigned long long)(ks->slots * ks->kw));
+    DevTables *T; int rc = build_on_device(ks, device, &T); if (rc) return rc;
+    HIPCHK(hipMemcpy(keys_out, T->keys, ks->slots * ks->kw * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MF_OK;
+}
+
+int mf_kmerset_free(mf_kmerset *ks)
+{
+    if (!ks) return MF_OK;
+    for (auto &kv : ks->dev) {
+        if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); }
+    }
+    delete ks;
+    return MF_OK;
+}
+
+} // extern "C"
+
+// -------------------------------------------------------------------- reads
+struct mf_reads {
+    int device = 0;
+    ReadsView v{};
+    uint32_t *d_words = nullptr; uint64_t *d_offsets = nullptr, *d_npos = nullptr;
+    uint32_t *d_has_n = nullptr, *d_cand = nullptr, *d_bits = nullptr, *d_hits = nullptr;
+    unsigned long long *d_counters = nullptr;
+    size_t bitmap_bytes = 0;
+};
+
+static void reads_release(mf_reads *r)
+{
+    if (!r) return;
+    if (hipSetDevice(r->device) == hipSuccess) {
+        hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
+        hipFree(r->d_cand); hipFree(r->d_bits); hipFree(r->d_hits); hipFree(r->d_counters);
+    }
+    delete r;
+}
+
+// words_padded: host buffer already padded to padded_words_for(n_words) (or nullptr with words_raw given)
+static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets, uint64_t n_reads,
+                        uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos, int device,
+                        mf_reads **out)
+{
+    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    mf_reads *r = new (std::nothrow) mf_reads();
+    if (!r) return fail(MF_E_NOMEM, "out of memory");
+    r->device = device;
+    const uint64_t padded = padded_words_for(n_words);
+#define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { reads_release(r); return fail(MF_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    RCHK(hipMalloc(&r->d_words, padded * 4));
+    if (already_padded) {
+        RCHK(hipMemcpyAsync(r->d_words, words, padded * 4, hipMemcpyHostToDevice, st));
+    } else {
+        RCHK(hipMemsetAsync(r->d_words + n_words, 0, (padded - n_words) * 4, st));
+        if (n_words) RCHK(hipMemcpyAsync(r->d_words, words, n_words * 4, hipMemcpyHostToDevice, st));
+    }
+    if (!uniform_len) {
+        RCHK(hipMalloc(&r->d_offsets, (n_reads + 1) * 8));
+        RCHK(hipMemcpyAsync(r->d_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    }
+    RCHK(hipMalloc(&r->d_npos, (n_npos ? n_npos : 1) * 8));
+    if (n_npos) RCHK(hipMemcpyAsync(r->d_npos, npos, n_npos * 8, hipMemcpyHostToDevice, st));
+    r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;
+    RCHK(hipMalloc(&r->d_has_n, r->bitmap_bytes));
+    RCHK(hipMalloc(&r->d_cand, r->bitmap_bytes));
+    RCHK(hipMalloc(&r->d_bits, r->bitmap_bytes));
+    RCHK(hipMalloc(&r->d_counters, 16));
+    RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
+    RCHK(hipMemsetAsync(r->d_bits, 0, r->bitmap_bytes, st));
+    ReadsView &V = r->v;
+    V.words = r->d_words; V.n_words = n_words; V.n_vec = (padded - 16) / 4;
+    V.offsets = r->d_offsets; V.uniform_len = uniform_len; V.n_reads = n_reads; V.total_bases = total_bases;
+    V.npos = r->d_npos; V.n_npos = n_npos; V.has_n = r->d_has_n;
+    RCHK(launch_mark_has_n(V, r->d_has_n, st));
+    RCHK(hipStreamSynchronize(st));
+#undef RCHK
+    *out = r;
+    return MF_OK;
+}
+
+extern "C" {
+
+int mf_reads_from_packed(const uint32_t *words, const uint64_t *offsets, uint64_t n_reads,
+                         const uint64_t *npos, uint64_t n_npos, int device, mf_reads **out)
+{
+    if (!out) return fail(MF_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (!offsets) return fail(MF_E_ARG, "offsets is NULL");
+    if (n_npos && !npos) return fail(MF_E_ARG, "npos is NULL");
+    if (offsets[0] != 0) return fail(MF_E_ARG, "offsets[0] must be 0");
+    for (uint64_t i = 0; i < n_reads; i++) if (offsets[i + 1] < offsets[i]) return fail(MF_E_ARG, "offsets must be non-decreasing");
+    for (uint64_t i = 1; i < n_npos; i++) if (npos[i] <= npos[i - 1]) return fail(MF_E_ARG, "npos must be strictly ascending");
+    const uint64_t total = offsets[n_reads];
+    if (n_npos && npos[n_npos - 1] >= total) return fail(MF_E_ARG, "npos entry beyond the last base");
+    const uint64_t n_words = (total + 15) / 16;
+    if (n_words && !words) return fail(MF_E_ARG, "words is NULL");
+    return reads_upload(words, n_words, false, offsets, n_reads, total, detect_uniform_len(offsets, n_reads), npos, n_npos, device, out);
+}
+
+int mf_reads_from_fastq(const char *path, int device, mf_reads **out)
+{
+    if (!out || !path) return fail(MF_E_ARG, "NULL argument");
+    *out = nullptr;
+    std::vector<char> buf; std::string err;
+    if (!slurp_file(path, buf, err)) return fail(MF_E_IO, "%s", err.c_str());
+    std::vector<FqRec> recs; parse_fastq(buf.data(), buf.size(), recs);
+    PackedHost P; pack_records(recs.data(), recs.size(), (int)std::thread::hardware_concurrency(), P);
+    return reads_upload(P.words.data(), P.n_words, true, P.offsets.data(), recs.size(), P.offsets.back(), P.uniform_len,
+                        P.npos.data(), P.npos.size(), device, out);
+}
+
+int mf_reads_synth(uint64_t n_reads, uint32_t read_len, uint64_t seed, const char *bait_text, size_t bait_len,
+                   uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm, int device, mf_reads **out,
+                   uint32_t **host_words_out, uint64_t *host_n_words_out, uint64_t **host_npos_out, uint64_t *host_n_npos_out)
+{
+    if (!out) return fail(MF_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (read_len == 0) return fail(MF_E_ARG, "read_len must be > 0");
+    BaitHost B; parse_bait_fasta(bait_text ? bait_text : "", bait_text ? bait_len : 0, B);
+    SynthOut S;
+    std::string err;
+    if (!synth_reads(n_reads, read_len, seed, B, mito_ppm, sub_ppm, n_read_ppm, n_base_ppm,
+                     (int)std::thread::hardware_concurrency(), S, err)) return fail(MF_E_ARG, "%s", err.c_str());
+    int rc = reads_upload(S.words.data(), S.n_words, true, nullptr, n_reads, n_reads * (uint64_t)read_len, read_len,
+                          S.npos.data(), S.npos.size(), device, out);
+    if (rc) return rc;
+    if (host_words_out) {
+        *host_words_out = (uint32_t *)malloc(S.words.size() * 4);
+        if (!*host_words_out) return fail(MF_E_NOMEM, "out of memory");
+        memcpy(*host_words_out, S.words.data(), S.words.size() * 4);
+        if (host_n_words_out) *host_n_words_out = S.n_words;
+    }
+    if (host_npos_out) {
+        *host_npos_out = (uint64_t *)malloc((S.npos.size() + 1) * 8);
+        if (!*host_npos_out) return fail(MF_E_NOMEM, "out of memory");
+        memcpy(*host_npos_out, S.npos.data(), S.npos.size() * 8);
+        if (host_n_npos_out) *host_n_npos_out = S.npos.size();
+    }
+    return MF_OK;
+}
+
+void mf_free_host(void *p) { free(p); }
+
+int mf_reads_info(const mf_reads *r, mf_reads_info_t *info)
+{
+    if (!r || !info) return fail(MF_E_ARG, "NULL argument");
+    info->n_reads = r->v.n_reads; info->total_bases = r->v.total_bases; info->n_invalid = r->v.n_npos;
+    info->uniform_len = r->v.uniform_len; info->device = r->device;
+    return MF_OK;
+}
+
+int mf_reads_free(mf_reads *r) { reads_release(r); return MF_OK; }
+
+} // extern "C"
+
+// ------------------------------------------------------------------- filter
+static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_bases + 7) / 8 + (V.n_reads + 7) / 8; }
+
+// enqueue one pass on `st`; ev[0..2] recorded before screen / between / after exact when non-null
+static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, int n_cu,
+                        hipStream_t st, hipEvent_t *ev)
+{
+    const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
+    HIPCHK(hipMemsetAsync(r->d_counters, 0, 16, st));
+    if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    if (screened) {
+        HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
+        HIPCHK(launch_screen(r->v, S, r->d_cand, n_cu, st));
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits, r->d_hits, r->d_counters, st));
+    if (ev) HIPCHK(hipEventRecord(ev[2], st));
+    return MF_OK;
+}
+
+static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, int mode, uint32_t *out_bits,
+                         uint32_t *hits_out, int steps, mf_filter_stats_t *stats)
+{
+    mf_kmerset *ks = const_cast<mf_kmerset *>(ks_);
+    mf_reads *r = const_cast<mf_reads *>(reads_);
+    if (!ks || !r) return fail(MF_E_ARG, "NULL handle");
+    if (thr < 1) return fail(MF_E_ARG, "threshold must be >= 1");
+    if (mode != MF_MODE_SCREENED && mode != MF_MODE_EXHAUSTIVE) return fail(MF_E_ARG, "bad mode %d", mode);
+    if (steps < 1) return fail(MF_E_ARG, "steps must be >= 1");
+    DevCtx *ctx; int rc = get_ctx(r->device, &ctx); if (rc) return rc;
+    DevTables *T; rc = build_on_device(ks, r->device, &T); if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const bool count_all = hits_out != nullptr;
+    if (count_all) {
+        if (!r->d_hits) HIPCHK(hipMalloc(&r->d_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4));
+        HIPCHK(hipMemsetAsync(r->d_hits, 0, (r->v.n_reads ? r->v.n_reads : 1) * 4, st));
+    }
+    std::vector<hipEvent_t> ev((size_t)steps * 3);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    for (int i = 0; i < steps; i++) {
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, &ev[(size_t)i * 3]);
+        if (rc) return rc;
+    }
+    unsigned long long cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt, r->d_counters, 16, hipMemcpyDeviceToHost, st));
+    if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits, ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
+    if (hits_out && r->v.n_reads) HIPCHK(hipMemcpyAsync(hits_out, r->d_hits, r->v.n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        float tot = 0, scr = 0, exa = 0, t;
+        HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[(size_t)steps * 3 - 1]));
+        for (int i = 0; i < steps; i++) {
+            HIPCHK(hipEventElapsedTime(&t, ev[(size_t)i * 3], ev[(size_t)i * 3 + 1])); scr += t;
+            HIPCHK(hipEventElapsedTime(&t, ev[(size_t)i * 3 + 1], ev[(size_t)i * 3 + 2])); exa += t;
+        }
+        stats->n_reads = r->v.n_reads; stats->n_pass = cnt[0];
+        stats->n_candidates = (mode == MF_MODE_SCREENED && T->view.s > 0) ? cnt[1] : r->v.n_reads;
+        stats->ms_total = tot / steps; stats->ms_screen = scr / steps; stats->ms_exact = exa / steps;
+        stats->algorithmic_bytes = algorithmic_bytes(r->v);
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    return MF_OK;
+}
+
+extern "C" {
+
+int mf_filter(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
+              uint32_t *out_bits, uint32_t *hits_out, mf_filter_stats_t *stats)
+{
+    if (!out_bits && !hits_out && !stats) return fail(MF_E_ARG, "nothing to return: out_bits, hits_out and stats are all NULL");
+    return filter_common(ks, reads, threshold, mode, out_bits, hits_out, 1, stats);
+}
+
+int mf_filter_resident(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode, int steps,
+                       mf_filter_stats_t *stats)
+{
+    return filter_common(ks, reads, threshold, mode, nullptr, nullptr, steps, stats);
+}
+
+int mf_filter_packed(const mf_kmerset *ks, int device, const uint32_t *words, const uint64_t *offsets, uint64_t n_reads,
+                     const uint64_t *npos, uint64_t n_npos, uint32_t threshold, uint32_t *out_bits)
+{
+    if (!out_bits) return fail(MF_E_ARG, "out_bits is NULL");
+    mf_reads *r = nullptr;
+    int rc = mf_reads_from_packed(words, offsets, n_reads, npos, n_npos, device, &r);
+    if (rc) return rc;
+    rc = filter_common(ks, r, threshold, MF_MODE_SCREENED, out_bits, nullptr, 1, nullptr);
+    reads_release(r);
+    return rc;
+}
+
+// ------------------------------------------------------------- file level
+int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2,
+                          uint32_t threshold, int pair_mode, int n_devices, uint64_t *kept, uint64_t *total)
+{
+    if (!ks || !fq1 || !out1) return fail(MF_E_ARG, "NULL argument");
+    if ((fq2 == nullptr) != (out2 == nullptr)) return fail(MF_E_ARG, "fq2 and out2 must be given together");
+    if (pair_mode != MF_PAIR_EITHER && pair_mode != MF_PAIR_BOTH) return fail(MF_E_ARG, "bad pair_mode %d", pair_mode);
+    if (threshold < 1) return fail(MF_E_ARG, "threshold must be >= 1");
+    const int have = mf_device_count();
+    if (have <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible; libmitofilter_hip has no CPU fallback");
+    if (n_devices < 1) n_devices = 1;
+    if (n_devices > have) n_devices = have;
+
+    const int hw = (int)std::thread::hardware_concurrency();
+    std::vector<char> b1, b2; std::string e1, e2; bool ok1 = true, ok2 = true;
+    {   // read both mates concurrently (inflate is the slow part for .gz)
+        std::thread t2; if (fq2) t2 = std::thread([&] { ok2 = slurp_file(fq2, b2, e2); });
+        ok1 = slurp_file(fq1, b1, e1);
+        if (fq2) t2.join();
+    }
+    if (!ok1) return fail(MF_E_IO, "%s", e1.c_str());
+    if (!ok2) return fail(MF_E_IO, "%s", e2.c_str());
+    std::vector<FqRec> r1, r2;
+    parse_fastq(b1.data(), b1.size(), r1);
+    if (fq2) parse_fastq(b2.data(), b2.size(), r2);
+    // PE records are zipped; the shorter file bounds the pair count (filter_bin main.rs:214)
+    const uint64_t n = fq2 ? (r1.size() < r2.size() ? r1.size() : r2.size()) : r1.size();
+    std::vector<uint8_t> keep(n ? n : 1, 0);
+
+    // contiguous chunks of whole pairs per device, one host thread each, no collective
+    std::vector<int> rcs(n_devices, MF_OK); std::vector<std::string> errs(n_devices);
+    auto worker = [&](int d) {
+        const uint64_t lo = n * d / n_devices, hi = n * (d + 1) / n_devices;
+        if (lo == hi) return;
+        const int nm = fq2 ? 2 : 1;
+        std::vector<uint32_t> bits[2];
+        for (int m = 0; m < nm; m++) {
+            const std::vector<FqRec> &rr = m ? r2 : r1;
+            PackedHost P; pack_records(rr.data() + lo, hi - lo, hw / n_devices > 0 ? hw / n_devices : 1, P);
+            mf_reads *R = nullptr;
+            int rc = reads_upload(P.words.data(), P.n_words, true, P.offsets.data(), hi - lo, P.offsets.back(), P.uniform_len,
+                                  P.npos.data(), P.npos.size(), d, &R);
+            if (rc) { rcs[d] = rc; errs[d] = t_err; return; }
+            bits[m].assign((hi - lo + 31) / 32, 0);
+            rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, bits[m].data(), nullptr, 1, nullptr);
+            reads_release(R);
+            if (rc) { rcs[d] = rc; errs[d] = t_err; return; }
+        }
+        for (uint64_t i = 0; i < hi - lo; i++) {
+            const int a = (bits[0][i >> 5] >> (i & 31)) & 1;
+            const int b = fq2 ? (bits[1][i >> 5] >> (i & 31)) & 1 : 0;
+            keep[lo + i] = (uint8_t)(fq2 ? (pair_mode == MF_PAIR_BOTH ? (a & b) : (a | b)) : a);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int d = 1; d < n_devices; d++) th.emplace_back(worker, d);
+        worker(0);
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < n_devices; d++) if (rcs[d]) return fail(rcs[d], "device %d: %s", d, errs[d].c_str());
+
+    uint64_t kc = 0; for (uint64_t i = 0; i < n; i++) kc += keep[i];
+    std::string we1, we2; bool wok1 = true, wok2 = true;
+    {
+        std::thread t2; if (fq2) t2 = std::thread([&] { wok2 = write_survivors(out2, r2.data(), n, keep.data(), we2); });
+        wok1 = write_survivors(out1, r1.data(), n, keep.data(), we1);
+        if (fq2) t2.join();
+    }
+    if (!wok1) return fail(MF_E_IO, "%s", we1.c_str());
+    if (!wok2) return fail(MF_E_IO, "%s", we2.c_str());
+    if (kept) *kept = kc;
+    if (total) *total = n;
+    return MF_OK;
+}
+
+} // extern "C"

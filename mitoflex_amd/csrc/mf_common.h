@@ -1,0 +1,129 @@
+// Shared definitions of libmitofilter_hip: hashing, table layout rules and the
+// plain-data views handed to kernels.  Host and device code include this.
+//
+// Semantics (the reference has no counterpart, see
+// DESIGN.md "Spec B"): 2-bit little-endian packing, canonical k-mer =
+// min(fwd, revcomp) with the first base least significant, exact membership in
+// an open-address table whose layout is history independent.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MF_HD __host__ __device__ __forceinline__
+#else
+#define MF_HD inline
+#endif
+
+namespace mf {
+
+constexpr uint64_t EMPTY64 = ~0ULL;
+constexpr uint32_t EMPTY32 = ~0u;
+
+// ---- hashing (identical on host, device and in the oracle) -----------------
+MF_HD uint64_t mix64(uint64_t x)
+{   // MurmurHash3 fmix64
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+MF_HD uint64_t hash_key1(uint64_t lo) { return mix64(lo); }
+MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi) { return mix64(lo ^ mix64(hi + 0x9E3779B97F4A7C15ULL)); }
+
+// screen hashes (implementation detail of the s-mer screen; not part of the
+// result semantics -- the screen is conservative for any choice)
+MF_HD uint32_t bloom_hash(uint32_t smer) { return smer * 0x9E3779B1u; }
+MF_HD uint32_t smer_hash(uint32_t smer) { uint32_t h = smer * 0xC2B2AE35u; return h ^ (h >> 15); }
+
+// ---- table sizing rules (must match oracle/kmer_bait_oracle.c) -------------
+MF_HD uint64_t table_slots_for(uint64_t n_windows)
+{
+    uint64_t s = 1024;
+    while (s < 2 * n_windows) s <<= 1;
+    return s;
+}
+
+// ---- screen geometry ---------------------------------------------------------
+// Any window of k bases laid anywhere in the dense stream fully contains one
+// s-mer that starts at a stream position divisible by `stride`, provided
+// k >= s + stride - 1.  stride is 16 bases (one u32 word) or 8.
+struct ScreenGeom { int s; int stride; };
+MF_HD ScreenGeom screen_geom_for(int k)
+{
+    if (k >= 31) return {16, 16};
+    if (k >= 23) return {16, 8};
+    if (k >= 19) return {k - 7, 8};
+    return {0, 0};   // too short for a selective screen: exhaustive only
+}
+
+// ---- reverse complement of a little-endian 2-bit code ------------------------
+MF_HD uint64_t swap_pairs_rev64(uint64_t x)
+{   // reverse the order of the 32 two-bit groups
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t y = __brevll(x);
+#else
+    uint64_t y = x;
+    y = ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+    y = ((y >> 2) & 0x3333333333333333ULL) | ((y & 0x3333333333333333ULL) << 2);
+    y = ((y >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((y & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    y = __builtin_bswap64(y);
+#endif
+    return ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+}
+MF_HD uint32_t swap_pairs_rev32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t y = __brev(x);
+#else
+    uint32_t y = x;
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    y = ((y >> 2) & 0x33333333u) | ((y & 0x33333333u) << 2);
+    y = ((y >> 4) & 0x0F0F0F0Fu) | ((y & 0x0F0F0F0Fu) << 4);
+    y = __builtin_bswap32(y);
+#endif
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+// k <= 32
+MF_HD uint64_t revcomp1(uint64_t fwd, int k) { return (~swap_pairs_rev64(fwd)) >> (64 - 2 * k); }
+// s <= 16
+MF_HD uint32_t revcomp_s(uint32_t fwd, int s) { return (~swap_pairs_rev32(fwd)) >> (32 - 2 * s); }
+// 33 <= k <= 63: value = hi:lo (128 bit)
+MF_HD void revcomp2(uint64_t lo, uint64_t hi, int k, uint64_t &rlo, uint64_t &rhi)
+{
+    uint64_t ylo = ~swap_pairs_rev64(hi), yhi = ~swap_pairs_rev64(lo);   // 128-bit reversed+complemented
+    int sh = 128 - 2 * k;                                                 // 2..62
+    rlo = (ylo >> sh) | (yhi << (64 - sh));
+    rhi = yhi >> sh;
+}
+
+// ---- plain-data views passed to kernels ------------------------------------
+struct ReadsView {
+    const uint32_t *words;      // padded with zero words past n_words
+    uint64_t        n_words;    // words holding bases
+    uint64_t        n_vec;      // uint4 count the screen kernel walks (padded, zero tail)
+    const uint64_t *offsets;    // n_reads+1 base offsets, nullptr when uniform_len > 0
+    uint32_t        uniform_len;
+    uint64_t        n_reads;
+    uint64_t        total_bases;
+    const uint64_t *npos;       // sorted invalid base positions
+    uint64_t        n_npos;
+    const uint32_t *has_n;      // bit r set: read r holds an invalid base
+};
+
+struct KmerSetView {
+    int32_t   k, kw;
+    uint64_t  slot_mask;        // slots-1
+    const uint64_t *keys;       // slots*kw
+    // screen
+    int32_t   s, stride;        // s == 0: disabled
+    uint32_t  smask;            // (1 << 2s) - 1
+    uint32_t  bloom_log2w;
+    const uint32_t *bloom;      // 1 << bloom_log2w words
+    uint32_t  stab_mask;
+    const uint32_t *stab;       // s-mer exact table (ordered linear probing, EMPTY32)
+    uint32_t  stab_has_ones;    // the all-ones s-mer (poly-T, only possible for s == 16) is present
+};
+
+} // namespace mf

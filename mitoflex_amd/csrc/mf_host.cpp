@@ -1,0 +1,225 @@
+// Host-side parsing and packing for libmitofilter_hip.  See mf_host.h.
+#include "mf_host.h"
+#include "mf_kernels_cfg.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <thread>
+#include <zlib.h>
+
+namespace mf {
+
+// B1 alphabet: A/a=0 C/c=1 G/g=2 T/t=3, anything else 4 (invalid)
+static const struct BaseLut {
+    uint8_t t[256];
+    BaseLut() {
+        memset(t, 4, sizeof t);
+        t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
+    }
+} g_lut;
+
+bool has_gz_ext(const char *path)
+{   // Path::extension() == "gz"  (filter/filter_bin/src/helper.rs:22)
+    const char *slash = strrchr(path, '/');
+    const char *name = slash ? slash + 1 : path;
+    const char *dot = strrchr(name, '.');
+    return dot && dot != name && strcmp(dot, ".gz") == 0;
+}
+
+bool slurp_file(const char *path, std::vector<char> &out, std::string &err)
+{
+    out.clear();
+    if (has_gz_ext(path)) {
+        gzFile g = gzopen(path, "rb");
+        if (!g) { err = std::string("Cannot open file ") + path; return false; }
+        gzbuffer(g, 1 << 20);
+        size_t len = 0;
+        out.resize(1 << 22);
+        for (;;) {
+            if (out.size() - len < (1 << 20)) out.resize(out.size() * 2);
+            size_t want = out.size() - len; if (want > (1u << 30)) want = 1u << 30;
+            int n = gzread(g, out.data() + len, (unsigned)want);
+            if (n < 0) { gzclose(g); err = std::string("gzip read error in ") + path; return false; }
+            if (n == 0) break;
+            len += (size_t)n;
+        }
+        gzclose(g);
+        out.resize(len);
+        return true;
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("Cannot open file ") + path; return false; }
+    if (fseeko(f, 0, SEEK_END) == 0) {
+        off_t sz = ftello(f);
+        if (sz > 0) out.reserve((size_t)sz);
+        fseeko(f, 0, SEEK_SET);
+    }
+    size_t len = 0;
+    out.resize(out.capacity() > (1 << 16) ? out.capacity() : (1 << 16));
+    for (;;) {
+        if (out.size() == len) out.resize(out.size() * 2);
+        size_t n = fread(out.data() + len, 1, out.size() - len, f);
+        if (n == 0) break;
+        len += n;
+    }
+    fclose(f);
+    out.resize(len);
+    return true;
+}
+
+// ------------------------------------------------------------------- bait
+uint64_t BaitHost::n_windows(int k) const
+{
+    uint64_t n = 0;
+    for (uint64_t l : rec_len) if (l >= (uint64_t)k) n += l - k + 1;
+    return n;
+}
+uint64_t BaitHost::n_swindows(int s) const { return n_windows(s); }
+
+void parse_bait_fasta(const char *text, size_t len, BaitHost &out)
+{
+    out = BaitHost();
+    std::vector<uint8_t> codes;            // 0..3 valid, 4 invalid, one per base
+    std::vector<uint64_t> rec_start;       // base index where each record starts
+    codes.reserve(len);
+    bool at_line_start = true, in_header = false, open = false;
+    for (size_t i = 0; i < len; i++) {
+        const unsigned char c = (unsigned char)text[i];
+        if (in_header) { if (c == '\n') { in_header = false; at_line_start = true; } continue; }
+        if (at_line_start && c == '>') { rec_start.push_back(codes.size()); open = true; in_header = true; at_line_start = false; continue; }
+        if (c == '\n') { at_line_start = true; continue; }
+        at_line_start = false;
+        if (c == '\r' || c == ' ' || c == '\t' || c == '\v' || c == '\f') continue;
+        if (!open) { rec_start.push_back(codes.size()); open = true; }   // sequence before any header
+        codes.push_back(g_lut.t[c]);
+    }
+    out.total = codes.size();
+    rec_start.push_back(out.total);
+    for (size_t r = 0; r + 1 < rec_start.size(); r++) out.rec_len.push_back(rec_start[r + 1] - rec_start[r]);
+    out.words.assign((out.total + 15) / 16 + 8, 0u);
+    out.runlen.assign(out.total + 1, 0);
+    for (uint64_t g = 0; g < out.total; g++)
+        if (codes[g] < 4) out.words[g >> 4] |= (uint32_t)codes[g] << (2 * (g & 15));
+    // run lengths: walk each record backwards
+    for (size_t r = 0; r + 1 < rec_start.size(); r++) {
+        uint32_t run = 0;
+        for (uint64_t g = rec_start[r + 1]; g-- > rec_start[r];) {
+            run = codes[g] < 4 ? (run < 255 ? run + 1 : 255) : 0;
+            out.runlen[g] = (uint8_t)run;
+        }
+    }
+}
+
+// ------------------------------------------------------------------- FASTQ
+void parse_fastq(const char *buf, size_t len, std::vector<FqRec> &recs)
+{
+    recs.clear();
+    const char *p = buf, *end = buf + len;
+    const char *ls[4]; uint32_t ll[4]; int li = 0;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;            // final line may lack its LF
+        size_t L = (size_t)(le - p);
+        if (L && p[L - 1] == '\r') L--;            // lines() strips "\r\n"
+        ls[li] = p; ll[li] = (uint32_t)L;
+        if (++li == 4) { recs.push_back(FqRec{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]}); li = 0; }
+        if (!nl) break;
+        p = nl + 1;
+    }
+}
+
+uint64_t padded_words_for(uint64_t n_words)
+{
+    const uint64_t chunk_vec = (uint64_t)SCREEN_BLOCK * SCREEN_U;
+    uint64_t n_vec = (n_words + 3) / 4;
+    n_vec = (n_vec + chunk_vec - 1) / chunk_vec * chunk_vec;
+    return n_vec * 4 + 16;
+}
+
+uint32_t detect_uniform_len(const uint64_t *off, uint64_t n)
+{
+    if (n == 0) return 0;
+    const uint64_t L = off[1] - off[0];
+    if (L == 0 || L > 0xFFFFFFFFull) return 0;
+    for (uint64_t i = 1; i < n; i++) if (off[i + 1] - off[i] != L) return 0;
+    return (uint32_t)L;
+}
+
+static void pack_range(const FqRec *recs, uint64_t lo, uint64_t hi, const uint64_t *offsets, uint32_t *words,
+                       std::vector<uint64_t> &npos)
+{
+    if (lo >= hi || offsets[lo] == offsets[hi]) return;
+    uint64_t g = offsets[lo];
+    uint64_t wi = g >> 4;
+    const uint64_t first_w = wi, last_w = (offsets[hi] - 1) >> 4;   // may be shared with neighbours
+    uint32_t acc = 0; int pos = 2 * (int)(g & 15);
+    auto flush = [&](uint64_t w, uint32_t v) {
+        if (w == first_w || w == last_w) __atomic_fetch_or(&words[w], v, __ATOMIC_RELAXED);
+        else words[w] = v;
+    };
+    for (uint64_t r = lo; r < hi; r++) {
+        const unsigned char *s = (const unsigned char *)recs[r].s;
+        const uint32_t L = recs[r].sl;
+        for (uint32_t i = 0; i < L; i++, g++) {
+            const uint32_t c = g_lut.t[s[i]];
+            if (c == 4) npos.push_back(g); else acc |= c << pos;
+            pos += 2;
+            if (pos == 32) { flush(wi, acc); wi++; acc = 0; pos = 0; }
+        }
+    }
+    if (pos) flush(wi, acc);
+}
+
+void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &out)
+{
+    out = PackedHost();
+    out.offsets.resize(count + 1);
+    uint64_t g = 0;
+    for (uint64_t i = 0; i < count; i++) { out.offsets[i] = g; g += recs[i].sl; }
+    out.offsets[count] = g;
+    out.n_words = (g + 15) / 16;
+    out.words.assign(padded_words_for(out.n_words), 0u);
+    out.uniform_len = detect_uniform_len(out.offsets.data(), count);
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > count) threads = count ? (int)count : 1;
+    std::vector<std::vector<uint64_t>> np(threads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) {
+        const uint64_t lo = count * t / threads, hi = count * (t + 1) / threads;
+        if (threads == 1) pack_range(recs, lo, hi, out.offsets.data(), out.words.data(), np[t]);
+        else th.emplace_back(pack_range, recs, lo, hi, out.offsets.data(), out.words.data(), std::ref(np[t]));
+    }
+    for (auto &x : th) x.join();
+    for (auto &v : np) out.npos.insert(out.npos.end(), v.begin(), v.end());   // ranges ascend with t
+}
+
+bool write_survivors(const char *path, const FqRec *recs, uint64_t n, const uint8_t *keep, std::string &err)
+{
+    const bool gz = has_gz_ext(path);
+    gzFile g = nullptr; FILE *f = nullptr;
+    if (gz) { g = gzopen(path, "wb6"); if (!g) { err = std::string("Cannot open file ") + path; return false; } gzbuffer(g, 1 << 20); }
+    else { f = fopen(path, "wb"); if (!f) { err = std::string("Cannot open file ") + path; return false; } }
+    std::vector<char> buf; buf.reserve(1 << 22);
+    auto drain = [&]() {
+        if (buf.empty()) return true;
+        bool ok = gz ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size()
+                     : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        buf.clear();
+        return ok;
+    };
+    bool ok = true;
+    for (uint64_t i = 0; i < n && ok; i++) {
+        if (!keep[i]) continue;
+        const FqRec &r = recs[i];
+        buf.insert(buf.end(), r.h, r.h + r.hl); buf.push_back('\n');
+        buf.insert(buf.end(), r.s, r.s + r.sl); buf.push_back('\n'); buf.push_back('+'); buf.push_back('\n');
+        buf.insert(buf.end(), r.q, r.q + r.ql); buf.push_back('\n');
+        if (buf.size() > (1u << 22) - 4096) ok = drain();
+    }
+    ok = ok && drain();
+    if (gz) ok = (gzclose(g) == Z_OK) && ok; else ok = (fclose(f) == 0) && ok;
+    if (!ok) err = std::string("write error on ") + path;
+    return ok;
+}
+
+} // namespace mf

@@ -1,0 +1,50 @@
+// Host-side parsing and packing for libmitofilter_hip (no HIP in here).
+//
+// FASTQ conventions are the reference's (filter/filter_bin/src/main.rs:287-321,
+// filter/filter_bin/src/helper.rs:14-31): strict 4-line records, line 3
+// ignored, CR stripped, partial tail dropped, gzip selected by ".gz" extension.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+namespace mf {
+
+bool has_gz_ext(const char *path);
+// whole file into memory; inflates when the path ends in ".gz".  false + err on failure
+bool slurp_file(const char *path, std::vector<char> &out, std::string &err);
+
+struct BaitHost {
+    std::vector<uint32_t> words;    // 2-bit LE, padded with 8 zero words
+    std::vector<uint8_t>  runlen;   // valid run length from each base (cap 255), 0 at invalid bases
+    uint64_t total = 0;             // bases over all records (invalid ones included)
+    std::vector<uint64_t> rec_len;  // per record
+    uint64_t n_windows(int k) const;
+    uint64_t n_swindows(int s) const;
+};
+// B5: '>' at line start opens a record; whitespace in sequence lines ignored;
+// anything but ACGTacgt is invalid and breaks windows; windows never span records.
+void parse_bait_fasta(const char *text, size_t len, BaitHost &out);
+
+struct FqRec { const char *h, *s, *q; uint32_t hl, sl, ql; };
+// strict 4-line records over an in-memory buffer (pointers into buf)
+void parse_fastq(const char *buf, size_t len, std::vector<FqRec> &recs);
+
+struct PackedHost {
+    std::vector<uint32_t> words;    // padded (see pad_words_for)
+    uint64_t n_words = 0;
+    std::vector<uint64_t> offsets;  // n_reads + 1
+    std::vector<uint64_t> npos;
+    uint32_t uniform_len = 0;       // >0 when all reads share one length
+};
+// words needed so the screen kernel can walk whole chunks past the end
+uint64_t padded_words_for(uint64_t n_words);
+// pack records [first, first+count) with `threads` workers
+void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &out);
+uint32_t detect_uniform_len(const uint64_t *offsets, uint64_t n_reads);
+
+// survivors in input order: header / seq / "+" / qual (filter_bin main.rs:261-268)
+bool write_survivors(const char *path, const FqRec *recs, uint64_t n, const uint8_t *keep, std::string &err);
+
+} // namespace mf

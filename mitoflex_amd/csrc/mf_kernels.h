@@ -1,0 +1,28 @@
+// Launcher declarations for mf_kernels.hip (internal to libmitofilter_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mf_common.h"
+#include "mf_kernels_cfg.h"
+
+namespace mf {
+
+// packed bait on the device: same 2-bit layout as reads; runlen[p] = number of
+// consecutive valid bases starting at p inside its record, capped at 255
+struct BaitView {
+    const uint32_t *words;
+    uint64_t        total;
+    const uint8_t  *runlen;
+};
+
+hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, hipStream_t st);
+hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, const uint32_t *cand, uint32_t thr, bool count_all,
+                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, hipStream_t st);
+hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, uint64_t slots, uint32_t *postab_scratch,
+                              hipStream_t st);
+hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t *stab, uint32_t stab_slots,
+                               uint32_t *has_ones, hipStream_t st);
+hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,
+                             unsigned long long *out2, hipStream_t st);
+hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);
+
+} // namespace mf

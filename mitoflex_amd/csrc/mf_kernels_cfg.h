@@ -1,0 +1,6 @@
+// Compile-time geometry shared by host packing and the screen kernel.
+#pragma once
+namespace mf {
+constexpr int SCREEN_U = 4;            // uint4 loads in flight per lane per chunk
+constexpr int SCREEN_BLOCK = 1024;     // threads per screen workgroup
+}

@@ -1,0 +1,142 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+PARITY UNPINNED BY THE REFERENCE for these rows (SURVEY.md 8a group B): the
+oracle is this repo's own (oracle/kmer_bait_oracle.c pinned to
+oracle/kmer_bait_ref.py).  Bar: bit-exact (integer work).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util_data import bits_to_bool, make_reads, write_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mf(built_lib):
+    from mitoflex_amd import mitofilter
+    if mitofilter.device_count() < 1:
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    return mitofilter
+
+
+@pytest.fixture(scope="module")
+def ol():
+    from oracle import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.mark.parametrize("k", [11, 15, 19, 21, 23, 27, 31, 32, 33, 41, 63])
+def test_table_byte_identical(mf, ol, bait_text, k):
+    """Device-built table == oracle table, byte for byte (history-independent layout)."""
+    ks = mf.KmerSet.from_text(bait_text, k)
+    t = ol.OracleTable(bait_text, k)
+    info = ks.info
+    assert (info.k, info.key_words, info.slots, info.n_keys) == (k, t.kw, t.slots, t.n_keys)
+    assert np.array_equal(ks.export_table(), t.keys)
+
+
+@pytest.mark.parametrize("k", [15, 21, 25, 31, 32, 33, 41, 63])
+@pytest.mark.parametrize("uniform", [False, True])
+def test_filter_matches_oracle(mf, ol, bait_text, k, uniform):
+    seqs = make_reads(bait_text, 6000, seed=100 + k, uniform=uniform)
+    R = ol.OracleReads.from_seqs(seqs)
+    t = ol.OracleTable(bait_text, k)
+    ks = mf.KmerSet.from_text(bait_text, k)
+    reads = mf.Reads.from_packed(R.words, R.offsets, R.npos)
+    assert reads.info.uniform_len == (150 if uniform else 0)
+    for thr in (1, 2, 7):
+        obits, ohits = ol.filter_reads(t, R, thr, threads=4)
+        for mode in (mf.MODE_SCREENED, mf.MODE_EXHAUSTIVE):
+            bits, hits, st = mf.filter_reads(ks, reads, thr, mode, want_hits=True)
+            assert np.array_equal(hits, ohits), (k, thr, mode)
+            assert np.array_equal(bits, obits), (k, thr, mode)
+            bits2, _, st2 = mf.filter_reads(ks, reads, thr, mode)          # early-exit variant
+            assert np.array_equal(bits2, obits), (k, thr, mode)
+            assert st2.n_pass == int(bits_to_bool(obits, len(seqs)).sum())
+    # one-shot host-buffer entry point
+    assert np.array_equal(mf.filter_packed(ks, R.words, R.offsets, R.npos, 1), ol.filter_reads(t, R, 1)[0])
+
+
+def test_edge_cases(mf, ol, bait_text):
+    k = 31
+    t = ol.OracleTable(bait_text, k)
+    ks = mf.KmerSet.from_text(bait_text, k)
+    from tests.util_data import bait_records
+    g = bait_records(bait_text)[0]
+    cases = {
+        "empty_set": [],
+        "all_empty_reads": ["", "", ""],
+        "one_exact_kmer": [g[100:131]],
+        "one_short": [g[100:130]],
+        "n_in_middle": [g[100:131][:15] + "N" + g[100:131][16:]],
+        "n_breaks_only_some": [g[200:300][:50] + "N" + g[200:300][51:]],
+        "polyT": ["T" * 150, "A" * 150, "T" * 31, "A" * 16],
+        "long_read": [g[1000:6000]],
+        "33_reads": [g[i * 10:i * 10 + 150] for i in range(33)],
+        "straddle": ["ACGT" * 3 + g[7000:7017], g[7017:7040] + "ACGT" * 30],
+    }
+    for name, seqs in cases.items():
+        R = ol.OracleReads.from_seqs(seqs)
+        reads = mf.Reads.from_packed(R.words, R.offsets, R.npos)
+        obits, ohits = ol.filter_reads(t, R, 1)
+        for mode in (mf.MODE_SCREENED, mf.MODE_EXHAUSTIVE):
+            bits, hits, _ = mf.filter_reads(ks, reads, 1, mode, want_hits=True)
+            assert np.array_equal(bits, obits), (name, mode)
+            if seqs:
+                assert np.array_equal(hits, ohits), (name, mode)
+
+
+def test_synth_uniform_matches_oracle(mf, ol, bait_text):
+    """Library's own synthetic generator (bench input shape) checked against the oracle."""
+    n, L = 300_000, 150
+    ks = mf.KmerSet.from_text(bait_text, 31)
+    reads = mf.Reads.synth(n, L, seed=7, bait_text=bait_text, keep_host=True)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    R = ol.OracleReads.from_arrays(reads.host_words, off, reads.host_npos)
+    t = ol.OracleTable(bait_text, 31)
+    obits, ohits = ol.filter_reads(t, R, 1, threads=os.cpu_count() or 1)
+    for mode in (mf.MODE_SCREENED, mf.MODE_EXHAUSTIVE):
+        bits, hits, st = mf.filter_reads(ks, reads, 1, mode, want_hits=True)
+        assert np.array_equal(hits, ohits)
+        assert np.array_equal(bits, obits)
+    n_pass = int(bits_to_bool(obits, n).sum())
+    assert 0.003 * n < n_pass < 0.008 * n            # ~0.5 % bait reads
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_fastq_files_match_oracle(mf, ol, bait_text, tmp_path, gz):
+    ext = ".fq.gz" if gz else ".fq"
+    s1 = make_reads(bait_text, 3000, seed=1)
+    s2 = make_reads(bait_text, 3100, seed=2)          # longer mate file: zipped to the shorter
+    fq1, fq2 = str(tmp_path / ("a_1" + ext)), str(tmp_path / ("a_2" + ext))
+    write_fastq(fq1, s1, "a", crlf=False, trailing_partial=True, gz=gz)
+    write_fastq(fq2, s2, "b", crlf=True, gz=gz)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    for pair_mode in (mf.PAIR_EITHER, mf.PAIR_BOTH):
+        o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+        g1, g2 = str(tmp_path / ("g1" + ext)), str(tmp_path / ("g2" + ext))
+        ok, ot = ol.filter_fastq_files(bait, 31, 1, pair_mode, fq1, fq2, o1, o2, threads=2)
+        gk, gt = mf.filter_fastq_files(ks, fq1, fq2, g1, g2, 1, pair_mode)
+        assert (gk, gt) == (ok, ot) and ot == 3000
+        import gzip
+        rd = (lambda p: gzip.open(p, "rb").read()) if gz else (lambda p: open(p, "rb").read())
+        assert rd(g1) == open(o1, "rb").read()
+        assert rd(g2) == open(o2, "rb").read()
+    # single end
+    o1, g1 = str(tmp_path / "se_o.fq"), str(tmp_path / "se_g.fq")
+    ok, ot = ol.filter_fastq_files(bait, 31, 2, 0, fq1, None, o1, None)
+    gk, gt = mf.filter_fastq_files(ks, fq1, None, g1, None, 2)
+    assert (gk, gt) == (ok, ot)
+    assert open(g1, "rb").read() == open(o1, "rb").read()
+    # reads straight from a FASTQ file
+    reads = mf.Reads.from_fastq(fq1)
+    R = ol.OracleReads.from_fastq(fq1)
+    assert reads.info.n_reads == R.n_reads == 3000
+    t = ol.OracleTable(bait_text, 31)
+    assert np.array_equal(mf.filter_reads(ks, reads, 1)[0], ol.filter_reads(t, R, 1)[0])

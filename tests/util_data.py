@@ -1,0 +1,101 @@
+"""Seeded synthetic inputs shared by the tests (SURVEY.md 8d shapes, small)."""
+from __future__ import annotations
+
+import random
+from typing import List
+
+import numpy as np
+
+COMP = str.maketrans("ACGTacgt", "TGCAtgca")
+
+
+def revcomp(s: str) -> str:
+    return s.translate(COMP)[::-1]
+
+
+def make_bait(seed: int = 20261003, length: int = 16569, second_record: int = 1200) -> str:
+    """A synthetic 16 569 bp 'mitogenome' plus a short second record with IUPAC codes,
+    lower case, a poly-T run and an N block, written as multi-line FASTA with CRLF on one line."""
+    rng = random.Random(seed)
+    g = "".join(rng.choices("ACGT", k=length))
+    g = g[:5000] + "T" * 40 + g[5040:9000] + "A" * 35 + g[9035:]          # homopolymers (all-ones / all-zero s-mers)
+    r2 = list("".join(rng.choices("ACGT", k=second_record)))
+    for p in (100, 101, 102, 500, 777):
+        r2[p] = "N"
+    r2[300] = "R"; r2[301] = "y"
+    r2 = "".join(r2)
+    r2 = r2[:600] + r2[600:900].lower() + r2[900:]
+    lines = [">synthetic_mito_1 len=%d" % length]
+    lines += [g[i:i + 70] for i in range(0, len(g), 70)]
+    lines += [">rec2 with iupac"]
+    lines += [r2[i:i + 60] for i in range(0, len(r2), 60)]
+    lines[3] += "\r"
+    return "\n".join(lines) + "\n"
+
+
+def bait_records(bait_text: str) -> List[str]:
+    recs, cur = [], None
+    for ln in bait_text.split("\n"):
+        if ln.startswith(">"):
+            cur = []; recs.append(cur)
+        elif cur is not None:
+            cur.append("".join(ln.split()))
+    return ["".join(r) for r in recs]
+
+
+def make_reads(bait_text: str, n: int, seed: int, read_len: int = 150, uniform: bool = False,
+               mito_frac: float = 0.3, n_frac: float = 0.1, sub_rate: float = 0.01) -> List[str]:
+    """Mixed bag: bait-derived reads (both strands, substitutions), random reads, reads with N,
+    short / empty reads, lower case.  uniform=True keeps every read at read_len."""
+    rng = random.Random(seed)
+    recs = [r for r in bait_records(bait_text) if len(r) > read_len + 10]
+    out = []
+    for i in range(n):
+        L = read_len if uniform else rng.choice([read_len, read_len, rng.randint(0, 40), rng.randint(20, 400), 31, 30, 0])
+        if rng.random() < mito_frac and L > 0:
+            r = rng.choice(recs)
+            p = rng.randrange(0, len(r) - L) if len(r) > L else 0
+            s = r[p:p + L].upper()
+            s = "".join(c if c in "ACGT" else "N" for c in s)
+            if rng.random() < 0.5:
+                s = revcomp(s)
+            s = list(s)
+            for j in range(len(s)):
+                if rng.random() < sub_rate:
+                    s[j] = rng.choice("ACGT")
+            s = "".join(s)
+        else:
+            s = "".join(rng.choices("ACGT", k=L))
+        if rng.random() < n_frac and L > 0:
+            s = list(s)
+            for _ in range(rng.randint(1, 3)):
+                s[rng.randrange(L)] = rng.choice("NnRK.")
+            s = "".join(s)
+        if rng.random() < 0.05:
+            s = s.lower()
+        out.append(s)
+    return out
+
+
+def write_fastq(path: str, seqs: List[str], prefix: str = "r", crlf: bool = False, trailing_partial: bool = False,
+                gz: bool = False):
+    import gzip
+    rng = random.Random(len(seqs))
+    eol = "\r\n" if crlf else "\n"
+    parts = []
+    for i, s in enumerate(seqs):
+        q = "".join(rng.choices("FGHIJ:;<=>?@", k=len(s)))
+        parts.append(f"@{prefix}{i} desc{eol}{s}{eol}+{'x' if i % 7 == 0 else ''}{eol}{q}{eol}")
+    if trailing_partial:
+        parts.append(f"@partial{eol}ACGT{eol}")
+    data = "".join(parts).encode()
+    if gz:
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+
+
+def bits_to_bool(bits: np.ndarray, n: int) -> np.ndarray:
+    return np.unpackbits(bits.view(np.uint8), bitorder="little")[:n].astype(bool)
