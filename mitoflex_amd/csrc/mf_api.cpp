@@ -64,7 +64,7 @@ static int get_ctx(int device, DevCtx **out)
 // ------------------------------------------------------------------ kmerset
 struct DevTables {
     uint64_t *keys = nullptr;
-    uint32_t *bloom = nullptr, *stab = nullptr;
+    uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr;
     KmerSetView view{};
     uint64_t n_keys = 0, n_smers = 0;
 };
@@ -73,7 +73,8 @@ struct mf_kmerset {
     BaitHost bait;
     uint64_t n_windows = 0, slots = 0;
     ScreenGeom geom{0, 0};
-    uint32_t bloom_log2w = 0, stab_slots = 0;
+    uint32_t bloom_log2w = 0, stage2_log2w = 0, stab_slots = 0, kb_log2w = 0;
+    size_t screen_words() const { return ((size_t)1 << bloom_log2w) + ((size_t)1 << stage2_log2w); }
     std::mutex mu;
     std::map<int, DevTables> dev;
 };
@@ -112,12 +113,15 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     BaitView bv{d_words, B.total, d_run};
     HIPCHK(launch_build_table(bv, ks->k, ks->kw, T.keys, ks->slots, d_pos, st));
     if (ks->geom.s) {
-        HIPCHK(hipMalloc(&T.bloom, sizeof(uint32_t) << ks->bloom_log2w));
-        HIPCHK(hipMemsetAsync(T.bloom, 0, sizeof(uint32_t) << ks->bloom_log2w, st));
+        HIPCHK(hipMalloc(&T.bloom, ks->screen_words() * 4));
+        HIPCHK(hipMemsetAsync(T.bloom, 0, ks->screen_words() * 4, st));
         HIPCHK(hipMalloc(&T.stab, (size_t)ks->stab_slots * 4));
         HIPCHK(hipMemsetAsync(T.stab, 0xFF, (size_t)ks->stab_slots * 4, st));
-        HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, T.stab, ks->stab_slots, d_flag, st));
+        HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag, st));
     }
+    HIPCHK(hipMalloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
+    HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
+    HIPCHK(launch_build_kbloom(T.keys, ks->slots, ks->kw, T.kbloom, ks->kb_log2w, st));
     HIPCHK(launch_count_keys(T.keys, ks->slots, ks->kw, T.stab, T.stab ? ks->stab_slots : 0, d_cnt, st));
     unsigned long long cnt[2] = {0, 0}; uint32_t flag = 0;
     HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
@@ -127,10 +131,13 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     T.n_keys = cnt[0]; T.n_smers = cnt[1] + (flag ? 1 : 0);
     KmerSetView &V = T.view;
     V.k = ks->k; V.kw = ks->kw; V.slot_mask = ks->slots - 1; V.keys = T.keys;
+    V.kb_log2w = ks->kb_log2w; V.kbloom = T.kbloom;
     V.s = ks->geom.s; V.stride = ks->geom.stride;
     V.smask = ks->geom.s >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ks->geom.s)) - 1);
-    V.bloom_log2w = ks->bloom_log2w; V.bloom = T.bloom;
+    V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
+    // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
+    V.use_stab = (T.n_smers / 2 * STAGE2_K > ((uint64_t)32 << ks->stage2_log2w) * 7 / 10) || getenv("MF_USE_STAB") ? 1u : 0u;
     ks->dev[device] = T;
     *out = &ks->dev[device];
     return MF_OK;
@@ -147,15 +154,29 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
     parse_bait_fasta(text, len, ks->bait);
     ks->n_windows = ks->bait.n_windows(k);
     ks->slots = table_slots_for(ks->n_windows);
+    {   // LDS k-mer bit table: about two k-mers per 128-bit block, 1 KiB .. 128 KiB
+        uint32_t lg = 8;
+        while (lg < 15 && (1ull << lg) < 2 * ks->n_windows) lg++;
+        ks->kb_log2w = env_u32("MF_KBLOOM_LOG2W", lg);
+        if (ks->kb_log2w < 8) ks->kb_log2w = 8;
+        if (ks->kb_log2w > 15) ks->kb_log2w = 15;
+    }
     ks->geom = screen_geom_for(k);
     if (getenv("MF_NO_SCREEN")) ks->geom = ScreenGeom{0, 0};
     if (ks->geom.s) {
         const uint64_t bound = 2 * ks->bait.n_swindows(ks->geom.s);
-        uint32_t lg = 8;                                 // 1 KiB .. 128 KiB of LDS
+        // stage 1: about one inserted s-mer per 32 bits (4 per 128-bit block), 1 KiB .. 128 KiB of LDS
+        uint32_t lg = 8;
         while (lg < 15 && (1ull << lg) < bound) lg++;
         ks->bloom_log2w = env_u32("MF_BLOOM_LOG2W", lg);
         if (ks->bloom_log2w < 8) ks->bloom_log2w = 8;
         if (ks->bloom_log2w > 15) ks->bloom_log2w = 15;
+        // stage 2: >= 16 bits per canonical s-mer, 256 B .. 32 KiB (stage 1 + stage 2 <= 160 KiB of LDS)
+        uint32_t lg2 = 6;
+        while (lg2 < 13 && (32ull << lg2) < 8 * bound) lg2++;
+        ks->stage2_log2w = env_u32("MF_STAGE2_LOG2W", lg2);
+        if (ks->stage2_log2w < 6) ks->stage2_log2w = 6;
+        if (ks->stage2_log2w > 13) ks->stage2_log2w = 13;
         uint64_t ss = 1024; while (ss < 2 * bound) ss <<= 1;
         if (ss > (1ull << 31)) { delete ks; return fail(MF_E_ARG, "bait too large for the s-mer screen table"); }
         ks->stab_slots = (uint32_t)ss;
@@ -216,7 +237,7 @@ int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info)
     memset(info, 0, sizeof *info);
     info->k = ks->k; info->key_words = ks->kw; info->slots = ks->slots; info->n_windows = ks->n_windows;
     info->screen_s = ks->geom.s; info->screen_stride = ks->geom.stride;
-    info->bloom_words = ks->geom.s ? (1u << ks->bloom_log2w) : 0; info->smer_slots = ks->stab_slots;
+    info->bloom_words = ks->geom.s ? (uint32_t)ks->screen_words() : 0; info->smer_slots = ks->stab_slots;
     if (!ks->dev.empty()) { info->n_keys = ks->dev.begin()->second.n_keys; info->n_smers = ks->dev.begin()->second.n_smers; }
     return MF_OK;
 }
@@ -235,7 +256,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 {
     if (!ks) return MF_OK;
     for (auto &kv : ks->dev) {
-        if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); }
+        if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); }
     }
     delete ks;
     return MF_OK;
@@ -298,6 +319,8 @@ static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_pa
     ReadsView &V = r->v;
     V.words = r->d_words; V.n_words = n_words; V.n_vec = (padded - 16) / 4;
     V.offsets = r->d_offsets; V.uniform_len = uniform_len; V.n_reads = n_reads; V.total_bases = total_bases;
+    V.len_magic = uniform_len > 1 ? ~0ULL / uniform_len + 1 : 0;
+    V.len_magic32 = (uniform_len > 1 && uniform_len <= 4096) ? 0xFFFFFFFFu / uniform_len + 1 : 0;
     V.npos = r->d_npos; V.n_npos = n_npos; V.has_n = r->d_has_n;
     RCHK(launch_mark_has_n(V, r->d_has_n, st));
     RCHK(hipStreamSynchronize(st));
@@ -390,13 +413,11 @@ static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, i
 {
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
     HIPCHK(hipMemsetAsync(r->d_counters, 0, 16, st));
+    if (screened) HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    if (screened) {
-        HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
-        HIPCHK(launch_screen(r->v, S, r->d_cand, n_cu, st));
-    }
+    if (screened) HIPCHK(launch_screen(r->v, S, r->d_cand, n_cu, st));
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits, r->d_hits, r->d_counters, st));
+    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st));
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
     return MF_OK;
 }

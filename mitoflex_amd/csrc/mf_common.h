@@ -29,12 +29,35 @@ MF_HD uint64_t mix64(uint64_t x)
     x ^= x >> 33;
     return x;
 }
-MF_HD uint64_t hash_key1(uint64_t lo) { return mix64(lo); }
-MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi) { return mix64(lo ^ mix64(hi + 0x9E3779B97F4A7C15ULL)); }
+// Table hash: two 32-bit multiplies per 64-bit word (cheap on the GPU's 32-bit
+// integer ALUs; a 64-bit multiply costs four), folded and finished with a
+// xor-shift so the low bits (the slot index) depend on every input bit.
+MF_HD uint32_t fold32(uint64_t x)
+{
+    const uint32_t a = (uint32_t)x * 0x9E3779B1u, b = (uint32_t)(x >> 32) * 0x85EBCA77u;
+    uint32_t h = a ^ ((b << 15) | (b >> 17));
+    return h ^ (h >> 15);
+}
+MF_HD uint64_t hash_key1(uint64_t lo) { return fold32(lo); }
+MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi)
+{
+    uint32_t h = fold32(lo) ^ (fold32(hi) * 0xC2B2AE3Du);
+    return h ^ (h >> 16);
+}
 
 // screen hashes (implementation detail of the s-mer screen; not part of the
 // result semantics -- the screen is conservative for any choice)
+//   stage 1: blocked bit table, one 128-bit block per s-mer (both strands
+//            inserted), one bit in each of the block's four dwords
+//   stage 2: classic Bloom filter over canonical s-mers, STAGE2_K probes
+//   stage 3: exact ordered s-mer table in global memory (L2 resident)
 MF_HD uint32_t bloom_hash(uint32_t smer) { return smer * 0x9E3779B1u; }
+MF_HD uint32_t bloom_bits(uint32_t h) { return h ^ (h >> 15); }          // low 20 bits pick the four bit positions
+constexpr int STAGE2_K = 4;
+MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }
+MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u; return (h ^ (h >> 16)) | 1u; }
+// k-mer bit table in front of the open-address table (exact kernel): h = 32-bit table hash of the key
+MF_HD uint32_t kbloom_hash(uint32_t h) { return h * 0x9E3779B1u; }
 MF_HD uint32_t smer_hash(uint32_t smer) { uint32_t h = smer * 0xC2B2AE35u; return h ^ (h >> 15); }
 
 // ---- table sizing rules (must match oracle/kmer_bait_oracle.c) -------------
@@ -105,6 +128,8 @@ struct ReadsView {
     uint64_t        n_vec;      // uint4 count the screen kernel walks (padded, zero tail)
     const uint64_t *offsets;    // n_reads+1 base offsets, nullptr when uniform_len > 0
     uint32_t        uniform_len;
+    uint64_t        len_magic;  // ceil(2^64 / uniform_len): g / uniform_len == umulhi64(g, len_magic) while g * len < 2^64
+    uint32_t        len_magic32;// ceil(2^32 / uniform_len), used for 32-bit offsets when uniform_len <= 4096 (else 0)
     uint64_t        n_reads;
     uint64_t        total_bases;
     const uint64_t *npos;       // sorted invalid base positions
@@ -116,14 +141,19 @@ struct KmerSetView {
     int32_t   k, kw;
     uint64_t  slot_mask;        // slots-1
     const uint64_t *keys;       // slots*kw
+    // LDS front of the table: blocked bit table over canonical k-mers (128-bit blocks, one bit per dword)
+    uint32_t  kb_log2w;         // 1 << kb_log2w words
+    const uint32_t *kbloom;
     // screen
     int32_t   s, stride;        // s == 0: disabled
     uint32_t  smask;            // (1 << 2s) - 1
-    uint32_t  bloom_log2w;
-    const uint32_t *bloom;      // 1 << bloom_log2w words
+    uint32_t  bloom_log2w;      // stage 1: 1 << bloom_log2w words (= 1 << (bloom_log2w-2) blocks of 128 bit)
+    uint32_t  stage2_log2w;     // stage 2: 1 << stage2_log2w words, stored right behind stage 1
+    const uint32_t *bloom;      // (1 << bloom_log2w) + (1 << stage2_log2w) words
     uint32_t  stab_mask;
     const uint32_t *stab;       // s-mer exact table (ordered linear probing, EMPTY32)
     uint32_t  stab_has_ones;    // the all-ones s-mer (poly-T, only possible for s == 16) is present
+    uint32_t  use_stab;         // stage 3 on: stage 2 is too full to be trusted alone (large baits)
 };
 
 } // namespace mf

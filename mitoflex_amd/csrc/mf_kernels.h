@@ -16,11 +16,12 @@ struct BaitView {
 
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, hipStream_t st);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, const uint32_t *cand, uint32_t thr, bool count_all,
-                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, hipStream_t st);
+                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st);
+hipError_t launch_build_kbloom(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, uint64_t slots, uint32_t *postab_scratch,
                               hipStream_t st);
-hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t *stab, uint32_t stab_slots,
-                               uint32_t *has_ones, hipStream_t st);
+hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
+                               uint32_t stab_slots, uint32_t *has_ones, hipStream_t st);
 hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,
                              unsigned long long *out2, hipStream_t st);
 hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);

@@ -21,6 +21,7 @@
 // full per-k-mer count, so the emitted bits equal the brute-force oracle's.
 #include "mf_common.h"
 #include "mf_kernels.h"
+#include <stdlib.h>
 
 namespace mf {
 
@@ -42,7 +43,8 @@ __device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g,
 {
     if (g + s > R.total_bases) return ~0ULL;
     if (R.uniform_len) {
-        uint64_t r = g / R.uniform_len;
+        // exact floor division by multiplication (g * uniform_len < 2^64 always holds here)
+        uint64_t r = R.uniform_len > 1 ? __umul64hi(g, R.len_magic) : g;
         uint64_t off = g - r * R.uniform_len;
         return off + s <= R.uniform_len ? r : ~0ULL;
     }
@@ -63,50 +65,67 @@ __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
 }
 
 // ------------------------------------------------------------ screen kernel
+// LDS image: [stage-1 blocks | stage-2 words].
+//   stage 1 (every sampled s-mer, in the hot loop): one ds_read_b128 of the
+//     s-mer's 128-bit block, test one bit in each dword.  Both strands of the
+//     bait are inserted, so the s-mer is used exactly as it lies in the stream.
+//   stage 2 (lanes with a stage-1 positive, a few per wave per chunk): classic
+//     Bloom probes of the canonical s-mer, still LDS only.
+//   stage 3 (what survives: true s-mer matches and ~1e-6 of the rest): exact
+//     ordered s-mer table in global memory, then the candidate bit of the read.
+// Global memory is therefore touched in the loop only by the streaming loads
+// and by (near-)true hits; an LDS false positive never costs a vmcnt stall.
 // SPW = samples per u32 word (1: stride 16 bases, 2: stride 8 bases)
 // U   = uint4 loads in flight per lane per chunk
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int SPW, int U>
 __global__ void __launch_bounds__(1024)
-screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand)
+screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t dbg)
 {
-    extern __shared__ uint32_t s_bloom[];
+    extern __shared__ uint4 s_tab4[];
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_tab4);
+    const uint32_t n1 = 1u << S.bloom_log2w;             // stage-1 words
     {
-        const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
+        const uint32_t nb4 = (n1 + (1u << S.stage2_log2w)) >> 2;
         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_bloom);
-        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
     }
     __syncthreads();
+    const uint32_t *s_st2 = s_tab + n1;
 
-    const uint4 *__restrict__ w4 = reinterpret_cast<const uint4 *>(R.words);
+    const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
     const uint64_t chunk = (uint64_t)blockDim.x * U;
     const uint64_t n_chunks = R.n_vec / chunk;          // n_vec is padded to a whole number of chunks
-    const uint32_t shift = 32 - S.bloom_log2w;
+    const uint32_t blk_shift = 32 - (S.bloom_log2w - 2);
+    const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
     const uint32_t smask = S.smask;
 
-    uint4 cur[U]; uint32_t curx[U];
+    u32x4 cur[U]; uint32_t curx[U];
     uint64_t c = blockIdx.x;
     if (c < n_chunks) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint64_t v = c * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
-            cur[u] = w4[v];
+            cur[u] = __builtin_nontemporal_load(&w4[v]);
             if (SPW == 2) curx[u] = R.words[4 * v + 4];
         }
     }
     for (; c < n_chunks; c += gridDim.x) {
         // prefetch the next chunk before touching this one
-        uint4 nxt[U]; uint32_t nxtx[U];
+        u32x4 nxt[U]; uint32_t nxtx[U];
         const uint64_t cn = c + gridDim.x;
         if (cn < n_chunks) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint64_t v = cn * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
-                nxt[u] = w4[v];
+                nxt[u] = __builtin_nontemporal_load(&w4[v]);
                 if (SPW == 2) nxtx[u] = R.words[4 * v + 4];
             }
         }
         uint32_t hitmask = 0;    // bit (u*4+q)*SPW+j
+        uint32_t pend = 0;       // s-mer of the most recent stage-1 positive (kept by select: no runtime-indexed registers)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t wv[5] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w, SPW == 2 ? curx[u] : 0u};
@@ -114,27 +133,72 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand)
             for (int q = 0; q < 4; q++) {
 #pragma unroll
                 for (int j = 0; j < SPW; j++) {
-                    uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
+                    const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
-                    const uint32_t bw = s_bloom[h >> shift];
-                    const uint32_t g = h ^ (h >> 15);
-                    const uint32_t m = (1u << (g & 31)) | (1u << ((g >> 5) & 31));
-                    hitmask |= ((bw & m) == m) ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
+                    const uint4 blk = s_tab4[h >> blk_shift];
+                    const uint32_t g = bloom_bits(h);
+                    // v_lshrrev uses only the low 5 bits of its shift operand
+                    const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
+                    const bool hit = t & 1u;
+                    hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
+                    pend = hit ? sm : pend;
                 }
             }
         }
-        // rare: verify LDS positives against the exact s-mer table, then mark the read
-        while (hitmask) {
-            const int idx = __ffs(hitmask) - 1;
-            hitmask &= hitmask - 1;
-            const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
-            const uint64_t wi = 4 * (c * chunk + (uint64_t)u * blockDim.x + threadIdx.x) + q;
-            uint32_t sm = R.words[wi];
-            if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * j) & smask;
-            if (stab_contains(S, sm)) {
-                const uint64_t g0 = wi * 16 + (uint64_t)j * 8;
-                const uint64_t r = read_holding(R, g0, (uint32_t)S.s);
-                if (r != ~0ULL) atomicOr(&cand[r >> 5], 1u << (r & 31));
+        if (dbg & 1) { if (hitmask == 0xFFFFFFFFu) cand[0] = pend; hitmask = 0; }   // timing experiment: no later stages
+        if (hitmask) {
+            // Read arithmetic for this chunk, done once on uniform values: the chunk's first base
+            // cb = rq * L + rrem.  A positive at 32-bit offset `off` inside the chunk then sits in
+            // read rq + (rrem + off) / L, a 32-bit division by multiplication.
+            const bool fast = R.len_magic32 != 0;
+            const uint64_t cb = c * chunk * 64;
+            uint64_t rq = 0; uint32_t rrem = 0;
+            if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
+            uint64_t last_r = ~0ULL;
+            bool first = true;
+            while (hitmask) {
+                // the newest positive is still in `pend`; older ones are re-read from memory, but
+                // only if they are not in the read this lane has just marked
+                const int idx = first ? 31 - __clz(hitmask) : __ffs(hitmask) - 1;
+                hitmask &= ~(1u << idx);
+                const bool use_pend = first;
+                first = false;
+                const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
+                const uint32_t off = ((((uint32_t)u * blockDim.x + threadIdx.x) * 4 + q) << 4) + (uint32_t)j * 8;
+                const uint64_t g0 = cb + off;
+                uint64_t r = ~0ULL;
+                if (fast) {
+                    const uint32_t t = rrem + off;
+                    const uint32_t dq = __umulhi(t, R.len_magic32);
+                    const uint32_t offr = t - dq * R.uniform_len;
+                    if (offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases) continue;   // straddles two reads / padding
+                    r = rq + dq;
+                    if (r == last_r) continue;
+                }
+                uint32_t sm = pend;
+                if (!use_pend) {
+                    const uint64_t wi = g0 >> 4;
+                    sm = R.words[wi];
+                    if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * j) & smask;
+                }
+                // stage 2: canonical s-mer, STAGE2_K Bloom probes in LDS
+                const uint32_t rc = revcomp_s(sm, S.s);
+                const uint32_t cn_ = sm < rc ? sm : rc;
+                const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
+                uint32_t ok = 1;
+#pragma unroll
+                for (int i = 0; i < STAGE2_K; i++) {
+                    const uint32_t pos = (ha + (uint32_t)i * hb) >> st2_shift;
+                    ok &= s_st2[pos >> 5] >> (pos & 31);
+                }
+                if (!(ok & 1u)) continue;
+                // stage 3 (large baits only): exact s-mer table in global memory
+                if (S.use_stab && !stab_contains(S, sm)) continue;
+                if (!fast) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) continue; }
+                // mark the read: no load, no returning atomic, so the streaming loads behind
+                // this never wait for it
+                atomicOr(&cand[r >> 5], 1u << (r & 31));
+                last_r = r;
             }
         }
 #pragma unroll
@@ -195,78 +259,259 @@ __device__ __forceinline__ bool table_contains(const KmerSetView &S, Key<2> v)
     }
 }
 
-template <int KW, bool COUNT_ALL>
-__device__ __forceinline__ uint32_t read_hits(const ReadsView &R, const KmerSetView &S, uint64_t r, uint32_t thr, int lane)
+// Exact path: k-mer extract -> canonicalise -> bait table probe -> hit threshold,
+// with the bait set staged through LDS.
+//
+// Each persistent 1024-thread workgroup first copies the k-mer bit table (a
+// blocked Bloom filter over the canonical bait k-mers, <= 128 KiB) into LDS.
+// A wave then takes 64 words of the candidate bitmap (2048 reads), gathers the
+// candidate reads among them with a prefix scan over per-lane popcounts, and
+// deals WORK ITEMS -- (candidate, run of ITEM_POS k-mer positions) -- to its
+// lanes, so a read's ~120 positions are spread over 8 lanes.  An item builds
+// its k-mers from one 128/192-bit window (a single unaligned 16-byte load plus
+// a dword), tests each in the LDS table, and only the positives are verified in
+// the open-address table in L2.  Measured before this structure existed: the
+// kernel was bound by scattered L2 line requests (~200 per read); the LDS front
+// leaves about one per item plus one per verified hit.  In threshold mode an
+// item stops verifying as soon as its read's verified count (an LDS counter
+// shared by the read's items) reaches the threshold.  Pass bits return to the
+// owning bitmap word through LDS and are stored coalesced.
+constexpr int ITEM_POS = 16;
+constexpr int EXACT_BLOCK = 1024;
+
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, int sh)   // (hi:lo >> sh), sh in [0,63]
 {
-    uint64_t b0, len;
-    if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; }
-    else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
-    const int k = S.k;
-    if (len < (uint64_t)k) return 0;
-    const uint64_t n_pos = len - k + 1;
-    const bool hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
-    uint64_t n_lo = 0, n_hi = 0;
-    if (hasn) { n_lo = lower_bound_u64(R.npos, R.n_npos, b0); n_hi = lower_bound_u64(R.npos, R.n_npos, b0 + len); }
-    uint32_t hits = 0;
-    for (uint64_t p0 = 0; p0 < n_pos; p0 += 64) {
-        const uint64_t p = p0 + lane;
-        const bool active = p < n_pos;
-        const uint64_t g = b0 + (active ? p : 0);
-        const Key<KW> key = canonical_at<KW>(R.words, g, k);
-        bool found = active && table_contains(S, key);
-        if (hasn) {
-            for (uint64_t i = n_lo; i < n_hi; i++) {
-                const uint64_t np = R.npos[i];
-                if (np >= g && np < g + k) found = false;
-            }
-        }
-        hits += (uint32_t)__popcll(__ballot(found));
-        if (!COUNT_ALL && hits >= thr) break;
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int KW>
+__device__ __forceinline__ bool table_has(const KmerSetView &S, uint64_t klo, uint64_t khi, uint32_t h)
+{
+    uint64_t slot = h & S.slot_mask;
+    if (KW == 1) {
+        uint64_t e = S.keys[slot];
+        while (e < klo) { slot = (slot + 1) & S.slot_mask; e = S.keys[slot]; }       // ordered table
+        return e == klo;
+    } else {
+        const ulonglong2 *__restrict__ kt = reinterpret_cast<const ulonglong2 *>(S.keys);
+        ulonglong2 e = kt[slot];
+        while ((e.y < khi) || (e.y == khi && e.x < klo)) { slot = (slot + 1) & S.slot_mask; e = kt[slot]; }
+        return e.x == klo && e.y == khi;
     }
-    return hits;
+}
+
+// One work item: k-mer positions [p0, p0 + ITEM_POS) of the read starting at base b0 with n_pos positions.
+// Verified hits are added to *cnt (LDS, shared by the read's items).
+template <int KW, bool COUNT_ALL>
+__device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView &S, const uint4 *__restrict__ s_kb4,
+                                          uint32_t kb_shift, uint64_t b0, uint64_t n_pos, uint64_t p0, bool hasn,
+                                          uint32_t thr, uint32_t *cnt)
+{
+    const int k = S.k;
+    const uint64_t mask_lo = (KW == 1 && k < 32) ? (1ULL << (2 * k)) - 1 : ~0ULL;
+    const uint64_t mask_hi = KW == 2 ? (1ULL << (2 * k - 64)) - 1 : 0;
+    // a window of (ITEM_POS - 1 + k) bases starting at base b0 + p0, first base at bit 0
+    const uint64_t bit = 2 * (b0 + p0);
+    const uint32_t *__restrict__ w = R.words + (bit >> 5);
+    const uint32_t sh = (uint32_t)bit & 31;
+    constexpr int NW = KW == 1 ? 4 : 6;                       // aligned words of window; one more is read for the shift
+    uint32_t raw[NW + 1];
+    {
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(w);
+        raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+        if (KW == 1) raw[4] = w[4];
+        else { const u32x2_a4 v2 = *reinterpret_cast<const u32x2_a4 *>(w + 4); raw[4] = v2.x; raw[5] = v2.y; raw[NW] = w[6]; }
+    }
+    uint32_t a[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) a[i] = alignbit(raw[i + 1], raw[i], sh);
+    const uint64_t x0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), x1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    uint64_t x2 = 0;
+    if (KW == 2) x2 = (uint64_t)a[NW - 2] | ((uint64_t)a[NW - 1] << 32);
+
+    // LDS stage: which of the ITEM_POS k-mers might be in the bait set
+    uint32_t pos_mask = 0;
+#pragma unroll
+    for (int i = 0; i < ITEM_POS; i++) {
+        uint64_t klo, khi = 0; uint32_t h;
+        if (KW == 1) {
+            const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
+            const uint64_t rc = revcomp1(fwd, k);
+            klo = fwd < rc ? fwd : rc;
+            h = (uint32_t)hash_key1(klo);
+        } else {
+            const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
+            uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
+            const bool f = (hi < rhi) || (hi == rhi && lo < rlo);
+            klo = f ? lo : rlo; khi = f ? hi : rhi;
+            h = (uint32_t)hash_key2(klo, khi);
+        }
+        const uint32_t hb = kbloom_hash(h);
+        const uint4 blk = s_kb4[hb >> kb_shift];
+        const uint32_t g = bloom_bits(hb);
+        const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
+        pos_mask |= (t & 1u) << i;
+    }
+    // positions past the end of the read, and windows holding an invalid base
+    const uint64_t left = n_pos - p0;
+    if (left < ITEM_POS) pos_mask &= (1u << left) - 1;
+    if (hasn && pos_mask) {
+        const uint64_t len = n_pos + k - 1;
+        const uint64_t n_lo = lower_bound_u64(R.npos, R.n_npos, b0), n_hi = lower_bound_u64(R.npos, R.n_npos, b0 + len);
+        for (uint64_t n = n_lo; n < n_hi; n++) {
+            const int64_t d = (int64_t)(R.npos[n] - (b0 + p0));       // window i holds it iff i <= d < i + k
+#pragma unroll
+            for (int i = 0; i < ITEM_POS; i++) if (d >= i && d < i + k) pos_mask &= ~(1u << i);
+        }
+    }
+    // L2 stage: verify the positives (rebuild the key of position i from the window)
+    while (pos_mask) {
+        if (!COUNT_ALL && *reinterpret_cast<volatile uint32_t *>(cnt) >= thr) break;
+        const int i = __ffs(pos_mask) - 1;
+        pos_mask &= pos_mask - 1;
+        uint64_t klo, khi = 0; uint32_t h;
+        if (KW == 1) {
+            const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
+            const uint64_t rc = revcomp1(fwd, k);
+            klo = fwd < rc ? fwd : rc;
+            h = (uint32_t)hash_key1(klo);
+        } else {
+            const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
+            uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
+            const bool f = (hi < rhi) || (hi == rhi && lo < rlo);
+            klo = f ? lo : rlo; khi = f ? hi : rhi;
+            h = (uint32_t)hash_key2(klo, khi);
+        }
+        if (table_has<KW>(S, klo, khi, h)) atomicAdd(cnt, 1u);
+    }
+}
+
+__device__ __forceinline__ uint32_t nth_set_bit(uint32_t w, uint32_t n)
+{   // position of the n-th (0-based) set bit of w; w has more than n bits set
+    uint32_t pos = 0;
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        const uint32_t c = __popc((w >> pos) & ((1u << s) - 1));
+        if (n >= c) { n -= c; pos += s; }
+    }
+    return pos;
 }
 
 template <int KW, bool COUNT_ALL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(EXACT_BLOCK)
 exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint32_t thr,
-             uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out, unsigned long long *__restrict__ counters)
+             uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out)
 {
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    extern __shared__ uint4 s_mem4[];
+    constexpr int WAVES = EXACT_BLOCK / 64;
+    uint32_t *s_res = reinterpret_cast<uint32_t *>(s_mem4);                  // [WAVES][64]
+    uint32_t *s_cnt = s_res + WAVES * 64;                                    // [WAVES][64]
+    const uint4 *s_kb4 = s_mem4 + (2 * WAVES * 64) / 4;
+    {
+        const uint32_t nb4 = (1u << S.kb_log2w) >> 2;
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.kbloom);
+        uint4 *dst = s_mem4 + (2 * WAVES * 64) / 4;
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t kb_shift = 32 - (S.kb_log2w - 2);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t *my_res = s_res + wid * 64, *my_cnt = s_cnt + wid * 64;
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
-    const uint64_t wbase = wave * 64;
-    if (wbase >= n_bw) return;
-    const uint64_t myw = wbase + lane;
-    uint32_t cw = 0;
-    if (myw < n_bw) {
-        cw = cand ? cand[myw] : 0xFFFFFFFFu;
-        const uint64_t rem = R.n_reads - myw * 32;
-        if (rem < 32) cw &= (1u << rem) - 1;
-    }
-    uint32_t res = 0;
-    uint64_t lanes = __ballot(cw != 0);
-    while (lanes) {
-        const int src = __ffsll((unsigned long long)lanes) - 1;
-        lanes &= lanes - 1;
-        uint32_t bits = __builtin_amdgcn_readlane(cw, src);
-        while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const uint64_t r = (wbase + src) * 32 + b;
-            const uint32_t h = read_hits<KW, COUNT_ALL>(R, S, r, thr, lane);
-            if (COUNT_ALL && lane == 0) hits_out[r] = h;
-            if (h >= thr && lane == src) res |= 1u << b;
+    const uint64_t n_wc = (n_bw + 63) >> 6;                                  // wave-chunks of 64 bitmap words
+    const int k = S.k;
+    for (uint64_t wc = (uint64_t)blockIdx.x * WAVES + wid; wc < n_wc; wc += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t wbase = wc * 64;
+        const uint64_t myw = wbase + lane;
+        uint32_t cw = 0;
+        if (myw < n_bw) {
+            cw = cand ? cand[myw] : 0xFFFFFFFFu;
+            const uint64_t rem = R.n_reads - myw * 32;
+            if (rem < 32) cw &= (1u << rem) - 1;
         }
-    }
-    if (myw < n_bw) out_bits[myw] = res;
-    // pass / candidate tallies: one atomic per wave
-    const uint32_t np = __popc(res), nc = __popc(cw);
-    uint32_t sp = np, sc = nc;
+        my_res[lane] = 0;
+        // inclusive scan of the per-lane candidate counts
+        uint32_t incl = __popc(cw);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sp += __shfl_down(sp, o); sc += __shfl_down(sc, o); }
-    if (lane == 0 && (sp | sc)) {
-        if (sp) atomicAdd(&counters[0], (unsigned long long)sp);
-        if (sc) atomicAdd(&counters[1], (unsigned long long)sc);
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const uint32_t total = __shfl(incl, 63);
+        for (uint32_t cbase = 0; cbase < total; cbase += 64) {
+            // lane i decodes candidate cbase + i of this wave-chunk
+            const uint32_t ncand = total - cbase < 64 ? total - cbase : 64;
+            const bool active = (uint32_t)lane < ncand;
+            const uint32_t c = active ? cbase + lane : total - 1;
+            int lo = 0, hi = 63;                      // smallest lane whose inclusive count exceeds c
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; if (__shfl(incl, mid) > c) hi = mid; else lo = mid + 1; }
+            const int src = lo;
+            const uint32_t w = __shfl(cw, src);
+            const uint32_t b = nth_set_bit(w, c - (__shfl(incl, src) - __popc(w)));
+            const uint64_t r = (wbase + src) * 32 + b;
+            uint64_t b0 = 0; uint32_t np = 0, hasn = 0;
+            if (active) {
+                uint64_t len;
+                if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; }
+                else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
+                const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
+                np = n_pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_pos;
+                hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
+            }
+            my_cnt[lane] = 0;
+            uint32_t maxpos = np;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(maxpos, o); maxpos = t > maxpos ? t : maxpos; }
+            const uint32_t b0_lo = (uint32_t)b0, b0_hi = (uint32_t)(b0 >> 32);
+            // passes of up to 32 items (512 positions) per candidate
+            for (uint32_t pbase = 0; pbase < maxpos; pbase += 32 * ITEM_POS) {
+                const uint32_t nit = (maxpos - pbase + ITEM_POS - 1) / ITEM_POS;
+                int lg = 0; while (lg < 5 && (1u << lg) < nit) lg++;
+                const uint32_t n_items = ncand << lg;
+                for (uint32_t t0 = 0; t0 < n_items; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    const int ci = (int)((t >> lg) & 63);
+                    const uint32_t it = t & ((1u << lg) - 1);
+                    const uint64_t cb0 = ((uint64_t)__shfl(b0_hi, ci) << 32) | __shfl(b0_lo, ci);
+                    const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
+                    const uint32_t p0 = pbase + it * ITEM_POS;
+                    if (t < n_items && p0 < cnp)
+                        item_hits<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
+                }
+            }
+            if (active) {
+                const uint32_t h = my_cnt[lane];
+                if (COUNT_ALL) hits_out[r] = h;
+                if (h >= thr) atomicOr(&my_res[src], 1u << b);
+            }
+        }
+        if (myw < n_bw) out_bits[myw] = my_res[lane];
+    }
+}
+
+// pass / candidate tallies: grid-stride popcount, one atomic pair per workgroup
+// (same-address atomics serialise at ~11 ns each, so never one per wave)
+__global__ void __launch_bounds__(1024)
+tally_kernel(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ cand, uint64_t n_bw,
+             unsigned long long *__restrict__ counters)
+{
+    __shared__ uint32_t s_p[16], s_c[16];
+    uint32_t p = 0, c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bw; i += (uint64_t)gridDim.x * blockDim.x) {
+        p += __popc(bits[i]);
+        if (cand) c += __popc(cand[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { p += __shfl_down(p, o); c += __shfl_down(c, o); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { s_p[wid] = p; s_c[wid] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tp = 0, tc = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { tp += s_p[w]; tc += s_c[w]; }
+        if (tp) atomicAdd(&counters[0], (unsigned long long)tp);
+        if (tc) atomicAdd(&counters[1], (unsigned long long)tc);
     }
 }
 
@@ -326,15 +571,22 @@ __global__ void materialize2_kernel(BaitView B, int k, const uint32_t *postab, u
     keys[2 * s] = kv.lo; keys[2 * s + 1] = kv.hi;
 }
 
-__device__ __forceinline__ void screen_insert(uint32_t sm, uint32_t *bloom, uint32_t log2w, uint32_t *stab, uint32_t stab_mask,
-                                              uint32_t *has_ones)
+__device__ __forceinline__ void stage1_insert(uint32_t sm, uint32_t *bloom, uint32_t log2w)
 {
     const uint32_t h = bloom_hash(sm);
-    const uint32_t g = h ^ (h >> 15);
-    atomicOr(&bloom[h >> (32 - log2w)], (1u << (g & 31)) | (1u << ((g >> 5) & 31)));
+    const uint32_t g = bloom_bits(h);
+    uint32_t *blk = bloom + 4 * (size_t)(h >> (32 - (log2w - 2)));
+    atomicOr(&blk[0], 1u << (g & 31));
+    atomicOr(&blk[1], 1u << ((g >> 5) & 31));
+    atomicOr(&blk[2], 1u << ((g >> 10) & 31));
+    atomicOr(&blk[3], 1u << ((g >> 15) & 31));
+}
+
+__device__ __forceinline__ void stab_insert(uint32_t sm, uint32_t *stab, uint32_t stab_mask, uint32_t *has_ones)
+{
     if (sm == EMPTY32) { *has_ones = 1u; return; }
     uint32_t v = sm, slot = smer_hash(sm) & stab_mask;
-    for (;;) {
+    for (;;) {                                          // history-independent ordered insertion
         const uint32_t old = atomicMin(&stab[slot], v);
         if (old == v) return;
         if (old > v) v = old;
@@ -343,16 +595,41 @@ __device__ __forceinline__ void screen_insert(uint32_t sm, uint32_t *bloom, uint
     }
 }
 
-__global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t log2w, uint32_t *stab, uint32_t stab_mask,
-                                    uint32_t *has_ones)
+__global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
+                                    uint32_t stab_mask, uint32_t *has_ones)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B.total || B.runlen[p] < s) return;
     const uint64_t bit = 2 * p; const uint64_t wi = bit >> 5; const uint32_t sh = (uint32_t)bit & 31;
     uint32_t fwd = alignbit(B.words[wi + 1], B.words[wi], sh);
     if (s < 16) fwd &= (1u << (2 * s)) - 1;
-    screen_insert(fwd, bloom, log2w, stab, stab_mask, has_ones);
-    screen_insert(revcomp_s(fwd, s), bloom, log2w, stab, stab_mask, has_ones);
+    const uint32_t rc = revcomp_s(fwd, s);
+    stage1_insert(fwd, bloom, log2w); stage1_insert(rc, bloom, log2w);
+    stab_insert(fwd, stab, stab_mask, has_ones); stab_insert(rc, stab, stab_mask, has_ones);
+    const uint32_t cn = fwd < rc ? fwd : rc;
+    const uint32_t ha = stage2_hash_a(cn), hb = stage2_hash_b(cn);
+    uint32_t *st2 = bloom + ((size_t)1 << log2w);
+#pragma unroll
+    for (int i = 0; i < STAGE2_K; i++) {
+        const uint32_t pos = (ha + (uint32_t)i * hb) >> (32 - (log2w2 + 5));
+        atomicOr(&st2[pos >> 5], 1u << (pos & 31));
+    }
+}
+
+// LDS front of the bait table: one 128-bit block per canonical k-mer, one bit in each dword
+__global__ void build_kbloom_kernel(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    const uint64_t lo = keys[i * kw], hi = kw == 2 ? keys[i * kw + 1] : 0;
+    if (lo == EMPTY64 && (kw == 1 || hi == EMPTY64)) return;
+    const uint32_t h = (uint32_t)(kw == 1 ? hash_key1(lo) : hash_key2(lo, hi));
+    const uint32_t hb = kbloom_hash(h), g = bloom_bits(hb);
+    uint32_t *blk = kbloom + 4 * (size_t)(hb >> (32 - (kb_log2w - 2)));
+    atomicOr(&blk[0], 1u << (g & 31));
+    atomicOr(&blk[1], 1u << ((g >> 5) & 31));
+    atomicOr(&blk[2], 1u << ((g >> 10) & 31));
+    atomicOr(&blk[3], 1u << ((g >> 15) & 31));
 }
 
 __global__ void count_keys_kernel(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,
@@ -383,7 +660,8 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, hipStream_t st)
 {
-    const size_t lds = sizeof(uint32_t) << S.bloom_log2w;
+    static const uint32_t dbg = getenv("MF_DEBUG_SCREEN") ? (uint32_t)atoi(getenv("MF_DEBUG_SCREEN")) : 0u;
+    const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + (sizeof(uint32_t) << S.stage2_log2w);
     int blocks_per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (blocks_per_cu > 2) blocks_per_cu = 2;          // 2 x 1024 threads = 32 waves/CU
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -393,25 +671,38 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *can
     if (grid == 0) return hipSuccess;
     if (S.stride == 16) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<1, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((screen_kernel<1, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand);
+        hipLaunchKernelGGL((screen_kernel<1, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand, dbg);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<2, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((screen_kernel<2, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand);
+        hipLaunchKernelGGL((screen_kernel<2, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand, dbg);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, const uint32_t *cand, uint32_t thr, bool count_all,
-                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, hipStream_t st)
+                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st)
 {
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
-    const uint64_t waves = (n_bw + 63) / 64;
-    if (waves == 0) return hipSuccess;
-    const unsigned grid = grid_for(waves * 64, 256);
-#define MF_LAUNCH_EXACT(KW, CA) hipLaunchKernelGGL((exact_kernel<KW, CA>), dim3(grid), dim3(256), 0, st, R, S, cand, thr, out_bits, hits_out, counters)
+    const uint64_t n_wc = (n_bw + 63) / 64;
+    if (n_wc == 0) return hipSuccess;
+    constexpr int WAVES = EXACT_BLOCK / 64;
+    uint64_t grid = (n_wc + WAVES - 1) / WAVES;
+    if (grid > (uint64_t)n_cu) grid = n_cu;                  // persistent: one 1024-thread workgroup per CU
+    const size_t lds = (sizeof(uint32_t) << S.kb_log2w) + 2 * WAVES * 64 * sizeof(uint32_t);
+#define MF_LAUNCH_EXACT(KW, CA) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&exact_kernel<KW, CA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, R, S, cand, thr, out_bits, hits_out); } while (0)
     if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true); else MF_LAUNCH_EXACT(1, false); }
     else           { if (count_all) MF_LAUNCH_EXACT(2, true); else MF_LAUNCH_EXACT(2, false); }
 #undef MF_LAUNCH_EXACT
+    uint64_t tg = (n_bw + 1023) / 1024; if (tg > 256) tg = 256;
+    hipLaunchKernelGGL(tally_kernel, dim3((unsigned)tg), dim3(1024), 0, st, out_bits, cand, n_bw, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_kbloom(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st)
+{
+    hipLaunchKernelGGL(build_kbloom_kernel, dim3(grid_for(slots, 256)), dim3(256), 0, st, keys, slots, kw, kbloom, kb_log2w);
     return hipGetLastError();
 }
 
@@ -428,11 +719,11 @@ hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, 
     return hipGetLastError();
 }
 
-hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t *stab, uint32_t stab_slots,
-                               uint32_t *has_ones, hipStream_t st)
+hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
+                               uint32_t stab_slots, uint32_t *has_ones, hipStream_t st)
 {
     if (B.total == 0) return hipSuccess;
-    hipLaunchKernelGGL(build_screen_kernel, dim3(grid_for(B.total, 256)), dim3(256), 0, st, B, s, bloom, log2w, stab, stab_slots - 1, has_ones);
+    hipLaunchKernelGGL(build_screen_kernel, dim3(grid_for(B.total, 256)), dim3(256), 0, st, B, s, bloom, log2w, log2w2, stab, stab_slots - 1, has_ones);
     return hipGetLastError();
 }
 

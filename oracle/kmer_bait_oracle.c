@@ -31,18 +31,19 @@ static inline int base_code(unsigned char c)
 }
 
 /* -------------------------------------------------------------------- hash */
-static inline uint64_t mix64(uint64_t x)
-{   /* MurmurHash3 fmix64 (public domain, Austin Appleby) */
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
-    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
-    x ^= x >> 33;
-    return x;
+/* Table hash (B3): two 32-bit multiplies per 64-bit word, folded, xor-shift finish. */
+static inline uint32_t fold32(uint64_t x)
+{
+    const uint32_t a = (uint32_t)x * 0x9E3779B1u, b = (uint32_t)(x >> 32) * 0x85EBCA77u;
+    uint32_t h = a ^ ((b << 15) | (b >> 17));
+    return h ^ (h >> 15);
 }
 
 uint64_t mfo_hash64(uint64_t lo, uint64_t hi, int kw)
 {
-    if (kw == 1) return mix64(lo);
-    return mix64(lo ^ mix64(hi + 0x9E3779B97F4A7C15ULL));
+    if (kw == 1) return fold32(lo);
+    uint32_t h = fold32(lo) ^ (fold32(hi) * 0xC2B2AE3Du);
+    return h ^ (h >> 16);
 }
 
 /* -------------------------------------------------------------- file input */
@@ -301,6 +302,23 @@ static uint32_t read_hits(const mfo_table *t, const mfo_reads *r, uint64_t idx)
     return hits;
 }
 
+/* same loop with 64-bit words for k <= 32 (the common case; identical results) */
+static uint32_t read_hits64(const mfo_table *t, const mfo_reads *r, uint64_t idx)
+{
+    const int k = t->k; const uint64_t M = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    uint64_t b0 = r->offsets[idx], b1 = r->offsets[idx + 1];
+    uint64_t ni = npos_lower_bound(r, b0);
+    uint64_t fwd = 0, rc = 0, run = 0; uint32_t hits = 0;
+    for (uint64_t g = b0; g < b1; g++) {
+        if (ni < r->n_npos && r->npos[ni] == g) { ni++; run = 0; fwd = rc = 0; continue; }
+        uint64_t b = (uint64_t)get_base(r, g);
+        fwd = (fwd >> 2) | (b << (2 * (k - 1)));
+        rc = ((rc << 2) | (3 - b)) & M;
+        if (++run >= (uint64_t)k) hits += (uint32_t)mfo_table_contains(t, fwd < rc ? fwd : rc, 0);
+    }
+    return hits;
+}
+
 typedef struct {
     const mfo_table *t; const mfo_reads *r; uint64_t first, lo, hi; uint32_t thr;
     uint32_t *bits; uint32_t *hits;
@@ -310,7 +328,7 @@ static void *filter_job(void *arg)
 {
     job_t *j = (job_t *)arg;
     for (uint64_t i = j->lo; i < j->hi; i++) {
-        uint32_t h = read_hits(j->t, j->r, j->first + i);
+        uint32_t h = j->t->kw == 1 ? read_hits64(j->t, j->r, j->first + i) : read_hits(j->t, j->r, j->first + i);
         if (j->hits) j->hits[i] = h;
         if (j->bits && h >= j->thr) __atomic_fetch_or(&j->bits[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED);
     }

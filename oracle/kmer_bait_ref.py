@@ -177,21 +177,23 @@ def pack_reads(seqs: Sequence[str]):
 _M64 = (1 << 64) - 1
 
 
-def mix64(x: int) -> int:
-    """MurmurHash3 fmix64."""
-    x ^= x >> 33
-    x = (x * 0xFF51AFD7ED558CCD) & _M64
-    x ^= x >> 33
-    x = (x * 0xC4CEB9FE1A85EC53) & _M64
-    x ^= x >> 33
-    return x
+_M32 = (1 << 32) - 1
+
+
+def fold32(x: int) -> int:
+    """Two 32-bit multiplies per 64-bit word, folded, xor-shift finish."""
+    a = ((x & _M32) * 0x9E3779B1) & _M32
+    b = ((x >> 32) * 0x85EBCA77) & _M32
+    h = a ^ (((b << 15) | (b >> 17)) & _M32)
+    return h ^ (h >> 15)
 
 
 def hash_key(code: int, k: int) -> int:
     lo, hi = code & _M64, code >> 64
     if k <= 32:
-        return mix64(lo)
-    return mix64(lo ^ mix64((hi + 0x9E3779B97F4A7C15) & _M64))
+        return fold32(lo)
+    h = fold32(lo) ^ ((fold32(hi) * 0xC2B2AE3D) & _M32)
+    return h ^ (h >> 16)
 
 
 def n_windows(fasta_text: str, k: int) -> int:
