@@ -154,9 +154,9 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
     parse_bait_fasta(text, len, ks->bait);
     ks->n_windows = ks->bait.n_windows(k);
     ks->slots = table_slots_for(ks->n_windows);
-    {   // LDS k-mer bit table: about two k-mers per 128-bit block, 1 KiB .. 128 KiB
+    {   // LDS k-mer bit table: about two k-mers per 128-bit block, 1 KiB .. 64 KiB (two workgroups per CU)
         uint32_t lg = 8;
-        while (lg < 15 && (1ull << lg) < 2 * ks->n_windows) lg++;
+        while (lg < 14 && (1ull << lg) < 2 * ks->n_windows) lg++;
         ks->kb_log2w = env_u32("MF_KBLOOM_LOG2W", lg);
         if (ks->kb_log2w < 8) ks->kb_log2w = 8;
         if (ks->kb_log2w > 15) ks->kb_log2w = 15;

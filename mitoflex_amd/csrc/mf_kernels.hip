@@ -156,6 +156,11 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
             if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
             uint64_t last_r = ~0ULL;
             bool first = true;
+            // offset (bases, inside the chunk) of sample idx of this lane
+            auto off_of = [&](int idx) -> uint32_t {
+                const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
+                return ((((uint32_t)u * blockDim.x + threadIdx.x) * 4 + q) << 4) + (uint32_t)j * 8;
+            };
             while (hitmask) {
                 // the newest positive is still in `pend`; older ones are re-read from memory, but
                 // only if they are not in the read this lane has just marked
@@ -163,8 +168,8 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
                 hitmask &= ~(1u << idx);
                 const bool use_pend = first;
                 first = false;
-                const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
-                const uint32_t off = ((((uint32_t)u * blockDim.x + threadIdx.x) * 4 + q) << 4) + (uint32_t)j * 8;
+                const int j = idx % SPW;
+                const uint32_t off = off_of(idx);
                 const uint64_t g0 = cb + off;
                 uint64_t r = ~0ULL;
                 if (fast) {
@@ -199,6 +204,12 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
                 // this never wait for it
                 atomicOr(&cand[r >> 5], 1u << (r & 31));
                 last_r = r;
+                // the positives a lane has left usually sit in the read it has just marked: if the
+                // lowest and the highest of them do, so does everything in between
+                if (fast && hitmask) {
+                    const uint32_t t_lo = rrem + off_of(__ffs(hitmask) - 1), t_hi = rrem + off_of(31 - __clz(hitmask));
+                    if (rq + __umulhi(t_lo, R.len_magic32) == r && rq + __umulhi(t_hi, R.len_magic32) == r) hitmask = 0;
+                }
             }
         }
 #pragma unroll
@@ -423,12 +434,18 @@ exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
     const uint64_t n_wc = (n_bw + 63) >> 6;                                  // wave-chunks of 64 bitmap words
     const int k = S.k;
-    for (uint64_t wc = (uint64_t)blockIdx.x * WAVES + wid; wc < n_wc; wc += (uint64_t)gridDim.x * WAVES) {
+    const uint64_t wc_step = (uint64_t)gridDim.x * WAVES;
+    auto load_cw = [&](uint64_t wc) -> uint32_t {
+        const uint64_t wi = wc * 64 + lane;
+        return (wc < n_wc && wi < n_bw) ? (cand ? cand[wi] : 0xFFFFFFFFu) : 0u;
+    };
+    uint32_t cw_next = load_cw((uint64_t)blockIdx.x * WAVES + wid);
+    for (uint64_t wc = (uint64_t)blockIdx.x * WAVES + wid; wc < n_wc; wc += wc_step) {
         const uint64_t wbase = wc * 64;
         const uint64_t myw = wbase + lane;
-        uint32_t cw = 0;
+        uint32_t cw = cw_next;
+        cw_next = load_cw(wc + wc_step);                                     // next chunk's candidate word, a whole chunk early
         if (myw < n_bw) {
-            cw = cand ? cand[myw] : 0xFFFFFFFFu;
             const uint64_t rem = R.n_reads - myw * 32;
             if (rem < 32) cw &= (1u << rem) - 1;
         }
@@ -686,9 +703,10 @@ hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, const uint32_t
     const uint64_t n_wc = (n_bw + 63) / 64;
     if (n_wc == 0) return hipSuccess;
     constexpr int WAVES = EXACT_BLOCK / 64;
-    uint64_t grid = (n_wc + WAVES - 1) / WAVES;
-    if (grid > (uint64_t)n_cu) grid = n_cu;                  // persistent: one 1024-thread workgroup per CU
     const size_t lds = (sizeof(uint32_t) << S.kb_log2w) + 2 * WAVES * 64 * sizeof(uint32_t);
+    const int per_cu = 2 * lds <= 160 * 1024 ? 2 : 1;       // persistent: 1-2 workgroups of 1024 threads per CU
+    uint64_t grid = (n_wc + WAVES - 1) / WAVES;
+    if (grid > (uint64_t)n_cu * per_cu) grid = (uint64_t)n_cu * per_cu;
 #define MF_LAUNCH_EXACT(KW, CA) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&exact_kernel<KW, CA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, R, S, cand, thr, out_bits, hits_out); } while (0)

@@ -11,5 +11,6 @@ for l in sys.stdin:
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 run A=1
 run MF_DEBUG_SCREEN=1
-run MF_BLOOM_LOG2W=14
-run MF_STAGE2_LOG2W=12
+run MF_KBLOOM_LOG2W=15
+run MF_KBLOOM_LOG2W=13
+run MF_KBLOOM_LOG2W=12
