@@ -25,6 +25,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -100,35 +103,29 @@ static bool parse_i32(const std::string &s, int32_t &out)
     return true;
 }
 
-// str::parse::<f32>: [sign] (digits [. digits] | . digits) [(e|E) [sign] digits], or inf / infinity / nan;
-// no surrounding whitespace, no hex.  Value correctly rounded to binary32 (strtof does the same).
+// str::parse::<f32> as the shipped binary does it (goldens X14-X17): [sign] then exactly "inf" or
+// "NaN", or (digits [. digits] | . digits) [(e|E) [sign] digits]; no surrounding whitespace, no hex,
+// no "infinity"/"nan".  Value correctly rounded to binary32 (strtof does the same).
 static bool parse_f32(const std::string &s, float &out)
 {
     size_t i = 0, n = s.size();
-    if (i < n && (s[i] == '+' || s[i] == '-')) i++;
-    auto ieq = [&](const char *w) {
-        size_t L = strlen(w);
-        if (n - i != L) return false;
-        for (size_t j = 0; j < L; j++) if (tolower((unsigned char)s[i + j]) != w[j]) return false;
-        return true;
-    };
-    bool ok = false;
-    if (ieq("inf") || ieq("infinity") || ieq("nan")) ok = true;
-    else {
-        size_t j = i, nd = 0;
-        while (j < n && isdigit((unsigned char)s[j])) { j++; nd++; }
-        if (j < n && s[j] == '.') { j++; while (j < n && isdigit((unsigned char)s[j])) { j++; nd++; } }
-        if (nd > 0) {
-            if (j < n && (s[j] == 'e' || s[j] == 'E')) {
-                j++;
-                if (j < n && (s[j] == '+' || s[j] == '-')) j++;
-                size_t ne = 0;
-                while (j < n && isdigit((unsigned char)s[j])) { j++; ne++; }
-                ok = ne > 0 && j == n;
-            } else ok = j == n;
-        }
+    bool neg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+    const std::string body = s.substr(i);
+    if (body == "inf") { out = neg ? -INFINITY : INFINITY; return true; }
+    if (body == "NaN") { out = NAN; return true; }
+    size_t j = i, nd = 0;
+    while (j < n && isdigit((unsigned char)s[j])) { j++; nd++; }
+    if (j < n && s[j] == '.') { j++; while (j < n && isdigit((unsigned char)s[j])) { j++; nd++; } }
+    if (nd == 0) return false;
+    if (j < n && (s[j] == 'e' || s[j] == 'E')) {
+        j++;
+        if (j < n && (s[j] == '+' || s[j] == '-')) j++;
+        size_t ne = 0;
+        while (j < n && isdigit((unsigned char)s[j])) { j++; ne++; }
+        if (ne == 0) return false;
     }
-    if (!ok) return false;
+    if (j != n) return false;
     out = strtof(s.c_str(), nullptr);
     return true;
 }
@@ -138,6 +135,10 @@ static bool valid_utf8(const char *p, size_t n)
     const unsigned char *s = (const unsigned char *)p;
     size_t i = 0;
     while (i < n) {
+        if (i + 8 <= n) {                       // ASCII fast path, 8 bytes at a time
+            uint64_t v; memcpy(&v, s + i, 8);
+            if (!(v & 0x8080808080808080ULL)) { i += 8; continue; }
+        }
         unsigned char c = s[i];
         if (c < 0x80) { i++; continue; }
         int len; uint32_t cp, min;
@@ -153,28 +154,57 @@ static bool valid_utf8(const char *p, size_t n)
     return true;
 }
 
+// Clinger's fast path in binary32: a decimal with < 2^24 mantissa and <= 10 fractional digits is
+// float(m) / 10^f with both operands exact, so the single division rounds correctly -- the same
+// value Rust's (correctly rounded) parser and strtof produce.  Anything else goes to parse_f32.
+static bool parse_f32_fast(const char *p, size_t n, float &out)
+{
+    static const float P10[11] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+    uint32_t m = 0; size_t i = 0, nd = 0, frac = 0;
+    for (; i < n && p[i] >= '0' && p[i] <= '9'; i++, nd++) { if (m > 1677721) return false; m = m * 10 + (uint32_t)(p[i] - '0'); }
+    if (i < n && p[i] == '.') {
+        for (i++; i < n && p[i] >= '0' && p[i] <= '9'; i++, nd++, frac++) { if (m > 1677721) return false; m = m * 10 + (uint32_t)(p[i] - '0'); }
+    }
+    if (i != n || nd == 0 || frac > 10 || m >= (1u << 24)) return false;
+    out = (float)m / P10[frac];
+    return true;
+}
+
 // title.split_whitespace()[2].split('=')[1].parse::<f32>().unwrap()   (main.rs:86-91 / :120-124)
 static float header_depth(const char *t, size_t n)
 {
-    // Unicode White_Space for the ASCII range: \t \n \v \f \r space (non-ASCII spaces are not produced by MEGAHIT)
-    std::vector<std::pair<size_t, size_t>> tok;
-    size_t i = 0;
-    auto ws = [](unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); };
-    while (i < n) {
-        while (i < n && ws((unsigned char)t[i])) i++;
-        size_t b = i;
-        while (i < n && !ws((unsigned char)t[i])) i++;
-        if (i > b) tok.emplace_back(b, i - b);
-        if (tok.size() == 3) break;
+    // str::split_whitespace(): Unicode White_Space (the line is already known to be valid UTF-8)
+    auto ws_len = [&](size_t i) -> size_t {       // length of the white-space character at i, 0 if none
+        const unsigned char c = (unsigned char)t[i];
+        if (c < 0x80) return (c == ' ' || (c >= 9 && c <= 13)) ? 1 : 0;
+        if (c == 0xC2 && i + 1 < n && ((unsigned char)t[i + 1] == 0x85 || (unsigned char)t[i + 1] == 0xA0)) return 2;
+        if (i + 2 < n) {
+            const unsigned char d = (unsigned char)t[i + 1], e = (unsigned char)t[i + 2];
+            if (c == 0xE1 && d == 0x9A && e == 0x80) return 3;                                   // U+1680
+            if (c == 0xE2 && d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xA8 || e == 0xA9 || e == 0xAF)) return 3;   // U+2000-200A, 2028, 2029, 202F
+            if (c == 0xE2 && d == 0x81 && e == 0x9F) return 3;                                   // U+205F
+            if (c == 0xE3 && d == 0x80 && e == 0x80) return 3;                                   // U+3000
+        }
+        return 0;
+    };
+    size_t i = 0, ntok = 0, tb = 0, tl = 0;
+    while (i < n && ntok < 3) {
+        size_t l;
+        while (i < n && (l = ws_len(i)) > 0) i += l;
+        const size_t b = i;
+        while (i < n && ws_len(i) == 0) i++;
+        if (i > b) { ntok++; tb = b; tl = i - b; }
     }
-    if (tok.size() < 3) rust_panic("index out of bounds: the len is " + std::to_string(tok.size()) + " but the index is 2");
-    std::string f(t + tok[2].first, tok[2].second);
-    size_t e1 = f.find('=');
-    if (e1 == std::string::npos) rust_panic("index out of bounds: the len is 1 but the index is 1");
-    size_t e2 = f.find('=', e1 + 1);
-    std::string val = f.substr(e1 + 1, e2 == std::string::npos ? std::string::npos : e2 - e1 - 1);
+    if (ntok < 3) rust_panic("index out of bounds: the len is " + std::to_string(ntok) + " but the index is 2");
+    const char *f = t + tb;
+    const char *e1 = (const char *)memchr(f, '=', tl);
+    if (!e1) rust_panic("index out of bounds: the len is 1 but the index is 1");
+    const char *vb = e1 + 1;
+    const char *e2 = (const char *)memchr(vb, '=', (size_t)(f + tl - vb));
+    const size_t vl = (size_t)((e2 ? e2 : f + tl) - vb);
     float v;
-    if (!parse_f32(val, v)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseFloatError { kind: Invalid }");
+    if (parse_f32_fast(vb, vl, v)) return v;
+    if (!parse_f32(std::string(vb, vl), v)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseFloatError { kind: Invalid }");
     return v;
 }
 
@@ -185,6 +215,26 @@ static bool has_gz_ext(const std::string &path)
     std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
     size_t dot = name.rfind('.');
     return dot != std::string::npos && dot != 0 && name.substr(dot) == ".gz";
+}
+
+// Input bytes: plain files are mapped (no copy), .gz files are inflated into `owned`.
+struct Input { const char *p = nullptr; size_t n = 0; std::string owned; };
+
+static void read_all(const std::string &path, std::string &data);
+static void open_input(const std::string &path, Input &in)
+{
+    if (!has_gz_ext(path)) {
+        int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) rust_panic("Cannot open file " + path + "!");
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            close(fd);
+            if (m != MAP_FAILED) { in.p = (const char *)m; in.n = (size_t)st.st_size; return; }
+        } else close(fd);
+    }
+    read_all(path, in.owned);
+    in.p = in.owned.data(); in.n = in.owned.size();
 }
 
 static void read_all(const std::string &path, std::string &data)
@@ -205,7 +255,14 @@ static void read_all(const std::string &path, std::string &data)
     }
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) rust_panic("Cannot open file " + path + "!");
-    char buf[1 << 16]; size_t n;
+    struct stat st;
+    size_t have = 0;
+    if (fstat(fileno(f), &st) == 0 && st.st_size > 0) {      // regular file: one allocation, one read
+        data.resize((size_t)st.st_size);
+        have = fread(&data[0], 1, data.size(), f);
+        data.resize(have);
+    }
+    char buf[1 << 16]; size_t n;                              // pipes / files that grew
     while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
     fclose(f);
 }
@@ -217,18 +274,18 @@ struct Writer {
         gz = has_gz_ext(path);
         if (gz) { g = gzopen(path.c_str(), "wb6"); if (!g) rust_panic("Cannot open file " + path); }   // Compression::default() = level 6
         else { f = fopen(path.c_str(), "wb"); if (!f) rust_panic("Cannot open file " + path); }
-        buf.reserve(128 * 1024);
+        buf.reserve((1u << 20) + 65536);
     }
     void drain() { if (buf.empty()) return; if (gz) gzwrite(g, buf.data(), (unsigned)buf.size()); else fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
-    void line(const char *p, size_t n) { buf.append(p, n); buf.push_back('\n'); if (buf.size() >= 128 * 1024) drain(); }
+    void line(const char *p, size_t n) { buf.append(p, n); buf.push_back('\n'); if (buf.size() >= (1u << 20)) drain(); }
     void close() { drain(); if (gz && g) gzclose(g); if (f) fclose(f); g = nullptr; f = nullptr; }
 };
 
 struct Line { const char *p; size_t n; };
 // BufRead::lines(): split at '\n', drop one trailing '\r', final line may lack '\n', empty trailing piece not yielded
-static void split_lines(const std::string &data, std::vector<Line> &lines)
+static void split_lines(const Input &data, std::vector<Line> &lines)
 {
-    const char *p = data.data(), *end = p + data.size();
+    const char *p = data.p, *end = p + data.n;
     while (p < end) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         const char *le = nl ? nl : end;
@@ -284,30 +341,43 @@ static int contig_filter_main(int argc, char **argv)
             size_t c = v_l.find(',', b);
             std::string piece = v_l.substr(b, c == std::string::npos ? std::string::npos : c - b);
             uint64_t v;
-            if (!parse_usize(piece, v)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
-            lengths.push_back(v);
+            if (!piece.empty()) {                // clap's delimiter split drops empty pieces (golden X37)
+                if (!parse_usize(piece, v)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
+                lengths.push_back(v);
+            }
             if (c == std::string::npos) break;
             b = c + 1;
         }
     }
     if (lengths.size() != 2) { puts("Input length string not valid, please input INT,INT."); }
-    if (lengths.size() < 2) rust_panic("index out of bounds: the len is 1 but the index is 1");
+    if (lengths.size() < 2) rust_panic("index out of bounds: the len is " + std::to_string(lengths.size()) + " but the index is " + std::to_string(lengths.size()));
     const uint64_t min = lengths[0], max = lengths[1];
 
-    std::string data; read_all(v_i, data);       // main.rs:69
+    Input data; open_input(v_i, data);           // main.rs:69
     static Writer out; out.open(v_o);            // main.rs:70
     g_flush_on_panic = [] { out.close(); };
-    std::vector<Line> lines; split_lines(data, lines);
     uint64_t count = 0;
+    std::vector<Line> lines;
 
     if (!has_m) {
-        // main.rs:74-105
+        // main.rs:74-105 -- pairs of lines are taken straight off the buffer (lines().tuples())
         if (!has_d) rust_panic("called `Option::unwrap()` on a `None` value");
         int32_t depth;
         if (!parse_i32(v_d, depth)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
-        for (size_t i = 0; i + 1 < lines.size(); i += 2) {
-            const Line &t = lines[i], &s = lines[i + 1];
-            if (!valid_utf8(t.p, t.n) || !valid_utf8(s.p, s.n)) { out.close(); rust_panic("called `Result::unwrap()` on an `Err` value: Custom { kind: InvalidData, error: \"stream did not contain valid UTF-8\" }"); }
+        const char *p = data.p, *end = p + data.n;
+        auto next_line = [&](Line &l) -> bool {      // BufRead::lines(): split at LF, drop one trailing CR
+            if (p >= end) return false;
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? nl : end;
+            size_t n = (size_t)(le - p);
+            if (n && p[n - 1] == '\r') n--;
+            l = Line{p, n};
+            p = nl ? nl + 1 : end;
+            return true;
+        };
+        Line t, s;
+        while (next_line(t) && next_line(s)) {
+            if (!valid_utf8(t.p, t.n) || !valid_utf8(s.p, s.n)) rust_panic("called `Result::unwrap()` on an `Err` value: Custom { kind: InvalidData, error: \"stream did not contain valid UTF-8\" }");
             if (t.n == 0 || t.p[0] != '>') continue;
             if (depth != 0) {
                 const float seq_depth = header_depth(t.p, t.n);
@@ -320,6 +390,7 @@ static int contig_filter_main(int argc, char **argv)
         }
     } else {
         // main.rs:106-131
+        split_lines(data, lines);
         uint64_t max_count;
         if (!parse_usize(v_m, max_count)) rust_panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
         for (const Line &l : lines)

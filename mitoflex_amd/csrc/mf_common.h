@@ -21,7 +21,7 @@ namespace mf {
 constexpr uint64_t EMPTY64 = ~0ULL;
 constexpr uint32_t EMPTY32 = ~0u;
 
-// ---- hashing (identical on host, device and in the oracle) -----------------
+// ---- hashing (identical on host and device; restated by the test oracle) ----
 MF_HD uint64_t mix64(uint64_t x)
 {   // MurmurHash3 fmix64
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -60,7 +60,7 @@ MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u;
 MF_HD uint32_t kbloom_hash(uint32_t h) { return h * 0x9E3779B1u; }
 MF_HD uint32_t smer_hash(uint32_t smer) { uint32_t h = smer * 0xC2B2AE35u; return h ^ (h >> 15); }
 
-// ---- table sizing rules (must match oracle/kmer_bait_oracle.c) -------------
+// ---- table sizing rules (the test oracle restates the same rule) -----------
 MF_HD uint64_t table_slots_for(uint64_t n_windows)
 {
     uint64_t s = 1024;
