@@ -140,3 +140,110 @@ def test_fastq_files_match_oracle(mf, ol, bait_text, tmp_path, gz):
     assert reads.info.n_reads == R.n_reads == 3000
     t = ol.OracleTable(bait_text, 31)
     assert np.array_equal(mf.filter_reads(ks, reads, 1)[0], ol.filter_reads(t, R, 1)[0])
+
+
+# --------------------------------------------------------------------------- full-size properties
+FULL = 33_333_334          # BASELINE.json configs[1]: 5 Gbp of 150-base reads
+
+
+@pytest.fixture(scope="module")
+def full_set(mf, bait_text):
+    reads = mf.Reads.synth(FULL, 150, seed=20261003, bait_text=bait_text, keep_host=True)
+    yield reads
+    reads.close()
+
+
+@pytest.mark.parametrize("k", [31, 21, 41])
+def test_full_size_screened_equals_exhaustive(mf, ol, bait_text, full_set, k):
+    """At the benchmark's full size the oracle is too slow to run on everything, so: (1) the
+    screened pipeline and the brute-force exhaustive kernel must agree on every bit, (2) two runs
+    agree (determinism), (3) a 1.5 M-read window from the middle equals the oracle, (4) the number of
+    passing reads is what the generator planted (about 0.5 %)."""
+    ks = mf.KmerSet.from_text(bait_text, k)
+    b_s, _, st_s = mf.filter_reads(ks, full_set, 1, mf.MODE_SCREENED)
+    b_e, _, st_e = mf.filter_reads(ks, full_set, 1, mf.MODE_EXHAUSTIVE)
+    assert np.array_equal(b_s, b_e)
+    assert st_s.n_pass == st_e.n_pass == int(np.unpackbits(b_s.view(np.uint8)).sum())
+    b_s2, _, _ = mf.filter_reads(ks, full_set, 1, mf.MODE_SCREENED)
+    assert np.array_equal(b_s, b_s2)
+    assert 0.003 * FULL < st_s.n_pass < 0.007 * FULL
+    assert st_s.n_candidates >= st_s.n_pass and st_s.n_candidates < 0.02 * FULL
+    # oracle on a window of whole bitmap words in the middle of the set
+    first, count = 16_000_000, 1_500_000
+    assert first % 32 == 0
+    L = 150
+    # the window as its own packed set: re-base the stream at a word boundary (first*L*2 bits is a multiple of 32)
+    w0 = first * L // 16
+    words = full_set.host_words[w0: w0 + (count * L + 15) // 16 + 8]
+    npos = full_set.host_npos
+    npos = npos[(npos >= first * L) & (npos < (first + count) * L)] - np.uint64(first * L)
+    off = np.arange(count + 1, dtype=np.uint64) * L
+    R = ol.OracleReads.from_arrays(words, off, npos)
+    obits, _ = ol.filter_reads(ol.OracleTable(bait_text, k), R, 1, threads=os.cpu_count() or 1)
+    assert np.array_equal(b_s[first // 32: (first + count) // 32], obits[: count // 32])
+
+
+def test_full_size_thresholds_are_monotone(mf, bait_text, full_set):
+    """pass(T+1) is a subset of pass(T); exhaustive and screened agree for T = 3 too."""
+    ks = mf.KmerSet.from_text(bait_text, 31)
+    prev = None
+    for thr in (1, 3, 20, 121):
+        b, _, st = mf.filter_reads(ks, full_set, thr, mf.MODE_SCREENED)
+        if thr == 3:
+            assert np.array_equal(b, mf.filter_reads(ks, full_set, thr, mf.MODE_EXHAUSTIVE)[0])
+        if prev is not None:
+            assert not np.any(b & ~prev)
+        prev = b
+    assert st.n_pass == 0                      # a 150-base read has only 120 windows
+
+
+def test_shard_of_50gbp_config(mf, bait_text):
+    """BASELINE.json configs[3]: 50 Gbp over 8 GPUs = 41 666 667 reads per GPU; one such shard."""
+    n = 41_666_667
+    ks = mf.KmerSet.from_text(bait_text, 31)
+    reads = mf.Reads.synth(n, 150, seed=5, bait_text=bait_text)
+    b_s, _, st_s = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
+    b_e, _, st_e = mf.filter_reads(ks, reads, 1, mf.MODE_EXHAUSTIVE)
+    assert np.array_equal(b_s, b_e) and st_s.n_pass == st_e.n_pass and 0.003 * n < st_s.n_pass < 0.007 * n
+
+
+def test_ragged_two_million(mf, ol, bait_text):
+    """Variable-length reads (offsets path, binary search on positives) at a size that matters."""
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    lens = rng.integers(0, 260, size=n).astype(np.uint64)
+    lens[rng.integers(0, n, size=1000)] = 0
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    words = rng.integers(0, 2**32, size=(total + 15) // 16 + 8, dtype=np.uint32)
+    words[(total + 15) // 16:] = 0
+    # plant bait-derived reads: copy bait sequence over ~1 % of reads
+    from tests.util_data import bait_records
+    g = bait_records(bait_text)[0]
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    gb = np.array([code[c] for c in g], dtype=np.uint64)
+    big = words.view(np.uint32)
+    for r in rng.integers(0, n, size=20000):
+        L = int(lens[r])
+        if L < 40:
+            continue
+        p = int(rng.integers(0, len(g) - L))
+        b0 = int(off[r])
+        for j in range(L):
+            gi = b0 + j
+            sh = 2 * (gi & 15)
+            big[gi >> 4] = (int(big[gi >> 4]) & ~(3 << sh) | (int(gb[p + j]) << sh)) & 0xFFFFFFFF
+    npos = np.unique(rng.integers(0, total, size=3000)).astype(np.uint64)
+    for gi in npos:                                   # invalid bases are stored as 0
+        gi = int(gi); sh = 2 * (gi & 15)
+        big[gi >> 4] = int(big[gi >> 4]) & ~(3 << sh) & 0xFFFFFFFF
+    R = ol.OracleReads.from_arrays(words, off, npos)
+    obits, ohits = ol.filter_reads(ol.OracleTable(bait_text, 31), R, 1, threads=os.cpu_count() or 1)
+    ks = mf.KmerSet.from_text(bait_text, 31)
+    reads = mf.Reads.from_packed(words, off, npos)
+    assert reads.info.uniform_len == 0
+    for mode in (mf.MODE_SCREENED, mf.MODE_EXHAUSTIVE):
+        bits, hits, _ = mf.filter_reads(ks, reads, 1, mode, want_hits=True)
+        assert np.array_equal(hits, ohits)
+        assert np.array_equal(bits, obits)
+    assert int(np.unpackbits(obits.view(np.uint8)).sum()) > 10000
