@@ -313,7 +313,7 @@ static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_pa
     RCHK(hipMalloc(&r->d_has_n, r->bitmap_bytes));
     RCHK(hipMalloc(&r->d_cand, r->bitmap_bytes));
     RCHK(hipMalloc(&r->d_bits, r->bitmap_bytes));
-    RCHK(hipMalloc(&r->d_counters, 16));
+    RCHK(hipMalloc(&r->d_counters, EXACT_MAX_GRID * 16));
     RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
     RCHK(hipMemsetAsync(r->d_bits, 0, r->bitmap_bytes, st));
     ReadsView &V = r->v;
@@ -412,7 +412,7 @@ static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, i
                         hipStream_t st, hipEvent_t *ev)
 {
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
-    HIPCHK(hipMemsetAsync(r->d_counters, 0, 16, st));
+    HIPCHK(hipMemsetAsync(r->d_counters, 0, EXACT_MAX_GRID * 16, st));
     if (screened) HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (screened) HIPCHK(launch_screen(r->v, S, r->d_cand, n_cu, st));
@@ -445,11 +445,13 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, &ev[(size_t)i * 3]);
         if (rc) return rc;
     }
-    unsigned long long cnt[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(cnt, r->d_counters, 16, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> part(EXACT_MAX_GRID * 2, 0);
+    HIPCHK(hipMemcpyAsync(part.data(), r->d_counters, EXACT_MAX_GRID * 16, hipMemcpyDeviceToHost, st));
     if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits, ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
     if (hits_out && r->v.n_reads) HIPCHK(hipMemcpyAsync(hits_out, r->d_hits, r->v.n_reads * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    unsigned long long cnt[2] = {0, 0};
+    for (int i = 0; i < EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         float tot = 0, scr = 0, exa = 0, t;

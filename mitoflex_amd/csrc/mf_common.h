@@ -52,12 +52,12 @@ MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi)
 //   stage 2: classic Bloom filter over canonical s-mers, STAGE2_K probes
 //   stage 3: exact ordered s-mer table in global memory (L2 resident)
 MF_HD uint32_t bloom_hash(uint32_t smer) { return smer * 0x9E3779B1u; }
-MF_HD uint32_t bloom_bits(uint32_t h) { return h ^ (h >> 15); }          // low 20 bits pick the four bit positions
+MF_HD uint32_t bloom_bits(uint32_t h) { return h; }                      // low 20 bits pick the four bit positions, top bits the block
 constexpr int STAGE2_K = 4;
 MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }
 MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u; return (h ^ (h >> 16)) | 1u; }
 // k-mer bit table in front of the open-address table (exact kernel): h = 32-bit table hash of the key
-MF_HD uint32_t kbloom_hash(uint32_t h) { return h * 0x9E3779B1u; }
+MF_HD uint32_t kbloom_hash(uint32_t h) { return h; }   // fold32 output is already mixed: block from the top bits, bits from the low 20
 MF_HD uint32_t smer_hash(uint32_t smer) { uint32_t h = smer * 0xC2B2AE35u; return h ^ (h >> 15); }
 
 // ---- table sizing rules (the test oracle restates the same rule) -----------

@@ -80,6 +80,8 @@ __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int SCREEN_QD = 4;     // chunks whose positives are handled in one pass
+
 template <int SPW, int U>
 __global__ void __launch_bounds__(1024)
 screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t dbg)
@@ -101,90 +103,120 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
     const uint32_t blk_shift = 32 - (S.bloom_log2w - 2);
     const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
     const uint32_t smask = S.smask;
+    const uint64_t cstep = gridDim.x;
 
     u32x4 cur[U]; uint32_t curx[U];
-    uint64_t c = blockIdx.x;
-    if (c < n_chunks) {
+    if (blockIdx.x < n_chunks) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint64_t v = c * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
+            const uint64_t v = (uint64_t)blockIdx.x * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
             cur[u] = __builtin_nontemporal_load(&w4[v]);
             if (SPW == 2) curx[u] = R.words[4 * v + 4];
         }
     }
-    for (; c < n_chunks; c += gridDim.x) {
-        // prefetch the next chunk before touching this one
-        u32x4 nxt[U]; uint32_t nxtx[U];
-        const uint64_t cn = c + gridDim.x;
-        if (cn < n_chunks) {
+    // offset (bases, inside its chunk) of sample idx of this lane
+    auto off_of = [&](int idx) -> uint32_t {
+        const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
+        return ((((uint32_t)u * blockDim.x + threadIdx.x) * 4 + q) << 4) + (uint32_t)j * 8;
+    };
+
+    for (uint64_t cbase = blockIdx.x; cbase < n_chunks; cbase += SCREEN_QD * cstep) {
+        // ---- stage 1 over SCREEN_QD chunks; their positives are queued in registers
+        uint32_t qm[SCREEN_QD], qp[SCREEN_QD];
+#pragma unroll
+        for (int d = 0; d < SCREEN_QD; d++) {
+            qm[d] = 0; qp[d] = 0;
+            const uint64_t c = cbase + d * cstep;
+            if (c >= n_chunks) continue;                                   // uniform
+            // prefetch the next chunk before touching this one
+            u32x4 nxt[U]; uint32_t nxtx[U];
+            if (c + cstep < n_chunks) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint64_t v = (c + cstep) * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
+                    nxt[u] = __builtin_nontemporal_load(&w4[v]);
+                    if (SPW == 2) nxtx[u] = R.words[4 * v + 4];
+                }
+            }
+            uint32_t hitmask = 0;    // bit (u*4+q)*SPW+j
+            uint32_t pend = 0;       // s-mer of the newest stage-1 positive (kept by select: no runtime-indexed registers)
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint64_t v = cn * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
-                nxt[u] = __builtin_nontemporal_load(&w4[v]);
-                if (SPW == 2) nxtx[u] = R.words[4 * v + 4];
-            }
-        }
-        uint32_t hitmask = 0;    // bit (u*4+q)*SPW+j
-        uint32_t pend = 0;       // s-mer of the most recent stage-1 positive (kept by select: no runtime-indexed registers)
+                const uint32_t wv[5] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w, SPW == 2 ? curx[u] : 0u};
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t wv[5] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w, SPW == 2 ? curx[u] : 0u};
+                for (int q = 0; q < 4; q++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-#pragma unroll
-                for (int j = 0; j < SPW; j++) {
-                    const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
-                    const uint32_t h = bloom_hash(sm);
-                    const uint4 blk = s_tab4[h >> blk_shift];
-                    const uint32_t g = bloom_bits(h);
-                    // v_lshrrev uses only the low 5 bits of its shift operand
-                    const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
-                    const bool hit = t & 1u;
-                    hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
-                    pend = hit ? sm : pend;
+                    for (int j = 0; j < SPW; j++) {
+                        const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
+                        const uint32_t h = bloom_hash(sm);
+                        const uint4 blk = s_tab4[h >> blk_shift];
+                        const uint32_t g = bloom_bits(h);
+                        // v_lshrrev uses only the low 5 bits of its shift operand
+                        const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
+                        const bool hit = t & 1u;
+                        hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
+                        pend = hit ? sm : pend;
+                    }
                 }
             }
+            qm[d] = hitmask; qp[d] = pend;
+#pragma unroll
+            for (int u = 0; u < U; u++) { cur[u] = nxt[u]; if (SPW == 2) curx[u] = nxtx[u]; }
         }
-        if (dbg & 1) { if (hitmask == 0xFFFFFFFFu) cand[0] = pend; hitmask = 0; }   // timing experiment: no later stages
-        if (hitmask) {
-            // Read arithmetic for this chunk, done once on uniform values: the chunk's first base
-            // cb = rq * L + rrem.  A positive at 32-bit offset `off` inside the chunk then sits in
-            // read rq + (rrem + off) / L, a 32-bit division by multiplication.
-            const bool fast = R.len_magic32 != 0;
-            const uint64_t cb = c * chunk * 64;
-            uint64_t rq = 0; uint32_t rrem = 0;
-            if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
-            uint64_t last_r = ~0ULL;
-            bool first = true;
-            // offset (bases, inside the chunk) of sample idx of this lane
-            auto off_of = [&](int idx) -> uint32_t {
-                const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
-                return ((((uint32_t)u * blockDim.x + threadIdx.x) * 4 + q) << 4) + (uint32_t)j * 8;
-            };
-            while (hitmask) {
-                // the newest positive is still in `pend`; older ones are re-read from memory, but
-                // only if they are not in the read this lane has just marked
-                const int idx = first ? 31 - __clz(hitmask) : __ffs(hitmask) - 1;
-                hitmask &= ~(1u << idx);
-                const bool use_pend = first;
-                first = false;
-                const int j = idx % SPW;
-                const uint32_t off = off_of(idx);
-                const uint64_t g0 = cb + off;
-                uint64_t r = ~0ULL;
-                if (fast) {
-                    const uint32_t t = rrem + off;
-                    const uint32_t dq = __umulhi(t, R.len_magic32);
-                    const uint32_t offr = t - dq * R.uniform_len;
-                    if (offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases) continue;   // straddles two reads / padding
-                    r = rq + dq;
-                    if (r == last_r) continue;
-                }
+        if (dbg & 1) { if ((qm[0] & qm[1]) == 0xFFFFFFFFu) cand[0] = qp[0]; continue; }   // timing experiment: no later stages
+
+        // ---- later stages for the queued positives, one pass for all SCREEN_QD chunks
+        uint32_t any = 0;
+#pragma unroll
+        for (int d = 0; d < SCREEN_QD; d++) any |= qm[d];
+        if (!any) continue;
+        // Read arithmetic per chunk, done on uniform values: a chunk's first base cb = rq * L + rrem.
+        // A positive at 32-bit offset `off` inside the chunk then sits in read rq + (rrem + off) / L,
+        // a 32-bit division by multiplication.
+        const bool fast = R.len_magic32 != 0;
+        uint64_t rq[SCREEN_QD]; uint32_t rrem[SCREEN_QD];
+#pragma unroll
+        for (int d = 0; d < SCREEN_QD; d++) {
+            const uint64_t cb = (cbase + d * cstep) * chunk * 64;
+            rq[d] = fast ? __umul64hi(cb, R.len_magic) : 0;
+            rrem[d] = fast ? (uint32_t)(cb - rq[d] * R.uniform_len) : 0;
+        }
+        uint32_t fresh = (1u << SCREEN_QD) - 1;          // bit d: qp[d] still is the newest positive of slot d
+        uint64_t last_r = ~0ULL;
+        for (;;) {
+            // this lane's first slot with work left (selects, no runtime-indexed registers)
+            int d = SCREEN_QD - 1;
+#pragma unroll
+            for (int i = SCREEN_QD - 2; i >= 0; i--) d = qm[i] ? i : d;
+            uint32_t m = qm[SCREEN_QD - 1], pend = qp[SCREEN_QD - 1], rr = rrem[SCREEN_QD - 1]; uint64_t rqd = rq[SCREEN_QD - 1];
+#pragma unroll
+            for (int i = SCREEN_QD - 2; i >= 0; i--) { m = d == i ? qm[i] : m; pend = d == i ? qp[i] : pend; rr = d == i ? rrem[i] : rr; rqd = d == i ? rq[i] : rqd; }
+            if (!m) break;
+            const bool use_pend = (fresh >> d) & 1u;
+            fresh &= ~(1u << d);
+            // the newest positive of a slot is still in a register; older ones are re-read from
+            // memory, but only if they are not in the read this lane has just marked
+            const int idx = use_pend ? 31 - __clz(m) : __ffs(m) - 1;
+            m &= ~(1u << idx);
+            const uint64_t cb = (cbase + (uint64_t)d * cstep) * chunk * 64;
+            const uint32_t off = off_of(idx);
+            const uint64_t g0 = cb + off;
+            uint64_t r = ~0ULL;
+            bool go = true;
+            if (fast) {
+                const uint32_t t = rr + off;
+                const uint32_t dq = __umulhi(t, R.len_magic32);
+                const uint32_t offr = t - dq * R.uniform_len;
+                r = rqd + dq;
+                // straddles two reads / lies in the padding / same read as just marked
+                go = !(offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases || r == last_r);
+            }
+            if (go) {
                 uint32_t sm = pend;
                 if (!use_pend) {
                     const uint64_t wi = g0 >> 4;
                     sm = R.words[wi];
-                    if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * j) & smask;
+                    if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
                 }
                 // stage 2: canonical s-mer, STAGE2_K Bloom probes in LDS
                 const uint32_t rc = revcomp_s(sm, S.s);
@@ -196,24 +228,26 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
                     const uint32_t pos = (ha + (uint32_t)i * hb) >> st2_shift;
                     ok &= s_st2[pos >> 5] >> (pos & 31);
                 }
-                if (!(ok & 1u)) continue;
+                go = ok & 1u;
                 // stage 3 (large baits only): exact s-mer table in global memory
-                if (S.use_stab && !stab_contains(S, sm)) continue;
-                if (!fast) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) continue; }
-                // mark the read: no load, no returning atomic, so the streaming loads behind
-                // this never wait for it
-                atomicOr(&cand[r >> 5], 1u << (r & 31));
-                last_r = r;
-                // the positives a lane has left usually sit in the read it has just marked: if the
-                // lowest and the highest of them do, so does everything in between
-                if (fast && hitmask) {
-                    const uint32_t t_lo = rrem + off_of(__ffs(hitmask) - 1), t_hi = rrem + off_of(31 - __clz(hitmask));
-                    if (rq + __umulhi(t_lo, R.len_magic32) == r && rq + __umulhi(t_hi, R.len_magic32) == r) hitmask = 0;
+                if (go && S.use_stab) go = stab_contains(S, sm);
+                if (go && !fast) { r = read_holding(R, g0, (uint32_t)S.s); go = r != ~0ULL; }
+                if (go) {
+                    // mark the read: no load, no returning atomic, so the streaming loads behind
+                    // this never wait for it
+                    atomicOr(&cand[r >> 5], 1u << (r & 31));
+                    last_r = r;
+                    // the positives a slot has left usually sit in the read just marked: if the
+                    // lowest and the highest of them do, so does everything in between
+                    if (fast && m) {
+                        const uint32_t t_lo = rr + off_of(__ffs(m) - 1), t_hi = rr + off_of(31 - __clz(m));
+                        if (rqd + __umulhi(t_lo, R.len_magic32) == r && rqd + __umulhi(t_hi, R.len_magic32) == r) m = 0;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; u++) { cur[u] = nxt[u]; if (SPW == 2) curx[u] = nxtx[u]; }
+            for (int i = 0; i < SCREEN_QD; i++) qm[i] = d == i ? m : qm[i];
+        }
     }
 }
 
@@ -343,24 +377,38 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
     uint64_t x2 = 0;
     if (KW == 2) x2 = (uint64_t)a[NW - 2] | ((uint64_t)a[NW - 1] << 32);
 
-    // LDS stage: which of the ITEM_POS k-mers might be in the bait set
-    uint32_t pos_mask = 0;
-#pragma unroll
-    for (int i = 0; i < ITEM_POS; i++) {
-        uint64_t klo, khi = 0; uint32_t h;
+    // KW == 1: reverse-complement the whole 128-bit window once.  Base j of W is base 63 - j of
+    // RCW, so the reverse complement of the k-mer at position i starts at RCW base 64 - k - i;
+    // after dropping the first 64 - k - (ITEM_POS - 1) bases it is a funnel shift by 2*(ITEM_POS-1-i).
+    uint64_t r0 = 0, r1 = 0;
+    if (KW == 1) {
+        const uint64_t y0 = ~swap_pairs_rev64(x1), y1 = ~swap_pairs_rev64(x0);     // RCW = y1:y0
+        const int drop = 2 * (64 - k - (ITEM_POS - 1));                            // 2 .. 72 bits, uniform
+        if (drop >= 64) { r0 = y1 >> (drop - 64); r1 = 0; }
+        else { r0 = (y0 >> drop) | (y1 << (64 - drop)); r1 = y1 >> drop; }
+    }
+    // canonical key of position i of this item
+    auto key_at = [&](int i, uint64_t &klo, uint64_t &khi) -> uint32_t {
         if (KW == 1) {
             const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
-            const uint64_t rc = revcomp1(fwd, k);
-            klo = fwd < rc ? fwd : rc;
-            h = (uint32_t)hash_key1(klo);
+            const uint64_t rc = funnel64(r0, r1, 2 * (ITEM_POS - 1 - i)) & mask_lo;
+            klo = fwd < rc ? fwd : rc; khi = 0;
+            return (uint32_t)hash_key1(klo);
         } else {
             const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
             uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
             const bool f = (hi < rhi) || (hi == rhi && lo < rlo);
             klo = f ? lo : rlo; khi = f ? hi : rhi;
-            h = (uint32_t)hash_key2(klo, khi);
+            return (uint32_t)hash_key2(klo, khi);
         }
-        const uint32_t hb = kbloom_hash(h);
+    };
+
+    // LDS stage: which of the ITEM_POS k-mers might be in the bait set
+    uint32_t pos_mask = 0;
+#pragma unroll
+    for (int i = 0; i < ITEM_POS; i++) {
+        uint64_t klo, khi;
+        const uint32_t hb = kbloom_hash(key_at(i, klo, khi));
         const uint4 blk = s_kb4[hb >> kb_shift];
         const uint32_t g = bloom_bits(hb);
         const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
@@ -383,19 +431,8 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
         if (!COUNT_ALL && *reinterpret_cast<volatile uint32_t *>(cnt) >= thr) break;
         const int i = __ffs(pos_mask) - 1;
         pos_mask &= pos_mask - 1;
-        uint64_t klo, khi = 0; uint32_t h;
-        if (KW == 1) {
-            const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
-            const uint64_t rc = revcomp1(fwd, k);
-            klo = fwd < rc ? fwd : rc;
-            h = (uint32_t)hash_key1(klo);
-        } else {
-            const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
-            uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
-            const bool f = (hi < rhi) || (hi == rhi && lo < rlo);
-            klo = f ? lo : rlo; khi = f ? hi : rhi;
-            h = (uint32_t)hash_key2(klo, khi);
-        }
+        uint64_t klo, khi;
+        const uint32_t h = key_at(i, klo, khi);
         if (table_has<KW>(S, klo, khi, h)) atomicAdd(cnt, 1u);
     }
 }
@@ -411,50 +448,65 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint32_t w, uint32_t n)
     return pos;
 }
 
+constexpr int WC_PER_LANE = 4;                     // candidate-bitmap words per lane
+constexpr int WC_WORDS = 64 * WC_PER_LANE;         // ... per wave-chunk (8192 reads)
+
 template <int KW, bool COUNT_ALL>
 __global__ void __launch_bounds__(EXACT_BLOCK)
 exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint32_t thr,
-             uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out)
+             uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out, unsigned long long *__restrict__ partials)
 {
     extern __shared__ uint4 s_mem4[];
     constexpr int WAVES = EXACT_BLOCK / 64;
-    uint32_t *s_res = reinterpret_cast<uint32_t *>(s_mem4);                  // [WAVES][64]
-    uint32_t *s_cnt = s_res + WAVES * 64;                                    // [WAVES][64]
-    const uint4 *s_kb4 = s_mem4 + (2 * WAVES * 64) / 4;
+    uint32_t *s_res = reinterpret_cast<uint32_t *>(s_mem4);                  // [WAVES][WC_WORDS]
+    uint32_t *s_cnt = s_res + WAVES * WC_WORDS;                              // [WAVES][64]
+    constexpr int HEAD4 = (WAVES * WC_WORDS + WAVES * 64) / 4;
+    const uint4 *s_kb4 = s_mem4 + HEAD4;
     {
         const uint32_t nb4 = (1u << S.kb_log2w) >> 2;
         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.kbloom);
-        uint4 *dst = s_mem4 + (2 * WAVES * 64) / 4;
+        uint4 *dst = s_mem4 + HEAD4;
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
     const uint32_t kb_shift = 32 - (S.kb_log2w - 2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t *my_res = s_res + wid * 64, *my_cnt = s_cnt + wid * 64;
+    uint32_t *my_res = s_res + wid * WC_WORDS, *my_cnt = s_cnt + wid * 64;
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
-    const uint64_t n_wc = (n_bw + 63) >> 6;                                  // wave-chunks of 64 bitmap words
+    const uint64_t n_wc = (n_bw + WC_WORDS - 1) / WC_WORDS;
     const int k = S.k;
+    uint32_t tot_pass = 0, tot_cand = 0;
+
     const uint64_t wc_step = (uint64_t)gridDim.x * WAVES;
-    auto load_cw = [&](uint64_t wc) -> uint32_t {
-        const uint64_t wi = wc * 64 + lane;
-        return (wc < n_wc && wi < n_bw) ? (cand ? cand[wi] : 0xFFFFFFFFu) : 0u;
+    // a lane owns WC_PER_LANE consecutive bitmap words (the buffers are padded past n_bw)
+    auto load_cw = [&](uint64_t wc, uint32_t (&w)[WC_PER_LANE]) {
+        const uint64_t wi = wc * WC_WORDS + (uint64_t)lane * WC_PER_LANE;
+#pragma unroll
+        for (int j = 0; j < WC_PER_LANE; j++) w[j] = (wc < n_wc && wi + j < n_bw) ? (cand ? cand[wi + j] : 0xFFFFFFFFu) : 0u;
     };
-    uint32_t cw_next = load_cw((uint64_t)blockIdx.x * WAVES + wid);
+    uint32_t cw_next[WC_PER_LANE];
+    load_cw((uint64_t)blockIdx.x * WAVES + wid, cw_next);
     for (uint64_t wc = (uint64_t)blockIdx.x * WAVES + wid; wc < n_wc; wc += wc_step) {
-        const uint64_t wbase = wc * 64;
-        const uint64_t myw = wbase + lane;
-        uint32_t cw = cw_next;
-        cw_next = load_cw(wc + wc_step);                                     // next chunk's candidate word, a whole chunk early
-        if (myw < n_bw) {
-            const uint64_t rem = R.n_reads - myw * 32;
-            if (rem < 32) cw &= (1u << rem) - 1;
+        const uint64_t wbase = wc * WC_WORDS;
+        uint32_t cw[WC_PER_LANE], pre[WC_PER_LANE + 1];
+        pre[0] = 0;
+#pragma unroll
+        for (int j = 0; j < WC_PER_LANE; j++) {
+            cw[j] = cw_next[j];
+            const uint64_t wi = wbase + (uint64_t)lane * WC_PER_LANE + j;
+            if (wi < n_bw) { const uint64_t rem = R.n_reads - wi * 32; if (rem < 32) cw[j] &= (1u << rem) - 1; }
+            pre[j + 1] = pre[j] + __popc(cw[j]);
+            my_res[lane * WC_PER_LANE + j] = 0;
         }
-        my_res[lane] = 0;
+        load_cw(wc + wc_step, cw_next);                                      // next chunk's words, a whole chunk early
+        tot_cand += pre[WC_PER_LANE];
         // inclusive scan of the per-lane candidate counts
-        uint32_t incl = __popc(cw);
+        uint32_t incl = pre[WC_PER_LANE];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const uint32_t total = __shfl(incl, 63);
+        // word-internal prefix counts of a lane, packed 4 x 8 bit (each <= 128)
+        const uint32_t pre_packed = pre[1] | (pre[2] << 8) | (pre[3] << 16);
         for (uint32_t cbase = 0; cbase < total; cbase += 64) {
             // lane i decodes candidate cbase + i of this wave-chunk
             const uint32_t ncand = total - cbase < 64 ? total - cbase : 64;
@@ -464,9 +516,17 @@ exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint
 #pragma unroll
             for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; if (__shfl(incl, mid) > c) hi = mid; else lo = mid + 1; }
             const int src = lo;
-            const uint32_t w = __shfl(cw, src);
-            const uint32_t b = nth_set_bit(w, c - (__shfl(incl, src) - __popc(w)));
-            const uint64_t r = (wbase + src) * 32 + b;
+            const uint32_t sp = __shfl(pre_packed, src);
+            const uint32_t w0 = __shfl(cw[0], src), w1 = __shfl(cw[1], src), w2 = __shfl(cw[2], src), w3 = __shfl(cw[3], src);
+            const uint32_t tot_src = (sp >> 16 & 255u) + __popc(w3);
+            uint32_t n = c - (__shfl(incl, src) - tot_src);                  // ordinal inside lane src
+            const uint32_t p1 = sp & 255u, p2 = (sp >> 8) & 255u, p3 = (sp >> 16) & 255u;
+            const int j = n >= p3 ? 3 : n >= p2 ? 2 : n >= p1 ? 1 : 0;
+            const uint32_t w = j == 3 ? w3 : j == 2 ? w2 : j == 1 ? w1 : w0;
+            n -= j == 3 ? p3 : j == 2 ? p2 : j == 1 ? p1 : 0u;
+            const uint32_t b = nth_set_bit(w, n);
+            const uint32_t wslot = (uint32_t)src * WC_PER_LANE + j;
+            const uint64_t r = (wbase + wslot) * 32 + b;
             uint64_t b0 = 0; uint32_t np = 0, hasn = 0;
             if (active) {
                 uint64_t len;
@@ -500,35 +560,28 @@ exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint
             if (active) {
                 const uint32_t h = my_cnt[lane];
                 if (COUNT_ALL) hits_out[r] = h;
-                if (h >= thr) atomicOr(&my_res[src], 1u << b);
+                if (h >= thr) atomicOr(&my_res[wslot], 1u << b);
             }
         }
-        if (myw < n_bw) out_bits[myw] = my_res[lane];
-    }
-}
-
-// pass / candidate tallies: grid-stride popcount, one atomic pair per workgroup
-// (same-address atomics serialise at ~11 ns each, so never one per wave)
-__global__ void __launch_bounds__(1024)
-tally_kernel(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ cand, uint64_t n_bw,
-             unsigned long long *__restrict__ counters)
-{
-    __shared__ uint32_t s_p[16], s_c[16];
-    uint32_t p = 0, c = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bw; i += (uint64_t)gridDim.x * blockDim.x) {
-        p += __popc(bits[i]);
-        if (cand) c += __popc(cand[i]);
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { p += __shfl_down(p, o); c += __shfl_down(c, o); }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) { s_p[wid] = p; s_c[wid] = c; }
+        for (int j = 0; j < WC_PER_LANE; j++) {
+            const uint64_t wi = wbase + (uint64_t)lane * WC_PER_LANE + j;
+            const uint32_t res = my_res[lane * WC_PER_LANE + j];
+            if (wi < n_bw) out_bits[wi] = res;
+            tot_pass += __popc(res);
+        }
+    }
+    // pass / candidate tallies: one plain store pair per workgroup, summed by the host
+    // (same-address atomics serialise at ~11 ns each, and a separate tally kernel costs a launch)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tot_pass += __shfl_down(tot_pass, o); tot_cand += __shfl_down(tot_cand, o); }
+    __syncthreads();
+    if (lane == 0) { s_cnt[wid * 2] = tot_pass; s_cnt[wid * 2 + 1] = tot_cand; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tp = 0, tc = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { tp += s_p[w]; tc += s_c[w]; }
-        if (tp) atomicAdd(&counters[0], (unsigned long long)tp);
-        if (tc) atomicAdd(&counters[1], (unsigned long long)tc);
+        unsigned long long p = 0, c = 0;
+        for (int w = 0; w < WAVES; w++) { p += s_cnt[w * 2]; c += s_cnt[w * 2 + 1]; }
+        partials[2 * blockIdx.x] = p; partials[2 * blockIdx.x + 1] = c;
     }
 }
 
@@ -697,24 +750,23 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *can
 }
 
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, const uint32_t *cand, uint32_t thr, bool count_all,
-                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st)
+                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st)
 {
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
-    const uint64_t n_wc = (n_bw + 63) / 64;
+    const uint64_t n_wc = (n_bw + WC_WORDS - 1) / WC_WORDS;
     if (n_wc == 0) return hipSuccess;
     constexpr int WAVES = EXACT_BLOCK / 64;
-    const size_t lds = (sizeof(uint32_t) << S.kb_log2w) + 2 * WAVES * 64 * sizeof(uint32_t);
+    const size_t lds = (sizeof(uint32_t) << S.kb_log2w) + (WAVES * WC_WORDS + WAVES * 64) * sizeof(uint32_t);
     const int per_cu = 2 * lds <= 160 * 1024 ? 2 : 1;       // persistent: 1-2 workgroups of 1024 threads per CU
     uint64_t grid = (n_wc + WAVES - 1) / WAVES;
     if (grid > (uint64_t)n_cu * per_cu) grid = (uint64_t)n_cu * per_cu;
+    if (grid > EXACT_MAX_GRID) grid = EXACT_MAX_GRID;
 #define MF_LAUNCH_EXACT(KW, CA) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&exact_kernel<KW, CA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, R, S, cand, thr, out_bits, hits_out); } while (0)
+        hipLaunchKernelGGL((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
     if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true); else MF_LAUNCH_EXACT(1, false); }
     else           { if (count_all) MF_LAUNCH_EXACT(2, true); else MF_LAUNCH_EXACT(2, false); }
 #undef MF_LAUNCH_EXACT
-    uint64_t tg = (n_bw + 1023) / 1024; if (tg > 256) tg = 256;
-    hipLaunchKernelGGL(tally_kernel, dim3((unsigned)tg), dim3(1024), 0, st, out_bits, cand, n_bw, counters);
     return hipGetLastError();
 }
 

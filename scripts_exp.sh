@@ -8,9 +8,6 @@ for l in sys.stdin:
         d=json.loads(l); e=d['extra']; print('value %.3e  screen %.4f ms  exact %.4f ms  pass_ev %.4f  roofline %.3f  cand %d pass %d exh %.3e' % (d['value'], e['ms_screen_kernel'], e['ms_exact_kernel'], e['ms_pass_events'], d['roofline']['frac'], e['candidates'], e['passed'], e.get('exhaustive_reads_per_s',0)))
     else: print(l.rstrip())
 "; }
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 run A=1
 run MF_DEBUG_SCREEN=1
-run MF_KBLOOM_LOG2W=15
-run MF_KBLOOM_LOG2W=13
-run MF_KBLOOM_LOG2W=12
