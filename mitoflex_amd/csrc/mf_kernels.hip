@@ -80,9 +80,22 @@ __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SCREEN_QD = 4;     // chunks whose positives are handled in one pass
+// data >> (byte BYTE of amt): v_lshrrev_b32 uses the low five bits of its shift operand, and an
+// SDWA source selector picks the byte, so no separate extract is issued (dst_sel is DWORD, so
+// the partial-write forwarding hazard of SDWA destinations does not apply)
+template <int BYTE>
+__device__ __forceinline__ uint32_t lshr_by_byte(uint32_t amt, uint32_t data)
+{
+    uint32_t r;
+    if (BYTE == 0) return data >> (amt & 31u);
+    if (BYTE == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
+    if (BYTE == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
+    if (BYTE == 3) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
+    return r;
+}
 
-template <int SPW, int U>
+// SCREEN_QD = chunks whose positives are handled in one pass
+template <int SPW, int U, int SCREEN_QD>
 __global__ void __launch_bounds__(1024)
 screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t dbg)
 {
@@ -150,9 +163,8 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
                         const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                         const uint32_t h = bloom_hash(sm);
                         const uint4 blk = s_tab4[h >> blk_shift];
-                        const uint32_t g = bloom_bits(h);
-                        // v_lshrrev uses only the low 5 bits of its shift operand
-                        const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
+                        // one bit per dword, positions = stage1_pos(sm, h, 0..3)
+                        const uint32_t t = lshr_by_byte<0>(h, blk.x) & lshr_by_byte<1>(h, blk.y) & lshr_by_byte<2>(h, blk.z) & lshr_by_byte<3>(sm, blk.w);
                         const bool hit = t & 1u;
                         hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
                         pend = hit ? sm : pend;
@@ -537,24 +549,51 @@ exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint
                 hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
             }
             my_cnt[lane] = 0;
-            uint32_t maxpos = np;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(maxpos, o); maxpos = t > maxpos ? t : maxpos; }
             const uint32_t b0_lo = (uint32_t)b0, b0_hi = (uint32_t)(b0 >> 32);
-            // passes of up to 32 items (512 positions) per candidate
-            for (uint32_t pbase = 0; pbase < maxpos; pbase += 32 * ITEM_POS) {
-                const uint32_t nit = (maxpos - pbase + ITEM_POS - 1) / ITEM_POS;
-                int lg = 0; while (lg < 5 && (1u << lg) < nit) lg++;
-                const uint32_t n_items = ncand << lg;
-                for (uint32_t t0 = 0; t0 < n_items; t0 += 64) {
-                    const uint32_t t = t0 + lane;
-                    const int ci = (int)((t >> lg) & 63);
-                    const uint32_t it = t & ((1u << lg) - 1);
-                    const uint64_t cb0 = ((uint64_t)__shfl(b0_hi, ci) << 32) | __shfl(b0_lo, ci);
-                    const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
-                    const uint32_t p0 = pbase + it * ITEM_POS;
-                    if (t < n_items && p0 < cnp)
-                        item_hits<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
+            auto wave_max = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+                return v;
+            };
+            // Phase 0: the first EARLY_ITEMS items of every candidate.  Most bait reads reach the
+            // threshold there; phase 1 runs the remaining items only for the candidates that did not.
+            // (One loop body for both phases, so the item code is instantiated once.)
+            constexpr uint32_t EARLY_ITEMS = 2;
+            const uint32_t items_all = (wave_max(np) + ITEM_POS - 1) / ITEM_POS;
+            uint32_t it_lo = 0, it_hi = (COUNT_ALL || !cand || items_all <= EARLY_ITEMS) ? items_all : EARLY_ITEMS;
+            uint32_t nc = ncand, map = (uint32_t)lane;       // lane m of `map` = lane number of the m-th candidate to run
+            for (int phase = 0; phase < 2; phase++) {
+                if (phase == 1) {
+                    if (it_hi >= items_all) break;                          // everything ran in phase 0
+                    const bool need = active && my_cnt[lane] < thr && np > EARLY_ITEMS * ITEM_POS;
+                    const uint64_t nb = __ballot(need);
+                    nc = (uint32_t)__popcll(nb);
+                    if (!nc) break;
+                    // lane m receives the position of the m-th set bit of the ballot (select by halving)
+                    uint64_t rem = nb; uint32_t m = (uint32_t)lane, posn = 0;
+#pragma unroll
+                    for (int sft = 32; sft >= 1; sft >>= 1) {
+                        const uint32_t cnt_lo = (uint32_t)__popcll(rem & ((1ull << sft) - 1));
+                        if (m >= cnt_lo) { m -= cnt_lo; rem >>= sft; posn += sft; } else rem &= (1ull << sft) - 1;
+                    }
+                    map = posn;
+                    it_lo = EARLY_ITEMS;
+                    it_hi = (wave_max(need ? np : 0) + ITEM_POS - 1) / ITEM_POS;
+                }
+                for (uint32_t ib = it_lo; ib < it_hi; ib += 32) {           // passes of up to 32 items per candidate
+                    const uint32_t nit = it_hi - ib < 32 ? it_hi - ib : 32;
+                    int lg = 0; while (lg < 5 && (1u << lg) < nit) lg++;
+                    const uint32_t n_items = nc << lg;
+                    for (uint32_t t0 = 0; t0 < n_items; t0 += 64) {
+                        const uint32_t t = t0 + lane;
+                        const int ci = (int)__shfl(map, (int)((t >> lg) & 63)) & 63;
+                        const uint32_t it = ib + (t & ((1u << lg) - 1));
+                        const uint64_t cb0 = ((uint64_t)__shfl(b0_hi, ci) << 32) | __shfl(b0_lo, ci);
+                        const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
+                        const uint32_t p0 = it * ITEM_POS;
+                        if (t < n_items && it < it_hi && p0 < cnp)
+                            item_hits<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
+                    }
                 }
             }
             if (active) {
@@ -644,12 +683,9 @@ __global__ void materialize2_kernel(BaitView B, int k, const uint32_t *postab, u
 __device__ __forceinline__ void stage1_insert(uint32_t sm, uint32_t *bloom, uint32_t log2w)
 {
     const uint32_t h = bloom_hash(sm);
-    const uint32_t g = bloom_bits(h);
     uint32_t *blk = bloom + 4 * (size_t)(h >> (32 - (log2w - 2)));
-    atomicOr(&blk[0], 1u << (g & 31));
-    atomicOr(&blk[1], 1u << ((g >> 5) & 31));
-    atomicOr(&blk[2], 1u << ((g >> 10) & 31));
-    atomicOr(&blk[3], 1u << ((g >> 15) & 31));
+#pragma unroll
+    for (int i = 0; i < 4; i++) atomicOr(&blk[i], 1u << stage1_pos(sm, h, i));
 }
 
 __device__ __forceinline__ void stab_insert(uint32_t sm, uint32_t *stab, uint32_t stab_mask, uint32_t *has_ones)
@@ -728,23 +764,37 @@ __global__ void mark_has_n_kernel(ReadsView R, uint32_t *has_n)
 // =================================================================== launchers
 static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, hipStream_t st)
+template <int SPW, int U, int QD>
+static void launch_screen_variant(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, size_t lds, uint32_t dbg, hipStream_t st)
 {
-    static const uint32_t dbg = getenv("MF_DEBUG_SCREEN") ? (uint32_t)atoi(getenv("MF_DEBUG_SCREEN")) : 0u;
-    const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + (sizeof(uint32_t) << S.stage2_log2w);
     int blocks_per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (blocks_per_cu > 2) blocks_per_cu = 2;          // 2 x 1024 threads = 32 waves/CU
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    uint64_t n_chunks = R.n_vec / ((uint64_t)SCREEN_BLOCK * SCREEN_U);
+    const uint64_t n_chunks = R.n_vec / ((uint64_t)SCREEN_BLOCK * U);
     uint64_t grid = (uint64_t)n_cu * blocks_per_cu;
     if (grid > n_chunks) grid = n_chunks;
-    if (grid == 0) return hipSuccess;
+    if (grid == 0) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, U, QD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((screen_kernel<SPW, U, QD>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand, dbg);
+}
+
+hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, hipStream_t st)
+{
+    static const uint32_t dbg = getenv("MF_DEBUG_SCREEN") ? (uint32_t)atoi(getenv("MF_DEBUG_SCREEN")) : 0u;
+    static const int variant = getenv("MF_SCREEN_VARIANT") ? atoi(getenv("MF_SCREEN_VARIANT")) : 0;
+    const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + (sizeof(uint32_t) << S.stage2_log2w);
     if (S.stride == 16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<1, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((screen_kernel<1, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand, dbg);
+        switch (variant) {                               // tuning variants; 0 is the shipped one
+        case 1: launch_screen_variant<1, 4, 8>(R, S, cand, n_cu, lds, dbg, st); break;
+        default: launch_screen_variant<1, SCREEN_U, 4>(R, S, cand, n_cu, lds, dbg, st);
+        }
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<2, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((screen_kernel<2, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand, dbg);
+        switch (variant) {
+        case 1: launch_screen_variant<2, 2, 4>(R, S, cand, n_cu, lds, dbg, st); break;
+        case 2: launch_screen_variant<2, 2, 2>(R, S, cand, n_cu, lds, dbg, st); break;
+        case 3: launch_screen_variant<2, 4, 1>(R, S, cand, n_cu, lds, dbg, st); break;
+        default: launch_screen_variant<2, SCREEN_U, 4>(R, S, cand, n_cu, lds, dbg, st);
+        }
     }
     return hipGetLastError();
 }
