@@ -99,7 +99,7 @@ def main():
     screen_s = st.ms_screen / 1e3
     achieved = alg_bytes / screen_s / 1e9 if screen_s > 0 else 0.0
 
-    extra = {"ms_screen_kernel": round(st.ms_screen, 4), "ms_exact_kernel": round(st.ms_exact, 4),
+    extra = {"ms_screen_kernel": round(st.ms_screen, 4), "ms_mark_kernel": round(st.ms_mark, 4), "ms_exact_kernel": round(st.ms_exact, 4),
              "ms_pass_events": round(st.ms_total, 4), "candidates": int(st.n_candidates), "passed": int(st.n_pass),
              "reads_per_gpu": a.reads, "synth_seconds": round(t_gen, 2), "device": mf.device_name(dev)}
     if rank == 0 and not a.no_exhaustive:

@@ -77,7 +77,8 @@ typedef struct {
     uint64_t n_pass;
     uint64_t n_candidates;   /* reads handed to the exact kernel (screened mode) */
     float    ms_total;       /* hipEvent time, first launch -> last kernel end  */
-    float    ms_screen;      /* screen kernel only */
+    float    ms_screen;      /* screen kernel only (streams every packed byte once) */
+    float    ms_mark;        /* mark kernel: finishes the screen's positives, sets candidate bits */
     float    ms_exact;       /* exact kernel only */
     uint64_t algorithmic_bytes; /* ceil(2*bases/8) + ceil(n_reads/8): SURVEY.md 8d byte model */
 } mf_filter_stats_t;

@@ -270,6 +270,7 @@ struct mf_reads {
     ReadsView v{};
     uint32_t *d_words = nullptr; uint64_t *d_offsets = nullptr, *d_npos = nullptr;
     uint32_t *d_has_n = nullptr, *d_cand = nullptr, *d_bits = nullptr, *d_hits = nullptr;
+    void *d_recs = nullptr; uint32_t *d_rec_counts = nullptr;     // stage-1 positive records (screen -> mark)
     unsigned long long *d_counters = nullptr;
     size_t bitmap_bytes = 0;
 };
@@ -280,6 +281,7 @@ static void reads_release(mf_reads *r)
     if (hipSetDevice(r->device) == hipSuccess) {
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
         hipFree(r->d_cand); hipFree(r->d_bits); hipFree(r->d_hits); hipFree(r->d_counters);
+        hipFree(r->d_recs); hipFree(r->d_rec_counts);
     }
     delete r;
 }
@@ -322,6 +324,11 @@ static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_pa
     V.len_magic = uniform_len > 1 ? ~0ULL / uniform_len + 1 : 0;
     V.len_magic32 = (uniform_len > 1 && uniform_len <= 4096) ? 0xFFFFFFFFu / uniform_len + 1 : 0;
     V.npos = r->d_npos; V.n_npos = n_npos; V.has_n = r->d_has_n;
+    {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %
+        const uint64_t grid = screen_grid_for(V, ctx->n_cu), cap = screen_rec_cap_for(V, ctx->n_cu);
+        RCHK(hipMalloc(&r->d_recs, (grid * cap ? grid * cap : 1) * 16));
+        RCHK(hipMalloc(&r->d_rec_counts, (grid ? grid : 1) * 4));
+    }
     RCHK(launch_mark_has_n(V, r->d_has_n, st));
     RCHK(hipStreamSynchronize(st));
 #undef RCHK
@@ -407,7 +414,7 @@ int mf_reads_free(mf_reads *r) { reads_release(r); return MF_OK; }
 // ------------------------------------------------------------------- filter
 static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_bases + 7) / 8 + (V.n_reads + 7) / 8; }
 
-// enqueue one pass on `st`; ev[0..2] recorded before screen / between / after exact when non-null
+// enqueue one pass on `st`; events (when non-null): ev[0] before screen, ev[3] after screen, ev[1] after mark, ev[2] after exact
 static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, int n_cu,
                         hipStream_t st, hipEvent_t *ev)
 {
@@ -415,7 +422,9 @@ static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, i
     HIPCHK(hipMemsetAsync(r->d_counters, 0, EXACT_MAX_GRID * 16, st));
     if (screened) HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    if (screened) HIPCHK(launch_screen(r->v, S, r->d_cand, n_cu, st));
+    if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs, r->d_rec_counts, n_cu, st));
+    if (ev) HIPCHK(hipEventRecord(ev[3], st));
+    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs, r->d_rec_counts, r->d_cand, n_cu, st));
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st));
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
@@ -439,10 +448,10 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         if (!r->d_hits) HIPCHK(hipMalloc(&r->d_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4));
         HIPCHK(hipMemsetAsync(r->d_hits, 0, (r->v.n_reads ? r->v.n_reads : 1) * 4, st));
     }
-    std::vector<hipEvent_t> ev((size_t)steps * 3);
+    std::vector<hipEvent_t> ev((size_t)steps * 4);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int i = 0; i < steps; i++) {
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, &ev[(size_t)i * 3]);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, &ev[(size_t)i * 4]);
         if (rc) return rc;
     }
     std::vector<unsigned long long> part(EXACT_MAX_GRID * 2, 0);
@@ -454,15 +463,17 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     for (int i = 0; i < EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
     if (stats) {
         memset(stats, 0, sizeof *stats);
-        float tot = 0, scr = 0, exa = 0, t;
-        HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[(size_t)steps * 3 - 1]));
+        float tot = 0, scr = 0, mrk = 0, exa = 0, t;
+        HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[(size_t)steps * 4 - 2]));
         for (int i = 0; i < steps; i++) {
-            HIPCHK(hipEventElapsedTime(&t, ev[(size_t)i * 3], ev[(size_t)i * 3 + 1])); scr += t;
-            HIPCHK(hipEventElapsedTime(&t, ev[(size_t)i * 3 + 1], ev[(size_t)i * 3 + 2])); exa += t;
+            hipEvent_t *e = &ev[(size_t)i * 4];
+            HIPCHK(hipEventElapsedTime(&t, e[0], e[3])); scr += t;
+            HIPCHK(hipEventElapsedTime(&t, e[3], e[1])); mrk += t;
+            HIPCHK(hipEventElapsedTime(&t, e[1], e[2])); exa += t;
         }
         stats->n_reads = r->v.n_reads; stats->n_pass = cnt[0];
         stats->n_candidates = (mode == MF_MODE_SCREENED && T->view.s > 0) ? cnt[1] : r->v.n_reads;
-        stats->ms_total = tot / steps; stats->ms_screen = scr / steps; stats->ms_exact = exa / steps;
+        stats->ms_total = tot / steps; stats->ms_screen = scr / steps; stats->ms_mark = mrk / steps; stats->ms_exact = exa / steps;
         stats->algorithmic_bytes = algorithmic_bytes(r->v);
     }
     for (auto &e : ev) hipEventDestroy(e);

@@ -94,29 +94,32 @@ __device__ __forceinline__ uint32_t lshr_by_byte(uint32_t amt, uint32_t data)
     return r;
 }
 
-// SCREEN_QD = chunks whose positives are handled in one pass
-template <int SPW, int U, int SCREEN_QD>
+// A stage-1 positive record: everything mark_kernel needs to finish the job later.
+// One per (lane, chunk) that saw at least one positive.
+struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pend; };
+
+template <int SPW, int U>
 __global__ void __launch_bounds__(1024)
-screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t dbg)
+screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
+              uint32_t dbg)
 {
-    extern __shared__ uint4 s_tab4[];
-    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_tab4);
-    const uint32_t n1 = 1u << S.bloom_log2w;             // stage-1 words
+    extern __shared__ uint4 s_tab4[];                                       // stage-1 table, then the record counter
+    const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
+    uint32_t &s_nrec = *reinterpret_cast<uint32_t *>(s_tab4 + nb4);         // (all LDS in one array: the dynamic base stays 16-byte aligned)
     {
-        const uint32_t nb4 = (n1 + (1u << S.stage2_log2w)) >> 2;
         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
+        if (threadIdx.x == 0) s_nrec = 0;
     }
     __syncthreads();
-    const uint32_t *s_st2 = s_tab + n1;
 
     const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
     const uint64_t chunk = (uint64_t)blockDim.x * U;
     const uint64_t n_chunks = R.n_vec / chunk;          // n_vec is padded to a whole number of chunks
     const uint32_t blk_shift = 32 - (S.bloom_log2w - 2);
-    const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
     const uint32_t smask = S.smask;
     const uint64_t cstep = gridDim.x;
+    ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
 
     u32x4 cur[U]; uint32_t curx[U];
     if (blockIdx.x < n_chunks) {
@@ -127,138 +130,135 @@ screen_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t 
             if (SPW == 2) curx[u] = R.words[4 * v + 4];
         }
     }
-    // offset (bases, inside its chunk) of sample idx of this lane
-    auto off_of = [&](int idx) -> uint32_t {
-        const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
-        return ((((uint32_t)u * blockDim.x + threadIdx.x) * 4 + q) << 4) + (uint32_t)j * 8;
-    };
-
-    for (uint64_t cbase = blockIdx.x; cbase < n_chunks; cbase += SCREEN_QD * cstep) {
-        // ---- stage 1 over SCREEN_QD chunks; their positives are queued in registers
-        uint32_t qm[SCREEN_QD], qp[SCREEN_QD];
-#pragma unroll
-        for (int d = 0; d < SCREEN_QD; d++) {
-            qm[d] = 0; qp[d] = 0;
-            const uint64_t c = cbase + d * cstep;
-            if (c >= n_chunks) continue;                                   // uniform
-            // prefetch the next chunk before touching this one
-            u32x4 nxt[U]; uint32_t nxtx[U];
-            if (c + cstep < n_chunks) {
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint64_t v = (c + cstep) * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
-                    nxt[u] = __builtin_nontemporal_load(&w4[v]);
-                    if (SPW == 2) nxtx[u] = R.words[4 * v + 4];
-                }
-            }
-            uint32_t hitmask = 0;    // bit (u*4+q)*SPW+j
-            uint32_t pend = 0;       // s-mer of the newest stage-1 positive (kept by select: no runtime-indexed registers)
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += cstep) {
+        // prefetch the next chunk before touching this one
+        u32x4 nxt[U]; uint32_t nxtx[U];
+        if (c + cstep < n_chunks) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t wv[5] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w, SPW == 2 ? curx[u] : 0u};
+                const uint64_t v = (c + cstep) * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
+                nxt[u] = __builtin_nontemporal_load(&w4[v]);
+                if (SPW == 2) nxtx[u] = R.words[4 * v + 4];
+            }
+        }
+        uint32_t hitmask = 0;    // bit (u*4+q)*SPW+j
+        uint32_t pend = 0;       // s-mer of the newest stage-1 positive (kept by select: no runtime-indexed registers)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+        for (int u = 0; u < U; u++) {
+            const uint32_t wv[5] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w, SPW == 2 ? curx[u] : 0u};
 #pragma unroll
-                    for (int j = 0; j < SPW; j++) {
-                        const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
-                        const uint32_t h = bloom_hash(sm);
-                        const uint4 blk = s_tab4[h >> blk_shift];
-                        // one bit per dword, positions = stage1_pos(sm, h, 0..3)
-                        const uint32_t t = lshr_by_byte<0>(h, blk.x) & lshr_by_byte<1>(h, blk.y) & lshr_by_byte<2>(h, blk.z) & lshr_by_byte<3>(sm, blk.w);
-                        const bool hit = t & 1u;
-                        hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
-                        pend = hit ? sm : pend;
-                    }
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int j = 0; j < SPW; j++) {
+                    const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
+                    const uint32_t h = bloom_hash(sm);
+                    const uint4 blk = s_tab4[h >> blk_shift];
+                    // one bit per dword, positions = stage1_pos(sm, h, 0..3)
+                    const uint32_t t = lshr_by_byte<0>(h, blk.x) & lshr_by_byte<1>(h, blk.y) & lshr_by_byte<2>(h, blk.z) & lshr_by_byte<3>(sm, blk.w);
+                    const bool hit = t & 1u;
+                    hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
+                    pend = hit ? sm : pend;
                 }
             }
-            qm[d] = hitmask; qp[d] = pend;
-#pragma unroll
-            for (int u = 0; u < U; u++) { cur[u] = nxt[u]; if (SPW == 2) curx[u] = nxtx[u]; }
         }
-        if (dbg & 1) { if ((qm[0] & qm[1]) == 0xFFFFFFFFu) cand[0] = qp[0]; continue; }   // timing experiment: no later stages
+        // Positives (a few lanes per wave per chunk) are only RECORDED here: an LDS counter hands out
+        // the slot, one 16-byte store leaves the lane.  No dependent load, no returning global atomic,
+        // no division in the streaming loop -- mark_kernel finishes them afterwards.
+        if (hitmask && !(dbg & 1)) {
+            const uint32_t slot = atomicAdd(&s_nrec, 1u);
+            ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = hitmask; rec.pend = pend;
+            my_recs[slot] = rec;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { cur[u] = nxt[u]; if (SPW == 2) curx[u] = nxtx[u]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
+}
 
-        // ---- later stages for the queued positives, one pass for all SCREEN_QD chunks
-        uint32_t any = 0;
-#pragma unroll
-        for (int d = 0; d < SCREEN_QD; d++) any |= qm[d];
-        if (!any) continue;
-        // Read arithmetic per chunk, done on uniform values: a chunk's first base cb = rq * L + rrem.
-        // A positive at 32-bit offset `off` inside the chunk then sits in read rq + (rrem + off) / L,
-        // a 32-bit division by multiplication.
-        const bool fast = R.len_magic32 != 0;
-        uint64_t rq[SCREEN_QD]; uint32_t rrem[SCREEN_QD];
-#pragma unroll
-        for (int d = 0; d < SCREEN_QD; d++) {
-            const uint64_t cb = (cbase + d * cstep) * chunk * 64;
-            rq[d] = fast ? __umul64hi(cb, R.len_magic) : 0;
-            rrem[d] = fast ? (uint32_t)(cb - rq[d] * R.uniform_len) : 0;
-        }
-        uint32_t fresh = (1u << SCREEN_QD) - 1;          // bit d: qp[d] still is the newest positive of slot d
+// Finishes the screen: for every recorded positive, stage 2 (canonical s-mer, Bloom probes in LDS),
+// optional stage 3 (exact s-mer table, large baits), then the candidate bit of the read that holds
+// the s-mer.  Dense: one record per lane, a few hundred thousand records per 5 Gbp.
+template <int SPW, int U>
+__global__ void __launch_bounds__(1024)
+mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint32_t rec_cap, const uint32_t *__restrict__ rec_counts,
+            uint32_t screen_block, uint32_t *__restrict__ cand)
+{
+    extern __shared__ uint4 s_tab4[];
+    uint32_t *s_st2 = reinterpret_cast<uint32_t *>(s_tab4);
+    {
+        const uint32_t nb4 = (1u << S.stage2_log2w) >> 2;
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom + ((size_t)1 << S.bloom_log2w));
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
+    const uint32_t smask = S.smask;
+    const uint64_t chunk = (uint64_t)screen_block * U;
+    const bool fast = R.len_magic32 != 0;
+    const uint32_t n = rec_counts[blockIdx.x];
+    const ScreenRec *__restrict__ my = recs + (size_t)blockIdx.x * rec_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const ScreenRec rec = my[i];
+        // offset (bases, inside its chunk) of sample idx of the recording lane
+        auto off_of = [&](int idx) -> uint32_t {
+            const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
+            return ((((uint32_t)u * screen_block + rec.tid) * 4 + q) << 4) + (uint32_t)j * 8;
+        };
+        // Read arithmetic: the chunk's first base cb = rq * L + rrem; a positive at 32-bit offset `off`
+        // inside the chunk sits in read rq + (rrem + off) / L, a 32-bit division by multiplication.
+        const uint64_t cb = (uint64_t)rec.chunk * chunk * 64;
+        uint64_t rq = 0; uint32_t rrem = 0;
+        if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
+        uint32_t m = rec.hitmask;
         uint64_t last_r = ~0ULL;
-        for (;;) {
-            // this lane's first slot with work left (selects, no runtime-indexed registers)
-            int d = SCREEN_QD - 1;
-#pragma unroll
-            for (int i = SCREEN_QD - 2; i >= 0; i--) d = qm[i] ? i : d;
-            uint32_t m = qm[SCREEN_QD - 1], pend = qp[SCREEN_QD - 1], rr = rrem[SCREEN_QD - 1]; uint64_t rqd = rq[SCREEN_QD - 1];
-#pragma unroll
-            for (int i = SCREEN_QD - 2; i >= 0; i--) { m = d == i ? qm[i] : m; pend = d == i ? qp[i] : pend; rr = d == i ? rrem[i] : rr; rqd = d == i ? rq[i] : rqd; }
-            if (!m) break;
-            const bool use_pend = (fresh >> d) & 1u;
-            fresh &= ~(1u << d);
-            // the newest positive of a slot is still in a register; older ones are re-read from
-            // memory, but only if they are not in the read this lane has just marked
-            const int idx = use_pend ? 31 - __clz(m) : __ffs(m) - 1;
+        bool first = true;
+        while (m) {
+            // the newest positive travelled in the record; older ones are re-read from memory, but
+            // only if they are not in the read just marked
+            const int idx = first ? 31 - __clz(m) : __ffs(m) - 1;
             m &= ~(1u << idx);
-            const uint64_t cb = (cbase + (uint64_t)d * cstep) * chunk * 64;
+            const bool use_pend = first;
+            first = false;
             const uint32_t off = off_of(idx);
             const uint64_t g0 = cb + off;
             uint64_t r = ~0ULL;
-            bool go = true;
             if (fast) {
-                const uint32_t t = rr + off;
+                const uint32_t t = rrem + off;
                 const uint32_t dq = __umulhi(t, R.len_magic32);
                 const uint32_t offr = t - dq * R.uniform_len;
-                r = rqd + dq;
+                r = rq + dq;
                 // straddles two reads / lies in the padding / same read as just marked
-                go = !(offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases || r == last_r);
+                if (offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases || r == last_r) continue;
             }
-            if (go) {
-                uint32_t sm = pend;
-                if (!use_pend) {
-                    const uint64_t wi = g0 >> 4;
-                    sm = R.words[wi];
-                    if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
-                }
-                // stage 2: canonical s-mer, STAGE2_K Bloom probes in LDS
-                const uint32_t rc = revcomp_s(sm, S.s);
-                const uint32_t cn_ = sm < rc ? sm : rc;
-                const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
-                uint32_t ok = 1;
-#pragma unroll
-                for (int i = 0; i < STAGE2_K; i++) {
-                    const uint32_t pos = (ha + (uint32_t)i * hb) >> st2_shift;
-                    ok &= s_st2[pos >> 5] >> (pos & 31);
-                }
-                go = ok & 1u;
-                // stage 3 (large baits only): exact s-mer table in global memory
-                if (go && S.use_stab) go = stab_contains(S, sm);
-                if (go && !fast) { r = read_holding(R, g0, (uint32_t)S.s); go = r != ~0ULL; }
-                if (go) {
-                    // mark the read: no load, no returning atomic, so the streaming loads behind
-                    // this never wait for it
-                    atomicOr(&cand[r >> 5], 1u << (r & 31));
-                    last_r = r;
-                    // the positives a slot has left usually sit in the read just marked: if the
-                    // lowest and the highest of them do, so does everything in between
-                    if (fast && m) {
-                        const uint32_t t_lo = rr + off_of(__ffs(m) - 1), t_hi = rr + off_of(31 - __clz(m));
-                        if (rqd + __umulhi(t_lo, R.len_magic32) == r && rqd + __umulhi(t_hi, R.len_magic32) == r) m = 0;
-                    }
-                }
+            uint32_t sm = rec.pend;
+            if (!use_pend) {
+                const uint64_t wi = g0 >> 4;
+                sm = R.words[wi];
+                if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
             }
+            // stage 2: canonical s-mer, STAGE2_K Bloom probes in LDS
+            const uint32_t rc = revcomp_s(sm, S.s);
+            const uint32_t cn_ = sm < rc ? sm : rc;
+            const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
+            uint32_t ok = 1;
 #pragma unroll
-            for (int i = 0; i < SCREEN_QD; i++) qm[i] = d == i ? m : qm[i];
+            for (int p = 0; p < STAGE2_K; p++) {
+                const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
+                ok &= s_st2[pos >> 5] >> (pos & 31);
+            }
+            if (!(ok & 1u)) continue;
+            // stage 3 (large baits only): exact s-mer table in global memory
+            if (S.use_stab && !stab_contains(S, sm)) continue;
+            if (!fast) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) continue; }
+            atomicOr(&cand[r >> 5], 1u << (r & 31));
+            last_r = r;
+            // the positives a lane has left usually sit in the read just marked: if the lowest and
+            // the highest of them do, so does everything in between
+            if (fast && m) {
+                const uint32_t t_lo = rrem + off_of(__ffs(m) - 1), t_hi = rrem + off_of(31 - __clz(m));
+                if (rq + __umulhi(t_lo, R.len_magic32) == r && rq + __umulhi(t_hi, R.len_magic32) == r) m = 0;
+            }
         }
     }
 }
@@ -764,38 +764,56 @@ __global__ void mark_has_n_kernel(ReadsView R, uint32_t *has_n)
 // =================================================================== launchers
 static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-template <int SPW, int U, int QD>
-static void launch_screen_variant(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, size_t lds, uint32_t dbg, hipStream_t st)
+uint64_t screen_grid_for(const ReadsView &R, int n_cu)
 {
-    int blocks_per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-    if (blocks_per_cu > 2) blocks_per_cu = 2;          // 2 x 1024 threads = 32 waves/CU
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    const uint64_t n_chunks = R.n_vec / ((uint64_t)SCREEN_BLOCK * U);
-    uint64_t grid = (uint64_t)n_cu * blocks_per_cu;
-    if (grid > n_chunks) grid = n_chunks;
-    if (grid == 0) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, U, QD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((screen_kernel<SPW, U, QD>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, R, S, cand, dbg);
+    const uint64_t n_chunks = R.n_vec / ((uint64_t)SCREEN_BLOCK * SCREEN_U);
+    return n_chunks < (uint64_t)n_cu ? n_chunks : (uint64_t)n_cu;          // persistent: one 1024-thread workgroup per CU
+}
+uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu)
+{   // records one workgroup can emit: one per lane per chunk it walks
+    const uint64_t n_chunks = R.n_vec / ((uint64_t)SCREEN_BLOCK * SCREEN_U);
+    const uint64_t grid = screen_grid_for(R, n_cu);
+    return grid ? (n_chunks + grid - 1) / grid * SCREEN_BLOCK : 0;
 }
 
-hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, uint32_t *cand, int n_cu, hipStream_t st)
+template <int SPW>
+static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, uint32_t dbg, hipStream_t st)
+{
+    const uint64_t grid = screen_grid_for(R, n_cu);
+    if (grid == 0) return;
+    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
+    const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, R, S,
+                       static_cast<ScreenRec *>(recs), cap, rec_counts, dbg);
+}
+
+template <int SPW>
+static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
+                            hipStream_t st)
+{
+    const uint64_t grid = screen_grid_for(R, n_cu);
+    if (grid == 0) return;
+    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
+    const size_t lds2 = sizeof(uint32_t) << S.stage2_log2w;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mark_kernel<SPW, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(1024), lds2, st, R, S,
+                       static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand);
+}
+
+hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st)
 {
     static const uint32_t dbg = getenv("MF_DEBUG_SCREEN") ? (uint32_t)atoi(getenv("MF_DEBUG_SCREEN")) : 0u;
-    static const int variant = getenv("MF_SCREEN_VARIANT") ? atoi(getenv("MF_SCREEN_VARIANT")) : 0;
-    const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + (sizeof(uint32_t) << S.stage2_log2w);
-    if (S.stride == 16) {
-        switch (variant) {                               // tuning variants; 0 is the shipped one
-        case 1: launch_screen_variant<1, 4, 8>(R, S, cand, n_cu, lds, dbg, st); break;
-        default: launch_screen_variant<1, SCREEN_U, 4>(R, S, cand, n_cu, lds, dbg, st);
-        }
-    } else {
-        switch (variant) {
-        case 1: launch_screen_variant<2, 2, 4>(R, S, cand, n_cu, lds, dbg, st); break;
-        case 2: launch_screen_variant<2, 2, 2>(R, S, cand, n_cu, lds, dbg, st); break;
-        case 3: launch_screen_variant<2, 4, 1>(R, S, cand, n_cu, lds, dbg, st); break;
-        default: launch_screen_variant<2, SCREEN_U, 4>(R, S, cand, n_cu, lds, dbg, st);
-        }
-    }
+    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, dbg, st);
+    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, dbg, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
+                       hipStream_t st)
+{
+    if (S.stride == 16) launch_mark_spw<1>(R, S, recs, rec_counts, cand, n_cu, st);
+    else launch_mark_spw<2>(R, S, recs, rec_counts, cand, n_cu, st);
     return hipGetLastError();
 }
 

@@ -48,7 +48,7 @@ class ReadsInfo(C.Structure):
 
 class FilterStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_pass", C.c_uint64), ("n_candidates", C.c_uint64),
-                ("ms_total", C.c_float), ("ms_screen", C.c_float), ("ms_exact", C.c_float),
+                ("ms_total", C.c_float), ("ms_screen", C.c_float), ("ms_mark", C.c_float), ("ms_exact", C.c_float),
                 ("algorithmic_bytes", C.c_uint64)]
 
     def as_dict(self):
