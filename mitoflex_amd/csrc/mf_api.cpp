@@ -317,6 +317,8 @@ static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_pa
     RCHK(hipMalloc(&r->d_bits, r->bitmap_bytes));
     RCHK(hipMalloc(&r->d_counters, EXACT_MAX_GRID * 16));
     RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
+    RCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
+    RCHK(hipMemsetAsync(r->d_counters, 0, EXACT_MAX_GRID * 16, st));
     RCHK(hipMemsetAsync(r->d_bits, 0, r->bitmap_bytes, st));
     ReadsView &V = r->v;
     V.words = r->d_words; V.n_words = n_words; V.n_vec = (padded - 16) / 4;
@@ -419,8 +421,7 @@ static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, i
                         hipStream_t st, hipEvent_t *ev)
 {
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
-    HIPCHK(hipMemsetAsync(r->d_counters, 0, EXACT_MAX_GRID * 16, st));
-    if (screened) HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
+    // no per-pass memsets: the exact kernel clears the candidate words it consumes and zeroes unused tally slots
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs, r->d_rec_counts, n_cu, st));
     if (ev) HIPCHK(hipEventRecord(ev[3], st));

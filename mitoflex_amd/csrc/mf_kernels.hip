@@ -176,29 +176,29 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
 }
 
-// Finishes the screen: for every recorded positive, stage 2 (canonical s-mer, Bloom probes in LDS),
+// Finishes the screen: for every recorded positive, stage 2 (canonical s-mer, Bloom probes),
 // optional stage 3 (exact s-mer table, large baits), then the candidate bit of the read that holds
 // the s-mer.  Dense: one record per lane, a few hundred thousand records per 5 Gbp.
+constexpr int MARK_SPLIT = 8;       // mark workgroups per screen workgroup
+constexpr int MARK_BLOCK = 256;
+
 template <int SPW, int U>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(MARK_BLOCK)
 mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint32_t rec_cap, const uint32_t *__restrict__ rec_counts,
-            uint32_t screen_block, uint32_t *__restrict__ cand)
+            uint32_t screen_block, uint32_t *__restrict__ cand, uint32_t dbg)
 {
-    extern __shared__ uint4 s_tab4[];
-    uint32_t *s_st2 = reinterpret_cast<uint32_t *>(s_tab4);
-    {
-        const uint32_t nb4 = (1u << S.stage2_log2w) >> 2;
-        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom + ((size_t)1 << S.bloom_log2w));
-        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
-    }
-    __syncthreads();
+    // stage-2 table straight from global memory: <= 32 KiB, L2 resident, a few probes per record
+    const uint32_t *__restrict__ s_st2 = S.bloom + ((size_t)1 << S.bloom_log2w);
     const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
     const uint32_t smask = S.smask;
     const uint64_t chunk = (uint64_t)screen_block * U;
     const bool fast = R.len_magic32 != 0;
-    const uint32_t n = rec_counts[blockIdx.x];
-    const ScreenRec *__restrict__ my = recs + (size_t)blockIdx.x * rec_cap;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    // MARK_SPLIT workgroups share one screen workgroup's record list (records are few, the work per
+    // record is a chain of latencies: more lanes in flight, fewer records per lane)
+    const uint32_t list = blockIdx.x / MARK_SPLIT, part = blockIdx.x % MARK_SPLIT;
+    const uint32_t n = rec_counts[list];
+    const ScreenRec *__restrict__ my = recs + (size_t)list * rec_cap;
+    for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += MARK_SPLIT * blockDim.x) {
         const ScreenRec rec = my[i];
         // offset (bases, inside its chunk) of sample idx of the recording lane
         auto off_of = [&](int idx) -> uint32_t {
@@ -237,7 +237,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
                 sm = R.words[wi];
                 if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
             }
-            // stage 2: canonical s-mer, STAGE2_K Bloom probes in LDS
+            // stage 2: canonical s-mer, STAGE2_K Bloom probes
             const uint32_t rc = revcomp_s(sm, S.s);
             const uint32_t cn_ = sm < rc ? sm : rc;
             const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
@@ -251,8 +251,9 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
             // stage 3 (large baits only): exact s-mer table in global memory
             if (S.use_stab && !stab_contains(S, sm)) continue;
             if (!fast) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) continue; }
-            atomicOr(&cand[r >> 5], 1u << (r & 31));
+            if (!(dbg & 1)) atomicOr(&cand[r >> 5], 1u << (r & 31));
             last_r = r;
+            if (dbg & 2) break;
             // the positives a lane has left usually sit in the read just marked: if the lowest and
             // the highest of them do, so does everything in between
             if (fast && m) {
@@ -465,7 +466,7 @@ constexpr int WC_WORDS = 64 * WC_PER_LANE;         // ... per wave-chunk (8192 r
 
 template <int KW, bool COUNT_ALL>
 __global__ void __launch_bounds__(EXACT_BLOCK)
-exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint32_t thr,
+exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t thr,
              uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out, unsigned long long *__restrict__ partials)
 {
     extern __shared__ uint4 s_mem4[];
@@ -491,10 +492,15 @@ exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint
 
     const uint64_t wc_step = (uint64_t)gridDim.x * WAVES;
     // a lane owns WC_PER_LANE consecutive bitmap words (the buffers are padded past n_bw)
+    // (candidate words are cleared as they are consumed, so the next pass needs no memset)
     auto load_cw = [&](uint64_t wc, uint32_t (&w)[WC_PER_LANE]) {
         const uint64_t wi = wc * WC_WORDS + (uint64_t)lane * WC_PER_LANE;
 #pragma unroll
-        for (int j = 0; j < WC_PER_LANE; j++) w[j] = (wc < n_wc && wi + j < n_bw) ? (cand ? cand[wi + j] : 0xFFFFFFFFu) : 0u;
+        for (int j = 0; j < WC_PER_LANE; j++) {
+            const bool in = wc < n_wc && wi + j < n_bw;
+            w[j] = in ? (cand ? cand[wi + j] : 0xFFFFFFFFu) : 0u;
+            if (in && cand && w[j]) cand[wi + j] = 0;
+        }
     };
     uint32_t cw_next[WC_PER_LANE];
     load_cw((uint64_t)blockIdx.x * WAVES + wid, cw_next);
@@ -622,6 +628,9 @@ exact_kernel(ReadsView R, KmerSetView S, const uint32_t *__restrict__ cand, uint
         for (int w = 0; w < WAVES; w++) { p += s_cnt[w * 2]; c += s_cnt[w * 2 + 1]; }
         partials[2 * blockIdx.x] = p; partials[2 * blockIdx.x + 1] = c;
     }
+    // slots of workgroups that do not exist in this launch must read as zero (no per-pass memset)
+    if (blockIdx.x == 0)
+        for (uint32_t i = 2 * gridDim.x + threadIdx.x; i < 2 * EXACT_MAX_GRID; i += blockDim.x) partials[i] = 0;
 }
 
 // ----------------------------------------------------------- bait builders
@@ -794,11 +803,10 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 {
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
+    static const uint32_t dbg = getenv("MF_DEBUG_MARK") ? (uint32_t)atoi(getenv("MF_DEBUG_MARK")) : 0u;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
-    const size_t lds2 = sizeof(uint32_t) << S.stage2_log2w;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mark_kernel<SPW, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(1024), lds2, st, R, S,
-                       static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand);
+    hipLaunchKernelGGL((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * MARK_SPLIT), dim3(MARK_BLOCK), 0, st, R, S,
+                       static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand, dbg);
 }
 
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st)
@@ -817,7 +825,7 @@ hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *rec
     return hipGetLastError();
 }
 
-hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, const uint32_t *cand, uint32_t thr, bool count_all,
+hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st)
 {
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
