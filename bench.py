@@ -42,6 +42,22 @@ def parse():
     return ap.parse_args()
 
 
+def committed_traffic():
+    """HBM bytes per screen-kernel launch from the newest committed PMC profile (profiles/rNN/traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  PMC counters cannot be collected from inside this process, so this is the profiled value of the
+    same command, not a live reading; None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d["screen_kernel"]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -64,7 +80,7 @@ def main():
 
     from tests.util_data import make_bait
     bait = make_bait()
-    dev = local_rank
+    dev = local_rank % max(1, mf.device_count())      # one rank per GPU; wraps only when ranks outnumber GPUs (tests)
     ks = mf.KmerSet.from_text(bait, a.k, dev)
     want_cpu = rank == 0 and world == 1 and a.cpu_sample > 0
     t0 = time.time()
@@ -126,6 +142,9 @@ def main():
         nw = n // 32
         extra["sample_bits_match_oracle"] = bool(np.array_equal(gbits[:nw], obits[:nw]))
 
+    traffic, traffic_src = committed_traffic()
+    if a.reads != READS_5GBP or a.k != K:
+        traffic, traffic_src = None, None              # the profile was taken on the default workload
     if rank == 0:
         out = {
             "metric": "filtered reads/sec on 5 Gbp PE150 k=31; achieved HBM GB/s vs peak",
@@ -138,7 +157,7 @@ def main():
                                    "reads packed 2 bit/base and resident in HBM",
                        "sharding": f"{world} rank(s), one per GPU, independent shards of whole pairs, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "screen_kernel", "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_kernel_ms": st.ms_screen},
             "cpu_baseline": cpu,

@@ -1,13 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; K=""; for a in "$@"; do case $a in --k) K="--k";; [0-9]*) [ -n "$K" ] && K="--k $a";; esac; done; env $(for a in "$@"; do case $a in *=*) echo $a;; esac; done) timeout 300 python bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive $K 2>&1 | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); e=d['extra']; print('value %.3e  screen %.4f ms  mark %.4f  exact %.4f ms  pass_ev %.4f  roofline %.3f  cand %d pass %d' % (d['value'], e['ms_screen_kernel'], e['ms_mark_kernel'], e['ms_exact_kernel'], e['ms_pass_events'], d['roofline']['frac'], e['candidates'], e['passed']))
-    else: print(l.rstrip())
-"; }
-run A=1
-run MF_DEBUG_MARK=1
-run MF_DEBUG_MARK=2
-run MF_DEBUG_MARK=3
+echo "== 2 ranks on one GPU through torch.distributed.run (gloo rendezvous, library loaded before torch)"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 --reads 8000000 2>&1 | tail -3
+echo "== 1 rank through torch.distributed.run"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-sample 0 2>&1 | tail -2
