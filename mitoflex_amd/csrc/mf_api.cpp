@@ -6,6 +6,7 @@
 #include "mf_common.h"
 #include "mf_host.h"
 #include "mf_kernels.h"
+#include "mf_pipeline.h"
 #include "mf_synth.h"
 
 #include <hip/hip_runtime.h>
@@ -522,65 +523,25 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     if (n_devices > have) n_devices = have;
 
     const int hw = (int)std::thread::hardware_concurrency();
-    std::vector<char> b1, b2; std::string e1, e2; bool ok1 = true, ok2 = true;
-    {   // read both mates concurrently (inflate is the slow part for .gz)
-        std::thread t2; if (fq2) t2 = std::thread([&] { ok2 = slurp_file(fq2, b2, e2); });
-        ok1 = slurp_file(fq1, b1, e1);
-        if (fq2) t2.join();
-    }
-    if (!ok1) return fail(MF_E_IO, "%s", e1.c_str());
-    if (!ok2) return fail(MF_E_IO, "%s", e2.c_str());
-    std::vector<FqRec> r1, r2;
-    parse_fastq(b1.data(), b1.size(), r1);
-    if (fq2) parse_fastq(b2.data(), b2.size(), r2);
-    // PE records are zipped; the shorter file bounds the pair count (filter_bin main.rs:214)
-    const uint64_t n = fq2 ? (r1.size() < r2.size() ? r1.size() : r2.size()) : r1.size();
-    std::vector<uint8_t> keep(n ? n : 1, 0);
-
-    // contiguous chunks of whole pairs per device, one host thread each, no collective
-    std::vector<int> rcs(n_devices, MF_OK); std::vector<std::string> errs(n_devices);
-    auto worker = [&](int d) {
-        const uint64_t lo = n * d / n_devices, hi = n * (d + 1) / n_devices;
-        if (lo == hi) return;
-        const int nm = fq2 ? 2 : 1;
-        std::vector<uint32_t> bits[2];
-        for (int m = 0; m < nm; m++) {
-            const std::vector<FqRec> &rr = m ? r2 : r1;
-            PackedHost P; pack_records(rr.data() + lo, hi - lo, hw / n_devices > 0 ? hw / n_devices : 1, P);
-            mf_reads *R = nullptr;
-            int rc = reads_upload(P.words.data(), P.n_words, true, P.offsets.data(), hi - lo, P.offsets.back(), P.uniform_len,
-                                  P.npos.data(), P.npos.size(), d, &R);
-            if (rc) { rcs[d] = rc; errs[d] = t_err; return; }
-            bits[m].assign((hi - lo + 31) / 32, 0);
-            rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, bits[m].data(), nullptr, 1, nullptr);
-            reads_release(R);
-            if (rc) { rcs[d] = rc; errs[d] = t_err; return; }
-        }
-        for (uint64_t i = 0; i < hi - lo; i++) {
-            const int a = (bits[0][i >> 5] >> (i & 31)) & 1;
-            const int b = fq2 ? (bits[1][i >> 5] >> (i & 31)) & 1 : 0;
-            keep[lo + i] = (uint8_t)(fq2 ? (pair_mode == MF_PAIR_BOTH ? (a & b) : (a | b)) : a);
-        }
+    // pack threads: what is left after the readers, writers and device workers
+    int pack_threads = hw - 4 - n_devices; if (pack_threads < 1) pack_threads = 1; if (pack_threads > 32) pack_threads = 32;
+    const uint64_t batch_reads = env_u32("MF_BATCH_READS", 2000000);
+    BatchFilterFn fn = [ks, threshold](int device, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
+        bits.assign((n + 31) / 32 + 1, 0);
+        if (n == 0) return MF_OK;
+        mf_reads *R = nullptr;
+        int rc = reads_upload(P.words.data(), P.n_words, true, P.offsets.data(), n, P.offsets[n], P.uniform_len,
+                              P.npos.data(), P.npos.size(), device, &R);
+        if (rc == MF_OK) rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, bits.data(), nullptr, 1, nullptr);
+        if (R) reads_release(R);
+        if (rc != MF_OK) err = t_err;
+        return rc;
     };
-    {
-        std::vector<std::thread> th;
-        for (int d = 1; d < n_devices; d++) th.emplace_back(worker, d);
-        worker(0);
-        for (auto &t : th) t.join();
-    }
-    for (int d = 0; d < n_devices; d++) if (rcs[d]) return fail(rcs[d], "device %d: %s", d, errs[d].c_str());
-
-    uint64_t kc = 0; for (uint64_t i = 0; i < n; i++) kc += keep[i];
-    std::string we1, we2; bool wok1 = true, wok2 = true;
-    {
-        std::thread t2; if (fq2) t2 = std::thread([&] { wok2 = write_survivors(out2, r2.data(), n, keep.data(), we2); });
-        wok1 = write_survivors(out1, r1.data(), n, keep.data(), we1);
-        if (fq2) t2.join();
-    }
-    if (!wok1) return fail(MF_E_IO, "%s", we1.c_str());
-    if (!wok2) return fail(MF_E_IO, "%s", we2.c_str());
-    if (kept) *kept = kc;
-    if (total) *total = n;
+    PipelineStats ps; std::string perr;
+    const int rc = run_fastq_pipeline(fq1, fq2, out1, out2, pair_mode == MF_PAIR_BOTH, n_devices, pack_threads, batch_reads, fn, ps, perr);
+    if (rc != MF_OK) return fail(rc, "%s", perr.c_str());
+    if (kept) *kept = ps.kept;
+    if (total) *total = ps.total;
     return MF_OK;
 }
 

@@ -1,0 +1,235 @@
+#include "mf_pipeline.h"
+#include "../../include/mitofilter.h"
+
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
+#include <thread>
+#include <zlib.h>
+
+namespace mf {
+
+// -------------------------------------------------------------- bounded channel
+template <class T>
+class Channel {
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    bool push(T v)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_space_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return false;
+        q_.push_back(std::move(v));
+        cv_item_.notify_one();
+        return true;
+    }
+    bool pop(T &v)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_item_.wait(lk, [&] { return !q_.empty() || done_ || closed_; });
+        if (closed_ || q_.empty()) return false;
+        v = std::move(q_.front()); q_.pop_front();
+        cv_space_.notify_one();
+        return true;
+    }
+    void finish() { std::lock_guard<std::mutex> lk(mu_); done_ = true; cv_item_.notify_all(); }          // no more items
+    void abort() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_item_.notify_all(); cv_space_.notify_all(); }
+private:
+    std::mutex mu_; std::condition_variable cv_item_, cv_space_;
+    std::deque<T> q_; size_t cap_; bool done_ = false, closed_ = false;
+};
+
+// --------------------------------------------------------- batched FASTQ reader
+// Hands out batches of up to `max_records` complete 4-line records.  The reference's conventions
+// apply to the stream as a whole (filter/filter_bin/src/main.rs:287-321): a partial record at the
+// very end is dropped, CR before LF is stripped by the parser.
+struct MateBatch { std::vector<char> text; std::vector<FqRec> recs; };
+
+class BatchReader {
+public:
+    bool open(const char *path, std::string &err)
+    {
+        gz_ = has_gz_ext(path);
+        if (gz_) { g_ = gzopen(path, "rb"); if (g_) gzbuffer(g_, 1 << 20); }
+        else f_ = fopen(path, "rb");
+        if (!g_ && !f_) { err = std::string("Cannot open file ") + path; return false; }
+        path_ = path;
+        return true;
+    }
+    ~BatchReader() { if (g_) gzclose(g_); if (f_) fclose(f_); }
+    // false at end of stream (no records left) or on error (err set)
+    bool next(MateBatch &b, uint64_t max_records, std::string &err)
+    {
+        b.text.clear(); b.recs.clear();
+        b.text.swap(carry_);
+        size_t scanned = 0; uint64_t lines = 0; size_t cut = 0; bool have_cut = false;
+        const uint64_t want = 4 * max_records;
+        for (;;) {
+            // count newlines in what is new
+            const char *base = b.text.data();
+            while (scanned < b.text.size()) {
+                const char *nl = (const char *)memchr(base + scanned, '\n', b.text.size() - scanned);
+                if (!nl) { scanned = b.text.size(); break; }
+                scanned = (size_t)(nl - base) + 1;
+                if (++lines == want) { cut = scanned; have_cut = true; break; }
+            }
+            if (have_cut || eof_) break;
+            const size_t old = b.text.size(), blk = 16u << 20;
+            b.text.resize(old + blk);
+            size_t got;
+            if (gz_) { int n = gzread(g_, b.text.data() + old, (unsigned)blk); if (n < 0) { err = "gzip read error in " + path_; return false; } got = (size_t)n; }
+            else got = fread(b.text.data() + old, 1, blk, f_);
+            b.text.resize(old + got);
+            if (got == 0) eof_ = true;
+        }
+        if (have_cut) {                                   // keep the rest for the next batch
+            carry_.assign(b.text.begin() + cut, b.text.end());
+            b.text.resize(cut);
+        }
+        parse_fastq(b.text.data(), b.text.size(), b.recs);
+        return !b.recs.empty();
+    }
+private:
+    bool gz_ = false, eof_ = false; gzFile g_ = nullptr; FILE *f_ = nullptr; std::string path_;
+    std::vector<char> carry_;
+};
+
+struct PairBatch {
+    uint64_t index = 0, n = 0;
+    std::shared_ptr<MateBatch> mate[2];
+    PackedHost packed[2];
+    std::vector<uint8_t> keep;
+};
+using PairPtr = std::shared_ptr<PairBatch>;
+
+int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const char *out2, bool pair_both,
+                       int n_devices, int pack_threads, uint64_t batch_reads, const BatchFilterFn &filter,
+                       PipelineStats &stats, std::string &err)
+{
+    const int nm = fq2 ? 2 : 1;
+    const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
+    BatchReader rd[2];
+    for (int m = 0; m < nm; m++) if (!rd[m].open(in_path[m], err)) return MF_E_IO;
+    // create/truncate the outputs up front so that an empty input still leaves files behind
+    std::mutex err_mu; int rc = MF_OK;
+    auto set_err = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (rc == MF_OK) { rc = code; err = msg; } };
+
+    Channel<std::shared_ptr<MateBatch>> q_read[2] = {Channel<std::shared_ptr<MateBatch>>(2), Channel<std::shared_ptr<MateBatch>>(2)};
+    std::vector<std::unique_ptr<Channel<PairPtr>>> q_dev;
+    for (int d = 0; d < n_devices; d++) q_dev.emplace_back(new Channel<PairPtr>(2));
+    Channel<PairPtr> q_write[2] = {Channel<PairPtr>(4 * (size_t)n_devices + 4), Channel<PairPtr>(4 * (size_t)n_devices + 4)};
+    auto abort_all = [&] { for (auto &q : q_read) q.abort(); for (auto &q : q_dev) q->abort(); for (auto &q : q_write) q.abort(); };
+
+    // ---- readers
+    std::vector<std::thread> threads;
+    for (int m = 0; m < nm; m++)
+        threads.emplace_back([&, m] {
+            for (;;) {
+                auto b = std::make_shared<MateBatch>();
+                std::string e;
+                if (!rd[m].next(*b, batch_reads, e)) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
+                if (!q_read[m].push(b)) break;
+            }
+            q_read[m].finish();
+        });
+
+    // ---- zip mates, pack, deal to devices (whole pairs stay together)
+    threads.emplace_back([&] {
+        uint64_t idx = 0;
+        for (;;) {
+            auto pb = std::make_shared<PairBatch>();
+            bool ok = true;
+            for (int m = 0; m < nm; m++) ok = q_read[m].pop(pb->mate[m]) && ok;
+            if (!ok) break;                               // the shorter file bounds the pair count (zip semantics)
+            pb->n = pb->mate[0]->recs.size();
+            if (nm == 2 && pb->mate[1]->recs.size() < pb->n) pb->n = pb->mate[1]->recs.size();
+            pb->index = idx;
+            if (nm == 2) {
+                std::thread t([&] { pack_records(pb->mate[1]->recs.data(), pb->n, pack_threads > 1 ? pack_threads / 2 : 1, pb->packed[1]); });
+                pack_records(pb->mate[0]->recs.data(), pb->n, pack_threads > 1 ? pack_threads - pack_threads / 2 : 1, pb->packed[0]);
+                t.join();
+            } else pack_records(pb->mate[0]->recs.data(), pb->n, pack_threads, pb->packed[0]);
+            const bool last = nm == 2 && pb->mate[0]->recs.size() != pb->mate[1]->recs.size();
+            if (!q_dev[idx % n_devices]->push(pb)) break;
+            idx++;
+            if (last) break;                              // mate files of different length: stop at the shorter
+        }
+        for (auto &q : q_read) q.abort();                 // readers may still be producing past the end of the shorter file
+        for (auto &q : q_dev) q->finish();
+    });
+
+    // ---- one worker per device: H2D + kernels + D2H, then the pair rule
+    std::mutex stat_mu; int dev_alive = n_devices;
+    for (int d = 0; d < n_devices; d++)
+        threads.emplace_back([&, d] {
+            PairPtr pb;
+            while (q_dev[d]->pop(pb)) {
+                std::vector<uint32_t> bits[2];
+                bool ok = true;
+                for (int m = 0; m < nm && ok; m++) {
+                    std::string e;
+                    const int r = filter(d, pb->packed[m], pb->n, bits[m], e);
+                    if (r != MF_OK) { set_err(r, e); abort_all(); ok = false; }
+                    pb->packed[m] = PackedHost();          // release host copy early
+                }
+                if (!ok) break;
+                pb->keep.assign(pb->n ? pb->n : 1, 0);
+                uint64_t kc = 0;
+                for (uint64_t i = 0; i < pb->n; i++) {
+                    const int a = (bits[0][i >> 5] >> (i & 31)) & 1, b = nm == 2 ? (bits[1][i >> 5] >> (i & 31)) & 1 : 0;
+                    const uint8_t k = (uint8_t)(nm == 2 ? (pair_both ? (a & b) : (a | b)) : a);
+                    pb->keep[i] = k; kc += k;
+                }
+                { std::lock_guard<std::mutex> lk(stat_mu); stats.kept += kc; stats.total += pb->n; stats.batches++; }
+                for (int m = 0; m < nm; m++) if (!q_write[m].push(pb)) { ok = false; break; }
+                if (!ok) break;
+            }
+            std::lock_guard<std::mutex> lk(stat_mu);
+            if (--dev_alive == 0) for (int m = 0; m < nm; m++) q_write[m].finish();
+        });
+
+    // ---- ordered writers (devices may finish out of order)
+    for (int m = 0; m < nm; m++)
+        threads.emplace_back([&, m] {
+            const bool gz = has_gz_ext(out_path[m]);
+            gzFile g = nullptr; FILE *f = nullptr;
+            if (gz) { g = gzopen(out_path[m], "wb6"); if (g) gzbuffer(g, 1 << 20); } else f = fopen(out_path[m], "wb");
+            if (!g && !f) { set_err(MF_E_IO, std::string("Cannot open file ") + out_path[m]); abort_all(); return; }
+            std::map<uint64_t, PairPtr> pending; uint64_t next = 0; bool ok = true;
+            std::vector<char> buf; buf.reserve((1u << 22) + (1u << 16));
+            auto drain = [&] {
+                if (buf.empty()) return;
+                const bool w = gz ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size() : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+                if (!w) ok = false;
+                buf.clear();
+            };
+            PairPtr pb;
+            while (ok && q_write[m].pop(pb)) {
+                pending[pb->index] = pb;
+                while (ok && !pending.empty() && pending.begin()->first == next) {
+                    PairPtr cur = pending.begin()->second; pending.erase(pending.begin()); next++;
+                    const FqRec *recs = cur->mate[m]->recs.data();
+                    for (uint64_t i = 0; i < cur->n && ok; i++) {
+                        if (!cur->keep[i]) continue;
+                        const FqRec &r = recs[i];                 // header / seq / "+" / qual (filter_bin main.rs:261-268)
+                        buf.insert(buf.end(), r.h, r.h + r.hl); buf.push_back('\n');
+                        buf.insert(buf.end(), r.s, r.s + r.sl); buf.push_back('\n'); buf.push_back('+'); buf.push_back('\n');
+                        buf.insert(buf.end(), r.q, r.q + r.ql); buf.push_back('\n');
+                        if (buf.size() > (1u << 22)) drain();
+                    }
+                }
+            }
+            drain();
+            if (gz) ok = (gzclose(g) == Z_OK) && ok; else ok = (fclose(f) == 0) && ok;
+            if (!ok) { set_err(MF_E_IO, std::string("write error on ") + out_path[m]); abort_all(); }
+        });
+
+    for (auto &t : threads) t.join();
+    return rc;
+}
+
+} // namespace mf
