@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 #include <zlib.h>
@@ -46,8 +47,14 @@ private:
 // --------------------------------------------------------- batched FASTQ reader
 // Hands out batches of up to `max_records` complete 4-line records.  The reference's conventions
 // apply to the stream as a whole (filter/filter_bin/src/main.rs:287-321): a partial record at the
-// very end is dropped, CR before LF is stripped by the parser.
-struct MateBatch { std::vector<char> text; std::vector<FqRec> recs; };
+// very end is dropped, CR before LF is stripped.
+// text is a malloc'd buffer (no zero fill on growth); recs point into it
+struct MateBatch {
+    char *text = nullptr; size_t len = 0, cap = 0;
+    std::vector<FqRec> recs;
+    ~MateBatch() { free(text); }
+    bool reserve(size_t want) { if (want <= cap) return true; size_t nc = cap ? cap : (32u << 20); while (nc < want) nc *= 2; char *p = (char *)realloc(text, nc); if (!p) return false; text = p; cap = nc; return true; }
+};
 
 class BatchReader {
 public:
@@ -57,40 +64,53 @@ public:
         if (gz_) { g_ = gzopen(path, "rb"); if (g_) gzbuffer(g_, 1 << 20); }
         else f_ = fopen(path, "rb");
         if (!g_ && !f_) { err = std::string("Cannot open file ") + path; return false; }
+        if (f_) setvbuf(f_, nullptr, _IONBF, 0);             // we read in 16 MiB blocks ourselves
         path_ = path;
         return true;
     }
     ~BatchReader() { if (g_) gzclose(g_); if (f_) fclose(f_); }
+    // One pass: bytes are read in blocks and lines are cut as they arrive; every fourth line closes a
+    // record.  Record fields are kept as offsets while the buffer may still move, pointers afterwards.
     // false at end of stream (no records left) or on error (err set)
     bool next(MateBatch &b, uint64_t max_records, std::string &err)
     {
-        b.text.clear(); b.recs.clear();
-        b.text.swap(carry_);
-        size_t scanned = 0; uint64_t lines = 0; size_t cut = 0; bool have_cut = false;
-        const uint64_t want = 4 * max_records;
+        b.recs.clear(); b.len = 0;
+        if (!carry_.empty()) { if (!b.reserve(carry_.size())) { err = "out of memory"; return false; } memcpy(b.text, carry_.data(), carry_.size()); b.len = carry_.size(); carry_.clear(); }
+        struct Off { size_t h, s, q; uint32_t hl, sl, ql; };
+        std::vector<Off> off; off.reserve(max_records < (1u << 22) ? max_records : (1u << 22));
+        size_t pos = 0, line_start = 0; int li = 0; size_t ls[4]; uint32_t ll[4]; size_t cut = 0; bool full = false;
+        const size_t blk = 16u << 20;
         for (;;) {
-            // count newlines in what is new
-            const char *base = b.text.data();
-            while (scanned < b.text.size()) {
-                const char *nl = (const char *)memchr(base + scanned, '\n', b.text.size() - scanned);
-                if (!nl) { scanned = b.text.size(); break; }
-                scanned = (size_t)(nl - base) + 1;
-                if (++lines == want) { cut = scanned; have_cut = true; break; }
+            while (pos < b.len) {
+                const char *nl = (const char *)memchr(b.text + pos, '\n', b.len - pos);
+                if (!nl) { pos = b.len; break; }
+                size_t e = (size_t)(nl - b.text), L = e - line_start;
+                if (L && b.text[e - 1] == '\r') L--;          // lines() strips "\r\n"
+                ls[li] = line_start; ll[li] = (uint32_t)L;
+                line_start = pos = e + 1;
+                if (++li == 4) {
+                    li = 0;
+                    off.push_back(Off{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]});
+                    if (off.size() == max_records) { cut = pos; full = true; break; }
+                }
             }
-            if (have_cut || eof_) break;
-            const size_t old = b.text.size(), blk = 16u << 20;
-            b.text.resize(old + blk);
+            if (full || eof_) break;
+            if (!b.reserve(b.len + blk)) { err = "out of memory"; return false; }
             size_t got;
-            if (gz_) { int n = gzread(g_, b.text.data() + old, (unsigned)blk); if (n < 0) { err = "gzip read error in " + path_; return false; } got = (size_t)n; }
-            else got = fread(b.text.data() + old, 1, blk, f_);
-            b.text.resize(old + got);
+            if (gz_) { int n = gzread(g_, b.text + b.len, (unsigned)blk); if (n < 0) { err = "gzip read error in " + path_; return false; } got = (size_t)n; }
+            else got = fread(b.text + b.len, 1, blk, f_);
+            b.len += got;
             if (got == 0) eof_ = true;
         }
-        if (have_cut) {                                   // keep the rest for the next batch
-            carry_.assign(b.text.begin() + cut, b.text.end());
-            b.text.resize(cut);
+        if (full) { carry_.assign(b.text + cut, b.text + b.len); b.len = cut; }
+        else if (eof_ && li == 3 && line_start < b.len) {
+            // the stream ended inside the 4th line of a record without a final LF: lines() still yields it
+            size_t L = b.len - line_start; if (L && b.text[b.len - 1] == '\r') L--;
+            off.push_back(Off{ls[0], ls[1], line_start, ll[0], ll[1], (uint32_t)L});
         }
-        parse_fastq(b.text.data(), b.text.size(), b.recs);
+        b.recs.resize(off.size());
+        for (size_t i = 0; i < off.size(); i++)
+            b.recs[i] = FqRec{b.text + off[i].h, b.text + off[i].s, b.text + off[i].q, off[i].hl, off[i].sl, off[i].ql};
         return !b.recs.empty();
     }
 private:

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Fast synthetic PE FASTQ writer (fixed-width records, numpy): n pairs of L-base reads, a fraction
+sampled from the bait (both strands, substitutions), a few N.  Used for end-to-end timing only."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util_data import bait_records, make_bait  # noqa: E402
+
+
+def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = acgt[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
+    g = np.frombuffer(bait_seq.encode(), dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    is_mito = np.random.default_rng(seed // 10).random(n) < mito_frac          # same choice for both mates
+    idx = np.nonzero(is_mito)[0]
+    pos = rng.integers(0, len(g) - L, size=len(idx))
+    win = g[pos[:, None] + np.arange(L)[None, :]]
+    rc = rng.random(len(idx)) < 0.5
+    win[rc] = comp[win[rc][:, ::-1]]
+    sub = rng.random(win.shape) < sub_rate
+    win[sub] = acgt[rng.integers(0, 4, size=int(sub.sum()), dtype=np.uint8)]
+    seq[idx] = win
+    nmask = rng.random(n) < 0.01
+    seq[np.nonzero(nmask)[0], rng.integers(0, L, size=int(nmask.sum()))] = ord("N")
+    hdr = np.char.add(np.char.add("@syn.", np.char.zfill(np.arange(n).astype(str), 9)), "/%d" % mate).astype("S")
+    hl = hdr.dtype.itemsize
+    rec = np.empty((n, hl + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, :hl] = hdr.view(np.uint8).reshape(n, hl)
+    rec[:, hl] = 10
+    rec[:, hl + 1: hl + 1 + L] = seq
+    rec[:, hl + 1 + L: hl + 4 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, hl + 4 + L: hl + 4 + 2 * L] = rng.integers(ord("8"), ord("J"), size=(n, L), dtype=np.uint8)
+    rec[:, -1] = 10
+    rec.tofile(path)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("prefix"); ap.add_argument("--pairs", type=int, default=1_000_000); ap.add_argument("--len", type=int, default=150)
+    ap.add_argument("--mito", type=float, default=0.005); ap.add_argument("--seed", type=int, default=12340)
+    a = ap.parse_args()
+    bait = make_bait()
+    open(a.prefix + ".bait.fa", "w").write(bait)
+    g = bait_records(bait)[0]
+    for mate in (1, 2):
+        write_mate(f"{a.prefix}_{mate}.fq", a.pairs, a.len, a.seed + mate, mate, g, a.mito, 0.01)
