@@ -52,14 +52,16 @@ MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi)
 //   stage 2: classic Bloom filter over canonical s-mers, STAGE2_K probes
 //   stage 3: exact ordered s-mer table in global memory (L2 resident)
 MF_HD uint32_t bloom_hash(uint32_t smer) { return smer * 0x9E3779B1u; }
-// stage-1 bit positions inside the 128-bit block: the low five bits of bytes 0, 1, 2 of the hash
-// and of byte 3 of the s-mer itself (the hash's byte 3 already chose the block).  Byte fields let
-// the kernel shift by them with SDWA operands instead of extracting them first.
-MF_HD uint32_t stage1_pos(uint32_t smer, uint32_t h, int i)
+// stage-1 bit of dword i of the 128-bit block: 31 - field_i, where the fields are the low five
+// bits of bytes 0, 1, 2 of the hash and of byte 3 of the s-mer itself (the hash's byte 3 already
+// chose the block).  The kernel tests a bit by shifting the dword LEFT by field_i -- the bit lands in
+// the sign position -- with the field taken straight from its byte through an SDWA operand selector.
+MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i)
 {
     return i == 0 ? (h & 31u) : i == 1 ? ((h >> 8) & 31u) : i == 2 ? ((h >> 16) & 31u) : ((smer >> 24) & 31u);
 }
-MF_HD uint32_t bloom_bits(uint32_t h) { return h; }                      // low 20 bits pick the four bit positions, top bits the block
+MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
+MF_HD uint32_t bloom_bits(uint32_t h) { return h; }   // k-mer bit table (exact kernel): low 20 bits pick the four bit positions, top bits the block
 constexpr int STAGE2_K = 4;
 MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }
 MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u; return (h ^ (h >> 16)) | 1u; }

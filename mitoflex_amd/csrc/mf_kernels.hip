@@ -80,23 +80,24 @@ __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// data >> (byte BYTE of amt): v_lshrrev_b32 uses the low five bits of its shift operand, and an
-// SDWA source selector picks the byte, so no separate extract is issued (dst_sel is DWORD, so
-// the partial-write forwarding hazard of SDWA destinations does not apply)
+// data << (byte BYTE of amt): v_lshlrev_b32 uses the low five bits of its shift operand, and an
+// SDWA source selector picks the byte, so no separate extract is issued (dst_sel is DWORD, so the
+// partial-write forwarding hazard of SDWA destinations does not apply)
 template <int BYTE>
-__device__ __forceinline__ uint32_t lshr_by_byte(uint32_t amt, uint32_t data)
+__device__ __forceinline__ uint32_t lshl_by_byte(uint32_t amt, uint32_t data)
 {
     uint32_t r;
-    if (BYTE == 0) return data >> (amt & 31u);
-    if (BYTE == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
-    if (BYTE == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
-    if (BYTE == 3) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
+    if (BYTE == 0) return data << (amt & 31u);
+    if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
+    if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
+    if (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(amt), "v"(data));
     return r;
 }
 
 // A stage-1 positive record: everything mark_kernel needs to finish the job later.
-// One per (lane, chunk) that saw at least one positive.
-struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pend; };
+// One per (lane, chunk) that saw at least one positive.  Sample i of the lane's chunk slice
+// (i = (u*4+q)*SPW+j) is bit NS-1-i of hitmask, NS = U*4*SPW.
+struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pad; };
 
 template <int SPW, int U>
 __global__ void __launch_bounds__(1024)
@@ -121,31 +122,25 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     const uint64_t cstep = gridDim.x;
     ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
 
-    u32x4 cur[U]; uint32_t curx[U];
-    if (blockIdx.x < n_chunks) {
+    auto load = [&](uint64_t c, u32x4 (&d)[U], uint32_t (&x)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint64_t v = (uint64_t)blockIdx.x * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
-            cur[u] = __builtin_nontemporal_load(&w4[v]);
-            if (SPW == 2) curx[u] = R.words[4 * v + 4];
+            const uint64_t v = c * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
+            d[u] = __builtin_nontemporal_load(&w4[v]);
+            if (SPW == 2) x[u] = R.words[4 * v + 4];
         }
-    }
-    for (uint64_t c = blockIdx.x; c < n_chunks; c += cstep) {
-        // prefetch the next chunk before touching this one
-        u32x4 nxt[U]; uint32_t nxtx[U];
-        if (c + cstep < n_chunks) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint64_t v = (c + cstep) * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
-                nxt[u] = __builtin_nontemporal_load(&w4[v]);
-                if (SPW == 2) nxtx[u] = R.words[4 * v + 4];
-            }
-        }
-        uint32_t hitmask = 0;    // bit (u*4+q)*SPW+j
-        uint32_t pend = 0;       // s-mer of the newest stage-1 positive (kept by select: no runtime-indexed registers)
+    };
+    // Stage 1 on one chunk slice held in registers.  Per sample: one multiply (hash), one
+    // ds_read_b128 (the sample's 128-bit block), four left shifts that bring the tested bit of each
+    // dword into the sign position (shift amounts are bytes of the hash / s-mer, picked by SDWA
+    // selectors), two three-input ANDs, and one funnel shift that appends the sign bit to the hit
+    // mask.  Positives are only RECORDED (LDS counter -> slot, one 16-byte store): no dependent load,
+    // no returning global atomic, no division in the streaming loop -- mark_kernel finishes them.
+    auto stage1 = [&](uint64_t c, const u32x4 (&d)[U], const uint32_t (&x)[U]) {
+        uint32_t hitmask = 0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t wv[5] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w, SPW == 2 ? curx[u] : 0u};
+            const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
 #pragma unroll
@@ -153,24 +148,30 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                     const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
                     const uint4 blk = s_tab4[h >> blk_shift];
-                    // one bit per dword, positions = stage1_pos(sm, h, 0..3)
-                    const uint32_t t = lshr_by_byte<0>(h, blk.x) & lshr_by_byte<1>(h, blk.y) & lshr_by_byte<2>(h, blk.z) & lshr_by_byte<3>(sm, blk.w);
-                    const bool hit = t & 1u;
-                    hitmask |= hit ? (1u << ((u * 4 + q) * SPW + j)) : 0u;
-                    pend = hit ? sm : pend;
+                    const uint32_t t = lshl_by_byte<0>(h, blk.x) & lshl_by_byte<1>(h, blk.y) & lshl_by_byte<2>(h, blk.z) & lshl_by_byte<3>(sm, blk.w);
+                    hitmask = alignbit(hitmask, t, 31);             // (hitmask << 1) | sign(t)
                 }
             }
         }
-        // Positives (a few lanes per wave per chunk) are only RECORDED here: an LDS counter hands out
-        // the slot, one 16-byte store leaves the lane.  No dependent load, no returning global atomic,
-        // no division in the streaming loop -- mark_kernel finishes them afterwards.
         if (hitmask && !(dbg & 1)) {
             const uint32_t slot = atomicAdd(&s_nrec, 1u);
-            ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = hitmask; rec.pend = pend;
+            ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = hitmask; rec.pad = 0;
             my_recs[slot] = rec;
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) { cur[u] = nxt[u]; if (SPW == 2) curx[u] = nxtx[u]; }
+    };
+
+    // two register sets, ping-pong: the next chunk is in flight while this one is examined
+    u32x4 a[U], b[U]; uint32_t ax[U], bx[U];
+    uint64_t c = blockIdx.x;
+    if (c < n_chunks) load(c, a, ax);
+    while (c < n_chunks) {
+        if (c + cstep < n_chunks) load(c + cstep, b, bx);
+        stage1(c, a, ax);
+        c += cstep;
+        if (c >= n_chunks) break;
+        if (c + cstep < n_chunks) load(c + cstep, a, ax);
+        stage1(c, b, bx);
+        c += cstep;
     }
     __syncthreads();
     if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
@@ -201,6 +202,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
     for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += MARK_SPLIT * blockDim.x) {
         const ScreenRec rec = my[i];
         // offset (bases, inside its chunk) of sample idx of the recording lane
+        constexpr int NS = U * 4 * SPW;
         auto off_of = [&](int idx) -> uint32_t {
             const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
             return ((((uint32_t)u * screen_block + rec.tid) * 4 + q) << 4) + (uint32_t)j * 8;
@@ -210,16 +212,28 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
         const uint64_t cb = (uint64_t)rec.chunk * chunk * 64;
         uint64_t rq = 0; uint32_t rrem = 0;
         if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
-        uint32_t m = rec.hitmask;
+        uint32_t m = rec.hitmask;                     // sample idx <-> bit NS-1-idx
         uint64_t last_r = ~0ULL;
-        bool first = true;
+        // Two or more stage-1 positives of one lane inside one read: practically always a bait read
+        // (two independent false positives there have probability ~1e-4 per lane and chunk), so the
+        // read is marked without fetching the s-mer for stage 2.  Marking is only ever conservative --
+        // the exact kernel decides.
+        if (fast && (m & (m - 1)) && !(dbg & 16)) {
+            const uint32_t o_lo = off_of(NS - 1 - (31 - __clz(m))), o_hi = off_of(NS - 1 - (__ffs(m) - 1));
+            const uint32_t t_lo = rrem + o_lo, t_hi = rrem + o_hi;
+            const uint32_t q_lo = __umulhi(t_lo, R.len_magic32), q_hi = __umulhi(t_hi, R.len_magic32);
+            const uint32_t r_lo = t_lo - q_lo * R.uniform_len, r_hi = t_hi - q_hi * R.uniform_len;
+            if (q_lo == q_hi && r_lo + (uint32_t)S.s <= R.uniform_len && r_hi + (uint32_t)S.s <= R.uniform_len
+                && cb + o_hi + S.s <= R.total_bases) {
+                const uint64_t r = rq + q_lo;
+                if (!(dbg & 1)) atomicOr(&cand[r >> 5], 1u << (r & 31));
+                continue;
+            }
+        }
         while (m) {
-            // the newest positive travelled in the record; older ones are re-read from memory, but
-            // only if they are not in the read just marked
-            const int idx = first ? 31 - __clz(m) : __ffs(m) - 1;
-            m &= ~(1u << idx);
-            const bool use_pend = first;
-            first = false;
+            const int bit = 31 - __clz(m);
+            m &= ~(1u << bit);
+            const int idx = NS - 1 - bit;
             const uint32_t off = off_of(idx);
             const uint64_t g0 = cb + off;
             uint64_t r = ~0ULL;
@@ -231,12 +245,9 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
                 // straddles two reads / lies in the padding / same read as just marked
                 if (offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases || r == last_r) continue;
             }
-            uint32_t sm = rec.pend;
-            if (!use_pend) {
-                const uint64_t wi = g0 >> 4;
-                sm = R.words[wi];
-                if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
-            }
+            const uint64_t wi = g0 >> 4;
+            uint32_t sm = (dbg & 8) ? (uint32_t)wi * 2654435761u : R.words[wi];
+            if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
             // stage 2: canonical s-mer, STAGE2_K Bloom probes
             const uint32_t rc = revcomp_s(sm, S.s);
             const uint32_t cn_ = sm < rc ? sm : rc;
@@ -245,7 +256,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
 #pragma unroll
             for (int p = 0; p < STAGE2_K; p++) {
                 const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
-                ok &= s_st2[pos >> 5] >> (pos & 31);
+                if (!(dbg & 4)) ok &= s_st2[pos >> 5] >> (pos & 31);
             }
             if (!(ok & 1u)) continue;
             // stage 3 (large baits only): exact s-mer table in global memory
@@ -257,7 +268,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
             // the positives a lane has left usually sit in the read just marked: if the lowest and
             // the highest of them do, so does everything in between
             if (fast && m) {
-                const uint32_t t_lo = rrem + off_of(__ffs(m) - 1), t_hi = rrem + off_of(31 - __clz(m));
+                const uint32_t t_lo = rrem + off_of(NS - 1 - (31 - __clz(m))), t_hi = rrem + off_of(NS - 1 - (__ffs(m) - 1));
                 if (rq + __umulhi(t_lo, R.len_magic32) == r && rq + __umulhi(t_hi, R.len_magic32) == r) m = 0;
             }
         }
@@ -694,7 +705,7 @@ __device__ __forceinline__ void stage1_insert(uint32_t sm, uint32_t *bloom, uint
     const uint32_t h = bloom_hash(sm);
     uint32_t *blk = bloom + 4 * (size_t)(h >> (32 - (log2w - 2)));
 #pragma unroll
-    for (int i = 0; i < 4; i++) atomicOr(&blk[i], 1u << stage1_pos(sm, h, i));
+    for (int i = 0; i < 4; i++) atomicOr(&blk[i], 1u << stage1_bit(sm, h, i));
 }
 
 __device__ __forceinline__ void stab_insert(uint32_t sm, uint32_t *stab, uint32_t stab_mask, uint32_t *has_ones)

@@ -1,0 +1,52 @@
+// Micro-benchmark (not part of the product): best achievable HBM READ bandwidth on this MI355X for
+// a few streaming shapes, to know the real ceiling under the screen kernel.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT, bool CONTIG>
+__global__ void rd(const u32x4* __restrict__ p, uint64_t n_vec, uint32_t* out)
+{
+    const uint64_t chunk = (uint64_t)blockDim.x * U, n_chunks = n_vec / chunk;
+    uint32_t acc = 0;
+    uint64_t c0, c1, step;
+    if (CONTIG) { const uint64_t per = (n_chunks + gridDim.x - 1) / gridDim.x; c0 = blockIdx.x * per; c1 = c0 + per < n_chunks ? c0 + per : n_chunks; step = 1; }
+    else { c0 = blockIdx.x; c1 = n_chunks; step = gridDim.x; }
+    u32x4 cur[U];
+    if (c0 < c1) for (int u = 0; u < U; u++) { const u32x4* a = &p[c0 * chunk + (uint64_t)u * blockDim.x + threadIdx.x]; cur[u] = NT ? __builtin_nontemporal_load(a) : *a; }
+    for (uint64_t c = c0; c < c1; c += step) {
+        u32x4 nxt[U];
+        if (c + step < c1) for (int u = 0; u < U; u++) { const u32x4* a = &p[(c + step) * chunk + (uint64_t)u * blockDim.x + threadIdx.x]; nxt[u] = NT ? __builtin_nontemporal_load(a) : *a; }
+        for (int u = 0; u < U; u++) acc += cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+template <int U, bool NT, bool CONTIG>
+void run(const char* name, const u32x4* buf, uint64_t n_vec, uint32_t* out, int grid, int block)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9;
+    for (int r = 0; r < 6; r++) {
+        hipEventRecord(a); hipLaunchKernelGGL((rd<U, NT, CONTIG>), dim3(grid), dim3(block), 0, 0, buf, n_vec, out); hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    printf("%-44s grid %5d block %4d : %.4f ms  %.0f GB/s\n", name, grid, block, best, n_vec * 16.0 / best / 1e6);
+}
+int main()
+{
+    const uint64_t n_vec = 78125056 / 4096 * 4096;   // ~1.25 GB
+    u32x4* buf; uint32_t* out; hipMalloc(&buf, n_vec * 16); hipMemset(buf, 1, n_vec * 16); hipMalloc(&out, 64);
+    run<4, true, false>("U4 nt interleaved (screen kernel shape)", buf, n_vec, out, 256, 1024);
+    run<4, false, false>("U4 plain interleaved", buf, n_vec, out, 256, 1024);
+    run<4, true, true>("U4 nt contiguous per block", buf, n_vec, out, 256, 1024);
+    run<8, true, false>("U8 nt interleaved", buf, n_vec, out, 256, 1024);
+    run<2, true, false>("U2 nt interleaved", buf, n_vec, out, 256, 1024);
+    run<4, true, false>("U4 nt interleaved 2 WG/CU", buf, n_vec, out, 512, 1024);
+    run<4, true, false>("U4 nt interleaved 512-thr", buf, n_vec, out, 512, 512);
+    run<4, true, false>("U4 nt interleaved 256-thr x8/CU", buf, n_vec, out, 2048, 256);
+    run<8, true, false>("U8 nt 256-thr x8/CU", buf, n_vec, out, 2048, 256);
+    run<4, false, false>("U4 plain 256-thr x8/CU", buf, n_vec, out, 2048, 256);
+    run<1, true, false>("U1 nt 256-thr x16/CU", buf, n_vec, out, 4096, 256);
+    return 0;
+}
