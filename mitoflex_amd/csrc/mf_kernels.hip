@@ -148,7 +148,8 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                     const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
                     const uint4 blk = s_tab4[h >> blk_shift];
-                    const uint32_t t = lshl_by_byte<0>(h, blk.x) & lshl_by_byte<1>(h, blk.y) & lshl_by_byte<2>(h, blk.z) & lshl_by_byte<3>(sm, blk.w);
+                    const uint32_t g = alignbit(h, sm, 13);          // stage1_mix
+                    const uint32_t t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.y) & lshl_by_byte<2>(g, blk.z) & lshl_by_byte<3>(g, blk.w);
                     hitmask = alignbit(hitmask, t, 31);             // (hitmask << 1) | sign(t)
                 }
             }

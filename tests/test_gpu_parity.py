@@ -255,3 +255,25 @@ def test_ragged_two_million(mf, ol, bait_text):
         assert np.array_equal(hits, ohits)
         assert np.array_equal(bits, obits)
     assert int(np.unpackbits(obits.view(np.uint8)).sum()) > 10000
+
+
+def test_large_bait_uses_exact_smer_stage(mf, ol):
+    """A 300 kbp bait overfills the LDS tables, which switches stage 3 (exact s-mer table in global
+    memory) on; results must still be bit-exact."""
+    import random
+    rng = random.Random(77)
+    bait = ">big\n" + "".join(rng.choices("ACGT", k=300_000)) + "\n>second\n" + "".join(rng.choices("ACGT", k=50_000)) + "\n"
+    for k in (31, 25, 41):
+        ks = mf.KmerSet.from_text(bait, k)
+        info = ks.info
+        assert info.n_keys > 300_000 and info.n_smers > 600_000
+        t = ol.OracleTable(bait, k)
+        assert np.array_equal(ks.export_table(), t.keys)
+        seqs = make_reads(bait, 20000, seed=k, uniform=(k != 25))
+        R = ol.OracleReads.from_seqs(seqs)
+        reads = mf.Reads.from_packed(R.words, R.offsets, R.npos)
+        obits, ohits = ol.filter_reads(t, R, 1, threads=os.cpu_count() or 1)
+        for mode in (mf.MODE_SCREENED, mf.MODE_EXHAUSTIVE):
+            bits, hits, _ = mf.filter_reads(ks, reads, 1, mode, want_hits=True)
+            assert np.array_equal(hits, ohits), (k, mode)
+            assert np.array_equal(bits, obits), (k, mode)
