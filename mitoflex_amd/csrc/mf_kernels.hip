@@ -101,8 +101,7 @@ struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pa
 
 template <int SPW, int U>
 __global__ void __launch_bounds__(1024)
-screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
-              uint32_t dbg)
+screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts)
 {
     extern __shared__ uint4 s_tab4[];                                       // stage-1 table, then the record counter
     const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
@@ -154,7 +153,7 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                 }
             }
         }
-        if (hitmask && !(dbg & 1)) {
+        if (hitmask) {
             const uint32_t slot = atomicAdd(&s_nrec, 1u);
             ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = hitmask; rec.pad = 0;
             my_recs[slot] = rec;
@@ -187,7 +186,7 @@ constexpr int MARK_BLOCK = 256;
 template <int SPW, int U>
 __global__ void __launch_bounds__(MARK_BLOCK)
 mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint32_t rec_cap, const uint32_t *__restrict__ rec_counts,
-            uint32_t screen_block, uint32_t *__restrict__ cand, uint32_t dbg)
+            uint32_t screen_block, uint32_t *__restrict__ cand)
 {
     // stage-2 table straight from global memory: <= 32 KiB, L2 resident, a few probes per record
     const uint32_t *__restrict__ s_st2 = S.bloom + ((size_t)1 << S.bloom_log2w);
@@ -219,7 +218,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
         // (two independent false positives there have probability ~1e-4 per lane and chunk), so the
         // read is marked without fetching the s-mer for stage 2.  Marking is only ever conservative --
         // the exact kernel decides.
-        if (fast && (m & (m - 1)) && !(dbg & 16)) {
+        if (fast && (m & (m - 1))) {
             const uint32_t o_lo = off_of(NS - 1 - (31 - __clz(m))), o_hi = off_of(NS - 1 - (__ffs(m) - 1));
             const uint32_t t_lo = rrem + o_lo, t_hi = rrem + o_hi;
             const uint32_t q_lo = __umulhi(t_lo, R.len_magic32), q_hi = __umulhi(t_hi, R.len_magic32);
@@ -227,7 +226,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
             if (q_lo == q_hi && r_lo + (uint32_t)S.s <= R.uniform_len && r_hi + (uint32_t)S.s <= R.uniform_len
                 && cb + o_hi + S.s <= R.total_bases) {
                 const uint64_t r = rq + q_lo;
-                if (!(dbg & 1)) atomicOr(&cand[r >> 5], 1u << (r & 31));
+                atomicOr(&cand[r >> 5], 1u << (r & 31));
                 continue;
             }
         }
@@ -247,7 +246,7 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
                 if (offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases || r == last_r) continue;
             }
             const uint64_t wi = g0 >> 4;
-            uint32_t sm = (dbg & 8) ? (uint32_t)wi * 2654435761u : R.words[wi];
+            uint32_t sm = R.words[wi];
             if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
             // stage 2: canonical s-mer, STAGE2_K Bloom probes
             const uint32_t rc = revcomp_s(sm, S.s);
@@ -257,15 +256,14 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
 #pragma unroll
             for (int p = 0; p < STAGE2_K; p++) {
                 const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
-                if (!(dbg & 4)) ok &= s_st2[pos >> 5] >> (pos & 31);
+                ok &= s_st2[pos >> 5] >> (pos & 31);
             }
             if (!(ok & 1u)) continue;
             // stage 3 (large baits only): exact s-mer table in global memory
             if (S.use_stab && !stab_contains(S, sm)) continue;
             if (!fast) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) continue; }
-            if (!(dbg & 1)) atomicOr(&cand[r >> 5], 1u << (r & 31));
+            atomicOr(&cand[r >> 5], 1u << (r & 31));
             last_r = r;
-            if (dbg & 2) break;
             // the positives a lane has left usually sit in the read just marked: if the lowest and
             // the highest of them do, so does everything in between
             if (fast && m) {
@@ -473,6 +471,69 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint32_t w, uint32_t n)
     return pos;
 }
 
+// Up to 64 candidate reads, one per lane (`owner` lanes, which must be lanes 0..n-1; b0 = first base, np = k-mer positions,
+// hasn = holds an invalid base): deal their work items to the wave's lanes and leave each
+// candidate's verified hit count in my_cnt[its lane].
+// Phase 0 runs the first EARLY_ITEMS items of every candidate -- most bait reads reach the threshold
+// there; phase 1 runs the remaining items only for the candidates that did not.  (One loop body for
+// both phases, so the item code is instantiated once.)
+__device__ __forceinline__ uint32_t nth_set_lane(uint64_t ballot, uint32_t m)
+{   // position of the m-th (0-based) set bit of a 64-bit ballot (select by halving)
+    uint32_t posn = 0;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const uint32_t cnt_lo = (uint32_t)__popcll(ballot & ((1ull << sft) - 1));
+        if (m >= cnt_lo) { m -= cnt_lo; ballot >>= sft; posn += sft; } else ballot &= (1ull << sft) - 1;
+    }
+    return posn;
+}
+
+template <int KW, bool COUNT_ALL>
+__device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSetView &S, const uint4 *__restrict__ s_kb4, uint32_t kb_shift,
+                                               uint32_t thr, bool two_phase, int lane, bool owner, uint64_t b0, uint32_t np,
+                                               uint32_t hasn, uint32_t *my_cnt)
+{
+    my_cnt[lane] = 0;
+    const uint32_t b0_lo = (uint32_t)b0, b0_hi = (uint32_t)(b0 >> 32);
+    auto wave_max = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+        return v;
+    };
+    constexpr uint32_t EARLY_ITEMS = 2;
+    const uint32_t items_all = (wave_max(owner ? np : 0) + ITEM_POS - 1) / ITEM_POS;
+    uint32_t it_lo = 0, it_hi = (COUNT_ALL || !two_phase || items_all <= EARLY_ITEMS) ? items_all : EARLY_ITEMS;
+    uint64_t who = __ballot(owner);
+    for (int phase = 0; phase < 2; phase++) {
+        if (phase == 1) {
+            if (it_hi >= items_all) break;                          // everything ran in phase 0
+            const bool need = owner && my_cnt[lane] < thr && np > EARLY_ITEMS * ITEM_POS;
+            who = __ballot(need);
+            it_lo = EARLY_ITEMS;
+            it_hi = (wave_max(need ? np : 0) + ITEM_POS - 1) / ITEM_POS;
+        }
+        const uint32_t nc = (uint32_t)__popcll(who);
+        if (!nc) break;
+        // lane m of `map` = lane number of the m-th candidate to run (phase 0: the owners are lanes 0..nc-1)
+        const uint32_t map = phase == 0 ? (uint32_t)lane : nth_set_lane(who, (uint32_t)lane);
+        for (uint32_t ib = it_lo; ib < it_hi; ib += 32) {           // passes of up to 32 items per candidate
+            const uint32_t nit = it_hi - ib < 32 ? it_hi - ib : 32;
+            int lg = 0; while (lg < 5 && (1u << lg) < nit) lg++;
+            const uint32_t n_items = nc << lg;
+            for (uint32_t t0 = 0; t0 < n_items; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                const int ci = (int)__shfl(map, (int)((t >> lg) & 63)) & 63;
+                const uint32_t it = ib + (t & ((1u << lg) - 1));
+                const uint64_t cb0 = ((uint64_t)__shfl(b0_hi, ci) << 32) | __shfl(b0_lo, ci);
+                const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
+                const uint32_t p0 = it * ITEM_POS;
+                if (t < n_items && it < it_hi && p0 < cnp)
+                    item_hits<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
+            }
+        }
+    }
+}
+
 constexpr int WC_PER_LANE = 4;                     // candidate-bitmap words per lane
 constexpr int WC_WORDS = 64 * WC_PER_LANE;         // ... per wave-chunk (8192 reads)
 
@@ -566,54 +627,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
                 np = n_pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_pos;
                 hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
             }
-            my_cnt[lane] = 0;
-            const uint32_t b0_lo = (uint32_t)b0, b0_hi = (uint32_t)(b0 >> 32);
-            auto wave_max = [&](uint32_t v) -> uint32_t {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-                return v;
-            };
-            // Phase 0: the first EARLY_ITEMS items of every candidate.  Most bait reads reach the
-            // threshold there; phase 1 runs the remaining items only for the candidates that did not.
-            // (One loop body for both phases, so the item code is instantiated once.)
-            constexpr uint32_t EARLY_ITEMS = 2;
-            const uint32_t items_all = (wave_max(np) + ITEM_POS - 1) / ITEM_POS;
-            uint32_t it_lo = 0, it_hi = (COUNT_ALL || !cand || items_all <= EARLY_ITEMS) ? items_all : EARLY_ITEMS;
-            uint32_t nc = ncand, map = (uint32_t)lane;       // lane m of `map` = lane number of the m-th candidate to run
-            for (int phase = 0; phase < 2; phase++) {
-                if (phase == 1) {
-                    if (it_hi >= items_all) break;                          // everything ran in phase 0
-                    const bool need = active && my_cnt[lane] < thr && np > EARLY_ITEMS * ITEM_POS;
-                    const uint64_t nb = __ballot(need);
-                    nc = (uint32_t)__popcll(nb);
-                    if (!nc) break;
-                    // lane m receives the position of the m-th set bit of the ballot (select by halving)
-                    uint64_t rem = nb; uint32_t m = (uint32_t)lane, posn = 0;
-#pragma unroll
-                    for (int sft = 32; sft >= 1; sft >>= 1) {
-                        const uint32_t cnt_lo = (uint32_t)__popcll(rem & ((1ull << sft) - 1));
-                        if (m >= cnt_lo) { m -= cnt_lo; rem >>= sft; posn += sft; } else rem &= (1ull << sft) - 1;
-                    }
-                    map = posn;
-                    it_lo = EARLY_ITEMS;
-                    it_hi = (wave_max(need ? np : 0) + ITEM_POS - 1) / ITEM_POS;
-                }
-                for (uint32_t ib = it_lo; ib < it_hi; ib += 32) {           // passes of up to 32 items per candidate
-                    const uint32_t nit = it_hi - ib < 32 ? it_hi - ib : 32;
-                    int lg = 0; while (lg < 5 && (1u << lg) < nit) lg++;
-                    const uint32_t n_items = nc << lg;
-                    for (uint32_t t0 = 0; t0 < n_items; t0 += 64) {
-                        const uint32_t t = t0 + lane;
-                        const int ci = (int)__shfl(map, (int)((t >> lg) & 63)) & 63;
-                        const uint32_t it = ib + (t & ((1u << lg) - 1));
-                        const uint64_t cb0 = ((uint64_t)__shfl(b0_hi, ci) << 32) | __shfl(b0_lo, ci);
-                        const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
-                        const uint32_t p0 = it * ITEM_POS;
-                        if (t < n_items && it < it_hi && p0 < cnp)
-                            item_hits<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
-                    }
-                }
-            }
+            run_candidates<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, thr, cand != nullptr, lane, active, b0, np, hasn, my_cnt);
             if (active) {
                 const uint32_t h = my_cnt[lane];
                 if (COUNT_ALL) hits_out[r] = h;
@@ -798,7 +812,7 @@ uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu)
 }
 
 template <int SPW>
-static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, uint32_t dbg, hipStream_t st)
+static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st)
 {
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
@@ -806,7 +820,7 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, R, S,
-                       static_cast<ScreenRec *>(recs), cap, rec_counts, dbg);
+                       static_cast<ScreenRec *>(recs), cap, rec_counts);
 }
 
 template <int SPW>
@@ -815,17 +829,15 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 {
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
-    static const uint32_t dbg = getenv("MF_DEBUG_MARK") ? (uint32_t)atoi(getenv("MF_DEBUG_MARK")) : 0u;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
     hipLaunchKernelGGL((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * MARK_SPLIT), dim3(MARK_BLOCK), 0, st, R, S,
-                       static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand, dbg);
+                       static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand);
 }
 
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st)
 {
-    static const uint32_t dbg = getenv("MF_DEBUG_SCREEN") ? (uint32_t)atoi(getenv("MF_DEBUG_SCREEN")) : 0u;
-    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, dbg, st);
-    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, dbg, st);
+    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, st);
+    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, st);
     return hipGetLastError();
 }
 
