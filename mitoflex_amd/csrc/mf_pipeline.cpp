@@ -1,6 +1,8 @@
 #include "mf_pipeline.h"
 #include "../../include/mitofilter.h"
 
+#include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -9,6 +11,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <thread>
 #include <zlib.h>
 
@@ -49,9 +55,15 @@ private:
 // apply to the stream as a whole (filter/filter_bin/src/main.rs:287-321): a partial record at the
 // very end is dropped, CR before LF is stripped.
 // text is a malloc'd buffer (no zero fill on growth); recs point into it
+struct MappedFile {                       // a plain input file mapped read-only for the run
+    const char *p = nullptr; size_t n = 0;
+    ~MappedFile() { if (p) munmap(const_cast<char *>(p), n); }
+};
+
 struct MateBatch {
     char *text = nullptr; size_t len = 0, cap = 0;
     std::vector<FqRec> recs;
+    std::shared_ptr<MappedFile> map;      // set when recs point into a mapped file instead of `text`
     ~MateBatch() { free(text); }
     bool reserve(size_t want) { if (want <= cap) return true; size_t nc = cap ? cap : (32u << 20); while (nc < want) nc *= 2; char *p = (char *)realloc(text, nc); if (!p) return false; text = p; cap = nc; return true; }
 };
@@ -66,14 +78,26 @@ public:
         if (!g_ && !f_) { err = std::string("Cannot open file ") + path; return false; }
         if (f_) setvbuf(f_, nullptr, _IONBF, 0);             // we read in 16 MiB blocks ourselves
         path_ = path;
+        if (f_ && parse_threads_ > 1) {                      // regular plain file: map it and parse segments in parallel
+            struct stat st;
+            if (fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
+                if (m != MAP_FAILED) {
+                    map_ = std::make_shared<MappedFile>(); map_->p = (const char *)m; map_->n = (size_t)st.st_size;
+                    madvise(m, map_->n, MADV_SEQUENTIAL);
+                }
+            }
+        }
         return true;
     }
+    void set_parse_threads(int t) { parse_threads_ = t < 1 ? 1 : t; }
     ~BatchReader() { if (g_) gzclose(g_); if (f_) fclose(f_); }
     // One pass: bytes are read in blocks and lines are cut as they arrive; every fourth line closes a
     // record.  Record fields are kept as offsets while the buffer may still move, pointers afterwards.
     // false at end of stream (no records left) or on error (err set)
     bool next(MateBatch &b, uint64_t max_records, std::string &err)
     {
+        if (map_) return next_mapped(b, max_records);
         b.recs.clear(); b.len = 0;
         if (!carry_.empty()) { if (!b.reserve(carry_.size())) { err = "out of memory"; return false; } memcpy(b.text, carry_.data(), carry_.size()); b.len = carry_.size(); carry_.clear(); }
         struct Off { size_t h, s, q; uint32_t hl, sl, ql; };
@@ -114,8 +138,92 @@ public:
         return !b.recs.empty();
     }
 private:
+    // ---- mapped mode.  The file is cut into segments of SEG bytes.  Newlines are counted per segment
+    // in parallel; a prefix sum gives every segment the index of its first line, hence that line's
+    // position inside its 4-line record; then segments are parsed in parallel, each taking the
+    // records whose header line starts inside it (following a record across the segment border).
+    size_t SEG = getenv("MF_PARSE_SEG") ? (size_t)strtoull(getenv("MF_PARSE_SEG"), nullptr, 10) : (size_t)(32u << 20);   // bytes per parse segment
+    bool next_mapped(MateBatch &b, uint64_t max_records)
+    {
+        b.recs.clear(); b.map = map_;
+        while (b.recs.size() < max_records) {
+            if (grp_pos_ == grp_.size()) { if (!parse_next_group()) break; }
+            const size_t take = std::min<size_t>(max_records - b.recs.size(), grp_.size() - grp_pos_);
+            b.recs.insert(b.recs.end(), grp_.begin() + grp_pos_, grp_.begin() + grp_pos_ + take);
+            grp_pos_ += take;
+        }
+        return !b.recs.empty();
+    }
+    bool parse_next_group()
+    {
+        const char *p = map_->p; const size_t n = map_->n;
+        const size_t nseg = (n + SEG - 1) / SEG;
+        if (seg_lines_.empty()) {                           // once: newline counts per segment
+            seg_lines_.assign(nseg + 1, 0);
+            std::vector<uint64_t> cnt(nseg, 0);
+            parallel_for(nseg, [&](size_t i) {
+                const char *q = p + i * SEG, *e = p + std::min(n, (i + 1) * SEG); uint64_t c = 0;
+                while (q < e) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!nl) break; c++; q = nl + 1; }
+                cnt[i] = c;
+            });
+            for (size_t i = 0; i < nseg; i++) seg_lines_[i + 1] = seg_lines_[i] + cnt[i];
+        }
+        if (next_seg_ >= nseg) return false;
+        const size_t g0 = next_seg_, g1 = std::min(nseg, g0 + (size_t)parse_threads_);
+        std::vector<std::vector<FqRec>> out(g1 - g0);
+        parallel_for(g1 - g0, [&](size_t gi) {
+            const size_t i = g0 + gi, off = i * SEG, end = std::min(n, off + SEG);
+            // first line that STARTS inside this segment, and its index in the file
+            size_t pos = off; uint64_t line = seg_lines_[i];
+            if (off > 0 && p[off - 1] != '\n') {            // byte `off` continues line `line`
+                const char *nl = (const char *)memchr(p + off, '\n', n - off);
+                if (!nl) return;
+                pos = (size_t)(nl - p) + 1; line++;
+            }
+            // skip to the next header line (index divisible by 4)
+            while (pos < n && (line & 3)) {
+                const char *nl = (const char *)memchr(p + pos, '\n', n - pos);
+                if (!nl) return;
+                pos = (size_t)(nl - p) + 1; line++;
+            }
+            std::vector<FqRec> &v = out[gi];
+            v.reserve(SEG / 200);
+            while (pos < end) {                            // this record's header starts inside the segment
+                const char *ls[4]; uint32_t ll[4]; int li = 0;
+                size_t q = pos;
+                for (; li < 4 && q < n; li++) {
+                    const char *nl = (const char *)memchr(p + q, '\n', n - q);
+                    const size_t e = nl ? (size_t)(nl - p) : n;
+                    size_t L = e - q; if (L && p[e - 1] == '\r') L--;      // lines() strips "\r\n"
+                    ls[li] = p + q; ll[li] = (uint32_t)L;
+                    if (!nl) { q = n; li++; break; }
+                    q = e + 1;
+                }
+                if (li < 4) break;                          // partial record at the very end: dropped
+                v.push_back(FqRec{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]});
+                pos = q;
+            }
+        });
+        grp_.clear(); grp_pos_ = 0;
+        for (auto &v : out) grp_.insert(grp_.end(), v.begin(), v.end());
+        next_seg_ = g1;
+        return !grp_.empty() || next_seg_ < nseg ? (grp_.empty() ? parse_next_group() : true) : false;
+    }
+    template <class F> void parallel_for(size_t count, F f)
+    {
+        std::vector<std::thread> th;
+        const size_t T = std::min<size_t>(count, (size_t)parse_threads_);
+        std::atomic<size_t> nexti{0};
+        for (size_t t = 1; t < T; t++) th.emplace_back([&] { for (size_t i; (i = nexti++) < count;) f(i); });
+        for (size_t i; (i = nexti++) < count;) f(i);
+        for (auto &x : th) x.join();
+    }
     bool gz_ = false, eof_ = false; gzFile g_ = nullptr; FILE *f_ = nullptr; std::string path_;
     std::vector<char> carry_;
+    int parse_threads_ = 1;
+    std::shared_ptr<MappedFile> map_;
+    std::vector<uint64_t> seg_lines_; size_t next_seg_ = 0;
+    std::vector<FqRec> grp_; size_t grp_pos_ = 0;
 };
 
 struct PairBatch {
@@ -133,7 +241,10 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     const int nm = fq2 ? 2 : 1;
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
     BatchReader rd[2];
-    for (int m = 0; m < nm; m++) if (!rd[m].open(in_path[m], err)) return MF_E_IO;
+    for (int m = 0; m < nm; m++) {
+        rd[m].set_parse_threads(std::max(1, pack_threads / (2 * nm)));     // plain files: segments parsed in parallel
+        if (!rd[m].open(in_path[m], err)) return MF_E_IO;
+    }
     // create/truncate the outputs up front so that an empty input still leaves files behind
     std::mutex err_mu; int rc = MF_OK;
     auto set_err = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (rc == MF_OK) { rc = code; err = msg; } };
