@@ -164,6 +164,21 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2,
                           uint32_t threshold, int pair_mode, int n_devices,
                           uint64_t *kept, uint64_t *total);
 
+/* ---- FASTQ quality filter: the reference's `filter/filter_v2` (filter/filter_bin/src/main.rs:14-329),
+ * the stage that runs on the raw reads before this path (SURVEY.md 8f "next" #2).  Same rules, same
+ * output bytes: cut [start, end), drop reads with more than `ns` 'N' or with at least
+ * (len * limit) quality bytes <= `quality`, optional de-duplication on mate 1 (first occurrence
+ * kept; SipHash-1-3 like Rust's DefaultHasher), stop once `trim` bases have been kept,
+ * `truncate_only` skips the tests.  fq1 NULL = standard input; out2 NULL with fq2 set = standard
+ * output.  Counting and hashing run on the GPU over the raw FASTQ text; the order-dependent rules
+ * are applied on the host.  *panicked is set when the reference would have aborted mid-file (cut
+ * start beyond a string, invalid UTF-8): output up to that record is written, as the reference's
+ * BufWriter flushes on unwind, and the CLI then exits 101. */
+int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, const char *out2,
+                        uint64_t start, uint64_t end, uint64_t ns, uint32_t quality, float limit,
+                        int dedup, uint64_t trim, int truncate_only, int device,
+                        uint64_t *kept, uint64_t *total, int *panicked);
+
 #ifdef __cplusplus
 }
 #endif

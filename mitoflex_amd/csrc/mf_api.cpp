@@ -545,4 +545,55 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     return MF_OK;
 }
 
+// ------------------------------------------------------------- quality filter
+int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, const char *out2,
+                        uint64_t start, uint64_t end, uint64_t ns, uint32_t quality, float limit,
+                        int dedup, uint64_t trim, int truncate_only, int device,
+                        uint64_t *kept, uint64_t *total, int *panicked)
+{
+    if (!out1) return fail(MF_E_ARG, "out1 is NULL");
+    if (start > end) return fail(MF_E_ARG, "start comes after end");
+    if (quality == 0 || quality > 100) return fail(MF_E_ARG, "quality must be in 1..100");
+    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;      // no CPU fallback: needs the GPU
+    hipStream_t st = ctx->stream;
+    struct Scratch { void *p = nullptr; size_t cap = 0; } d_text, d_recs, d_cnt, d_hash;
+    auto need = [&](Scratch &s, size_t bytes) -> hipError_t {
+        if (bytes <= s.cap) return hipSuccess;
+        if (s.p) hipFree(s.p);
+        s.p = nullptr; s.cap = 0;
+        hipError_t e = hipMalloc(&s.p, bytes + bytes / 4 + 4096);
+        if (e == hipSuccess) s.cap = bytes + bytes / 4 + 4096;
+        return e;
+    };
+    QualScanFn scan = [&](const char *text, size_t len, const QualSpan *recs, uint32_t n, uint32_t q, uint32_t *n_count,
+                          uint32_t *bad_count, uint64_t *hashes, std::string &err) -> int {
+#define QCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return MF_E_HIP; } } while (0)
+        QCHK(hipSetDevice(device));
+        QCHK(need(d_text, len + 64)); QCHK(need(d_recs, (size_t)n * sizeof(QualSpan))); QCHK(need(d_cnt, (size_t)n * 8));
+        if (hashes) QCHK(need(d_hash, (size_t)n * 8));
+        QCHK(hipMemcpyAsync(d_text.p, text, len, hipMemcpyHostToDevice, st));
+        QCHK(hipMemcpyAsync(d_recs.p, recs, (size_t)n * sizeof(QualSpan), hipMemcpyHostToDevice, st));
+        uint32_t *dn = (uint32_t *)d_cnt.p, *db = dn + n;
+        QCHK(launch_qualscan((const uint8_t *)d_text.p, (const QualRec *)d_recs.p, n, q, dn, db, hashes ? (uint64_t *)d_hash.p : nullptr, st));
+        QCHK(hipMemcpyAsync(n_count, dn, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        QCHK(hipMemcpyAsync(bad_count, db, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        if (hashes) QCHK(hipMemcpyAsync(hashes, d_hash.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        QCHK(hipStreamSynchronize(st));
+#undef QCHK
+        return MF_OK;
+    };
+    static_assert(sizeof(QualSpan) == sizeof(QualRec), "host and device record layouts must match");
+    QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
+    P.dedup = dedup != 0; P.trunc = truncate_only != 0;
+    int threads = (int)std::thread::hardware_concurrency() - 4; if (threads < 2) threads = 2; if (threads > 32) threads = 32;
+    QualStats qs; std::string perr;
+    rc = run_qualfilter_pipeline(fq1, fq2, out1, out2, P, threads, env_u32("MF_BATCH_READS", 2000000), scan, qs, perr);
+    hipFree(d_text.p); hipFree(d_recs.p); hipFree(d_cnt.p); hipFree(d_hash.p);
+    if (rc != MF_OK) return fail(rc, "%s", perr.c_str());
+    if (kept) *kept = qs.kept;
+    if (total) *total = qs.total;
+    if (panicked) *panicked = qs.panicked ? 1 : 0;
+    return MF_OK;
+}
+
 } // extern "C"

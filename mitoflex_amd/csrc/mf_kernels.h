@@ -29,6 +29,10 @@ hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32
                                uint32_t stab_slots, uint32_t *has_ones, hipStream_t st);
 hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,
                              unsigned long long *out2, hipStream_t st);
+// FASTQ quality filter: a record's (cut) sequence and quality strings as offsets into the uploaded text
+struct QualRec { uint32_t s_off, s_len, q_off, q_len; };
+hipError_t launch_qualscan(const uint8_t *text, const QualRec *recs, uint32_t n, uint32_t quality, uint32_t *n_count, uint32_t *bad_count,
+                           uint64_t *hashes /* nullptr: no dedup hashes */, hipStream_t st);
 hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);
 
 } // namespace mf

@@ -796,6 +796,76 @@ __global__ void mark_has_n_kernel(ReadsView R, uint32_t *has_n)
     if (r != ~0ULL) atomicOr(&has_n[r >> 5], 1u << (r & 31));
 }
 
+// ------------------------------------------------- FASTQ quality filter (filter_v2)
+// Per-read counts the reference's quality filter decides on (filter/filter_bin/src/main.rs:236-243,
+// 302-307): number of 'N' in the (cut) sequence, number of quality bytes <= q in the (cut) quality
+// string.  The FASTQ text is uploaded as it is; a record is four offsets into it.  16 lanes per
+// record, byte loads coalesced inside the record, counts reduced with 16-wide shuffles.
+__global__ void __launch_bounds__(256)
+qualscan_kernel(const uint8_t *__restrict__ text, const QualRec *__restrict__ recs, uint32_t n, uint32_t quality,
+                uint32_t *__restrict__ n_count, uint32_t *__restrict__ bad_count)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = t >> 4, l16 = t & 15;
+    uint32_t nn = 0, nb = 0;
+    if (r < n) {
+        const QualRec rec = recs[r];
+        const uint8_t *__restrict__ s = text + rec.s_off;
+        for (uint32_t i = l16; i < rec.s_len; i += 16) nn += s[i] == 'N';
+        const uint8_t *__restrict__ q = text + rec.q_off;
+        for (uint32_t i = l16; i < rec.q_len; i += 16) nb += q[i] <= quality;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 16); nb += __shfl_xor(nb, o, 16); }
+    if (r < n && l16 == 0) { n_count[r] = nn; bad_count[r] = nb; }
+}
+
+// SipHash-1-3 with keys (0, 0) of the (cut) sequence followed by 0xff: what Rust's DefaultHasher
+// gives for `seq1.hash()` (main.rs:325-329), so the dedup set behaves exactly like the reference's
+// HashSet<u64>.  One lane per record.
+__device__ __forceinline__ void sip_round(uint64_t &v0, uint64_t &v1, uint64_t &v2, uint64_t &v3)
+{
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+    v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+}
+
+__global__ void __launch_bounds__(256)
+seqhash_kernel(const uint8_t *__restrict__ text, const QualRec *__restrict__ recs, uint32_t n, uint64_t *__restrict__ hashes)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const QualRec rec = recs[r];
+    const uint8_t *__restrict__ s = text + rec.s_off;
+    const uint64_t len = (uint64_t)rec.s_len + 1;                 // the bytes, then 0xff
+    uint64_t v0 = 0x736F6D6570736575ULL, v1 = 0x646F72616E646F6DULL, v2 = 0x6C7967656E657261ULL, v3 = 0x7465646279746573ULL;
+    auto byte_at = [&](uint64_t i) -> uint64_t { return i < rec.s_len ? s[i] : 0xFFu; };
+    uint64_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t m = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) m |= byte_at(i + b) << (8 * b);
+        v3 ^= m; sip_round(v0, v1, v2, v3); v0 ^= m;
+    }
+    uint64_t b = (len & 0xFF) << 56;
+    for (int k = 0; i < len; i++, k++) b |= byte_at(i) << (8 * k);
+    v3 ^= b; sip_round(v0, v1, v2, v3); v0 ^= b;
+    v2 ^= 0xFF;
+    sip_round(v0, v1, v2, v3); sip_round(v0, v1, v2, v3); sip_round(v0, v1, v2, v3);
+    hashes[r] = v0 ^ v1 ^ v2 ^ v3;
+}
+
+hipError_t launch_qualscan(const uint8_t *text, const QualRec *recs, uint32_t n, uint32_t quality, uint32_t *n_count, uint32_t *bad_count,
+                           uint64_t *hashes, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(qualscan_kernel, dim3((unsigned)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, st, text, recs, n, quality, n_count, bad_count);
+    if (hashes) hipLaunchKernelGGL(seqhash_kernel, dim3((n + 255) / 256), dim3(256), 0, st, text, recs, n, hashes);
+    return hipGetLastError();
+}
+
 // =================================================================== launchers
 static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 

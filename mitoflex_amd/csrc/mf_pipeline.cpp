@@ -72,6 +72,7 @@ class BatchReader {
 public:
     bool open(const char *path, std::string &err)
     {
+        if (!path) { f_ = stdin; own_f_ = false; path_ = "<stdin>"; return true; }
         gz_ = has_gz_ext(path);
         if (gz_) { g_ = gzopen(path, "rb"); if (g_) gzbuffer(g_, 1 << 20); }
         else f_ = fopen(path, "rb");
@@ -91,7 +92,7 @@ public:
         return true;
     }
     void set_parse_threads(int t) { parse_threads_ = t < 1 ? 1 : t; }
-    ~BatchReader() { if (g_) gzclose(g_); if (f_) fclose(f_); }
+    ~BatchReader() { if (g_) gzclose(g_); if (f_ && own_f_) fclose(f_); }
     // One pass: bytes are read in blocks and lines are cut as they arrive; every fourth line closes a
     // record.  Record fields are kept as offsets while the buffer may still move, pointers afterwards.
     // false at end of stream (no records left) or on error (err set)
@@ -218,7 +219,7 @@ private:
         for (size_t i; (i = nexti++) < count;) f(i);
         for (auto &x : th) x.join();
     }
-    bool gz_ = false, eof_ = false; gzFile g_ = nullptr; FILE *f_ = nullptr; std::string path_;
+    bool gz_ = false, eof_ = false, own_f_ = true; gzFile g_ = nullptr; FILE *f_ = nullptr; std::string path_;
     std::vector<char> carry_;
     int parse_threads_ = 1;
     std::shared_ptr<MappedFile> map_;
@@ -360,6 +361,211 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
         });
 
     for (auto &t : threads) t.join();
+    return rc;
+}
+
+// ================================================================ FASTQ quality filter (filter_v2)
+// Same readers; the decision stage is one thread because the reference's rules are sequential
+// (dedup keeps the first occurrence, the -t budget stops at the first read that overflows it:
+// filter/filter_bin/src/main.rs:244-259).  What is data parallel -- counting N and low-quality
+// bytes, hashing the sequences -- runs on the GPU over the raw text of each batch.
+namespace {
+
+struct U64Set {                                     // open-address set with HashSet<u64> semantics
+    std::vector<uint64_t> slot; std::vector<uint8_t> used; size_t n = 0, mask = 0;
+    U64Set() { slot.assign(1 << 16, 0); used.assign(1 << 16, 0); mask = (1 << 16) - 1; }
+    static uint64_t mix(uint64_t x) { x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 32; return x; }
+    void grow()
+    {
+        std::vector<uint64_t> os; std::vector<uint8_t> ou; os.swap(slot); ou.swap(used);
+        slot.assign(os.size() * 2, 0); used.assign(os.size() * 2, 0); mask = slot.size() - 1; n = 0;
+        for (size_t i = 0; i < os.size(); i++) if (ou[i]) insert(os[i]);
+    }
+    bool insert(uint64_t v)                          // false when already present
+    {
+        if (2 * (n + 1) > slot.size()) grow();
+        size_t i = mix(v) & mask;
+        while (used[i]) { if (slot[i] == v) return false; i = (i + 1) & mask; }
+        used[i] = 1; slot[i] = v; n++;
+        return true;
+    }
+};
+
+bool utf8_ok(const char *p, size_t n)
+{
+    const unsigned char *s = (const unsigned char *)p; size_t i = 0;
+    while (i < n) {
+        if (i + 8 <= n) { uint64_t v; memcpy(&v, s + i, 8); if (!(v & 0x8080808080808080ULL)) { i += 8; continue; } }
+        const unsigned char c = s[i];
+        if (c < 0x80) { i++; continue; }
+        int len; uint32_t cp, mn;
+        if ((c & 0xE0) == 0xC0) { len = 2; cp = c & 0x1F; mn = 0x80; }
+        else if ((c & 0xF0) == 0xE0) { len = 3; cp = c & 0x0F; mn = 0x800; }
+        else if ((c & 0xF8) == 0xF0) { len = 4; cp = c & 0x07; mn = 0x10000; }
+        else return false;
+        if (i + len > n) return false;
+        for (int k = 1; k < len; k++) { if ((s[i + k] & 0xC0) != 0x80) return false; cp = (cp << 6) | (s[i + k] & 0x3F); }
+        if (cp < mn || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += len;
+    }
+    return true;
+}
+
+struct QualBatch {
+    uint64_t index = 0, n = 0;
+    std::shared_ptr<MateBatch> mate[2];
+    std::vector<uint8_t> keep;
+    bool last = false;
+};
+using QualPtr = std::shared_ptr<QualBatch>;
+
+} // namespace
+
+int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &P,
+                            int threads, uint64_t batch_reads, const QualScanFn &scan, QualStats &stats, std::string &err)
+{
+    const int nm = fq2 ? 2 : 1;
+    const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
+    BatchReader rd[2];
+    for (int m = 0; m < nm; m++) {
+        rd[m].set_parse_threads(std::max(1, threads / (2 * nm)));
+        if (!rd[m].open(in_path[m], err)) return MF_E_IO;
+    }
+    std::mutex err_mu; int rc = MF_OK;
+    auto set_err = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (rc == MF_OK) { rc = code; err = msg; } };
+    Channel<std::shared_ptr<MateBatch>> q_read[2] = {Channel<std::shared_ptr<MateBatch>>(2), Channel<std::shared_ptr<MateBatch>>(2)};
+    Channel<QualPtr> q_write[2] = {Channel<QualPtr>(4), Channel<QualPtr>(4)};
+    auto abort_all = [&] { for (auto &q : q_read) q.abort(); for (auto &q : q_write) q.abort(); };
+
+    std::vector<std::thread> th;
+    for (int m = 0; m < nm; m++)
+        th.emplace_back([&, m] {
+            for (;;) {
+                auto b = std::make_shared<MateBatch>();
+                std::string e;
+                if (!rd[m].next(*b, batch_reads, e)) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
+                if (!q_read[m].push(b)) break;
+            }
+            q_read[m].finish();
+        });
+
+    // ---- decisions (sequential semantics), GPU counting per batch
+    th.emplace_back([&] {
+        U64Set seen; uint64_t budget = 0, idx = 0; bool stop = false;
+        const uint64_t L = P.end - P.start;
+        while (!stop) {
+            auto qb = std::make_shared<QualBatch>();
+            bool ok = true;
+            for (int m = 0; m < nm; m++) ok = q_read[m].pop(qb->mate[m]) && ok;
+            if (!ok) break;
+            uint64_t n = qb->mate[0]->recs.size();
+            if (nm == 2 && qb->mate[1]->recs.size() < n) n = qb->mate[1]->recs.size();
+            const bool short_mate = nm == 2 && qb->mate[0]->recs.size() != qb->mate[1]->recs.size();
+            // the cut (main.rs:222-233, 291-299) and the first record at which the reference would panic:
+            // `drain(..start)` past the end of a string, or a line that is not valid UTF-8
+            uint64_t n_ok = n;
+            for (uint64_t i = 0; i < n_ok; i++) {
+                for (int m = 0; m < nm; m++) {
+                    FqRec &r = qb->mate[m]->recs[i];
+                    // the line between sequence and quality is also decoded by lines(): it spans [s+sl .. q)
+                    if (!utf8_ok(r.h, r.hl) || !utf8_ok(r.s, (size_t)(r.q - r.s) + r.ql)) { n_ok = i; break; }
+                }
+                if (n_ok == i) break;
+                if (P.start) {
+                    bool bad = false;
+                    for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].sl;      // seq1, seq2 first
+                    for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].ql;      // then qua1, qua2
+                    if (bad) { n_ok = i; break; }
+                }
+                for (int m = 0; m < nm; m++) {
+                    FqRec &r = qb->mate[m]->recs[i];
+                    if (P.start) { r.s += P.start; r.sl -= (uint32_t)P.start; r.q += P.start; r.ql -= (uint32_t)P.start; }
+                    if (P.end) { if (r.sl > L) r.sl = (uint32_t)L; if (r.ql > L) r.ql = (uint32_t)L; }
+                }
+            }
+            const bool panicked = n_ok < n;
+            // GPU: counts (and hashes of mate 1 when deduplicating)
+            std::vector<uint32_t> nc[2], bc[2]; std::vector<uint64_t> hs;
+            if (!P.trunc && n_ok) {
+                for (int m = 0; m < nm && ok; m++) {
+                    const std::vector<FqRec> &recs = qb->mate[m]->recs;
+                    const char *base = recs[0].h, *endp = recs[n_ok - 1].q + recs[n_ok - 1].ql;
+                    if ((size_t)(endp - base) >= 0xFFFFFFF0ull) { set_err(MF_E_ARG, "batch larger than 4 GiB: lower MF_BATCH_READS"); ok = false; break; }
+                    std::vector<QualSpan> sp(n_ok);
+                    for (uint64_t i = 0; i < n_ok; i++)
+                        sp[i] = QualSpan{(uint32_t)(recs[i].s - base), recs[i].sl, (uint32_t)(recs[i].q - base), recs[i].ql};
+                    nc[m].resize(n_ok); bc[m].resize(n_ok);
+                    if (m == 0 && P.dedup) hs.resize(n_ok);
+                    std::string e;
+                    const int r = scan(base, (size_t)(endp - base), sp.data(), (uint32_t)n_ok, P.quality, nc[m].data(), bc[m].data(),
+                                       (m == 0 && P.dedup) ? hs.data() : nullptr, e);
+                    if (r != MF_OK) { set_err(r, e); ok = false; }
+                }
+                if (!ok) { abort_all(); break; }
+            }
+            qb->keep.assign(n ? n : 1, 0);
+            for (uint64_t i = 0; i < n_ok; i++) {
+                const FqRec &r1 = qb->mate[0]->recs[i];
+                if (!P.trunc) {
+                    bool drop = nc[0][i] > P.ns || (nm == 2 && nc[1][i] > P.ns);                       // main.rs:236, 302
+                    if (!drop) {
+                        // PE: both mates against a cutoff from seq1's length (main.rs:239-243); SE: from the quality string (:305)
+                        const float cf = (float)(nm == 2 ? r1.sl : r1.ql) * P.limit;
+                        const uint64_t cutoff = !(cf > 0.0f) ? 0 : (cf >= 18446744073709551616.0f ? ~0ull : (uint64_t)cf);
+                        drop = bc[0][i] >= cutoff || (nm == 2 && bc[1][i] >= cutoff);
+                    }
+                    if (!drop && P.dedup) drop = !seen.insert(hs[i]);                                     // main.rs:244-250
+                    if (drop) continue;
+                }
+                if (P.trim) { budget += r1.sl; if (budget > P.trim) { stop = true; break; } }          // main.rs:254-259
+                qb->keep[i] = 1; stats.kept++;
+            }
+            stats.total += n_ok;
+            qb->n = n_ok; qb->index = idx++;
+            if (panicked) { stats.panicked = true; stop = true; }
+            if (short_mate) stop = true;
+            for (int m = 0; m < nm; m++) if (!q_write[m].push(qb)) { stop = true; break; }
+        }
+        for (auto &q : q_read) q.abort();
+        for (auto &q : q_write) q.finish();
+    });
+
+    // ---- writers: header / cut seq / "+" / cut qual (main.rs:261-268, 317-321); nullptr path = stdout
+    for (int m = 0; m < nm; m++)
+        th.emplace_back([&, m] {
+            const bool to_stdout = out_path[m] == nullptr;
+            const bool gz = !to_stdout && has_gz_ext(out_path[m]);
+            gzFile g = nullptr; FILE *f = nullptr;
+            if (to_stdout) f = stdout;
+            else if (gz) { g = gzopen(out_path[m], "wb6"); if (g) gzbuffer(g, 1 << 20); } else f = fopen(out_path[m], "wb");
+            if (!g && !f) { set_err(MF_E_IO, std::string("Cannot open file ") + out_path[m]); abort_all(); return; }
+            bool ok = true;
+            std::vector<char> buf; buf.reserve((1u << 22) + (1u << 16));
+            auto drain = [&] {
+                if (buf.empty()) return;
+                const bool w = gz ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size() : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+                if (!w) ok = false;
+                buf.clear();
+            };
+            QualPtr qb;
+            while (ok && q_write[m].pop(qb)) {
+                const FqRec *recs = qb->mate[m]->recs.data();
+                for (uint64_t i = 0; i < qb->n && ok; i++) {
+                    if (!qb->keep[i]) continue;
+                    const FqRec &r = recs[i];
+                    buf.insert(buf.end(), r.h, r.h + r.hl); buf.push_back('\n');
+                    buf.insert(buf.end(), r.s, r.s + r.sl); buf.push_back('\n'); buf.push_back('+'); buf.push_back('\n');
+                    buf.insert(buf.end(), r.q, r.q + r.ql); buf.push_back('\n');
+                    if (buf.size() > (1u << 22)) drain();
+                }
+            }
+            drain();
+            if (to_stdout) fflush(stdout);
+            else if (gz) ok = (gzclose(g) == Z_OK) && ok; else ok = (fclose(f) == 0) && ok;
+            if (!ok) { set_err(MF_E_IO, std::string("write error on ") + (to_stdout ? "<stdout>" : out_path[m])); abort_all(); }
+        });
+
+    for (auto &t : th) t.join();
     return rc;
 }
 

@@ -19,4 +19,19 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
                        int n_devices, int pack_threads, uint64_t batch_reads, const BatchFilterFn &filter,
                        PipelineStats &stats, std::string &err);
 
+// ---------------------------------------------------------------- FASTQ quality filter (filter_v2)
+struct QualParams {
+    uint64_t start = 0, end = 0, ns = 10, trim = 0;
+    uint32_t quality = 55; float limit = 0.2f;
+    bool dedup = false, trunc = false;
+};
+struct QualSpan { uint32_t s_off, s_len, q_off, q_len; };     // same layout as the kernels' QualRec
+// counts (and, when hashes != nullptr, SipHash-1-3 of the sequences) of n records whose strings are offsets into text
+using QualScanFn = std::function<int(const char *text, size_t len, const QualSpan *recs, uint32_t n, uint32_t quality,
+                                     uint32_t *n_count, uint32_t *bad_count, uint64_t *hashes, std::string &err)>;
+struct QualStats { uint64_t kept = 0, total = 0; bool panicked = false; };
+// fq1 == nullptr: standard input; out2 == nullptr with fq2 set: standard output (reference: helper.rs:14-52)
+int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &p,
+                            int threads, uint64_t batch_reads, const QualScanFn &scan, QualStats &stats, std::string &err);
+
 } // namespace mf

@@ -27,7 +27,7 @@ EXPORTS = (
     "mf_kmerset_build_from_fasta", "mf_kmerset_build_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_packed",
-    "mf_filter_fastq_files",
+    "mf_filter_fastq_files", "mf_qualfilter_files",
 )
 
 
@@ -93,6 +93,9 @@ def load(path: Optional[str] = None):
     L.mf_filter_packed.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, vp]
     L.mf_filter_fastq_files.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
                                         C.c_int, u64p, u64p]
+    L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                      C.c_uint32, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
+                                      C.POINTER(C.c_int)]
     if L.mf_abi_version() != 1:
         raise MitoFilterError("libmitofilter_hip ABI version mismatch")
     _lib = L
@@ -262,6 +265,17 @@ def filter_fastq_files(ks: KmerSet, fq1: str, fq2: Optional[str], out1: str, out
     _chk(load().mf_filter_fastq_files(ks._h, _enc(fq1), _enc(fq2), _enc(out1), _enc(out2), threshold, pair_mode,
                                       n_devices, C.byref(kept), C.byref(total)))
     return kept.value, total.value
+
+
+def qualfilter_files(fq1: Optional[str], fq2: Optional[str], out1: str, out2: Optional[str], start: int = 0, end: int = 0,
+                     ns: int = 10, quality: int = 55, limit: float = 0.2, dedup: bool = False, trim: int = 0,
+                     truncate_only: bool = False, device: int = 0) -> Tuple[int, int, bool]:
+    """The reference's `filter_v2` rules (filter/filter_bin/src/main.rs) with GPU counting.
+    -> (kept, total, panicked)."""
+    kept, total, pan = C.c_uint64(), C.c_uint64(), C.c_int()
+    _chk(load().mf_qualfilter_files(_enc(fq1), _enc(fq2), _enc(out1), _enc(out2), start, end, ns, quality, limit, int(dedup),
+                                    trim, int(truncate_only), device, C.byref(kept), C.byref(total), C.byref(pan)))
+    return kept.value, total.value, bool(pan.value)
 
 
 def unpack_bits(bits: np.ndarray, n: int) -> np.ndarray:

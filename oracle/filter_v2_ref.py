@@ -1,0 +1,262 @@
+"""TEST INFRASTRUCTURE ONLY -- Python restatement of the reference FASTQ quality filter
+(`filter/filter_v2`, Rust: filter/filter_bin/src/main.rs:14-329, helper.rs:14-52).
+
+Pinned against golden vectors captured from the reference's prebuilt ELF
+(tests/golden/filter_v2_golden.json, made by tests/golden/make_filter_v2_golden.py); used to
+check the product (mitoflex_amd/filter/filter_v2, GPU counting) beyond those vectors.
+
+run(argv, read_file) -> (rc, out1 bytes | None, out2 bytes | None);  rc 0 ok, 101 = Rust panic,
+1 = clap usage error.  stdout carries nothing in this tool.
+"""
+from __future__ import annotations
+
+import re
+import struct
+from typing import Callable, List, Optional, Tuple
+
+from oracle.fastfilter_ref import ClapError, Panic, parse_usize
+
+_M64 = (1 << 64) - 1
+
+
+def _rotl(x, b):
+    return ((x << b) | (x >> (64 - b))) & _M64
+
+
+def siphash13(data: bytes, k0: int = 0, k1: int = 0) -> int:
+    """SipHash-1-3, what std::collections::hash_map::DefaultHasher::new() computes (keys 0, 0)."""
+    v0 = k0 ^ 0x736F6D6570736575; v1 = k1 ^ 0x646F72616E646F6D
+    v2 = k0 ^ 0x6C7967656E657261; v3 = k1 ^ 0x7465646279746573
+
+    def rnd(v0, v1, v2, v3):
+        v0 = (v0 + v1) & _M64; v1 = _rotl(v1, 13); v1 ^= v0; v0 = _rotl(v0, 32)
+        v2 = (v2 + v3) & _M64; v3 = _rotl(v3, 16); v3 ^= v2
+        v0 = (v0 + v3) & _M64; v3 = _rotl(v3, 21); v3 ^= v0
+        v2 = (v2 + v1) & _M64; v1 = _rotl(v1, 17); v1 ^= v2; v2 = _rotl(v2, 32)
+        return v0, v1, v2, v3
+    n = len(data)
+    for i in range(0, n - n % 8, 8):
+        m = struct.unpack_from("<Q", data, i)[0]
+        v3 ^= m
+        v0, v1, v2, v3 = rnd(v0, v1, v2, v3)
+        v0 ^= m
+    tail = data[n - n % 8:]
+    b = (n & 0xFF) << 56
+    for i, c in enumerate(tail):
+        b |= c << (8 * i)
+    v3 ^= b
+    v0, v1, v2, v3 = rnd(v0, v1, v2, v3)
+    v0 ^= b
+    v2 ^= 0xFF
+    for _ in range(3):
+        v0, v1, v2, v3 = rnd(v0, v1, v2, v3)
+    return (v0 ^ v1 ^ v2 ^ v3) & _M64
+
+
+def str_hash(s: bytes) -> int:
+    """`impl Hash for str`: the bytes followed by 0xff  (calculate_hash, main.rs:325-329)."""
+    return siphash13(s + b"\xff")
+
+
+def f32(x: float) -> float:
+    return struct.unpack("f", struct.pack("f", float(x)))[0]
+
+
+def f32_as_usize(x: float) -> int:
+    """Rust `as usize` on an f32: truncates toward zero, saturates, NaN -> 0."""
+    if x != x or x <= 0:
+        return 0
+    if x >= 2.0 ** 64:
+        return _M64
+    return int(x)
+
+
+def lines_of(data: bytes) -> List[bytes]:
+    if not data:
+        return []
+    parts = data.split(b"\n")
+    if parts[-1] == b"":
+        parts.pop()
+    return [p[:-1] if p.endswith(b"\r") else p for p in parts]
+
+
+LONG = {"fastq1": "1", "fastq2": "2", "cleanq1": "3", "cleanq2": "4", "start": "s", "end": "e", "quality": "q",
+        "limit": "l", "nvalues": "n", "trim": "t", "deduplication": "d"}
+VALUED = set("1234seqlnt")
+
+
+def parse_args(argv: List[str]):
+    o = {}
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a in ("-h", "--help", "-V", "--version"):
+            return {"help": True}
+        if a == "--truncate_only":
+            key, val = "T", True
+        elif a.startswith("--"):
+            name, eq, v = a[2:].partition("=")
+            if name not in LONG:
+                raise ClapError(a)
+            key = LONG[name]
+            if key == "d":
+                val = True
+            else:
+                if eq:
+                    val = v
+                else:
+                    if i + 1 >= len(argv):
+                        raise ClapError(a)
+                    i += 1; val = argv[i]
+        elif a.startswith("-") and len(a) >= 2:
+            key = a[1]
+            if key == "d":
+                val = True
+                if len(a) > 2:
+                    raise ClapError(a)
+            elif key in VALUED:
+                if len(a) > 2:
+                    val = a[2:]
+                    if val.startswith("="):
+                        val = val[1:]
+                else:
+                    if i + 1 >= len(argv):
+                        raise ClapError(a)
+                    i += 1; val = argv[i]
+                    if len(val) > 1 and val.startswith("-"):
+                        raise ClapError(val)
+            else:
+                raise ClapError(a)
+        else:
+            raise ClapError(a)
+        if key in o:
+            raise ClapError("twice " + a)
+        o[key] = val
+        i += 1
+    if "3" not in o:
+        raise ClapError("cleanq1 required")
+    if "4" in o and "2" not in o:
+        raise ClapError("cleanq2 requires fastq2")
+    if "d" in o and "2" not in o:
+        raise ClapError("deduplication requires fastq2")
+    return o
+
+
+def _f32_parse(s: str) -> float:
+    from oracle.fastfilter_ref import parse_f32
+    return parse_f32(s)
+
+
+def run(argv: List[str], read_file: Callable[[Optional[str]], Optional[bytes]]):
+    """read_file(path or None for stdin) -> decompressed bytes, or None if it cannot be opened."""
+    out1: Optional[List[bytes]] = None
+    out2: Optional[List[bytes]] = None
+
+    def done(rc):
+        j = lambda o: None if o is None else b"".join(o)
+        return rc, j(out1), j(out2)
+    try:
+        try:
+            o = parse_args(argv)
+        except ClapError:
+            return 1, None, None
+        if o.get("help"):
+            return 0, None, None
+        # main.rs:124-175 -- parse order: start, end (checks start > end), quality, limit, nvalues, trim
+        try:
+            start = parse_usize(o.get("s", "0"))
+        except Panic:
+            raise Panic("Cannot parse start position!")
+        try:
+            end = parse_usize(o.get("e", "0"))
+        except Panic:
+            raise Panic("Cannot parse end position!")
+        if start > end:
+            raise Panic("Start position comes after the end!")
+        qs = o.get("q", "55")
+        if not re.fullmatch(r"\+?[0-9]+", qs) or int(qs) > 255:
+            raise Panic("Canoot parse quality value!")
+        quality = int(qs)
+        if quality <= 0 or quality > 100:
+            raise Panic("Wrong quality number!")
+        try:
+            limit = _f32_parse(o.get("l", "0.2"))
+        except Panic:
+            raise Panic("Cannot parse limit value!")
+        if not (limit > 0.0 and limit < 1.0):            # n <= 0.0 || n >= 1.0 panics; NaN passes both tests
+            if limit == limit:
+                raise Panic("Wrong percentage value!")
+        ns = parse_usize(o.get("n", "10"))
+        trim = parse_usize(o.get("t", "0"))
+        dedup, trunc = "d" in o, "T" in o
+        pe = "2" in o
+        d1 = read_file(o.get("1"))
+        if d1 is None:
+            raise Panic("Cannot open file")
+        d2 = None
+        if pe:
+            d2 = read_file(o["2"])
+            if d2 is None:
+                raise Panic("Cannot open file")
+        out1 = []
+        if pe:
+            out2 = []                                    # write_file(cleanq2): None -> stdout
+        L = end - start
+
+        def cut(s: bytes) -> bytes:
+            if start != 0:
+                if start > len(s):
+                    raise Panic("drain out of range")
+                s = s[start:]
+            if end != 0:
+                s = s[:L]
+            return s
+        l1 = lines_of(d1)
+        if not pe:
+            times = 0
+            for i in range(0, len(l1) - 3, 4):
+                head, bps, quas = l1[i], l1[i + 1], l1[i + 3]
+                for x in (l1[i], l1[i + 1], l1[i + 2], l1[i + 3]):
+                    x.decode("utf-8")
+                bps = cut(bps); quas = cut(quas)
+                if not trunc:
+                    if bps.count(b"N") > ns:
+                        continue
+                    cutoff = f32(f32(len(quas)) * limit)
+                    if sum(1 for c in quas if c <= quality) >= f32_as_usize(cutoff):
+                        continue
+                if trim != 0:
+                    times += len(bps)
+                    if times > trim:
+                        break
+                out1 += [head, b"\n", bps, b"\n+\n", quas, b"\n"]
+            return done(0)
+        l2 = lines_of(d2)
+        n = min(len(l1), len(l2))
+        seen = set()
+        counts = 0
+        for i in range(0, n - 3, 4):
+            for x in l1[i:i + 4] + l2[i:i + 4]:
+                x.decode("utf-8")
+            h1, h2 = l1[i], l2[i]
+            s1 = cut(l1[i + 1]); s2 = cut(l2[i + 1]); q1 = cut(l1[i + 3]); q2 = cut(l2[i + 3])
+            if not trunc:
+                if s1.count(b"N") > ns or s2.count(b"N") > ns:
+                    continue
+                cutoff = f32_as_usize(f32(f32(len(s1)) * limit))
+                if sum(1 for c in q1 if c <= quality) >= cutoff or sum(1 for c in q2 if c <= quality) >= cutoff:
+                    continue
+                if dedup:
+                    h = str_hash(s1)
+                    if h in seen:
+                        continue
+                    seen.add(h)
+            if trim != 0:
+                counts += len(s1)
+                if counts > trim:
+                    break
+            out1 += [h1, b"\n", s1, b"\n+\n", q1, b"\n"]
+            out2 += [h2, b"\n", s2, b"\n+\n", q2, b"\n"]
+        return done(0)
+    except (Panic, UnicodeDecodeError):
+        return done(101)

@@ -1,0 +1,165 @@
+"""`filter_v2` (SURVEY.md 8f "next" #2): the reference's FASTQ quality filter.
+CPU part: the Python restatement (oracle/filter_v2_ref.py) against golden vectors captured from the
+reference's ELF, and the wrapper mirror's command strings against the reference's own.
+GPU part (-m gpu): the drop-in CLI (GPU counting) against the same vectors, bulk md5s and the oracle
+on randomized inputs -- bit-exact output bytes and exit codes."""
+import gzip
+import hashlib
+import importlib.util
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "filter_v2_golden.json")))
+CALLS = json.load(open(os.path.join(HERE, "golden", "filter_callsite_golden.json")))
+
+
+def _mk():
+    spec = importlib.util.spec_from_file_location("mkf", os.path.join(HERE, "golden", "make_filter_v2_golden.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _expect(case):
+    e1 = None if case["out1"] is None else case["out1"].encode("latin-1")
+    e2 = None if case["out2"] is None else case["out2"].encode("latin-1")
+    if case["name"] == "pe_out2_stdout":
+        e2 = case["stdout"].encode("latin-1")
+    return e1, e2
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_oracle_matches_elf(case):
+    from oracle import filter_v2_ref as ref
+    t1 = None if case["in1"] is None else case["in1"].encode("latin-1")
+    t2 = None if case["in2"] is None else case["in2"].encode("latin-1")
+    rc, o1, o2 = ref.run(list(case["argv"]), lambda p: t1 if (p is None or "in1" in p) else t2)
+    e1, e2 = _expect(case)
+    assert rc == case["rc"]
+    assert (o1 or b"") == (e1 or b"") and (o2 or b"") == (e2 or b"")
+
+
+def test_siphash_known_value():
+    from oracle.filter_v2_ref import siphash13
+    assert siphash13(b"") == 15130871412783076140          # DefaultHasher::new().finish()
+
+
+@pytest.mark.parametrize("c", CALLS, ids=lambda c: c["kind"])
+def test_wrapper_command_strings(c, tmp_path, monkeypatch):
+    from mitoflex_amd.filter import filter as w
+    from mitoflex_amd.utility import helper
+    calls = []
+    monkeypatch.setattr(helper, "direct_call", lambda cmd: calls.append(cmd) or "")
+    d = str(tmp_path)
+    if c["kind"] == "se":
+        w.filter_se(fqiabs=f"{d}/a.fq", fqoabs=f"{d}/o1.fq", **c["kwargs"])
+    else:
+        w.filter_pe(fq1=f"{d}/a.fq", fq2=f"{d}/b.fq", o1=f"{d}/o1.fq", o2=f"{d}/o2.fq", **c["kwargs"])
+    assert calls[0].replace(d, "{dir}").replace(os.path.dirname(os.path.abspath(w.__file__)), "{bin}") == c["command"]
+
+
+# ------------------------------------------------------------------------------------------- GPU
+def _run_cli(cli, tmp, t1, t2, argv):
+    paths = {k: os.path.join(tmp, v) for k, v in dict(in1="a_1.fq", in2="a_2.fq", out1="o_1.fq", out2="o_2.fq", in1gz="a_1.fq.gz",
+                                                       in2gz="a_2.fq.gz", out1gz="o_1.fq.gz", out2gz="o_2.fq.gz").items()}
+    for p in paths.values():
+        if os.path.exists(p):
+            os.remove(p)
+    for key, t in (("in1", t1), ("in2", t2)):
+        if t is not None:
+            raw = t if isinstance(t, bytes) else t.encode("latin-1")
+            open(paths[key], "wb").write(raw)
+            with gzip.open(paths[key + "gz"], "wb") as f:
+                f.write(raw)
+    args = [a.format(**paths) for a in argv]
+    use_stdin = "-1" not in argv and not any(a.startswith("--fastq1") for a in argv) and t1 is not None
+    p = subprocess.run([cli] + args, input=((t1 if isinstance(t1, bytes) else t1.encode("latin-1")) if use_stdin else None),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    outs = []
+    for k in ("out1", "out2"):
+        ob = None
+        for suffix in ("", "gz"):
+            pth = paths[k + suffix]
+            if os.path.exists(pth):
+                ob = open(pth, "rb").read()
+                if suffix == "gz":
+                    ob = gzip.decompress(ob) if ob else b""
+        outs.append(ob)
+    return p.returncode, p.stdout, outs
+
+
+@pytest.fixture(scope="module")
+def cli(built_lib):
+    from mitoflex_amd import mitofilter
+    if mitofilter.device_count() < 1:
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    p = os.path.join(os.path.dirname(HERE), "mitoflex_amd", "filter", "filter_v2")
+    assert os.path.exists(p)
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_cli_matches_elf(cli, tmp_path, case):
+    rc, so, outs = _run_cli(cli, str(tmp_path), case["in1"], case["in2"], case["argv"])
+    e1, e2 = _expect(case)
+    assert rc == case["rc"]
+    if case["name"] == "pe_out2_stdout":
+        assert so == e2
+    elif case["argv"][0] not in ("-h", "-V"):
+        assert so == case["stdout"].encode("latin-1")
+    assert outs[0] == e1
+    if case["name"] != "pe_out2_stdout":
+        assert outs[1] == (None if case["out2"] is None else case["out2"].encode("latin-1"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD["bulk"], ids=lambda b: b["name"])
+def test_cli_bulk_md5(cli, tmp_path, case, monkeypatch):
+    mk = _mk()
+    monkeypatch.setenv("MF_BATCH_READS", "3001")           # several batches, dedup/trim state carried across
+    monkeypatch.setenv("MF_PARSE_SEG", "40000")
+    s1, s2, q1, q2 = mk.rand_pair(case["n"], case["seed"], L=case["L"])
+    t1, t2 = mk.fq(s1, q1, "a"), mk.fq(s2, q2, "b")
+    rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if "{in2}" in case["argv"] else None, case["argv"])
+    assert rc == case["rc"]
+    assert hashlib.md5(outs[0]).hexdigest() == case["out1_md5"] and outs[0].count(b"\n") == case["out1_lines"]
+    if case["out2_md5"]:
+        assert hashlib.md5(outs[1]).hexdigest() == case["out2_md5"]
+
+
+@pytest.mark.gpu
+def test_cli_random_against_oracle(cli, tmp_path, monkeypatch):
+    from oracle import filter_v2_ref as ref
+    mk = _mk()
+    rng = random.Random(11)
+    for it in range(40):
+        n = rng.randint(0, 300)
+        s1, s2, q1, q2 = mk.rand_pair(n, 1000 + it, L=rng.choice([12, 40, 90]), lowq=rng.choice([0.02, 0.2]), dup=rng.choice([0, 0.4]))
+        t1, t2 = mk.fq(s1, q1, "a", eol=rng.choice(["\n", "\r\n"])), mk.fq(s2, q2, "b")
+        pe = rng.random() < 0.6
+        argv = ["-1", "{in1}", "-3", "{out1}"] + (["-2", "{in2}", "-4", "{out2}"] if pe else [])
+        if rng.random() < 0.5:
+            a = rng.randint(0, 8); argv += ["-s", str(a), "-e", str(a + rng.randint(0, 60))]
+        if rng.random() < 0.5:
+            argv += ["-q", str(rng.choice([35, 42, 55, 70])), "-l", rng.choice(["0.1", "0.25", "0.5", "0.99"])]
+        if rng.random() < 0.4:
+            argv += ["-n", str(rng.choice([0, 1, 5]))]
+        if rng.random() < 0.3:
+            argv += ["-t", str(rng.randint(1, 4000))]
+        if pe and rng.random() < 0.5:
+            argv += ["-d"]
+        if rng.random() < 0.15:
+            argv += ["--truncate_only"]
+        monkeypatch.setenv("MF_BATCH_READS", str(rng.choice([1, 7, 64, 2000000])))
+        monkeypatch.setenv("MF_PARSE_SEG", str(rng.choice([64, 1000, 1 << 25])))
+        rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if pe else None, argv)
+        b1, b2 = t1.encode("latin-1"), t2.encode("latin-1")
+        erc, e1, e2 = ref.run(list(argv), lambda p: b1 if "in1" in p else b2)
+        assert rc == erc, (it, argv)
+        assert (outs[0] or b"") == (e1 or b""), (it, argv)
+        assert (outs[1] or b"") == (e2 or b""), (it, argv)
