@@ -801,6 +801,15 @@ __global__ void mark_has_n_kernel(ReadsView R, uint32_t *has_n)
 // 302-307): number of 'N' in the (cut) sequence, number of quality bytes <= q in the (cut) quality
 // string.  The FASTQ text is uploaded as it is; a record is four offsets into it.  16 lanes per
 // record, byte loads coalesced inside the record, counts reduced with 16-wide shuffles.
+// bytes of w inside [lo, hi) (byte addresses; w sits at address `addr`) as a 0x80-per-byte mask
+__device__ __forceinline__ uint32_t byte_window80(uint32_t addr, uint32_t lo, uint32_t hi)
+{
+    const uint32_t b0 = lo > addr ? lo - addr : 0u, b1 = hi < addr + 4 ? (hi > addr ? hi - addr : 0u) : 4u;   // valid bytes [b0, b1)
+    if (b1 <= b0) return 0u;
+    const uint32_t upto1 = b1 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * b1)) - 1), upto0 = b0 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * b0)) - 1);
+    return upto1 & ~upto0 & 0x80808080u;
+}
+
 __global__ void __launch_bounds__(256)
 qualscan_kernel(const uint8_t *__restrict__ text, const QualRec *__restrict__ recs, uint32_t n, uint32_t quality,
                 uint32_t *__restrict__ n_count, uint32_t *__restrict__ bad_count)
@@ -810,10 +819,35 @@ qualscan_kernel(const uint8_t *__restrict__ text, const QualRec *__restrict__ re
     uint32_t nn = 0, nb = 0;
     if (r < n) {
         const QualRec rec = recs[r];
-        const uint8_t *__restrict__ s = text + rec.s_off;
-        for (uint32_t i = l16; i < rec.s_len; i += 16) nn += s[i] == 'N';
-        const uint8_t *__restrict__ q = text + rec.q_off;
-        for (uint32_t i = l16; i < rec.q_len; i += 16) nb += q[i] <= quality;
+        const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(text);
+        // 16-byte aligned blocks covering the string, one per lane per step; bytes outside the string are
+        // masked.  Byte tests are done four at a time on the dwords (SWAR), exact for every byte value.
+        {   // sequence: bytes == 'N'
+            const uint32_t lo = rec.s_off, hi = rec.s_off + rec.s_len;
+            for (uint32_t blk = (lo >> 4) + l16; rec.s_len && blk <= ((hi - 1) >> 4); blk += 16) {
+                const uint4 v = t4[blk];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t x = w[j] ^ 0x4E4E4E4Eu;                              // zero byte <=> 'N'
+                    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 exactly in zero bytes
+                    nn += __popc(z & byte_window80(blk * 16 + 4 * j, lo, hi));
+                }
+            }
+        }
+        {   // quality: bytes <= q  (q <= 100 < 0x80, so a byte with its top bit set never counts)
+            const uint32_t lo = rec.q_off, hi = rec.q_off + rec.q_len;
+            const uint32_t q1 = (quality + 1) * 0x01010101u;
+            for (uint32_t blk = (lo >> 4) + l16; rec.q_len && blk <= ((hi - 1) >> 4); blk += 16) {
+                const uint4 v = t4[blk];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t d = (w[j] | 0x80808080u) - q1;                       // per byte, no borrow: top bit clear <=> low7 <= q
+                    nb += __popc(~d & ~w[j] & byte_window80(blk * 16 + 4 * j, lo, hi));
+                }
+            }
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 16); nb += __shfl_xor(nb, o, 16); }
