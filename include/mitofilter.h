@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 1
+#define MF_ABI_VERSION 2
 
 enum {
     MF_OK = 0,
@@ -43,6 +43,12 @@ enum {
 enum {
     MF_MODE_SCREENED = 0,   /* s-mer screen kernel + exact kernel on candidates (default) */
     MF_MODE_EXHAUSTIVE = 1  /* exact kernel on every read (no screen) */
+};
+
+/* what a mf_kmerset holds */
+enum {
+    MF_KIND_NUCLEOTIDE = 0, /* canonical nucleotide k-mers (the north-star path) */
+    MF_KIND_PROTEIN = 1     /* peptide k-mers of a protein database; reads are translated in six frames */
 };
 
 /* pair rule for mf_filter_fastq_files */
@@ -62,6 +68,8 @@ typedef struct {
     uint32_t bloom_words;  /* LDS bit-table size in u32 words */
     uint32_t smer_slots;   /* exact s-mer table slots */
     uint64_t n_smers;      /* distinct s-mers (both strands) */
+    int32_t  kind;         /* MF_KIND_*; for MF_KIND_PROTEIN k is the peptide k-mer length (ABI 2) */
+    int32_t  genetic_code; /* NCBI translation table of a protein set, else 0 (ABI 2) */
 } mf_kmerset_info_t;
 
 typedef struct {
@@ -99,6 +107,18 @@ int         mf_device_synchronize(int device);
  * table is byte-identical to the CPU oracle's (history-independent layout). */
 int mf_kmerset_build_from_fasta(const char *fasta_path, int k, int device, mf_kmerset **out);
 int mf_kmerset_build_from_text(const char *fasta_text, size_t len, int k, int device, mf_kmerset **out);
+/* Protein-space bait set (SURVEY.md 8f "next" #4): the peptide k-mers (kp residues, 4..12; 5 bits per
+ * residue, first residue least significant) of a PROTEIN FASTA such as the reference's
+ * profile/MT_database/<clade>.fa, which the reference itself only hands to tblastn
+ * (findmitoscaf/findmitoscaf.py:57, annotation/annotation_tookit.py:55-97 `-db_gencode`).
+ * genetic_code is the NCBI translation table the reads are translated with -- the reference's
+ * --genetic-code / profile/codes.json value (arguments.py:449-453): 1, 2, 3, 4, 5, 9, 11, 13, 14, 21.
+ * The handle goes to the same mf_filter* entry points: every read is translated in six frames,
+ * hits = number of (frame, window) pairs whose kp codons are all sense codons free of invalid
+ * bases and whose peptide k-mer is in the set; `mode` is ignored (there is no screen). */
+int mf_kmerset_build_protein_from_fasta(const char *protein_fasta_path, int kp, int genetic_code, int device, mf_kmerset **out);
+int mf_kmerset_build_protein_from_text(const char *protein_fasta_text, size_t len, int kp, int genetic_code, int device,
+                                       mf_kmerset **out);
 int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info);
 /* copy the device table back: keys_out must hold slots*key_words u64 */
 int mf_kmerset_export(const mf_kmerset *ks, int device, uint64_t *keys_out, size_t n_u64);

@@ -6,7 +6,9 @@
   MEGAHIT.prefilter()   -> NEW: the k-mer bait read pre-filter (HIP), placed where the north
                            star puts it: on the reads, before `megahit_core buildlib`
   MEGAHIT.build_lib()   -> read-library hand-off as in the reference, with the pre-filter hooked
-                           in front of it and fq1/fq2 swapped for the survivors [ref :162-200]
+                           in front of it and fq1/fq2 swapped for the survivors [ref :162-200];
+                           with `bait_fifo` the survivors go to `buildlib` through named pipes,
+                           the way the reference feeds it gunzipped reads      [ref :176-184]
 
 Everything else of the reference class (graph/assemble/local/iterate/finalize) drives
 `megahit_core` and is out of scope.
@@ -37,6 +39,7 @@ class AssembleConf:
     bait_pair_mode = "either"
     bait_devices = 1
     prefilter_in_process = True        # ctypes (libmitofilter_hip.so) instead of the CLI
+    bait_fifo = False                  # stream survivors to `buildlib` through named pipes (no FASTQ round trip)
 
 
 a_conf = AssembleConf()
@@ -111,13 +114,40 @@ class MEGAHIT:
         return kept, total
 
     # --------------------------------------------------- read library (ref :162-200)
+    def prefilter_fifo(self, bait_fasta: Optional[str] = None):
+        """Start the bait filter as a background writer into two (one) named pipes and point fq1/fq2 at
+        them -- the hand-off the reference uses for `gzip -dc` (ref :176-184), so survivors never touch
+        the disk.  Returns the Popen; its stdout carries the kept count once the reader has drained."""
+        bait = bait_fasta or a_conf.bait_fasta
+        if not bait:
+            raise ValueError("no bait FASTA configured")
+        pipes = [path.join(self.temp_dir, "pipe.bait1")]
+        if self.fq2:
+            pipes.append(path.join(self.temp_dir, "pipe.bait2"))
+        for p in pipes:
+            os.mkfifo(p)
+        opts = dict(bait=bait, kmer=a_conf.bait_kmer, threshold=a_conf.bait_threshold, fq1=self.fq1, fq2=self.fq2,
+                    out1=pipes[0], out2=pipes[1] if self.fq2 else None, pair=a_conf.bait_pair_mode,
+                    devices=a_conf.bait_devices)
+        cmd = helper.concat_command(self.FAST_FILTER, "bait", **opts)
+        proc = subprocess.Popen(cmd, shell=True, stdout=subprocess.PIPE, preexec_fn=os.setsid)
+        self.fq1 = pipes[0]
+        self.fq2 = pipes[1] if len(pipes) > 1 else None
+        return proc
+
+    # --------------------------------------------------- read library (ref :162-200)
     def build_lib(self):
-        if a_conf.bait_fasta:
-            self.prefilter()
         fifos = []
+        bait_proc = None
+        orig = (self.fq1, self.fq2)
+        if a_conf.bait_fasta:
+            if a_conf.bait_fifo:
+                bait_proc = self.prefilter_fifo()
+            else:
+                self.prefilter()
         with open(self.read_lib, "w") as lib:
             if self.fq1 and self.fq2:
-                print(self.fq1, self.fq2, sep=",", file=lib)
+                print(*(orig if bait_proc else (self.fq1, self.fq2)), sep=",", file=lib)
                 names = []
                 for fq, pipe in ((self.fq1, "pipe.pe1"), (self.fq2, "pipe.pe2")):
                     if fq.endswith("gz"):
@@ -129,11 +159,16 @@ class MEGAHIT:
                         names.append(fq)
                 print("pe", names[0], names[1], file=lib)
             else:
-                print(self.fq1, file=lib)
+                print(orig[0] if bait_proc else self.fq1, file=lib)
                 name = self.fq1 if not self.fq1.endswith("gz") else path.join(self.temp_dir, "pipe.se")
                 print("se", name, file=lib)
         helper.shell_call(self.MEGAHIT_CORE, "buildlib", self.read_lib, self.read_lib)
         if any(p.wait() != 0 for p in fifos):
             raise RuntimeError("Error occured in reading input fifos")
+        if bait_proc is not None:
+            out = bait_proc.communicate()[0]
+            if bait_proc.returncode != 0:
+                raise RuntimeError("Error occured in the bait filter feeding buildlib")
+            self.bait_kept = int(out.decode().strip() or 0)
 
     MEGAHIT_CORE = "megahit_core"

@@ -65,12 +65,16 @@ static int get_ctx(int device, DevCtx **out)
 // ------------------------------------------------------------------ kmerset
 struct DevTables {
     uint64_t *keys = nullptr;
-    uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr;
+    uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr, *plut = nullptr;
     KmerSetView view{};
     uint64_t n_keys = 0, n_smers = 0;
 };
 struct mf_kmerset {
     int k = 0, kw = 1;
+    int kind = MF_KIND_NUCLEOTIDE, genetic_code = 0;   // protein sets: k = residues per key, reads translated with genetic_code
+    ProtBaitHost pbait;
+    uint32_t codon_lut[256] = {0};
+    bool kb_in_lds = true;
     BaitHost bait;
     uint64_t n_windows = 0, slots = 0;
     ScreenGeom geom{0, 0};
@@ -93,6 +97,36 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     if (it != ks->dev.end()) { *out = &it->second; return MF_OK; }
     DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;
     hipStream_t st = ctx->stream;
+    if (ks->kind == MF_KIND_PROTEIN) {
+        const ProtBaitHost &P = ks->pbait;
+        DevTables T;
+        uint8_t *d_aa = nullptr, *d_run = nullptr; unsigned long long *d_cnt = nullptr;
+        HIPCHK(hipMalloc(&d_aa, P.aa.size())); HIPCHK(hipMalloc(&d_run, P.runlen.size()));
+        HIPCHK(hipMemcpyAsync(d_aa, P.aa.data(), P.aa.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_run, P.runlen.data(), P.runlen.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMalloc(&T.keys, ks->slots * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(T.keys, 0xFF, ks->slots * sizeof(uint64_t), st));
+        HIPCHK(launch_build_ptable(d_aa, d_run, P.total, ks->k, T.keys, ks->slots, st));
+        HIPCHK(hipMalloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
+        HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
+        HIPCHK(launch_build_kbloom(T.keys, ks->slots, 1, T.kbloom, ks->kb_log2w, st));
+        HIPCHK(hipMalloc(&T.plut, sizeof ks->codon_lut));
+        HIPCHK(hipMemcpyAsync(T.plut, ks->codon_lut, sizeof ks->codon_lut, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMalloc(&d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
+        HIPCHK(launch_count_keys(T.keys, ks->slots, 1, nullptr, 0, d_cnt, st));
+        unsigned long long cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(d_aa); hipFree(d_run); hipFree(d_cnt);
+        T.n_keys = cnt[0];
+        KmerSetView &V = T.view;
+        V.k = ks->k; V.kw = 1; V.slot_mask = ks->slots - 1; V.keys = T.keys;
+        V.kb_log2w = ks->kb_log2w; V.kbloom = T.kbloom;
+        V.prot = 1; V.kb_in_lds = ks->kb_in_lds ? 1u : 0u; V.plut = T.plut;
+        ks->dev[device] = T;
+        *out = &ks->dev[device];
+        return MF_OK;
+    }
     const BaitHost &B = ks->bait;
     DevTables T;
     uint32_t *d_words = nullptr; uint8_t *d_run = nullptr; uint32_t *d_pos = nullptr, *d_flag = nullptr;
@@ -188,6 +222,39 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
     return MF_OK;
 }
 
+static int protset_new(const char *text, size_t len, int kp, int genetic_code, int device, mf_kmerset **out)
+{
+    if (!out) return fail(MF_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (kp < 4 || kp > 12) return fail(MF_E_ARG, "peptide k=%d out of range [4,12]", kp);
+    mf_kmerset *ks = new (std::nothrow) mf_kmerset();
+    if (!ks) return fail(MF_E_NOMEM, "out of memory");
+    ks->kind = MF_KIND_PROTEIN; ks->k = kp; ks->kw = 1; ks->genetic_code = genetic_code;
+    if (!codon_lut_for(genetic_code, kp, ks->codon_lut)) { delete ks; return fail(MF_E_ARG, "genetic code %d is not supported (1, 2, 3, 4, 5, 9, 11, 13, 14, 21)", genetic_code); }
+    parse_bait_protein(text, len, ks->pbait);
+    ks->n_windows = ks->pbait.n_windows(kp);
+    ks->slots = table_slots_for(ks->n_windows);
+    {   // k-mer bit table in front of the open-address table.  Small databases: staged in LDS (<= 64 KiB, about two keys
+        // per 128-bit block; still worth it at 32 keys per block, where one probe in six goes on to the table).  Large
+        // ones (a whole MT_database clade is ~1 M keys): in global memory at >= 16 bits per key, sized to stay in L2.
+        uint32_t lg = 8;
+        while (lg < 14 && (1ull << lg) < 2 * ks->n_windows) lg++;
+        ks->kb_in_lds = ks->n_windows <= (1u << 17);
+        if (!ks->kb_in_lds) { lg = 15; while (lg < 24 && (32ull << lg) < 16 * ks->n_windows) lg++; }
+        if (getenv("MF_KBLOOM_LOG2W")) {
+            lg = env_u32("MF_KBLOOM_LOG2W", lg);
+            if (lg < 8) lg = 8;
+            if (lg > 24) lg = 24;
+            ks->kb_in_lds = lg <= 14;
+        }
+        ks->kb_log2w = lg;
+    }
+    DevTables *T; int rc = build_on_device(ks, device, &T);
+    if (rc) { delete ks; return rc; }
+    *out = ks;
+    return MF_OK;
+}
+
 extern "C" {
 
 int mf_abi_version(void) { return MF_ABI_VERSION; }
@@ -232,6 +299,20 @@ int mf_kmerset_build_from_fasta(const char *path, int k, int device, mf_kmerset 
     return kmerset_new(buf.data(), buf.size(), k, device, out);
 }
 
+int mf_kmerset_build_protein_from_text(const char *text, size_t len, int kp, int genetic_code, int device, mf_kmerset **out)
+{
+    if (!text && len) return fail(MF_E_ARG, "protein_fasta_text is NULL");
+    return protset_new(text ? text : "", len, kp, genetic_code, device, out);
+}
+
+int mf_kmerset_build_protein_from_fasta(const char *path, int kp, int genetic_code, int device, mf_kmerset **out)
+{
+    if (!path) return fail(MF_E_ARG, "protein_fasta_path is NULL");
+    std::vector<char> buf; std::string err;
+    if (!slurp_file(path, buf, err)) return fail(MF_E_IO, "%s", err.c_str());
+    return protset_new(buf.data(), buf.size(), kp, genetic_code, device, out);
+}
+
 int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info)
 {
     if (!ks || !info) return fail(MF_E_ARG, "NULL argument");
@@ -240,6 +321,7 @@ int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info)
     info->screen_s = ks->geom.s; info->screen_stride = ks->geom.stride;
     info->bloom_words = ks->geom.s ? (uint32_t)ks->screen_words() : 0; info->smer_slots = ks->stab_slots;
     if (!ks->dev.empty()) { info->n_keys = ks->dev.begin()->second.n_keys; info->n_smers = ks->dev.begin()->second.n_smers; }
+    info->kind = ks->kind; info->genetic_code = ks->genetic_code;
     return MF_OK;
 }
 
@@ -257,7 +339,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 {
     if (!ks) return MF_OK;
     for (auto &kv : ks->dev) {
-        if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); }
+        if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.plut); }
     }
     delete ks;
     return MF_OK;
@@ -421,6 +503,12 @@ static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_base
 static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, int n_cu,
                         hipStream_t st, hipEvent_t *ev)
 {
+    if (S.prot) {          // protein-space set: one kernel translates and probes every read (no screen exists in residue space)
+        if (ev) { HIPCHK(hipEventRecord(ev[0], st)); HIPCHK(hipEventRecord(ev[3], st)); HIPCHK(hipEventRecord(ev[1], st)); }
+        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st));
+        if (ev) HIPCHK(hipEventRecord(ev[2], st));
+        return MF_OK;
+    }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
     // no per-pass memsets: the exact kernel clears the candidate words it consumes and zeroes unused tally slots
     if (ev) HIPCHK(hipEventRecord(ev[0], st));

@@ -162,6 +162,10 @@ struct KmerSetView {
     const uint32_t *stab;       // s-mer exact table (ordered linear probing, EMPTY32)
     uint32_t  stab_has_ones;    // the all-ones s-mer (poly-T, only possible for s == 16) is present
     uint32_t  use_stab;         // stage 3 on: stage 2 is too full to be trusted alone (large baits)
+    // protein-space set (peptide k-mers, 5 bits per residue; k = residues per key, kw = 1, no screen)
+    uint32_t  prot;             // 1: keys are peptide k-mers and reads are translated in six frames
+    uint32_t  kb_in_lds;        // the k-mer bit table is small enough to be staged in LDS
+    const uint32_t *plut;       // 64 codon entries of 4 dwords (see CodonLutEntry in mf_host.h)
 };
 
 } // namespace mf

@@ -110,6 +110,82 @@ void parse_bait_fasta(const char *text, size_t len, BaitHost &out)
     }
 }
 
+// ------------------------------------------------------------ protein bait
+uint64_t ProtBaitHost::n_windows(int kp) const
+{
+    uint64_t n = 0;
+    for (uint64_t L : rec_len) if (L >= (uint64_t)kp) n += L - kp + 1;
+    return n;
+}
+
+static int residue_code(unsigned char c)
+{
+    static const char AA[] = "ACDEFGHIKLMNPQRSTVWY";
+    if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 'a' + 'A');
+    for (int i = 0; i < 20; i++) if ((unsigned char)AA[i] == c) return i;
+    return -1;
+}
+
+void parse_bait_protein(const char *text, size_t len, ProtBaitHost &out)
+{
+    out = ProtBaitHost();
+    std::vector<int8_t> codes; codes.reserve(len);
+    std::vector<uint64_t> rec_start;
+    bool at_line_start = true, in_header = false, open = false;
+    for (size_t i = 0; i < len; i++) {
+        const unsigned char c = (unsigned char)text[i];
+        if (in_header) { if (c == '\n') { in_header = false; at_line_start = true; } continue; }
+        if (at_line_start && c == '>') { rec_start.push_back(codes.size()); open = true; in_header = true; at_line_start = false; continue; }
+        if (c == '\n') { at_line_start = true; continue; }
+        at_line_start = false;
+        if (c == '\r' || c == ' ' || c == '\t' || c == '\v' || c == '\f') continue;
+        if (!open) { rec_start.push_back(codes.size()); open = true; }
+        codes.push_back((int8_t)residue_code(c));
+    }
+    out.total = codes.size();
+    rec_start.push_back(out.total);
+    for (size_t r = 0; r + 1 < rec_start.size(); r++) out.rec_len.push_back(rec_start[r + 1] - rec_start[r]);
+    out.aa.assign(out.total + 16, 0);
+    out.runlen.assign(out.total + 1, 0);
+    for (uint64_t g = 0; g < out.total; g++) out.aa[g] = codes[g] < 0 ? 0 : (uint8_t)codes[g];
+    for (size_t r = 0; r + 1 < rec_start.size(); r++) {
+        uint32_t run = 0;
+        for (uint64_t g = rec_start[r + 1]; g-- > rec_start[r];) {
+            run = codes[g] >= 0 ? (run < 255 ? run + 1 : 255) : 0;
+            out.runlen[g] = (uint8_t)run;
+        }
+    }
+}
+
+bool codon_lut_for(int genetic_code, int kp, uint32_t out[256])
+{
+    // NCBI transl_table strings, codons in the order TTT TTC TTA TTG TCT ... GGG (bases T, C, A, G)
+    const char *tab = nullptr;
+    switch (genetic_code) {
+    case 1: case 11: tab = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"; break;
+    case 2:  tab = "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG"; break;
+    case 3:  tab = "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG"; break;
+    case 4:  tab = "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"; break;
+    case 5:  tab = "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG"; break;
+    case 9:  tab = "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG"; break;
+    case 13: tab = "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG"; break;
+    case 14: tab = "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG"; break;
+    case 21: tab = "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNNKSSSSVVVVAAAADDEEGGGG"; break;
+    default: return false;
+    }
+    static const int tcag[4] = {2, 1, 3, 0};                       // our base codes A C G T -> position in "TCAG"
+    auto residue = [&](int b1, int b2, int b3) { return residue_code((unsigned char)tab[16 * tcag[b1] + 4 * tcag[b2] + tcag[b3]]); };
+    for (int c = 0; c < 64; c++) {
+        const int b1 = c & 3, b2 = (c >> 2) & 3, b3 = (c >> 4) & 3;
+        const int f = residue(b1, b2, b3), r = residue(3 - b3, 3 - b2, 3 - b1);
+        const uint64_t top = f < 0 ? 0 : (uint64_t)f << (5 * (kp - 1));
+        out[4 * c] = (uint32_t)top; out[4 * c + 1] = (uint32_t)(top >> 32);
+        out[4 * c + 2] = r < 0 ? 0u : (uint32_t)r;
+        out[4 * c + 3] = (f >= 0 ? 1u : 0u) | (r >= 0 ? 2u : 0u);
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------- FASTQ
 void parse_fastq(const char *buf, size_t len, std::vector<FqRec> &recs)
 {

@@ -27,6 +27,22 @@ struct BaitHost {
 // anything but ACGTacgt is invalid and breaks windows; windows never span records.
 void parse_bait_fasta(const char *text, size_t len, BaitHost &out);
 
+// ---- protein-space baiting (DESIGN.md "Spec P") ------------------------------
+struct ProtBaitHost {
+    std::vector<uint8_t> aa;        // residue codes 0..19 (rank in "ACDEFGHIKLMNPQRSTVWY"), 0 at invalid letters, 16 B padding
+    std::vector<uint8_t> runlen;    // valid run length from each residue (cap 255), 0 at invalid letters
+    uint64_t total = 0;             // residues over all records (invalid ones included)
+    std::vector<uint64_t> rec_len;
+    uint64_t n_windows(int kp) const;
+};
+// same record rules as parse_bait_fasta; anything but the 20 standard residues (either case) is invalid
+void parse_bait_protein(const char *text, size_t len, ProtBaitHost &out);
+// NCBI translation table `genetic_code` (1, 2, 3, 4, 5, 9, 11, 13, 14, 21) as the filter kernel wants it:
+// 64 entries of 4 dwords, indexed by the codon as it sits in the packed stream (first base in bits 0-1):
+//   [0],[1]  forward-strand residue << 5*(kp-1) (64 bit), [2] residue of the reverse-complemented codon,
+//   [3]      bit 0: forward codon translates to a residue (not a stop), bit 1: same for the reverse codon
+bool codon_lut_for(int genetic_code, int kp, uint32_t out[256]);
+
 struct FqRec { const char *h, *s, *q; uint32_t hl, sl, ql; };
 // strict 4-line records over an in-memory buffer (pointers into buf)
 void parse_fastq(const char *buf, size_t len, std::vector<FqRec> &recs);

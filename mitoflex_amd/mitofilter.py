@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmitofilter_hip.so")
 
+KIND_NUCLEOTIDE, KIND_PROTEIN = 0, 1
 MODE_SCREENED = 0
 MODE_EXHAUSTIVE = 1
 PAIR_EITHER = 0
@@ -24,7 +25,8 @@ PAIR_BOTH = 1
 # every symbol include/mitofilter.h declares (checked by tests/test_abi.py)
 EXPORTS = (
     "mf_abi_version", "mf_last_error", "mf_device_count", "mf_device_name", "mf_device_synchronize",
-    "mf_kmerset_build_from_fasta", "mf_kmerset_build_from_text", "mf_kmerset_info", "mf_kmerset_export",
+    "mf_kmerset_build_from_fasta", "mf_kmerset_build_from_text", "mf_kmerset_build_protein_from_fasta",
+    "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_packed",
     "mf_filter_fastq_files", "mf_qualfilter_files",
@@ -38,7 +40,8 @@ class MitoFilterError(RuntimeError):
 class KmerSetInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("key_words", C.c_int32), ("slots", C.c_uint64), ("n_keys", C.c_uint64),
                 ("n_windows", C.c_uint64), ("screen_s", C.c_int32), ("screen_stride", C.c_int32),
-                ("bloom_words", C.c_uint32), ("smer_slots", C.c_uint32), ("n_smers", C.c_uint64)]
+                ("bloom_words", C.c_uint32), ("smer_slots", C.c_uint32), ("n_smers", C.c_uint64),
+                ("kind", C.c_int32), ("genetic_code", C.c_int32)]
 
 
 class ReadsInfo(C.Structure):
@@ -76,6 +79,8 @@ def load(path: Optional[str] = None):
     L.mf_device_synchronize.argtypes = [C.c_int]
     L.mf_kmerset_build_from_fasta.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
     L.mf_kmerset_build_from_text.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mf_kmerset_build_protein_from_fasta.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mf_kmerset_build_protein_from_text.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.mf_kmerset_info.argtypes = [vp, C.POINTER(KmerSetInfo)]
     L.mf_kmerset_export.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.mf_kmerset_free.argtypes = [vp]
@@ -96,7 +101,7 @@ def load(path: Optional[str] = None):
     L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                       C.c_uint32, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
                                       C.POINTER(C.c_int)]
-    if L.mf_abi_version() != 1:
+    if L.mf_abi_version() != 2:
         raise MitoFilterError("libmitofilter_hip ABI version mismatch")
     _lib = L
     return L
@@ -146,6 +151,22 @@ class KmerSet:
             fasta_text = fasta_text.encode()
         h = C.c_void_p()
         _chk(load().mf_kmerset_build_from_text(fasta_text, len(fasta_text), k, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def protein_from_fasta(cls, path: str, kp: int = 9, genetic_code: int = 5, device: int = 0) -> "KmerSet":
+        """Peptide k-mer set of a protein FASTA (e.g. the reference's profile/MT_database/<clade>.fa); reads
+        filtered against it are translated in six frames with NCBI table `genetic_code`."""
+        h = C.c_void_p()
+        _chk(load().mf_kmerset_build_protein_from_fasta(_enc(path), kp, genetic_code, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def protein_from_text(cls, fasta_text, kp: int = 9, genetic_code: int = 5, device: int = 0) -> "KmerSet":
+        if isinstance(fasta_text, str):
+            fasta_text = fasta_text.encode()
+        h = C.c_void_p()
+        _chk(load().mf_kmerset_build_protein_from_text(fasta_text, len(fasta_text), kp, genetic_code, device, C.byref(h)))
         return cls(h)
 
     @property

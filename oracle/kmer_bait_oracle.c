@@ -322,21 +322,25 @@ static uint32_t read_hits64(const mfo_table *t, const mfo_reads *r, uint64_t idx
 typedef struct {
     const mfo_table *t; const mfo_reads *r; uint64_t first, lo, hi; uint32_t thr;
     uint32_t *bits; uint32_t *hits;
+    const int8_t *plut;          /* non-NULL: protein-space baiting with this codon -> residue table */
 } job_t;
+
+static uint32_t pread_hits(const mfo_table *t, const mfo_reads *r, uint64_t idx, const int8_t *lut);
 
 static void *filter_job(void *arg)
 {
     job_t *j = (job_t *)arg;
     for (uint64_t i = j->lo; i < j->hi; i++) {
-        uint32_t h = j->t->kw == 1 ? read_hits64(j->t, j->r, j->first + i) : read_hits(j->t, j->r, j->first + i);
+        uint32_t h = j->plut ? pread_hits(j->t, j->r, j->first + i, j->plut)
+                   : j->t->kw == 1 ? read_hits64(j->t, j->r, j->first + i) : read_hits(j->t, j->r, j->first + i);
         if (j->hits) j->hits[i] = h;
         if (j->bits && h >= j->thr) __atomic_fetch_or(&j->bits[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED);
     }
     return NULL;
 }
 
-int mfo_filter(const mfo_table *t, const mfo_reads *r, uint64_t first, uint64_t count,
-               uint32_t thr, uint32_t *bits, uint32_t *hits, int n_threads)
+static int filter_impl(const mfo_table *t, const mfo_reads *r, uint64_t first, uint64_t count,
+                       uint32_t thr, uint32_t *bits, uint32_t *hits, int n_threads, const int8_t *plut)
 {
     if (thr < 1) return -11;
     if (first + count > r->n_reads) return -12;
@@ -346,13 +350,19 @@ int mfo_filter(const mfo_table *t, const mfo_reads *r, uint64_t first, uint64_t 
     pthread_t *th = (pthread_t *)malloc(n_threads * sizeof *th);
     job_t *jobs = (job_t *)malloc(n_threads * sizeof *jobs);
     for (int i = 0; i < n_threads; i++) {
-        jobs[i] = (job_t){ t, r, first, count * i / n_threads, count * (i + 1) / n_threads, thr, bits, hits };
+        jobs[i] = (job_t){ t, r, first, count * i / n_threads, count * (i + 1) / n_threads, thr, bits, hits, plut };
         if (n_threads == 1) filter_job(&jobs[i]);
         else pthread_create(&th[i], NULL, filter_job, &jobs[i]);
     }
     if (n_threads > 1) for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
     free(th); free(jobs);
     return 0;
+}
+
+int mfo_filter(const mfo_table *t, const mfo_reads *r, uint64_t first, uint64_t count,
+               uint32_t thr, uint32_t *bits, uint32_t *hits, int n_threads)
+{
+    return filter_impl(t, r, first, count, thr, bits, hits, n_threads, NULL);
 }
 
 /* -------------------------------------------------------------- whole files */
@@ -374,12 +384,11 @@ static int write_survivors(const char *path, const fq_rec *recs, uint64_t n, con
     return 0;
 }
 
-int mfo_filter_fastq_files(const char *bait, int k, uint32_t thr, int pair_mode,
-                           const char *fq1, const char *fq2, const char *out1, const char *out2,
-                           uint64_t *kept, uint64_t *total, int n_threads)
+static int files_impl(mfo_table t, const int8_t *plut, uint32_t thr, int pair_mode,
+                      const char *fq1, const char *fq2, const char *out1, const char *out2,
+                      uint64_t *kept, uint64_t *total, int n_threads)
 {
-    mfo_table t; int rc = mfo_table_build_file(bait, k, &t);
-    if (rc) return rc;
+    int rc;
     char *b1 = NULL, *b2 = NULL; size_t l1 = 0, l2 = 0;
     fq_rec *r1 = NULL, *r2 = NULL; uint64_t n1 = 0, n2 = 0;
     if ((rc = slurp(fq1, &b1, &l1))) return rc;
@@ -392,8 +401,8 @@ int mfo_filter_fastq_files(const char *bait, int k, uint32_t thr, int pair_mode,
     uint32_t *h1 = (uint32_t *)malloc((n ? n : 1) * 4), *h2 = (uint32_t *)malloc((n ? n : 1) * 4);
     mfo_reads p1, p2;
     pack_recs(r1, n, &p1);
-    mfo_filter(&t, &p1, 0, n, thr, NULL, h1, n_threads);
-    if (fq2) { pack_recs(r2, n, &p2); mfo_filter(&t, &p2, 0, n, thr, NULL, h2, n_threads); }
+    filter_impl(&t, &p1, 0, n, thr, NULL, h1, n_threads, plut);
+    if (fq2) { pack_recs(r2, n, &p2); filter_impl(&t, &p2, 0, n, thr, NULL, h2, n_threads, plut); }
     uint64_t kc = 0;
     for (uint64_t i = 0; i < n; i++) {
         int a = h1[i] >= thr, b = fq2 ? h2[i] >= thr : 0;
@@ -408,4 +417,162 @@ int mfo_filter_fastq_files(const char *bait, int k, uint32_t thr, int pair_mode,
     free(keep); free(h1); free(h2); free(r1); free(r2); free(b1); free(b2);
     mfo_table_free(&t);
     return rc;
+}
+
+int mfo_filter_fastq_files(const char *bait, int k, uint32_t thr, int pair_mode,
+                           const char *fq1, const char *fq2, const char *out1, const char *out2,
+                           uint64_t *kept, uint64_t *total, int n_threads)
+{
+    mfo_table t; int rc = mfo_table_build_file(bait, k, &t);
+    if (rc) return rc;
+    return files_impl(t, NULL, thr, pair_mode, fq1, fq2, out1, out2, kept, total, n_threads);
+}
+
+/* ---------------------------------------------------- protein-space baiting
+ * Spec P of oracle/prot_bait_ref.py (PARITY UNPINNED BY THE REFERENCE, which
+ * only ever hands profile/MT_database to tblastn: annotation/annotation_tookit.py:55-97).  Written
+ * the long way round on purpose: the reverse strand is built explicitly and translated like the
+ * forward one. */
+static int cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+static const char *gcode_string(int code)
+{
+    switch (code) {   /* NCBI transl_table, codons ordered TTT TTC TTA TTG TCT ... GGG */
+    case 1: case 11: return "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    case 2:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG";
+    case 3:  return "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    case 4:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    case 5:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG";
+    case 9:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG";
+    case 13: return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG";
+    case 14: return "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG";
+    case 21: return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNNKSSSSVVVVAAAADDEEGGGG";
+    default: return NULL;
+    }
+}
+
+static int aa_code(unsigned char c)
+{
+    static const char *AA = "ACDEFGHIKLMNPQRSTVWY";
+    if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+    const char *p = c ? strchr(AA, c) : NULL;
+    return p ? (int)(p - AA) : -1;
+}
+
+/* lut[b1*16 + b2*4 + b3] with A=0 C=1 G=2 T=3: residue code, or -1 for a stop */
+static int codon_lut(int gcode, int8_t lut[64])
+{
+    const char *tab = gcode_string(gcode);
+    if (!tab) return -13;
+    static const int tcag_of[4] = {2, 1, 3, 0};          /* A C G T -> index in "TCAG" */
+    for (int b1 = 0; b1 < 4; b1++) for (int b2 = 0; b2 < 4; b2++) for (int b3 = 0; b3 < 4; b3++)
+        lut[b1 * 16 + b2 * 4 + b3] = (int8_t)aa_code((unsigned char)tab[16 * tcag_of[b1] + 4 * tcag_of[b2] + tcag_of[b3]]);
+    return 0;
+}
+
+int mfo_ptable_build(const char *text, size_t len, int kp, mfo_table *out)
+{
+    memset(out, 0, sizeof *out);
+    if (kp < 4 || kp > 12) return -10;
+    uint64_t cap = 1024, nk = 0, n_windows = 0, run = 0, reclen = 0, key = 0;
+    uint64_t *keys = (uint64_t *)malloc(cap * sizeof *keys);
+    int at_line_start = 1, in_header = 0;
+    for (size_t i = 0; i <= len; i++) {
+        int eof = (i == len);
+        unsigned char c = eof ? '\n' : (unsigned char)text[i];
+        if (in_header) { if (c == '\n') { in_header = 0; at_line_start = 1; } continue; }
+        if (at_line_start && c == '>' && !eof) {
+            if (reclen >= (uint64_t)kp) n_windows += reclen - kp + 1;
+            reclen = 0; run = 0; key = 0; in_header = 1; at_line_start = 0;
+            continue;
+        }
+        if (c == '\n') { at_line_start = 1; continue; }
+        at_line_start = 0;
+        if (c == '\r' || c == ' ' || c == '\t' || c == '\v' || c == '\f') continue;
+        reclen++;
+        int a = aa_code(c);
+        if (a < 0) { run = 0; key = 0; continue; }
+        key = (key >> 5) | ((uint64_t)a << (5 * (kp - 1)));
+        if (++run >= (uint64_t)kp) {
+            if (nk == cap) { cap *= 2; keys = (uint64_t *)realloc(keys, cap * sizeof *keys); }
+            keys[nk++] = key;
+        }
+    }
+    if (reclen >= (uint64_t)kp) n_windows += reclen - kp + 1;
+    qsort(keys, nk, sizeof *keys, cmp_u64);
+    uint64_t nu = 0;
+    for (uint64_t j = 0; j < nk; j++) if (j == 0 || keys[j] != keys[j - 1]) keys[nu++] = keys[j];
+    uint64_t slots = 1024;
+    while (slots < 2 * n_windows) slots <<= 1;
+    uint64_t *tab = (uint64_t *)malloc(slots * sizeof(uint64_t));
+    if (!tab) return -1;
+    memset(tab, 0xFF, slots * sizeof(uint64_t));
+    for (uint64_t j = 0; j < nu; j++) {
+        uint64_t s = mfo_hash64(keys[j], 0, 1) & (slots - 1);
+        while (tab[s] != ~0ULL) s = (s + 1) & (slots - 1);
+        tab[s] = keys[j];
+    }
+    free(keys);
+    out->k = kp; out->kw = 1; out->slots = slots; out->n_keys = nu; out->keys = tab;
+    return 0;
+}
+
+/* hits of one strand given as base codes (0..3, 4 = invalid) */
+static uint32_t strand_hits(const mfo_table *t, const uint8_t *b, uint64_t L, const int8_t *lut)
+{
+    const int kp = t->k; uint32_t hits = 0;
+    for (uint64_t off = 0; off < 3; off++) {
+        uint64_t run = 0, key = 0;
+        for (uint64_t p = off; p + 3 <= L; p += 3) {
+            int a = (b[p] > 3 || b[p + 1] > 3 || b[p + 2] > 3) ? -1 : lut[b[p] * 16 + b[p + 1] * 4 + b[p + 2]];
+            if (a < 0) { run = 0; key = 0; continue; }
+            key = (key >> 5) | ((uint64_t)a << (5 * (kp - 1)));
+            if (++run >= (uint64_t)kp) hits += (uint32_t)mfo_table_contains(t, key, 0);
+        }
+    }
+    return hits;
+}
+
+static uint32_t pread_hits(const mfo_table *t, const mfo_reads *r, uint64_t idx, const int8_t *lut)
+{
+    uint64_t b0 = r->offsets[idx], b1 = r->offsets[idx + 1], L = b1 - b0;
+    uint8_t stack_f[512], stack_r[512];
+    uint8_t *f = L <= 512 ? stack_f : (uint8_t *)malloc(L), *rv = L <= 512 ? stack_r : (uint8_t *)malloc(L);
+    uint64_t ni = npos_lower_bound(r, b0);
+    for (uint64_t g = b0; g < b1; g++) {
+        if (ni < r->n_npos && r->npos[ni] == g) { ni++; f[g - b0] = 4; }
+        else f[g - b0] = (uint8_t)get_base(r, g);
+    }
+    for (uint64_t i = 0; i < L; i++) rv[i] = f[L - 1 - i] > 3 ? 4 : (uint8_t)(3 - f[L - 1 - i]);
+    uint32_t h = strand_hits(t, f, L, lut) + strand_hits(t, rv, L, lut);
+    if (L > 512) { free(f); free(rv); }
+    return h;
+}
+
+int mfo_pfilter(const mfo_table *t, const mfo_reads *r, uint64_t first, uint64_t count, uint32_t thr,
+                int genetic_code, uint32_t *bits, uint32_t *hits, int n_threads)
+{
+    int8_t lut[64];
+    int rc = codon_lut(genetic_code, lut);
+    if (rc) return rc;
+    return filter_impl(t, r, first, count, thr, bits, hits, n_threads, lut);
+}
+
+int mfo_pfilter_fastq_files(const char *bait, int kp, int genetic_code, uint32_t thr, int pair_mode,
+                            const char *fq1, const char *fq2, const char *out1, const char *out2,
+                            uint64_t *kept, uint64_t *total, int n_threads)
+{
+    int8_t lut[64];
+    int rc = codon_lut(genetic_code, lut);
+    if (rc) return rc;
+    char *buf; size_t len;
+    if ((rc = slurp(bait, &buf, &len))) return rc;
+    mfo_table t; rc = mfo_ptable_build(buf, len, kp, &t);
+    free(buf);
+    if (rc) return rc;
+    return files_impl(t, lut, thr, pair_mode, fq1, fq2, out1, out2, kept, total, n_threads);
 }

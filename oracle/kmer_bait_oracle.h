@@ -74,6 +74,17 @@ int  mfo_filter_fastq_files(const char *bait_fasta, int k, uint32_t threshold, i
 
 uint64_t mfo_hash64(uint64_t lo, uint64_t hi, int kw);
 
+/* ---- protein-space baiting (Spec P, oracle/prot_bait_ref.py).  The table
+ * holds peptide k-mers (5 bits per residue, first residue least significant; k = kp in 4..12,
+ * kw = 1) in the same layout; reads are translated in six frames with NCBI genetic code
+ * `genetic_code` (1, 2, 3, 4, 5, 9, 11, 13, 14, 21). */
+int  mfo_ptable_build(const char *protein_fasta_text, size_t len, int kp, mfo_table *out);
+int  mfo_pfilter(const mfo_table *t, const mfo_reads *r, uint64_t first, uint64_t count, uint32_t threshold,
+                 int genetic_code, uint32_t *bits_out, uint32_t *hits_out, int n_threads);
+int  mfo_pfilter_fastq_files(const char *protein_fasta, int kp, int genetic_code, uint32_t threshold, int pair_mode,
+                             const char *fq1, const char *fq2, const char *out1, const char *out2,
+                             uint64_t *kept, uint64_t *total, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

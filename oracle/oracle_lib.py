@@ -52,6 +52,12 @@ def lib():
         L.mfo_filter_fastq_files.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_char_p,
                                              C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                              C.c_int]
+        L.mfo_ptable_build.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(Table)]
+        L.mfo_pfilter.argtypes = [C.POINTER(Table), C.POINTER(Reads), C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int]
+        L.mfo_pfilter_fastq_files.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_char_p,
+                                              C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                              C.c_int]
         L.mfo_hash64.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
         L.mfo_hash64.restype = C.c_uint64
         _lib = L
@@ -120,11 +126,13 @@ class OracleReads:
 
 
 class OracleTable:
-    def __init__(self, fasta_text: str | bytes, k: int):
+    def __init__(self, fasta_text: str | bytes, k: int, protein: bool = False):
+        """protein=True: `fasta_text` is a protein FASTA and k the peptide k-mer length (Spec P)."""
         if isinstance(fasta_text, str):
             fasta_text = fasta_text.encode()
         self._t = Table()
-        _chk(lib().mfo_table_build(fasta_text, len(fasta_text), k, C.byref(self._t)), "table_build")
+        build = lib().mfo_ptable_build if protein else lib().mfo_table_build
+        _chk(build(fasta_text, len(fasta_text), k, C.byref(self._t)), "table_build")
 
     k = property(lambda s: s._t.k)
     kw = property(lambda s: s._t.kw)
@@ -158,4 +166,22 @@ def filter_fastq_files(bait, k, threshold, pair_mode, fq1, fq2, out1, out2, thre
     enc = lambda p: None if p is None else os.fsencode(p)
     _chk(lib().mfo_filter_fastq_files(enc(bait), k, threshold, pair_mode, enc(fq1), enc(fq2), enc(out1), enc(out2),
                                       C.byref(kept), C.byref(total), threads), "filter_fastq_files")
+    return kept.value, total.value
+
+
+def pfilter_reads(table: OracleTable, reads: OracleReads, genetic_code: int, threshold=1, first=0, count=None, threads=1):
+    """Protein-space baiting (Spec P): -> (bits u32[ceil(n/32)], hits u32[n])"""
+    n = reads.n_reads - first if count is None else count
+    bits = np.zeros((n + 31) // 32, dtype=np.uint32)
+    hits = np.zeros(max(n, 1), dtype=np.uint32)
+    _chk(lib().mfo_pfilter(C.byref(table._t), C.byref(reads._r), first, n, threshold, genetic_code,
+                           bits.ctypes.data, hits.ctypes.data, threads), "pfilter")
+    return bits, hits[:n]
+
+
+def pfilter_fastq_files(bait, kp, genetic_code, threshold, pair_mode, fq1, fq2, out1, out2, threads=1):
+    kept, total = C.c_uint64(0), C.c_uint64(0)
+    enc = lambda p: None if p is None else os.fsencode(p)
+    _chk(lib().mfo_pfilter_fastq_files(enc(bait), kp, genetic_code, threshold, pair_mode, enc(fq1), enc(fq2), enc(out1),
+                                       enc(out2), C.byref(kept), C.byref(total), threads), "pfilter_fastq_files")
     return kept.value, total.value

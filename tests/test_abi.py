@@ -17,7 +17,7 @@ def test_exports_match_header(built_lib):
     assert declared == set(mitofilter.EXPORTS)
     for name in declared:
         assert hasattr(built_lib, name), name
-    assert built_lib.mf_abi_version() == 1
+    assert built_lib.mf_abi_version() == 2
 
 
 def test_no_cpu_fallback(built_lib):
@@ -26,6 +26,8 @@ def test_no_cpu_fallback(built_lib):
         pytest.skip("a GPU is visible")
     with pytest.raises(mf.MitoFilterError, match="no CPU fallback|no HIP device"):
         mf.KmerSet.from_text(">a\n" + "ACGT" * 20 + "\n", 31)
+    with pytest.raises(mf.MitoFilterError, match="no CPU fallback|no HIP device"):
+        mf.KmerSet.protein_from_text(">p\nMLSFIVGATMPYNWKEDHQRC\n", 7, 5)
 
 
 def test_product_does_not_touch_oracle():

@@ -79,3 +79,41 @@ def test_build_lib_writes_reference_layout(tmp_path, monkeypatch):
     m = w.MEGAHIT(fq1="/d/s.fq", fq2=None, temp_dir=str(tmp_path), read_lib=str(tmp_path / "se.lib"))
     m.build_lib()
     assert (tmp_path / "se.lib").read_text() == "/d/s.fq\nse /d/s.fq\n"
+
+
+FAKE_CORE = """#!/bin/bash
+# stands in for `megahit_core buildlib LIB LIB`: reads the mates named by the lib's second line
+lib=$2; line=$(sed -n 2p "$lib"); set -- $line
+if [ "$1" = pe ]; then cat "$2" > "$lib.m1" & cat "$3" > "$lib.m2"; wait; else cat "$2" > "$lib.m1"; fi
+"""
+
+
+def test_build_lib_fifo_handoff_plumbing(tmp_path, monkeypatch):
+    """bait_fifo: survivors reach `buildlib` through named pipes (ref :176-184 does the same for gunzipped
+    reads).  The filter is a stub here (no GPU on this box); tests/test_gpu_parity.py runs the real one."""
+    from mitoflex_amd.assemble import assemble_wrapper as w
+    stub = tmp_path / "fastfilter"
+    stub.write_text("#!/bin/bash\n# bait --bait B --kmer K --threshold T --fq1 A --fq2 B --out1 X --out2 Y ...\n"
+                    "while [ $# -gt 0 ]; do case $1 in --fq1) a=$2;; --fq2) b=$2;; --out1) x=$2;; --out2) y=$2;; esac; shift; done\n"
+                    "cat $a > $x & [ -n \"$b\" ] && cat $b > $y; wait; echo 7\n")
+    stub.chmod(0o755)
+    core = tmp_path / "megahit_core"
+    core.write_text(FAKE_CORE)
+    core.chmod(0o755)
+    (tmp_path / "a_1.fq").write_text("@r\nACGT\n+\nIIII\n")
+    (tmp_path / "a_2.fq").write_text("@r\nTTTT\n+\nIIII\n")
+    monkeypatch.setattr(w.MEGAHIT, "FAST_FILTER", property(lambda self: str(stub)))
+    monkeypatch.setattr(w.MEGAHIT, "MEGAHIT_CORE", str(core))
+    monkeypatch.setattr(w.a_conf, "bait_fasta", str(tmp_path / "bait.fa"))
+    monkeypatch.setattr(w.a_conf, "bait_fifo", True)
+    t = tmp_path / "t"; t.mkdir()
+    m = w.MEGAHIT(fq1=str(tmp_path / "a_1.fq"), fq2=str(tmp_path / "a_2.fq"), temp_dir=str(t), read_lib=str(t / "reads.lib"))
+    m.build_lib()
+    assert (t / "reads.lib").read_text() == f"{tmp_path}/a_1.fq,{tmp_path}/a_2.fq\npe {t}/pipe.bait1 {t}/pipe.bait2\n"
+    assert (t / "reads.lib.m1").read_text() == "@r\nACGT\n+\nIIII\n" and (t / "reads.lib.m2").read_text() == "@r\nTTTT\n+\nIIII\n"
+    assert m.bait_kept == 7
+    t2 = tmp_path / "t2"; t2.mkdir()
+    m = w.MEGAHIT(fq1=str(tmp_path / "a_1.fq"), fq2=None, temp_dir=str(t2), read_lib=str(t2 / "reads.lib"))
+    m.build_lib()
+    assert (t2 / "reads.lib").read_text() == f"{tmp_path}/a_1.fq\nse {t2}/pipe.bait1\n"
+    assert (t2 / "reads.lib.m1").read_text() == "@r\nACGT\n+\nIIII\n"

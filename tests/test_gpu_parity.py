@@ -153,6 +153,36 @@ def test_fastq_files_match_oracle(mf, ol, bait_text, tmp_path, gz, batch, monkey
     assert np.array_equal(mf.filter_reads(ks, reads, 1)[0], ol.filter_reads(t, R, 1)[0])
 
 
+def test_fifo_handoff_to_buildlib(mf, ol, bait_text, tmp_path, monkeypatch):
+    """MEGAHIT.build_lib() with bait_fifo streams the survivors of the real HIP filter
+    to `megahit_core buildlib` through named pipes; what the (stand-in) reader receives is byte for byte
+    what the oracle writes to files."""
+    from mitoflex_amd.assemble import assemble_wrapper as w
+    from tests.test_callsite import FAKE_CORE
+    core = tmp_path / "megahit_core"
+    core.write_text(FAKE_CORE)
+    core.chmod(0o755)
+    fq1, fq2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    write_fastq(fq1, make_reads(bait_text, 20000, seed=11), "a")
+    write_fastq(fq2, make_reads(bait_text, 20000, seed=12), "b")
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    monkeypatch.setattr(w.MEGAHIT, "MEGAHIT_CORE", str(core))
+    monkeypatch.setattr(w.a_conf, "bait_fasta", bait)
+    monkeypatch.setattr(w.a_conf, "bait_fifo", True)
+    for pe in (True, False):
+        t = tmp_path / ("pe" if pe else "se")
+        t.mkdir()
+        m = w.MEGAHIT(fq1=fq1, fq2=fq2 if pe else None, temp_dir=str(t), read_lib=str(t / "reads.lib"))
+        m.build_lib()
+        o1, o2 = str(t / "o1.fq"), str(t / "o2.fq")
+        ok, _ = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2 if pe else None, o1, o2 if pe else None, threads=2)
+        assert m.bait_kept == ok and ok > 0
+        assert open(str(t / "reads.lib.m1"), "rb").read() == open(o1, "rb").read()
+        if pe:
+            assert open(str(t / "reads.lib.m2"), "rb").read() == open(o2, "rb").read()
+
+
 # --------------------------------------------------------------------------- full-size properties
 FULL = 33_333_334          # BASELINE.json configs[1]: 5 Gbp of 150-base reads
 

@@ -99,3 +99,35 @@ def write_fastq(path: str, seqs: List[str], prefix: str = "r", crlf: bool = Fals
 
 def bits_to_bool(bits: np.ndarray, n: int) -> np.ndarray:
     return np.unpackbits(bits.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def make_protein_bait(seed: int = 20261003, n_records: int = 12, code: int = 5):
+    """A small synthetic protein database in the style of profile/MT_database (one record per gene,
+    residues on one or several lines) plus the DNA of genes that translate to it under genetic code
+    `code` -- the DNA is what reads are sampled from.  Returns (protein_fasta, gene_dna_fasta).
+    Oddities on purpose: an 'X', a 'B', lower case, a trailing '*', a CRLF line, a record shorter
+    than any k-mer, the same peptide in two records."""
+    from oracle import prot_bait_ref as pr
+    rng = random.Random(seed)
+    # residue frequencies roughly like mitochondrial proteins (L, S, F, I heavy)
+    weights = {"L": 16, "S": 10, "F": 9, "I": 8, "V": 7, "G": 7, "A": 6, "T": 6, "M": 5, "P": 4, "Y": 4, "N": 4,
+               "W": 3, "K": 2, "E": 2, "D": 2, "H": 2, "Q": 2, "R": 2, "C": 1}
+    aas, w = list(weights), list(weights.values())
+    prots = ["".join(rng.choices(aas, weights=w, k=rng.randint(120, 520))) for _ in range(n_records)]
+    prots[3] = prots[3][:200] + prots[1][50:110] + prots[3][200:]          # shared peptide stretch
+    genes = [pr.back_translate(p, code, rng) for p in prots]
+    shown = list(prots)
+    shown[0] = shown[0][:40] + "X" + shown[0][41:90] + "B" + shown[0][91:]
+    shown[2] = shown[2][:100] + shown[2][100:160].lower() + shown[2][160:] + "*"
+    lines_p, lines_g = [], []
+    for i, (p, g) in enumerate(zip(shown, genes)):
+        lines_p.append(f">gi_SYN{i:03d}_GENE{i}_Synthetica_sp._{len(p)}_aa")
+        if i % 3 == 0:
+            lines_p.append(p)
+        else:
+            lines_p += [p[j:j + 60] for j in range(0, len(p), 60)]
+        lines_g.append(f">gene{i}")
+        lines_g.append(g)
+    lines_p[2] = lines_p[2] + "\r"
+    lines_p += [">tiny", "MLS"]
+    return "\n".join(lines_p) + "\n", "\n".join(lines_g) + "\n"
