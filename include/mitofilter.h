@@ -160,8 +160,11 @@ int mf_filter(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, i
               uint32_t *out_bits, uint32_t *hits_out, mf_filter_stats_t *stats);
 
 /* Same, result left on the device (no D2H); for timing loops.  Runs `steps`
- * passes back to back on the library's stream and reports per-pass averages
- * measured with hipEvents on that stream. */
+ * passes back to back on the library's stream.  ms_total is the whole loop
+ * (one event pair around it) divided by steps; the per-kernel times are
+ * averages over the passes that carry events between their kernels -- every
+ * pass up to 8 steps, every 8th pass beyond (the events themselves cost
+ * about 16 us per pass). */
 int mf_filter_resident(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
                        int steps, mf_filter_stats_t *stats);
 

@@ -538,12 +538,21 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         if (!r->d_hits) HIPCHK(hipMalloc(&r->d_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4));
         HIPCHK(hipMemsetAsync(r->d_hits, 0, (r->v.n_reads ? r->v.n_reads : 1) * 4, st));
     }
-    std::vector<hipEvent_t> ev((size_t)steps * 4);
+    // per-kernel timing with events between the kernels costs a few microseconds of command-processor work per pass,
+    // so long timing loops sample every `stride`-th pass; the whole loop is bracketed by its own pair of events
+    int stride = steps <= 8 ? 1 : (int)env_u32("MF_EVENT_STRIDE", 8);
+    if (stride < 1) stride = 1;
+    const int n_sampled = (steps + stride - 1) / stride;
+    std::vector<hipEvent_t> ev((size_t)n_sampled * 4);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    hipEvent_t e_begin, e_end;
+    HIPCHK(hipEventCreate(&e_begin)); HIPCHK(hipEventCreate(&e_end));
+    HIPCHK(hipEventRecord(e_begin, st));
     for (int i = 0; i < steps; i++) {
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, &ev[(size_t)i * 4]);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, i % stride == 0 ? &ev[(size_t)(i / stride) * 4] : nullptr);
         if (rc) return rc;
     }
+    HIPCHK(hipEventRecord(e_end, st));
     std::vector<unsigned long long> part(EXACT_MAX_GRID * 2, 0);
     HIPCHK(hipMemcpyAsync(part.data(), r->d_counters, EXACT_MAX_GRID * 16, hipMemcpyDeviceToHost, st));
     if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits, ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
@@ -554,8 +563,8 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     if (stats) {
         memset(stats, 0, sizeof *stats);
         float tot = 0, scr = 0, mrk = 0, exa = 0, t;
-        HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[(size_t)steps * 4 - 2]));
-        for (int i = 0; i < steps; i++) {
+        HIPCHK(hipEventElapsedTime(&tot, e_begin, e_end));
+        for (int i = 0; i < n_sampled; i++) {
             hipEvent_t *e = &ev[(size_t)i * 4];
             HIPCHK(hipEventElapsedTime(&t, e[0], e[3])); scr += t;
             HIPCHK(hipEventElapsedTime(&t, e[3], e[1])); mrk += t;
@@ -563,10 +572,11 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         }
         stats->n_reads = r->v.n_reads; stats->n_pass = cnt[0];
         stats->n_candidates = (mode == MF_MODE_SCREENED && T->view.s > 0) ? cnt[1] : r->v.n_reads;
-        stats->ms_total = tot / steps; stats->ms_screen = scr / steps; stats->ms_mark = mrk / steps; stats->ms_exact = exa / steps;
+        stats->ms_total = tot / steps; stats->ms_screen = scr / n_sampled; stats->ms_mark = mrk / n_sampled; stats->ms_exact = exa / n_sampled;
         stats->algorithmic_bytes = algorithmic_bytes(r->v);
     }
     for (auto &e : ev) hipEventDestroy(e);
+    hipEventDestroy(e_begin); hipEventDestroy(e_end);
     return MF_OK;
 }
 
