@@ -356,6 +356,8 @@ struct mf_reads {
     void *d_recs = nullptr; uint32_t *d_rec_counts = nullptr;     // stage-1 positive records (screen -> mark)
     unsigned long long *d_counters = nullptr;
     size_t bitmap_bytes = 0;
+    // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
+    size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0;
 };
 
 static void reads_release(mf_reads *r)
@@ -369,19 +371,27 @@ static void reads_release(mf_reads *r)
     delete r;
 }
 
-// words_padded: host buffer already padded to padded_words_for(n_words) (or nullptr with words_raw given)
-static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets, uint64_t n_reads,
-                        uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos, int device,
-                        mf_reads **out)
+// grow a device buffer to at least `bytes` (with some slack when it is being re-used)
+template <class T> static hipError_t dev_reserve(T *&p, size_t &cap, size_t bytes, bool slack)
 {
-    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    const size_t want = slack ? bytes + bytes / 4 + 4096 : (bytes ? bytes : 16);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+}
+
+// Fill `r` (fresh, or holding buffers of an earlier batch on the same device) with one packed read set.
+// words: host buffer; already_padded = it extends to padded_words_for(n_words) with a zero tail.
+static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets,
+                      uint64_t n_reads, uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos,
+                      DevCtx *ctx)
+{
     hipStream_t st = ctx->stream;
-    mf_reads *r = new (std::nothrow) mf_reads();
-    if (!r) return fail(MF_E_NOMEM, "out of memory");
-    r->device = device;
     const uint64_t padded = padded_words_for(n_words);
-#define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { reads_release(r); return fail(MF_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
-    RCHK(hipMalloc(&r->d_words, padded * 4));
+#define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(MF_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+    RCHK(dev_reserve(r->d_words, r->cap_words, padded * 4, reuse));
     if (already_padded) {
         RCHK(hipMemcpyAsync(r->d_words, words, padded * 4, hipMemcpyHostToDevice, st));
     } else {
@@ -389,34 +399,55 @@ static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_pa
         if (n_words) RCHK(hipMemcpyAsync(r->d_words, words, n_words * 4, hipMemcpyHostToDevice, st));
     }
     if (!uniform_len) {
-        RCHK(hipMalloc(&r->d_offsets, (n_reads + 1) * 8));
+        RCHK(dev_reserve(r->d_offsets, r->cap_offsets, (n_reads + 1) * 8, reuse));
         RCHK(hipMemcpyAsync(r->d_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
     }
-    RCHK(hipMalloc(&r->d_npos, (n_npos ? n_npos : 1) * 8));
+    RCHK(dev_reserve(r->d_npos, r->cap_npos, (n_npos ? n_npos : 1) * 8, reuse));
     if (n_npos) RCHK(hipMemcpyAsync(r->d_npos, npos, n_npos * 8, hipMemcpyHostToDevice, st));
     r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;
-    RCHK(hipMalloc(&r->d_has_n, r->bitmap_bytes));
-    RCHK(hipMalloc(&r->d_cand, r->bitmap_bytes));
-    RCHK(hipMalloc(&r->d_bits, r->bitmap_bytes));
-    RCHK(hipMalloc(&r->d_counters, EXACT_MAX_GRID * 16));
+    if (r->bitmap_bytes > r->cap_bitmap || !r->d_has_n) {     // the three bitmaps share one capacity
+        size_t c0 = 0, c1 = 0, c2 = 0;
+        if (r->d_has_n) { hipFree(r->d_has_n); r->d_has_n = nullptr; }
+        if (r->d_cand) { hipFree(r->d_cand); r->d_cand = nullptr; }
+        if (r->d_bits) { hipFree(r->d_bits); r->d_bits = nullptr; }
+        RCHK(dev_reserve(r->d_has_n, c0, r->bitmap_bytes, reuse));
+        RCHK(dev_reserve(r->d_cand, c1, r->bitmap_bytes, reuse));
+        RCHK(dev_reserve(r->d_bits, c2, r->bitmap_bytes, reuse));
+        r->cap_bitmap = c0 < c1 ? (c0 < c2 ? c0 : c2) : (c1 < c2 ? c1 : c2);
+    }
+    if (!r->d_counters) RCHK(hipMalloc(&r->d_counters, EXACT_MAX_GRID * 16));
     RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
     RCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
     RCHK(hipMemsetAsync(r->d_counters, 0, EXACT_MAX_GRID * 16, st));
     RCHK(hipMemsetAsync(r->d_bits, 0, r->bitmap_bytes, st));
     ReadsView &V = r->v;
+    V = ReadsView{};
     V.words = r->d_words; V.n_words = n_words; V.n_vec = (padded - 16) / 4;
-    V.offsets = r->d_offsets; V.uniform_len = uniform_len; V.n_reads = n_reads; V.total_bases = total_bases;
+    V.offsets = uniform_len ? nullptr : r->d_offsets; V.uniform_len = uniform_len; V.n_reads = n_reads; V.total_bases = total_bases;
     V.len_magic = uniform_len > 1 ? ~0ULL / uniform_len + 1 : 0;
     V.len_magic32 = (uniform_len > 1 && uniform_len <= 4096) ? 0xFFFFFFFFu / uniform_len + 1 : 0;
     V.npos = r->d_npos; V.n_npos = n_npos; V.has_n = r->d_has_n;
     {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %
         const uint64_t grid = screen_grid_for(V, ctx->n_cu), cap = screen_rec_cap_for(V, ctx->n_cu);
-        RCHK(hipMalloc(&r->d_recs, (grid * cap ? grid * cap : 1) * 16));
-        RCHK(hipMalloc(&r->d_rec_counts, (grid ? grid : 1) * 4));
+        RCHK(dev_reserve(r->d_recs, r->cap_recs, (grid * cap ? grid * cap : 1) * 16, reuse));
+        RCHK(dev_reserve(r->d_rec_counts, r->cap_rec_counts, (grid ? grid : 1) * 4, reuse));
     }
     RCHK(launch_mark_has_n(V, r->d_has_n, st));
     RCHK(hipStreamSynchronize(st));
 #undef RCHK
+    return MF_OK;
+}
+
+static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets, uint64_t n_reads,
+                        uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos, int device,
+                        mf_reads **out)
+{
+    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;
+    mf_reads *r = new (std::nothrow) mf_reads();
+    if (!r) return fail(MF_E_NOMEM, "out of memory");
+    r->device = device;
+    rc = reads_fill(r, false, words, n_words, already_padded, offsets, n_reads, total_bases, uniform_len, npos, n_npos, ctx);
+    if (rc) { reads_release(r); return rc; }
     *out = r;
     return MF_OK;
 }
@@ -535,7 +566,7 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     hipStream_t st = ctx->stream;
     const bool count_all = hits_out != nullptr;
     if (count_all) {
-        if (!r->d_hits) HIPCHK(hipMalloc(&r->d_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4));
+        HIPCHK(dev_reserve(r->d_hits, r->cap_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4, false));
         HIPCHK(hipMemsetAsync(r->d_hits, 0, (r->v.n_reads ? r->v.n_reads : 1) * 4, st));
     }
     // per-kernel timing with events between the kernels costs a few microseconds of command-processor work per pass,
@@ -622,21 +653,30 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
 
     const int hw = (int)std::thread::hardware_concurrency();
     // pack threads: what is left after the readers, writers and device workers
-    int pack_threads = hw - 4 - n_devices; if (pack_threads < 1) pack_threads = 1; if (pack_threads > 32) pack_threads = 32;
+    int pack_threads = hw - 4 - n_devices; if (pack_threads < 1) pack_threads = 1; if (pack_threads > 64) pack_threads = 64;
+    pack_threads = (int)env_u32("MF_PACK_THREADS", (uint32_t)pack_threads);
+    if (pack_threads < 1) pack_threads = 1;
     const uint64_t batch_reads = env_u32("MF_BATCH_READS", 2000000);
-    BatchFilterFn fn = [ks, threshold](int device, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
+    // one refillable device-side read set per device worker: steady-state batches do not touch the allocator
+    std::vector<mf_reads *> arena((size_t)n_devices, nullptr);
+    BatchFilterFn fn = [ks, threshold, &arena](int device, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
         bits.assign((n + 31) / 32 + 1, 0);
         if (n == 0) return MF_OK;
-        mf_reads *R = nullptr;
-        int rc = reads_upload(P.words.data(), P.n_words, true, P.offsets.data(), n, P.offsets[n], P.uniform_len,
-                              P.npos.data(), P.npos.size(), device, &R);
-        if (rc == MF_OK) rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, bits.data(), nullptr, 1, nullptr);
-        if (R) reads_release(R);
+        DevCtx *ctx; int rc = get_ctx(device, &ctx);
+        if (rc == MF_OK && !arena[device]) {
+            arena[device] = new (std::nothrow) mf_reads();
+            if (!arena[device]) rc = fail(MF_E_NOMEM, "out of memory"); else arena[device]->device = device;
+        }
+        if (rc == MF_OK)
+            rc = reads_fill(arena[device], true, P.words.data(), P.n_words, true, P.offsets.data(), n, P.offsets[n], P.uniform_len,
+                            P.npos.data(), P.npos.size(), ctx);
+        if (rc == MF_OK) rc = filter_common(ks, arena[device], threshold, MF_MODE_SCREENED, bits.data(), nullptr, 1, nullptr);
         if (rc != MF_OK) err = t_err;
         return rc;
     };
     PipelineStats ps; std::string perr;
     const int rc = run_fastq_pipeline(fq1, fq2, out1, out2, pair_mode == MF_PAIR_BOTH, n_devices, pack_threads, batch_reads, fn, ps, perr);
+    for (mf_reads *a : arena) reads_release(a);
     if (rc != MF_OK) return fail(rc, "%s", perr.c_str());
     if (kept) *kept = ps.kept;
     if (total) *total = ps.total;

@@ -2,7 +2,9 @@
 #include "mf_host.h"
 #include "mf_kernels_cfg.h"
 
+#include <immintrin.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 #include <zlib.h>
@@ -221,51 +223,140 @@ uint32_t detect_uniform_len(const uint64_t *off, uint64_t n)
     return (uint32_t)L;
 }
 
+// 32 sequence bytes -> 64 bits of 2-bit codes (invalid bytes code 0) + a bit mask of the invalid ones.
+// Case is folded with & 0xDF; of a folded byte, bits 1-2 tell A, C, T, G apart as 0, 1, 2, 3, and
+// x ^ (x >> 1) turns that into A, C, G, T = 0, 1, 2, 3.
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2"))) static inline uint64_t codes32_avx2(const unsigned char *s, uint32_t &invalid)
+{
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s));
+    const __m256i f = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(f, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(f, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(f, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(f, _mm256_set1_epi8('T'))));
+    const __m256i x = _mm256_and_si256(_mm256_srli_epi16(f, 1), _mm256_set1_epi8(3));
+    const __m256i c = _mm256_and_si256(_mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(1))), ok);
+    invalid = ~(uint32_t)_mm256_movemask_epi8(ok);
+    const uint64_t m = 0x0303030303030303ULL;
+    return _pext_u64((uint64_t)_mm256_extract_epi64(c, 0), m) | (_pext_u64((uint64_t)_mm256_extract_epi64(c, 1), m) << 16) |
+           (_pext_u64((uint64_t)_mm256_extract_epi64(c, 2), m) << 32) | (_pext_u64((uint64_t)_mm256_extract_epi64(c, 3), m) << 48);
+}
+#endif
+
+// pack records [lo, hi).  The words that lie entirely inside the range are written plainly (and only
+// once: nothing zero-fills the buffer first); the first and the last word may be shared with the
+// neighbouring ranges -- those were zeroed by the caller and are OR-ed atomically.
+// The same function body is compiled twice: plain, and for AVX2 + BMI2 (picked at run time).
+#define MF_PACK_RANGE_BODY(SIMD_LOOP)                                                                            \
+    if (lo >= hi || offsets[lo] == offsets[hi]) return;                                                          \
+    uint64_t g = offsets[lo];                                                                                    \
+    uint64_t wi = g >> 4;                                                                                        \
+    const uint64_t first_w = wi, last_w = (offsets[hi] - 1) >> 4;   /* may be shared with neighbours */          \
+    unsigned __int128 acc = 0; int nb = 2 * (int)(g & 15);          /* bits of the current word already taken */ \
+    auto flush = [&](uint64_t w, uint32_t v) {                                                                   \
+        if (w == first_w || w == last_w) __atomic_fetch_or(&words[w], v, __ATOMIC_RELAXED);                      \
+        else words[w] = v;                                                                                       \
+    };                                                                                                           \
+    auto emit = [&](uint64_t bits, int n_bases) {                    /* append n_bases (<= 32) codes */           \
+        acc |= (unsigned __int128)bits << nb;                                                                    \
+        nb += 2 * n_bases;                                                                                       \
+        while (nb >= 32) { flush(wi++, (uint32_t)acc); acc >>= 32; nb -= 32; }                                   \
+    };                                                                                                           \
+    for (uint64_t r = lo; r < hi; r++) {                                                                         \
+        const unsigned char *s = (const unsigned char *)recs[r].s;                                               \
+        const uint32_t L = recs[r].sl;                                                                           \
+        uint32_t i = 0;                                                                                          \
+        SIMD_LOOP                                                                                                \
+        while (i < L) {                                              /* the tail (or everything without AVX2) */ \
+            const uint32_t n = L - i < 32 ? L - i : 32;                                                          \
+            uint64_t bits = 0;                                                                                   \
+            for (uint32_t j = 0; j < n; j++) {                                                                   \
+                const uint32_t c = g_lut.t[s[i + j]];                                                            \
+                if (c == 4) npos.push_back(g + i + j); else bits |= (uint64_t)c << (2 * j);                      \
+            }                                                                                                    \
+            emit(bits, (int)n);                                                                                  \
+            i += n;                                                                                              \
+        }                                                                                                        \
+        g += L;                                                                                                  \
+    }                                                                                                            \
+    if (nb) flush(wi, (uint32_t)acc);
+
+static void pack_range_plain(const FqRec *recs, uint64_t lo, uint64_t hi, const uint64_t *offsets, uint32_t *words,
+                             std::vector<uint64_t> &npos)
+{
+    MF_PACK_RANGE_BODY()
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2")))
+static void pack_range_avx2(const FqRec *recs, uint64_t lo, uint64_t hi, const uint64_t *offsets, uint32_t *words,
+                            std::vector<uint64_t> &npos)
+{
+    MF_PACK_RANGE_BODY(
+        for (; i + 32 <= L; i += 32) {
+            uint32_t bad;
+            const uint64_t bits = codes32_avx2(s + i, bad);
+            for (; bad; bad &= bad - 1) npos.push_back(g + i + (uint32_t)__builtin_ctz(bad));
+            emit(bits, 32);
+        })
+}
+#endif
+
 static void pack_range(const FqRec *recs, uint64_t lo, uint64_t hi, const uint64_t *offsets, uint32_t *words,
                        std::vector<uint64_t> &npos)
 {
-    if (lo >= hi || offsets[lo] == offsets[hi]) return;
-    uint64_t g = offsets[lo];
-    uint64_t wi = g >> 4;
-    const uint64_t first_w = wi, last_w = (offsets[hi] - 1) >> 4;   // may be shared with neighbours
-    uint32_t acc = 0; int pos = 2 * (int)(g & 15);
-    auto flush = [&](uint64_t w, uint32_t v) {
-        if (w == first_w || w == last_w) __atomic_fetch_or(&words[w], v, __ATOMIC_RELAXED);
-        else words[w] = v;
-    };
-    for (uint64_t r = lo; r < hi; r++) {
-        const unsigned char *s = (const unsigned char *)recs[r].s;
-        const uint32_t L = recs[r].sl;
-        for (uint32_t i = 0; i < L; i++, g++) {
-            const uint32_t c = g_lut.t[s[i]];
-            if (c == 4) npos.push_back(g); else acc |= c << pos;
-            pos += 2;
-            if (pos == 32) { flush(wi, acc); wi++; acc = 0; pos = 0; }
-        }
-    }
-    if (pos) flush(wi, acc);
+#if defined(__x86_64__)
+    static const bool simd = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("MF_NO_SIMD");
+    if (simd) { pack_range_avx2(recs, lo, hi, offsets, words, npos); return; }
+#endif
+    pack_range_plain(recs, lo, hi, offsets, words, npos);
 }
 
 void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &out)
 {
-    out = PackedHost();
+    out.npos.clear(); out.uniform_len = 0; out.n_words = 0;     // buffers keep their capacity (batches are recycled)
     out.offsets.resize(count + 1);
-    uint64_t g = 0;
-    for (uint64_t i = 0; i < count; i++) { out.offsets[i] = g; g += recs[i].sl; }
-    out.offsets[count] = g;
-    out.n_words = (g + 15) / 16;
-    out.words.assign(padded_words_for(out.n_words), 0u);
-    out.uniform_len = detect_uniform_len(out.offsets.data(), count);
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > count) threads = count ? (int)count : 1;
-    std::vector<std::vector<uint64_t>> np(threads);
-    std::vector<std::thread> th;
-    for (int t = 0; t < threads; t++) {
-        const uint64_t lo = count * t / threads, hi = count * (t + 1) / threads;
-        if (threads == 1) pack_range(recs, lo, hi, out.offsets.data(), out.words.data(), np[t]);
-        else th.emplace_back(pack_range, recs, lo, hi, out.offsets.data(), out.words.data(), std::ref(np[t]));
+    auto run = [&](auto fn) {                               // fn(t) on `threads` workers
+        if (threads == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    auto lo_of = [&](int t) { return count * (uint64_t)t / (uint64_t)threads; };
+    // offsets: per-range sums, then the running offsets of every range; the uniform-length test rides along
+    std::vector<uint64_t> sum(threads + 1, 0);
+    std::vector<uint8_t> uni(threads, 1);
+    const uint32_t L0 = count ? recs[0].sl : 0;
+    run([&](int t) {
+        uint64_t s = 0; bool u = true;
+        for (uint64_t i = lo_of(t), e = lo_of(t + 1); i < e; i++) { s += recs[i].sl; u = u && recs[i].sl == L0; }
+        sum[t + 1] = s; uni[t] = u;
+    });
+    for (int t = 0; t < threads; t++) sum[t + 1] += sum[t];
+    const uint64_t total = sum[threads];
+    out.offsets[count] = total;
+    out.n_words = (total + 15) / 16;
+    const uint64_t padded = padded_words_for(out.n_words);
+    out.words.resize(padded);                                // not zero-filled (DefaultInitAlloc)
+    bool uniform = count > 0 && L0 > 0;
+    for (int t = 0; t < threads; t++) uniform = uniform && uni[t];
+    out.uniform_len = uniform ? L0 : 0;
+    run([&](int t) {
+        uint64_t g = sum[t];
+        for (uint64_t i = lo_of(t), e = lo_of(t + 1); i < e; i++) { out.offsets[i] = g; g += recs[i].sl; }
+    });
+    // words shared by two ranges (and the padding tail) must start from zero
+    uint32_t *W = out.words.data();
+    for (int t = 0; t <= threads; t++) {
+        const uint64_t g = out.offsets[t == threads ? count : lo_of(t)];      // a range boundary, in bases
+        W[g >> 4] = 0;                                       // first word of the range that starts here
+        if (g) W[(g - 1) >> 4] = 0;                          // last word of the range that ends here
     }
-    for (auto &x : th) x.join();
+    memset(W + out.n_words, 0, (padded - out.n_words) * sizeof(uint32_t));
+    std::vector<std::vector<uint64_t>> np(threads);
+    run([&](int t) { pack_range(recs, lo_of(t), lo_of(t + 1), out.offsets.data(), W, np[t]); });
     for (auto &v : np) out.npos.insert(out.npos.end(), v.begin(), v.end());   // ranges ascend with t
 }
 

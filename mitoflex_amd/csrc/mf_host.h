@@ -6,7 +6,10 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace mf {
@@ -47,16 +50,25 @@ struct FqRec { const char *h, *s, *q; uint32_t hl, sl, ql; };
 // strict 4-line records over an in-memory buffer (pointers into buf)
 void parse_fastq(const char *buf, size_t len, std::vector<FqRec> &recs);
 
+// allocator whose construct() default-initialises: a vector of it can be sized without being zero-filled
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+using WordVec = std::vector<uint32_t, DefaultInitAlloc<uint32_t>>;
+using U64Vec = std::vector<uint64_t, DefaultInitAlloc<uint64_t>>;
+
 struct PackedHost {
-    std::vector<uint32_t> words;    // padded (see pad_words_for)
+    WordVec words;                  // padded (see pad_words_for); every word is written by pack_records
     uint64_t n_words = 0;
-    std::vector<uint64_t> offsets;  // n_reads + 1
+    U64Vec offsets;                 // n_reads + 1
     std::vector<uint64_t> npos;
     uint32_t uniform_len = 0;       // >0 when all reads share one length
 };
 // words needed so the screen kernel can walk whole chunks past the end
 uint64_t padded_words_for(uint64_t n_words);
-// pack records [first, first+count) with `threads` workers
+// pack records [first, first+count) with `threads` workers; `out` keeps its capacity when it is reused
 void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &out);
 uint32_t detect_uniform_len(const uint64_t *offsets, uint64_t n_reads);
 

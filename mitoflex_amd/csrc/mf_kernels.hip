@@ -799,8 +799,8 @@ __global__ void mark_has_n_kernel(ReadsView R, uint32_t *has_n)
 // ------------------------------------------------- FASTQ quality filter (filter_v2)
 // Per-read counts the reference's quality filter decides on (filter/filter_bin/src/main.rs:236-243,
 // 302-307): number of 'N' in the (cut) sequence, number of quality bytes <= q in the (cut) quality
-// string.  The FASTQ text is uploaded as it is; a record is four offsets into it.  16 lanes per
-// record, byte loads coalesced inside the record, counts reduced with 16-wide shuffles.
+// string.  The FASTQ text is uploaded as it is; a record is four offsets into it.  Eight lanes per
+// record, aligned 16-byte loads coalesced inside the record, counts reduced with 8-wide shuffles.
 // bytes of w inside [lo, hi) (byte addresses; w sits at address `addr`) as a 0x80-per-byte mask
 __device__ __forceinline__ uint32_t byte_window80(uint32_t addr, uint32_t lo, uint32_t hi)
 {
@@ -810,48 +810,66 @@ __device__ __forceinline__ uint32_t byte_window80(uint32_t addr, uint32_t lo, ui
     return upto1 & ~upto0 & 0x80808080u;
 }
 
+constexpr int QS_LANES = 8;         // lanes per record
+
+__device__ __forceinline__ uint32_t count_n_bytes(const uint4 v, uint32_t blk, uint32_t lo, uint32_t hi)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t x = w[j] ^ 0x4E4E4E4Eu;                                      // zero byte <=> 'N'
+        const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 exactly in zero bytes
+        c += __popc(z & byte_window80(blk * 16 + 4 * j, lo, hi));
+    }
+    return c;
+}
+
+__device__ __forceinline__ uint32_t count_lowq_bytes(const uint4 v, uint32_t blk, uint32_t lo, uint32_t hi, uint32_t q1)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t d = (w[j] | 0x80808080u) - q1;                               // per byte, no borrow: top bit clear <=> low7 <= q
+        c += __popc(~d & ~w[j] & byte_window80(blk * 16 + 4 * j, lo, hi));
+    }
+    return c;
+}
+
 __global__ void __launch_bounds__(256)
 qualscan_kernel(const uint8_t *__restrict__ text, const QualRec *__restrict__ recs, uint32_t n, uint32_t quality,
                 uint32_t *__restrict__ n_count, uint32_t *__restrict__ bad_count)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = t >> 4, l16 = t & 15;
+    const uint32_t r = t / QS_LANES, l = t % QS_LANES;
     uint32_t nn = 0, nb = 0;
     if (r < n) {
         const QualRec rec = recs[r];
         const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(text);
-        // 16-byte aligned blocks covering the string, one per lane per step; bytes outside the string are
-        // masked.  Byte tests are done four at a time on the dwords (SWAR), exact for every byte value.
-        {   // sequence: bytes == 'N'
-            const uint32_t lo = rec.s_off, hi = rec.s_off + rec.s_len;
-            for (uint32_t blk = (lo >> 4) + l16; rec.s_len && blk <= ((hi - 1) >> 4); blk += 16) {
-                const uint4 v = t4[blk];
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t x = w[j] ^ 0x4E4E4E4Eu;                              // zero byte <=> 'N'
-                    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 exactly in zero bytes
-                    nn += __popc(z & byte_window80(blk * 16 + 4 * j, lo, hi));
-                }
-            }
-        }
-        {   // quality: bytes <= q  (q <= 100 < 0x80, so a byte with its top bit set never counts)
-            const uint32_t lo = rec.q_off, hi = rec.q_off + rec.q_len;
-            const uint32_t q1 = (quality + 1) * 0x01010101u;
-            for (uint32_t blk = (lo >> 4) + l16; rec.q_len && blk <= ((hi - 1) >> 4); blk += 16) {
-                const uint4 v = t4[blk];
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t d = (w[j] | 0x80808080u) - q1;                       // per byte, no borrow: top bit clear <=> low7 <= q
-                    nb += __popc(~d & ~w[j] & byte_window80(blk * 16 + 4 * j, lo, hi));
-                }
-            }
+        // 16-byte aligned blocks covering the two strings; bytes outside a string are masked.  Byte tests are done
+        // four at a time on the dwords (SWAR), exact for every byte value (q <= 100 < 0x80, so a quality byte with
+        // its top bit set never counts).  A step issues two sequence and two quality loads per lane before any
+        // of them is used: a 150-byte string is 10 or 11 blocks, i.e. one step of the eight lanes.
+        const uint32_t s_lo = rec.s_off, s_hi = rec.s_off + rec.s_len, q_lo = rec.q_off, q_hi = rec.q_off + rec.q_len;
+        const uint32_t sb0 = s_lo >> 4, nsb = rec.s_len ? ((s_hi - 1) >> 4) - sb0 + 1 : 0;
+        const uint32_t qb0 = q_lo >> 4, nqb = rec.q_len ? ((q_hi - 1) >> 4) - qb0 + 1 : 0;
+        const uint32_t q1 = (quality + 1) * 0x01010101u;
+        const uint32_t nmax = nsb > nqb ? nsb : nqb;
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = l; i < nmax; i += 2 * QS_LANES) {
+            const uint32_t i2 = i + QS_LANES;
+            const uint4 s0 = i < nsb ? t4[sb0 + i] : zero, s1 = i2 < nsb ? t4[sb0 + i2] : zero;
+            const uint4 q0 = i < nqb ? t4[qb0 + i] : zero, q2 = i2 < nqb ? t4[qb0 + i2] : zero;
+            if (i < nsb) nn += count_n_bytes(s0, sb0 + i, s_lo, s_hi);
+            if (i2 < nsb) nn += count_n_bytes(s1, sb0 + i2, s_lo, s_hi);
+            if (i < nqb) nb += count_lowq_bytes(q0, qb0 + i, q_lo, q_hi, q1);
+            if (i2 < nqb) nb += count_lowq_bytes(q2, qb0 + i2, q_lo, q_hi, q1);
         }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 16); nb += __shfl_xor(nb, o, 16); }
-    if (r < n && l16 == 0) { n_count[r] = nn; bad_count[r] = nb; }
+    for (int o = QS_LANES / 2; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, QS_LANES); nb += __shfl_xor(nb, o, QS_LANES); }
+    if (r < n && l == 0) { n_count[r] = nn; bad_count[r] = nb; }
 }
 
 // SipHash-1-3 with keys (0, 0) of the (cut) sequence followed by 0xff: what Rust's DefaultHasher
@@ -909,7 +927,7 @@ hipError_t launch_qualscan(const uint8_t *text, const QualRec *recs, uint32_t n,
                            uint64_t *hashes, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(qualscan_kernel, dim3((unsigned)(((uint64_t)n * 16 + 255) / 256)), dim3(256), 0, st, text, recs, n, quality, n_count, bad_count);
+    hipLaunchKernelGGL(qualscan_kernel, dim3((unsigned)(((uint64_t)n * QS_LANES + 255) / 256)), dim3(256), 0, st, text, recs, n, quality, n_count, bad_count);
     if (hashes) hipLaunchKernelGGL(seqhash_kernel, dim3((n + 255) / 256), dim3(256), 0, st, text, recs, n, hashes);
     return hipGetLastError();
 }

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -60,11 +61,31 @@ struct MappedFile {                       // a plain input file mapped read-only
     ~MappedFile() { if (p) munmap(const_cast<char *>(p), n); }
 };
 
+// Batch objects are recycled through a pool: their vectors keep their capacity, so a steady-state batch
+// touches no freshly mapped memory (page faults on new mappings serialise on the process's mmap lock and
+// were the limit of the pack and parse stages with many threads).
+template <class T> class Pool : public std::enable_shared_from_this<Pool<T>> {
+public:
+    std::shared_ptr<T> get()
+    {
+        T *p = nullptr;
+        { std::lock_guard<std::mutex> lk(mu_); if (!free_.empty()) { p = free_.back().release(); free_.pop_back(); } }
+        if (!p) p = new T();
+        auto self = this->shared_from_this();
+        return std::shared_ptr<T>(p, [self](T *x) { x->recycle(); std::lock_guard<std::mutex> lk(self->mu_); self->free_.emplace_back(x); });
+    }
+private:
+    std::mutex mu_; std::vector<std::unique_ptr<T>> free_;
+};
+
+using RecVec = std::vector<FqRec, DefaultInitAlloc<FqRec>>;
+
 struct MateBatch {
     char *text = nullptr; size_t len = 0, cap = 0;
-    std::vector<FqRec> recs;
+    RecVec recs;
     std::shared_ptr<MappedFile> map;      // set when recs point into a mapped file instead of `text`
     ~MateBatch() { free(text); }
+    void recycle() { recs.clear(); len = 0; map.reset(); }
     bool reserve(size_t want) { if (want <= cap) return true; size_t nc = cap ? cap : (32u << 20); while (nc < want) nc *= 2; char *p = (char *)realloc(text, nc); if (!p) return false; text = p; cap = nc; return true; }
 };
 
@@ -140,46 +161,59 @@ public:
     }
 private:
     // ---- mapped mode.  The file is cut into segments of SEG bytes.  Newlines are counted per segment
-    // in parallel; a prefix sum gives every segment the index of its first line, hence that line's
-    // position inside its 4-line record; then segments are parsed in parallel, each taking the
-    // records whose header line starts inside it (following a record across the segment border).
-    size_t SEG = getenv("MF_PARSE_SEG") ? (size_t)strtoull(getenv("MF_PARSE_SEG"), nullptr, 10) : (size_t)(32u << 20);   // bytes per parse segment
-    bool next_mapped(MateBatch &b, uint64_t max_records)
-    {
-        b.recs.clear(); b.map = map_;
-        while (b.recs.size() < max_records) {
-            if (grp_pos_ == grp_.size()) { if (!parse_next_group()) break; }
-            const size_t take = std::min<size_t>(max_records - b.recs.size(), grp_.size() - grp_pos_);
-            b.recs.insert(b.recs.end(), grp_.begin() + grp_pos_, grp_.begin() + grp_pos_ + take);
-            grp_pos_ += take;
-        }
-        return !b.recs.empty();
-    }
-    bool parse_next_group()
+    // in parallel (once); a prefix sum gives every segment the index of the first line that starts in
+    // it, hence the index of the first record whose header starts in it.  A batch is then a range of
+    // record indices: the segments holding those headers are parsed in parallel, every record written
+    // straight to its slot of the batch (a record is followed across the segment border).
+    size_t SEG = getenv("MF_PARSE_SEG") ? (size_t)strtoull(getenv("MF_PARSE_SEG"), nullptr, 10) : (size_t)(4u << 20);   // bytes per parse segment
+    void index_segments()
     {
         const char *p = map_->p; const size_t n = map_->n;
         const size_t nseg = (n + SEG - 1) / SEG;
-        if (seg_lines_.empty()) {                           // once: newline counts per segment
-            seg_lines_.assign(nseg + 1, 0);
-            std::vector<uint64_t> cnt(nseg, 0);
-            parallel_for(nseg, [&](size_t i) {
-                const char *q = p + i * SEG, *e = p + std::min(n, (i + 1) * SEG); uint64_t c = 0;
-                while (q < e) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!nl) break; c++; q = nl + 1; }
-                cnt[i] = c;
-            });
-            for (size_t i = 0; i < nseg; i++) seg_lines_[i + 1] = seg_lines_[i] + cnt[i];
+        std::vector<uint64_t> cnt(nseg, 0);
+        parallel_for(nseg, [&](size_t i) {
+            const char *q = p + i * SEG, *e = p + std::min(n, (i + 1) * SEG); uint64_t c = 0;
+            while (q < e) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!nl) break; c++; q = nl + 1; }
+            cnt[i] = c;
+        });
+        // seg_first_line_[i]: index of the first line that STARTS inside segment i (a line starts after every '\n' and at 0)
+        seg_first_line_.assign(nseg + 1, 0);
+        uint64_t newlines = 0;
+        for (size_t i = 0; i < nseg; i++) {
+            const size_t off = i * SEG;
+            seg_first_line_[i] = newlines + ((off > 0 && p[off - 1] != '\n') ? 1 : 0);
+            newlines += cnt[i];
         }
-        if (next_seg_ >= nseg) return false;
-        const size_t g0 = next_seg_, g1 = std::min(nseg, g0 + (size_t)parse_threads_);
-        std::vector<std::vector<FqRec>> out(g1 - g0);
-        parallel_for(g1 - g0, [&](size_t gi) {
-            const size_t i = g0 + gi, off = i * SEG, end = std::min(n, off + SEG);
-            // first line that STARTS inside this segment, and its index in the file
-            size_t pos = off; uint64_t line = seg_lines_[i];
-            if (off > 0 && p[off - 1] != '\n') {            // byte `off` continues line `line`
+        const uint64_t total_lines = newlines + ((n > 0 && p[n - 1] != '\n') ? 1 : 0);   // lines() yields an unterminated last line
+        seg_first_line_[nseg] = total_lines;
+        n_records_ = total_lines / 4;                       // a partial record at the very end is dropped
+        indexed_ = true;
+    }
+    // records whose header line starts in segments before i
+    uint64_t seg_rec_base(size_t i) const { return (seg_first_line_[i] + 3) / 4; }
+    bool next_mapped(MateBatch &b, uint64_t max_records)
+    {
+        b.recs.clear(); b.map = map_;
+        if (!indexed_) index_segments();
+        if (rec_pos_ >= n_records_) return false;
+        const char *p = map_->p; const size_t n = map_->n;
+        const size_t nseg = (n + SEG - 1) / SEG;
+        const uint64_t r0 = rec_pos_, r1 = std::min<uint64_t>(n_records_, r0 + max_records);
+        b.recs.resize((size_t)(r1 - r0));
+        // first segment holding record r0's header: the last i with seg_rec_base(i) <= r0
+        size_t lo = 0, hi = nseg;
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (seg_rec_base(mid) <= r0) lo = mid; else hi = mid; }
+        size_t s0 = lo, s1 = s0;
+        while (s1 < nseg && seg_rec_base(s1) < r1) s1++;
+        FqRec *out = b.recs.data();
+        parallel_for(s1 - s0, [&](size_t gi) {
+            const size_t i = s0 + gi, off = i * SEG, end = std::min(n, off + SEG);
+            uint64_t line = seg_first_line_[i];
+            size_t pos = off;
+            if (off > 0 && p[off - 1] != '\n') {            // byte `off` continues an earlier line
                 const char *nl = (const char *)memchr(p + off, '\n', n - off);
                 if (!nl) return;
-                pos = (size_t)(nl - p) + 1; line++;
+                pos = (size_t)(nl - p) + 1;
             }
             // skip to the next header line (index divisible by 4)
             while (pos < n && (line & 3)) {
@@ -187,9 +221,8 @@ private:
                 if (!nl) return;
                 pos = (size_t)(nl - p) + 1; line++;
             }
-            std::vector<FqRec> &v = out[gi];
-            v.reserve(SEG / 200);
-            while (pos < end) {                            // this record's header starts inside the segment
+            uint64_t rec = line / 4;
+            while (pos < end && rec < r1) {                 // this record's header starts inside the segment
                 const char *ls[4]; uint32_t ll[4]; int li = 0;
                 size_t q = pos;
                 for (; li < 4 && q < n; li++) {
@@ -201,14 +234,13 @@ private:
                     q = e + 1;
                 }
                 if (li < 4) break;                          // partial record at the very end: dropped
-                v.push_back(FqRec{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]});
+                if (rec >= r0) out[rec - r0] = FqRec{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]};
+                rec++;
                 pos = q;
             }
         });
-        grp_.clear(); grp_pos_ = 0;
-        for (auto &v : out) grp_.insert(grp_.end(), v.begin(), v.end());
-        next_seg_ = g1;
-        return !grp_.empty() || next_seg_ < nseg ? (grp_.empty() ? parse_next_group() : true) : false;
+        rec_pos_ = r1;
+        return true;
     }
     template <class F> void parallel_for(size_t count, F f)
     {
@@ -223,8 +255,8 @@ private:
     std::vector<char> carry_;
     int parse_threads_ = 1;
     std::shared_ptr<MappedFile> map_;
-    std::vector<uint64_t> seg_lines_; size_t next_seg_ = 0;
-    std::vector<FqRec> grp_; size_t grp_pos_ = 0;
+    std::vector<uint64_t> seg_first_line_; bool indexed_ = false;
+    uint64_t n_records_ = 0, rec_pos_ = 0;
 };
 
 struct PairBatch {
@@ -232,6 +264,7 @@ struct PairBatch {
     std::shared_ptr<MateBatch> mate[2];
     PackedHost packed[2];
     std::vector<uint8_t> keep;
+    void recycle() { mate[0].reset(); mate[1].reset(); keep.clear(); index = n = 0; }
 };
 using PairPtr = std::shared_ptr<PairBatch>;
 
@@ -241,6 +274,11 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
 {
     const int nm = fq2 ? 2 : 1;
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
+    // MF_PIPE_TIMING=1: busy seconds of every stage on stderr (diagnostics)
+    const bool timing = getenv("MF_PIPE_TIMING") != nullptr;
+    std::atomic<uint64_t> t_read[2] = {{0}, {0}}, t_pack{0}, t_dev{0}, t_write[2] = {{0}, {0}};
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const uint64_t t_start = now_us();
     BatchReader rd[2];
     for (int m = 0; m < nm; m++) {
         rd[m].set_parse_threads(std::max(1, pack_threads / (2 * nm)));     // plain files: segments parsed in parallel
@@ -250,6 +288,8 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     std::mutex err_mu; int rc = MF_OK;
     auto set_err = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (rc == MF_OK) { rc = code; err = msg; } };
 
+    auto mate_pool = std::make_shared<Pool<MateBatch>>();
+    auto pair_pool = std::make_shared<Pool<PairBatch>>();
     Channel<std::shared_ptr<MateBatch>> q_read[2] = {Channel<std::shared_ptr<MateBatch>>(2), Channel<std::shared_ptr<MateBatch>>(2)};
     std::vector<std::unique_ptr<Channel<PairPtr>>> q_dev;
     for (int d = 0; d < n_devices; d++) q_dev.emplace_back(new Channel<PairPtr>(2));
@@ -261,9 +301,12 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     for (int m = 0; m < nm; m++)
         threads.emplace_back([&, m] {
             for (;;) {
-                auto b = std::make_shared<MateBatch>();
+                auto b = mate_pool->get();
                 std::string e;
-                if (!rd[m].next(*b, batch_reads, e)) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
+                const uint64_t t0 = now_us();
+                const bool got = rd[m].next(*b, batch_reads, e);
+                t_read[m] += now_us() - t0;
+                if (!got) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
                 if (!q_read[m].push(b)) break;
             }
             q_read[m].finish();
@@ -273,18 +316,20 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     threads.emplace_back([&] {
         uint64_t idx = 0;
         for (;;) {
-            auto pb = std::make_shared<PairBatch>();
+            auto pb = pair_pool->get();
             bool ok = true;
             for (int m = 0; m < nm; m++) ok = q_read[m].pop(pb->mate[m]) && ok;
             if (!ok) break;                               // the shorter file bounds the pair count (zip semantics)
             pb->n = pb->mate[0]->recs.size();
             if (nm == 2 && pb->mate[1]->recs.size() < pb->n) pb->n = pb->mate[1]->recs.size();
             pb->index = idx;
+            const uint64_t t0 = now_us();
             if (nm == 2) {
                 std::thread t([&] { pack_records(pb->mate[1]->recs.data(), pb->n, pack_threads > 1 ? pack_threads / 2 : 1, pb->packed[1]); });
                 pack_records(pb->mate[0]->recs.data(), pb->n, pack_threads > 1 ? pack_threads - pack_threads / 2 : 1, pb->packed[0]);
                 t.join();
             } else pack_records(pb->mate[0]->recs.data(), pb->n, pack_threads, pb->packed[0]);
+            t_pack += now_us() - t0;
             const bool last = nm == 2 && pb->mate[0]->recs.size() != pb->mate[1]->recs.size();
             if (!q_dev[idx % n_devices]->push(pb)) break;
             idx++;
@@ -304,9 +349,10 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
                 bool ok = true;
                 for (int m = 0; m < nm && ok; m++) {
                     std::string e;
+                    const uint64_t t0 = now_us();
                     const int r = filter(d, pb->packed[m], pb->n, bits[m], e);
+                    t_dev += now_us() - t0;
                     if (r != MF_OK) { set_err(r, e); abort_all(); ok = false; }
-                    pb->packed[m] = PackedHost();          // release host copy early
                 }
                 if (!ok) break;
                 pb->keep.assign(pb->n ? pb->n : 1, 0);
@@ -343,6 +389,8 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
             while (ok && q_write[m].pop(pb)) {
                 pending[pb->index] = pb;
                 while (ok && !pending.empty() && pending.begin()->first == next) {
+                    const uint64_t t0w = now_us();
+                    struct Acc { std::atomic<uint64_t> &a; uint64_t t0; std::function<uint64_t()> now; ~Acc() { a += now() - t0; } } acc{t_write[m], t0w, now_us};
                     PairPtr cur = pending.begin()->second; pending.erase(pending.begin()); next++;
                     const FqRec *recs = cur->mate[m]->recs.data();
                     for (uint64_t i = 0; i < cur->n && ok; i++) {
@@ -361,6 +409,10 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
         });
 
     for (auto &t : threads) t.join();
+    if (timing)
+        fprintf(stderr, "[mf pipeline] wall %.3f s | read %.3f %.3f | pack %.3f | device %.3f | write %.3f %.3f | batches %llu\n",
+                (now_us() - t_start) / 1e6, t_read[0] / 1e6, t_read[1] / 1e6, t_pack / 1e6, t_dev / 1e6, t_write[0] / 1e6, t_write[1] / 1e6,
+                (unsigned long long)stats.batches);
     return rc;
 }
 
@@ -488,7 +540,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             std::vector<uint32_t> nc[2], bc[2]; std::vector<uint64_t> hs;
             if (!P.trunc && n_ok) {
                 for (int m = 0; m < nm && ok; m++) {
-                    const std::vector<FqRec> &recs = qb->mate[m]->recs;
+                    const RecVec &recs = qb->mate[m]->recs;
                     const char *base = recs[0].h, *endp = recs[n_ok - 1].q + recs[n_ok - 1].ql;
                     if ((size_t)(endp - base) >= 0xFFFFFFF0ull) { set_err(MF_E_ARG, "batch larger than 4 GiB: lower MF_BATCH_READS"); ok = false; break; }
                     std::vector<QualSpan> sp(n_ok);
