@@ -109,7 +109,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
         HIPCHK(launch_build_ptable(d_aa, d_run, P.total, ks->k, T.keys, ks->slots, st));
         HIPCHK(hipMalloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
         HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
-        HIPCHK(launch_build_kbloom(T.keys, ks->slots, 1, T.kbloom, ks->kb_log2w, st));
+        HIPCHK(launch_build_pbits(T.keys, ks->slots, T.kbloom, ks->kb_log2w, st));
         HIPCHK(hipMalloc(&T.plut, sizeof ks->codon_lut));
         HIPCHK(hipMemcpyAsync(T.plut, ks->codon_lut, sizeof ks->codon_lut, hipMemcpyHostToDevice, st));
         HIPCHK(hipMalloc(&d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
@@ -723,7 +723,7 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     static_assert(sizeof(QualSpan) == sizeof(QualRec), "host and device record layouts must match");
     QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
     P.dedup = dedup != 0; P.trunc = truncate_only != 0;
-    int threads = (int)std::thread::hardware_concurrency() - 4; if (threads < 2) threads = 2; if (threads > 32) threads = 32;
+    int threads = (int)std::thread::hardware_concurrency() - 4; if (threads < 2) threads = 2; if (threads > 64) threads = 64;
     QualStats qs; std::string perr;
     rc = run_qualfilter_pipeline(fq1, fq2, out1, out2, P, threads, env_u32("MF_BATCH_READS", 2000000), scan, qs, perr);
     hipFree(d_text.p); hipFree(d_recs.p); hipFree(d_cnt.p); hipFree(d_hash.p);

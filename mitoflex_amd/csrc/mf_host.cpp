@@ -180,9 +180,9 @@ bool codon_lut_for(int genetic_code, int kp, uint32_t out[256])
     for (int c = 0; c < 64; c++) {
         const int b1 = c & 3, b2 = (c >> 2) & 3, b3 = (c >> 4) & 3;
         const int f = residue(b1, b2, b3), r = residue(3 - b3, 3 - b2, 3 - b1);
-        const uint64_t top = f < 0 ? 0 : (uint64_t)f << (5 * (kp - 1));
+        const uint64_t top = (uint64_t)(f < 0 ? 31 : f) << (5 * (kp - 1));        // 31: the non-residue code (stop codon)
         out[4 * c] = (uint32_t)top; out[4 * c + 1] = (uint32_t)(top >> 32);
-        out[4 * c + 2] = r < 0 ? 0u : (uint32_t)r;
+        out[4 * c + 2] = r < 0 ? 31u : (uint32_t)r;
         out[4 * c + 3] = (f >= 0 ? 1u : 0u) | (r >= 0 ? 2u : 0u);
     }
     return true;

@@ -43,7 +43,8 @@ void parse_bait_protein(const char *text, size_t len, ProtBaitHost &out);
 // NCBI translation table `genetic_code` (1, 2, 3, 4, 5, 9, 11, 13, 14, 21) as the filter kernel wants it:
 // 64 entries of 4 dwords, indexed by the codon as it sits in the packed stream (first base in bits 0-1):
 //   [0],[1]  forward-strand residue << 5*(kp-1) (64 bit), [2] residue of the reverse-complemented codon,
-//   [3]      bit 0: forward codon translates to a residue (not a stop), bit 1: same for the reverse codon
+//   [3]      bit 0: the forward codon is a sense codon, bit 1: same for the reverse codon;
+//   a stop codon has the non-residue code 31, which no database key holds
 bool codon_lut_for(int genetic_code, int kp, uint32_t out[256]);
 
 struct FqRec { const char *h, *s, *q; uint32_t hl, sl, ql; };

@@ -36,6 +36,7 @@ hipError_t launch_qualscan(const uint8_t *text, const QualRec *recs, uint32_t n,
 // protein-space baiting (mf_protein.hip): peptide k-mer table builder and the six-frame filter kernel
 hipError_t launch_build_ptable(const uint8_t *aa, const uint8_t *runlen, uint64_t total, int kp, uint64_t *keys, uint64_t slots,
                                hipStream_t st);
+hipError_t launch_build_pbits(const uint64_t *keys, uint64_t slots, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_pfilter(const ReadsView &R, const KmerSetView &S, uint32_t thr, bool count_all, uint32_t *out_bits,
                           uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st);
 hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);

@@ -424,21 +424,25 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
 namespace {
 
 struct U64Set {                                     // open-address set with HashSet<u64> semantics
-    std::vector<uint64_t> slot; std::vector<uint8_t> used; size_t n = 0, mask = 0;
-    U64Set() { slot.assign(1 << 16, 0); used.assign(1 << 16, 0); mask = (1 << 16) - 1; }
+    // one array (0 = empty slot, the value 0 itself is kept in a flag): an insert is one cache miss,
+    // and prefetch() lets the caller start that miss a few records ahead
+    std::vector<uint64_t> slot; size_t n = 0, mask = 0; bool has_zero = false;
+    U64Set() { slot.assign(1 << 16, 0); mask = (1 << 16) - 1; }
     static uint64_t mix(uint64_t x) { x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 32; return x; }
     void grow()
     {
-        std::vector<uint64_t> os; std::vector<uint8_t> ou; os.swap(slot); ou.swap(used);
-        slot.assign(os.size() * 2, 0); used.assign(os.size() * 2, 0); mask = slot.size() - 1; n = 0;
-        for (size_t i = 0; i < os.size(); i++) if (ou[i]) insert(os[i]);
+        std::vector<uint64_t> os; os.swap(slot);
+        slot.assign(os.size() * 2, 0); mask = slot.size() - 1; n = 0;
+        for (uint64_t v : os) if (v) insert(v);
     }
+    void prefetch(uint64_t v) const { __builtin_prefetch(&slot[mix(v) & mask], 1, 1); }
     bool insert(uint64_t v)                          // false when already present
     {
+        if (v == 0) { const bool fresh = !has_zero; has_zero = true; return fresh; }
         if (2 * (n + 1) > slot.size()) grow();
         size_t i = mix(v) & mask;
-        while (used[i]) { if (slot[i] == v) return false; i = (i + 1) & mask; }
-        used[i] = 1; slot[i] = v; n++;
+        while (slot[i]) { if (slot[i] == v) return false; i = (i + 1) & mask; }
+        slot[i] = v; n++;
         return true;
     }
 };
@@ -468,7 +472,20 @@ struct QualBatch {
     std::shared_ptr<MateBatch> mate[2];
     std::vector<uint8_t> keep;
     bool last = false;
+    void recycle() { mate[0].reset(); mate[1].reset(); keep.clear(); index = n = 0; last = false; }
 };
+
+// fn(lo, hi) over [0, n) cut into one contiguous chunk per worker
+template <class F> void parallel_chunks(uint64_t n, int threads, F fn)
+{
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);      // not worth a thread below a few thousand records
+    if (threads == 1) { fn((uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(fn, n * (uint64_t)t / threads, n * (uint64_t)(t + 1) / threads);
+    fn((uint64_t)0, n / threads);
+    for (auto &x : th) x.join();
+}
 using QualPtr = std::shared_ptr<QualBatch>;
 
 } // namespace
@@ -485,6 +502,8 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
     }
     std::mutex err_mu; int rc = MF_OK;
     auto set_err = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (rc == MF_OK) { rc = code; err = msg; } };
+    auto mate_pool = std::make_shared<Pool<MateBatch>>();
+    auto qual_pool = std::make_shared<Pool<QualBatch>>();
     Channel<std::shared_ptr<MateBatch>> q_read[2] = {Channel<std::shared_ptr<MateBatch>>(2), Channel<std::shared_ptr<MateBatch>>(2)};
     Channel<QualPtr> q_write[2] = {Channel<QualPtr>(4), Channel<QualPtr>(4)};
     auto abort_all = [&] { for (auto &q : q_read) q.abort(); for (auto &q : q_write) q.abort(); };
@@ -493,7 +512,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
     for (int m = 0; m < nm; m++)
         th.emplace_back([&, m] {
             for (;;) {
-                auto b = std::make_shared<MateBatch>();
+                auto b = mate_pool->get();
                 std::string e;
                 if (!rd[m].next(*b, batch_reads, e)) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
                 if (!q_read[m].push(b)) break;
@@ -505,8 +524,10 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
     th.emplace_back([&] {
         U64Set seen; uint64_t budget = 0, idx = 0; bool stop = false;
         const uint64_t L = P.end - P.start;
+        std::vector<uint32_t> nc[2], bc[2]; std::vector<uint64_t> hs;      // per-batch scratch, capacity kept
+        std::vector<QualSpan, DefaultInitAlloc<QualSpan>> sp;
         while (!stop) {
-            auto qb = std::make_shared<QualBatch>();
+            auto qb = qual_pool->get();
             bool ok = true;
             for (int m = 0; m < nm; m++) ok = q_read[m].pop(qb->mate[m]) && ok;
             if (!ok) break;
@@ -515,37 +536,46 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             const bool short_mate = nm == 2 && qb->mate[0]->recs.size() != qb->mate[1]->recs.size();
             // the cut (main.rs:222-233, 291-299) and the first record at which the reference would panic:
             // `drain(..start)` past the end of a string, or a line that is not valid UTF-8
-            uint64_t n_ok = n;
-            for (uint64_t i = 0; i < n_ok; i++) {
-                for (int m = 0; m < nm; m++) {
-                    FqRec &r = qb->mate[m]->recs[i];
-                    // the line between sequence and quality is also decoded by lines(): it spans [s+sl .. q)
-                    if (!utf8_ok(r.h, r.hl) || !utf8_ok(r.s, (size_t)(r.q - r.s) + r.ql)) { n_ok = i; break; }
-                }
-                if (n_ok == i) break;
-                if (P.start) {
+            // Records are independent here, so the batch is cut into chunks; each chunk stops at its first
+            // offender and the earliest one bounds the batch (records past it are never looked at again).
+            std::atomic<uint64_t> first_bad{n};
+            parallel_chunks(n, threads, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; i++) {
                     bool bad = false;
-                    for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].sl;      // seq1, seq2 first
-                    for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].ql;      // then qua1, qua2
-                    if (bad) { n_ok = i; break; }
+                    for (int m = 0; m < nm && !bad; m++) {
+                        const FqRec &r = qb->mate[m]->recs[i];
+                        // the line between sequence and quality is also decoded by lines(): it spans [s+sl .. q)
+                        bad = !utf8_ok(r.h, r.hl) || !utf8_ok(r.s, (size_t)(r.q - r.s) + r.ql);
+                    }
+                    if (!bad && P.start) {
+                        for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].sl;      // seq1, seq2 first
+                        for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].ql;      // then qua1, qua2
+                    }
+                    if (bad) {
+                        uint64_t cur = first_bad.load();
+                        while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+                        return;
+                    }
+                    for (int m = 0; m < nm; m++) {
+                        FqRec &r = qb->mate[m]->recs[i];
+                        if (P.start) { r.s += P.start; r.sl -= (uint32_t)P.start; r.q += P.start; r.ql -= (uint32_t)P.start; }
+                        if (P.end) { if (r.sl > L) r.sl = (uint32_t)L; if (r.ql > L) r.ql = (uint32_t)L; }
+                    }
                 }
-                for (int m = 0; m < nm; m++) {
-                    FqRec &r = qb->mate[m]->recs[i];
-                    if (P.start) { r.s += P.start; r.sl -= (uint32_t)P.start; r.q += P.start; r.ql -= (uint32_t)P.start; }
-                    if (P.end) { if (r.sl > L) r.sl = (uint32_t)L; if (r.ql > L) r.ql = (uint32_t)L; }
-                }
-            }
+            });
+            const uint64_t n_ok = first_bad.load();
             const bool panicked = n_ok < n;
             // GPU: counts (and hashes of mate 1 when deduplicating)
-            std::vector<uint32_t> nc[2], bc[2]; std::vector<uint64_t> hs;
             if (!P.trunc && n_ok) {
                 for (int m = 0; m < nm && ok; m++) {
                     const RecVec &recs = qb->mate[m]->recs;
                     const char *base = recs[0].h, *endp = recs[n_ok - 1].q + recs[n_ok - 1].ql;
                     if ((size_t)(endp - base) >= 0xFFFFFFF0ull) { set_err(MF_E_ARG, "batch larger than 4 GiB: lower MF_BATCH_READS"); ok = false; break; }
-                    std::vector<QualSpan> sp(n_ok);
-                    for (uint64_t i = 0; i < n_ok; i++)
-                        sp[i] = QualSpan{(uint32_t)(recs[i].s - base), recs[i].sl, (uint32_t)(recs[i].q - base), recs[i].ql};
+                    sp.resize(n_ok);
+                    parallel_chunks(n_ok, threads, [&](uint64_t lo, uint64_t hi) {
+                        for (uint64_t i = lo; i < hi; i++)
+                            sp[i] = QualSpan{(uint32_t)(recs[i].s - base), recs[i].sl, (uint32_t)(recs[i].q - base), recs[i].ql};
+                    });
                     nc[m].resize(n_ok); bc[m].resize(n_ok);
                     if (m == 0 && P.dedup) hs.resize(n_ok);
                     std::string e;
@@ -558,6 +588,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             qb->keep.assign(n ? n : 1, 0);
             for (uint64_t i = 0; i < n_ok; i++) {
                 const FqRec &r1 = qb->mate[0]->recs[i];
+                if (P.dedup && !P.trunc && i + 16 < n_ok) seen.prefetch(hs[i + 16]);
                 if (!P.trunc) {
                     bool drop = nc[0][i] > P.ns || (nm == 2 && nc[1][i] > P.ns);                       // main.rs:236, 302
                     if (!drop) {

@@ -9,9 +9,16 @@
 // keys roll in opposite directions over the same codon stream, exactly like a k-mer and its reverse
 // complement.  Three lanes per read (one per phase), 256 reads per workgroup iteration, no idle
 // lanes.  The codon table (64 entries, residues pre-shifted to the key's top position) and, when it
-// fits, the k-mer bit table in front of the open-address table live in LDS; the table itself is
-// read through L2 only for bit-table positives.  The kernel is VALU-bound: about 60 integer
-// instructions per codon and lane, 296 codon-strand steps per 150-base read.
+// fits, the key bit table in front of the open-address table live in LDS; the table itself is
+// read through L2 only for bit-table positives.
+//
+// Validity costs nothing in the loop: a stop codon or a codon holding an invalid base translates to
+// the non-residue code 31, and both keys start out as all 31s, so a window that is incomplete or
+// broken carries a 31 somewhere and can never equal a database key (codes 0..19 only).
+//
+// The kernel is VALU-bound (296 codon-strand steps per 150-base read), so the loop is kept short:
+// a three-instruction hash for the bit table (the table hash is computed for positives only), a
+// two-bit test in one 64-bit block.
 #include "mf_kernels.h"
 
 namespace mf {
@@ -28,19 +35,23 @@ __device__ __forceinline__ uint64_t lower_bound_npos(const uint64_t *__restrict_
 
 __device__ __forceinline__ uint32_t alignbit32(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
-// bit-table test of one key: 1 when all four bits of its 128-bit block are set
+// bit-table hash of a peptide key: one multiply per half and a xor (block index from the top bits); the two bit
+// positions come from the low bits folded with the middle ones, which do not take part in the block index alone
+__device__ __forceinline__ uint32_t pep_hash(uint64_t key) { return ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u); }
+__device__ __forceinline__ uint32_t pep_bits(uint32_t hb) { return hb ^ (hb >> 16); }
+
+// bit-table test of one key: 1 when both bits of its 64-bit block are set
 template <bool LDS_KB>
-__device__ __forceinline__ uint32_t bit_test(const KmerSetView &S, const uint4 *__restrict__ s_kb4, uint32_t kb_shift, uint32_t h)
+__device__ __forceinline__ uint32_t bit_test(const KmerSetView &S, const uint2 *__restrict__ s_kb2, uint32_t kb_shift, uint32_t hb)
 {
-    const uint32_t hb = kbloom_hash(h);
-    const uint4 blk = LDS_KB ? s_kb4[hb >> kb_shift] : reinterpret_cast<const uint4 *>(S.kbloom)[hb >> kb_shift];
-    const uint32_t g = bloom_bits(hb);
-    return (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31)) & 1u;
+    const uint2 blk = LDS_KB ? s_kb2[hb >> kb_shift] : reinterpret_cast<const uint2 *>(S.kbloom)[hb >> kb_shift];
+    const uint32_t g = pep_bits(hb);
+    return (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & 1u;
 }
 
-__device__ __forceinline__ uint32_t table_has_key(const KmerSetView &S, uint64_t key, uint32_t h)
+__device__ __forceinline__ uint32_t table_has_key(const KmerSetView &S, uint64_t key)
 {
-    uint64_t slot = h & S.slot_mask;
+    uint64_t slot = hash_key1(key) & S.slot_mask;
     uint64_t e = S.keys[slot];
     while (e < key) { slot = (slot + 1) & S.slot_mask; e = S.keys[slot]; }       // ordered table
     return e == key ? 1u : 0u;
@@ -53,17 +64,19 @@ pfilter_kernel(ReadsView R, KmerSetView S, uint32_t thr, uint32_t *__restrict__ 
 {
     extern __shared__ uint4 s_dyn[];
     uint4 *s_lut = s_dyn;                          // 64 codon entries
-    uint4 *s_kb4 = s_dyn + 64;                     // k-mer bit table blocks (LDS_KB)
+    uint2 *s_kb2 = reinterpret_cast<uint2 *>(s_dyn + 64);   // key bit table, 64-bit blocks (LDS_KB)
     __shared__ uint32_t s_hits[PF_READS];
     __shared__ unsigned long long s_tot;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid < 64) s_lut[tid] = reinterpret_cast<const uint4 *>(S.plut)[tid];
     if (LDS_KB)
-        for (uint32_t i = tid; i < (1u << (S.kb_log2w - 2)); i += PF_BLOCK) s_kb4[i] = reinterpret_cast<const uint4 *>(S.kbloom)[i];
+        for (uint32_t i = tid; i < (1u << (S.kb_log2w - 2)); i += PF_BLOCK)
+            reinterpret_cast<uint4 *>(s_kb2)[i] = reinterpret_cast<const uint4 *>(S.kbloom)[i];
     if (tid == 0) s_tot = 0;
-    const uint32_t kb_shift = 32 - (S.kb_log2w - 2);
+    const uint32_t kb_shift = 32 - (S.kb_log2w - 1);
     const uint32_t kp = (uint32_t)S.k;
     const uint64_t mask = (1ULL << (5 * kp)) - 1;
+    const uint64_t top31 = 31ULL << (5 * (kp - 1));            // the non-residue code in the key's top position
     const uint32_t rl = tid / 3, phase = tid - 3 * rl;
     const uint64_t n_groups = (R.n_reads + PF_READS - 1) / PF_READS;
 
@@ -83,35 +96,36 @@ pfilter_kernel(ReadsView R, KmerSetView S, uint32_t thr, uint32_t *__restrict__ 
             const uint32_t q_end = (uint32_t)(b0 & 15) + (uint32_t)(b1 - b0);
             uint64_t ni = 0, next_n = ~0ULL;
             if (hasn) { ni = lower_bound_npos(R.npos, R.n_npos, g0 + q); next_n = ni < R.n_npos ? R.npos[ni] : ~0ULL; }
-            uint64_t kf = 0, kr = 0;
-            uint32_t run_f = 0, run_r = 0, cnt = 0;
+            uint64_t kf = mask, kr = mask;                                     // all non-residues: no window yet
+            uint32_t cnt = 0, run_f = 0, run_r = 0;                            // run counters: bit table in L2 only
             while (q + 3 <= q_end) {
                 const uint32_t wi = q >> 4;
                 const uint32_t lo = wp[wi], hi = wp[wi + 1];                       // 32 bases from an aligned word
                 do {
                     const uint32_t c = alignbit32(hi, lo, 2 * (q & 15)) & 63u;
                     const uint4 e = s_lut[c];
-                    uint32_t fl = e.w;
+                    uint64_t ef = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                    uint32_t er = e.z, fl = e.w;
                     if (hasn) {
                         const uint64_t g = g0 + q;
                         while (next_n < g) { ni++; next_n = ni < R.n_npos ? R.npos[ni] : ~0ULL; }
-                        if (next_n <= g + 2) fl = 0;                      // an invalid base inside this codon
+                        if (next_n <= g + 2) { ef = top31; er = 31u; fl = 0; }   // an invalid base inside this codon
                     }
-                    kf = (kf >> 5) | ((uint64_t)e.x | ((uint64_t)e.y << 32));
-                    kr = ((kr << 5) | e.z) & mask;
-                    run_f = (fl & 1u) ? run_f + 1 : 0;
-                    run_r = (fl & 2u) ? run_r + 1 : 0;
-                    const uint32_t hf = (uint32_t)hash_key1(kf), hr = (uint32_t)hash_key1(kr);
-                    if (LDS_KB) {          // both LDS tests unconditionally (no branch between them: the reads overlap)
-                        const uint32_t tf = bit_test<true>(S, s_kb4, kb_shift, hf) & (run_f >= kp ? 1u : 0u);
-                        const uint32_t tr = bit_test<true>(S, s_kb4, kb_shift, hr) & (run_r >= kp ? 1u : 0u);
-                        if (tf | tr) {
-                            if (tf) cnt += table_has_key(S, kf, hf);
-                            if (tr) cnt += table_has_key(S, kr, hr);
-                        }
-                    } else {               // bit table in L2: only windows that exist cost a load
-                        if (run_f >= kp && bit_test<false>(S, s_kb4, kb_shift, hf)) cnt += table_has_key(S, kf, hf);
-                        if (run_r >= kp && bit_test<false>(S, s_kb4, kb_shift, hr)) cnt += table_has_key(S, kr, hr);
+                    kf = (kf >> 5) | ef;
+                    kr = ((kr << 5) | er) & mask;
+                    uint32_t tf, tr;
+                    if (LDS_KB) {          // LDS tests are cheaper than knowing whether the window is whole
+                        tf = bit_test<true>(S, s_kb2, kb_shift, pep_hash(kf));
+                        tr = bit_test<true>(S, s_kb2, kb_shift, pep_hash(kr));
+                    } else {               // bit table in L2: only whole windows are worth a load
+                        run_f = (fl & 1u) ? run_f + 1 : 0;
+                        run_r = (fl & 2u) ? run_r + 1 : 0;
+                        tf = run_f >= kp ? bit_test<false>(S, s_kb2, kb_shift, pep_hash(kf)) : 0u;
+                        tr = run_r >= kp ? bit_test<false>(S, s_kb2, kb_shift, pep_hash(kr)) : 0u;
+                    }
+                    if (tf | tr) {                                       // rare: the open-address table decides
+                        if (tf) cnt += table_has_key(S, kf);
+                        if (tr) cnt += table_has_key(S, kr);
                     }
                     q += 3;
                 } while (q + 3 <= q_end && (q >> 4) == wi);
@@ -157,6 +171,25 @@ __global__ void build_pkeys_kernel(const uint8_t *__restrict__ aa, const uint8_t
         if (v == EMPTY64) return;
         slot = (slot + 1) & slot_mask;
     }
+}
+
+// key bit table of a peptide set: one 64-bit block per key, one bit in each dword
+__global__ void build_pbits_kernel(const uint64_t *__restrict__ keys, uint64_t slots, uint32_t *kbloom, uint32_t kb_log2w)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    const uint64_t key = keys[i];
+    if (key == EMPTY64) return;
+    const uint32_t hb = pep_hash(key), g = pep_bits(hb);
+    uint32_t *blk = kbloom + 2 * (size_t)(hb >> (32 - (kb_log2w - 1)));
+    atomicOr(&blk[0], 1u << (g & 31));
+    atomicOr(&blk[1], 1u << ((g >> 5) & 31));
+}
+
+hipError_t launch_build_pbits(const uint64_t *keys, uint64_t slots, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st)
+{
+    hipLaunchKernelGGL(build_pbits_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, keys, slots, kbloom, kb_log2w);
+    return hipGetLastError();
 }
 
 hipError_t launch_build_ptable(const uint8_t *aa, const uint8_t *runlen, uint64_t total, int kp, uint64_t *keys, uint64_t slots,
