@@ -10,6 +10,7 @@
 #include "mf_synth.h"
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <stdarg.h>
@@ -676,7 +677,12 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     };
     PipelineStats ps; std::string perr;
     const int rc = run_fastq_pipeline(fq1, fq2, out1, out2, pair_mode == MF_PAIR_BOTH, n_devices, pack_threads, batch_reads, fn, ps, perr);
-    for (mf_reads *a : arena) reads_release(a);
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (mf_reads *a : arena) reads_release(a);
+        if (getenv("MF_PIPE_TIMING"))
+            fprintf(stderr, "[mf pipeline] device buffers released in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
     if (rc != MF_OK) return fail(rc, "%s", perr.c_str());
     if (kept) *kept = ps.kept;
     if (total) *total = ps.total;

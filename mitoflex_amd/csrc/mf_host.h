@@ -8,6 +8,8 @@
 #include <stddef.h>
 #include <memory>
 #include <new>
+#include <stdlib.h>
+#include <sys/mman.h>
 #include <string>
 #include <utility>
 #include <vector>
@@ -51,9 +53,24 @@ struct FqRec { const char *h, *s, *q; uint32_t hl, sl, ql; };
 // strict 4-line records over an in-memory buffer (pointers into buf)
 void parse_fastq(const char *buf, size_t len, std::vector<FqRec> &recs);
 
-// allocator whose construct() default-initialises: a vector of it can be sized without being zero-filled
+// allocator whose construct() default-initialises: a vector of it can be sized without being zero-filled.
+// Large blocks are 2 MiB aligned and marked for transparent huge pages: a batch buffer of ~100 MB is then
+// some fifty page faults instead of twenty-five thousand, and just as cheap to give back.
 template <class T> struct DefaultInitAlloc : std::allocator<T> {
     template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T), huge = (size_t)2 << 20;
+        void *p;
+        if (bytes >= 2 * huge) {
+            const size_t rounded = (bytes + huge - 1) / huge * huge;
+            p = aligned_alloc(huge, rounded);
+            if (p) madvise(p, rounded, MADV_HUGEPAGE);
+        } else p = malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) noexcept { free(p); }
     template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
 };

@@ -28,4 +28,8 @@ pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS
 pmc grbm GRBM_GUI_ACTIVE
+cd $R
+timeout 600 ./tools/e2e_bench.sh 8000000 > $OUT/e2e_files.log 2>&1; tail -12 $OUT/e2e_files.log
+timeout 600 ./tools/e2e_filter_v2.sh > $OUT/filter_v2_e2e.log 2>&1; tail -12 $OUT/filter_v2_e2e.log
+timeout 600 python tools/bench_protein.py > $OUT/protein_bench.json 2> $OUT/protein_bench.err; cat $OUT/protein_bench.json
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm
