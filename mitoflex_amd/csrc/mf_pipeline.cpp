@@ -1,4 +1,5 @@
 #include "mf_pipeline.h"
+#include "mf_inflate.h"
 #include "../../include/mitofilter.h"
 
 #include <algorithm>
@@ -95,6 +96,22 @@ public:
     {
         if (!path) { f_ = stdin; own_f_ = false; path_ = "<stdin>"; return true; }
         gz_ = has_gz_ext(path);
+        if (gz_ && !getenv("MF_ZLIB_INFLATE")) {             // regular .gz file: map it and decode with the streaming decoder
+            int fd = ::open(path, O_RDONLY);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+                void *m = st.st_size > 0 ? mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+                if (st.st_size == 0 || m != MAP_FAILED) {
+                    gzmap_ = std::make_shared<MappedFile>();
+                    if (st.st_size > 0) { gzmap_->p = (const char *)m; gzmap_->n = (size_t)st.st_size; madvise(m, gzmap_->n, MADV_SEQUENTIAL); }
+                    inflater_.open((const uint8_t *)gzmap_->p, gzmap_->n);
+                    ::close(fd);
+                    path_ = path;
+                    return true;
+                }
+            }
+            if (fd >= 0) ::close(fd);
+        }
         if (gz_) { g_ = gzopen(path, "rb"); if (g_) gzbuffer(g_, 1 << 20); }
         else f_ = fopen(path, "rb");
         if (!g_ && !f_) { err = std::string("Cannot open file ") + path; return false; }
@@ -143,7 +160,13 @@ public:
             if (full || eof_) break;
             if (!b.reserve(b.len + blk)) { err = "out of memory"; return false; }
             size_t got;
-            if (gz_) { int n = gzread(g_, b.text + b.len, (unsigned)blk); if (n < 0) { err = "gzip read error in " + path_; return false; } got = (size_t)n; }
+            if (gzmap_) {
+                std::string why;
+                const long n = inflater_.read((uint8_t *)b.text + b.len, blk, why);
+                if (n < 0) { err = "gzip read error in " + path_ + ": " + why; return false; }
+                got = (size_t)n;
+            }
+            else if (gz_) { int n = gzread(g_, b.text + b.len, (unsigned)blk); if (n < 0) { err = "gzip read error in " + path_; return false; } got = (size_t)n; }
             else got = fread(b.text + b.len, 1, blk, f_);
             b.len += got;
             if (got == 0) eof_ = true;
@@ -252,6 +275,7 @@ private:
         for (auto &x : th) x.join();
     }
     bool gz_ = false, eof_ = false, own_f_ = true; gzFile g_ = nullptr; FILE *f_ = nullptr; std::string path_;
+    std::shared_ptr<MappedFile> gzmap_; GzInflater inflater_;   // .gz input: the compressed file, mapped, and its decoder
     std::vector<char> carry_;
     int parse_threads_ = 1;
     std::shared_ptr<MappedFile> map_;

@@ -1,0 +1,123 @@
+"""The host-side streaming gzip decoder (mitoflex_amd/csrc/mf_inflate.cpp) against zlib: every block
+type, sub-table codes, multi-member files, resume points (the caller's buffer ends anywhere), matches
+that reach back across calls, transparent pass-through, trailing garbage, and damaged streams."""
+import gzip
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(built_lib, tmp_path_factory):
+    csrc = os.path.join(ROOT, "mitoflex_amd", "csrc")
+    out = str(tmp_path_factory.mktemp("inflate") / "inflate_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tests", "native", "inflate_check.cpp"),
+                           os.path.join(csrc, "build", "mf_inflate.o"), "-lz", "-lpthread", "-o", out])
+    return out
+
+
+def gz_member(data: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, name=None, extra=False) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    body = c.compress(data) + c.flush()
+    flg = (8 if name else 0) | (4 if extra else 0)
+    hdr = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\x00\x03"
+    if extra:
+        hdr += b"\x06\x00BC\x02\x00\x12\x34"
+    if name:
+        hdr += name + b"\0"
+    return hdr + body + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xFFFFFFFF).to_bytes(4, "little")
+
+
+def fastq_like(rng, n):
+    out = []
+    for i in range(n):
+        L = rng.choice([150, 150, 151, 100])
+        out.append("@SRR000.%d %d/1\n%s\n+\n%s\n" % (i, i, "".join(rng.choices("ACGTN", weights=[30, 20, 20, 30, 1], k=L)),
+                                                  "".join(rng.choices("FFFFF:,#", k=L))))
+    return "".join(out).encode()
+
+
+def check(exe, tmp_path, blob: bytes, want: bytes, chunks=(1 << 20,)):
+    f, w = tmp_path / "x.gz", tmp_path / "x.raw"
+    f.write_bytes(blob); w.write_bytes(want)
+    for c in chunks:
+        out = subprocess.check_output([exe, str(f), str(w), str(c)]).decode().strip()
+        assert out == "ok", (out, c, len(blob), len(want))
+
+
+def test_block_types_and_resume_points(exe, tmp_path):
+    rng = random.Random(1)
+    text = fastq_like(rng, 3000)
+    rnd = bytes(rng.getrandbits(8) for _ in range(200_000))
+    runs = (b"A" * 70000 + b"xyz" * 30000 + bytes(range(256)) * 300)
+    cases = {
+        "fastq_l6": gz_member(text, 6), "fastq_l1": gz_member(text, 1), "fastq_l9": gz_member(text, 9),
+        "stored": gz_member(text[:150_000], 0), "fixed": gz_member(text[:100_000], 6, zlib.Z_FIXED),
+        "huffman_only": gz_member(text[:100_000], 6, zlib.Z_HUFFMAN_ONLY), "rle": gz_member(runs, 6, zlib.Z_RLE),
+        "random": gz_member(rnd, 6), "runs": gz_member(runs, 9), "named": gz_member(text[:5000], 6, name=b"reads.fq", extra=True),
+        "empty": gz_member(b""), "one": gz_member(b"A"), "tiny": gz_member(b"@r\nACGT\n+\nIIII\n"),
+    }
+    raw = {"fastq_l6": text, "fastq_l1": text, "fastq_l9": text, "stored": text[:150_000], "fixed": text[:100_000],
+           "huffman_only": text[:100_000], "rle": runs, "random": rnd, "runs": runs, "named": text[:5000], "empty": b"", "one": b"A",
+           "tiny": b"@r\nACGT\n+\nIIII\n"}
+    for name, blob in cases.items():
+        chunks = (1 << 20, 65536, 4099, 300, 274, 7) if len(raw[name]) < 300_000 else (1 << 20, 65536, 4099)
+        check(exe, tmp_path, blob, raw[name], chunks)
+        assert gzip.decompress(blob) == raw[name]               # the vector itself is a valid gzip file
+    check(exe, tmp_path, cases["tiny"], raw["tiny"], (1, 2, 3))
+
+
+def test_long_codes_use_subtables(exe, tmp_path):
+    # a skewed alphabet makes zlib emit 12..15-bit literal codes (longer than the 11-bit first-level table)
+    rng = random.Random(2)
+    weights = [2 ** max(0, 14 - i // 12) for i in range(256)]
+    data = bytes(rng.choices(range(256), weights=weights, k=400_000))
+    check(exe, tmp_path, gz_member(data, 6, zlib.Z_HUFFMAN_ONLY), data, (1 << 20, 1000))
+    # far matches: 32 KiB window used to the last byte, and matches that cross the caller's buffer boundary
+    blk = bytes(rng.getrandbits(8) for _ in range(32768 - 3))
+    data = (blk + b"###") * 12
+    check(exe, tmp_path, gz_member(data, 9), data, (1 << 20, 32768, 32767, 40000, 5))
+
+
+def test_members_garbage_and_passthrough(exe, tmp_path):
+    rng = random.Random(3)
+    a, b, c = fastq_like(rng, 500), fastq_like(rng, 20), b""
+    multi = gz_member(a, 6) + gz_member(c) + gz_member(b, 1) + gz_member(a[:1000], 0)
+    check(exe, tmp_path, multi, a + b + a[:1000], (1 << 20, 997))
+    check(exe, tmp_path, multi + b"\0\0\0\0 trailing junk", a + b + a[:1000], (1 << 20, 13))
+    check(exe, tmp_path, multi + b"\x1f", a + b + a[:1000], (4096,))
+    plain = b"@r1\nACGT\n+\nFFFF\n" * 1000                     # not gzip at all: gzread hands it through
+    check(exe, tmp_path, plain, plain, (1 << 20, 100))
+    check(exe, tmp_path, b"", b"", (16,))
+
+
+def test_damaged_streams_are_errors(exe, tmp_path):
+    rng = random.Random(4)
+    text = fastq_like(rng, 400)
+    good = gz_member(text, 6)
+    f = tmp_path / "bad.gz"
+
+    def result(blob):
+        f.write_bytes(blob)
+        return subprocess.check_output([exe, str(f), "-", "65536"]).decode().strip()
+
+    assert result(good) == "ok %d" % len(text)
+    for cut in (len(good) - 1, len(good) - 4, len(good) - 8, len(good) - 9, len(good) // 2, 12, 9, 3):
+        assert result(good[:cut]).startswith("error"), cut
+    bad_crc = bytearray(good); bad_crc[-6] ^= 1
+    assert result(bytes(bad_crc)) == "error: incorrect data check"
+    bad_len = bytearray(good); bad_len[-1] ^= 1
+    assert result(bytes(bad_len)) == "error: incorrect length check"
+    flipped = 0
+    for pos in range(20, len(good) - 8, max(1, len(good) // 40)):
+        dmg = bytearray(good); dmg[pos] ^= 0x10
+        r = result(bytes(dmg))
+        assert r.startswith("error")                              # caught by the decoder or, at the latest, by the CRC
+        flipped += 1
+    assert flipped > 20
+    assert result(b"\x1f\x8b\x07" + good[3:]).startswith("error")
