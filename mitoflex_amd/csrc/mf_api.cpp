@@ -85,6 +85,24 @@ struct mf_kmerset {
     std::map<int, DevTables> dev;
 };
 
+// device temporaries of one build: released on every exit path
+struct DevScratch {
+    std::vector<void *> bufs;
+    template <class T> hipError_t alloc(T *&p, size_t bytes) { hipError_t e = hipMalloc(&p, bytes); if (e == hipSuccess) bufs.push_back(p); return e; }
+    ~DevScratch() { for (void *p : bufs) hipFree(p); }
+};
+// tables under construction: released unless the build commits them
+struct TablesGuard {
+    DevTables *t;
+    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->plut); } }
+};
+// events of one timing loop
+struct EventList {
+    std::vector<hipEvent_t> ev;
+    hipError_t create(size_t n) { ev.reserve(n); for (size_t i = 0; i < n; i++) { hipEvent_t e; hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; ev.push_back(e); } return hipSuccess; }
+    ~EventList() { for (hipEvent_t e : ev) hipEventDestroy(e); }
+};
+
 static uint32_t env_u32(const char *name, uint32_t dflt)
 {
     const char *v = getenv(name);
@@ -100,9 +118,9 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     hipStream_t st = ctx->stream;
     if (ks->kind == MF_KIND_PROTEIN) {
         const ProtBaitHost &P = ks->pbait;
-        DevTables T;
+        DevTables T; TablesGuard guard{&T}; DevScratch tmp;
         uint8_t *d_aa = nullptr, *d_run = nullptr; unsigned long long *d_cnt = nullptr;
-        HIPCHK(hipMalloc(&d_aa, P.aa.size())); HIPCHK(hipMalloc(&d_run, P.runlen.size()));
+        HIPCHK(tmp.alloc(d_aa, P.aa.size())); HIPCHK(tmp.alloc(d_run, P.runlen.size()));
         HIPCHK(hipMemcpyAsync(d_aa, P.aa.data(), P.aa.size(), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_run, P.runlen.data(), P.runlen.size(), hipMemcpyHostToDevice, st));
         HIPCHK(hipMalloc(&T.keys, ks->slots * sizeof(uint64_t)));
@@ -113,27 +131,26 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
         HIPCHK(launch_build_pbits(T.keys, ks->slots, T.kbloom, ks->kb_log2w, st));
         HIPCHK(hipMalloc(&T.plut, sizeof ks->codon_lut));
         HIPCHK(hipMemcpyAsync(T.plut, ks->codon_lut, sizeof ks->codon_lut, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMalloc(&d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
+        HIPCHK(tmp.alloc(d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
         HIPCHK(launch_count_keys(T.keys, ks->slots, 1, nullptr, 0, d_cnt, st));
         unsigned long long cnt[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        hipFree(d_aa); hipFree(d_run); hipFree(d_cnt);
         T.n_keys = cnt[0];
         KmerSetView &V = T.view;
         V.k = ks->k; V.kw = 1; V.slot_mask = ks->slots - 1; V.keys = T.keys;
         V.kb_log2w = ks->kb_log2w; V.kbloom = T.kbloom;
         V.prot = 1; V.kb_in_lds = ks->kb_in_lds ? 1u : 0u; V.plut = T.plut;
-        ks->dev[device] = T;
+        ks->dev[device] = T; guard.t = nullptr;
         *out = &ks->dev[device];
         return MF_OK;
     }
     const BaitHost &B = ks->bait;
-    DevTables T;
+    DevTables T; TablesGuard guard{&T}; DevScratch tmp;
     uint32_t *d_words = nullptr; uint8_t *d_run = nullptr; uint32_t *d_pos = nullptr, *d_flag = nullptr;
     unsigned long long *d_cnt = nullptr;
-    HIPCHK(hipMalloc(&d_words, B.words.size() * 4));
-    HIPCHK(hipMalloc(&d_run, B.runlen.size()));
+    HIPCHK(tmp.alloc(d_words, B.words.size() * 4));
+    HIPCHK(tmp.alloc(d_run, B.runlen.size()));
     HIPCHK(hipMemcpyAsync(d_words, B.words.data(), B.words.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_run, B.runlen.data(), B.runlen.size(), hipMemcpyHostToDevice, st));
     const size_t key_bytes = ks->slots * ks->kw * sizeof(uint64_t);
@@ -141,11 +158,11 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     HIPCHK(hipMemsetAsync(T.keys, 0xFF, key_bytes, st));
     if (ks->kw == 2) {
         if (B.total > 0xFFFFFFF0ull) return fail(MF_E_ARG, "bait longer than 2^32 bases is not supported for k > 32");
-        HIPCHK(hipMalloc(&d_pos, ks->slots * 4));
+        HIPCHK(tmp.alloc(d_pos, ks->slots * 4));
         HIPCHK(hipMemsetAsync(d_pos, 0xFF, ks->slots * 4, st));
     }
-    HIPCHK(hipMalloc(&d_flag, 4)); HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
-    HIPCHK(hipMalloc(&d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
+    HIPCHK(tmp.alloc(d_flag, 4)); HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
+    HIPCHK(tmp.alloc(d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
     BaitView bv{d_words, B.total, d_run};
     HIPCHK(launch_build_table(bv, ks->k, ks->kw, T.keys, ks->slots, d_pos, st));
     if (ks->geom.s) {
@@ -163,7 +180,6 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_words); hipFree(d_run); hipFree(d_pos); hipFree(d_flag); hipFree(d_cnt);
     T.n_keys = cnt[0]; T.n_smers = cnt[1] + (flag ? 1 : 0);
     KmerSetView &V = T.view;
     V.k = ks->k; V.kw = ks->kw; V.slot_mask = ks->slots - 1; V.keys = T.keys;
@@ -174,7 +190,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
     // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
     V.use_stab = (T.n_smers / 2 * STAGE2_K > ((uint64_t)32 << ks->stage2_log2w) * 7 / 10) || getenv("MF_USE_STAB") ? 1u : 0u;
-    ks->dev[device] = T;
+    ks->dev[device] = T; guard.t = nullptr;
     *out = &ks->dev[device];
     return MF_OK;
 }
@@ -575,10 +591,10 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     int stride = steps <= 8 ? 1 : (int)env_u32("MF_EVENT_STRIDE", 8);
     if (stride < 1) stride = 1;
     const int n_sampled = (steps + stride - 1) / stride;
-    std::vector<hipEvent_t> ev((size_t)n_sampled * 4);
-    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-    hipEvent_t e_begin, e_end;
-    HIPCHK(hipEventCreate(&e_begin)); HIPCHK(hipEventCreate(&e_end));
+    EventList events;
+    HIPCHK(events.create((size_t)n_sampled * 4 + 2));
+    hipEvent_t *ev = events.ev.data();
+    const hipEvent_t e_begin = ev[(size_t)n_sampled * 4], e_end = ev[(size_t)n_sampled * 4 + 1];
     HIPCHK(hipEventRecord(e_begin, st));
     for (int i = 0; i < steps; i++) {
         rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, i % stride == 0 ? &ev[(size_t)(i / stride) * 4] : nullptr);
@@ -607,8 +623,6 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         stats->ms_total = tot / steps; stats->ms_screen = scr / n_sampled; stats->ms_mark = mrk / n_sampled; stats->ms_exact = exa / n_sampled;
         stats->algorithmic_bytes = algorithmic_bytes(r->v);
     }
-    for (auto &e : ev) hipEventDestroy(e);
-    hipEventDestroy(e_begin); hipEventDestroy(e_end);
     return MF_OK;
 }
 
