@@ -1,0 +1,55 @@
+// Parallel decoding of ONE gzip stream (host side).
+//
+// A deflate stream has no index, so a single-member .gz is normally inflated by one thread.  This
+// reader cuts the compressed file into chunks and decodes them concurrently all the same:
+//   * chunk 0 of a group starts at a known block boundary with a known 32 KiB window;
+//   * every other chunk SEARCHES for the next dynamic-Huffman block header after its nominal start
+//     (bit by bit; a candidate must carry complete precode, literal/length and distance codes) and
+//     decodes from there into 16-bit symbols, writing a marker instead of a byte wherever a match
+//     reaches back into the window it does not know;
+//   * the chunks are then linked in order: a chunk is accepted only if the bit position where the
+//     accepted data ends is exactly the position it started from -- by induction from chunk 0 every
+//     accepted chunk starts at a true block boundary of the true stream.  Whatever does not link
+//     (a false candidate, a stored or fixed block at the seam) is decoded serially across the gap;
+//   * markers are replaced from the (now known) windows, chunk by chunk in parallel.
+// The result is the same byte stream a serial inflate produces; CRC-32 and ISIZE of every member are
+// verified.  The idea follows the published two-pass schemes for gzip (pugz, rapidgzip).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace mf {
+
+class ParallelGzReader {
+public:
+    // data must stay mapped while the reader lives.  chunk_bytes: compressed bytes per speculative chunk.
+    ParallelGzReader() = default;
+    ~ParallelGzReader();
+    ParallelGzReader(const ParallelGzReader &) = delete;
+    ParallelGzReader &operator=(const ParallelGzReader &) = delete;
+    void open(const uint8_t *data, size_t size, int threads, size_t chunk_bytes = (size_t)2 << 20);
+    // same contract as GzInflater::read: bytes written, 0 at the end, -1 on a damaged stream
+    long read(uint8_t *out, size_t cap, std::string &err);
+    bool eof() const { return !pre_running_ && done_ && opos_ == obuf_.size(); }   // done_ belongs to the helper thread while it runs
+    // bookkeeping for tests and tuning
+    uint64_t chunks_linked = 0, chunks_discarded = 0, gap_fill_bytes = 0;
+
+private:
+    bool fill(std::vector<uint8_t> &dst, std::string &err);   // decode the next group of chunks into dst
+    void start_prefetch();                             // ... on a helper thread, while the current group is being served
+    std::thread pre_; bool pre_running_ = false, pre_ok_ = true; std::string pre_err_;
+    std::vector<uint8_t> nbuf_;
+    bool begin_member(std::string &err);               // gzip header at cur_bit_ (byte aligned) -> first block
+    const uint8_t *data_ = nullptr; size_t size_ = 0;
+    int threads_ = 1; size_t chunk_ = 0;
+    size_t cur_bit_ = 0;                               // block boundary where the accepted data ends
+    bool in_member_ = false, done_ = false, any_member_ = false, transparent_ = false;
+    std::vector<uint8_t> window_; size_t wlen_ = 0;    // last 32 KiB of accepted output, right-aligned
+    uint32_t crc_ = 0; uint64_t member_out_ = 0;
+    std::vector<uint8_t> obuf_; size_t opos_ = 0;
+};
+
+} // namespace mf

@@ -1,5 +1,6 @@
 #include "mf_pipeline.h"
 #include "mf_inflate.h"
+#include "mf_pinflate.h"
 #include "../../include/mitofilter.h"
 
 #include <algorithm>
@@ -87,7 +88,22 @@ struct MateBatch {
     std::shared_ptr<MappedFile> map;      // set when recs point into a mapped file instead of `text`
     ~MateBatch() { free(text); }
     void recycle() { recs.clear(); len = 0; map.reset(); }
-    bool reserve(size_t want) { if (want <= cap) return true; size_t nc = cap ? cap : (32u << 20); while (nc < want) nc *= 2; char *p = (char *)realloc(text, nc); if (!p) return false; text = p; cap = nc; return true; }
+    // the text buffer of a stream-mode batch (hundreds of MB): 2 MiB aligned and marked for huge pages, like the vectors
+    bool reserve(size_t want)
+    {
+        if (want <= cap) return true;
+        size_t nc = cap ? cap : ((size_t)64 << 20);
+        while (nc < want) nc *= 2;
+        const size_t huge = (size_t)2 << 20;
+        nc = (nc + huge - 1) / huge * huge;
+        char *p = (char *)aligned_alloc(huge, nc);
+        if (!p) return false;
+        madvise(p, nc, MADV_HUGEPAGE);
+        if (len) memcpy(p, text, len);
+        free(text);
+        text = p; cap = nc;
+        return true;
+    }
 };
 
 class BatchReader {
@@ -104,7 +120,10 @@ public:
                 if (st.st_size == 0 || m != MAP_FAILED) {
                     gzmap_ = std::make_shared<MappedFile>();
                     if (st.st_size > 0) { gzmap_->p = (const char *)m; gzmap_->n = (size_t)st.st_size; madvise(m, gzmap_->n, MADV_SEQUENTIAL); }
-                    inflater_.open((const uint8_t *)gzmap_->p, gzmap_->n);
+                    // big files: several chunks of the one stream are decoded at a time (mf_pinflate.h)
+                    par_gz_ = parse_threads_ >= 3 && gzmap_->n >= ((size_t)16 << 20) && !getenv("MF_SERIAL_INFLATE");
+                    if (par_gz_) pinflater_.open((const uint8_t *)gzmap_->p, gzmap_->n, parse_threads_);
+                    else inflater_.open((const uint8_t *)gzmap_->p, gzmap_->n);
                     ::close(fd);
                     path_ = path;
                     return true;
@@ -162,7 +181,7 @@ public:
             size_t got;
             if (gzmap_) {
                 std::string why;
-                const long n = inflater_.read((uint8_t *)b.text + b.len, blk, why);
+                const long n = par_gz_ ? pinflater_.read((uint8_t *)b.text + b.len, blk, why) : inflater_.read((uint8_t *)b.text + b.len, blk, why);
                 if (n < 0) { err = "gzip read error in " + path_ + ": " + why; return false; }
                 got = (size_t)n;
             }
@@ -276,6 +295,7 @@ private:
     }
     bool gz_ = false, eof_ = false, own_f_ = true; gzFile g_ = nullptr; FILE *f_ = nullptr; std::string path_;
     std::shared_ptr<MappedFile> gzmap_; GzInflater inflater_;   // .gz input: the compressed file, mapped, and its decoder
+    ParallelGzReader pinflater_; bool par_gz_ = false;
     std::vector<char> carry_;
     int parse_threads_ = 1;
     std::shared_ptr<MappedFile> map_;

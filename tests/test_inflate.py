@@ -17,7 +17,8 @@ def exe(built_lib, tmp_path_factory):
     csrc = os.path.join(ROOT, "mitoflex_amd", "csrc")
     out = str(tmp_path_factory.mktemp("inflate") / "inflate_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tests", "native", "inflate_check.cpp"),
-                           os.path.join(csrc, "build", "mf_inflate.o"), "-lz", "-lpthread", "-o", out])
+                           os.path.join(csrc, "build", "mf_inflate.o"), os.path.join(csrc, "build", "mf_pinflate.o"),
+                           "-lz", "-lpthread", "-o", out])
     return out
 
 
@@ -42,12 +43,19 @@ def fastq_like(rng, n):
     return "".join(out).encode()
 
 
-def check(exe, tmp_path, blob: bytes, want: bytes, chunks=(1 << 20,)):
+def check(exe, tmp_path, blob: bytes, want: bytes, chunks=(1 << 20,), parallel=((3, 4096), (8, 20000), (4, 1 << 20))):
+    """Serial decoder with every caller buffer size in `chunks`, then the parallel reader with (threads,
+    compressed chunk size) pairs -- tiny chunks force many speculative starts, seams inside stored and fixed
+    blocks, and gap fills."""
     f, w = tmp_path / "x.gz", tmp_path / "x.raw"
     f.write_bytes(blob); w.write_bytes(want)
     for c in chunks:
         out = subprocess.check_output([exe, str(f), str(w), str(c)]).decode().strip()
         assert out == "ok", (out, c, len(blob), len(want))
+    for threads, cchunk in parallel:
+        for c in (chunks[0], chunks[-1] if chunks[-1] >= 100 else 4099):
+            out = subprocess.check_output([exe, str(f), str(w), str(c), "--parallel", str(threads), str(cchunk)]).decode().strip()
+            assert out.startswith("ok"), (out, c, threads, cchunk, len(blob), len(want))
 
 
 def test_block_types_and_resume_points(exe, tmp_path):
@@ -104,7 +112,10 @@ def test_damaged_streams_are_errors(exe, tmp_path):
 
     def result(blob):
         f.write_bytes(blob)
-        return subprocess.check_output([exe, str(f), "-", "65536"]).decode().strip()
+        serial = subprocess.check_output([exe, str(f), "-", "65536"]).decode().strip()
+        par = subprocess.check_output([exe, str(f), "-", "65536", "--parallel", "4", "8192"]).decode().strip()
+        assert serial.startswith("error") == par.startswith("error"), (serial, par)     # same verdict from both decoders
+        return serial
 
     assert result(good) == "ok %d" % len(text)
     for cut in (len(good) - 1, len(good) - 4, len(good) - 8, len(good) - 9, len(good) // 2, 12, 9, 3):
@@ -121,3 +132,24 @@ def test_damaged_streams_are_errors(exe, tmp_path):
         flipped += 1
     assert flipped > 20
     assert result(b"\x1f\x8b\x07" + good[3:]).startswith("error")
+
+
+def test_parallel_reader_links_chunks(exe, tmp_path):
+    """On an ordinary single-member file every speculative chunk must link (that is where the speed comes from);
+    flush points (empty stored blocks), a level change in mid-stream and a member boundary go through gap fills."""
+    rng = random.Random(5)
+    text = fastq_like(rng, 30000)                                   # ~10 MB of text
+    f, w = tmp_path / "big.gz", tmp_path / "big.raw"
+    f.write_bytes(gz_member(text, 6)); w.write_bytes(text)
+    out = subprocess.check_output([exe, str(f), str(w), str(1 << 20), "--parallel", "8", "300000"]).decode().split()
+    assert out[0] == "ok" and int(out[2]) >= 7 and int(out[4]) == 0 and int(out[6]) == 0, out   # every chunk behind the first links, no gap fill
+    # sync-flush points every 100 KB, then a switch to stored blocks, then level 9
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = b""
+    for i in range(0, 3_000_000, 100_000):
+        body += c.compress(text[i:i + 100_000]) + c.flush(zlib.Z_SYNC_FLUSH if (i // 100_000) % 3 else zlib.Z_FULL_FLUSH)
+    body += c.compress(text[3_000_000:5_000_000]) + c.flush()
+    raw = text[:5_000_000]
+    blob = (b"\x1f\x8b\x08\0\0\0\0\0\x00\x03" + body + zlib.crc32(raw).to_bytes(4, "little") + len(raw).to_bytes(4, "little")
+            + gz_member(text[5_000_000:7_000_000], 0) + gz_member(text[7_000_000:], 9))
+    check(exe, tmp_path, blob, text, (1 << 20, 70001), parallel=((8, 150000), (5, 40000), (16, 1 << 20)))
