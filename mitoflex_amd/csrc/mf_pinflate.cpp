@@ -158,12 +158,13 @@ bool decode_block(Bits &in, const Tables &t, Out<Sym> &out, const char *&err)
 enum Stop { AT_BOUNDARY, MEMBER_END, FAILED };
 
 // Decode whole blocks from the reader's position; stops in front of the first block that starts at
-// or after stop_bit, or behind the final block of the member.
+// or after stop_bit, or behind the final block of the member, or (memory bound: a few bytes of
+// deflate can expand to megabytes) at the first block boundary after max_out symbols.
 template <class Sym>
-Stop decode_until(Bits &in, Tables &t, Out<Sym> &out, size_t stop_bit, const char *&err)
+Stop decode_until(Bits &in, Tables &t, Out<Sym> &out, size_t stop_bit, size_t max_out, const char *&err)
 {
     for (;;) {
-        if (in.bitpos() >= stop_bit) return AT_BOUNDARY;
+        if (in.bitpos() >= stop_bit || out.n - out.prefix >= max_out) return AT_BOUNDARY;
         if (!in.need(3)) { err = "truncated deflate stream"; return FAILED; }
         const bool final = in.peek(1); in.drop(1);
         const unsigned type = in.peek(2); in.drop(2);
@@ -322,6 +323,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
     size_t G = (size_t)threads_;
     while (G > 1 && base_byte + (G - 1) * chunk_ >= size_) G--;
     auto nominal_bit = [&](size_t j) { return (base_byte + j * chunk_) * 8; };
+    const size_t max_out = chunk_ * 32 > ((size_t)16 << 20) ? chunk_ * 32 : ((size_t)16 << 20);   // symbols per piece before it is cut short
     struct Res { bool valid = false; size_t start = 0, end = 0; Stop stop = FAILED; Out<uint16_t> sym; };
     std::vector<Res> res(G);
     Out<uint8_t> first; const char *first_err = nullptr; Stop first_stop = FAILED; size_t first_end = 0;
@@ -336,7 +338,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
                 Tables t; const char *why = nullptr;
                 r.sym.v.resize(chunk_ * 3 + 4096);
                 r.start = s;
-                r.stop = decode_until<uint16_t>(in, t, r.sym, nominal_bit(j + 1), why);
+                r.stop = decode_until<uint16_t>(in, t, r.sym, nominal_bit(j + 1), max_out, why);
                 r.end = in.bitpos();
                 r.valid = r.stop != FAILED;
             });
@@ -346,7 +348,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
             first.v.resize(wlen_ + chunk_ * 3 + 4096);
             memcpy(first.v.data(), window_.data() + WINDOW - wlen_, wlen_);
             first.n = first.prefix = wlen_;
-            first_stop = decode_until<uint8_t>(in, t, first, nominal_bit(1), first_err);
+            first_stop = decode_until<uint8_t>(in, t, first, nominal_bit(1), max_out, first_err);
             first_end = in.bitpos();
         }
         for (auto &t : th) t.join();
@@ -389,15 +391,16 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
             f.n = f.prefix = wlen_;
             Bits in(data_, size_); in.seek(cur_bit_);
             Tables t; const char *why = nullptr;
-            const Stop st = decode_until<uint8_t>(in, t, f, r.start, why);
+            const Stop st = decode_until<uint8_t>(in, t, f, r.start, max_out, why);
             if (st == FAILED) { err = why ? why : "damaged deflate stream"; ok = false; break; }
             gap_fill_bytes += f.n - f.prefix;
             add_bytes(f.v.data() + f.prefix, f.n - f.prefix);
             cur_bit_ = in.bitpos();
             if (st == MEMBER_END) { ok = finish_member(); if (!ok || done_) break; }
-            if (r.start != cur_bit_) {                                   // overshot (the candidate was not a block start) or a new member began
+            if (r.start != cur_bit_) {                                   // overshot (the candidate was not a block start), a new member began, or the fill hit its size bound
                 if (r.start < cur_bit_) { chunks_discarded++; continue; }
-                j--; continue;                                           // still ahead of us: fill again from the new position
+                if (st == AT_BOUNDARY) break;                            // size bound: hand out what there is, the next group starts here
+                j--; continue;                                           // a member ended in the gap: fill again from the next member's first block
             }
         }
         // r.start == cur_bit_: by induction a true block boundary -- accept the chunk

@@ -153,3 +153,10 @@ def test_parallel_reader_links_chunks(exe, tmp_path):
     blob = (b"\x1f\x8b\x08\0\0\0\0\0\x00\x03" + body + zlib.crc32(raw).to_bytes(4, "little") + len(raw).to_bytes(4, "little")
             + gz_member(text[5_000_000:7_000_000], 0) + gz_member(text[7_000_000:], 9))
     check(exe, tmp_path, blob, text, (1 << 20, 70001), parallel=((8, 150000), (5, 40000), (16, 1 << 20)))
+
+
+def test_highly_compressible_input_stays_bounded(exe, tmp_path):
+    """A few hundred KB of deflate that expand a thousandfold: speculative chunks are cut short at their size
+    bound, nothing links, everything goes through bounded gap fills -- and the bytes are still right."""
+    raw = b"\0" * (64 << 20) + b"ACGT" * (1 << 20) + bytes(random.Random(6).getrandbits(8) for _ in range(100_000))
+    check(exe, tmp_path, gz_member(raw, 6), raw, (1 << 20,), parallel=((8, 16384), (4, 4096)))
