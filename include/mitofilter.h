@@ -85,7 +85,8 @@ typedef struct {
     uint64_t n_pass;
     uint64_t n_candidates;   /* reads handed to the exact kernel (screened mode) */
     float    ms_total;       /* hipEvent time, first launch -> last kernel end  */
-    float    ms_screen;      /* screen kernel only (streams every packed byte once) */
+    float    ms_screen;      /* screen kernel only (streams every packed byte once); the three kernel times come from
+                                events attached to the dispatches themselves (hipExtLaunchKernelGGL start/stop) */
     float    ms_mark;        /* mark kernel: finishes the screen's positives, sets candidate bits */
     float    ms_exact;       /* exact kernel only */
     uint64_t algorithmic_bytes; /* ceil(2*bases/8) + ceil(n_reads/8): SURVEY.md 8d byte model */
@@ -162,9 +163,9 @@ int mf_filter(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, i
 /* Same, result left on the device (no D2H); for timing loops.  Runs `steps`
  * passes back to back on the library's stream.  ms_total is the whole loop
  * (one event pair around it) divided by steps; the per-kernel times are
- * averages over the passes that carry events between their kernels -- every
- * pass up to 8 steps, every 8th pass beyond (the events themselves cost
- * about 16 us per pass). */
+ * averages over the passes whose dispatches carry start/stop events --
+ * every pass up to 8 steps, every 8th pass beyond (a profiled dispatch costs
+ * a few microseconds of command-processor work). */
 int mf_filter_resident(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
                        int steps, mf_filter_stats_t *stats);
 

@@ -547,25 +547,22 @@ int mf_reads_free(mf_reads *r) { reads_release(r); return MF_OK; }
 // ------------------------------------------------------------------- filter
 static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_bases + 7) / 8 + (V.n_reads + 7) / 8; }
 
-// enqueue one pass on `st`; events (when non-null): ev[0] before screen, ev[3] after screen, ev[1] after mark, ev[2] after exact
+// enqueue one pass on `st`.  ev (when non-null) holds six events that are attached to the three kernels themselves
+// (start/stop of screen, mark, exact): each pair reads that dispatch's own duration and the stream carries no extra packets.
 static int enqueue_pass(const mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, int n_cu,
                         hipStream_t st, hipEvent_t *ev)
 {
+    KernelTiming tm[3]; const KernelTiming *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;
+    if (ev) { for (int i = 0; i < 3; i++) tm[i] = KernelTiming{ev[2 * i], ev[2 * i + 1]}; t0 = &tm[0]; t1 = &tm[1]; t2 = &tm[2]; }
     if (S.prot) {          // protein-space set: one kernel translates and probes every read (no screen exists in residue space)
-        if (ev) { HIPCHK(hipEventRecord(ev[0], st)); HIPCHK(hipEventRecord(ev[3], st)); HIPCHK(hipEventRecord(ev[1], st)); }
-        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st));
-        if (ev) HIPCHK(hipEventRecord(ev[2], st));
+        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st, t2));
         return MF_OK;
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
     // no per-pass memsets: the exact kernel clears the candidate words it consumes and zeroes unused tally slots
-    if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs, r->d_rec_counts, n_cu, st));
-    if (ev) HIPCHK(hipEventRecord(ev[3], st));
-    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs, r->d_rec_counts, r->d_cand, n_cu, st));
-    if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st));
-    if (ev) HIPCHK(hipEventRecord(ev[2], st));
+    if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs, r->d_rec_counts, n_cu, st, t0));
+    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs, r->d_rec_counts, r->d_cand, n_cu, st, t1));
+    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits, r->d_hits, r->d_counters, n_cu, st, t2));
     return MF_OK;
 }
 
@@ -586,18 +583,18 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         HIPCHK(dev_reserve(r->d_hits, r->cap_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4, false));
         HIPCHK(hipMemsetAsync(r->d_hits, 0, (r->v.n_reads ? r->v.n_reads : 1) * 4, st));
     }
-    // per-kernel timing with events between the kernels costs a few microseconds of command-processor work per pass,
-    // so long timing loops sample every `stride`-th pass; the whole loop is bracketed by its own pair of events
+    // per-kernel timing: events attached to the dispatches of every `stride`-th pass (profiling-enabled dispatches
+    // cost a little command-processor work each); the whole loop is bracketed by its own pair of events
     int stride = steps <= 8 ? 1 : (int)env_u32("MF_EVENT_STRIDE", 8);
     if (stride < 1) stride = 1;
     const int n_sampled = (steps + stride - 1) / stride;
     EventList events;
-    HIPCHK(events.create((size_t)n_sampled * 4 + 2));
+    HIPCHK(events.create((size_t)n_sampled * 6 + 2));
     hipEvent_t *ev = events.ev.data();
-    const hipEvent_t e_begin = ev[(size_t)n_sampled * 4], e_end = ev[(size_t)n_sampled * 4 + 1];
+    const hipEvent_t e_begin = ev[(size_t)n_sampled * 6], e_end = ev[(size_t)n_sampled * 6 + 1];
     HIPCHK(hipEventRecord(e_begin, st));
     for (int i = 0; i < steps; i++) {
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, i % stride == 0 ? &ev[(size_t)(i / stride) * 4] : nullptr);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(e_end, st));
@@ -612,11 +609,14 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         memset(stats, 0, sizeof *stats);
         float tot = 0, scr = 0, mrk = 0, exa = 0, t;
         HIPCHK(hipEventElapsedTime(&tot, e_begin, e_end));
+        const bool prot = T->view.prot != 0, screened = !prot && mode == MF_MODE_SCREENED && T->view.s > 0;
         for (int i = 0; i < n_sampled; i++) {
-            hipEvent_t *e = &ev[(size_t)i * 4];
-            HIPCHK(hipEventElapsedTime(&t, e[0], e[3])); scr += t;
-            HIPCHK(hipEventElapsedTime(&t, e[3], e[1])); mrk += t;
-            HIPCHK(hipEventElapsedTime(&t, e[1], e[2])); exa += t;
+            hipEvent_t *e = &ev[(size_t)i * 6];
+            if (screened) {
+                HIPCHK(hipEventElapsedTime(&t, e[0], e[1])); scr += t;
+                HIPCHK(hipEventElapsedTime(&t, e[2], e[3])); mrk += t;
+            }
+            HIPCHK(hipEventElapsedTime(&t, e[4], e[5])); exa += t;
         }
         stats->n_reads = r->v.n_reads; stats->n_pass = cnt[0];
         stats->n_candidates = (mode == MF_MODE_SCREENED && T->view.s > 0) ? cnt[1] : r->v.n_reads;

@@ -14,14 +14,19 @@ struct BaitView {
     const uint8_t  *runlen;
 };
 
+// optional kernel-attached timing: the events receive the dispatch's own begin and end timestamps
+struct KernelTiming { hipEvent_t start, stop; };
+
 // screen = screen_kernel (records stage-1 positives) + mark_kernel (finishes them, sets candidate bits)
 uint64_t screen_grid_for(const ReadsView &R, int n_cu);
 uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu);          // 16-byte records per screen workgroup
-hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st);
+hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
+                         const KernelTiming *tm = nullptr);
 hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
-                       hipStream_t st);
+                       hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
-                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st);
+                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st,
+                        const KernelTiming *tm = nullptr);
 hipError_t launch_build_kbloom(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, uint64_t slots, uint32_t *postab_scratch,
                               hipStream_t st);
@@ -38,7 +43,7 @@ hipError_t launch_build_ptable(const uint8_t *aa, const uint8_t *runlen, uint64_
                                hipStream_t st);
 hipError_t launch_build_pbits(const uint64_t *keys, uint64_t slots, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_pfilter(const ReadsView &R, const KmerSetView &S, uint32_t thr, bool count_all, uint32_t *out_bits,
-                          uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st);
+                          uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);
 
 } // namespace mf

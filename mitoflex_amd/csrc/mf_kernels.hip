@@ -21,6 +21,7 @@
 // full per-k-mer count, so the emitted bits equal the brute-force oracle's.
 #include "mf_common.h"
 #include "mf_kernels.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 namespace mf {
@@ -947,46 +948,58 @@ uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu)
     return grid ? (n_chunks + grid - 1) / grid * SCREEN_BLOCK : 0;
 }
 
+// Launch with or without kernel-attached timing events: hipExtLaunchKernelGGL stamps the events with the
+// dispatch's own begin and end, so the elapsed time is the kernel's duration (what rocprofv3 reports) and no
+// extra packet sits between two kernels of the pass.
+#define MF_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                                             \
+    do {                                                                                                             \
+        if (tm) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), st, (tm)->start, (tm)->stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                           \
+    } while (0)
+
 template <int SPW>
-static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st)
+static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
+                              const KernelTiming *tm)
 {
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, R, S,
-                       static_cast<ScreenRec *>(recs), cap, rec_counts);
+    MF_LAUNCH((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
+              static_cast<ScreenRec *>(recs), cap, rec_counts);
 }
 
 template <int SPW>
 static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
-                            hipStream_t st)
+                            hipStream_t st, const KernelTiming *tm)
 {
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
-    hipLaunchKernelGGL((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * MARK_SPLIT), dim3(MARK_BLOCK), 0, st, R, S,
-                       static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand);
+    MF_LAUNCH((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * MARK_SPLIT), dim3(MARK_BLOCK), 0, st, tm, R, S,
+              static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand);
 }
 
-hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st)
+hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
+                         const KernelTiming *tm)
 {
-    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, st);
-    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, st);
+    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, st, tm);
+    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, st, tm);
     return hipGetLastError();
 }
 
 hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
-                       hipStream_t st)
+                       hipStream_t st, const KernelTiming *tm)
 {
-    if (S.stride == 16) launch_mark_spw<1>(R, S, recs, rec_counts, cand, n_cu, st);
-    else launch_mark_spw<2>(R, S, recs, rec_counts, cand, n_cu, st);
+    if (S.stride == 16) launch_mark_spw<1>(R, S, recs, rec_counts, cand, n_cu, st, tm);
+    else launch_mark_spw<2>(R, S, recs, rec_counts, cand, n_cu, st, tm);
     return hipGetLastError();
 }
 
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
-                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st)
+                        uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st,
+                        const KernelTiming *tm)
 {
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
     const uint64_t n_wc = (n_bw + WC_WORDS - 1) / WC_WORDS;
@@ -999,7 +1012,7 @@ hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand
     if (grid > EXACT_MAX_GRID) grid = EXACT_MAX_GRID;
 #define MF_LAUNCH_EXACT(KW, CA) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&exact_kernel<KW, CA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
+        MF_LAUNCH((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, tm, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
     if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true); else MF_LAUNCH_EXACT(1, false); }
     else           { if (count_all) MF_LAUNCH_EXACT(2, true); else MF_LAUNCH_EXACT(2, false); }
 #undef MF_LAUNCH_EXACT

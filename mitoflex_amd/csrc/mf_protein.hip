@@ -20,6 +20,7 @@
 // a three-instruction hash for the bit table (the table hash is computed for positives only), a
 // two-bit test in one 64-bit block.
 #include "mf_kernels.h"
+#include <hip/hip_ext.h>
 
 namespace mf {
 
@@ -202,7 +203,7 @@ hipError_t launch_build_ptable(const uint8_t *aa, const uint8_t *runlen, uint64_
 }
 
 hipError_t launch_pfilter(const ReadsView &R, const KmerSetView &S, uint32_t thr, bool count_all, uint32_t *out_bits,
-                          uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st)
+                          uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st, const KernelTiming *tm)
 {
     const uint64_t n_groups = (R.n_reads + PF_READS - 1) / PF_READS;
     uint64_t grid = (uint64_t)2 * (n_cu > 0 ? n_cu : 256);            // two 12-wave workgroups per CU
@@ -214,8 +215,10 @@ hipError_t launch_pfilter(const ReadsView &R, const KmerSetView &S, uint32_t thr
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&pfilter_kernel<LK, CA>),               \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
         if (e_ != hipSuccess) return e_;                                                                           \
-        hipLaunchKernelGGL((pfilter_kernel<LK, CA>), dim3((unsigned)grid), dim3(PF_BLOCK), lds, st, R, S, thr, out_bits, hits_out, \
-                           counters);                                                                              \
+        if (tm) hipExtLaunchKernelGGL((pfilter_kernel<LK, CA>), dim3((unsigned)grid), dim3(PF_BLOCK), (uint32_t)lds, st, tm->start,    \
+                                      tm->stop, 0, R, S, thr, out_bits, hits_out, counters);                        \
+        else hipLaunchKernelGGL((pfilter_kernel<LK, CA>), dim3((unsigned)grid), dim3(PF_BLOCK), lds, st, R, S, thr, out_bits,        \
+                                hits_out, counters);                                                               \
     } while (0)
     if (S.kb_in_lds) { if (count_all) PF_LAUNCH(true, true); else PF_LAUNCH(true, false); }
     else { if (count_all) PF_LAUNCH(false, true); else PF_LAUNCH(false, false); }
