@@ -612,11 +612,10 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         const bool prot = T->view.prot != 0, screened = !prot && mode == MF_MODE_SCREENED && T->view.s > 0;
         for (int i = 0; i < n_sampled; i++) {
             hipEvent_t *e = &ev[(size_t)i * 6];
-            if (screened) {
-                HIPCHK(hipEventElapsedTime(&t, e[0], e[1])); scr += t;
-                HIPCHK(hipEventElapsedTime(&t, e[2], e[3])); mrk += t;
-            }
-            HIPCHK(hipEventElapsedTime(&t, e[4], e[5])); exa += t;
+            // a kernel that had nothing to do was not launched and its events were never recorded: that reads as zero
+            auto span = [&](hipEvent_t a, hipEvent_t b) { t = 0; if (hipEventElapsedTime(&t, a, b) != hipSuccess) { (void)hipGetLastError(); t = 0; } return t; };
+            if (screened) { scr += span(e[0], e[1]); mrk += span(e[2], e[3]); }
+            exa += span(e[4], e[5]);
         }
         stats->n_reads = r->v.n_reads; stats->n_pass = cnt[0];
         stats->n_candidates = (mode == MF_MODE_SCREENED && T->view.s > 0) ? cnt[1] : r->v.n_reads;

@@ -107,13 +107,6 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     extern __shared__ uint4 s_tab4[];                                       // stage-1 table, then the record counter
     const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
     uint32_t &s_nrec = *reinterpret_cast<uint32_t *>(s_tab4 + nb4);         // (all LDS in one array: the dynamic base stays 16-byte aligned)
-    {
-        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
-        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
-        if (threadIdx.x == 0) s_nrec = 0;
-    }
-    __syncthreads();
-
     const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
     const uint64_t chunk = (uint64_t)blockDim.x * U;
     const uint64_t n_chunks = R.n_vec / chunk;          // n_vec is padded to a whole number of chunks
@@ -164,7 +157,13 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     // two register sets, ping-pong: the next chunk is in flight while this one is examined
     u32x4 a[U], b[U]; uint32_t ax[U], bx[U];
     uint64_t c = blockIdx.x;
-    if (c < n_chunks) load(c, a, ax);
+    if (c < n_chunks) load(c, a, ax);                  // the first chunk is already on its way while the table is staged
+    {
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
+        if (threadIdx.x == 0) s_nrec = 0;
+    }
+    __syncthreads();
     while (c < n_chunks) {
         if (c + cstep < n_chunks) load(c + cstep, b, bx);
         stage1(c, a, ax);

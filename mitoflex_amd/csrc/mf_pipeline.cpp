@@ -156,6 +156,7 @@ public:
     bool next(MateBatch &b, uint64_t max_records, std::string &err)
     {
         if (map_) return next_mapped(b, max_records);
+        if (parse_threads_ > 1 && !getenv("MF_SERIAL_PARSE")) return next_stream_indexed(b, max_records, err);
         b.recs.clear(); b.len = 0;
         if (!carry_.empty()) { if (!b.reserve(carry_.size())) { err = "out of memory"; return false; } memcpy(b.text, carry_.data(), carry_.size()); b.len = carry_.size(); carry_.clear(); }
         struct Off { size_t h, s, q; uint32_t hl, sl, ql; };
@@ -202,15 +203,17 @@ public:
         return !b.recs.empty();
     }
 private:
-    // ---- mapped mode.  The file is cut into segments of SEG bytes.  Newlines are counted per segment
-    // in parallel (once); a prefix sum gives every segment the index of the first line that starts in
-    // it, hence the index of the first record whose header starts in it.  A batch is then a range of
-    // record indices: the segments holding those headers are parsed in parallel, every record written
-    // straight to its slot of the batch (a record is followed across the segment border).
+    // ---- indexed parsing of a text buffer (a mapped plain file, or the decoded text of a stream batch).
+    // The buffer is cut into segments of SEG bytes.  Newlines are counted per segment in parallel; a
+    // prefix sum gives every segment the index of the first line that starts in it, hence the index of
+    // the first record whose header starts in it.  A range of record indices is then parsed by the
+    // segments holding those headers, in parallel, every record written straight to its slot (a record
+    // is followed across the segment border).
     size_t SEG = getenv("MF_PARSE_SEG") ? (size_t)strtoull(getenv("MF_PARSE_SEG"), nullptr, 10) : (size_t)(4u << 20);   // bytes per parse segment
-    void index_segments()
+    struct LineIndex { std::vector<uint64_t> first_line; uint64_t n_records = 0; };
+    // final: the buffer ends where the input ends, so an unterminated last line is a line (lines() yields it)
+    void build_index(const char *p, size_t n, bool final, LineIndex &ix)
     {
-        const char *p = map_->p; const size_t n = map_->n;
         const size_t nseg = (n + SEG - 1) / SEG;
         std::vector<uint64_t> cnt(nseg, 0);
         parallel_for(nseg, [&](size_t i) {
@@ -218,39 +221,31 @@ private:
             while (q < e) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!nl) break; c++; q = nl + 1; }
             cnt[i] = c;
         });
-        // seg_first_line_[i]: index of the first line that STARTS inside segment i (a line starts after every '\n' and at 0)
-        seg_first_line_.assign(nseg + 1, 0);
+        // first_line[i]: index of the first line that STARTS inside segment i (a line starts after every '\n' and at 0)
+        ix.first_line.assign(nseg + 1, 0);
         uint64_t newlines = 0;
         for (size_t i = 0; i < nseg; i++) {
             const size_t off = i * SEG;
-            seg_first_line_[i] = newlines + ((off > 0 && p[off - 1] != '\n') ? 1 : 0);
+            ix.first_line[i] = newlines + ((off > 0 && p[off - 1] != '\n') ? 1 : 0);
             newlines += cnt[i];
         }
-        const uint64_t total_lines = newlines + ((n > 0 && p[n - 1] != '\n') ? 1 : 0);   // lines() yields an unterminated last line
-        seg_first_line_[nseg] = total_lines;
-        n_records_ = total_lines / 4;                       // a partial record at the very end is dropped
-        indexed_ = true;
+        const uint64_t total_lines = newlines + ((final && n > 0 && p[n - 1] != '\n') ? 1 : 0);
+        ix.first_line[nseg] = total_lines;
+        ix.n_records = total_lines / 4;                     // a partial record at the very end is dropped / left for the next batch
     }
-    // records whose header line starts in segments before i
-    uint64_t seg_rec_base(size_t i) const { return (seg_first_line_[i] + 3) / 4; }
-    bool next_mapped(MateBatch &b, uint64_t max_records)
+    // records [r0, r1) of the buffer -> out[0 .. r1-r0); *end_off (optional): offset just behind record r1-1
+    void parse_records(const char *p, size_t n, const LineIndex &ix, uint64_t r0, uint64_t r1, FqRec *out, size_t *end_off)
     {
-        b.recs.clear(); b.map = map_;
-        if (!indexed_) index_segments();
-        if (rec_pos_ >= n_records_) return false;
-        const char *p = map_->p; const size_t n = map_->n;
         const size_t nseg = (n + SEG - 1) / SEG;
-        const uint64_t r0 = rec_pos_, r1 = std::min<uint64_t>(n_records_, r0 + max_records);
-        b.recs.resize((size_t)(r1 - r0));
-        // first segment holding record r0's header: the last i with seg_rec_base(i) <= r0
+        auto rec_base = [&](size_t i) { return (ix.first_line[i] + 3) / 4; };      // records whose header starts in segments before i
+        // first segment holding record r0's header: the last i with rec_base(i) <= r0
         size_t lo = 0, hi = nseg;
-        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (seg_rec_base(mid) <= r0) lo = mid; else hi = mid; }
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (rec_base(mid) <= r0) lo = mid; else hi = mid; }
         size_t s0 = lo, s1 = s0;
-        while (s1 < nseg && seg_rec_base(s1) < r1) s1++;
-        FqRec *out = b.recs.data();
+        while (s1 < nseg && rec_base(s1) < r1) s1++;
         parallel_for(s1 - s0, [&](size_t gi) {
             const size_t i = s0 + gi, off = i * SEG, end = std::min(n, off + SEG);
-            uint64_t line = seg_first_line_[i];
+            uint64_t line = ix.first_line[i];
             size_t pos = off;
             if (off > 0 && p[off - 1] != '\n') {            // byte `off` continues an earlier line
                 const char *nl = (const char *)memchr(p + off, '\n', n - off);
@@ -275,13 +270,68 @@ private:
                     if (!nl) { q = n; li++; break; }
                     q = e + 1;
                 }
-                if (li < 4) break;                          // partial record at the very end: dropped
+                if (li < 4) break;                          // partial record at the very end
                 if (rec >= r0) out[rec - r0] = FqRec{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]};
+                if (rec + 1 == r1 && end_off) *end_off = q;
                 rec++;
                 pos = q;
             }
         });
+    }
+    // ---- mapped mode: the whole file is indexed once, a batch is a range of record indices
+    bool next_mapped(MateBatch &b, uint64_t max_records)
+    {
+        b.recs.clear(); b.map = map_;
+        if (!indexed_) { build_index(map_->p, map_->n, true, map_ix_); indexed_ = true; }
+        if (rec_pos_ >= map_ix_.n_records) return false;
+        const uint64_t r0 = rec_pos_, r1 = std::min<uint64_t>(map_ix_.n_records, r0 + max_records);
+        b.recs.resize((size_t)(r1 - r0));
+        parse_records(map_->p, map_->n, map_ix_, r0, r1, b.recs.data(), nullptr);
         rec_pos_ = r1;
+        return true;
+    }
+    // ---- stream mode with several threads (decoded .gz text, pipes): enough text for the batch is read
+    // first, then indexed and parsed like a mapped file; what lies behind the last record goes to the next batch
+    size_t read_some(char *dst, size_t want, std::string &err, bool &failed)
+    {
+        if (gzmap_) {
+            std::string why;
+            const long n = par_gz_ ? pinflater_.read((uint8_t *)dst, want, why) : inflater_.read((uint8_t *)dst, want, why);
+            if (n < 0) { err = "gzip read error in " + path_ + ": " + why; failed = true; return 0; }
+            return (size_t)n;
+        }
+        if (gz_) { const int n = gzread(g_, dst, (unsigned)std::min<size_t>(want, (size_t)1 << 30)); if (n < 0) { err = "gzip read error in " + path_; failed = true; return 0; } return (size_t)n; }
+        return fread(dst, 1, want, f_);
+    }
+    bool next_stream_indexed(MateBatch &b, uint64_t max_records, std::string &err)
+    {
+        b.recs.clear(); b.len = 0;
+        if (!carry_.empty()) { if (!b.reserve(carry_.size())) { err = "out of memory"; return false; } memcpy(b.text, carry_.data(), carry_.size()); b.len = carry_.size(); carry_.clear(); }
+        LineIndex ix;
+        size_t target = (size_t)((double)max_records * rec_bytes_est_ * 1.02) + 4096;
+        for (;;) {
+            while (!eof_ && b.len < target) {
+                const size_t want = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)1 << 16, target - b.len));
+                if (!b.reserve(b.len + want)) { err = "out of memory"; return false; }
+                bool failed = false;
+                const size_t got = read_some(b.text + b.len, want, err, failed);
+                if (failed) return false;
+                b.len += got;
+                if (got == 0) eof_ = true;
+            }
+            build_index(b.text, b.len, eof_, ix);
+            if (ix.n_records >= max_records || eof_) break;
+            const double per = ix.n_records ? (double)b.len / (double)ix.n_records : rec_bytes_est_ * 2;
+            target = b.len + (size_t)((double)(max_records - ix.n_records + 1) * per * 1.05) + ((size_t)1 << 16);
+        }
+        const uint64_t take = std::min<uint64_t>(max_records, ix.n_records);
+        if (take == 0) return false;                        // nothing but a partial record left: dropped
+        b.recs.resize((size_t)take);
+        size_t cut = b.len;
+        parse_records(b.text, b.len, ix, 0, take, b.recs.data(), &cut);
+        rec_bytes_est_ = 0.5 * rec_bytes_est_ + 0.5 * ((double)cut / (double)take);
+        if (take < ix.n_records || !eof_) carry_.assign(b.text + cut, b.text + b.len);
+        b.len = cut;
         return true;
     }
     template <class F> void parallel_for(size_t count, F f)
@@ -299,8 +349,9 @@ private:
     std::vector<char> carry_;
     int parse_threads_ = 1;
     std::shared_ptr<MappedFile> map_;
-    std::vector<uint64_t> seg_first_line_; bool indexed_ = false;
-    uint64_t n_records_ = 0, rec_pos_ = 0;
+    LineIndex map_ix_; bool indexed_ = false;
+    uint64_t rec_pos_ = 0;
+    double rec_bytes_est_ = 350.0;                      // bytes per record seen so far (stream mode read-ahead)
 };
 
 struct PairBatch {
