@@ -592,6 +592,10 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
 {
     const int nm = fq2 ? 2 : 1;
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
+    const bool timing = getenv("MF_PIPE_TIMING") != nullptr;      // busy seconds of every stage on stderr (diagnostics)
+    std::atomic<uint64_t> t_read[2] = {{0}, {0}}, t_check{0}, t_scan{0}, t_decide{0}, t_write[2] = {{0}, {0}};
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const uint64_t t_start = now_us();
     BatchReader rd[2];
     for (int m = 0; m < nm; m++) {
         rd[m].set_parse_threads(std::max(1, threads / (2 * nm)));
@@ -611,7 +615,10 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             for (;;) {
                 auto b = mate_pool->get();
                 std::string e;
-                if (!rd[m].next(*b, batch_reads, e)) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
+                const uint64_t t0 = now_us();
+                const bool got = rd[m].next(*b, batch_reads, e);
+                t_read[m] += now_us() - t0;
+                if (!got) { if (!e.empty()) { set_err(MF_E_IO, e); abort_all(); } break; }
                 if (!q_read[m].push(b)) break;
             }
             q_read[m].finish();
@@ -635,6 +642,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             // `drain(..start)` past the end of a string, or a line that is not valid UTF-8
             // Records are independent here, so the batch is cut into chunks; each chunk stops at its first
             // offender and the earliest one bounds the batch (records past it are never looked at again).
+            const uint64_t tc0 = now_us();
             std::atomic<uint64_t> first_bad{n};
             parallel_chunks(n, threads, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) {
@@ -661,6 +669,8 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                 }
             });
             const uint64_t n_ok = first_bad.load();
+            t_check += now_us() - tc0;
+            const uint64_t ts0 = now_us();
             const bool panicked = n_ok < n;
             // GPU: counts (and hashes of mate 1 when deduplicating)
             if (!P.trunc && n_ok) {
@@ -682,6 +692,8 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                 }
                 if (!ok) { abort_all(); break; }
             }
+            t_scan += now_us() - ts0;
+            const uint64_t td0 = now_us();
             qb->keep.assign(n ? n : 1, 0);
             for (uint64_t i = 0; i < n_ok; i++) {
                 const FqRec &r1 = qb->mate[0]->recs[i];
@@ -701,6 +713,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                 qb->keep[i] = 1; stats.kept++;
             }
             stats.total += n_ok;
+            t_decide += now_us() - td0;
             qb->n = n_ok; qb->index = idx++;
             if (panicked) { stats.panicked = true; stop = true; }
             if (short_mate) stop = true;
@@ -729,6 +742,8 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             };
             QualPtr qb;
             while (ok && q_write[m].pop(qb)) {
+                const uint64_t tw0 = now_us();
+                struct Acc { std::atomic<uint64_t> &a; uint64_t t0; std::function<uint64_t()> now; ~Acc() { a += now() - t0; } } acc{t_write[m], tw0, now_us};
                 const FqRec *recs = qb->mate[m]->recs.data();
                 for (uint64_t i = 0; i < qb->n && ok; i++) {
                     if (!qb->keep[i]) continue;
@@ -746,6 +761,9 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
         });
 
     for (auto &t : th) t.join();
+    if (timing)
+        fprintf(stderr, "[mf qualfilter] wall %.3f s | read %.3f %.3f | validate %.3f | scan (H2D, kernels, D2H) %.3f | decide %.3f | write %.3f %.3f\n",
+                (now_us() - t_start) / 1e6, t_read[0] / 1e6, t_read[1] / 1e6, t_check / 1e6, t_scan / 1e6, t_decide / 1e6, t_write[0] / 1e6, t_write[1] / 1e6);
     return rc;
 }
 
