@@ -180,13 +180,13 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
 // Finishes the screen: for every recorded positive, stage 2 (canonical s-mer, Bloom probes),
 // optional stage 3 (exact s-mer table, large baits), then the candidate bit of the read that holds
 // the s-mer.  Dense: one record per lane, a few hundred thousand records per 5 Gbp.
-constexpr int MARK_SPLIT = 8;       // mark workgroups per screen workgroup
-constexpr int MARK_BLOCK = 256;
+constexpr int MARK_SPLIT = 1;       // mark workgroups per screen workgroup (workgroup dispatch costs ~7 ns each: few, fat workgroups)
+constexpr int MARK_BLOCK = 1024;     // launch bound; the launch may use fewer threads
 
 template <int SPW, int U>
 __global__ void __launch_bounds__(MARK_BLOCK)
 mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint32_t rec_cap, const uint32_t *__restrict__ rec_counts,
-            uint32_t screen_block, uint32_t *__restrict__ cand)
+            uint32_t screen_block, uint32_t split, uint32_t *__restrict__ cand)
 {
     // stage-2 table straight from global memory: <= 32 KiB, L2 resident, a few probes per record
     const uint32_t *__restrict__ s_st2 = S.bloom + ((size_t)1 << S.bloom_log2w);
@@ -194,12 +194,28 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
     const uint32_t smask = S.smask;
     const uint64_t chunk = (uint64_t)screen_block * U;
     const bool fast = R.len_magic32 != 0;
-    // MARK_SPLIT workgroups share one screen workgroup's record list (records are few, the work per
-    // record is a chain of latencies: more lanes in flight, fewer records per lane)
-    const uint32_t list = blockIdx.x / MARK_SPLIT, part = blockIdx.x % MARK_SPLIT;
+    // `split` workgroups share one screen workgroup's record list.  Measured: the work per record is a chain of
+    // latencies, but dispatching a workgroup costs about as much as a record does, so one 1024-thread workgroup
+    // per list (two records per lane at 0.5 % bait reads) beats eight of 256 threads by 7 us.
+    const uint32_t list = blockIdx.x / split, part = blockIdx.x % split;
     const uint32_t n = rec_counts[list];
     const ScreenRec *__restrict__ my = recs + (size_t)list * rec_cap;
-    for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += MARK_SPLIT * blockDim.x) {
+    // Candidate bits are not written one atomic per positive: the records of a wave are neighbours in the
+    // stream, so their reads share a handful of bitmap words, and same-line atomics of one wave instruction are
+    // executed one after the other (measured: 85 ns per mark with 10 % bait reads).  Every lane collects its
+    // marks in (pend_w, pend_b); at the end of the iteration lanes holding the same word OR their bits together
+    // with a segmented scan and the last lane of each run issues one atomic.
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = part * blockDim.x + (threadIdx.x & ~63u); base < n; base += split * blockDim.x) {   // wave-uniform trip count
+        const uint32_t i = base + lane;
+        uint32_t pend_w = EMPTY32, pend_b = 0;
+        auto mark = [&](uint64_t r) {
+            const uint32_t w = (uint32_t)(r >> 5), b = 1u << (r & 31);
+            if (w == pend_w) { pend_b |= b; return; }
+            if (pend_b) atomicOr(&cand[pend_w], pend_b);              // a lane's reads span two bitmap words at most: rare
+            pend_w = w; pend_b = b;
+        };
+        if (i < n) {
         const ScreenRec rec = my[i];
         // offset (bases, inside its chunk) of sample idx of the recording lane
         constexpr int NS = U * 4 * SPW;
@@ -213,42 +229,13 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
         uint64_t rq = 0; uint32_t rrem = 0;
         if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
         uint32_t m = rec.hitmask;                     // sample idx <-> bit NS-1-idx
-        uint64_t last_r = ~0ULL;
-        // Two or more stage-1 positives of one lane inside one read: practically always a bait read
-        // (two independent false positives there have probability ~1e-4 per lane and chunk), so the
-        // read is marked without fetching the s-mer for stage 2.  Marking is only ever conservative --
-        // the exact kernel decides.
-        if (fast && (m & (m - 1))) {
-            const uint32_t o_lo = off_of(NS - 1 - (31 - __clz(m))), o_hi = off_of(NS - 1 - (__ffs(m) - 1));
-            const uint32_t t_lo = rrem + o_lo, t_hi = rrem + o_hi;
-            const uint32_t q_lo = __umulhi(t_lo, R.len_magic32), q_hi = __umulhi(t_hi, R.len_magic32);
-            const uint32_t r_lo = t_lo - q_lo * R.uniform_len, r_hi = t_hi - q_hi * R.uniform_len;
-            if (q_lo == q_hi && r_lo + (uint32_t)S.s <= R.uniform_len && r_hi + (uint32_t)S.s <= R.uniform_len
-                && cb + o_hi + S.s <= R.total_bases) {
-                const uint64_t r = rq + q_lo;
-                atomicOr(&cand[r >> 5], 1u << (r & 31));
-                continue;
-            }
-        }
-        while (m) {
-            const int bit = 31 - __clz(m);
-            m &= ~(1u << bit);
-            const int idx = NS - 1 - bit;
-            const uint32_t off = off_of(idx);
-            const uint64_t g0 = cb + off;
-            uint64_t r = ~0ULL;
-            if (fast) {
-                const uint32_t t = rrem + off;
-                const uint32_t dq = __umulhi(t, R.len_magic32);
-                const uint32_t offr = t - dq * R.uniform_len;
-                r = rq + dq;
-                // straddles two reads / lies in the padding / same read as just marked
-                if (offr + (uint32_t)S.s > R.uniform_len || g0 + S.s > R.total_bases || r == last_r) continue;
-            }
+        // finish one positive: fetch its s-mer, stage 2 (canonical s-mer, STAGE2_K Bloom probes), optional stage 3,
+        // then the candidate bit of the read that holds it
+        auto verify = [&](int idx, uint64_t r_known) {
+            const uint64_t g0 = cb + off_of(idx);
             const uint64_t wi = g0 >> 4;
             uint32_t sm = R.words[wi];
             if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
-            // stage 2: canonical s-mer, STAGE2_K Bloom probes
             const uint32_t rc = revcomp_s(sm, S.s);
             const uint32_t cn_ = sm < rc ? sm : rc;
             const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
@@ -258,19 +245,51 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
                 const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
                 ok &= s_st2[pos >> 5] >> (pos & 31);
             }
-            if (!(ok & 1u)) continue;
-            // stage 3 (large baits only): exact s-mer table in global memory
-            if (S.use_stab && !stab_contains(S, sm)) continue;
-            if (!fast) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) continue; }
-            atomicOr(&cand[r >> 5], 1u << (r & 31));
-            last_r = r;
-            // the positives a lane has left usually sit in the read just marked: if the lowest and
-            // the highest of them do, so does everything in between
-            if (fast && m) {
-                const uint32_t t_lo = rrem + off_of(NS - 1 - (31 - __clz(m))), t_hi = rrem + off_of(NS - 1 - (__ffs(m) - 1));
-                if (rq + __umulhi(t_lo, R.len_magic32) == r && rq + __umulhi(t_hi, R.len_magic32) == r) m = 0;
-            }
+            if (!(ok & 1u)) return;
+            if (S.use_stab && !stab_contains(S, sm)) return;          // stage 3 (large baits only): exact s-mer table
+            uint64_t r = r_known;
+            if (r == ~0ULL) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) return; }
+            mark(r);
+        };
+        if (!fast) {                                  // ragged reads: every positive is looked up on its own
+            while (m) { const int bit = 31 - __clz(m); m &= ~(1u << bit); verify(NS - 1 - bit, ~0ULL); }
+        } else {
+        // Uniform read length: the positives of a lane are walked in stream order and grouped by the read
+        // they fall into (a division by multiplication each).  Two or more stage-1 positives of one lane
+        // inside one read are practically always a bait read (two independent false positives there have
+        // probability ~1e-4 per lane and chunk), so such a read is marked without fetching anything; a
+        // lone positive goes through stage 2.  Marking is only ever conservative -- the exact kernel decides.
+        uint64_t cur_r = ~0ULL; int cur_idx = 0; uint32_t cur_n = 0;
+        auto flush = [&] {
+            if (cur_n >= 2) mark(cur_r);
+            else if (cur_n == 1) verify(cur_idx, cur_r);
+        };
+        while (m) {
+            const int bit = 31 - __clz(m);
+            m &= ~(1u << bit);
+            const int idx = NS - 1 - bit;
+            const uint32_t off = off_of(idx);
+            const uint32_t t = rrem + off;
+            const uint32_t dq = __umulhi(t, R.len_magic32);
+            const uint32_t offr = t - dq * R.uniform_len;
+            // straddles two reads / lies in the padding behind the last read: not a sample of any read
+            if (offr + (uint32_t)S.s > R.uniform_len || cb + off + S.s > R.total_bases) continue;
+            const uint64_t r = rq + dq;
+            if (r == cur_r) { cur_n++; continue; }
+            flush();
+            cur_r = r; cur_idx = idx; cur_n = 1;
         }
+        flush();
+        }
+        }
+        // wave-level merge of the pending marks (all 64 lanes take part)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ow = __shfl_up(pend_w, d), ob = __shfl_up(pend_b, d);
+            if (lane >= (uint32_t)d && ow == pend_w) pend_b |= ob;
+        }
+        const uint32_t next_w = __shfl_down(pend_w, 1);
+        if (pend_b && (lane == 63 || next_w != pend_w)) atomicOr(&cand[pend_w], pend_b);
     }
 }
 
@@ -976,8 +995,10 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
-    MF_LAUNCH((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * MARK_SPLIT), dim3(MARK_BLOCK), 0, st, tm, R, S,
-              static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, cand);
+    static const uint32_t split = getenv("MF_MARK_SPLIT") ? (uint32_t)atoi(getenv("MF_MARK_SPLIT")) : (uint32_t)MARK_SPLIT;
+    static const uint32_t mblock = getenv("MF_MARK_BLOCK") ? (uint32_t)atoi(getenv("MF_MARK_BLOCK")) : (uint32_t)MARK_BLOCK;
+    MF_LAUNCH((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * split), dim3(mblock), 0, st, tm, R, S,
+              static_cast<const ScreenRec *>(recs), cap, rec_counts, (uint32_t)SCREEN_BLOCK, split, cand);
 }
 
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
