@@ -60,12 +60,15 @@ MF_HD uint32_t bloom_hash(uint32_t smer) { return smer * 0x9E3779B1u; }
 MF_HD uint32_t stage1_mix(uint32_t smer, uint32_t h) { return (smer >> 13) | (h << 19); }
 MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return (stage1_mix(smer, h) >> (8 * i)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
-MF_HD uint32_t bloom_bits(uint32_t h) { return h; }   // k-mer bit table (exact kernel): low 20 bits pick the four bit positions, top bits the block
 constexpr int STAGE2_K = 4;
 MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }
 MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u; return (h ^ (h >> 16)) | 1u; }
-// k-mer bit table in front of the open-address table (exact kernel): h = 32-bit table hash of the key
-MF_HD uint32_t kbloom_hash(uint32_t h) { return h; }   // fold32 output is already mixed: block from the top bits, bits from the low 20
+// k-mer bit table in front of the open-address table (exact kernel): one 64-bit block per key, one bit in each
+// dword.  Its hash is one multiply per 32 bits of key and xors -- the table hash proper is only computed for the
+// positives; the block index comes from the top bits, the two bit positions from the low bits folded with the middle.
+MF_HD uint32_t kbit_hash1(uint64_t lo) { return ((uint32_t)lo * 0x9E3779B1u) ^ ((uint32_t)(lo >> 32) * 0x85EBCA77u); }
+MF_HD uint32_t kbit_hash2(uint64_t lo, uint64_t hi) { return kbit_hash1(lo) ^ ((uint32_t)hi * 0xC2B2AE3Du) ^ ((uint32_t)(hi >> 32) * 0x27D4EB2Fu); }
+MF_HD uint32_t kbit_pos(uint32_t hb) { return hb ^ (hb >> 16); }   // bit of dword 0: low five bits, of dword 1: the next five
 MF_HD uint32_t smer_hash(uint32_t smer) { uint32_t h = smer * 0xC2B2AE35u; return h ^ (h >> 15); }
 
 // ---- table sizing rules (the test oracle restates the same rule) -----------

@@ -393,7 +393,7 @@ __device__ __forceinline__ bool table_has(const KmerSetView &S, uint64_t klo, ui
 // One work item: k-mer positions [p0, p0 + ITEM_POS) of the read starting at base b0 with n_pos positions.
 // Verified hits are added to *cnt (LDS, shared by the read's items).
 template <int KW, bool COUNT_ALL>
-__device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView &S, const uint4 *__restrict__ s_kb4,
+__device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView &S, const uint2 *__restrict__ s_kb2,
                                           uint32_t kb_shift, uint64_t b0, uint64_t n_pos, uint64_t p0, bool hasn,
                                           uint32_t thr, uint32_t *cnt)
 {
@@ -430,18 +430,16 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
         else { r0 = (y0 >> drop) | (y1 << (64 - drop)); r1 = y1 >> drop; }
     }
     // canonical key of position i of this item
-    auto key_at = [&](int i, uint64_t &klo, uint64_t &khi) -> uint32_t {
+    auto key_at = [&](int i, uint64_t &klo, uint64_t &khi) {
         if (KW == 1) {
             const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
             const uint64_t rc = funnel64(r0, r1, 2 * (ITEM_POS - 1 - i)) & mask_lo;
             klo = fwd < rc ? fwd : rc; khi = 0;
-            return (uint32_t)hash_key1(klo);
         } else {
             const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
             uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
             const bool f = (hi < rhi) || (hi == rhi && lo < rlo);
             klo = f ? lo : rlo; khi = f ? hi : rhi;
-            return (uint32_t)hash_key2(klo, khi);
         }
     };
 
@@ -450,10 +448,11 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
 #pragma unroll
     for (int i = 0; i < ITEM_POS; i++) {
         uint64_t klo, khi;
-        const uint32_t hb = kbloom_hash(key_at(i, klo, khi));
-        const uint4 blk = s_kb4[hb >> kb_shift];
-        const uint32_t g = bloom_bits(hb);
-        const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31)) & (blk.z >> ((g >> 10) & 31)) & (blk.w >> ((g >> 15) & 31));
+        key_at(i, klo, khi);
+        const uint32_t hb = KW == 1 ? kbit_hash1(klo) : kbit_hash2(klo, khi);
+        const uint2 blk = s_kb2[hb >> kb_shift];
+        const uint32_t g = kbit_pos(hb);
+        const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31));
         pos_mask |= (t & 1u) << i;
     }
     // positions past the end of the read, and windows holding an invalid base
@@ -474,7 +473,8 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
         const int i = __ffs(pos_mask) - 1;
         pos_mask &= pos_mask - 1;
         uint64_t klo, khi;
-        const uint32_t h = key_at(i, klo, khi);
+        key_at(i, klo, khi);
+        const uint32_t h = (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi));
         if (table_has<KW>(S, klo, khi, h)) atomicAdd(cnt, 1u);
     }
 }
@@ -508,7 +508,7 @@ __device__ __forceinline__ uint32_t nth_set_lane(uint64_t ballot, uint32_t m)
 }
 
 template <int KW, bool COUNT_ALL>
-__device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSetView &S, const uint4 *__restrict__ s_kb4, uint32_t kb_shift,
+__device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSetView &S, const uint2 *__restrict__ s_kb2, uint32_t kb_shift,
                                                uint32_t thr, bool two_phase, int lane, bool owner, uint64_t b0, uint32_t np,
                                                uint32_t hasn, uint32_t *my_cnt)
 {
@@ -547,7 +547,7 @@ __device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSet
                 const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
                 const uint32_t p0 = it * ITEM_POS;
                 if (t < n_items && it < it_hi && p0 < cnp)
-                    item_hits<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
+                    item_hits<KW, COUNT_ALL>(R, S, s_kb2, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
             }
         }
     }
@@ -566,7 +566,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
     uint32_t *s_res = reinterpret_cast<uint32_t *>(s_mem4);                  // [WAVES][WC_WORDS]
     uint32_t *s_cnt = s_res + WAVES * WC_WORDS;                              // [WAVES][64]
     constexpr int HEAD4 = (WAVES * WC_WORDS + WAVES * 64) / 4;
-    const uint4 *s_kb4 = s_mem4 + HEAD4;
+    const uint2 *s_kb2 = reinterpret_cast<const uint2 *>(s_mem4 + HEAD4);
     {
         const uint32_t nb4 = (1u << S.kb_log2w) >> 2;
         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.kbloom);
@@ -574,7 +574,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const uint32_t kb_shift = 32 - (S.kb_log2w - 2);
+    const uint32_t kb_shift = 32 - (S.kb_log2w - 1);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t *my_res = s_res + wid * WC_WORDS, *my_cnt = s_cnt + wid * 64;
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
@@ -646,7 +646,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
                 np = n_pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_pos;
                 hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
             }
-            run_candidates<KW, COUNT_ALL>(R, S, s_kb4, kb_shift, thr, cand != nullptr, lane, active, b0, np, hasn, my_cnt);
+            run_candidates<KW, COUNT_ALL>(R, S, s_kb2, kb_shift, thr, cand != nullptr, lane, active, b0, np, hasn, my_cnt);
             if (active) {
                 const uint32_t h = my_cnt[lane];
                 if (COUNT_ALL) hits_out[r] = h;
@@ -776,20 +776,17 @@ __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t
     }
 }
 
-// LDS front of the bait table: one 128-bit block per canonical k-mer, one bit in each dword
+// LDS front of the bait table: one 64-bit block per canonical k-mer, one bit in each dword
 __global__ void build_kbloom_kernel(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots) return;
     const uint64_t lo = keys[i * kw], hi = kw == 2 ? keys[i * kw + 1] : 0;
     if (lo == EMPTY64 && (kw == 1 || hi == EMPTY64)) return;
-    const uint32_t h = (uint32_t)(kw == 1 ? hash_key1(lo) : hash_key2(lo, hi));
-    const uint32_t hb = kbloom_hash(h), g = bloom_bits(hb);
-    uint32_t *blk = kbloom + 4 * (size_t)(hb >> (32 - (kb_log2w - 2)));
+    const uint32_t hb = kw == 1 ? kbit_hash1(lo) : kbit_hash2(lo, hi), g = kbit_pos(hb);
+    uint32_t *blk = kbloom + 2 * (size_t)(hb >> (32 - (kb_log2w - 1)));
     atomicOr(&blk[0], 1u << (g & 31));
     atomicOr(&blk[1], 1u << ((g >> 5) & 31));
-    atomicOr(&blk[2], 1u << ((g >> 10) & 31));
-    atomicOr(&blk[3], 1u << ((g >> 15) & 31));
 }
 
 __global__ void count_keys_kernel(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,

@@ -38,8 +38,8 @@ __device__ __forceinline__ uint32_t alignbit32(uint32_t hi, uint32_t lo, uint32_
 
 // bit-table hash of a peptide key: one multiply per half and a xor (block index from the top bits); the two bit
 // positions come from the low bits folded with the middle ones, which do not take part in the block index alone
-__device__ __forceinline__ uint32_t pep_hash(uint64_t key) { return ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u); }
-__device__ __forceinline__ uint32_t pep_bits(uint32_t hb) { return hb ^ (hb >> 16); }
+__device__ __forceinline__ uint32_t pep_hash(uint64_t key) { return kbit_hash1(key); }
+__device__ __forceinline__ uint32_t pep_bits(uint32_t hb) { return kbit_pos(hb); }
 
 // bit-table test of one key: 1 when both bits of its 64-bit block are set
 template <bool LDS_KB>
