@@ -274,6 +274,76 @@ void ParallelGzReader::open(const uint8_t *data, size_t size, int threads, size_
     chunks_linked = chunks_discarded = gap_fill_bytes = 0;
 }
 
+// BGZF (bgzip, htslib): a gzip file made of many small members, each announcing its own compressed size in an
+// extra subfield 'B','C' (BSIZE = member bytes - 1).  Returns the member's total size, 0 if `pos` is not such a member.
+static size_t bgzf_member_size(const uint8_t *d, size_t size, size_t pos, size_t &cdata_off)
+{
+    if (size - pos < 18 || d[pos] != 0x1f || d[pos + 1] != 0x8b || d[pos + 2] != 8 || (d[pos + 3] & 4) == 0) return 0;
+    if (d[pos + 3] & ~4u) return 0;                                      // only FEXTRA set, as bgzip writes it
+    const size_t xlen = d[pos + 10] | ((size_t)d[pos + 11] << 8);
+    if (size - pos < 12 + xlen + 8) return 0;
+    for (size_t q = pos + 12, e = pos + 12 + xlen; q + 4 <= e;) {
+        const size_t slen = d[q + 2] | ((size_t)d[q + 3] << 8);
+        if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= e) {
+            const size_t total = (d[q + 4] | ((size_t)d[q + 5] << 8)) + 1;
+            if (total < 12 + xlen + 8 || pos + total > size) return 0;
+            cdata_off = 12 + xlen;
+            return total;
+        }
+        q += 4 + slen;
+    }
+    return 0;
+}
+
+// A run of BGZF members starting at cur_bit_: every member is an independent deflate stream of known compressed
+// and uncompressed size, so they are decoded side by side, each straight into its place of the output.
+bool ParallelGzReader::fill_bgzf(std::vector<uint8_t> &obuf_, std::string &err, bool &handled)
+{
+    handled = false;
+    struct Member { size_t cdata, cend; uint32_t crc, isize; size_t out_off; };
+    std::vector<Member> ms;
+    size_t pos = cur_bit_ >> 3, total = 0;
+    const size_t max_out = (size_t)threads_ * ((size_t)8 << 20);
+    while (pos < size_ && total < max_out) {
+        size_t coff = 0;
+        const size_t sz = bgzf_member_size(data_, size_, pos, coff);
+        if (!sz) break;
+        Member m; m.cdata = pos + coff; m.cend = pos + sz - 8; m.out_off = total;
+        memcpy(&m.crc, data_ + pos + sz - 8, 4); memcpy(&m.isize, data_ + pos + sz - 4, 4);
+        total += m.isize;
+        ms.push_back(m);
+        pos += sz;
+    }
+    if (ms.empty()) return true;
+    handled = true;
+    obuf_.resize(total);
+    std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+    auto work = [&] {
+        Tables t; Out<uint8_t> o;
+        for (size_t i; (i = next++) < ms.size();) {
+            const Member &m = ms[i];
+            Bits in(data_, m.cend); in.seek(m.cdata * 8);             // the member's deflate data ends where its trailer begins
+            o.n = o.prefix = 0;
+            if (o.v.size() < (size_t)m.isize + 1024) o.v.resize((size_t)m.isize + 1024);
+            const char *why = nullptr;
+            const Stop st = decode_until<uint8_t>(in, t, o, SIZE_MAX, SIZE_MAX, why);
+            if (st != MEMBER_END || o.n != m.isize || (uint32_t)crc32(0, o.v.data(), (uInt)o.n) != m.crc) { bad = 1; continue; }
+            memcpy(obuf_.data() + m.out_off, o.v.data(), o.n);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        const size_t T = ms.size() < (size_t)threads_ ? ms.size() : (size_t)threads_;
+        for (size_t k = 1; k < T; k++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    if (bad) { err = "damaged BGZF member (deflate data, length or CRC)"; return false; }
+    cur_bit_ = pos * 8; in_member_ = false; any_member_ = true; wlen_ = 0; crc_ = 0; member_out_ = 0;
+    if (pos >= size_) done_ = true;
+    return true;
+}
+
 bool ParallelGzReader::begin_member(std::string &err)
 {
     size_t pos = cur_bit_ >> 3;                                          // byte aligned between members
@@ -316,7 +386,13 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
         if (pos + n == size_) done_ = true;
         return true;
     }
-    if (!in_member_) { if (!begin_member(err)) return false; if (done_) return true; }
+    if (!in_member_) {
+        bool handled = false;
+        if (!fill_bgzf(obuf_, err, handled)) return false;
+        if (handled) return true;
+        if (!begin_member(err)) return false;
+        if (done_) return true;
+    }
 
     // ---- speculative decode of one group of chunks
     const size_t base_byte = cur_bit_ >> 3;

@@ -12,6 +12,8 @@
 //     accepted chunk starts at a true block boundary of the true stream.  Whatever does not link
 //     (a false candidate, a stored or fixed block at the seam) is decoded serially across the gap;
 //   * markers are replaced from the (now known) windows, chunk by chunk in parallel.
+// BGZF files (bgzip / htslib: many small members that state their own size) need none of this: a run of
+// members is decoded side by side.
 // The result is the same byte stream a serial inflate produces; CRC-32 and ISIZE of every member are
 // verified.  The idea follows the published two-pass schemes for gzip (pugz, rapidgzip).
 #pragma once
@@ -39,6 +41,7 @@ public:
 
 private:
     bool fill(std::vector<uint8_t> &dst, std::string &err);   // decode the next group of chunks into dst
+    bool fill_bgzf(std::vector<uint8_t> &dst, std::string &err, bool &handled);   // ... or a run of BGZF members, side by side
     void start_prefetch();                             // ... on a helper thread, while the current group is being served
     std::thread pre_; bool pre_running_ = false, pre_ok_ = true; std::string pre_err_;
     std::vector<uint8_t> nbuf_;

@@ -160,3 +160,37 @@ def test_highly_compressible_input_stays_bounded(exe, tmp_path):
     bound, nothing links, everything goes through bounded gap fills -- and the bytes are still right."""
     raw = b"\0" * (64 << 20) + b"ACGT" * (1 << 20) + bytes(random.Random(6).getrandbits(8) for _ in range(100_000))
     check(exe, tmp_path, gz_member(raw, 6), raw, (1 << 20,), parallel=((8, 16384), (4, 4096)))
+
+
+def bgzf(data: bytes, block=60000, level=6, eof_marker=True) -> bytes:
+    """BGZF as bgzip / htslib write it: independent members of <= 64 KiB, each with a 'BC' extra subfield
+    holding its own size minus one, and an empty member as end-of-file marker."""
+    out = b""
+    for i in list(range(0, len(data), block)) + ([None] if eof_marker else []):
+        raw = b"" if i is None else data[i:i + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(raw) + c.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + b"\x06\x00" + b"BC\x02\x00" + bsize.to_bytes(2, "little") + body
+                + zlib.crc32(raw).to_bytes(4, "little") + len(raw).to_bytes(4, "little"))
+    return out
+
+
+def test_bgzf_members_are_decoded_side_by_side(exe, tmp_path):
+    rng = random.Random(7)
+    text = fastq_like(rng, 12000)                                   # ~3.6 MB -> ~60 members
+    blob = bgzf(text)
+    assert gzip.decompress(blob) == text
+    check(exe, tmp_path, blob, text, (1 << 20, 4099), parallel=((8, 1 << 20), (3, 4096)))
+    check(exe, tmp_path, bgzf(text, eof_marker=False), text, (1 << 20,), parallel=((4, 1 << 20),))
+    check(exe, tmp_path, bgzf(b""), b"", (100,), parallel=((4, 1 << 20),))
+    # BGZF members followed by an ordinary member, and the other way round
+    check(exe, tmp_path, bgzf(text[:500_000], eof_marker=False) + gz_member(text[500_000:], 6), text, (1 << 20,), parallel=((4, 65536),))
+    check(exe, tmp_path, gz_member(text[:500_000], 6) + bgzf(text[500_000:]), text, (1 << 20,), parallel=((4, 65536),))
+    # damage inside a member: length, CRC or deflate data
+    f = tmp_path / "bad.gz"
+    for pos in (len(blob) // 3, len(blob) // 2 + 17, len(blob) - 40):
+        dmg = bytearray(blob); dmg[pos] ^= 0x20
+        f.write_bytes(bytes(dmg))
+        out = subprocess.check_output([exe, str(f), "-", "65536", "--parallel", "4", "1048576"]).decode().strip()
+        assert out.startswith("error"), (pos, out)
