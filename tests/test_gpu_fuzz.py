@@ -1,6 +1,7 @@
 """Randomised differential test: the HIP path against the C oracle on many small random
 configurations (k, bait shape, read-length mix, invalid bases, threshold).  Seeds are fixed, so a
 failure reproduces; the assertion message carries the configuration."""
+import os
 import random
 
 import numpy as np
@@ -55,7 +56,7 @@ def _reads_from(rng, recs, n, max_len, junk):
     return out
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MF_FUZZ_SEEDS", "40"))))
 def test_fuzz_nucleotide(mf, ol, seed):
     rng = random.Random(7000 + seed)
     k = rng.choice([11, 12, 15, 16, 17, 19, 20, 21, 22, 23, 24, 27, 30, 31, 32, 33, 34, 40, 47, 48, 55, 62, 63])
@@ -82,7 +83,7 @@ def test_fuzz_nucleotide(mf, ol, seed):
         assert np.array_equal(mf.filter_reads(ks, reads, thr, mode)[0], obits), (cfg, mode)
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MF_FUZZ_SEEDS", "40")) // 2))
 def test_fuzz_protein(mf, ol, seed):
     from oracle import prot_bait_ref as pr
     rng = random.Random(9000 + seed)
