@@ -100,7 +100,9 @@ __device__ __forceinline__ uint32_t lshl_by_byte(uint32_t amt, uint32_t data)
 // (i = (u*4+q)*SPW+j) is bit NS-1-i of hitmask, NS = U*4*SPW.
 struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pad; };
 
-template <int SPW, int U>
+// SPW: samples per word (stride 16 -> 1, stride 8 -> 2).  MASKED: stride 16 with s < 16 (28 <= k <= 30): the sample is
+// the low 2s bits of the word.
+template <int SPW, int U, bool MASKED>
 __global__ void __launch_bounds__(1024)
 screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts)
 {
@@ -138,7 +140,7 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
             for (int q = 0; q < 4; q++) {
 #pragma unroll
                 for (int j = 0; j < SPW; j++) {
-                    const uint32_t sm = (SPW == 1) ? wv[q] : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
+                    const uint32_t sm = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
                     const uint4 blk = s_tab4[h >> blk_shift];
                     const uint32_t g = alignbit(h, sm, 13);          // stage1_mix
@@ -235,7 +237,8 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
             const uint64_t g0 = cb + off_of(idx);
             const uint64_t wi = g0 >> 4;
             uint32_t sm = R.words[wi];
-            if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW)) & smask;
+            if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW));
+            sm &= smask;                                               // all ones for s == 16
             const uint32_t rc = revcomp_s(sm, S.s);
             const uint32_t cn_ = sm < rc ? sm : rc;
             const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
@@ -972,7 +975,7 @@ uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu)
         else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                           \
     } while (0)
 
-template <int SPW>
+template <int SPW, bool MASKED>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm)
 {
@@ -980,8 +983,8 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, SCREEN_U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    MF_LAUNCH((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, SCREEN_U, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    MF_LAUNCH((screen_kernel<SPW, SCREEN_U, MASKED>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
               static_cast<ScreenRec *>(recs), cap, rec_counts);
 }
 
@@ -1001,8 +1004,9 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                          const KernelTiming *tm)
 {
-    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, st, tm);
-    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, st, tm);
+    if (S.stride == 16 && S.s == 16) launch_screen_spw<1, false>(R, S, recs, rec_counts, n_cu, st, tm);
+    else if (S.stride == 16) launch_screen_spw<1, true>(R, S, recs, rec_counts, n_cu, st, tm);
+    else launch_screen_spw<2, true>(R, S, recs, rec_counts, n_cu, st, tm);
     return hipGetLastError();
 }
 
