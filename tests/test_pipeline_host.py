@@ -1,0 +1,87 @@
+"""The FASTQ file pipeline without a GPU: readers (mapped plain files, serial and parallel gzip, indexed stream
+parsing), batch pools, the packer and the ordered writers run with a stand-in filter ("first base is A") and
+are compared with the obvious Python; tiny batches and parse segments put a border inside almost every record."""
+import gzip
+import os
+import random
+import subprocess
+
+import pytest
+
+from tests.util_data import write_fastq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRCS = ["mf_pipeline.cpp", "mf_host.cpp", "mf_inflate.cpp", "mf_pinflate.cpp"]
+
+
+def build(tmp, flags=()):
+    csrc = os.path.join(ROOT, "mitoflex_amd", "csrc")
+    exe = os.path.join(tmp, "pipeline_check" + "_".join(f.replace("=", "").replace(",", "") for f in flags))
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", *flags, "-I", csrc, os.path.join(ROOT, "tests", "native", "pipeline_check.cpp"),
+                           *[os.path.join(csrc, s) for s in SRCS], "-lz", "-lpthread", "-o", exe])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pipe")
+    rng = random.Random(42)
+    def seqs(n):
+        out = []
+        for _ in range(n):
+            L = rng.choice([150, 150, 151, 40, 0, 1, 300])
+            out.append("".join(rng.choices("ACGTNacgt", k=L)))
+        return out
+    s1, s2 = seqs(5000), seqs(5100)
+    for gz in (False, True):
+        ext = ".fq.gz" if gz else ".fq"
+        write_fastq(str(d / ("a_1" + ext)), s1, "a", trailing_partial=True, gz=gz)
+        write_fastq(str(d / ("a_2" + ext)), s2, "b", crlf=True, gz=gz)
+    return d, s1, s2
+
+
+def expected(d, s1, s2, both):
+    r1 = open(d / "a_1.fq", newline="").read().split("\n")
+    r2 = open(d / "a_2.fq", newline="").read().split("\n")
+    n = min(len(s1), len(s2))
+    keep = []
+    for i in range(n):
+        a, b = s1[i][:1] in ("A", "a"), s2[i][:1] in ("A", "a")
+        keep.append((a and b) if both else (a or b))
+    def out(lines, strip_cr):
+        o = []
+        for i in range(n):
+            if keep[i]:
+                rec = [x.rstrip("\r") if strip_cr else x for x in lines[4 * i:4 * i + 4]]
+                o.append(rec[0] + "\n" + rec[1] + "\n+\n" + rec[3] + "\n")
+        return "".join(o)
+    return sum(keep), n, out(r1, False), out(r2, True)
+
+
+@pytest.mark.parametrize("flags", [(), ("-fsanitize=address,undefined", "-fno-omit-frame-pointer"), ("-fsanitize=thread",)],
+                         ids=["plain", "asan_ubsan", "tsan"])
+def test_pipeline_with_stand_in_filter(data, tmp_path, flags):
+    d, s1, s2 = data
+    exe = build(str(tmp_path), flags)
+    for gz in (False, True):
+        ext = ".fq.gz" if gz else ".fq"
+        for batch, threads, seg, extra in ((2_000_000, 8, None, {}), (700, 4, "997", {}), (64, 3, "64", {}), (700, 1, None, {}),
+                                          (1000, 6, "4096", {"MF_SERIAL_INFLATE": "1"}), (1000, 6, None, {"MF_ZLIB_INFLATE": "1"})):
+            for both in (False, True):
+                env = dict(os.environ, **extra)
+                if seg:
+                    env["MF_PARSE_SEG"] = seg
+                o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+                p = subprocess.run([exe, str(d / ("a_1" + ext)), str(d / ("a_2" + ext)), o1, o2, str(batch), str(threads)] + (["both"] if both else []),
+                                   capture_output=True, env=env)
+                err = p.stderr.decode()
+                assert "Sanitizer" not in err and "runtime error" not in err, err[:2000]
+                kept, total, w1, w2 = expected(d, s1, s2, both)
+                assert p.stdout.decode().split() == [str(kept), str(total)], (gz, batch, threads, seg, both, p.stdout, err[:500])
+                assert open(o1, newline="").read() == w1 and open(o2, newline="").read() == w2, (gz, batch, threads, seg, both)
+    # single end, gz output
+    o = str(tmp_path / "se.fq.gz")
+    p = subprocess.run([exe, str(d / "a_1.fq.gz"), "-", o, "-", "900", "5"], capture_output=True)
+    kept = sum(s[:1] in ("A", "a") for s in s1)
+    assert p.stdout.decode().split() == [str(kept), str(len(s1))] and "Sanitizer" not in p.stderr.decode()
+    assert gzip.open(o, "rt", newline="").read().count("\n") == 4 * kept
