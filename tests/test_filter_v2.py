@@ -102,9 +102,23 @@ def cli(built_lib):
     return p
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
-def test_cli_matches_elf(cli, tmp_path, case):
+@pytest.fixture(scope="module")
+def cli_host_only(built_lib, tmp_path_factory):
+    """The real drop-in CLI and the real host pipeline with tests/native/qualfilter_stub.cpp standing in for the
+    GPU library (test infrastructure: obvious loops instead of the counting / hashing kernels) -- the host logic
+    against the ELF's golden vectors without a GPU."""
+    root = os.path.dirname(HERE)
+    csrc = os.path.join(root, "mitoflex_amd", "csrc")
+    so = str(tmp_path_factory.mktemp("stub") / "libqualfilter_stub.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", csrc, os.path.join(HERE, "native", "qualfilter_stub.cpp"),
+                           *[os.path.join(csrc, f) for f in ("mf_pipeline.cpp", "mf_host.cpp", "mf_inflate.cpp", "mf_pinflate.cpp")],
+                           "-lz", "-lpthread", "-o", so])
+    p = os.path.join(root, "mitoflex_amd", "filter", "filter_v2")
+    assert os.path.exists(p)
+    return p, so
+
+
+def _check_case(cli, tmp_path, case):
     rc, so, outs = _run_cli(cli, str(tmp_path), case["in1"], case["in2"], case["argv"])
     e1, e2 = _expect(case)
     assert rc == case["rc"]
@@ -117,9 +131,36 @@ def test_cli_matches_elf(cli, tmp_path, case):
         assert outs[1] == (None if case["out2"] is None else case["out2"].encode("latin-1"))
 
 
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_cli_host_logic_matches_elf(cli_host_only, tmp_path, case, monkeypatch):
+    monkeypatch.setenv("MITOFILTER_LIB", cli_host_only[1])
+    _check_case(cli_host_only[0], tmp_path, case)
+
+
+@pytest.mark.parametrize("case", GOLD["bulk"], ids=lambda b: b["name"])
+def test_cli_host_logic_bulk_md5(cli_host_only, tmp_path, case, monkeypatch):
+    monkeypatch.setenv("MITOFILTER_LIB", cli_host_only[1])
+    _check_bulk(cli_host_only[0], tmp_path, case, monkeypatch)
+
+
+def test_cli_host_logic_random_against_oracle(cli_host_only, tmp_path, monkeypatch):
+    monkeypatch.setenv("MITOFILTER_LIB", cli_host_only[1])
+    _check_random(cli_host_only[0], tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_cli_matches_elf(cli, tmp_path, case):
+    _check_case(cli, tmp_path, case)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", GOLD["bulk"], ids=lambda b: b["name"])
 def test_cli_bulk_md5(cli, tmp_path, case, monkeypatch):
+    _check_bulk(cli, tmp_path, case, monkeypatch)
+
+
+def _check_bulk(cli, tmp_path, case, monkeypatch):
     mk = _mk()
     monkeypatch.setenv("MF_BATCH_READS", "3001")           # several batches, dedup/trim state carried across
     monkeypatch.setenv("MF_PARSE_SEG", "40000")
@@ -134,6 +175,10 @@ def test_cli_bulk_md5(cli, tmp_path, case, monkeypatch):
 
 @pytest.mark.gpu
 def test_cli_random_against_oracle(cli, tmp_path, monkeypatch):
+    _check_random(cli, tmp_path, monkeypatch)
+
+
+def _check_random(cli, tmp_path, monkeypatch):
     from oracle import filter_v2_ref as ref
     mk = _mk()
     rng = random.Random(11)
