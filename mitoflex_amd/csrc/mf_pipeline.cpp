@@ -76,6 +76,8 @@ public:
         auto self = this->shared_from_this();
         return std::shared_ptr<T>(p, [self](T *x) { x->recycle(); std::lock_guard<std::mutex> lk(self->mu_); self->free_.emplace_back(x); });
     }
+    // keep at most `keep` idle objects (the rest is released)
+    void trim(size_t keep) { std::lock_guard<std::mutex> lk(mu_); while (free_.size() > keep) free_.pop_back(); }
 private:
     std::mutex mu_; std::vector<std::unique_ptr<T>> free_;
 };
@@ -383,8 +385,15 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     std::mutex err_mu; int rc = MF_OK;
     auto set_err = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (rc == MF_OK) { rc = code; err = msg; } };
 
-    auto mate_pool = std::make_shared<Pool<MateBatch>>();
-    auto pair_pool = std::make_shared<Pool<PairBatch>>();
+    // Batch buffers outlive the call (a handful of idle batches, about 1.5 GB for 2 M-record batches): giving a
+    // gigabyte back to the kernel and faulting it in again costs 0.1 s per call, which matters to callers that
+    // filter file after file (the bim loop).  MF_KEEP_BUFFERS=0 releases everything at the end of every call.
+    static std::shared_ptr<Pool<MateBatch>> g_mate_pool = std::make_shared<Pool<MateBatch>>();
+    static std::shared_ptr<Pool<PairBatch>> g_pair_pool = std::make_shared<Pool<PairBatch>>();
+    const char *kb = getenv("MF_KEEP_BUFFERS");
+    const bool keep_buffers = !(kb && kb[0] == '0');
+    auto mate_pool = keep_buffers ? g_mate_pool : std::make_shared<Pool<MateBatch>>();
+    auto pair_pool = keep_buffers ? g_pair_pool : std::make_shared<Pool<PairBatch>>();
     Channel<std::shared_ptr<MateBatch>> q_read[2] = {Channel<std::shared_ptr<MateBatch>>(2), Channel<std::shared_ptr<MateBatch>>(2)};
     std::vector<std::unique_ptr<Channel<PairPtr>>> q_dev;
     for (int d = 0; d < n_devices; d++) q_dev.emplace_back(new Channel<PairPtr>(2));
@@ -505,7 +514,8 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
 
     for (auto &t : threads) t.join();
     const uint64_t t_joined = now_us();
-    mate_pool.reset(); pair_pool.reset();                     // every batch is back by now: the buffers are released here
+    if (keep_buffers) { mate_pool->trim(8); pair_pool->trim(4); }   // every batch is back by now
+    mate_pool.reset(); pair_pool.reset();                     // (not kept: the buffers are released here)
     if (timing)
         fprintf(stderr, "[mf pipeline] wall %.3f s (+%.3f s releasing buffers) | read %.3f %.3f | pack %.3f | device %.3f | write %.3f %.3f | batches %llu\n",
                 (t_joined - t_start) / 1e6, (now_us() - t_joined) / 1e6, t_read[0] / 1e6, t_read[1] / 1e6, t_pack / 1e6, t_dev / 1e6, t_write[0] / 1e6, t_write[1] / 1e6,
