@@ -254,7 +254,10 @@ void slide_window(std::vector<uint8_t> &window, size_t &wlen, const uint8_t *byt
 
 } // namespace
 
-ParallelGzReader::~ParallelGzReader() { if (pre_.joinable()) pre_.join(); }
+struct ChunkResult { bool valid = false; size_t start = 0, end = 0; Stop stop = FAILED; Out<uint16_t> sym; };
+struct ParallelGzReader::Scratch { std::vector<ChunkResult> res; Out<uint8_t> first; };
+
+ParallelGzReader::~ParallelGzReader() { if (pre_.joinable()) pre_.join(); delete scratch_; }
 
 void ParallelGzReader::start_prefetch()
 {
@@ -400,9 +403,13 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
     while (G > 1 && base_byte + (G - 1) * chunk_ >= size_) G--;
     auto nominal_bit = [&](size_t j) { return (base_byte + j * chunk_) * 8; };
     const size_t max_out = chunk_ * 32 > ((size_t)16 << 20) ? chunk_ * 32 : ((size_t)16 << 20);   // symbols per piece before it is cut short
-    struct Res { bool valid = false; size_t start = 0, end = 0; Stop stop = FAILED; Out<uint16_t> sym; };
-    std::vector<Res> res(G);
-    Out<uint8_t> first; const char *first_err = nullptr; Stop first_stop = FAILED; size_t first_end = 0;
+    using Res = ChunkResult;
+    if (!scratch_) scratch_ = new Scratch();
+    std::vector<Res> &res = scratch_->res;
+    if (res.size() < G) res.resize(G);
+    for (size_t j = 0; j < G; j++) { res[j].valid = false; res[j].start = res[j].end = 0; res[j].stop = FAILED; res[j].sym.n = res[j].sym.prefix = 0; }
+    Out<uint8_t> &first = scratch_->first; first.n = first.prefix = 0;
+    const char *first_err = nullptr; Stop first_stop = FAILED; size_t first_end = 0;
     {
         std::vector<std::thread> th;
         for (size_t j = 1; j < G; j++)
@@ -412,7 +419,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
                 if (s == SIZE_MAX) return;
                 Bits in(data_, size_); in.seek(s);
                 Tables t; const char *why = nullptr;
-                r.sym.v.resize(chunk_ * 3 + 4096);
+                if (r.sym.v.size() < chunk_ * 3 + 4096) r.sym.v.resize(chunk_ * 3 + 4096);
                 r.start = s;
                 r.stop = decode_until<uint16_t>(in, t, r.sym, nominal_bit(j + 1), max_out, why);
                 r.end = in.bitpos();
@@ -421,7 +428,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
         {   // chunk 0: the true position, the true window
             Bits in(data_, size_); in.seek(cur_bit_);
             Tables t;
-            first.v.resize(wlen_ + chunk_ * 3 + 4096);
+            if (first.v.size() < wlen_ + chunk_ * 3 + 4096) first.v.resize(wlen_ + chunk_ * 3 + 4096);
             memcpy(first.v.data(), window_.data() + WINDOW - wlen_, wlen_);
             first.n = first.prefix = wlen_;
             first_stop = decode_until<uint8_t>(in, t, first, nominal_bit(1), max_out, first_err);

@@ -45,6 +45,7 @@ private:
     void start_prefetch();                             // ... on a helper thread, while the current group is being served
     std::thread pre_; bool pre_running_ = false, pre_ok_ = true; std::string pre_err_;
     std::vector<uint8_t> nbuf_;
+    struct Scratch; Scratch *scratch_ = nullptr;       // per-chunk symbol buffers, kept from group to group (no fresh pages per group)
     bool begin_member(std::string &err);               // gzip header at cur_bit_ (byte aligned) -> first block
     const uint8_t *data_ = nullptr; size_t size_ = 0;
     int threads_ = 1; size_t chunk_ = 0;
