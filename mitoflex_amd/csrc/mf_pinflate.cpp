@@ -4,6 +4,9 @@
 #include "mf_inflate_core.h"
 
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 #include <zlib.h>               // crc32, crc32_combine only
@@ -300,7 +303,7 @@ static size_t bgzf_member_size(const uint8_t *d, size_t size, size_t pos, size_t
 
 // A run of BGZF members starting at cur_bit_: every member is an independent deflate stream of known compressed
 // and uncompressed size, so they are decoded side by side, each straight into its place of the output.
-bool ParallelGzReader::fill_bgzf(std::vector<uint8_t> &obuf_, std::string &err, bool &handled)
+bool ParallelGzReader::fill_bgzf(ByteBuf &obuf_, std::string &err, bool &handled)
 {
     handled = false;
     struct Member { size_t cdata, cend; uint32_t crc, isize; size_t out_off; };
@@ -378,13 +381,13 @@ bool ParallelGzReader::begin_member(std::string &err)
     return true;
 }
 
-bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
+bool ParallelGzReader::fill(ByteBuf &obuf_, std::string &err)
 {
     obuf_.clear();
     if (done_) return true;
     if (transparent_) {
         const size_t pos = cur_bit_ >> 3, n = size_ - pos < ((size_t)64 << 20) ? size_ - pos : ((size_t)64 << 20);
-        obuf_.assign(data_ + pos, data_ + pos + n);
+        obuf_.resize(n); memcpy(obuf_.data(), data_ + pos, n);
         cur_bit_ = (pos + n) * 8;
         if (pos + n == size_) done_ = true;
         return true;
@@ -397,6 +400,9 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
         if (done_) return true;
     }
 
+    static const bool gz_timing = getenv("MF_GZ_TIMING") != nullptr;   // phase times of every group on stderr (diagnostics)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t_a = now();
     // ---- speculative decode of one group of chunks
     const size_t base_byte = cur_bit_ >> 3;
     size_t G = (size_t)threads_;
@@ -438,6 +444,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
     }
     if (first_stop == FAILED) { err = first_err ? first_err : "damaged deflate stream"; return false; }
 
+    const auto t_b = now();
     // ---- link (serial, cheap): which pieces make up the output, and the window in front of each
     struct Piece { const uint8_t *bytes = nullptr; const uint16_t *syms = nullptr; size_t n = 0, out_off = 0; std::vector<uint8_t> window; };
     struct Check { size_t out_off; uint32_t crc, isize; };
@@ -507,6 +514,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
     }
     if (!ok) return false;
 
+    const auto t_c = now();
     // ---- assemble: copy bytes, replace markers (parallel over pieces)
     obuf_.resize(total);
     {
@@ -526,6 +534,7 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
         work();
         for (auto &t : th) t.join();
     }
+    const auto t_d = now();
     // ---- member checks
     size_t seg = 0;
     for (const Check &c : checks) {
@@ -537,6 +546,11 @@ bool ParallelGzReader::fill(std::vector<uint8_t> &obuf_, std::string &err)
     }
     crc_ = crc32_parallel(crc_, obuf_.data() + seg, total - seg, threads_);
     member_out_ += total - seg;
+    if (gz_timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[mf gz] group of %zu chunks -> %.1f MB: decode %.1f ms, link %.1f ms, assemble %.1f ms, crc %.1f ms\n", G, total / 1e6,
+                ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, now()));
+    }
     return true;
 }
 

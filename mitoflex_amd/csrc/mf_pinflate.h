@@ -17,6 +17,7 @@
 // The result is the same byte stream a serial inflate produces; CRC-32 and ISIZE of every member are
 // verified.  The idea follows the published two-pass schemes for gzip (pugz, rapidgzip).
 #pragma once
+#include "mf_host.h"            // DefaultInitAlloc
 #include <stddef.h>
 #include <stdint.h>
 #include <string>
@@ -26,6 +27,7 @@
 namespace mf {
 
 class ParallelGzReader {
+    using ByteBuf = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;   // sized without being zero-filled
 public:
     // data must stay mapped while the reader lives.  chunk_bytes: compressed bytes per speculative chunk.
     ParallelGzReader() = default;
@@ -40,11 +42,11 @@ public:
     uint64_t chunks_linked = 0, chunks_discarded = 0, gap_fill_bytes = 0;
 
 private:
-    bool fill(std::vector<uint8_t> &dst, std::string &err);   // decode the next group of chunks into dst
-    bool fill_bgzf(std::vector<uint8_t> &dst, std::string &err, bool &handled);   // ... or a run of BGZF members, side by side
+    bool fill(ByteBuf &dst, std::string &err);   // decode the next group of chunks into dst
+    bool fill_bgzf(ByteBuf &dst, std::string &err, bool &handled);   // ... or a run of BGZF members, side by side
     void start_prefetch();                             // ... on a helper thread, while the current group is being served
     std::thread pre_; bool pre_running_ = false, pre_ok_ = true; std::string pre_err_;
-    std::vector<uint8_t> nbuf_;
+    ByteBuf nbuf_;
     struct Scratch; Scratch *scratch_ = nullptr;       // per-chunk symbol buffers, kept from group to group (no fresh pages per group)
     bool begin_member(std::string &err);               // gzip header at cur_bit_ (byte aligned) -> first block
     const uint8_t *data_ = nullptr; size_t size_ = 0;
@@ -53,7 +55,7 @@ private:
     bool in_member_ = false, done_ = false, any_member_ = false, transparent_ = false;
     std::vector<uint8_t> window_; size_t wlen_ = 0;    // last 32 KiB of accepted output, right-aligned
     uint32_t crc_ = 0; uint64_t member_out_ = 0;
-    std::vector<uint8_t> obuf_; size_t opos_ = 0;
+    ByteBuf obuf_; size_t opos_ = 0;
 };
 
 } // namespace mf
