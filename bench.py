@@ -59,6 +59,16 @@ def committed_traffic():
         return None, None
 
 
+def cpu_quota():
+    """CPUs the container may actually use (cgroup v2 cpu.max), or None when unlimited / unknown: the oracle runs on
+    every visible hardware thread, but a quota caps what those threads get."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -137,8 +147,11 @@ def main():
         obits, _ = ol.filter_reads(T, R, THRESHOLD, threads=cores)
         cs = time.perf_counter() - c0
         what = "all" if n == a.reads else "first"
+        quota = cpu_quota()
         cpu = {"value": n / cs, "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": f"{what} {n} reads of the same synthetic set, oracle/kmer_bait_oracle.c, {cores} threads, {cs:.1f}s"}
+               "sample": f"{what} {n} reads of the same synthetic set, oracle/kmer_bait_oracle.c, {cores} threads, {cs:.1f}s"
+                         + (f"; the container's cgroup quota is {quota:g} CPUs" if quota else ""),
+               "cpu_quota": quota}
         # the same sample doubles as a checker: GPU bits of the sample == oracle bits
         gbits, _, _ = mf.filter_reads(ks, reads, THRESHOLD, mf.MODE_SCREENED)
         nw = n // 32

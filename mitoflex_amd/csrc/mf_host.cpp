@@ -2,6 +2,8 @@
 #include "mf_host.h"
 #include "mf_kernels_cfg.h"
 
+#include <algorithm>
+#include <atomic>
 #include <immintrin.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -360,20 +362,93 @@ void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &ou
     for (auto &v : np) out.npos.insert(out.npos.end(), v.begin(), v.end());   // ranges ascend with t
 }
 
+// ------------------------------------------------------------------ output
+OutFile::~OutFile() { if (f_) close(); }
+
+bool OutFile::open(const char *path, int threads)
+{
+    if (threads < 1) { threads = (int)std::thread::hardware_concurrency() / 4; if (threads > 32) threads = 32; if (threads < 2) threads = 2; }
+    threads_ = threads;
+    if (!path) { f_ = stdout; own_ = false; gz_ = false; return true; }
+    gz_ = has_gz_ext(path);
+    f_ = fopen(path, "wb");
+    if (f_ && gz_) setvbuf(f_, nullptr, _IOFBF, 1 << 20);
+    return f_ != nullptr;
+}
+
+bool OutFile::write(const char *p, size_t n)
+{
+    if (!gz_) return fwrite(p, 1, n, f_) == n;
+    pend_.insert(pend_.end(), p, p + n);
+    if (pend_.size() >= (size_t)threads_ << 22) return flush_members();     // four slices per thread: thread start-up and the serial write amortised
+    return true;
+}
+
+// one gzip member per slice of the pending text, compressed side by side, written in order.  No allocation per
+// slice: every worker keeps one deflate state for the whole flush and compresses straight into its slice's place of
+// one output buffer that lives as long as the file (fresh mappings per slice made 32 threads queue on the mmap lock).
+bool OutFile::flush_members()
+{
+    if (pend_.empty()) return true;
+    const size_t slice = (size_t)1 << 20, n = (pend_.size() + slice - 1) / slice;
+    const size_t stride = 18 + slice + slice / 1000 + 64;           // header + deflateBound of a slice + trailer, with room to spare
+    if (obuf_.size() < n * stride) obuf_.resize(n * stride);
+    std::vector<size_t> olen(n, 0);
+    std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+    auto work = [&] {
+        z_stream z; memset(&z, 0, sizeof z);
+        if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+        for (size_t i; (i = next++) < n;) {
+            const size_t off = i * slice, len = std::min(slice, pend_.size() - off);
+            unsigned char *o = obuf_.data() + i * stride;
+            static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+            memcpy(o, hdr, 10);
+            deflateReset(&z);
+            z.next_in = (Bytef *)(pend_.data() + off); z.avail_in = (uInt)len;
+            z.next_out = o + 10; z.avail_out = (uInt)(stride - 18);
+            if (deflate(&z, Z_FINISH) != Z_STREAM_END) { bad = 1; continue; }
+            const size_t clen = z.total_out;
+            const uint32_t crc = (uint32_t)crc32(0, (const Bytef *)(pend_.data() + off), (uInt)len), isz = (uint32_t)len;
+            memcpy(o + 10 + clen, &crc, 4); memcpy(o + 14 + clen, &isz, 4);
+            olen[i] = 18 + clen;
+        }
+        deflateEnd(&z);
+    };
+    {
+        std::vector<std::thread> th;
+        const size_t T = std::min<size_t>(n, (size_t)threads_);
+        for (size_t t = 1; t < T; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    pend_.clear();
+    if (bad) return false;
+    for (size_t i = 0; i < n; i++) if (fwrite(obuf_.data() + i * stride, 1, olen[i], f_) != olen[i]) return false;
+    wrote_ = true;
+    return true;
+}
+
+bool OutFile::close()
+{
+    if (!f_) return true;
+    bool ok = true;
+    if (gz_) {
+        ok = flush_members();
+        if (ok && !wrote_) {                                  // no text at all: one empty member, what gzclose leaves behind
+            static const unsigned char empty[20] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            ok = fwrite(empty, 1, 20, f_) == 20;
+        }
+    }
+    if (own_) ok = (fclose(f_) == 0) && ok; else ok = (fflush(f_) == 0) && ok;
+    f_ = nullptr;
+    return ok;
+}
+
 bool write_survivors(const char *path, const FqRec *recs, uint64_t n, const uint8_t *keep, std::string &err)
 {
-    const bool gz = has_gz_ext(path);
-    gzFile g = nullptr; FILE *f = nullptr;
-    if (gz) { g = gzopen(path, "wb6"); if (!g) { err = std::string("Cannot open file ") + path; return false; } gzbuffer(g, 1 << 20); }
-    else { f = fopen(path, "wb"); if (!f) { err = std::string("Cannot open file ") + path; return false; } }
+    OutFile out;
+    if (!out.open(path)) { err = std::string("Cannot open file ") + path; return false; }
     std::vector<char> buf; buf.reserve(1 << 22);
-    auto drain = [&]() {
-        if (buf.empty()) return true;
-        bool ok = gz ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size()
-                     : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-        buf.clear();
-        return ok;
-    };
     bool ok = true;
     for (uint64_t i = 0; i < n && ok; i++) {
         if (!keep[i]) continue;
@@ -381,10 +456,10 @@ bool write_survivors(const char *path, const FqRec *recs, uint64_t n, const uint
         buf.insert(buf.end(), r.h, r.h + r.hl); buf.push_back('\n');
         buf.insert(buf.end(), r.s, r.s + r.sl); buf.push_back('\n'); buf.push_back('+'); buf.push_back('\n');
         buf.insert(buf.end(), r.q, r.q + r.ql); buf.push_back('\n');
-        if (buf.size() > (1u << 22) - 4096) ok = drain();
+        if (buf.size() > (1u << 22) - 4096) { ok = out.write(buf.data(), buf.size()); buf.clear(); }
     }
-    ok = ok && drain();
-    if (gz) ok = (gzclose(g) == Z_OK) && ok; else ok = (fclose(f) == 0) && ok;
+    ok = ok && out.write(buf.data(), buf.size());
+    ok = out.close() && ok;
     if (!ok) err = std::string("write error on ") + path;
     return ok;
 }

@@ -8,6 +8,7 @@
 #include <stddef.h>
 #include <memory>
 #include <new>
+#include <stdio.h>
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <string>
@@ -89,6 +90,21 @@ uint64_t padded_words_for(uint64_t n_words);
 // pack records [first, first+count) with `threads` workers; `out` keeps its capacity when it is reused
 void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &out);
 uint32_t detect_uniform_len(const uint64_t *offsets, uint64_t n_reads);
+
+// Output file, plain or gzip by extension.  Gzip output is written as consecutive members of ~1 MiB of text, compressed
+// on several threads (any gzip reader takes multi-member files; deflate on one thread does ~50 MB/s of text).
+class OutFile {
+public:
+    ~OutFile();
+    bool open(const char *path, int threads = 0);          // nullptr: standard output (never compressed); 0: a quarter of the host threads, at most 32
+    bool write(const char *p, size_t n);
+    bool close();
+private:
+    bool flush_members();
+    FILE *f_ = nullptr; bool gz_ = false, own_ = true, wrote_ = false; int threads_ = 1;
+    std::vector<char, DefaultInitAlloc<char>> pend_;
+    std::vector<unsigned char, DefaultInitAlloc<unsigned char>> obuf_;
+};
 
 // survivors in input order: header / seq / "+" / qual (filter_bin main.rs:261-268)
 bool write_survivors(const char *path, const FqRec *recs, uint64_t n, const uint8_t *keep, std::string &err);

@@ -477,16 +477,13 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     // ---- ordered writers (devices may finish out of order)
     for (int m = 0; m < nm; m++)
         threads.emplace_back([&, m] {
-            const bool gz = has_gz_ext(out_path[m]);
-            gzFile g = nullptr; FILE *f = nullptr;
-            if (gz) { g = gzopen(out_path[m], "wb6"); if (g) gzbuffer(g, 1 << 20); } else f = fopen(out_path[m], "wb");
-            if (!g && !f) { set_err(MF_E_IO, std::string("Cannot open file ") + out_path[m]); abort_all(); return; }
+            OutFile of;
+            if (!of.open(out_path[m])) { set_err(MF_E_IO, std::string("Cannot open file ") + out_path[m]); abort_all(); return; }
             std::map<uint64_t, PairPtr> pending; uint64_t next = 0; bool ok = true;
             std::vector<char> buf; buf.reserve((1u << 22) + (1u << 16));
             auto drain = [&] {
                 if (buf.empty()) return;
-                const bool w = gz ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size() : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-                if (!w) ok = false;
+                if (!of.write(buf.data(), buf.size())) ok = false;
                 buf.clear();
             };
             PairPtr pb;
@@ -508,7 +505,7 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
                 }
             }
             drain();
-            if (gz) ok = (gzclose(g) == Z_OK) && ok; else ok = (fclose(f) == 0) && ok;
+            ok = of.close() && ok;
             if (!ok) { set_err(MF_E_IO, std::string("write error on ") + out_path[m]); abort_all(); }
         });
 
@@ -737,17 +734,13 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
     for (int m = 0; m < nm; m++)
         th.emplace_back([&, m] {
             const bool to_stdout = out_path[m] == nullptr;
-            const bool gz = !to_stdout && has_gz_ext(out_path[m]);
-            gzFile g = nullptr; FILE *f = nullptr;
-            if (to_stdout) f = stdout;
-            else if (gz) { g = gzopen(out_path[m], "wb6"); if (g) gzbuffer(g, 1 << 20); } else f = fopen(out_path[m], "wb");
-            if (!g && !f) { set_err(MF_E_IO, std::string("Cannot open file ") + out_path[m]); abort_all(); return; }
+            OutFile of;
+            if (!of.open(out_path[m])) { set_err(MF_E_IO, std::string("Cannot open file ") + out_path[m]); abort_all(); return; }
             bool ok = true;
             std::vector<char> buf; buf.reserve((1u << 22) + (1u << 16));
             auto drain = [&] {
                 if (buf.empty()) return;
-                const bool w = gz ? gzwrite(g, buf.data(), (unsigned)buf.size()) == (int)buf.size() : fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-                if (!w) ok = false;
+                if (!of.write(buf.data(), buf.size())) ok = false;
                 buf.clear();
             };
             QualPtr qb;
@@ -765,8 +758,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                 }
             }
             drain();
-            if (to_stdout) fflush(stdout);
-            else if (gz) ok = (gzclose(g) == Z_OK) && ok; else ok = (fclose(f) == 0) && ok;
+            ok = of.close() && ok;
             if (!ok) { set_err(MF_E_IO, std::string("write error on ") + (to_stdout ? "<stdout>" : out_path[m])); abort_all(); }
         });
 
