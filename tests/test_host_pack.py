@@ -15,3 +15,24 @@ def test_pack_records_threaded_equals_naive(built_lib, tmp_path):
     env = dict(os.environ, MALLOC_PERTURB_="165")
     out = subprocess.check_output([exe], env=env).decode()
     assert out.strip() == "pack ok"
+
+
+def test_outfile_gzip_members_round_trip(built_lib, tmp_path):
+    """OutFile writes .gz output as consecutive gzip members compressed on several threads: whatever goes in comes
+    back out of any gzip reader (Python's here, the library's own decoders in tests/test_pipeline_host.py)."""
+    import gzip
+    import random
+    csrc = os.path.join(ROOT, "mitoflex_amd", "csrc")
+    exe = str(tmp_path / "outfile_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tests", "native", "outfile_check.cpp"),
+                           os.path.join(csrc, "build", "mf_host.o"), "-lz", "-lpthread", "-o", exe])
+    rng = random.Random(3)
+    for size in (0, 1, 70_000, 9_000_000):
+        raw = bytes(rng.choices(b"ACGTN\n@+FI", k=size))
+        src, dst, plain = tmp_path / "in.bin", tmp_path / "out.fq.gz", tmp_path / "out.fq"
+        src.write_bytes(raw)
+        for threads in (1, 5):
+            assert subprocess.check_output([exe, str(src), str(dst), str(threads)]).decode().startswith("ok")
+            assert gzip.decompress(dst.read_bytes()) == raw
+        assert subprocess.check_output([exe, str(src), str(plain), "3"]).decode().startswith("ok")
+        assert plain.read_bytes() == raw
