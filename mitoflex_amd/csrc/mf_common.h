@@ -51,13 +51,16 @@ MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi)
 //            inserted), one bit in each of the block's four dwords
 //   stage 2: classic Bloom filter over canonical s-mers, STAGE2_K probes
 //   stage 3: exact ordered s-mer table in global memory (L2 resident)
-MF_HD uint32_t bloom_hash(uint32_t smer) { return smer * 0x9E3779B1u; }
+// stage-1 hash: (low 24 bits of the s-mer) * 0x9E3779 + s-mer -- one full-rate v_mad_u32_u24 (a full 32-bit multiply is a
+// quarter-rate instruction on CDNA).  The block index is the top bits of h.
+MF_HD uint32_t bloom_hash(uint32_t smer) { return (smer & 0xFFFFFFu) * 0x9E3779u + smer; }
 // stage-1 bit of dword i of the 128-bit block: 31 - field_i, where field_i is the low five bits of
-// byte i of g = (h:smer) >> 13 (one funnel shift; measured on the synthetic mitogenome: 0.062 %
-// false positives, the same as four bytes of an independent second hash, against 0.19 % for bytes
-// of h itself).  The kernel tests a bit by shifting the dword LEFT by field_i -- the bit lands in
+// byte i of g = (h:smer) >> 11 (one funnel shift).  Simulated on the synthetic mitogenome (35 250 s-mers, both strands,
+// 8192 blocks): 0.059 % false positives, what four independent ideal fields give (0.062 %); shifts of 5, 7, 13 or 15
+// give 0.11 %, bytes of h alone 0.19 %.  The kernel tests a bit by shifting the dword LEFT by field_i -- the bit lands in
 // the sign position -- with the field taken straight from its byte through an SDWA operand selector.
-MF_HD uint32_t stage1_mix(uint32_t smer, uint32_t h) { return (smer >> 13) | (h << 19); }
+constexpr uint32_t STAGE1_MIX_SHIFT = 11;
+MF_HD uint32_t stage1_mix(uint32_t smer, uint32_t h) { return (smer >> STAGE1_MIX_SHIFT) | (h << (32 - STAGE1_MIX_SHIFT)); }
 MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return (stage1_mix(smer, h) >> (8 * i)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
 constexpr int STAGE2_K = 4;
@@ -137,6 +140,7 @@ MF_HD void revcomp2(uint64_t lo, uint64_t hi, int k, uint64_t &rlo, uint64_t &rh
 }
 
 // ---- plain-data views passed to kernels ------------------------------------
+constexpr int NPOS_BLK_SHIFT = 12;
 struct ReadsView {
     const uint32_t *words;      // padded with zero words past n_words
     uint64_t        n_words;    // words holding bases
@@ -149,6 +153,8 @@ struct ReadsView {
     uint64_t        total_bases;
     const uint64_t *npos;       // sorted invalid base positions
     uint64_t        n_npos;
+    const uint32_t *npos_blk;   // npos_blk[b] = first index i with npos[i] >= b << NPOS_BLK_SHIFT (one entry per 4096 bases, plus
+                                // two): a lookup is one load and a search over the few entries of a block instead of ~17 dependent loads
     const uint32_t *has_n;      // bit r set: read r holds an invalid base
 };
 

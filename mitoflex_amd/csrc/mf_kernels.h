@@ -24,6 +24,27 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, u
                          const KernelTiming *tm = nullptr);
 hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
                        hipStream_t st, const KernelTiming *tm = nullptr);
+// fused pass (screen + mark + exact in one launch): geometry of a read set and the buffers one pass works on
+struct FusedGeom {
+    uint32_t n_stream;          // streaming waves per workgroup (MF_STREAM_WAVES, default 14)
+    uint64_t chunk_vec;         // uint4 per chunk (n_stream x 64 x SCREEN_U)
+    uint64_t n_chunks, grid;
+    uint64_t ovf_cap;           // overflow records per streaming wave
+    uint64_t words_needed;      // device words the kernel may read (zero past the data)
+    bool ok;                    // false: the set is too large for the record format (fall back to the split path)
+};
+struct FusedBuffers {
+    uint32_t *cand, *bits, *cand_other, *bits_other;
+    uint64_t bitmap_vec4;
+    unsigned long long *ovf;
+    uint32_t *hits_out;
+    unsigned long long *partials;
+    uint32_t flags;                 // debugging: bit 0 drops the stage-1 records (stream-only timing)
+    unsigned long long *dbg;        // debugging: per-wave timestamps and counts, or nullptr
+};
+FusedGeom fused_geom_for(uint64_t n_words, int n_cu);
+hipError_t launch_fused(const ReadsView &R, const KmerSetView &S, const FusedGeom &G, const FusedBuffers &B, uint32_t thr, bool count_all,
+                        hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st,
                         const KernelTiming *tm = nullptr);
@@ -44,6 +65,8 @@ hipError_t launch_build_ptable(const uint8_t *aa, const uint8_t *runlen, uint64_
 hipError_t launch_build_pbits(const uint64_t *keys, uint64_t slots, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_pfilter(const ReadsView &R, const KmerSetView &S, uint32_t thr, bool count_all, uint32_t *out_bits,
                           uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr);
+// npos_blk: n_blk = (total_bases >> NPOS_BLK_SHIFT) + 3 entries
+hipError_t launch_build_npos_blk(const uint64_t *npos, uint64_t n_npos, uint64_t n_blk, uint32_t *blk, hipStream_t st);
 hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);
 
 } // namespace mf

@@ -23,6 +23,7 @@
 #include "mf_kernels.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace mf {
 
@@ -36,6 +37,15 @@ __device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t *__restrict__
 {
     uint64_t lo = 0, hi = n;
     while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// first index i with npos[i] >= v, through the block index
+__device__ __forceinline__ uint64_t npos_lower_bound(const ReadsView &R, uint64_t v)
+{
+    const uint64_t b = v >> NPOS_BLK_SHIFT;
+    uint64_t lo = R.npos_blk[b], hi = R.npos_blk[b + 1];          // the answer lies in [lo, hi]
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.npos[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
 
@@ -80,6 +90,16 @@ __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
 // U   = uint4 loads in flight per lane per chunk
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// pointers that keep the LDS address space (a generic pointer to LDS compiles to flat_* instructions, which count
+// in vmcnt and would drain a streaming wave's prefetch queue)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+__device__ __forceinline__ uint32_t lds_ld(const lds_u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(lds_u32 *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long lds_ld(const lds_u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(lds_u64 *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_add(lds_u32 *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define MF_COMPILER_FENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
 
 // data << (byte BYTE of amt): v_lshlrev_b32 uses the low five bits of its shift operand, and an
 // SDWA source selector picks the byte, so no separate extract is issued (dst_sel is DWORD, so the
@@ -143,7 +163,7 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                     const uint32_t sm = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
                     const uint4 blk = s_tab4[h >> blk_shift];
-                    const uint32_t g = alignbit(h, sm, 13);          // stage1_mix
+                    const uint32_t g = alignbit(h, sm, STAGE1_MIX_SHIFT);   // stage1_mix
                     const uint32_t t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.y) & lshl_by_byte<2>(g, blk.z) & lshl_by_byte<3>(g, blk.w);
                     hitmask = alignbit(hitmask, t, 31);             // (hitmask << 1) | sign(t)
                 }
@@ -395,10 +415,10 @@ __device__ __forceinline__ bool table_has(const KmerSetView &S, uint64_t klo, ui
 
 // One work item: k-mer positions [p0, p0 + ITEM_POS) of the read starting at base b0 with n_pos positions.
 // Verified hits are added to *cnt (LDS, shared by the read's items).
-template <int KW, bool COUNT_ALL>
+template <int KW>
 __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView &S, const uint2 *__restrict__ s_kb2,
                                           uint32_t kb_shift, uint64_t b0, uint64_t n_pos, uint64_t p0, bool hasn,
-                                          uint32_t thr, uint32_t *cnt)
+                                          uint32_t thr, lds_u32 *cnt, const bool COUNT_ALL)
 {
     const int k = S.k;
     const uint64_t mask_lo = (KW == 1 && k < 32) ? (1ULL << (2 * k)) - 1 : ~0ULL;
@@ -463,7 +483,7 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
     if (left < ITEM_POS) pos_mask &= (1u << left) - 1;
     if (hasn && pos_mask) {
         const uint64_t len = n_pos + k - 1;
-        const uint64_t n_lo = lower_bound_u64(R.npos, R.n_npos, b0), n_hi = lower_bound_u64(R.npos, R.n_npos, b0 + len);
+        const uint64_t n_lo = npos_lower_bound(R, b0), n_hi = npos_lower_bound(R, b0 + len);
         for (uint64_t n = n_lo; n < n_hi; n++) {
             const int64_t d = (int64_t)(R.npos[n] - (b0 + p0));       // window i holds it iff i <= d < i + k
 #pragma unroll
@@ -472,13 +492,13 @@ __device__ __forceinline__ void item_hits(const ReadsView &R, const KmerSetView 
     }
     // L2 stage: verify the positives (rebuild the key of position i from the window)
     while (pos_mask) {
-        if (!COUNT_ALL && *reinterpret_cast<volatile uint32_t *>(cnt) >= thr) break;
+        if (!COUNT_ALL && lds_ld(cnt) >= thr) break;
         const int i = __ffs(pos_mask) - 1;
         pos_mask &= pos_mask - 1;
         uint64_t klo, khi;
         key_at(i, klo, khi);
         const uint32_t h = (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi));
-        if (table_has<KW>(S, klo, khi, h)) atomicAdd(cnt, 1u);
+        if (table_has<KW>(S, klo, khi, h)) lds_add(cnt, 1u);
     }
 }
 
@@ -510,10 +530,10 @@ __device__ __forceinline__ uint32_t nth_set_lane(uint64_t ballot, uint32_t m)
     return posn;
 }
 
-template <int KW, bool COUNT_ALL>
+template <int KW>
 __device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSetView &S, const uint2 *__restrict__ s_kb2, uint32_t kb_shift,
                                                uint32_t thr, bool two_phase, int lane, bool owner, uint64_t b0, uint32_t np,
-                                               uint32_t hasn, uint32_t *my_cnt)
+                                               uint32_t hasn, lds_u32 *my_cnt, const bool COUNT_ALL)
 {
     my_cnt[lane] = 0;
     const uint32_t b0_lo = (uint32_t)b0, b0_hi = (uint32_t)(b0 >> 32);
@@ -550,7 +570,7 @@ __device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSet
                 const uint32_t cnp = __shfl(np, ci), chn = __shfl(hasn, ci);
                 const uint32_t p0 = it * ITEM_POS;
                 if (t < n_items && it < it_hi && p0 < cnp)
-                    item_hits<KW, COUNT_ALL>(R, S, s_kb2, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci]);
+                    item_hits<KW>(R, S, s_kb2, kb_shift, cb0, cnp, p0, chn != 0, thr, &my_cnt[ci], COUNT_ALL);
             }
         }
     }
@@ -579,7 +599,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
     __syncthreads();
     const uint32_t kb_shift = 32 - (S.kb_log2w - 1);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t *my_res = s_res + wid * WC_WORDS, *my_cnt = s_cnt + wid * 64;
+    uint32_t *my_res = s_res + wid * WC_WORDS; lds_u32 *my_cnt = (lds_u32 *)(s_cnt + wid * 64);
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
     const uint64_t n_wc = (n_bw + WC_WORDS - 1) / WC_WORDS;
     const int k = S.k;
@@ -649,7 +669,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
                 np = n_pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_pos;
                 hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
             }
-            run_candidates<KW, COUNT_ALL>(R, S, s_kb2, kb_shift, thr, cand != nullptr, lane, active, b0, np, hasn, my_cnt);
+            run_candidates<KW>(R, S, s_kb2, kb_shift, thr, cand != nullptr, lane, active, b0, np, hasn, my_cnt, COUNT_ALL);
             if (active) {
                 const uint32_t h = my_cnt[lane];
                 if (COUNT_ALL) hits_out[r] = h;
@@ -679,6 +699,550 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
     // slots of workgroups that do not exist in this launch must read as zero (no per-pass memset)
     if (blockIdx.x == 0)
         for (uint32_t i = 2 * gridDim.x + threadIdx.x; i < 2 * EXACT_MAX_GRID; i += blockDim.x) partials[i] = 0;
+}
+
+// -------------------------------------------------------------- fused pass kernel
+// One launch per pass.  Every persistent 1024-thread workgroup (one per CU) splits its 16 waves into
+//   STREAMING waves (A.n_stream of them): walk the dense read stream in chunks of n_stream * 64 * U 16-byte
+//     non-temporal loads (workgroup b takes chunks b, b + grid, ...; the next chunk is in flight while this one is
+//     examined).  Every stream-aligned s-mer gets the stage-1 test in the LDS bit table; a lane with a positive pushes
+//     one 8-byte record {chunk, lane, hit mask} into the wave's own LDS ring (single producer: slots come from a
+//     ballot, no atomics; a full ring spills to a global overflow list);
+//   FINISHER waves (the rest): poll the rings while the stream is still running, 64 records per batch: group a
+//     record's positives by read, verify lone positives (stage 2 / 3), claim the read in the candidate bitmap
+//     (returning atomicOr: a read is claimed by exactly one lane of the whole grid), and count the claimed reads
+//     exactly (k-mer extract -> canonicalise -> LDS bit table -> open-address table in L2 -> threshold), 64
+//     candidates per run, the work items of a candidate dealt to the wave's lanes (run_candidates).
+// A finisher has its own vmcnt queue, so its dependent loads never stall a streaming wave, and its latency chains
+// run under the stream instead of behind it in two more launches.  When a streaming wave runs out of chunks it
+// turns into a finisher for its own overflow list.  No barrier after table staging, no cross-wave wait other than
+// the finishers polling LDS counters -- a streaming wave never waits for anybody.
+// Bitmaps are double buffered by pass parity: a pass finds its candidate and result bitmaps clean, sets bits with
+// atomics, and clears the other parity's pair for the next pass (no memset launches, no per-pass host work).
+// SAMPLE-mode work item of the fused pass: does one of the (<= 16) windows starting at read positions p0, p0 + 1, ...
+// hold a bait k-mer?  Positions are examined four at a time and the wave stops as soon as no lane needs more.
+// `lone`: the record's only positive -- most of those are stage-1 false positives, so the s-mer (it starts `soff` bases
+// into the window) is checked in the stage-2 table first and a lane that fails drops out after the first step.
+template <int KW>
+__device__ __forceinline__ bool sample_item(const ReadsView &R, const KmerSetView &S, const uint2 *__restrict__ s_kb2, uint32_t kb_shift,
+                                            bool active, uint64_t r, uint64_t b0, uint64_t n_pos, uint64_t p0, bool lone, uint32_t soff,
+                                            const uint32_t *__restrict__ st2, uint32_t st2_shift)
+{
+    const int k = S.k;
+    const uint64_t mask_lo = (KW == 1 && k < 32) ? (1ULL << (2 * k)) - 1 : ~0ULL;
+    const uint64_t mask_hi = KW == 2 ? (1ULL << (2 * k - 64)) - 1 : 0;
+    constexpr int NW = KW == 1 ? 4 : 6;
+    uint64_t x0 = 0, x1 = 0, x2 = 0, r0 = 0, r1 = 0;
+    uint32_t ok2 = 1, hasn = 0;
+    if (active) {
+        const uint64_t bit = 2 * (b0 + p0);
+        const uint32_t *__restrict__ w = R.words + (bit >> 5);
+        const uint32_t sh = (uint32_t)bit & 31;
+        uint32_t raw[NW + 1];
+        {
+            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(w);
+            raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+            if (KW == 1) raw[4] = w[4];
+            else { const u32x2_a4 v2 = *reinterpret_cast<const u32x2_a4 *>(w + 4); raw[4] = v2.x; raw[5] = v2.y; raw[NW] = w[6]; }
+        }
+        hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
+        uint32_t a[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) a[i] = alignbit(raw[i + 1], raw[i], sh);
+        x0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32); x1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+        if (KW == 2) x2 = (uint64_t)a[NW - 2] | ((uint64_t)a[NW - 1] << 32);
+        if (KW == 1) {                                  // reverse complement of the whole window, as in item_hits
+            const uint64_t y0 = ~swap_pairs_rev64(x1), y1 = ~swap_pairs_rev64(x0);
+            const int drop = 2 * (64 - k - (ITEM_POS - 1));
+            if (drop >= 64) { r0 = y1 >> (drop - 64); r1 = 0; }
+            else { r0 = (y0 >> drop) | (y1 << (64 - drop)); r1 = y1 >> drop; }
+        }
+        if (lone) {
+            const uint32_t sm = (uint32_t)funnel64(x0, x1, 2 * (int)soff) & S.smask;
+            const uint32_t rc = revcomp_s(sm, S.s);
+            const uint32_t cn_ = sm < rc ? sm : rc;
+            const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
+#pragma unroll
+            for (int p = 0; p < STAGE2_K; p++) {
+                const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
+                ok2 &= st2[pos >> 5] >> (pos & 31);
+            }
+            if ((ok2 & 1u) && S.use_stab) ok2 = stab_contains(S, sm) ? 1u : 0u;
+        }
+    }
+    auto key_at = [&](int i, uint64_t &klo, uint64_t &khi) {
+        if (KW == 1) {
+            const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
+            const uint64_t rc = funnel64(r0, r1, 2 * (ITEM_POS - 1 - i)) & mask_lo;
+            klo = fwd < rc ? fwd : rc; khi = 0;
+        } else {
+            const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
+            uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
+            const bool fl = (hi < rhi) || (hi == rhi && lo < rlo);
+            klo = fl ? lo : rlo; khi = fl ? hi : rhi;
+        }
+    };
+    const uint64_t left64 = n_pos - p0;
+    const uint32_t left = left64 < (uint64_t)ITEM_POS ? (uint32_t)left64 : (uint32_t)ITEM_POS;
+    bool hit = false, n_known = false; uint32_t nmask = 0;
+#pragma unroll
+    for (int step = 0; step < ITEM_POS / 4; step++) {
+        if (!__ballot(active)) break;
+        if (active) {
+            uint32_t pm = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = 4 * step + j;
+                uint64_t klo, khi;
+                key_at(i, klo, khi);
+                const uint32_t hb = KW == 1 ? kbit_hash1(klo) : kbit_hash2(klo, khi);
+                const uint2 blk = s_kb2[hb >> kb_shift];
+                const uint32_t g = kbit_pos(hb);
+                const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31));
+                pm |= (t & 1u) << i;
+            }
+            if (left < (uint32_t)ITEM_POS) pm &= (1u << left) - 1;
+            if (step == 0 && lone && !(ok2 & 1u)) { active = false; pm = 0; }
+            if (hasn && pm) {                               // windows holding an invalid base
+                if (!n_known) {
+                    n_known = true;
+                    const uint64_t len = n_pos + k - 1;
+                    const uint64_t n_lo = npos_lower_bound(R, b0), n_hi = npos_lower_bound(R, b0 + len);
+                    for (uint64_t n = n_lo; n < n_hi; n++) {
+                        const int64_t d = (int64_t)(R.npos[n] - (b0 + p0));       // window i holds it iff i <= d < i + k
+#pragma unroll
+                        for (int i = 0; i < ITEM_POS; i++) if (d >= i && d < i + k) nmask |= 1u << i;
+                    }
+                }
+                pm &= ~nmask;
+            }
+            while (pm) {                                    // open-address table for the bit-table positives
+                const int i = __ffs(pm) - 1;
+                pm &= pm - 1;
+                uint64_t klo, khi;
+                key_at(i, klo, khi);
+                const uint32_t h = (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi));
+                if (table_has<KW>(S, klo, khi, h)) { hit = true; break; }
+            }
+            if (hit || 4u * (step + 1) >= left) active = false;
+        }
+    }
+    return hit;
+}
+
+constexpr int FUSED_BLOCK = 1024;
+constexpr int FUSED_WAVES = FUSED_BLOCK / 64;
+constexpr int RING = 64;                         // records per streaming-wave ring
+constexpr uint32_t KBF_MAX_LOG2W = 12;           // k-mer bit table folded to <= 16 KiB of LDS
+
+struct FusedArgs {
+    uint32_t *cand, *bits;                       // this pass's candidate / result bitmaps (clean at entry)
+    uint4 *cand_other, *bits_other;              // the other parity's pair, cleared by this pass
+    uint64_t bitmap_vec4;                        // uint4 per bitmap to clear
+    unsigned long long *ovf;                     // overflow records: [grid][n_stream][ovf_cap]
+    uint32_t ovf_cap;
+    uint32_t n_chunks;                           // chunks of n_stream * 64 * U uint4 (buffer readable, zero past the data)
+    uint32_t n_stream;                           // streaming waves per workgroup
+    uint32_t thr, count_all;
+    uint32_t *hits_out;
+    unsigned long long *partials;                // [2 * grid] pass / candidate tallies; [2 * EXACT_MAX_GRID - 1] error flag
+    uint32_t flags;                              // bit 0: drop the records (stream-only timing experiment, results are wrong)
+    unsigned long long *dbg;                     // optional [grid][FUSED_WAVES][4]: stream end, exit (10 ns ticks since kernel entry), records by ring, by overflow / rounds
+};
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+    return ((uint64_t)__shfl((uint32_t)(v >> 32), src) << 32) | __shfl((uint32_t)v, src);
+}
+
+template <int SPW, int U, bool MASKED, int KW>
+__global__ void __launch_bounds__(FUSED_BLOCK)
+fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
+{
+    extern __shared__ uint4 s_mem4[];
+    const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
+    const uint32_t kbf_log2w = S.kb_log2w < KBF_MAX_LOG2W ? S.kb_log2w : KBF_MAX_LOG2W;
+    const uint32_t n_kb2 = 1u << (kbf_log2w - 1);                              // 64-bit blocks of the folded k-mer bit table
+    uint4 *s_tab4 = s_mem4;                                                    // stage-1 table
+    uint2 *s_kb2 = reinterpret_cast<uint2 *>(s_mem4 + nb4);
+    lds_u64 *s_ring = (lds_u64 *)(s_kb2 + n_kb2);                              // [FUSED_WAVES][RING]
+    lds_u32 *s_cnt = (lds_u32 *)(s_ring + FUSED_WAVES * RING);                 // [FUSED_WAVES][64]
+    lds_u32 *s_ctl = s_cnt + FUSED_WAVES * 64;                                 // 64 control words
+    lds_u32 *s_prod = s_ctl, *s_cons = s_ctl + 16;
+    lds_u32 *s_done = s_ctl + 32, *s_exit = s_ctl + 33, *s_tot = s_ctl + 34;
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t t_entry = A.dbg ? wall_clock64() : 0;
+    uint64_t t_stream_end = 0; uint32_t n_rounds = 0;
+    uint64_t tm_refill = 0, tm_pick = 0, tm_item = 0, tm_mark = 0;      // debug: 10 ns ticks a finisher spent in each part of its rounds
+    const uint32_t n_stream = A.n_stream;
+    const bool streamer = (uint32_t)wid < n_stream;
+    const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
+    const uint32_t NST = n_stream * 64;                                        // streaming threads
+    const uint32_t chunk_vec = NST * U;                                        // uint4 per chunk
+    const uint32_t n_chunks = A.n_chunks;
+    const uint64_t cstep = gridDim.x;
+    const uint32_t blk_shift = 32 - (S.bloom_log2w - 2);
+    const uint32_t smask = S.smask;
+    constexpr int NSAMP = U * 4 * SPW;
+
+    // ---- streaming machinery (used by streaming waves only)
+    auto load = [&](uint32_t c, u32x4 (&d)[U], uint32_t (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t v = (uint64_t)c * chunk_vec + (uint32_t)u * NST + threadIdx.x;
+            d[u] = __builtin_nontemporal_load(&w4[v]);
+            if (SPW == 2) x[u] = R.words[4 * v + 4];
+        }
+    };
+    lds_u64 *my_ring = s_ring + wid * RING;
+    unsigned long long *my_ovf = A.ovf + ((size_t)blockIdx.x * n_stream + (streamer ? wid : 0)) * A.ovf_cap;
+    uint32_t prod = 0, ovf_n = 0;
+    // Stage 1 on one chunk slice held in registers.  Per sample: one v_mad_u32_u24 (hash), one ds_read_b128 (the
+    // sample's 128-bit block), four left shifts that bring the tested bit of each dword into the sign position (shift
+    // amounts are bytes of (hash:s-mer) >> 11, picked by SDWA selectors), two three-input ANDs and one funnel shift that
+    // appends the sign bit to the hit mask.  The block reads of one 16-byte piece are issued together.
+    auto stage1 = [&](uint32_t c, const u32x4 (&d)[U], const uint32_t (&x)[U]) {
+        uint32_t hitmask = 0;
+        const uint32_t cons = lds_ld(&s_cons[wid]);        // read early: an older value only under-estimates the free space
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
+            uint32_t sm[4 * SPW], h[4 * SPW]; uint4 blk[4 * SPW];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int j = 0; j < SPW; j++)
+                    sm[q * SPW + j] = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
+#pragma unroll
+            for (int i = 0; i < 4 * SPW; i++) { h[i] = bloom_hash(sm[i]); blk[i] = s_tab4[h[i] >> blk_shift]; }
+#pragma unroll
+            for (int i = 0; i < 4 * SPW; i++) {
+                const uint32_t g = alignbit(h[i], sm[i], STAGE1_MIX_SHIFT);          // stage1_mix
+                const uint32_t t = lshl_by_byte<0>(g, blk[i].x) & lshl_by_byte<1>(g, blk[i].y) & lshl_by_byte<2>(g, blk[i].z) & lshl_by_byte<3>(g, blk[i].w);
+                hitmask = alignbit(hitmask, t, 31);                                  // (hitmask << 1) | sign(t)
+            }
+        }
+        const uint64_t hm = (A.flags & 1u) ? 0 : __ballot(hitmask != 0);
+        if (hm) {                                           // wave-uniform
+            const uint32_t n = (uint32_t)__popcll(hm);
+            const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+            const unsigned long long rec = ((unsigned long long)hitmask << 32) | (c << 10) | threadIdx.x;
+            if (RING - (prod - cons) >= n) {
+                if (hitmask) lds_st(&my_ring[(prod + mb) & (RING - 1)], rec);
+                prod += n;
+                MF_COMPILER_FENCE();
+                lds_st(&s_prod[wid], prod);                 // LDS executes a wave's instructions in order: the records are there first
+            } else {
+                if (hitmask) my_ovf[ovf_n + mb] = rec;
+                ovf_n += n;
+            }
+        }
+    };
+
+    // ---- prologue: first chunk in flight, clear the other parity's bitmaps, stage the tables
+    u32x4 a[U], b[U]; uint32_t ax[U], bx[U];
+    uint32_t c = blockIdx.x;
+    const uint32_t cs = gridDim.x;
+    if (streamer && c < n_chunks) load(c, a, ax);
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = (uint64_t)blockIdx.x * FUSED_BLOCK + threadIdx.x; i < A.bitmap_vec4; i += cstep * FUSED_BLOCK) { A.cand_other[i] = z; A.bits_other[i] = z; }
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
+        for (uint32_t i = threadIdx.x; i < nb4; i += FUSED_BLOCK) s_tab4[i] = src[i];
+        // fold the k-mer bit table: the block index is the top bits of the hash, so 2^f neighbouring blocks OR into one
+        const uint32_t fold = 1u << (S.kb_log2w - kbf_log2w);
+        const uint2 *__restrict__ src2 = reinterpret_cast<const uint2 *>(S.kbloom);
+        for (uint32_t i = threadIdx.x; i < n_kb2; i += FUSED_BLOCK) {
+            uint2 acc = make_uint2(0, 0);
+            for (uint32_t j = 0; j < fold; j++) { const uint2 t = src2[i * fold + j]; acc.x |= t.x; acc.y |= t.y; }
+            s_kb2[i] = acc;
+        }
+        if (threadIdx.x < 64) s_ctl[threadIdx.x] = 0;
+    }
+    __syncthreads();
+
+    if (streamer) {
+        // Two register sets, ping-pong: the next chunk is in flight while this one is examined.  The loads sit on
+        // unconditional paths (the last chunk is peeled), so the compiler's vmcnt counts are exact and examining a
+        // chunk never waits for the loads issued right before it.
+        if (c < n_chunks) for (;;) {
+            if (c + cs >= n_chunks) { stage1(c, a, ax); break; }
+            load(c + cs, b, bx);
+            stage1(c, a, ax);
+            c += cs;
+            if (c + cs >= n_chunks) { stage1(c, b, bx); break; }
+            load(c + cs, a, ax);
+            stage1(c, b, bx);
+            c += cs;
+        }
+        if (A.dbg) t_stream_end = wall_clock64() - t_entry;
+        MF_COMPILER_FENCE();
+        if (lane == 0) lds_add(s_done, 1u);         // after the last s_prod store, in LDS order
+        __threadfence_block();                      // own overflow records are read back below
+    } else {
+        __builtin_amdgcn_s_setprio(2);              // a finisher's short bursts of work go ahead of the streaming waves on its SIMD
+    }
+
+    // ---- finishing machinery (every wave: finishers from the start, streaming waves once their chunks are done)
+    // Lanes are persistent workers: a lane holds one record until all its positives are dealt with; idle lanes are
+    // refilled from the rings (finishers) or from the wave's own overflow list (streaming waves, afterwards) before
+    // every round, so the rounds -- each one or two memory round trips long -- run with as many lanes as there is work.
+    //
+    // Two ways to finish a positive:
+    //  SAMPLE mode (threshold 1, no hit counts wanted): a window of k bases that is a bait k-mer contains only
+    //    true stage-1 positives, in particular the first stream-aligned s-mer at or after its start -- call that
+    //    sample its owner.  Every window inside a read therefore belongs to exactly one sample inside that read (the
+    //    `stride` windows starting at g0 - stride + 1 .. g0), and the read passes iff some positive sample owns a
+    //    window that is in the bait set.  So a positive costs ONE work item (16 k-mer positions: one unaligned
+    //    16-byte window, LDS bit table, open-address table for the bit-table positives) and a pass is an idempotent
+    //    atomicOr: no grouping state beyond "the read my record already passed", no claim, no candidate bitmap.
+    //  CLAIM mode (threshold > 1 or hit counts): positives are grouped by read, lone ones verified (stage 2 / 3), the
+    //    read is claimed in the candidate bitmap (returning atomicOr: exactly one lane of the grid wins) and claimed
+    //    reads are counted whole, 64 per run, their work items dealt to the wave's lanes (run_candidates).
+    const uint2 *__restrict__ kb2 = s_kb2;
+    const uint32_t kb_shift = 32 - (kbf_log2w - 1);
+    lds_u32 *my_cnt = s_cnt + wid * 64;
+    const uint32_t *__restrict__ st2 = S.bloom + ((size_t)1 << S.bloom_log2w);      // stage 2: <= 32 KiB, L2 resident
+    const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
+    const bool fast = R.len_magic32 != 0;
+    const bool sample_mode = A.thr == 1 && !A.count_all;
+    const int k = S.k;
+    // finisher f serves rings f, f + NF, f + 2 NF, ...: lane l < 16 keeps the consumer count of ring f + l * NF
+    const uint32_t NF = FUSED_WAVES - n_stream, f = (uint32_t)wid - n_stream;
+    const uint32_t my_ring_id = streamer ? 0xFFFFu : f + (uint32_t)lane * NF;
+    const bool ring_lane = !streamer && lane < 16 && my_ring_id < n_stream;
+    uint32_t my_cons = 0, ovf_pos = 0;
+    uint64_t cand_r = 0; uint32_t ncand = 0;          // claim mode: lane i < ncand owns candidate read cand_r
+    uint64_t def_r = 0; bool def_v = false;           // claim mode: a read this lane claimed in the last round, not yet dealt to a lane
+    uint32_t m = 0, rtid = 0, rrem = 0; uint64_t cb = 0, rq = 0;    // record in progress: remaining positives, recording lane, first base of its piece
+    bool lone = false;                                // the record has a single positive (most of those are stage-1 false positives)
+    uint64_t passed_r = ~0ULL;                        // sample mode: the read this lane's record has already passed
+    uint32_t pend_old = 0, pend_bit = 0;              // sample mode: result of the last pass-bit atomic, looked at one round later
+    uint32_t tot_pass = 0, tot_cand = 0, spins = 0;
+    auto off_of = [&](int idx) -> uint32_t {          // offset (bases, inside its chunk) of sample idx of the recording lane
+        const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
+        return ((((uint32_t)u * NST + rtid) * 4 + q) << 4) + (uint32_t)j * 8;
+    };
+    for (;;) {
+        // (1) claim mode: reads claimed in the last round move to free lanes; if they do not fit, the lanes are counted first
+        bool flush = false;
+        if (!sample_mode) {
+            const uint64_t defm = __ballot(def_v);
+            const uint32_t ndef = (uint32_t)__popcll(defm);
+            if (ndef) {
+                if (ncand + ndef <= 64) {
+                    const uint32_t src = nth_set_lane(defm, ((uint32_t)lane - ncand) & 63u) & 63u;
+                    const uint64_t v = shfl_u64(def_r, (int)src);
+                    if ((uint32_t)lane >= ncand && (uint32_t)lane < ncand + ndef) cand_r = v;
+                    ncand += ndef; def_v = false;
+                } else flush = true;
+            }
+        }
+        // (2) refill idle lanes
+        bool finished = false;
+        const uint64_t tq0 = A.dbg ? wall_clock64() : 0;
+        const uint64_t idle = __ballot(m == 0);
+        if (idle && !flush) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const bool is_idle = m == 0;
+            uint32_t n_take = 0; unsigned long long rec = 0;
+            if (!streamer) {
+                const uint32_t done = lds_ld(s_done);          // before the producer counts
+                MF_COMPILER_FENCE();
+                const uint32_t avail = ring_lane ? lds_ld(&s_prod[my_ring_id]) - my_cons : 0u;
+                MF_COMPILER_FENCE();
+                uint32_t incl = avail;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                const uint32_t total = __shfl(incl, 15);
+                n_take = total < n_idle ? total : n_idle;
+                finished = done == n_stream && total == 0;
+                if (n_take) {
+                    int lo = 0, hi = 15;                       // smallest ring lane whose inclusive count exceeds this lane's ordinal
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; s_++) { const int mid = (lo + hi) >> 1; if (__shfl(incl, mid) > ord) hi = mid; else lo = mid + 1; }
+                    const uint32_t incl_j = __shfl(incl, lo), avail_j = __shfl(avail, lo), cons_j = __shfl(my_cons, lo);
+                    const uint32_t ring = f + (uint32_t)lo * NF;
+                    if (is_idle && ord < n_take) rec = lds_ld(&s_ring[ring * RING + ((cons_j + (ord - (incl_j - avail_j))) & (RING - 1))]);
+                    MF_COMPILER_FENCE();
+                    const uint32_t excl = incl - avail;
+                    const uint32_t taken = n_take > excl ? (n_take - excl < avail ? n_take - excl : avail) : 0u;
+                    if (ring_lane && taken) { my_cons += taken; lds_st(&s_cons[my_ring_id], my_cons); }      // after the ring reads, in LDS order
+                }
+            } else {
+                finished = ovf_pos >= ovf_n;
+                n_take = ovf_n - ovf_pos < n_idle ? ovf_n - ovf_pos : n_idle;
+                if (is_idle && ord < n_take) rec = my_ovf[ovf_pos + ord];
+                ovf_pos += n_take;
+            }
+            if (is_idle && ord < n_take) {
+                m = (uint32_t)(rec >> 32);
+                lone = __popc(m) == 1;
+                rtid = (uint32_t)rec & 1023u;
+                cb = (uint64_t)((uint32_t)rec >> 10) * ((uint64_t)chunk_vec * 64);
+                if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
+                passed_r = ~0ULL;
+            }
+        }
+        if (A.dbg) tm_refill += wall_clock64() - tq0;
+        if (!flush && !__ballot(m != 0)) {                     // no lane has anything to do
+            if (ncand) flush = true;                           // claim mode, idle: count what is waiting
+            else if (finished) break;
+            else {                                             // a finisher ahead of the stream
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 24)) { if (lane == 0) A.partials[2 * EXACT_MAX_GRID - 1] = 1; break; }    // watchdog: never hang the device
+                continue;
+            }
+        }
+        spins = 0;
+        // (3) claim mode: exact count of the candidates in the lanes
+        if (flush) {
+            const bool owner = (uint32_t)lane < ncand;
+            const uint64_t r = cand_r;
+            uint64_t b0 = 0; uint32_t np = 0, hasn = 0;
+            if (owner) {
+                uint64_t len;
+                if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; }
+                else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
+                const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
+                np = n_pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_pos;
+                hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
+            }
+            run_candidates<KW>(R, S, kb2, kb_shift, A.thr, true, lane, owner, b0, np, hasn, my_cnt, A.count_all != 0);
+            if (owner) {
+                const uint32_t hcnt = my_cnt[lane];
+                if (A.count_all) A.hits_out[r] = hcnt;
+                if (hcnt >= A.thr) { atomicOr(&A.bits[r >> 5], 1u << (r & 31)); tot_pass++; }
+                tot_cand++;
+            }
+            ncand = 0;
+            continue;
+        }
+        if (sample_mode) {
+            // (4a) one round: every lane takes its record's next positive whose read has not passed yet
+            const uint64_t tq1 = A.dbg ? wall_clock64() : 0;
+            bool got = false; uint64_t r = 0, g0 = 0, b0 = 0, len = 0;
+            if (fast) {
+                while (m) {
+                    const int bit = 31 - __clz(m);
+                    m &= ~(1u << bit);
+                    const uint32_t off = off_of(NSAMP - 1 - bit);
+                    const uint32_t t = rrem + off;
+                    const uint32_t dq = __umulhi(t, R.len_magic32);
+                    const uint32_t offr = t - dq * R.uniform_len;
+                    // straddles two reads / lies in the padding behind the last read: not a sample of any read
+                    if (offr + (uint32_t)S.s > R.uniform_len || cb + off + S.s > R.total_bases) continue;
+                    r = rq + dq;
+                    if (r == passed_r) continue;
+                    got = true; g0 = cb + off; b0 = g0 - offr; len = R.uniform_len;
+                    break;
+                }
+            } else if (m) {
+                const int bit = 31 - __clz(m);
+                m &= ~(1u << bit);
+                g0 = cb + off_of(NSAMP - 1 - bit);
+                r = read_holding(R, g0, (uint32_t)S.s);
+                got = r != ~0ULL && r != passed_r;
+                if (got) { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
+            }
+            const uint32_t po = pend_old, pb = pend_bit;          // looked at after this round's loads: never waited for on its own
+            pend_bit = 0;
+            // the windows this sample owns start at g0 - stride + 1 .. g0; the item tests 16 positions from the first
+            // of them that lies inside the read (positions past g0 belong to the next sample: harmless for threshold 1)
+            const uint64_t own_lo = g0 + 1 > (uint64_t)S.stride ? g0 + 1 - S.stride : 0;
+            const uint64_t p0 = own_lo > b0 ? own_lo - b0 : 0;
+            const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
+            const bool act = got && p0 < n_pos;
+            const uint64_t tq2 = A.dbg ? wall_clock64() : 0;
+            if (A.dbg) tm_pick += tq2 - tq1;
+            if (sample_item<KW>(R, S, kb2, kb_shift, act, r, b0, n_pos, p0, lone, (uint32_t)(g0 - (b0 + p0)), st2, st2_shift)) {
+                passed_r = r;
+                pend_bit = 1u << (r & 31);
+                pend_old = atomicOr(&A.bits[r >> 5], pend_bit);           // first setter of the bit counts the pass (next round)
+            }
+            tot_cand += act;
+            if (A.dbg) { const uint64_t tq3 = wall_clock64(); tm_item += tq3 - tq2; }
+            if (pb && !(po & pb)) tot_pass++;
+            if (A.dbg) { n_rounds++; tm_mark += (uint64_t)__popcll(__ballot(act)); }
+            continue;
+        }
+        // (4b) claim mode, one round: every lane takes the next read its record has positives in
+        bool got = false; uint64_t r = 0; int idx = 0; uint32_t npos_in = 0;
+        if (fast) {
+            // Uniform read length: positives are walked in stream order and grouped by the read they fall into (a
+            // division by multiplication each).  Two or more stage-1 positives of one lane inside one read are
+            // practically always a bait read, so such a read is claimed without fetching anything; a lone positive
+            // goes through stage 2.  Claiming is only ever conservative -- the exact count decides.
+            while (m) {
+                const int bit = 31 - __clz(m);
+                m &= ~(1u << bit);
+                const int i0 = NSAMP - 1 - bit;
+                const uint32_t off = off_of(i0);
+                const uint32_t t = rrem + off;
+                const uint32_t dq = __umulhi(t, R.len_magic32);
+                const uint32_t offr = t - dq * R.uniform_len;
+                if (offr + (uint32_t)S.s > R.uniform_len || cb + off + S.s > R.total_bases) continue;
+                const uint64_t rr = rq + dq;
+                if (!got) { got = true; r = rr; idx = i0; npos_in = 1; continue; }
+                if (rr == r) { npos_in++; continue; }
+                m |= 1u << bit;                                // first positive of the next read: next round
+                break;
+            }
+        } else if (m) {                                        // ragged reads: every positive is looked up on its own
+            const int bit = 31 - __clz(m);
+            m &= ~(1u << bit);
+            got = true; idx = NSAMP - 1 - bit; npos_in = 1;
+        }
+        bool ok = got;
+        if (got && npos_in == 1) {
+            // stage 2 (canonical s-mer, STAGE2_K Bloom probes), optional stage 3 (exact s-mer table, large baits)
+            const uint64_t g0 = cb + off_of(idx);
+            const uint64_t wi = g0 >> 4;
+            uint32_t sm = R.words[wi];
+            if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW));
+            sm &= smask;
+            const uint32_t rc = revcomp_s(sm, S.s);
+            const uint32_t cn_ = sm < rc ? sm : rc;
+            const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
+            uint32_t bitsok = 1;
+#pragma unroll
+            for (int p = 0; p < STAGE2_K; p++) {
+                const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
+                bitsok &= st2[pos >> 5] >> (pos & 31);
+            }
+            ok = (bitsok & 1u) != 0;
+            if (ok && S.use_stab) ok = stab_contains(S, sm);
+            if (ok && !fast) { r = read_holding(R, g0, (uint32_t)S.s); ok = r != ~0ULL; }
+        }
+        // claim the read: exactly one lane of the grid sees its bit clear
+        def_v = false;
+        if (ok) {
+            const uint32_t bitm = 1u << (r & 31);
+            const uint32_t old = atomicOr(&A.cand[r >> 5], bitm);
+            def_v = !(old & bitm); def_r = r;
+        }
+    }
+    if (pend_bit && !(pend_old & pend_bit)) tot_pass++;
+
+    if (A.dbg && lane == 0) {
+        unsigned long long *d = A.dbg + ((size_t)blockIdx.x * FUSED_WAVES + wid) * 4;
+        d[0] = t_stream_end; d[1] = wall_clock64() - t_entry; d[2] = streamer ? prod : my_cons; d[3] = streamer ? ovf_n : n_rounds;
+        if (!streamer) { d[0] = tm_refill | (tm_pick << 32); d[2] = tm_item | (tm_mark << 32); }
+    }
+    // ---- tallies: the last wave out stores the workgroup's pair (summed by the host)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tot_pass += __shfl_down(tot_pass, o); tot_cand += __shfl_down(tot_cand, o); }
+    if (lane == 0) {
+        lds_add(&s_tot[0], tot_pass); lds_add(&s_tot[1], tot_cand);
+        MF_COMPILER_FENCE();
+        if (lds_add(s_exit, 1u) == FUSED_WAVES - 1) {
+            MF_COMPILER_FENCE();
+            A.partials[2 * blockIdx.x] = lds_ld(&s_tot[0]);
+            A.partials[2 * blockIdx.x + 1] = lds_ld(&s_tot[1]);
+        }
+    }
 }
 
 // ----------------------------------------------------------- bait builders
@@ -804,6 +1368,14 @@ __global__ void count_keys_kernel(const uint64_t *keys, uint64_t slots, int kw, 
         if (ca) atomicAdd(&out[0], (unsigned long long)ca);
         if (cb) atomicAdd(&out[1], (unsigned long long)cb);
     }
+}
+
+// block index over the invalid-base list (one thread per block of 4096 bases)
+__global__ void build_npos_blk_kernel(const uint64_t *__restrict__ npos, uint64_t n_npos, uint64_t n_blk, uint32_t *__restrict__ blk)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blk) return;
+    blk[b] = (uint32_t)lower_bound_u64(npos, n_npos, b << NPOS_BLK_SHIFT);
 }
 
 // mark reads that hold an invalid base (one thread per invalid position)
@@ -975,6 +1547,17 @@ uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu)
         else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                           \
     } while (0)
 
+// the dynamic-LDS ceiling of a kernel is raised once per (kernel, device), not on every launch
+template <auto Kernel> static void raise_lds_limit_once(size_t max_bytes)
+{
+    static std::atomic<uint64_t> done{0};                     // one bit per device (0..63)
+    int dev = 0; (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+
 template <int SPW, bool MASKED>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm)
@@ -983,7 +1566,7 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&screen_kernel<SPW, SCREEN_U, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U, MASKED>>(128 * 1024 + 16);
     MF_LAUNCH((screen_kernel<SPW, SCREEN_U, MASKED>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
               static_cast<ScreenRec *>(recs), cap, rec_counts);
 }
@@ -1018,6 +1601,63 @@ hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *rec
     return hipGetLastError();
 }
 
+// ---- fused pass
+static uint32_t fused_stream_waves()
+{
+    static const uint32_t n = [] {
+        const char *v = getenv("MF_STREAM_WAVES");
+        uint32_t w = v && *v ? (uint32_t)atoi(v) : 14u;
+        return w < 4 ? 4u : (w > FUSED_WAVES - 1 ? (uint32_t)FUSED_WAVES - 1 : w);
+    }();
+    return n;
+}
+
+FusedGeom fused_geom_for(uint64_t n_words, int n_cu)
+{
+    FusedGeom g{};
+    g.n_stream = fused_stream_waves();
+    g.chunk_vec = (uint64_t)g.n_stream * 64 * SCREEN_U;
+    const uint64_t n_vec = (n_words + 3) / 4;
+    g.n_chunks = (n_vec + g.chunk_vec - 1) / g.chunk_vec;
+    g.grid = g.n_chunks < (uint64_t)n_cu ? g.n_chunks : (uint64_t)n_cu;     // persistent: one 1024-thread workgroup per CU
+    const uint64_t iters = g.grid ? (g.n_chunks + g.grid - 1) / g.grid : 0;
+    g.ovf_cap = iters * 64;                                   // one record per lane per chunk a wave walks
+    g.words_needed = g.n_chunks * g.chunk_vec * 4 + 16;
+    g.ok = g.n_chunks < (1u << 22) && g.ovf_cap < (1ull << 32);
+    return g;
+}
+
+size_t fused_lds_bytes(const KmerSetView &S)
+{
+    const uint32_t kbf = S.kb_log2w < KBF_MAX_LOG2W ? S.kb_log2w : KBF_MAX_LOG2W;
+    return (sizeof(uint32_t) << S.bloom_log2w) + (sizeof(uint32_t) << kbf) + (size_t)FUSED_WAVES * RING * 8 + (size_t)FUSED_WAVES * 64 * 4 + 256;
+}
+
+hipError_t launch_fused(const ReadsView &R, const KmerSetView &S, const FusedGeom &G, const FusedBuffers &B, uint32_t thr, bool count_all,
+                        hipStream_t st, const KernelTiming *tm)
+{
+    if (G.grid == 0) return hipSuccess;
+    FusedArgs A{};
+    A.cand = B.cand; A.bits = B.bits; A.cand_other = reinterpret_cast<uint4 *>(B.cand_other); A.bits_other = reinterpret_cast<uint4 *>(B.bits_other);
+    A.bitmap_vec4 = B.bitmap_vec4; A.ovf = B.ovf; A.ovf_cap = (uint32_t)G.ovf_cap; A.n_chunks = (uint32_t)G.n_chunks; A.n_stream = G.n_stream;
+    A.thr = thr; A.count_all = count_all ? 1u : 0u; A.hits_out = B.hits_out; A.partials = B.partials; A.flags = B.flags; A.dbg = B.dbg;
+    const size_t lds = fused_lds_bytes(S);
+#define MF_LAUNCH_FUSED(SPW, MASKED, KW) do { \
+        raise_lds_limit_once<&fused_kernel<SPW, SCREEN_U, MASKED, KW>>(160 * 1024); \
+        MF_LAUNCH((fused_kernel<SPW, SCREEN_U, MASKED, KW>), dim3((unsigned)G.grid), dim3(FUSED_BLOCK), lds, st, tm, R, S, A); } while (0)
+    if (S.kw == 1) {
+        if (S.stride == 16 && S.s == 16) MF_LAUNCH_FUSED(1, false, 1);
+        else if (S.stride == 16) MF_LAUNCH_FUSED(1, true, 1);
+        else MF_LAUNCH_FUSED(2, true, 1);
+    } else {
+        if (S.stride == 16 && S.s == 16) MF_LAUNCH_FUSED(1, false, 2);
+        else if (S.stride == 16) MF_LAUNCH_FUSED(1, true, 2);
+        else MF_LAUNCH_FUSED(2, true, 2);
+    }
+#undef MF_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st,
                         const KernelTiming *tm)
@@ -1032,7 +1672,7 @@ hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand
     if (grid > (uint64_t)n_cu * per_cu) grid = (uint64_t)n_cu * per_cu;
     if (grid > EXACT_MAX_GRID) grid = EXACT_MAX_GRID;
 #define MF_LAUNCH_EXACT(KW, CA) do { \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&exact_kernel<KW, CA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        raise_lds_limit_once<&exact_kernel<KW, CA>>(160 * 1024); \
         MF_LAUNCH((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, tm, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
     if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true); else MF_LAUNCH_EXACT(1, false); }
     else           { if (count_all) MF_LAUNCH_EXACT(2, true); else MF_LAUNCH_EXACT(2, false); }
@@ -1072,6 +1712,12 @@ hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const
 {
     const uint64_t n = slots > stab_slots ? slots : stab_slots;
     hipLaunchKernelGGL(count_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, slots, kw, stab, stab_slots, out2);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_npos_blk(const uint64_t *npos, uint64_t n_npos, uint64_t n_blk, uint32_t *blk, hipStream_t st)
+{
+    hipLaunchKernelGGL(build_npos_blk_kernel, dim3(grid_for(n_blk, 256)), dim3(256), 0, st, npos, n_npos, n_blk, blk);
     return hipGetLastError();
 }
 
