@@ -378,12 +378,13 @@ struct mf_reads {
     int cur = 0;
     void *d_recs = nullptr; uint32_t *d_rec_counts = nullptr;     // split path: stage-1 positive records (screen -> mark)
     unsigned long long *d_ovf = nullptr;                          // fused path: ring-overflow records
+    unsigned long long *d_dfr = nullptr;                          // fused path: parked sixteen-window items (FUSED_DFR_CAP per wave)
     unsigned long long *d_dbg = nullptr;                          // MF_FUSED_DEBUG: per-wave timestamps of the last fused pass
     FusedGeom fgeom{};
     unsigned long long *d_counters = nullptr;
     size_t bitmap_bytes = 0;
     // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
-    size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0, cap_ovf = 0, cap_npos_blk = 0;
+    size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0, cap_ovf = 0, cap_npos_blk = 0, cap_dfr = 0;
 };
 
 // MF_PASS=split selects the three-kernel pass (screen, mark, exact) instead of the fused one
@@ -400,7 +401,7 @@ static void reads_release(mf_reads *r)
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
         for (int i = 0; i < 2; i++) { hipFree(r->d_cand[i]); hipFree(r->d_bits[i]); }
         hipFree(r->d_hits); hipFree(r->d_counters); hipFree(r->d_npos_blk);
-        hipFree(r->d_recs); hipFree(r->d_rec_counts); hipFree(r->d_ovf); hipFree(r->d_dbg);
+        hipFree(r->d_recs); hipFree(r->d_rec_counts); hipFree(r->d_ovf); hipFree(r->d_dfr); hipFree(r->d_dbg);
     }
     delete r;
 }
@@ -476,6 +477,7 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
         // ring-overflow lists: worst case one 8-byte record per lane per chunk (an eighth of the packed stream); normally unused
         const uint64_t n = fg.grid * fg.n_stream * fg.ovf_cap;
         RCHK(dev_reserve(r->d_ovf, r->cap_ovf, (n ? n : 1) * 8, reuse));
+        RCHK(dev_reserve(r->d_dfr, r->cap_dfr, (fg.grid ? fg.grid : 1) * 16 * FUSED_DFR_CAP * 8, reuse));
     } else {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %
         const uint64_t grid = screen_grid_for(V, ctx->n_cu), cap = screen_rec_cap_for(V, ctx->n_cu);
         RCHK(dev_reserve(r->d_recs, r->cap_recs, (grid * cap ? grid * cap : 1) * 16, reuse));
@@ -600,7 +602,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         if (!r->bits_clean[q]) HIPCHK(hipMemsetAsync(r->d_bits[q], 0, r->bitmap_bytes, st));
         FusedBuffers B{};
         B.cand = r->d_cand[q]; B.bits = r->d_bits[q]; B.cand_other = r->d_cand[1 - q]; B.bits_other = r->d_bits[1 - q];
-        B.bitmap_vec4 = ((r->v.n_reads + 31) / 32 + 3) / 4; B.ovf = r->d_ovf; B.hits_out = r->d_hits; B.partials = r->d_counters;
+        B.bitmap_vec4 = ((r->v.n_reads + 31) / 32 + 3) / 4; B.ovf = r->d_ovf; B.dfr = r->d_dfr; B.dfr_cap = FUSED_DFR_CAP; B.hits_out = r->d_hits; B.partials = r->d_counters;
         static const bool dbg_on = getenv("MF_FUSED_DEBUG") != nullptr, drop = getenv("MF_FUSED_DROP") != nullptr;
         B.flags = drop ? 1u : 0u;
         if (dbg_on) {

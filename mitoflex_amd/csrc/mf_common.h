@@ -67,10 +67,12 @@ constexpr int STAGE2_K = 4;
 MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }
 MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u; return (h ^ (h >> 16)) | 1u; }
 // k-mer bit table in front of the open-address table (exact kernel): one 64-bit block per key, one bit in each
-// dword.  Its hash is one multiply per 32 bits of key and xors -- the table hash proper is only computed for the
+// dword.  Its hash is one 24-bit multiply-add per 32 bits of key (full rate; a 32-bit multiply is a quarter-rate instruction) and xors -- the table hash proper is only computed for the
 // positives; the block index comes from the top bits, the two bit positions from the low bits folded with the middle.
-MF_HD uint32_t kbit_hash1(uint64_t lo) { return ((uint32_t)lo * 0x9E3779B1u) ^ ((uint32_t)(lo >> 32) * 0x85EBCA77u); }
-MF_HD uint32_t kbit_hash2(uint64_t lo, uint64_t hi) { return kbit_hash1(lo) ^ ((uint32_t)hi * 0xC2B2AE3Du) ^ ((uint32_t)(hi >> 32) * 0x27D4EB2Fu); }
+MF_HD uint32_t mad24(uint32_t x, uint32_t c) { return (x & 0xFFFFFFu) * c + x; }          // one full-rate v_mad_u32_u24
+MF_HD uint32_t rot16(uint32_t x) { return (x << 16) | (x >> 16); }
+MF_HD uint32_t kbit_hash1(uint64_t lo) { return mad24((uint32_t)lo, 0x9E3779u) ^ rot16(mad24((uint32_t)(lo >> 32), 0x85EBCBu)); }
+MF_HD uint32_t kbit_hash2(uint64_t lo, uint64_t hi) { return kbit_hash1(lo) ^ mad24((uint32_t)hi, 0xC2B2AFu) ^ rot16(mad24((uint32_t)(hi >> 32), 0x27D4EBu)); }
 MF_HD uint32_t kbit_pos(uint32_t hb) { return hb ^ (hb >> 16); }   // bit of dword 0: low five bits, of dword 1: the next five
 MF_HD uint32_t smer_hash(uint32_t smer) { uint32_t h = smer * 0xC2B2AE35u; return h ^ (h >> 15); }
 

@@ -37,6 +37,7 @@ struct FusedBuffers {
     uint32_t *cand, *bits, *cand_other, *bits_other;
     uint64_t bitmap_vec4;
     unsigned long long *ovf;
+    unsigned long long *dfr; uint32_t dfr_cap;     // parked sixteen-window items: [grid][16][dfr_cap]
     uint32_t *hits_out;
     unsigned long long *partials;
     uint32_t flags;                 // debugging: bit 0 drops the stage-1 records (stream-only timing)

@@ -720,20 +720,31 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
 // Bitmaps are double buffered by pass parity: a pass finds its candidate and result bitmaps clean, sets bits with
 // atomics, and clears the other parity's pair for the next pass (no memset launches, no per-pass host work).
 // SAMPLE-mode work item of the fused pass: does one of the (<= 16) windows starting at read positions p0, p0 + 1, ...
-// hold a bait k-mer?  Positions are examined four at a time and the wave stops as soon as no lane needs more.
-// `lone`: the record's only positive -- most of those are stage-1 false positives, so the s-mer (it starts `soff` bases
-// into the window) is checked in the stage-2 table first and a lane that fails drops out after the first step.
+// hold a bait k-mer?  A finisher's round is a chain of memory round trips under a saturated memory system, so the
+// chain is kept at two: the window (and the read's has-N bit) -- then all sixteen k-mers go through the LDS bit table
+// and the open-address table probes of the positives are issued four at a time, together.
 template <int KW>
 __device__ __forceinline__ bool sample_item(const ReadsView &R, const KmerSetView &S, const uint2 *__restrict__ s_kb2, uint32_t kb_shift,
-                                            bool active, uint64_t r, uint64_t b0, uint64_t n_pos, uint64_t p0, bool lone, uint32_t soff,
-                                            const uint32_t *__restrict__ st2, uint32_t st2_shift)
+                                            bool active, uint64_t r, uint64_t b0, uint64_t n_pos, uint64_t p0)
 {
     const int k = S.k;
     const uint64_t mask_lo = (KW == 1 && k < 32) ? (1ULL << (2 * k)) - 1 : ~0ULL;
     const uint64_t mask_hi = KW == 2 ? (1ULL << (2 * k - 64)) - 1 : 0;
     constexpr int NW = KW == 1 ? 4 : 6;
     uint64_t x0 = 0, x1 = 0, x2 = 0, r0 = 0, r1 = 0;
-    uint32_t ok2 = 1, hasn = 0;
+    uint32_t hasn = 0, pm = 0;
+    auto key_at = [&](int i, uint64_t &klo, uint64_t &khi) {
+        if (KW == 1) {
+            const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
+            const uint64_t rc = funnel64(r0, r1, 2 * (ITEM_POS - 1 - i)) & mask_lo;
+            klo = fwd < rc ? fwd : rc; khi = 0;
+        } else {
+            const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
+            uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
+            const bool fl = (hi < rhi) || (hi == rhi && lo < rlo);
+            klo = fl ? lo : rlo; khi = fl ? hi : rhi;
+        }
+    };
     if (active) {
         const uint64_t bit = 2 * (b0 + p0);
         const uint32_t *__restrict__ w = R.words + (bit >> 5);
@@ -757,75 +768,63 @@ __device__ __forceinline__ bool sample_item(const ReadsView &R, const KmerSetVie
             if (drop >= 64) { r0 = y1 >> (drop - 64); r1 = 0; }
             else { r0 = (y0 >> drop) | (y1 << (64 - drop)); r1 = y1 >> drop; }
         }
-        if (lone) {
-            const uint32_t sm = (uint32_t)funnel64(x0, x1, 2 * (int)soff) & S.smask;
-            const uint32_t rc = revcomp_s(sm, S.s);
-            const uint32_t cn_ = sm < rc ? sm : rc;
-            const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
+        // LDS stage: which of the k-mers might be in the bait set
 #pragma unroll
-            for (int p = 0; p < STAGE2_K; p++) {
-                const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
-                ok2 &= st2[pos >> 5] >> (pos & 31);
+        for (int i = 0; i < ITEM_POS; i++) {
+            uint64_t klo, khi;
+            key_at(i, klo, khi);
+            const uint32_t hb = KW == 1 ? kbit_hash1(klo) : kbit_hash2(klo, khi);
+            const uint2 blk = s_kb2[hb >> kb_shift];
+            const uint32_t g = kbit_pos(hb);
+            const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31));
+            pm |= (t & 1u) << i;
+        }
+        const uint64_t left = n_pos - p0;               // positions past the end of the read
+        if (left < (uint64_t)ITEM_POS) pm &= (1u << left) - 1;
+        if (hasn && pm) {                               // windows holding an invalid base
+            const uint64_t len = n_pos + k - 1;
+            const uint64_t n_lo = npos_lower_bound(R, b0), n_hi = npos_lower_bound(R, b0 + len);
+            for (uint64_t n = n_lo; n < n_hi; n++) {
+                const int64_t d = (int64_t)(R.npos[n] - (b0 + p0));           // window i holds it iff i <= d < i + k
+#pragma unroll
+                for (int i = 0; i < ITEM_POS; i++) if (d >= i && d < i + k) pm &= ~(1u << i);
             }
-            if ((ok2 & 1u) && S.use_stab) ok2 = stab_contains(S, sm) ? 1u : 0u;
         }
     }
-    auto key_at = [&](int i, uint64_t &klo, uint64_t &khi) {
-        if (KW == 1) {
-            const uint64_t fwd = funnel64(x0, x1, 2 * i) & mask_lo;
-            const uint64_t rc = funnel64(r0, r1, 2 * (ITEM_POS - 1 - i)) & mask_lo;
-            klo = fwd < rc ? fwd : rc; khi = 0;
-        } else {
-            const uint64_t lo = funnel64(x0, x1, 2 * i), hi = funnel64(x1, x2, 2 * i) & mask_hi;
-            uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
-            const bool fl = (hi < rhi) || (hi == rhi && lo < rlo);
-            klo = fl ? lo : rlo; khi = fl ? hi : rhi;
-        }
-    };
-    const uint64_t left64 = n_pos - p0;
-    const uint32_t left = left64 < (uint64_t)ITEM_POS ? (uint32_t)left64 : (uint32_t)ITEM_POS;
-    bool hit = false, n_known = false; uint32_t nmask = 0;
+    // table stage: the probes of up to four positives are in flight together; an ordered probe sequence that has to
+    // go on (first slot holds a smaller key) is followed on its own, which is rare
+    bool hit = false;
+    while (__ballot(pm != 0)) {
+        uint64_t klo[4], khi[4], slot[4]; bool v[4];
 #pragma unroll
-    for (int step = 0; step < ITEM_POS / 4; step++) {
-        if (!__ballot(active)) break;
-        if (active) {
-            uint32_t pm = 0;
+        for (int j = 0; j < 4; j++) {
+            v[j] = pm != 0;
+            const int i = v[j] ? __ffs(pm) - 1 : 0;
+            pm &= pm - 1;                               // (0 stays 0)
+            key_at(i, klo[j], khi[j]);
+            slot[j] = (KW == 1 ? hash_key1(klo[j]) : hash_key2(klo[j], khi[j])) & S.slot_mask;
+        }
+        if (KW == 1) {
+            uint64_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) e[j] = v[j] ? S.keys[slot[j]] : EMPTY64;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int i = 4 * step + j;
-                uint64_t klo, khi;
-                key_at(i, klo, khi);
-                const uint32_t hb = KW == 1 ? kbit_hash1(klo) : kbit_hash2(klo, khi);
-                const uint2 blk = s_kb2[hb >> kb_shift];
-                const uint32_t g = kbit_pos(hb);
-                const uint32_t t = (blk.x >> (g & 31)) & (blk.y >> ((g >> 5) & 31));
-                pm |= (t & 1u) << i;
+                while (e[j] < klo[j]) { slot[j] = (slot[j] + 1) & S.slot_mask; e[j] = S.keys[slot[j]]; }
+                hit |= v[j] && e[j] == klo[j];
             }
-            if (left < (uint32_t)ITEM_POS) pm &= (1u << left) - 1;
-            if (step == 0 && lone && !(ok2 & 1u)) { active = false; pm = 0; }
-            if (hasn && pm) {                               // windows holding an invalid base
-                if (!n_known) {
-                    n_known = true;
-                    const uint64_t len = n_pos + k - 1;
-                    const uint64_t n_lo = npos_lower_bound(R, b0), n_hi = npos_lower_bound(R, b0 + len);
-                    for (uint64_t n = n_lo; n < n_hi; n++) {
-                        const int64_t d = (int64_t)(R.npos[n] - (b0 + p0));       // window i holds it iff i <= d < i + k
+        } else {
+            const ulonglong2 *__restrict__ kt = reinterpret_cast<const ulonglong2 *>(S.keys);
+            ulonglong2 e[4];
 #pragma unroll
-                        for (int i = 0; i < ITEM_POS; i++) if (d >= i && d < i + k) nmask |= 1u << i;
-                    }
-                }
-                pm &= ~nmask;
+            for (int j = 0; j < 4; j++) e[j] = v[j] ? kt[slot[j]] : make_ulonglong2(EMPTY64, EMPTY64);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                while ((e[j].y < khi[j]) || (e[j].y == khi[j] && e[j].x < klo[j])) { slot[j] = (slot[j] + 1) & S.slot_mask; e[j] = kt[slot[j]]; }
+                hit |= v[j] && e[j].x == klo[j] && e[j].y == khi[j];
             }
-            while (pm) {                                    // open-address table for the bit-table positives
-                const int i = __ffs(pm) - 1;
-                pm &= pm - 1;
-                uint64_t klo, khi;
-                key_at(i, klo, khi);
-                const uint32_t h = (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi));
-                if (table_has<KW>(S, klo, khi, h)) { hit = true; break; }
-            }
-            if (hit || 4u * (step + 1) >= left) active = false;
         }
+        if (hit) pm = 0;
     }
     return hit;
 }
@@ -846,6 +845,8 @@ struct FusedArgs {
     uint32_t thr, count_all;
     uint32_t *hits_out;
     unsigned long long *partials;                // [2 * grid] pass / candidate tallies; [2 * EXACT_MAX_GRID - 1] error flag
+    unsigned long long *dfr; uint32_t dfr_cap;   // deferred sixteen-window items: [grid][FUSED_WAVES][dfr_cap] first bases of samples
+    uint32_t refill_min;                         // a finisher tops its lanes up when this many are idle and as many records wait
     uint32_t flags;                              // bit 0: drop the records (stream-only timing experiment, results are wrong)
     unsigned long long *dbg;                     // optional [grid][FUSED_WAVES][4]: stream end, exit (10 ns ticks since kernel entry), records by ring, by overflow / rounds
 };
@@ -928,7 +929,7 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
             const uint32_t n = (uint32_t)__popcll(hm);
             const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
             const unsigned long long rec = ((unsigned long long)hitmask << 32) | (c << 10) | threadIdx.x;
-            if (RING - (prod - cons) >= n) {
+            if (n_stream < FUSED_WAVES && RING - (prod - cons) >= n) {
                 if (hitmask) lds_st(&my_ring[(prod + mb) & (RING - 1)], rec);
                 prod += n;
                 MF_COMPILER_FENCE();
@@ -941,9 +942,14 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
     };
 
     // ---- prologue: first chunk in flight, clear the other parity's bitmaps, stage the tables
+    // Round `it` deals chunks it * grid .. it * grid + grid - 1, workgroup b taking number (b + 37 it) mod grid: with a
+    // fixed number every chunk of a workgroup would lie at the same offset modulo grid * chunk bytes, i.e. on the same
+    // few memory channels for the whole pass, and the workgroups with the busy channels finish 20 % behind the average.
     u32x4 a[U], b[U]; uint32_t ax[U], bx[U];
-    uint32_t c = blockIdx.x;
     const uint32_t cs = gridDim.x;
+    uint32_t it = 0;
+    auto chunk_of = [&](uint32_t i) -> uint32_t { return i * cs + (blockIdx.x + i * 37u) % cs; };
+    uint32_t c = chunk_of(0);
     if (streamer && c < n_chunks) load(c, a, ax);
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -967,14 +973,16 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
         // unconditional paths (the last chunk is peeled), so the compiler's vmcnt counts are exact and examining a
         // chunk never waits for the loads issued right before it.
         if (c < n_chunks) for (;;) {
-            if (c + cs >= n_chunks) { stage1(c, a, ax); break; }
-            load(c + cs, b, bx);
+            uint32_t cn = chunk_of(++it);
+            if (cn >= n_chunks) { stage1(c, a, ax); break; }
+            load(cn, b, bx);
             stage1(c, a, ax);
-            c += cs;
-            if (c + cs >= n_chunks) { stage1(c, b, bx); break; }
-            load(c + cs, a, ax);
+            c = cn;
+            cn = chunk_of(++it);
+            if (cn >= n_chunks) { stage1(c, b, bx); break; }
+            load(cn, a, ax);
             stage1(c, b, bx);
-            c += cs;
+            c = cn;
         }
         if (A.dbg) t_stream_end = wall_clock64() - t_entry;
         MF_COMPILER_FENCE();
@@ -1016,8 +1024,20 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
     uint64_t cand_r = 0; uint32_t ncand = 0;          // claim mode: lane i < ncand owns candidate read cand_r
     uint64_t def_r = 0; bool def_v = false;           // claim mode: a read this lane claimed in the last round, not yet dealt to a lane
     uint32_t m = 0, rtid = 0, rrem = 0; uint64_t cb = 0, rq = 0;    // record in progress: remaining positives, recording lane, first base of its piece
-    bool lone = false;                                // the record has a single positive (most of those are stage-1 false positives)
-    uint64_t passed_r = ~0ULL;                        // sample mode: the read this lane's record has already passed
+    uint64_t passed_r = ~0ULL, passed_r2 = ~0ULL;     // sample mode: the last two reads this lane's record has passed
+    uint32_t runs = 0;                                // sample mode: positives of the record that start a run of n_adj neighbouring positives
+    // sample mode: positives that need the sixteen-window item are not counted on the spot -- a few lanes a round would make
+    // the wave run that code every round -- but parked (first base of the sample) and counted together, 64 a round, at the end
+    unsigned long long *my_dfr = A.dfr + ((size_t)blockIdx.x * FUSED_WAVES + wid) * A.dfr_cap;
+    uint32_t n_dfr = 0, dfr_pos = 0; bool draining = false;
+    // a run of n_adj samples covers s + (n_adj - 1) * stride >= k bases; its samples lie in one 16-byte piece of the recording lane
+    const uint32_t n_adj = (uint32_t)((S.k - S.s + S.stride - 1) / S.stride) + 1;
+    const uint32_t run_span = (uint32_t)S.s + (n_adj - 1) * (uint32_t)S.stride;
+    uint32_t run_ok = 0;                              // bits whose sample has n_adj - 1 successors inside its piece
+    {
+        constexpr int SPP = 4 * SPW;                  // samples per piece
+        for (int i = 0; i < NSAMP; i++) if ((uint32_t)(i % SPP) + n_adj <= (uint32_t)SPP) run_ok |= 1u << (NSAMP - 1 - i);
+    }
     uint32_t pend_old = 0, pend_bit = 0;              // sample mode: result of the last pass-bit atomic, looked at one round later
     uint32_t tot_pass = 0, tot_cand = 0, spins = 0;
     auto off_of = [&](int idx) -> uint32_t {          // offset (bases, inside its chunk) of sample idx of the recording lane
@@ -1045,6 +1065,9 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
         const uint64_t idle = __ballot(m == 0);
         if (idle && !flush) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
+            // a round costs the wave the same whether four lanes work or sixty-four, so a finisher that still has busy
+            // lanes tops up only once a fair number are idle (the rings buffer the records meanwhile)
+            const bool top_up = n_idle == 64 || n_idle >= A.refill_min;
             const uint32_t ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const bool is_idle = m == 0;
             uint32_t n_take = 0; unsigned long long rec = 0;
@@ -1058,6 +1081,9 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
                 for (int o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
                 const uint32_t total = __shfl(incl, 15);
                 n_take = total < n_idle ? total : n_idle;
+                // ... and an idle finisher waits until a batch has gathered, unless the stream is over or a ring is filling up
+                const uint32_t fullest = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(__ballot(avail >= RING / 2)));
+                if (!(top_up && (n_take >= A.refill_min || (n_take == total && done == n_stream) || fullest))) n_take = 0;
                 finished = done == n_stream && total == 0;
                 if (n_take) {
                     int lo = 0, hi = 15;                       // smallest ring lane whose inclusive count exceeds this lane's ordinal
@@ -1079,16 +1105,18 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
             }
             if (is_idle && ord < n_take) {
                 m = (uint32_t)(rec >> 32);
-                lone = __popc(m) == 1;
                 rtid = (uint32_t)rec & 1023u;
                 cb = (uint64_t)((uint32_t)rec >> 10) * ((uint64_t)chunk_vec * 64);
                 if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
-                passed_r = ~0ULL;
+                passed_r = passed_r2 = ~0ULL;
+                runs = m & run_ok;                             // bit B (sample i) starts a run iff bits B, B-1, ..., B-(n_adj-1) are set
+                for (uint32_t j = 1; j < n_adj; j++) runs &= m << j;
             }
         }
         if (A.dbg) tm_refill += wall_clock64() - tq0;
         if (!flush && !__ballot(m != 0)) {                     // no lane has anything to do
             if (ncand) flush = true;                           // claim mode, idle: count what is waiting
+            else if (finished && dfr_pos < n_dfr) draining = true;      // sample mode: the parked sixteen-window items, 64 a round
             else if (finished) break;
             else {                                             // a finisher ahead of the stream
                 __builtin_amdgcn_s_sleep(8);
@@ -1097,6 +1125,32 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
             }
         }
         spins = 0;
+        if (draining) {
+            __threadfence_block();                             // own parked entries are read back
+            const uint32_t n_take = n_dfr - dfr_pos < 64 ? n_dfr - dfr_pos : 64;
+            bool act = (uint32_t)lane < n_take;
+            uint64_t g0 = 0, r = ~0ULL, b0 = 0, len = 0;
+            if (act) {
+                g0 = my_dfr[dfr_pos + lane];
+                r = read_holding(R, g0, (uint32_t)S.s);
+                act = r != ~0ULL;
+            }
+            if (act) {
+                if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; } else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
+                const uint32_t bw = __hip_atomic_load(&A.bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((bw >> (r & 31)) & 1u) act = false;        // passed meanwhile
+            }
+            dfr_pos += n_take;
+            const uint64_t own_lo = g0 + 1 > (uint64_t)S.stride ? g0 + 1 - S.stride : 0;
+            const uint64_t p0 = own_lo > b0 ? own_lo - b0 : 0;
+            const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
+            if (sample_item<KW>(R, S, kb2, kb_shift, act && p0 < n_pos, r, b0, n_pos, p0)) {
+                const uint32_t bitm = 1u << (r & 31);
+                if (!(atomicOr(&A.bits[r >> 5], bitm) & bitm)) tot_pass++;
+            }
+            draining = false;
+            continue;
+        }
         // (3) claim mode: exact count of the candidates in the lanes
         if (flush) {
             const bool owner = (uint32_t)lane < ncand;
@@ -1121,51 +1175,87 @@ fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
             continue;
         }
         if (sample_mode) {
-            // (4a) one round: every lane takes its record's next positive whose read has not passed yet
+            // (4a) one round.  Exact counting of a positive's sixteen windows is dear (~900 instructions a round for the
+            // wave, whoever needs it), and nearly every positive can be settled for a tenth of that:
+            //  RUN     a bait read shows as runs of neighbouring positives; a run of n_adj samples spans k bases, and the
+            //          window of k bases at its first sample is almost surely a bait k-mer: ONE canonical key, ONE table
+            //          probe.  Runs are tried first; a hit passes the read and its other positives are skipped.
+            //  ISOLATED  what is left (mostly stage-1 false positives) is looked up in the exact s-mer table; only a true
+            //          bait s-mer goes on to the sixteen-window item, and only then does the wave run that code.
             const uint64_t tq1 = A.dbg ? wall_clock64() : 0;
-            bool got = false; uint64_t r = 0, g0 = 0, b0 = 0, len = 0;
+            bool got = false, is_run = false; uint64_t r = 0, g0 = 0, b0 = 0, len = 0; uint32_t sj = 0;
             if (fast) {
                 while (m) {
-                    const int bit = 31 - __clz(m);
-                    m &= ~(1u << bit);
-                    const uint32_t off = off_of(NSAMP - 1 - bit);
+                    const bool from_runs = (m & runs) != 0;                // run starts first, in stream order
+                    const int bit = 31 - __clz(from_runs ? (m & runs) : m);
+                    if (from_runs) runs &= ~(1u << bit); else m &= ~(1u << bit);
+                    const int idx = NSAMP - 1 - bit;
+                    const uint32_t off = off_of(idx);
                     const uint32_t t = rrem + off;
                     const uint32_t dq = __umulhi(t, R.len_magic32);
                     const uint32_t offr = t - dq * R.uniform_len;
-                    // straddles two reads / lies in the padding behind the last read: not a sample of any read
-                    if (offr + (uint32_t)S.s > R.uniform_len || cb + off + S.s > R.total_bases) continue;
+                    const uint32_t span = from_runs ? run_span : (uint32_t)S.s;         // bases that have to lie inside one read
+                    // straddles two reads / lies in the padding behind the last read: not a sample (or run) of any read
+                    if (offr + span > R.uniform_len || cb + off + span > R.total_bases) continue;
                     r = rq + dq;
-                    if (r == passed_r) continue;
-                    got = true; g0 = cb + off; b0 = g0 - offr; len = R.uniform_len;
+                    if (r == passed_r || r == passed_r2) continue;
+                    got = true; is_run = from_runs; g0 = cb + off; b0 = g0 - offr; len = R.uniform_len; sj = (uint32_t)(idx % SPW);
                     break;
                 }
-            } else if (m) {
+            } else if (m) {                                                // ragged reads: every positive on its own
                 const int bit = 31 - __clz(m);
                 m &= ~(1u << bit);
-                g0 = cb + off_of(NSAMP - 1 - bit);
+                const int idx = NSAMP - 1 - bit;
+                g0 = cb + off_of(idx); sj = (uint32_t)(idx % SPW);
                 r = read_holding(R, g0, (uint32_t)S.s);
-                got = r != ~0ULL && r != passed_r;
+                got = r != ~0ULL && r != passed_r && r != passed_r2;
                 if (got) { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
             }
             const uint32_t po = pend_old, pb = pend_bit;          // looked at after this round's loads: never waited for on its own
             pend_bit = 0;
-            // the windows this sample owns start at g0 - stride + 1 .. g0; the item tests 16 positions from the first
-            // of them that lies inside the read (positions past g0 belong to the next sample: harmless for threshold 1)
-            const uint64_t own_lo = g0 + 1 > (uint64_t)S.stride ? g0 + 1 - S.stride : 0;
-            const uint64_t p0 = own_lo > b0 ? own_lo - b0 : 0;
-            const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
-            const bool act = got && p0 < n_pos;
             const uint64_t tq2 = A.dbg ? wall_clock64() : 0;
             if (A.dbg) tm_pick += tq2 - tq1;
-            if (sample_item<KW>(R, S, kb2, kb_shift, act, r, b0, n_pos, p0, lone, (uint32_t)(g0 - (b0 + p0)), st2, st2_shift)) {
-                passed_r = r;
+            bool hit = false, full = false;
+            if (got) {
+                const uint32_t hn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
+                if (is_run && !hn) {
+                    hit = table_contains(S, canonical_at<KW>(R.words, g0, k));
+                } else if (!is_run) {
+                    // another lane (or wave) may have passed this read meanwhile: a device-coherent look at its bit
+                    const uint32_t bw = __hip_atomic_load(&A.bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t wi = g0 >> 4;
+                    uint32_t sm = R.words[wi];
+                    if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * sj);
+                    sm &= smask;
+                    if ((bw >> (r & 31)) & 1u) { passed_r2 = passed_r; passed_r = r; }
+                    else full = stab_contains(S, sm);            // a true bait s-mer (either strand): its windows are counted
+                }                                                // (a run in a read with invalid bases: its positives come back as isolated ones)
+            }
+            // park the sixteen-window items; if the list is full (never, in practice) they are counted right here
+            const uint64_t fm = __ballot(full);
+            bool now = false;
+            if (fm) {
+                const uint32_t nf = (uint32_t)__popcll(fm);
+                if (n_dfr + nf <= A.dfr_cap) {
+                    if (full) my_dfr[n_dfr + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = g0;
+                    n_dfr += nf;
+                } else now = true;
+            }
+            if (now) {
+                const uint64_t own_lo = g0 + 1 > (uint64_t)S.stride ? g0 + 1 - S.stride : 0;
+                const uint64_t p0 = own_lo > b0 ? own_lo - b0 : 0;
+                const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
+                hit |= sample_item<KW>(R, S, kb2, kb_shift, full && p0 < n_pos, r, b0, n_pos, p0);
+            }
+            if (hit) {
+                passed_r2 = passed_r; passed_r = r;
                 pend_bit = 1u << (r & 31);
                 pend_old = atomicOr(&A.bits[r >> 5], pend_bit);           // first setter of the bit counts the pass (next round)
             }
-            tot_cand += act;
+            tot_cand += got;
             if (A.dbg) { const uint64_t tq3 = wall_clock64(); tm_item += tq3 - tq2; }
             if (pb && !(po & pb)) tot_pass++;
-            if (A.dbg) { n_rounds++; tm_mark += (uint64_t)__popcll(__ballot(act)); }
+            if (A.dbg) { n_rounds++; tm_mark += (uint64_t)__popcll(__ballot(got)); }
             continue;
         }
         // (4b) claim mode, one round: every lane takes the next read its record has positives in
@@ -1607,7 +1697,7 @@ static uint32_t fused_stream_waves()
     static const uint32_t n = [] {
         const char *v = getenv("MF_STREAM_WAVES");
         uint32_t w = v && *v ? (uint32_t)atoi(v) : 14u;
-        return w < 4 ? 4u : (w > FUSED_WAVES - 1 ? (uint32_t)FUSED_WAVES - 1 : w);
+        return w < 4 ? 4u : (w > FUSED_WAVES ? (uint32_t)FUSED_WAVES : w);       // 16: no finisher waves, every wave finishes its own records after the stream
     }();
     return n;
 }
@@ -1640,7 +1730,8 @@ hipError_t launch_fused(const ReadsView &R, const KmerSetView &S, const FusedGeo
     FusedArgs A{};
     A.cand = B.cand; A.bits = B.bits; A.cand_other = reinterpret_cast<uint4 *>(B.cand_other); A.bits_other = reinterpret_cast<uint4 *>(B.bits_other);
     A.bitmap_vec4 = B.bitmap_vec4; A.ovf = B.ovf; A.ovf_cap = (uint32_t)G.ovf_cap; A.n_chunks = (uint32_t)G.n_chunks; A.n_stream = G.n_stream;
-    A.thr = thr; A.count_all = count_all ? 1u : 0u; A.hits_out = B.hits_out; A.partials = B.partials; A.flags = B.flags; A.dbg = B.dbg;
+    A.thr = thr; A.count_all = count_all ? 1u : 0u; A.hits_out = B.hits_out; A.partials = B.partials; A.flags = B.flags; A.dbg = B.dbg; A.dfr = B.dfr; A.dfr_cap = B.dfr_cap;
+    { static const uint32_t rm = getenv("MF_REFILL_MIN") ? (uint32_t)atoi(getenv("MF_REFILL_MIN")) : 32u; A.refill_min = rm < 1 ? 1 : (rm > 64 ? 64 : rm); }
     const size_t lds = fused_lds_bytes(S);
 #define MF_LAUNCH_FUSED(SPW, MASKED, KW) do { \
         raise_lds_limit_once<&fused_kernel<SPW, SCREEN_U, MASKED, KW>>(160 * 1024); \
