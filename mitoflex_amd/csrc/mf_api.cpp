@@ -38,7 +38,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // --------------------------------------------------------------- device ctx
-struct DevCtx { int device = -1; hipStream_t stream = nullptr; int n_cu = 0; };
+struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr; int n_cu = 0; };    // stream2: finish kernels of pipelined passes
 static std::mutex g_ctx_mu;
 static std::map<int, DevCtx> g_ctx;
 
@@ -58,6 +58,11 @@ static int get_ctx(int device, DevCtx **out)
     HIPCHK(hipSetDevice(device));
     DevCtx c; c.device = device; c.n_cu = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    {   // the second stream carries the short, latency-bound finish kernels that run under the next screen kernel: highest priority
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
+    }
     g_ctx[device] = c;
     *out = &g_ctx[device];
     return MF_OK;
@@ -370,28 +375,27 @@ struct mf_reads {
     ReadsView v{};
     uint32_t *d_words = nullptr; uint64_t *d_offsets = nullptr, *d_npos = nullptr;
     uint32_t *d_has_n = nullptr, *d_hits = nullptr, *d_npos_blk = nullptr;
-    // Candidate and result bitmaps exist twice.  A fused pass needs both of its pair clean on entry, sets bits with
-    // atomics and clears the other pair for the pass after it; the split and exhaustive paths need a clean candidate
-    // bitmap, leave it clean and overwrite every result word.  `cur` is the pair holding the latest result.
-    uint32_t *d_cand[2] = {nullptr, nullptr}, *d_bits[2] = {nullptr, nullptr};
-    bool cand_clean[2] = {false, false}, bits_clean[2] = {false, false};
+    // Threshold-1 passes (screen_kernel + finish_kernel) are pipelined: the finish kernel of pass i runs on a second stream
+    // under the screen kernel of pass i + 1, the way consecutive batches of a file do.  What a pass writes therefore
+    // exists twice and alternates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.
+    uint32_t *d_cand = nullptr, *d_bits[2] = {nullptr, nullptr};
+    void *d_recs[2] = {nullptr, nullptr}; uint32_t *d_rec_counts[2] = {nullptr, nullptr};     // stage-1 positive records (screen -> finish / mark)
+    unsigned long long *d_counters[2] = {nullptr, nullptr};                                    // 2 * EXACT_MAX_GRID tally pairs each
+    hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_finish[2] = {nullptr, nullptr};           // ordering between the two streams
+    bool cand_clean = false, sample_pass = false;     // sample_pass: the latest pass was a screen + finish + park one
     int cur = 0;
-    void *d_recs = nullptr; uint32_t *d_rec_counts = nullptr;     // split path: stage-1 positive records (screen -> mark)
-    unsigned long long *d_ovf = nullptr;                          // fused path: ring-overflow records
-    unsigned long long *d_dfr = nullptr;                          // fused path: parked sixteen-window items (FUSED_DFR_CAP per wave)
-    unsigned long long *d_dbg = nullptr;                          // MF_FUSED_DEBUG: per-wave timestamps of the last fused pass
-    FusedGeom fgeom{};
-    unsigned long long *d_counters = nullptr;
     size_t bitmap_bytes = 0;
     // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
-    size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0, cap_ovf = 0, cap_npos_blk = 0, cap_dfr = 0;
+    size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0, cap_npos_blk = 0;
 };
 
-// MF_PASS=split selects the three-kernel pass (screen, mark, exact) instead of the fused one
-static bool use_fused_pass()
+// How a screened pass is run.  Default: screen_kernel, then finish_kernel when the threshold is 1 and no hit counts are wanted
+// (mark_kernel + exact_kernel otherwise).  MF_PASS=split: always screen, mark, exact.  MF_PASS=serial: screen + finish
+// without overlapping consecutive passes (for comparison).
+static int pass_kind()
 {
-    static const bool fused = [] { const char *v = getenv("MF_PASS"); return !(v && strcmp(v, "split") == 0); }();
-    return fused;
+    static const int kind = [] { const char *v = getenv("MF_PASS"); return v && strcmp(v, "split") == 0 ? 1 : (v && strcmp(v, "serial") == 0 ? 2 : 0); }();
+    return kind;
 }
 
 static void reads_release(mf_reads *r)
@@ -399,9 +403,13 @@ static void reads_release(mf_reads *r)
     if (!r) return;
     if (hipSetDevice(r->device) == hipSuccess) {
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
-        for (int i = 0; i < 2; i++) { hipFree(r->d_cand[i]); hipFree(r->d_bits[i]); }
-        hipFree(r->d_hits); hipFree(r->d_counters); hipFree(r->d_npos_blk);
-        hipFree(r->d_recs); hipFree(r->d_rec_counts); hipFree(r->d_ovf); hipFree(r->d_dfr); hipFree(r->d_dbg);
+        hipFree(r->d_cand);
+        for (int i = 0; i < 2; i++) {
+            hipFree(r->d_bits[i]); hipFree(r->d_recs[i]); hipFree(r->d_rec_counts[i]); hipFree(r->d_counters[i]);
+            if (r->ev_screen[i]) hipEventDestroy(r->ev_screen[i]);
+            if (r->ev_finish[i]) hipEventDestroy(r->ev_finish[i]);
+        }
+        hipFree(r->d_hits); hipFree(r->d_npos_blk);
     }
     delete r;
 }
@@ -425,8 +433,7 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
 {
     hipStream_t st = ctx->stream;
     const uint64_t padded = padded_words_for(n_words);
-    const FusedGeom fg = fused_geom_for(n_words, ctx->n_cu);
-    const uint64_t dev_words = padded > fg.words_needed ? padded : fg.words_needed;      // readable and zero past the data
+    const uint64_t dev_words = padded;                                                   // readable and zero past the data
 #define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(MF_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
     RCHK(dev_reserve(r->d_words, r->cap_words, dev_words * 4, reuse));
     {
@@ -445,24 +452,26 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     RCHK(dev_reserve(r->d_npos_blk, r->cap_npos_blk, n_blk * 4, reuse));
     RCHK(launch_build_npos_blk(r->d_npos, n_npos, n_blk, r->d_npos_blk, st));
     r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;
-    if (r->bitmap_bytes > r->cap_bitmap || !r->d_has_n) {     // the five bitmaps share one capacity
-        size_t c[5] = {0, 0, 0, 0, 0};
-        uint32_t **bm[5] = {&r->d_has_n, &r->d_cand[0], &r->d_cand[1], &r->d_bits[0], &r->d_bits[1]};
+    if (r->bitmap_bytes > r->cap_bitmap || !r->d_has_n) {     // the four bitmaps share one capacity
+        size_t c[4] = {0, 0, 0, 0};
+        uint32_t **bm[4] = {&r->d_has_n, &r->d_cand, &r->d_bits[0], &r->d_bits[1]};
         size_t least = ~(size_t)0;
-        for (int i = 0; i < 5; i++) {
+        for (int i = 0; i < 4; i++) {
             if (*bm[i]) { hipFree(*bm[i]); *bm[i] = nullptr; }
             RCHK(dev_reserve(*bm[i], c[i], r->bitmap_bytes, reuse));
             if (c[i] < least) least = c[i];
         }
         r->cap_bitmap = least;
     }
-    if (!r->d_counters) RCHK(hipMalloc(&r->d_counters, EXACT_MAX_GRID * 16));
     RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
-    RCHK(hipMemsetAsync(r->d_counters, 0, EXACT_MAX_GRID * 16, st));
+    RCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
+    r->cand_clean = true;
     for (int i = 0; i < 2; i++) {
-        RCHK(hipMemsetAsync(r->d_cand[i], 0, r->bitmap_bytes, st));
+        if (!r->d_counters[i]) RCHK(hipMalloc(&r->d_counters[i], 2 * EXACT_MAX_GRID * 16));
+        RCHK(hipMemsetAsync(r->d_counters[i], 0, 2 * EXACT_MAX_GRID * 16, st));
         RCHK(hipMemsetAsync(r->d_bits[i], 0, r->bitmap_bytes, st));
-        r->cand_clean[i] = r->bits_clean[i] = true;
+        if (!r->ev_screen[i]) RCHK(hipEventCreateWithFlags(&r->ev_screen[i], hipEventDisableTiming));
+        if (!r->ev_finish[i]) RCHK(hipEventCreateWithFlags(&r->ev_finish[i], hipEventDisableTiming));
     }
     r->cur = 0;
     ReadsView &V = r->v;
@@ -472,16 +481,16 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     V.len_magic = uniform_len > 1 ? ~0ULL / uniform_len + 1 : 0;
     V.len_magic32 = (uniform_len > 1 && uniform_len <= 4096) ? 0xFFFFFFFFu / uniform_len + 1 : 0;
     V.npos = r->d_npos; V.n_npos = n_npos; V.npos_blk = r->d_npos_blk; V.has_n = r->d_has_n;
-    r->fgeom = fg;
-    if (use_fused_pass() && fg.ok) {
-        // ring-overflow lists: worst case one 8-byte record per lane per chunk (an eighth of the packed stream); normally unused
-        const uint64_t n = fg.grid * fg.n_stream * fg.ovf_cap;
-        RCHK(dev_reserve(r->d_ovf, r->cap_ovf, (n ? n : 1) * 8, reuse));
-        RCHK(dev_reserve(r->d_dfr, r->cap_dfr, (fg.grid ? fg.grid : 1) * 16 * FUSED_DFR_CAP * 8, reuse));
-    } else {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %
+    {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %.  The second
+        // list is only needed by pipelined threshold-1 passes and is allocated on first use (enqueue_pass).
         const uint64_t grid = screen_grid_for(V, ctx->n_cu), cap = screen_rec_cap_for(V, ctx->n_cu);
-        RCHK(dev_reserve(r->d_recs, r->cap_recs, (grid * cap ? grid * cap : 1) * 16, reuse));
-        RCHK(dev_reserve(r->d_rec_counts, r->cap_rec_counts, (grid ? grid : 1) * 4, reuse));
+        size_t c0 = r->cap_recs, c1 = r->cap_rec_counts;
+        RCHK(dev_reserve(r->d_recs[0], c0, (grid * cap ? grid * cap : 1) * 16, reuse));
+        RCHK(dev_reserve(r->d_rec_counts[0], c1, (grid ? grid : 1) * 4, reuse));
+        if (r->d_recs[1] && (c0 != r->cap_recs || c1 != r->cap_rec_counts)) {   // grown: the twin follows on its next use
+            hipFree(r->d_recs[1]); hipFree(r->d_rec_counts[1]); r->d_recs[1] = nullptr; r->d_rec_counts[1] = nullptr;
+        }
+        r->cap_recs = c0; r->cap_rec_counts = c1;
     }
     RCHK(launch_mark_has_n(V, r->d_has_n, st));
     RCHK(hipStreamSynchronize(st));
@@ -581,48 +590,50 @@ int mf_reads_free(mf_reads *r) { reads_release(r); return MF_OK; }
 // ------------------------------------------------------------------- filter
 static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_bases + 7) / 8 + (V.n_reads + 7) / 8; }
 
-// enqueue one pass on `st`.  ev (when non-null) holds six events that are attached to the three kernels themselves
-// (start/stop of screen, mark, exact): each pair reads that dispatch's own duration and the stream carries no extra packets.
-static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, int n_cu,
-                        hipStream_t st, hipEvent_t *ev)
+// enqueue one pass.  ev (when non-null) holds six events that are attached to the kernels themselves (start/stop of
+// screen, mark, exact or finish): each pair reads that dispatch's own duration and the streams carry no extra packets.
+// `overlap`: a threshold-1 pass may leave its finish kernel running on the second stream (filter_common joins the streams).
+static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, DevCtx *ctx, hipEvent_t *ev, bool overlap,
+                        bool force_split = false)   // (force_split: reserved for callers that want the three-kernel pass)
 {
+    r->sample_pass = false;
+    hipStream_t st = ctx->stream;
+    const int n_cu = ctx->n_cu;
     KernelTiming tm[3]; const KernelTiming *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;
     if (ev) { for (int i = 0; i < 3; i++) tm[i] = KernelTiming{ev[2 * i], ev[2 * i + 1]}; t0 = &tm[0]; t1 = &tm[1]; t2 = &tm[2]; }
     const int p = r->cur;
     if (S.prot) {          // protein-space set: one kernel translates and probes every read (no screen exists in residue space)
-        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters, n_cu, st, t2));
-        r->bits_clean[p] = false;
+        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters[p], n_cu, st, t2));
         return MF_OK;
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
-    if (screened && use_fused_pass() && r->fgeom.ok && r->d_ovf) {
-        // one launch: stream + finish.  It works on the pair the last pass left clean and cleans the other one.
-        const int q = (r->cand_clean[p] && r->bits_clean[p]) ? p : 1 - p;
-        if (!r->cand_clean[q]) HIPCHK(hipMemsetAsync(r->d_cand[q], 0, r->bitmap_bytes, st));      // only after a change of mode
-        if (!r->bits_clean[q]) HIPCHK(hipMemsetAsync(r->d_bits[q], 0, r->bitmap_bytes, st));
-        FusedBuffers B{};
-        B.cand = r->d_cand[q]; B.bits = r->d_bits[q]; B.cand_other = r->d_cand[1 - q]; B.bits_other = r->d_bits[1 - q];
-        B.bitmap_vec4 = ((r->v.n_reads + 31) / 32 + 3) / 4; B.ovf = r->d_ovf; B.dfr = r->d_dfr; B.dfr_cap = FUSED_DFR_CAP; B.hits_out = r->d_hits; B.partials = r->d_counters;
-        static const bool dbg_on = getenv("MF_FUSED_DEBUG") != nullptr, drop = getenv("MF_FUSED_DROP") != nullptr;
-        B.flags = drop ? 1u : 0u;
-        if (dbg_on) {
-            if (!r->d_dbg) HIPCHK(hipMalloc(&r->d_dbg, r->fgeom.grid * 16 * 4 * 8 + 8));
-            B.dbg = r->d_dbg;
+    if (screened && pass_kind() != 1 && !force_split && thr == 1 && !count_all) {
+        // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
+        // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
+        // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
+        const int q = 1 - p;
+        if (!r->d_recs[q]) {
+            size_t c0 = 0, c1 = 0;
+            HIPCHK(dev_reserve(r->d_recs[q], c0, r->cap_recs, false));
+            HIPCHK(dev_reserve(r->d_rec_counts[q], c1, r->cap_rec_counts, false));
         }
-        HIPCHK(launch_fused(r->v, S, r->fgeom, B, thr, count_all, st, t0));
-        r->cand_clean[q] = r->bits_clean[q] = false;
-        r->cand_clean[1 - q] = r->bits_clean[1 - q] = true;
+        const bool two = overlap && pass_kind() == 0;
+        hipStream_t sf = two ? ctx->stream2 : st;
+        if (two) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[q], 0));           // the finish kernel of two passes ago read this set
+        HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, st, t0, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
+        if (two) { HIPCHK(hipEventRecord(r->ev_screen[q], st)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
+        HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], r->d_counters[q], n_cu, sf, t2));
+        r->sample_pass = true;
+        if (two) HIPCHK(hipEventRecord(r->ev_finish[q], sf));
         r->cur = q;
         return MF_OK;
     }
-    // split / exhaustive: no per-pass memsets either -- the exact kernel clears the candidate words it consumes,
-    // writes every result word and zeroes unused tally slots
-    if (screened && !r->cand_clean[p]) { HIPCHK(hipMemsetAsync(r->d_cand[p], 0, r->bitmap_bytes, st)); r->cand_clean[p] = true; }
-    if (screened && !r->d_recs) return fail(MF_E_ARG, "read set was prepared for the fused pass only");
-    if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs, r->d_rec_counts, n_cu, st, t0));
-    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs, r->d_rec_counts, r->d_cand[p], n_cu, st, t1));
-    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand[p] : nullptr, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters, n_cu, st, t2));
-    r->bits_clean[p] = false;
+    // split / exhaustive: no per-pass memsets -- the exact kernel clears the candidate words it consumes, writes every
+    // result word and zeroes unused tally slots
+    if (screened && !r->cand_clean) { HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st)); r->cand_clean = true; }
+    if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs[0], r->d_rec_counts[0], n_cu, st, t0));
+    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs[0], r->d_rec_counts[0], r->d_cand, n_cu, st, t1));
+    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters[p], n_cu, st, t2));
     return MF_OK;
 }
 
@@ -654,50 +665,21 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     const hipEvent_t e_begin = ev[(size_t)n_sampled * 6], e_end = ev[(size_t)n_sampled * 6 + 1];
     HIPCHK(hipEventRecord(e_begin, st));
     for (int i = 0; i < steps; i++) {
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx->n_cu, st, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true);
         if (rc) return rc;
     }
+    // join: finish kernels still running on the second stream belong to this call (unrecorded events are no-ops)
+    HIPCHK(hipStreamWaitEvent(st, r->ev_finish[0], 0));
+    HIPCHK(hipStreamWaitEvent(st, r->ev_finish[1], 0));
     HIPCHK(hipEventRecord(e_end, st));
-    std::vector<unsigned long long> part(EXACT_MAX_GRID * 2, 0);
-    HIPCHK(hipMemcpyAsync(part.data(), r->d_counters, EXACT_MAX_GRID * 16, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> part(EXACT_MAX_GRID * 4, 0);
+    const bool two_halves = r->sample_pass;
+    HIPCHK(hipMemcpyAsync(part.data(), r->d_counters[r->cur], (two_halves ? 2 : 1) * EXACT_MAX_GRID * 16, hipMemcpyDeviceToHost, st));
     if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits[r->cur], ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
     if (hits_out && r->v.n_reads) HIPCHK(hipMemcpyAsync(hits_out, r->d_hits, r->v.n_reads * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (r->d_dbg) {          // MF_FUSED_DEBUG: where the time of the last fused pass went, per wave role
-        const size_t n = r->fgeom.grid * 16;
-        std::vector<unsigned long long> d(n * 4);
-        HIPCHK(hipMemcpy(d.data(), r->d_dbg, n * 32, hipMemcpyDeviceToHost));
-        double se_max = 0, se_sum = 0, ex_max = 0, exs_sum = 0, exf_sum = 0; unsigned long long ring = 0, ovf = 0, rounds = 0; size_t ns = 0, nf = 0;
-        double f_refill = 0, f_pick = 0, f_item = 0, f_lanes = 0;
-        for (size_t i = 0; i < n; i++) {
-            const bool streamer = (i % 16) < r->fgeom.n_stream;
-            const double ex = d[4 * i + 1] * 0.01;          // 100 MHz ticks -> us
-            if (streamer) { const double se = d[4 * i] * 0.01; ns++; se_sum += se; if (se > se_max) se_max = se; exs_sum += ex; ring += d[4 * i + 2]; ovf += d[4 * i + 3]; }
-            else {
-                nf++; exf_sum += ex; rounds += d[4 * i + 3];
-                f_refill += (d[4 * i] & 0xFFFFFFFFull) * 0.01; f_pick += (d[4 * i] >> 32) * 0.01;
-                f_item += (d[4 * i + 2] & 0xFFFFFFFFull) * 0.01; f_lanes += (double)(d[4 * i + 2] >> 32);
-            }
-            if (ex > ex_max) ex_max = ex;
-        }
-        {
-            double xs[8] = {0}; size_t xn[8] = {0};
-            for (size_t i = 0; i < n; i++) if ((i % 16) < r->fgeom.n_stream) { xs[(i / 16) % 8] += d[4 * i] * 0.01; xn[(i / 16) % 8]++; }
-            fprintf(stderr, "[mf fused] stream end by workgroup %% 8:");
-            for (int x = 0; x < 8; x++) fprintf(stderr, " %.1f", xs[x] / (xn[x] ? xn[x] : 1));
-            fprintf(stderr, " us\n");
-        }
-        fprintf(stderr, "[mf fused] stream end avg %.1f max %.1f us | streaming-wave exit avg %.1f, finisher exit avg %.1f, last exit %.1f us | records: ring %llu overflow %llu | finisher rounds/wave %.1f\n",
-                se_sum / (ns ? ns : 1), se_max, exs_sum / (ns ? ns : 1), exf_sum / (nf ? nf : 1), ex_max, ring, ovf, (double)rounds / (nf ? nf : 1));
-        if (rounds) fprintf(stderr, "[mf fused] finisher per round: refill %.2f us, pick %.2f us, item %.2f us, %.1f lanes with an item\n",
-                            f_refill / rounds, f_pick / rounds, f_item / rounds, f_lanes / rounds);
-    }
     unsigned long long cnt[2] = {0, 0};
-    const bool fused_ran = !T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && use_fused_pass() && r->fgeom.ok && r->d_ovf;
-    if (fused_ran && part[2 * EXACT_MAX_GRID - 1]) return fail(MF_E_HIP, "fused pass: a finisher wave gave up waiting for the stream (watchdog)");
-    // the fused kernel stores one tally pair per workgroup it ran with; the other kernels keep every unused slot at zero
-    const int n_part = fused_ran ? (int)r->fgeom.grid : EXACT_MAX_GRID;
-    for (int i = 0; i < n_part; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
+    for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         float tot = 0, scr = 0, mrk = 0, exa = 0, t;

@@ -60,6 +60,14 @@ MF_HD uint32_t bloom_hash(uint32_t smer) { return (smer & 0xFFFFFFu) * 0x9E3779u
 // give 0.11 %, bytes of h alone 0.19 %.  The kernel tests a bit by shifting the dword LEFT by field_i -- the bit lands in
 // the sign position -- with the field taken straight from its byte through an SDWA operand selector.
 constexpr uint32_t STAGE1_MIX_SHIFT = 11;
+// stage-1 block size.  128-bit blocks (ds_read_b128, one tested bit per dword: 0.059 % false positives on the synthetic
+// mitogenome) or 64-bit blocks (ds_read_b64, two tested bits per dword: 0.104 %, half the LDS bytes per sample -- a random
+// 16-byte read per lane runs into ~3-way bank conflicts, and at 128 bytes a clock that made LDS, not HBM, the pacing
+// resource of the screen).
+#ifndef MF_STAGE1_B64
+#define MF_STAGE1_B64 0
+#endif
+constexpr int STAGE1_BLOCK_DWORDS = MF_STAGE1_B64 ? 2 : 4;
 MF_HD uint32_t stage1_mix(uint32_t smer, uint32_t h) { return (smer >> STAGE1_MIX_SHIFT) | (h << (32 - STAGE1_MIX_SHIFT)); }
 MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return (stage1_mix(smer, h) >> (8 * i)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }

@@ -20,32 +20,15 @@ struct KernelTiming { hipEvent_t start, stop; };
 // screen = screen_kernel (records stage-1 positives) + mark_kernel (finishes them, sets candidate bits)
 uint64_t screen_grid_for(const ReadsView &R, int n_cu);
 uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu);          // 16-byte records per screen workgroup
+// clear (optional): a result bitmap of clear_vec4 uint4 that the screen zeroes on the side (for the pass after this one)
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
-                         const KernelTiming *tm = nullptr);
+                         const KernelTiming *tm = nullptr, uint32_t *clear = nullptr, uint64_t clear_vec4 = 0);
+// threshold 1, no hit counts: two launches of finish_kernel (runs, then the rest) settle every stage-1 record and set the pass
+// bits (bits must be clean).  partials: 2 * EXACT_MAX_GRID tally pairs (first half phase 0, second half phase 1).
+hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
+                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
                        hipStream_t st, const KernelTiming *tm = nullptr);
-// fused pass (screen + mark + exact in one launch): geometry of a read set and the buffers one pass works on
-struct FusedGeom {
-    uint32_t n_stream;          // streaming waves per workgroup (MF_STREAM_WAVES, default 14)
-    uint64_t chunk_vec;         // uint4 per chunk (n_stream x 64 x SCREEN_U)
-    uint64_t n_chunks, grid;
-    uint64_t ovf_cap;           // overflow records per streaming wave
-    uint64_t words_needed;      // device words the kernel may read (zero past the data)
-    bool ok;                    // false: the set is too large for the record format (fall back to the split path)
-};
-struct FusedBuffers {
-    uint32_t *cand, *bits, *cand_other, *bits_other;
-    uint64_t bitmap_vec4;
-    unsigned long long *ovf;
-    unsigned long long *dfr; uint32_t dfr_cap;     // parked sixteen-window items: [grid][16][dfr_cap]
-    uint32_t *hits_out;
-    unsigned long long *partials;
-    uint32_t flags;                 // debugging: bit 0 drops the stage-1 records (stream-only timing)
-    unsigned long long *dbg;        // debugging: per-wave timestamps and counts, or nullptr
-};
-FusedGeom fused_geom_for(uint64_t n_words, int n_cu);
-hipError_t launch_fused(const ReadsView &R, const KmerSetView &S, const FusedGeom &G, const FusedBuffers &B, uint32_t thr, bool count_all,
-                        hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st,
                         const KernelTiming *tm = nullptr);

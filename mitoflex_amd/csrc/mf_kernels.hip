@@ -124,7 +124,8 @@ struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pa
 // the low 2s bits of the word.
 template <int SPW, int U, bool MASKED>
 __global__ void __launch_bounds__(1024)
-screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts)
+screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
+              uint4 *__restrict__ clear, uint64_t clear_vec4)
 {
     extern __shared__ uint4 s_tab4[];                                       // stage-1 table, then the record counter
     const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
@@ -162,9 +163,15 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                 for (int j = 0; j < SPW; j++) {
                     const uint32_t sm = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
-                    const uint4 blk = s_tab4[h >> blk_shift];
                     const uint32_t g = alignbit(h, sm, STAGE1_MIX_SHIFT);   // stage1_mix
-                    const uint32_t t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.y) & lshl_by_byte<2>(g, blk.z) & lshl_by_byte<3>(g, blk.w);
+                    uint32_t t;
+                    if (MF_STAGE1_B64) {
+                        const uint2 blk = reinterpret_cast<const uint2 *>(s_tab4)[h >> (blk_shift - 1)];
+                        t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.x) & lshl_by_byte<2>(g, blk.y) & lshl_by_byte<3>(g, blk.y);
+                    } else {
+                        const uint4 blk = s_tab4[h >> blk_shift];
+                        t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.y) & lshl_by_byte<2>(g, blk.z) & lshl_by_byte<3>(g, blk.w);
+                    }
                     hitmask = alignbit(hitmask, t, 31);             // (hitmask << 1) | sign(t)
                 }
             }
@@ -181,17 +188,23 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     uint64_t c = blockIdx.x;
     if (c < n_chunks) load(c, a, ax);                  // the first chunk is already on its way while the table is staged
     {
+        // a threshold-1 pass sets its result bits with atomics: the bitmap of the pass after this one is cleared here
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < clear_vec4; i += cstep * blockDim.x) clear[i] = z;
         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
         if (threadIdx.x == 0) s_nrec = 0;
     }
     __syncthreads();
-    while (c < n_chunks) {
-        if (c + cstep < n_chunks) load(c + cstep, b, bx);
+    // The loads sit on unconditional paths (the last chunk is peeled), so the compiler's vmcnt counts are exact and
+    // examining a chunk never waits for the loads issued right before it.
+    if (c < n_chunks) for (;;) {
+        if (c + cstep >= n_chunks) { stage1(c, a, ax); break; }
+        load(c + cstep, b, bx);
         stage1(c, a, ax);
         c += cstep;
-        if (c >= n_chunks) break;
-        if (c + cstep < n_chunks) load(c + cstep, a, ax);
+        if (c + cstep >= n_chunks) { stage1(c, b, bx); break; }
+        load(c + cstep, a, ax);
         stage1(c, b, bx);
         c += cstep;
     }
@@ -701,25 +714,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
         for (uint32_t i = 2 * gridDim.x + threadIdx.x; i < 2 * EXACT_MAX_GRID; i += blockDim.x) partials[i] = 0;
 }
 
-// -------------------------------------------------------------- fused pass kernel
-// One launch per pass.  Every persistent 1024-thread workgroup (one per CU) splits its 16 waves into
-//   STREAMING waves (A.n_stream of them): walk the dense read stream in chunks of n_stream * 64 * U 16-byte
-//     non-temporal loads (workgroup b takes chunks b, b + grid, ...; the next chunk is in flight while this one is
-//     examined).  Every stream-aligned s-mer gets the stage-1 test in the LDS bit table; a lane with a positive pushes
-//     one 8-byte record {chunk, lane, hit mask} into the wave's own LDS ring (single producer: slots come from a
-//     ballot, no atomics; a full ring spills to a global overflow list);
-//   FINISHER waves (the rest): poll the rings while the stream is still running, 64 records per batch: group a
-//     record's positives by read, verify lone positives (stage 2 / 3), claim the read in the candidate bitmap
-//     (returning atomicOr: a read is claimed by exactly one lane of the whole grid), and count the claimed reads
-//     exactly (k-mer extract -> canonicalise -> LDS bit table -> open-address table in L2 -> threshold), 64
-//     candidates per run, the work items of a candidate dealt to the wave's lanes (run_candidates).
-// A finisher has its own vmcnt queue, so its dependent loads never stall a streaming wave, and its latency chains
-// run under the stream instead of behind it in two more launches.  When a streaming wave runs out of chunks it
-// turns into a finisher for its own overflow list.  No barrier after table staging, no cross-wave wait other than
-// the finishers polling LDS counters -- a streaming wave never waits for anybody.
-// Bitmaps are double buffered by pass parity: a pass finds its candidate and result bitmaps clean, sets bits with
-// atomics, and clears the other parity's pair for the next pass (no memset launches, no per-pass host work).
-// SAMPLE-mode work item of the fused pass: does one of the (<= 16) windows starting at read positions p0, p0 + 1, ...
+// Sixteen-window work item of the finish kernel: does one of the (<= 16) windows starting at read positions p0, p0 + 1, ...
 // hold a bait k-mer?  A finisher's round is a chain of memory round trips under a saturated memory system, so the
 // chain is kept at two: the window (and the read's has-N bit) -- then all sixteen k-mers go through the LDS bit table
 // and the open-address table probes of the positives are issued four at a time, together.
@@ -829,510 +824,170 @@ __device__ __forceinline__ bool sample_item(const ReadsView &R, const KmerSetVie
     return hit;
 }
 
-constexpr int FUSED_BLOCK = 1024;
-constexpr int FUSED_WAVES = FUSED_BLOCK / 64;
-constexpr int RING = 64;                         // records per streaming-wave ring
-constexpr uint32_t KBF_MAX_LOG2W = 12;           // k-mer bit table folded to <= 16 KiB of LDS
+// --------------------------------------------------------------- finish kernels
+// Second stage of a threshold-1 pass (no hit counts wanted): one thread per stage-1 record of screen_kernel.
+// A window of k bases that is a bait k-mer contains only true stage-1 positives, in particular the first stream-aligned
+// s-mer at or after its start -- call that sample its OWNER.  Every window inside a read belongs to exactly one sample
+// inside that read (the `stride` windows starting at g0 - stride + 1 .. g0), so a read passes iff some positive sample
+// owns a window that is in the bait set, and a pass is an idempotent atomicOr: no claim, no candidate bitmap.
+// Nearly every positive is settled cheaply, in two memory round trips, by two launches of this kernel:
+//  PHASE 0, RUNS      a bait read shows as runs of neighbouring positives; a run of n_adj samples spans k bases and the window of
+//                     k bases at its first sample is almost surely a bait k-mer: ONE canonical key, ONE table probe per record.
+//                     49 registers, no table in LDS: it runs on the second stream under the next pass's screen kernel, in the
+//                     registers and wave slots that one leaves free.
+//  PHASE 1, THE REST  every read a run has passed is known now (kernel boundary), so a record's remaining positives mostly
+//                     end at one look at their read's bit.  What is left (mostly stage-1 false positives) is looked up in the
+//                     exact s-mer table, and a true bait s-mer outside any run gets its sixteen windows counted (sample_item).
+constexpr int FINISH_BLOCK = 256;
+constexpr int FINISH_GRID = 1024;            // one tally pair per workgroup in the first half of the tally buffer
+static_assert(FINISH_GRID <= EXACT_MAX_GRID, "tally buffer");          // phase 1's pairs go to the second half
 
-struct FusedArgs {
-    uint32_t *cand, *bits;                       // this pass's candidate / result bitmaps (clean at entry)
-    uint4 *cand_other, *bits_other;              // the other parity's pair, cleared by this pass
-    uint64_t bitmap_vec4;                        // uint4 per bitmap to clear
-    unsigned long long *ovf;                     // overflow records: [grid][n_stream][ovf_cap]
-    uint32_t ovf_cap;
-    uint32_t n_chunks;                           // chunks of n_stream * 64 * U uint4 (buffer readable, zero past the data)
-    uint32_t n_stream;                           // streaming waves per workgroup
-    uint32_t thr, count_all;
-    uint32_t *hits_out;
-    unsigned long long *partials;                // [2 * grid] pass / candidate tallies; [2 * EXACT_MAX_GRID - 1] error flag
-    unsigned long long *dfr; uint32_t dfr_cap;   // deferred sixteen-window items: [grid][FUSED_WAVES][dfr_cap] first bases of samples
-    uint32_t refill_min;                         // a finisher tops its lanes up when this many are idle and as many records wait
-    uint32_t flags;                              // bit 0: drop the records (stream-only timing experiment, results are wrong)
-    unsigned long long *dbg;                     // optional [grid][FUSED_WAVES][4]: stream end, exit (10 ns ticks since kernel entry), records by ring, by overflow / rounds
-};
-
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+template <int SPW, int U, int KW, int PHASE>
+__global__ void __launch_bounds__(FINISH_BLOCK)
+finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint32_t rec_cap, const uint32_t *__restrict__ rec_counts,
+              uint32_t n_lists, uint32_t screen_block, uint32_t *__restrict__ bits, unsigned long long *__restrict__ partials)
 {
-    return ((uint64_t)__shfl((uint32_t)(v >> 32), src) << 32) | __shfl((uint32_t)v, src);
-}
-
-template <int SPW, int U, bool MASKED, int KW>
-__global__ void __launch_bounds__(FUSED_BLOCK)
-fused_kernel(ReadsView R, KmerSetView S, FusedArgs A)
-{
-    extern __shared__ uint4 s_mem4[];
-    const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
-    const uint32_t kbf_log2w = S.kb_log2w < KBF_MAX_LOG2W ? S.kb_log2w : KBF_MAX_LOG2W;
-    const uint32_t n_kb2 = 1u << (kbf_log2w - 1);                              // 64-bit blocks of the folded k-mer bit table
-    uint4 *s_tab4 = s_mem4;                                                    // stage-1 table
-    uint2 *s_kb2 = reinterpret_cast<uint2 *>(s_mem4 + nb4);
-    lds_u64 *s_ring = (lds_u64 *)(s_kb2 + n_kb2);                              // [FUSED_WAVES][RING]
-    lds_u32 *s_cnt = (lds_u32 *)(s_ring + FUSED_WAVES * RING);                 // [FUSED_WAVES][64]
-    lds_u32 *s_ctl = s_cnt + FUSED_WAVES * 64;                                 // 64 control words
-    lds_u32 *s_prod = s_ctl, *s_cons = s_ctl + 16;
-    lds_u32 *s_done = s_ctl + 32, *s_exit = s_ctl + 33, *s_tot = s_ctl + 34;
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint64_t t_entry = A.dbg ? wall_clock64() : 0;
-    uint64_t t_stream_end = 0; uint32_t n_rounds = 0;
-    uint64_t tm_refill = 0, tm_pick = 0, tm_item = 0, tm_mark = 0;      // debug: 10 ns ticks a finisher spent in each part of its rounds
-    const uint32_t n_stream = A.n_stream;
-    const bool streamer = (uint32_t)wid < n_stream;
-    const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
-    const uint32_t NST = n_stream * 64;                                        // streaming threads
-    const uint32_t chunk_vec = NST * U;                                        // uint4 per chunk
-    const uint32_t n_chunks = A.n_chunks;
-    const uint64_t cstep = gridDim.x;
-    const uint32_t blk_shift = 32 - (S.bloom_log2w - 2);
-    const uint32_t smask = S.smask;
-    constexpr int NSAMP = U * 4 * SPW;
-
-    // ---- streaming machinery (used by streaming waves only)
-    auto load = [&](uint32_t c, u32x4 (&d)[U], uint32_t (&x)[U]) {
+    __shared__ uint32_t s_pre[EXACT_MAX_GRID + 1];           // exclusive prefix of the record counts
+    __shared__ uint32_t s_tot[2];
+    {   // every thread sums the counts of four consecutive lists, a wave scan and a scan over the four waves do the rest
+        uint32_t c[4], sum = 0;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t v = (uint64_t)c * chunk_vec + (uint32_t)u * NST + threadIdx.x;
-            d[u] = __builtin_nontemporal_load(&w4[v]);
-            if (SPW == 2) x[u] = R.words[4 * v + 4];
-        }
-    };
-    lds_u64 *my_ring = s_ring + wid * RING;
-    unsigned long long *my_ovf = A.ovf + ((size_t)blockIdx.x * n_stream + (streamer ? wid : 0)) * A.ovf_cap;
-    uint32_t prod = 0, ovf_n = 0;
-    // Stage 1 on one chunk slice held in registers.  Per sample: one v_mad_u32_u24 (hash), one ds_read_b128 (the
-    // sample's 128-bit block), four left shifts that bring the tested bit of each dword into the sign position (shift
-    // amounts are bytes of (hash:s-mer) >> 11, picked by SDWA selectors), two three-input ANDs and one funnel shift that
-    // appends the sign bit to the hit mask.  The block reads of one 16-byte piece are issued together.
-    auto stage1 = [&](uint32_t c, const u32x4 (&d)[U], const uint32_t (&x)[U]) {
-        uint32_t hitmask = 0;
-        const uint32_t cons = lds_ld(&s_cons[wid]);        // read early: an older value only under-estimates the free space
+        for (int j = 0; j < 4; j++) { const uint32_t i = threadIdx.x * 4 + j; c[j] = i < n_lists ? rec_counts[i] : 0u; sum += c[j]; }
+        uint32_t incl = sum;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
-            uint32_t sm[4 * SPW], h[4 * SPW]; uint4 blk[4 * SPW];
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((threadIdx.x & 63) >= (uint32_t)o) incl += t; }
+        __shared__ uint32_t s_wave[FINISH_BLOCK / 64];
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t base = incl - sum;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += s_wave[w];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int j = 0; j < SPW; j++)
-                    sm[q * SPW + j] = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
-#pragma unroll
-            for (int i = 0; i < 4 * SPW; i++) { h[i] = bloom_hash(sm[i]); blk[i] = s_tab4[h[i] >> blk_shift]; }
-#pragma unroll
-            for (int i = 0; i < 4 * SPW; i++) {
-                const uint32_t g = alignbit(h[i], sm[i], STAGE1_MIX_SHIFT);          // stage1_mix
-                const uint32_t t = lshl_by_byte<0>(g, blk[i].x) & lshl_by_byte<1>(g, blk[i].y) & lshl_by_byte<2>(g, blk[i].z) & lshl_by_byte<3>(g, blk[i].w);
-                hitmask = alignbit(hitmask, t, 31);                                  // (hitmask << 1) | sign(t)
-            }
-        }
-        const uint64_t hm = (A.flags & 1u) ? 0 : __ballot(hitmask != 0);
-        if (hm) {                                           // wave-uniform
-            const uint32_t n = (uint32_t)__popcll(hm);
-            const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-            const unsigned long long rec = ((unsigned long long)hitmask << 32) | (c << 10) | threadIdx.x;
-            if (n_stream < FUSED_WAVES && RING - (prod - cons) >= n) {
-                if (hitmask) lds_st(&my_ring[(prod + mb) & (RING - 1)], rec);
-                prod += n;
-                MF_COMPILER_FENCE();
-                lds_st(&s_prod[wid], prod);                 // LDS executes a wave's instructions in order: the records are there first
-            } else {
-                if (hitmask) my_ovf[ovf_n + mb] = rec;
-                ovf_n += n;
-            }
-        }
-    };
-
-    // ---- prologue: first chunk in flight, clear the other parity's bitmaps, stage the tables
-    // Round `it` deals chunks it * grid .. it * grid + grid - 1, workgroup b taking number (b + 37 it) mod grid: with a
-    // fixed number every chunk of a workgroup would lie at the same offset modulo grid * chunk bytes, i.e. on the same
-    // few memory channels for the whole pass, and the workgroups with the busy channels finish 20 % behind the average.
-    u32x4 a[U], b[U]; uint32_t ax[U], bx[U];
-    const uint32_t cs = gridDim.x;
-    uint32_t it = 0;
-    auto chunk_of = [&](uint32_t i) -> uint32_t { return i * cs + (blockIdx.x + i * 37u) % cs; };
-    uint32_t c = chunk_of(0);
-    if (streamer && c < n_chunks) load(c, a, ax);
-    {
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint64_t i = (uint64_t)blockIdx.x * FUSED_BLOCK + threadIdx.x; i < A.bitmap_vec4; i += cstep * FUSED_BLOCK) { A.cand_other[i] = z; A.bits_other[i] = z; }
-        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
-        for (uint32_t i = threadIdx.x; i < nb4; i += FUSED_BLOCK) s_tab4[i] = src[i];
-        // fold the k-mer bit table: the block index is the top bits of the hash, so 2^f neighbouring blocks OR into one
-        const uint32_t fold = 1u << (S.kb_log2w - kbf_log2w);
-        const uint2 *__restrict__ src2 = reinterpret_cast<const uint2 *>(S.kbloom);
-        for (uint32_t i = threadIdx.x; i < n_kb2; i += FUSED_BLOCK) {
-            uint2 acc = make_uint2(0, 0);
-            for (uint32_t j = 0; j < fold; j++) { const uint2 t = src2[i * fold + j]; acc.x |= t.x; acc.y |= t.y; }
-            s_kb2[i] = acc;
-        }
-        if (threadIdx.x < 64) s_ctl[threadIdx.x] = 0;
+        for (int j = 0; j < 4; j++) { const uint32_t i = threadIdx.x * 4 + j; if (i <= n_lists) s_pre[i] = base; base += c[j]; }
+        __syncthreads();
     }
-    __syncthreads();
-
-    if (streamer) {
-        // Two register sets, ping-pong: the next chunk is in flight while this one is examined.  The loads sit on
-        // unconditional paths (the last chunk is peeled), so the compiler's vmcnt counts are exact and examining a
-        // chunk never waits for the loads issued right before it.
-        if (c < n_chunks) for (;;) {
-            uint32_t cn = chunk_of(++it);
-            if (cn >= n_chunks) { stage1(c, a, ax); break; }
-            load(cn, b, bx);
-            stage1(c, a, ax);
-            c = cn;
-            cn = chunk_of(++it);
-            if (cn >= n_chunks) { stage1(c, b, bx); break; }
-            load(cn, a, ax);
-            stage1(c, b, bx);
-            c = cn;
-        }
-        if (A.dbg) t_stream_end = wall_clock64() - t_entry;
-        MF_COMPILER_FENCE();
-        if (lane == 0) lds_add(s_done, 1u);         // after the last s_prod store, in LDS order
-        __threadfence_block();                      // own overflow records are read back below
-    } else {
-        __builtin_amdgcn_s_setprio(2);              // a finisher's short bursts of work go ahead of the streaming waves on its SIMD
-    }
-
-    // ---- finishing machinery (every wave: finishers from the start, streaming waves once their chunks are done)
-    // Lanes are persistent workers: a lane holds one record until all its positives are dealt with; idle lanes are
-    // refilled from the rings (finishers) or from the wave's own overflow list (streaming waves, afterwards) before
-    // every round, so the rounds -- each one or two memory round trips long -- run with as many lanes as there is work.
-    //
-    // Two ways to finish a positive:
-    //  SAMPLE mode (threshold 1, no hit counts wanted): a window of k bases that is a bait k-mer contains only
-    //    true stage-1 positives, in particular the first stream-aligned s-mer at or after its start -- call that
-    //    sample its owner.  Every window inside a read therefore belongs to exactly one sample inside that read (the
-    //    `stride` windows starting at g0 - stride + 1 .. g0), and the read passes iff some positive sample owns a
-    //    window that is in the bait set.  So a positive costs ONE work item (16 k-mer positions: one unaligned
-    //    16-byte window, LDS bit table, open-address table for the bit-table positives) and a pass is an idempotent
-    //    atomicOr: no grouping state beyond "the read my record already passed", no claim, no candidate bitmap.
-    //  CLAIM mode (threshold > 1 or hit counts): positives are grouped by read, lone ones verified (stage 2 / 3), the
-    //    read is claimed in the candidate bitmap (returning atomicOr: exactly one lane of the grid wins) and claimed
-    //    reads are counted whole, 64 per run, their work items dealt to the wave's lanes (run_candidates).
-    const uint2 *__restrict__ kb2 = s_kb2;
-    const uint32_t kb_shift = 32 - (kbf_log2w - 1);
-    lds_u32 *my_cnt = s_cnt + wid * 64;
-    const uint32_t *__restrict__ st2 = S.bloom + ((size_t)1 << S.bloom_log2w);      // stage 2: <= 32 KiB, L2 resident
-    const uint32_t st2_shift = 32 - (S.stage2_log2w + 5);
-    const bool fast = R.len_magic32 != 0;
-    const bool sample_mode = A.thr == 1 && !A.count_all;
+    const uint32_t total = s_pre[n_lists];
+    constexpr int NSAMP = U * 4 * SPW, SPP = 4 * SPW;
     const int k = S.k;
-    // finisher f serves rings f, f + NF, f + 2 NF, ...: lane l < 16 keeps the consumer count of ring f + l * NF
-    const uint32_t NF = FUSED_WAVES - n_stream, f = (uint32_t)wid - n_stream;
-    const uint32_t my_ring_id = streamer ? 0xFFFFu : f + (uint32_t)lane * NF;
-    const bool ring_lane = !streamer && lane < 16 && my_ring_id < n_stream;
-    uint32_t my_cons = 0, ovf_pos = 0;
-    uint64_t cand_r = 0; uint32_t ncand = 0;          // claim mode: lane i < ncand owns candidate read cand_r
-    uint64_t def_r = 0; bool def_v = false;           // claim mode: a read this lane claimed in the last round, not yet dealt to a lane
-    uint32_t m = 0, rtid = 0, rrem = 0; uint64_t cb = 0, rq = 0;    // record in progress: remaining positives, recording lane, first base of its piece
-    uint64_t passed_r = ~0ULL, passed_r2 = ~0ULL;     // sample mode: the last two reads this lane's record has passed
-    uint32_t runs = 0;                                // sample mode: positives of the record that start a run of n_adj neighbouring positives
-    // sample mode: positives that need the sixteen-window item are not counted on the spot -- a few lanes a round would make
-    // the wave run that code every round -- but parked (first base of the sample) and counted together, 64 a round, at the end
-    unsigned long long *my_dfr = A.dfr + ((size_t)blockIdx.x * FUSED_WAVES + wid) * A.dfr_cap;
-    uint32_t n_dfr = 0, dfr_pos = 0; bool draining = false;
+    const uint32_t smask = S.smask;
+    const bool fast = R.len_magic32 != 0;
+    const uint64_t chunk_bases = (uint64_t)screen_block * U * 64;
+    const uint64_t mask_lo = (KW == 1 && k < 32) ? (1ULL << (2 * k)) - 1 : ~0ULL;
+    const uint64_t mask_hi = KW == 2 ? (1ULL << (2 * k - 64)) - 1 : 0;
     // a run of n_adj samples covers s + (n_adj - 1) * stride >= k bases; its samples lie in one 16-byte piece of the recording lane
     const uint32_t n_adj = (uint32_t)((S.k - S.s + S.stride - 1) / S.stride) + 1;
     const uint32_t run_span = (uint32_t)S.s + (n_adj - 1) * (uint32_t)S.stride;
     uint32_t run_ok = 0;                              // bits whose sample has n_adj - 1 successors inside its piece
-    {
-        constexpr int SPP = 4 * SPW;                  // samples per piece
-        for (int i = 0; i < NSAMP; i++) if ((uint32_t)(i % SPP) + n_adj <= (uint32_t)SPP) run_ok |= 1u << (NSAMP - 1 - i);
-    }
-    uint32_t pend_old = 0, pend_bit = 0;              // sample mode: result of the last pass-bit atomic, looked at one round later
-    uint32_t tot_pass = 0, tot_cand = 0, spins = 0;
-    auto off_of = [&](int idx) -> uint32_t {          // offset (bases, inside its chunk) of sample idx of the recording lane
-        const int j = idx % SPW, q = (idx / SPW) & 3, u = idx / (4 * SPW);
-        return ((((uint32_t)u * NST + rtid) * 4 + q) << 4) + (uint32_t)j * 8;
+    for (int i = 0; i < NSAMP; i++) if ((uint32_t)(i % SPP) + n_adj <= (uint32_t)SPP) run_ok |= 1u << (NSAMP - 1 - i);
+    uint32_t n_pass = 0, n_items = 0;
+    uint32_t pend_old = 0, pend_bit = 0;              // result of the last pass-bit atomic, looked at a turn later (never waited for)
+    auto load_rec = [&](uint32_t ri) -> ScreenRec {
+        uint32_t lo = 0, hi = n_lists;                // the list holding record ri: last l with s_pre[l] <= ri
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= ri) lo = mid; else hi = mid; }
+        return recs[(size_t)lo * rec_cap + (ri - s_pre[lo])];
     };
-    for (;;) {
-        // (1) claim mode: reads claimed in the last round move to free lanes; if they do not fit, the lanes are counted first
-        bool flush = false;
-        if (!sample_mode) {
-            const uint64_t defm = __ballot(def_v);
-            const uint32_t ndef = (uint32_t)__popcll(defm);
-            if (ndef) {
-                if (ncand + ndef <= 64) {
-                    const uint32_t src = nth_set_lane(defm, ((uint32_t)lane - ncand) & 63u) & 63u;
-                    const uint64_t v = shfl_u64(def_r, (int)src);
-                    if ((uint32_t)lane >= ncand && (uint32_t)lane < ncand + ndef) cand_r = v;
-                    ncand += ndef; def_v = false;
-                } else flush = true;
-            }
-        }
-        // (2) refill idle lanes
-        bool finished = false;
-        const uint64_t tq0 = A.dbg ? wall_clock64() : 0;
-        const uint64_t idle = __ballot(m == 0);
-        if (idle && !flush) {
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            // a round costs the wave the same whether four lanes work or sixty-four, so a finisher that still has busy
-            // lanes tops up only once a fair number are idle (the rings buffer the records meanwhile)
-            const bool top_up = n_idle == 64 || n_idle >= A.refill_min;
-            const uint32_t ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const bool is_idle = m == 0;
-            uint32_t n_take = 0; unsigned long long rec = 0;
-            if (!streamer) {
-                const uint32_t done = lds_ld(s_done);          // before the producer counts
-                MF_COMPILER_FENCE();
-                const uint32_t avail = ring_lane ? lds_ld(&s_prod[my_ring_id]) - my_cons : 0u;
-                MF_COMPILER_FENCE();
-                uint32_t incl = avail;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-                const uint32_t total = __shfl(incl, 15);
-                n_take = total < n_idle ? total : n_idle;
-                // ... and an idle finisher waits until a batch has gathered, unless the stream is over or a ring is filling up
-                const uint32_t fullest = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(__ballot(avail >= RING / 2)));
-                if (!(top_up && (n_take >= A.refill_min || (n_take == total && done == n_stream) || fullest))) n_take = 0;
-                finished = done == n_stream && total == 0;
-                if (n_take) {
-                    int lo = 0, hi = 15;                       // smallest ring lane whose inclusive count exceeds this lane's ordinal
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; s_++) { const int mid = (lo + hi) >> 1; if (__shfl(incl, mid) > ord) hi = mid; else lo = mid + 1; }
-                    const uint32_t incl_j = __shfl(incl, lo), avail_j = __shfl(avail, lo), cons_j = __shfl(my_cons, lo);
-                    const uint32_t ring = f + (uint32_t)lo * NF;
-                    if (is_idle && ord < n_take) rec = lds_ld(&s_ring[ring * RING + ((cons_j + (ord - (incl_j - avail_j))) & (RING - 1))]);
-                    MF_COMPILER_FENCE();
-                    const uint32_t excl = incl - avail;
-                    const uint32_t taken = n_take > excl ? (n_take - excl < avail ? n_take - excl : avail) : 0u;
-                    if (ring_lane && taken) { my_cons += taken; lds_st(&s_cons[my_ring_id], my_cons); }      // after the ring reads, in LDS order
-                }
-            } else {
-                finished = ovf_pos >= ovf_n;
-                n_take = ovf_n - ovf_pos < n_idle ? ovf_n - ovf_pos : n_idle;
-                if (is_idle && ord < n_take) rec = my_ovf[ovf_pos + ord];
-                ovf_pos += n_take;
-            }
-            if (is_idle && ord < n_take) {
-                m = (uint32_t)(rec >> 32);
-                rtid = (uint32_t)rec & 1023u;
-                cb = (uint64_t)((uint32_t)rec >> 10) * ((uint64_t)chunk_vec * 64);
-                if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
-                passed_r = passed_r2 = ~0ULL;
-                runs = m & run_ok;                             // bit B (sample i) starts a run iff bits B, B-1, ..., B-(n_adj-1) are set
-                for (uint32_t j = 1; j < n_adj; j++) runs &= m << j;
-            }
-        }
-        if (A.dbg) tm_refill += wall_clock64() - tq0;
-        if (!flush && !__ballot(m != 0)) {                     // no lane has anything to do
-            if (ncand) flush = true;                           // claim mode, idle: count what is waiting
-            else if (finished && dfr_pos < n_dfr) draining = true;      // sample mode: the parked sixteen-window items, 64 a round
-            else if (finished) break;
-            else {                                             // a finisher ahead of the stream
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 24)) { if (lane == 0) A.partials[2 * EXACT_MAX_GRID - 1] = 1; break; }    // watchdog: never hang the device
-                continue;
-            }
-        }
-        spins = 0;
-        if (draining) {
-            __threadfence_block();                             // own parked entries are read back
-            const uint32_t n_take = n_dfr - dfr_pos < 64 ? n_dfr - dfr_pos : 64;
-            bool act = (uint32_t)lane < n_take;
-            uint64_t g0 = 0, r = ~0ULL, b0 = 0, len = 0;
-            if (act) {
-                g0 = my_dfr[dfr_pos + lane];
-                r = read_holding(R, g0, (uint32_t)S.s);
-                act = r != ~0ULL;
-            }
-            if (act) {
-                if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; } else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
-                const uint32_t bw = __hip_atomic_load(&A.bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((bw >> (r & 31)) & 1u) act = false;        // passed meanwhile
-            }
-            dfr_pos += n_take;
-            const uint64_t own_lo = g0 + 1 > (uint64_t)S.stride ? g0 + 1 - S.stride : 0;
-            const uint64_t p0 = own_lo > b0 ? own_lo - b0 : 0;
-            const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
-            if (sample_item<KW>(R, S, kb2, kb_shift, act && p0 < n_pos, r, b0, n_pos, p0)) {
-                const uint32_t bitm = 1u << (r & 31);
-                if (!(atomicOr(&A.bits[r >> 5], bitm) & bitm)) tot_pass++;
-            }
-            draining = false;
-            continue;
-        }
-        // (3) claim mode: exact count of the candidates in the lanes
-        if (flush) {
-            const bool owner = (uint32_t)lane < ncand;
-            const uint64_t r = cand_r;
-            uint64_t b0 = 0; uint32_t np = 0, hasn = 0;
-            if (owner) {
-                uint64_t len;
-                if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; }
-                else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
-                const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
-                np = n_pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_pos;
-                hasn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
-            }
-            run_candidates<KW>(R, S, kb2, kb_shift, A.thr, true, lane, owner, b0, np, hasn, my_cnt, A.count_all != 0);
-            if (owner) {
-                const uint32_t hcnt = my_cnt[lane];
-                if (A.count_all) A.hits_out[r] = hcnt;
-                if (hcnt >= A.thr) { atomicOr(&A.bits[r >> 5], 1u << (r & 31)); tot_pass++; }
-                tot_cand++;
-            }
-            ncand = 0;
-            continue;
-        }
-        if (sample_mode) {
-            // (4a) one round.  Exact counting of a positive's sixteen windows is dear (~900 instructions a round for the
-            // wave, whoever needs it), and nearly every positive can be settled for a tenth of that:
-            //  RUN     a bait read shows as runs of neighbouring positives; a run of n_adj samples spans k bases, and the
-            //          window of k bases at its first sample is almost surely a bait k-mer: ONE canonical key, ONE table
-            //          probe.  Runs are tried first; a hit passes the read and its other positives are skipped.
-            //  ISOLATED  what is left (mostly stage-1 false positives) is looked up in the exact s-mer table; only a true
-            //          bait s-mer goes on to the sixteen-window item, and only then does the wave run that code.
-            const uint64_t tq1 = A.dbg ? wall_clock64() : 0;
-            bool got = false, is_run = false; uint64_t r = 0, g0 = 0, b0 = 0, len = 0; uint32_t sj = 0;
-            if (fast) {
-                while (m) {
-                    const bool from_runs = (m & runs) != 0;                // run starts first, in stream order
-                    const int bit = 31 - __clz(from_runs ? (m & runs) : m);
-                    if (from_runs) runs &= ~(1u << bit); else m &= ~(1u << bit);
-                    const int idx = NSAMP - 1 - bit;
-                    const uint32_t off = off_of(idx);
-                    const uint32_t t = rrem + off;
-                    const uint32_t dq = __umulhi(t, R.len_magic32);
-                    const uint32_t offr = t - dq * R.uniform_len;
-                    const uint32_t span = from_runs ? run_span : (uint32_t)S.s;         // bases that have to lie inside one read
-                    // straddles two reads / lies in the padding behind the last read: not a sample (or run) of any read
-                    if (offr + span > R.uniform_len || cb + off + span > R.total_bases) continue;
-                    r = rq + dq;
-                    if (r == passed_r || r == passed_r2) continue;
-                    got = true; is_run = from_runs; g0 = cb + off; b0 = g0 - offr; len = R.uniform_len; sj = (uint32_t)(idx % SPW);
-                    break;
-                }
-            } else if (m) {                                                // ragged reads: every positive on its own
+    const uint32_t stride_r = gridDim.x * FINISH_BLOCK;
+    uint32_t ri = blockIdx.x * FINISH_BLOCK + threadIdx.x;
+    ScreenRec rec_next{0, 0, 0, 0};
+    if (ri < total) rec_next = load_rec(ri);
+    for (; ri < total; ri += stride_r) {
+        const ScreenRec rec = rec_next;
+        if (ri + stride_r < total) rec_next = load_rec(ri + stride_r);        // the next record is on its way while this one is settled
+        const uint64_t cb = (uint64_t)rec.chunk * chunk_bases;
+        uint64_t rq = 0; uint32_t rrem = 0;
+        if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
+        uint32_t m = rec.hitmask;
+        uint32_t runs = fast ? m & run_ok : 0u;       // bit B (sample i) starts a run iff bits B, B-1, ..., B-(n_adj-1) are set
+        for (uint32_t j = 1; j < n_adj; j++) runs &= m << j;
+        if (PHASE == 0) m = runs; else runs = 0;      // phase 0 looks at run starts only, phase 1 at every positive on its own
+        uint64_t passed_r = ~0ULL, passed_r2 = ~0ULL; // the last two reads this record has passed
+        while (m) {
+            // ---- pick the next positive that needs work (run starts first, in stream order) and the read it lies in.  No
+            // memory access for uniform read lengths, so positives that need nothing (outside any read, read already passed)
+            // are skipped right here instead of costing the wave a turn of round trips.
+            bool is_run = false, got = false; uint64_t g0 = 0, r = 0;
+            while (m) {
+                is_run = PHASE == 0;                                             // (phase 0: m holds the run starts only)
                 const int bit = 31 - __clz(m);
                 m &= ~(1u << bit);
                 const int idx = NSAMP - 1 - bit;
-                g0 = cb + off_of(idx); sj = (uint32_t)(idx % SPW);
-                r = read_holding(R, g0, (uint32_t)S.s);
-                got = r != ~0ULL && r != passed_r && r != passed_r2;
-                if (got) { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
+                const int sj = idx % SPW, sq = (idx / SPW) & 3, su = idx / (4 * SPW);
+                const uint32_t off = ((((uint32_t)su * screen_block + rec.tid) * 4 + sq) << 4) + (uint32_t)sj * 8;
+                g0 = cb + off;
+                const uint32_t span = is_run ? run_span : (uint32_t)S.s;        // bases that have to lie inside one read
+                if (fast) {
+                    const uint32_t t = rrem + off;
+                    const uint32_t dq = __umulhi(t, R.len_magic32);
+                    const uint32_t offr = t - dq * R.uniform_len;
+                    // straddles two reads / lies in the padding behind the last read: not a sample (or run) of any read
+                    if (offr + span > R.uniform_len || g0 + span > R.total_bases) continue;
+                    r = rq + dq;
+                } else {
+                    r = read_holding(R, g0, span);
+                    if (r == ~0ULL) continue;
+                }
+                if (r == passed_r || r == passed_r2) continue;
+                got = true;
+                break;
             }
-            const uint32_t po = pend_old, pb = pend_bit;          // looked at after this round's loads: never waited for on its own
+            if (!got) break;
+            n_items++;
+            // ---- round trip 1, the same loads for both kinds: the words at the sample, the read's has-N and pass bits
+            const uint32_t bitm = 1u << (r & 31);
+            const uint64_t wbit = 2 * g0;
+            const uint32_t *__restrict__ w = R.words + (wbit >> 5);
+            const uint32_t sh = (uint32_t)wbit & 31;
+            constexpr int NKW = KW == 1 ? 3 : 5;
+            uint32_t raw[NKW];
+#pragma unroll
+            for (int i = 0; i < NKW; i++) raw[i] = w[i];
+            const uint32_t hn_w = R.has_n[r >> 5];
+            const uint32_t bw = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-coherent: other records pass reads meanwhile
+            if (pend_bit && !(pend_old & pend_bit)) n_pass++;
             pend_bit = 0;
-            const uint64_t tq2 = A.dbg ? wall_clock64() : 0;
-            if (A.dbg) tm_pick += tq2 - tq1;
-            bool hit = false, full = false;
-            if (got) {
-                const uint32_t hn = (R.has_n[r >> 5] >> (r & 31)) & 1u;
-                if (is_run && !hn) {
-                    hit = table_contains(S, canonical_at<KW>(R.words, g0, k));
-                } else if (!is_run) {
-                    // another lane (or wave) may have passed this read meanwhile: a device-coherent look at its bit
-                    const uint32_t bw = __hip_atomic_load(&A.bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint64_t wi = g0 >> 4;
-                    uint32_t sm = R.words[wi];
-                    if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * sj);
-                    sm &= smask;
-                    if ((bw >> (r & 31)) & 1u) { passed_r2 = passed_r; passed_r = r; }
-                    else full = stab_contains(S, sm);            // a true bait s-mer (either strand): its windows are counted
-                }                                                // (a run in a read with invalid bases: its positives come back as isolated ones)
-            }
-            // park the sixteen-window items; if the list is full (never, in practice) they are counted right here
-            const uint64_t fm = __ballot(full);
-            bool now = false;
-            if (fm) {
-                const uint32_t nf = (uint32_t)__popcll(fm);
-                if (n_dfr + nf <= A.dfr_cap) {
-                    if (full) my_dfr[n_dfr + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = g0;
-                    n_dfr += nf;
-                } else now = true;
-            }
-            if (now) {
+            if (bw & bitm) { passed_r2 = passed_r; passed_r = r; continue; }     // passed meanwhile
+            if (is_run && ((hn_w >> (r & 31)) & 1u)) continue;                   // invalid bases in the read: its positives come back as isolated ones
+            // ---- round trip 2: one probe -- the k-mer table for a run, the exact s-mer table for an isolated positive
+            if (PHASE == 0) {
+                uint64_t klo, khi = 0;
+                const uint64_t lo = (uint64_t)alignbit(raw[1], raw[0], sh) | ((uint64_t)alignbit(raw[2], raw[1], sh) << 32);
+                if (KW == 1) {
+                    const uint64_t fwd = lo & mask_lo, rc = revcomp1(fwd, k);
+                    klo = fwd < rc ? fwd : rc;
+                } else {
+                    const uint64_t hi = ((uint64_t)alignbit(raw[NKW - 2], raw[2], sh) | ((uint64_t)alignbit(raw[NKW - 1], raw[NKW - 2], sh) << 32)) & mask_hi;
+                    uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
+                    const bool fl = (hi < rhi) || (hi == rhi && lo < rlo);
+                    klo = fl ? lo : rlo; khi = fl ? hi : rhi;
+                }
+                if (table_has<KW>(S, klo, khi, (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi)))) {
+                    passed_r2 = passed_r; passed_r = r;
+                    pend_bit = bitm;
+                    pend_old = atomicOr(&bits[r >> 5], bitm);              // the first setter of the bit counts the pass
+                }
+            } else if (stab_contains(S, alignbit(raw[1], raw[0], sh) & smask)) {   // a true bait s-mer (either strand) outside any run
+                // the windows this sample owns start at g0 - stride + 1 .. g0; the item tests 16 positions from the first of them
+                // that lies inside the read (positions past g0 belong to the next sample: harmless for threshold 1)
+                uint64_t b0, len;
+                if (R.uniform_len) { b0 = r * R.uniform_len; len = R.uniform_len; } else { b0 = R.offsets[r]; len = R.offsets[r + 1] - b0; }
                 const uint64_t own_lo = g0 + 1 > (uint64_t)S.stride ? g0 + 1 - S.stride : 0;
                 const uint64_t p0 = own_lo > b0 ? own_lo - b0 : 0;
                 const uint64_t n_pos = len >= (uint64_t)k ? len - k + 1 : 0;
-                hit |= sample_item<KW>(R, S, kb2, kb_shift, full && p0 < n_pos, r, b0, n_pos, p0);
+                if (p0 < n_pos && sample_item<KW>(R, S, reinterpret_cast<const uint2 *>(S.kbloom), 32 - (S.kb_log2w - 1), true, r, b0, n_pos, p0)) {
+                    passed_r2 = passed_r; passed_r = r;
+                    pend_bit = bitm;
+                    pend_old = atomicOr(&bits[r >> 5], bitm);
+                }
             }
-            if (hit) {
-                passed_r2 = passed_r; passed_r = r;
-                pend_bit = 1u << (r & 31);
-                pend_old = atomicOr(&A.bits[r >> 5], pend_bit);           // first setter of the bit counts the pass (next round)
-            }
-            tot_cand += got;
-            if (A.dbg) { const uint64_t tq3 = wall_clock64(); tm_item += tq3 - tq2; }
-            if (pb && !(po & pb)) tot_pass++;
-            if (A.dbg) { n_rounds++; tm_mark += (uint64_t)__popcll(__ballot(got)); }
-            continue;
         }
-        // (4b) claim mode, one round: every lane takes the next read its record has positives in
-        bool got = false; uint64_t r = 0; int idx = 0; uint32_t npos_in = 0;
-        if (fast) {
-            // Uniform read length: positives are walked in stream order and grouped by the read they fall into (a
-            // division by multiplication each).  Two or more stage-1 positives of one lane inside one read are
-            // practically always a bait read, so such a read is claimed without fetching anything; a lone positive
-            // goes through stage 2.  Claiming is only ever conservative -- the exact count decides.
-            while (m) {
-                const int bit = 31 - __clz(m);
-                m &= ~(1u << bit);
-                const int i0 = NSAMP - 1 - bit;
-                const uint32_t off = off_of(i0);
-                const uint32_t t = rrem + off;
-                const uint32_t dq = __umulhi(t, R.len_magic32);
-                const uint32_t offr = t - dq * R.uniform_len;
-                if (offr + (uint32_t)S.s > R.uniform_len || cb + off + S.s > R.total_bases) continue;
-                const uint64_t rr = rq + dq;
-                if (!got) { got = true; r = rr; idx = i0; npos_in = 1; continue; }
-                if (rr == r) { npos_in++; continue; }
-                m |= 1u << bit;                                // first positive of the next read: next round
-                break;
-            }
-        } else if (m) {                                        // ragged reads: every positive is looked up on its own
-            const int bit = 31 - __clz(m);
-            m &= ~(1u << bit);
-            got = true; idx = NSAMP - 1 - bit; npos_in = 1;
-        }
-        bool ok = got;
-        if (got && npos_in == 1) {
-            // stage 2 (canonical s-mer, STAGE2_K Bloom probes), optional stage 3 (exact s-mer table, large baits)
-            const uint64_t g0 = cb + off_of(idx);
-            const uint64_t wi = g0 >> 4;
-            uint32_t sm = R.words[wi];
-            if (SPW == 2) sm = alignbit(R.words[wi + 1], sm, 16u * (idx % SPW));
-            sm &= smask;
-            const uint32_t rc = revcomp_s(sm, S.s);
-            const uint32_t cn_ = sm < rc ? sm : rc;
-            const uint32_t ha = stage2_hash_a(cn_), hb = stage2_hash_b(cn_);
-            uint32_t bitsok = 1;
+    }
+    if (pend_bit && !(pend_old & pend_bit)) n_pass++;
+    // tallies: one plain store pair per workgroup, summed by the host
 #pragma unroll
-            for (int p = 0; p < STAGE2_K; p++) {
-                const uint32_t pos = (ha + (uint32_t)p * hb) >> st2_shift;
-                bitsok &= st2[pos >> 5] >> (pos & 31);
-            }
-            ok = (bitsok & 1u) != 0;
-            if (ok && S.use_stab) ok = stab_contains(S, sm);
-            if (ok && !fast) { r = read_holding(R, g0, (uint32_t)S.s); ok = r != ~0ULL; }
-        }
-        // claim the read: exactly one lane of the grid sees its bit clear
-        def_v = false;
-        if (ok) {
-            const uint32_t bitm = 1u << (r & 31);
-            const uint32_t old = atomicOr(&A.cand[r >> 5], bitm);
-            def_v = !(old & bitm); def_r = r;
-        }
-    }
-    if (pend_bit && !(pend_old & pend_bit)) tot_pass++;
-
-    if (A.dbg && lane == 0) {
-        unsigned long long *d = A.dbg + ((size_t)blockIdx.x * FUSED_WAVES + wid) * 4;
-        d[0] = t_stream_end; d[1] = wall_clock64() - t_entry; d[2] = streamer ? prod : my_cons; d[3] = streamer ? ovf_n : n_rounds;
-        if (!streamer) { d[0] = tm_refill | (tm_pick << 32); d[2] = tm_item | (tm_mark << 32); }
-    }
-    // ---- tallies: the last wave out stores the workgroup's pair (summed by the host)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { tot_pass += __shfl_down(tot_pass, o); tot_cand += __shfl_down(tot_cand, o); }
-    if (lane == 0) {
-        lds_add(&s_tot[0], tot_pass); lds_add(&s_tot[1], tot_cand);
-        MF_COMPILER_FENCE();
-        if (lds_add(s_exit, 1u) == FUSED_WAVES - 1) {
-            MF_COMPILER_FENCE();
-            A.partials[2 * blockIdx.x] = lds_ld(&s_tot[0]);
-            A.partials[2 * blockIdx.x + 1] = lds_ld(&s_tot[1]);
-        }
-    }
+    for (int o = 32; o > 0; o >>= 1) { n_pass += __shfl_down(n_pass, o); n_items += __shfl_down(n_items, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot[0], n_pass); atomicAdd(&s_tot[1], n_items); }
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t o = PHASE * EXACT_MAX_GRID + blockIdx.x; partials[2 * o] = s_tot[0]; partials[2 * o + 1] = s_tot[1]; }
 }
 
 // ----------------------------------------------------------- bait builders
@@ -1394,6 +1049,12 @@ __global__ void materialize2_kernel(BaitView B, int k, const uint32_t *postab, u
 __device__ __forceinline__ void stage1_insert(uint32_t sm, uint32_t *bloom, uint32_t log2w)
 {
     const uint32_t h = bloom_hash(sm);
+    if (MF_STAGE1_B64) {
+        uint32_t *blk = bloom + 2 * (size_t)(h >> (32 - (log2w - 1)));
+#pragma unroll
+        for (int i = 0; i < 4; i++) atomicOr(&blk[i >> 1], 1u << stage1_bit(sm, h, i));
+        return;
+    }
     uint32_t *blk = bloom + 4 * (size_t)(h >> (32 - (log2w - 2)));
 #pragma unroll
     for (int i = 0; i < 4; i++) atomicOr(&blk[i], 1u << stage1_bit(sm, h, i));
@@ -1650,7 +1311,7 @@ template <auto Kernel> static void raise_lds_limit_once(size_t max_bytes)
 
 template <int SPW, bool MASKED>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
-                              const KernelTiming *tm)
+                              const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
     const uint64_t grid = screen_grid_for(R, n_cu);
     if (grid == 0) return;
@@ -1658,7 +1319,7 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
     raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U, MASKED>>(128 * 1024 + 16);
     MF_LAUNCH((screen_kernel<SPW, SCREEN_U, MASKED>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
-              static_cast<ScreenRec *>(recs), cap, rec_counts);
+              static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
 }
 
 template <int SPW>
@@ -1675,11 +1336,30 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 }
 
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
-                         const KernelTiming *tm)
+                         const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
-    if (S.stride == 16 && S.s == 16) launch_screen_spw<1, false>(R, S, recs, rec_counts, n_cu, st, tm);
-    else if (S.stride == 16) launch_screen_spw<1, true>(R, S, recs, rec_counts, n_cu, st, tm);
-    else launch_screen_spw<2, true>(R, S, recs, rec_counts, n_cu, st, tm);
+    if (S.stride == 16 && S.s == 16) launch_screen_spw<1, false>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else if (S.stride == 16) launch_screen_spw<1, true>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else launch_screen_spw<2, true>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
+                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm)
+{
+    const uint64_t lists = screen_grid_for(R, n_cu);
+    if (lists == 0) return hipSuccess;
+    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
+    const ScreenRec *rc = static_cast<const ScreenRec *>(recs);
+    const KernelTiming *none = nullptr;
+#define MF_LAUNCH_FINISH(SPW, KW) do { \
+        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm, R, S, rc, cap, rec_counts, \
+                  (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); \
+        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 1>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, none, R, S, rc, cap, rec_counts, \
+                  (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); } while (0)
+    if (S.stride == 16) { if (S.kw == 1) MF_LAUNCH_FINISH(1, 1); else MF_LAUNCH_FINISH(1, 2); }
+    else                { if (S.kw == 1) MF_LAUNCH_FINISH(2, 1); else MF_LAUNCH_FINISH(2, 2); }
+#undef MF_LAUNCH_FINISH
     return hipGetLastError();
 }
 
@@ -1688,64 +1368,6 @@ hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *rec
 {
     if (S.stride == 16) launch_mark_spw<1>(R, S, recs, rec_counts, cand, n_cu, st, tm);
     else launch_mark_spw<2>(R, S, recs, rec_counts, cand, n_cu, st, tm);
-    return hipGetLastError();
-}
-
-// ---- fused pass
-static uint32_t fused_stream_waves()
-{
-    static const uint32_t n = [] {
-        const char *v = getenv("MF_STREAM_WAVES");
-        uint32_t w = v && *v ? (uint32_t)atoi(v) : 14u;
-        return w < 4 ? 4u : (w > FUSED_WAVES ? (uint32_t)FUSED_WAVES : w);       // 16: no finisher waves, every wave finishes its own records after the stream
-    }();
-    return n;
-}
-
-FusedGeom fused_geom_for(uint64_t n_words, int n_cu)
-{
-    FusedGeom g{};
-    g.n_stream = fused_stream_waves();
-    g.chunk_vec = (uint64_t)g.n_stream * 64 * SCREEN_U;
-    const uint64_t n_vec = (n_words + 3) / 4;
-    g.n_chunks = (n_vec + g.chunk_vec - 1) / g.chunk_vec;
-    g.grid = g.n_chunks < (uint64_t)n_cu ? g.n_chunks : (uint64_t)n_cu;     // persistent: one 1024-thread workgroup per CU
-    const uint64_t iters = g.grid ? (g.n_chunks + g.grid - 1) / g.grid : 0;
-    g.ovf_cap = iters * 64;                                   // one record per lane per chunk a wave walks
-    g.words_needed = g.n_chunks * g.chunk_vec * 4 + 16;
-    g.ok = g.n_chunks < (1u << 22) && g.ovf_cap < (1ull << 32);
-    return g;
-}
-
-size_t fused_lds_bytes(const KmerSetView &S)
-{
-    const uint32_t kbf = S.kb_log2w < KBF_MAX_LOG2W ? S.kb_log2w : KBF_MAX_LOG2W;
-    return (sizeof(uint32_t) << S.bloom_log2w) + (sizeof(uint32_t) << kbf) + (size_t)FUSED_WAVES * RING * 8 + (size_t)FUSED_WAVES * 64 * 4 + 256;
-}
-
-hipError_t launch_fused(const ReadsView &R, const KmerSetView &S, const FusedGeom &G, const FusedBuffers &B, uint32_t thr, bool count_all,
-                        hipStream_t st, const KernelTiming *tm)
-{
-    if (G.grid == 0) return hipSuccess;
-    FusedArgs A{};
-    A.cand = B.cand; A.bits = B.bits; A.cand_other = reinterpret_cast<uint4 *>(B.cand_other); A.bits_other = reinterpret_cast<uint4 *>(B.bits_other);
-    A.bitmap_vec4 = B.bitmap_vec4; A.ovf = B.ovf; A.ovf_cap = (uint32_t)G.ovf_cap; A.n_chunks = (uint32_t)G.n_chunks; A.n_stream = G.n_stream;
-    A.thr = thr; A.count_all = count_all ? 1u : 0u; A.hits_out = B.hits_out; A.partials = B.partials; A.flags = B.flags; A.dbg = B.dbg; A.dfr = B.dfr; A.dfr_cap = B.dfr_cap;
-    { static const uint32_t rm = getenv("MF_REFILL_MIN") ? (uint32_t)atoi(getenv("MF_REFILL_MIN")) : 32u; A.refill_min = rm < 1 ? 1 : (rm > 64 ? 64 : rm); }
-    const size_t lds = fused_lds_bytes(S);
-#define MF_LAUNCH_FUSED(SPW, MASKED, KW) do { \
-        raise_lds_limit_once<&fused_kernel<SPW, SCREEN_U, MASKED, KW>>(160 * 1024); \
-        MF_LAUNCH((fused_kernel<SPW, SCREEN_U, MASKED, KW>), dim3((unsigned)G.grid), dim3(FUSED_BLOCK), lds, st, tm, R, S, A); } while (0)
-    if (S.kw == 1) {
-        if (S.stride == 16 && S.s == 16) MF_LAUNCH_FUSED(1, false, 1);
-        else if (S.stride == 16) MF_LAUNCH_FUSED(1, true, 1);
-        else MF_LAUNCH_FUSED(2, true, 1);
-    } else {
-        if (S.stride == 16 && S.s == 16) MF_LAUNCH_FUSED(1, false, 2);
-        else if (S.stride == 16) MF_LAUNCH_FUSED(1, true, 2);
-        else MF_LAUNCH_FUSED(2, true, 2);
-    }
-#undef MF_LAUNCH_FUSED
     return hipGetLastError();
 }
 

@@ -1,8 +1,7 @@
 // Compile-time geometry shared by host packing and the screen kernel.
 #pragma once
 namespace mf {
-constexpr int SCREEN_U = 4;            // uint4 loads in flight per lane per chunk
+constexpr int SCREEN_U = 2;            // uint4 loads in flight per lane per chunk
 constexpr int SCREEN_BLOCK = 1024;     // threads per screen workgroup
-constexpr int FUSED_DFR_CAP = 1024;    // parked sixteen-window items per wave of the fused pass
 constexpr int EXACT_MAX_GRID = 1024;   // workgroups of the exact kernel (one (pass, candidate) partial pair each)
 }
