@@ -19,6 +19,7 @@ Everything else of the reference class (graph/assemble/local/iterate/finalize) d
 from __future__ import annotations
 
 import os
+import signal
 import subprocess
 from os import path
 from typing import Optional, Tuple
@@ -162,13 +163,33 @@ class MEGAHIT:
                 print(orig[0] if bait_proc else self.fq1, file=lib)
                 name = self.fq1 if not self.fq1.endswith("gz") else path.join(self.temp_dir, "pipe.se")
                 print("se", name, file=lib)
-        helper.shell_call(self.MEGAHIT_CORE, "buildlib", self.read_lib, self.read_lib)
+        try:
+            helper.shell_call(self.MEGAHIT_CORE, "buildlib", self.read_lib, self.read_lib)
+        except BaseException:
+            # buildlib died: the bait filter is blocked writing into pipes nobody reads.  End its process group, reap it and
+            # take the pipes away, so that a retry in the same temp_dir does not stumble over them.
+            if bait_proc is not None:
+                try:
+                    os.killpg(bait_proc.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+                bait_proc.wait()
+            self._unlink_bait_pipes()
+            raise
         if any(p.wait() != 0 for p in fifos):
             raise RuntimeError("Error occured in reading input fifos")
         if bait_proc is not None:
             out = bait_proc.communicate()[0]
+            self._unlink_bait_pipes()
             if bait_proc.returncode != 0:
                 raise RuntimeError("Error occured in the bait filter feeding buildlib")
             self.bait_kept = int(out.decode().strip() or 0)
+
+    def _unlink_bait_pipes(self):
+        for name in ("pipe.bait1", "pipe.bait2"):
+            try:
+                os.unlink(path.join(self.temp_dir, name))
+            except FileNotFoundError:
+                pass
 
     MEGAHIT_CORE = "megahit_core"

@@ -42,20 +42,33 @@ struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr
 static std::mutex g_ctx_mu;
 static std::map<int, DevCtx> g_ctx;
 
+// MF_FAKE_DEVICES=N: the library reports N logical devices and maps logical device d onto physical device d mod <visible>.
+// Every logical device has its own context (streams), bait tables and read sets, so the multi-device code paths -- batch
+// dealing in the file pipeline, one worker per device -- run for real on a single-GPU box (tests; not a performance mode).
+static int fake_devices()
+{
+    static const int n = [] { const char *v = getenv("MF_FAKE_DEVICES"); const int k = v ? atoi(v) : 0; return k > 0 && k <= 64 ? k : 0; }();
+    return n;
+}
+static int physical_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+static int phys(int device) { const int n = physical_count(); return fake_devices() && n > 0 ? device % n : device; }
+
 static int get_ctx(int device, DevCtx **out)
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     auto it = g_ctx.find(device);
-    if (it != g_ctx.end()) { *out = &it->second; hipError_t e = hipSetDevice(device); if (e != hipSuccess) return fail(MF_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return MF_OK; }
+    if (it != g_ctx.end()) { *out = &it->second; hipError_t e = hipSetDevice(phys(device)); if (e != hipSuccess) return fail(MF_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return MF_OK; }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible (%s); libmitofilter_hip has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
-    if (device < 0 || device >= n) return fail(MF_E_ARG, "device %d out of range (have %d)", device, n);
+    const int logical = fake_devices() ? fake_devices() : n;
+    if (device < 0 || device >= logical) return fail(MF_E_ARG, "device %d out of range (have %d)", device, logical);
+    const int pdev = phys(device);
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
+    HIPCHK(hipGetDeviceProperties(&prop, pdev));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(MF_E_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
-    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipSetDevice(pdev));
     DevCtx c; c.device = device; c.n_cu = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     {   // the second stream carries the short, latency-bound finish kernels that run under the next screen kernel: highest priority
@@ -288,21 +301,21 @@ int mf_device_count(void)
     hipError_t e = hipGetDeviceCount(&n);
     if (e == hipErrorNoDevice) return 0;
     if (e != hipSuccess) return fail(MF_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
-    return n;
+    return n > 0 && fake_devices() ? fake_devices() : n;
 }
 
 int mf_device_name(int device, char *buf, size_t buflen)
 {
     if (!buf || !buflen) return fail(MF_E_ARG, "bad buffer");
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
+    HIPCHK(hipGetDeviceProperties(&prop, phys(device)));
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return MF_OK;
 }
 
 int mf_device_synchronize(int device)
 {
-    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipSetDevice(phys(device)));
     HIPCHK(hipDeviceSynchronize());
     return MF_OK;
 }
@@ -361,7 +374,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 {
     if (!ks) return MF_OK;
     for (auto &kv : ks->dev) {
-        if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.plut); }
+        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.plut); }
     }
     delete ks;
     return MF_OK;
@@ -401,7 +414,7 @@ static int pass_kind()
 static void reads_release(mf_reads *r)
 {
     if (!r) return;
-    if (hipSetDevice(r->device) == hipSuccess) {
+    if (hipSetDevice(phys(r->device)) == hipSuccess) {
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
         hipFree(r->d_cand);
         for (int i = 0; i < 2; i++) {
@@ -800,7 +813,7 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     QualScanFn scan = [&](const char *text, size_t len, const QualSpan *recs, uint32_t n, uint32_t q, uint32_t *n_count,
                           uint32_t *bad_count, uint64_t *hashes, std::string &err) -> int {
 #define QCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return MF_E_HIP; } } while (0)
-        QCHK(hipSetDevice(device));
+        QCHK(hipSetDevice(phys(device)));
         QCHK(need(d_text, len + 64)); QCHK(need(d_recs, (size_t)n * sizeof(QualSpan))); QCHK(need(d_cnt, (size_t)n * 8));
         if (hashes) QCHK(need(d_hash, (size_t)n * 8));
         QCHK(hipMemcpyAsync(d_text.p, text, len, hipMemcpyHostToDevice, st));

@@ -384,16 +384,21 @@ bool OutFile::write(const char *p, size_t n)
     return true;
 }
 
-// one gzip member per slice of the pending text, compressed side by side, written in order.  No allocation per
-// slice: every worker keeps one deflate state for the whole flush and compresses straight into its slice's place of
+// Gzip output is ONE member, as flate2's GzEncoder writes and GzDecoder (the reference's own reader, helper.rs:22) expects --
+// a single-member reader stops after the first member of a multi-member file -- but it is compressed on many threads the
+// way pigz does it: the pending text is cut into 1 MiB slices, every slice becomes a run of non-final deflate blocks ending
+// on a byte boundary (Z_SYNC_FLUSH from a reset state, so no back-reference crosses a slice), the runs are written in
+// order behind one header, and close() appends an empty final block, the combined CRC-32 and the length.  No allocation
+// per slice: every worker keeps one deflate state for the whole flush and compresses straight into its slice's place of
 // one output buffer that lives as long as the file (fresh mappings per slice made 32 threads queue on the mmap lock).
 bool OutFile::flush_members()
 {
     if (pend_.empty()) return true;
     const size_t slice = (size_t)1 << 20, n = (pend_.size() + slice - 1) / slice;
-    const size_t stride = 18 + slice + slice / 1000 + 64;           // header + deflateBound of a slice + trailer, with room to spare
+    const size_t stride = slice + slice / 1000 + 128;               // deflateBound of a slice plus the sync marker, with room to spare
     if (obuf_.size() < n * stride) obuf_.resize(n * stride);
     std::vector<size_t> olen(n, 0);
+    std::vector<uint32_t> crcs(n, 0);
     std::atomic<size_t> next{0}; std::atomic<int> bad{0};
     auto work = [&] {
         z_stream z; memset(&z, 0, sizeof z);
@@ -401,16 +406,12 @@ bool OutFile::flush_members()
         for (size_t i; (i = next++) < n;) {
             const size_t off = i * slice, len = std::min(slice, pend_.size() - off);
             unsigned char *o = obuf_.data() + i * stride;
-            static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
-            memcpy(o, hdr, 10);
             deflateReset(&z);
             z.next_in = (Bytef *)(pend_.data() + off); z.avail_in = (uInt)len;
-            z.next_out = o + 10; z.avail_out = (uInt)(stride - 18);
-            if (deflate(&z, Z_FINISH) != Z_STREAM_END) { bad = 1; continue; }
-            const size_t clen = z.total_out;
-            const uint32_t crc = (uint32_t)crc32(0, (const Bytef *)(pend_.data() + off), (uInt)len), isz = (uint32_t)len;
-            memcpy(o + 10 + clen, &crc, 4); memcpy(o + 14 + clen, &isz, 4);
-            olen[i] = 18 + clen;
+            z.next_out = o; z.avail_out = (uInt)stride;
+            if (deflate(&z, Z_SYNC_FLUSH) != Z_OK || z.avail_in != 0 || z.avail_out == 0) { bad = 1; continue; }
+            olen[i] = z.total_out;
+            crcs[i] = (uint32_t)crc32(0, (const Bytef *)(pend_.data() + off), (uInt)len);
         }
         deflateEnd(&z);
     };
@@ -421,10 +422,19 @@ bool OutFile::flush_members()
         work();
         for (auto &x : th) x.join();
     }
+    if (bad) { pend_.clear(); return false; }
+    if (!wrote_) {
+        static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+        if (fwrite(hdr, 1, 10, f_) != 10) return false;
+        wrote_ = true;
+    }
+    for (size_t i = 0; i < n; i++) {
+        const size_t len = std::min(slice, pend_.size() - i * slice);
+        crc_ = (uint32_t)crc32_combine(crc_, crcs[i], (z_off_t)len);
+        total_ += len;
+        if (fwrite(obuf_.data() + i * stride, 1, olen[i], f_) != olen[i]) return false;
+    }
     pend_.clear();
-    if (bad) return false;
-    for (size_t i = 0; i < n; i++) if (fwrite(obuf_.data() + i * stride, 1, olen[i], f_) != olen[i]) return false;
-    wrote_ = true;
     return true;
 }
 
@@ -434,9 +444,15 @@ bool OutFile::close()
     bool ok = true;
     if (gz_) {
         ok = flush_members();
-        if (ok && !wrote_) {                                  // no text at all: one empty member, what gzclose leaves behind
-            static const unsigned char empty[20] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            ok = fwrite(empty, 1, 20, f_) == 20;
+        if (ok && !wrote_) {                                  // no text at all: header only so far
+            static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+            ok = fwrite(hdr, 1, 10, f_) == 10;
+        }
+        if (ok) {                                             // empty final block (fixed Huffman, end of block), CRC-32, ISIZE
+            unsigned char tail[10] = {3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t isz = (uint32_t)total_;
+            memcpy(tail + 2, &crc_, 4); memcpy(tail + 6, &isz, 4);
+            ok = fwrite(tail, 1, 10, f_) == 10;
         }
     }
     if (own_) ok = (fclose(f_) == 0) && ok; else ok = (fflush(f_) == 0) && ok;

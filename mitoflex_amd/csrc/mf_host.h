@@ -91,8 +91,9 @@ uint64_t padded_words_for(uint64_t n_words);
 void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &out);
 uint32_t detect_uniform_len(const uint64_t *offsets, uint64_t n_reads);
 
-// Output file, plain or gzip by extension.  Gzip output is written as consecutive members of ~1 MiB of text, compressed
-// on several threads (any gzip reader takes multi-member files; deflate on one thread does ~50 MB/s of text).
+// Output file, plain or gzip by extension.  Gzip output is a single member (what the reference's flate2 GzEncoder writes and
+// its GzDecoder reads) whose deflate blocks are compressed in 1 MiB slices on several threads (deflate on one thread does
+// ~50 MB/s of text).
 class OutFile {
 public:
     ~OutFile();
@@ -102,6 +103,7 @@ public:
 private:
     bool flush_members();
     FILE *f_ = nullptr; bool gz_ = false, own_ = true, wrote_ = false; int threads_ = 1;
+    uint32_t crc_ = 0; uint64_t total_ = 0;                // of the whole member
     std::vector<char, DefaultInitAlloc<char>> pend_;
     std::vector<unsigned char, DefaultInitAlloc<unsigned char>> obuf_;
 };

@@ -316,6 +316,9 @@ bool ParallelGzReader::fill_bgzf(ByteBuf &obuf_, std::string &err, bool &handled
         if (!sz) break;
         Member m; m.cdata = pos + coff; m.cend = pos + sz - 8; m.out_off = total;
         memcpy(&m.crc, data_ + pos + sz - 8, 4); memcpy(&m.isize, data_ + pos + sz - 4, 4);
+        // a BGZF block holds at most 64 KiB of text; a trailer that claims more is damage or not BGZF, and taking its word
+        // would size buffers from a field an input file controls (up to 4 GiB a worker): leave it to the general decoder
+        if (m.isize > 65536) break;
         total += m.isize;
         ms.push_back(m);
         pos += sz;

@@ -151,6 +151,7 @@ public:
         return true;
     }
     void set_parse_threads(int t) { parse_threads_ = t < 1 ? 1 : t; }
+    void set_stop_flag(const std::atomic<bool> *f) { stop_ = f; }
     ~BatchReader() { if (g_) gzclose(g_); if (f_ && own_f_) fclose(f_); }
     // One pass: bytes are read in blocks and lines are cut as they arrive; every fourth line closes a
     // record.  Record fields are kept as offsets while the buffer may still move, pointers afterwards.
@@ -163,7 +164,7 @@ public:
         if (!carry_.empty()) { if (!b.reserve(carry_.size())) { err = "out of memory"; return false; } memcpy(b.text, carry_.data(), carry_.size()); b.len = carry_.size(); carry_.clear(); }
         struct Off { size_t h, s, q; uint32_t hl, sl, ql; };
         std::vector<Off> off; off.reserve(max_records < (1u << 22) ? max_records : (1u << 22));
-        size_t pos = 0, line_start = 0; int li = 0; size_t ls[4]; uint32_t ll[4]; size_t cut = 0; bool full = false;
+        size_t pos = 0, line_start = 0; int li = 0; size_t ls[4]; uint32_t ll[4]; size_t cut = 0, rec_end = 0; bool full = false, short_read = false;
         const size_t blk = 16u << 20;
         for (;;) {
             while (pos < b.len) {
@@ -176,20 +177,19 @@ public:
                 if (++li == 4) {
                     li = 0;
                     off.push_back(Off{ls[0], ls[1], ls[3], ll[0], ll[1], ll[3]});
+                    rec_end = pos;
                     if (off.size() == max_records) { cut = pos; full = true; break; }
                 }
             }
             if (full || eof_) break;
+            // a pipe or stdin whose producer has nothing more right now: hand over the complete records (see next_stream_indexed)
+            if (short_read && !off.empty()) { cut = rec_end; full = true; break; }
+            if (stopped()) return false;
             if (!b.reserve(b.len + blk)) { err = "out of memory"; return false; }
-            size_t got;
-            if (gzmap_) {
-                std::string why;
-                const long n = par_gz_ ? pinflater_.read((uint8_t *)b.text + b.len, blk, why) : inflater_.read((uint8_t *)b.text + b.len, blk, why);
-                if (n < 0) { err = "gzip read error in " + path_ + ": " + why; return false; }
-                got = (size_t)n;
-            }
-            else if (gz_) { int n = gzread(g_, b.text + b.len, (unsigned)blk); if (n < 0) { err = "gzip read error in " + path_; return false; } got = (size_t)n; }
-            else got = fread(b.text + b.len, 1, blk, f_);
+            bool failed = false;
+            const size_t got = read_some(b.text + b.len, blk, err, failed);
+            if (failed) return false;
+            short_read = !gz_ && !gzmap_ && got > 0 && got < blk;
             b.len += got;
             if (got == 0) eof_ = true;
         }
@@ -303,16 +303,27 @@ private:
             return (size_t)n;
         }
         if (gz_) { const int n = gzread(g_, dst, (unsigned)std::min<size_t>(want, (size_t)1 << 30)); if (n < 0) { err = "gzip read error in " + path_; failed = true; return 0; } return (size_t)n; }
-        return fread(dst, 1, want, f_);
+        // plain stream (pipe, stdin; the stream is unbuffered): read() returns what a slow producer has written so far instead
+        // of blocking until `want` bytes are there, so the stop flag is looked at again in good time
+        for (;;) {
+            const ssize_t n = ::read(fileno(f_), dst, std::min<size_t>(want, (size_t)1 << 30));
+            if (n >= 0) return (size_t)n;
+            if (errno != EINTR) { err = "read error in " + path_; failed = true; return 0; }
+        }
     }
+    // the pipeline is winding down (error elsewhere, the -t budget is spent, a mate file ran out): stop reading ahead
+    bool stopped() const { return stop_ && stop_->load(std::memory_order_relaxed); }
     bool next_stream_indexed(MateBatch &b, uint64_t max_records, std::string &err)
     {
         b.recs.clear(); b.len = 0;
         if (!carry_.empty()) { if (!b.reserve(carry_.size())) { err = "out of memory"; return false; } memcpy(b.text, carry_.data(), carry_.size()); b.len = carry_.size(); carry_.clear(); }
         LineIndex ix;
         size_t target = (size_t)((double)max_records * rec_bytes_est_ * 1.02) + 4096;
+        const bool live = !gz_ && !gzmap_;                 // a pipe or stdin: the producer may be slower than we are
         for (;;) {
+            bool short_read = false;
             while (!eof_ && b.len < target) {
+                if (stopped()) return false;
                 const size_t want = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)1 << 16, target - b.len));
                 if (!b.reserve(b.len + want)) { err = "out of memory"; return false; }
                 bool failed = false;
@@ -320,9 +331,12 @@ private:
                 if (failed) return false;
                 b.len += got;
                 if (got == 0) eof_ = true;
+                // the producer has nothing more right now: hand over the records that are complete instead of waiting for a
+                // whole batch (the reference works line by line -- with a -t budget it may never need the rest)
+                if (live && got < want && got > 0) { short_read = true; break; }
             }
             build_index(b.text, b.len, eof_, ix);
-            if (ix.n_records >= max_records || eof_) break;
+            if (ix.n_records >= max_records || eof_ || (short_read && ix.n_records > 0)) break;
             const double per = ix.n_records ? (double)b.len / (double)ix.n_records : rec_bytes_est_ * 2;
             target = b.len + (size_t)((double)(max_records - ix.n_records + 1) * per * 1.05) + ((size_t)1 << 16);
         }
@@ -350,6 +364,7 @@ private:
     ParallelGzReader pinflater_; bool par_gz_ = false;
     std::vector<char> carry_;
     int parse_threads_ = 1;
+    const std::atomic<bool> *stop_ = nullptr;
     std::shared_ptr<MappedFile> map_;
     LineIndex map_ix_; bool indexed_ = false;
     uint64_t rec_pos_ = 0;
@@ -377,7 +392,9 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const uint64_t t_start = now_us();
     BatchReader rd[2];
+    std::atomic<bool> winding_down{false};          // set with the queues' abort: the readers stop reading ahead
     for (int m = 0; m < nm; m++) {
+        rd[m].set_stop_flag(&winding_down);
         rd[m].set_parse_threads(std::max(1, pack_threads / (2 * nm)));     // plain files: segments parsed in parallel
         if (!rd[m].open(in_path[m], err)) return MF_E_IO;
     }
@@ -398,7 +415,7 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
     std::vector<std::unique_ptr<Channel<PairPtr>>> q_dev;
     for (int d = 0; d < n_devices; d++) q_dev.emplace_back(new Channel<PairPtr>(2));
     Channel<PairPtr> q_write[2] = {Channel<PairPtr>(4 * (size_t)n_devices + 4), Channel<PairPtr>(4 * (size_t)n_devices + 4)};
-    auto abort_all = [&] { for (auto &q : q_read) q.abort(); for (auto &q : q_dev) q->abort(); for (auto &q : q_write) q.abort(); };
+    auto abort_all = [&] { winding_down = true; for (auto &q : q_read) q.abort(); for (auto &q : q_dev) q->abort(); for (auto &q : q_write) q.abort(); };
 
     // ---- readers
     std::vector<std::thread> threads;
@@ -439,7 +456,8 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
             idx++;
             if (last) break;                              // mate files of different length: stop at the shorter
         }
-        for (auto &q : q_read) q.abort();                 // readers may still be producing past the end of the shorter file
+        winding_down = true;                              // readers may still be producing past the end of the shorter file
+        for (auto &q : q_read) q.abort();
         for (auto &q : q_dev) q->finish();
     });
 
@@ -604,7 +622,9 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const uint64_t t_start = now_us();
     BatchReader rd[2];
-    for (int m = 0; m < nm; m++) {
+    std::atomic<bool> winding_down{false};          // set when the decision loop stops (budget spent, panic, short mate file, error):
+    for (int m = 0; m < nm; m++) {                  // the reference exits at its `break`, so the readers must not sit in a read
+        rd[m].set_stop_flag(&winding_down);
         rd[m].set_parse_threads(std::max(1, threads / (2 * nm)));
         if (!rd[m].open(in_path[m], err)) return MF_E_IO;
     }
@@ -614,7 +634,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
     auto qual_pool = std::make_shared<Pool<QualBatch>>();
     Channel<std::shared_ptr<MateBatch>> q_read[2] = {Channel<std::shared_ptr<MateBatch>>(2), Channel<std::shared_ptr<MateBatch>>(2)};
     Channel<QualPtr> q_write[2] = {Channel<QualPtr>(4), Channel<QualPtr>(4)};
-    auto abort_all = [&] { for (auto &q : q_read) q.abort(); for (auto &q : q_write) q.abort(); };
+    auto abort_all = [&] { winding_down = true; for (auto &q : q_read) q.abort(); for (auto &q : q_write) q.abort(); };
 
     std::vector<std::thread> th;
     for (int m = 0; m < nm; m++)
@@ -656,8 +676,9 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                     bool bad = false;
                     for (int m = 0; m < nm && !bad; m++) {
                         const FqRec &r = qb->mate[m]->recs[i];
-                        // the line between sequence and quality is also decoded by lines(): it spans [s+sl .. q)
-                        bad = !utf8_ok(r.h, r.hl) || !utf8_ok(r.s, (size_t)(r.q - r.s) + r.ql);
+                        // header, sequence and quality are unwrapped (main.rs:214-216, 287-289) and panic on invalid UTF-8; the
+                        // '+' line is bound to `_` and never unwrapped: lines() yields an Err for it and carries on
+                        bad = !utf8_ok(r.h, r.hl) || !utf8_ok(r.s, r.sl) || !utf8_ok(r.q, r.ql);
                     }
                     if (!bad && P.start) {
                         for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].sl;      // seq1, seq2 first
@@ -726,6 +747,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             if (short_mate) stop = true;
             for (int m = 0; m < nm; m++) if (!q_write[m].push(qb)) { stop = true; break; }
         }
+        winding_down = true;
         for (auto &q : q_read) q.abort();
         for (auto &q : q_write) q.finish();
     });

@@ -216,7 +216,7 @@ def run(argv: List[str], read_file: Callable[[Optional[str]], Optional[bytes]]):
             times = 0
             for i in range(0, len(l1) - 3, 4):
                 head, bps, quas = l1[i], l1[i + 1], l1[i + 3]
-                for x in (l1[i], l1[i + 1], l1[i + 2], l1[i + 3]):
+                for x in (l1[i], l1[i + 1], l1[i + 3]):          # the '+' line is never unwrapped (main.rs:287): invalid UTF-8 there is tolerated
                     x.decode("utf-8")
                 bps = cut(bps); quas = cut(quas)
                 if not trunc:
@@ -236,7 +236,7 @@ def run(argv: List[str], read_file: Callable[[Optional[str]], Optional[bytes]]):
         seen = set()
         counts = 0
         for i in range(0, n - 3, 4):
-            for x in l1[i:i + 4] + l2[i:i + 4]:
+            for x in (l1[i], l1[i + 1], l1[i + 3], l2[i], l2[i + 1], l2[i + 3]):      # (main.rs:214: the '+' lines are bound to `_`)
                 x.decode("utf-8")
             h1, h2 = l1[i], l2[i]
             s1 = cut(l1[i + 1]); s2 = cut(l2[i + 1]); q1 = cut(l1[i + 3]); q2 = cut(l2[i + 3])

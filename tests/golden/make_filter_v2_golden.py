@@ -103,6 +103,9 @@ CASES = [
     ("unknown_option", F1, None, SE + ["-z"]),
     ("missing_input", None, None, ["-1", "{in1}", "-3", "{out1}"]),
     ("invalid_utf8", fq(S1[:3], Q1[:3], "a") + "@b\nAC\xffGT\n+\nIIIII\n", None, SE),
+    ("invalid_utf8_plus_line", fq(S1[:2], Q1[:2], "a") + "@b\nACGTACGA\n+\xff\nIIIIIIII\n" + fq(S1[2:4], Q1[2:4], "c"), None, SE),
+    ("pe_invalid_utf8_plus_line", fq(S1[:3], Q1[:3], "a", plus="+\xfe\xff"), fq(S2[:3], Q2[:3], "b", plus="+\xc3"), PE),
+    ("invalid_utf8_quality", fq(S1[:2], Q1[:2], "a") + "@b\nACGT\n+\nII\xffI\n", None, SE),
     ("empty_input", "", None, SE),
     ("pe_empty_seq", fq(["", "ACGT"], ["", "IIII"]), fq(["ACGT", ""], ["IIII", ""]), PE),
 ]

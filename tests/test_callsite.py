@@ -117,3 +117,42 @@ def test_build_lib_fifo_handoff_plumbing(tmp_path, monkeypatch):
     m.build_lib()
     assert (t2 / "reads.lib").read_text() == f"{tmp_path}/a_1.fq\nse {t2}/pipe.bait1\n"
     assert (t2 / "reads.lib.m1").read_text() == "@r\nACGT\n+\nIIII\n"
+
+
+def test_build_lib_fifo_cleans_up_when_buildlib_fails(tmp_path, monkeypatch):
+    """`megahit_core buildlib` dying must not leave the bait filter blocked on its pipes, nor the pipes in temp_dir: the
+    same temp_dir is usable for a retry."""
+    import pytest
+    from mitoflex_amd.assemble import assemble_wrapper as w
+    stub = tmp_path / "fastfilter"
+    stub.write_text("#!/bin/bash\nwhile [ $# -gt 0 ]; do case $1 in --fq1) a=$2;; --out1) x=$2;; esac; shift; done\n"
+                    "echo $$ > $(dirname $x)/filter.pid\ncat $a > $x; echo 1\n")     # blocks opening the pipe: nobody reads it
+    stub.chmod(0o755)
+    bad_core = tmp_path / "megahit_core"
+    bad_core.write_text("#!/bin/bash\nsleep 0.5\nexit 3\n")       # (the filter is up and blocked on its pipe by then)
+    bad_core.chmod(0o755)
+    (tmp_path / "a_1.fq").write_text("@r\nACGT\n+\nIIII\n")
+    monkeypatch.setattr(w.MEGAHIT, "FAST_FILTER", property(lambda self: str(stub)))
+    monkeypatch.setattr(w.MEGAHIT, "MEGAHIT_CORE", str(bad_core))
+    monkeypatch.setattr(w.a_conf, "bait_fasta", str(tmp_path / "bait.fa"))
+    monkeypatch.setattr(w.a_conf, "bait_fifo", True)
+    t = tmp_path / "t"; t.mkdir()
+    m = w.MEGAHIT(fq1=str(tmp_path / "a_1.fq"), fq2=None, temp_dir=str(t), read_lib=str(t / "reads.lib"))
+    with pytest.raises(RuntimeError):
+        m.build_lib()
+    assert not (t / "pipe.bait1").exists()
+    pid = int((t / "filter.pid").read_text())
+    import time
+    for _ in range(100):                                # the filter's process group is gone
+        try:
+            os.kill(pid, 0)
+            time.sleep(0.02)
+        except ProcessLookupError:
+            break
+    else:
+        raise AssertionError("bait filter still running")
+    good_core = tmp_path / "megahit_core"
+    good_core.write_text(FAKE_CORE)
+    m = w.MEGAHIT(fq1=str(tmp_path / "a_1.fq"), fq2=None, temp_dir=str(t), read_lib=str(t / "reads.lib"))
+    m.build_lib()                                       # the retry in the same temp_dir works
+    assert (t / "reads.lib.m1").read_text() == "@r\nACGT\n+\nIIII\n" and not (t / "pipe.bait1").exists()

@@ -208,3 +208,23 @@ def _check_random(cli, tmp_path, monkeypatch):
         assert rc == erc, (it, argv)
         assert (outs[0] or b"") == (e1 or b""), (it, argv)
         assert (outs[1] or b"") == (e2 or b""), (it, argv)
+
+
+def test_trim_budget_exits_without_waiting_for_a_slow_producer(cli_host_only, tmp_path, monkeypatch):
+    """The reference leaves its loop at the `break` of the -t budget (main.rs:254-259) and exits; the drop-in's reader
+    thread must not sit in a read for the rest of a batch while a slow producer still holds stdin open."""
+    import time
+    monkeypatch.setenv("MITOFILTER_LIB", cli_host_only[1])
+    out = str(tmp_path / "o.fq")
+    recs = "".join("@r%d d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(20)).encode()
+    p = subprocess.Popen([cli_host_only[0], "-3", out, "-t", "25"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0 = time.time()
+    p.stdin.write(recs)
+    p.stdin.flush()                                   # ... and the pipe stays open: the producer is "slow"
+    try:
+        rc = p.wait(timeout=20)
+    finally:
+        p.stdin.close()
+        p.kill()
+    assert rc == 0 and time.time() - t0 < 15
+    assert open(out).read() == "".join("@r%d d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(2))

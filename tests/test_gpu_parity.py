@@ -12,6 +12,7 @@ import pytest
 from tests.util_data import bits_to_bool, make_reads, write_fastq
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -341,3 +342,47 @@ def test_bim_bait_sensitivity(mf, bait_text, tmp_path):
     assert kept <= want                                  # no background pair survives
     assert len(kept) >= 0.99 * len(want)                 # sensitivity on bait-derived pairs
     assert open(o2).read().count("\n") == 4 * len(kept)
+
+
+@pytest.mark.parametrize("n_dev", [2, 4])
+def test_many_logical_devices_match_oracle(ol, bait_text, tmp_path, n_dev):
+    """The multi-device file path (one worker, context, table copy and read set per device; batches dealt round robin and
+    written back in order) on a single-GPU box: MF_FAKE_DEVICES maps N logical devices onto the physical one.  Runs in a
+    child process (the variable is read when the library is loaded) through the `fastfilter bait` CLI."""
+    import subprocess
+    s1 = make_reads(bait_text, 4000, seed=5)
+    s2 = make_reads(bait_text, 4000, seed=6)
+    fq1, fq2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    write_fastq(fq1, s1, "a")
+    write_fastq(fq2, s2, "b")
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+    ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
+    g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
+    cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
+    env = dict(os.environ, MF_FAKE_DEVICES=str(n_dev), MF_BATCH_READS="300")
+    p = subprocess.run([cli, "bait", "--bait", bait, "-k", "31", "--fq1", fq1, "--fq2", fq2, "--out1", g1, "--out2", g2,
+                        "--devices", str(n_dev)], capture_output=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[:2000]
+    assert int(p.stdout.decode().split()[0]) == ok and ot == 4000
+    assert open(g1, "rb").read() == open(o1, "rb").read()
+    assert open(g2, "rb").read() == open(o2, "rb").read()
+
+
+def test_bench_two_ranks_under_torchrun(tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with two ranks
+    sharing the one visible GPU: the launcher's environment, the /dev/shm rendezvous, per-rank shards and rank 0's JSON line."""
+    import json
+    import subprocess
+    import sys
+    port = 29000 + os.getpid() % 2000
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--reads", "2000000", "--no-exhaustive"], capture_output=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["extra"]["reads_per_gpu"] == 2000000 and 0.003 < d["extra"]["passed"] / 2000000 < 0.008

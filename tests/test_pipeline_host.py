@@ -85,3 +85,24 @@ def test_pipeline_with_stand_in_filter(data, tmp_path, flags):
     kept = sum(s[:1] in ("A", "a") for s in s1)
     assert p.stdout.decode().split() == [str(kept), str(len(s1))] and "Sanitizer" not in p.stderr.decode()
     assert gzip.open(o, "rt", newline="").read().count("\n") == 4 * kept
+
+
+@pytest.mark.parametrize("flags", [(), ("-fsanitize=thread",)], ids=["plain", "tsan"])
+def test_pipeline_many_devices(data, tmp_path, flags):
+    """N device workers with randomised delays (batches come back out of order): output bytes and counts equal the
+    single-device run's, for paired and single-end input."""
+    d, s1, s2 = data
+    exe = build(str(tmp_path), flags)
+    kept, total, w1, w2 = expected(d, s1, s2, False)
+    for ext in (".fq", ".fq.gz"):
+        for n_dev in (1, 2, 4, 8):
+            o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+            p = subprocess.run([exe, str(d / ("a_1" + ext)), str(d / ("a_2" + ext)), o1, o2, "300", "4", "either", str(n_dev)], capture_output=True)
+            err = p.stderr.decode()
+            assert "Sanitizer" not in err and "runtime error" not in err, err[:2000]
+            assert p.stdout.decode().split() == [str(kept), str(total)], (ext, n_dev, p.stdout, err[:500])
+            assert open(o1, newline="").read() == w1 and open(o2, newline="").read() == w2, (ext, n_dev)
+    o = str(tmp_path / "se.fq")
+    p = subprocess.run([exe, str(d / "a_1.fq"), "-", o, "-", "250", "3", "either", "5"], capture_output=True)
+    assert "Sanitizer" not in p.stderr.decode()
+    assert p.stdout.decode().split() == [str(sum(s[:1] in ("A", "a") for s in s1)), str(len(s1))]

@@ -1,0 +1,50 @@
+"""Multi-GPU path: ranks are independent -- every rank filters its own shard of whole pairs and there
+is no collective -- so all bench.py needs from the launcher is RANK / WORLD_SIZE plus a barrier and a max over ranks,
+which go through a directory in /dev/shm (no torch, no process group).  Covered here on CPU with two and four
+processes; the GPU suite runs bench.py itself under torch.distributed.run with two ranks on one device
+(tests/test_gpu_parity.py::test_bench_two_ranks_under_torchrun)."""
+import multiprocessing as mp
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TORCHELASTIC_RUN_ID"] = "pytest%d" % port
+    import bench
+    r = bench.ShmRendezvous(rank, world)
+    got = []
+    for i in range(5):
+        got.append(r.allmax(float(rank * 10 + i)))       # max over ranks of a rank-dependent value
+        r.barrier()
+    r.close()
+    q.put((rank, got))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shm_rendezvous(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 20000 + os.getpid() % 20000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r] == [float((world - 1) * 10 + i) for i in range(5)]
+    assert not any(n.startswith("mf_bench_%d_pytest%d" % (port, port)) for n in os.listdir("/dev/shm"))
+
+
+def test_bench_workloads_follow_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.READS_5GBP * 150 == pytest.approx(5e9, rel=1e-6) and bench.READS_5GBP % 2 == 0
+    assert bench.READS_50GBP_8 * 8 * 150 == pytest.approx(50e9, rel=1e-6) and bench.READS_50GBP_8 % 2 == 0
