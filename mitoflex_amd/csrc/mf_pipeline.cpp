@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <fcntl.h>
+#include <poll.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -306,9 +307,13 @@ private:
         // plain stream (pipe, stdin; the stream is unbuffered): read() returns what a slow producer has written so far instead
         // of blocking until `want` bytes are there, so the stop flag is looked at again in good time
         for (;;) {
+            struct pollfd pfd; pfd.fd = fileno(f_); pfd.events = POLLIN; pfd.revents = 0;
+            const int pr = poll(&pfd, 1, 50);                 // a blocked read() cannot be told to stop; a poll that times out can
+            if (stopped()) { failed = true; return 0; }       // (no error text: the pipeline is winding down for its own reasons)
+            if (pr == 0) continue;
             const ssize_t n = ::read(fileno(f_), dst, std::min<size_t>(want, (size_t)1 << 30));
             if (n >= 0) return (size_t)n;
-            if (errno != EINTR) { err = "read error in " + path_; failed = true; return 0; }
+            if (errno != EINTR && errno != EAGAIN) { err = "read error in " + path_; failed = true; return 0; }
         }
     }
     // the pipeline is winding down (error elsewhere, the -t budget is spent, a mate file ran out): stop reading ahead
