@@ -78,9 +78,13 @@ class ShmRendezvous:
 
     barrier = allmax
 
-    def close(self):
+    def close(self, timeout=120.0):
         self.allmax()
-        if self.rank == 0:
+        open(os.path.join(self.dir, "done.%d" % self.rank), "w").close()       # this rank has read everything it will ever read here
+        if self.rank == 0:                                                      # ... so rank 0 may take the directory away once all have
+            t0 = time.time()
+            while not all(os.path.exists(os.path.join(self.dir, "done.%d" % r)) for r in range(self.world)) and time.time() - t0 < timeout:
+                time.sleep(0.001)
             import shutil
             shutil.rmtree(self.dir, ignore_errors=True)
 

@@ -335,8 +335,10 @@ def test_bim_bait_sensitivity(mf, bait_text, tmp_path):
     fq1, fq2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
     write_fastq(fq1, m1, "p"); write_fastq(fq2, m2, "p")
     bait = str(tmp_path / "seed.fa"); open(bait, "w").write(bait_text)
-    bam, o1, o2 = kmer_bait_map(8, bait, str(tmp_path), "gen0", fq1, fq2)
-    assert bam is None and o1.endswith("gen0.1.fq") and o2.endswith("gen0.2.fq")
+    stats, o1, o2 = kmer_bait_map(8, bait, str(tmp_path), "gen0", fq1, fq2)
+    assert stats.endswith("gen0.bait.stats") and o1.endswith("gen0.1.fq") and o2.endswith("gen0.2.fq")
+    from mitoflex_amd.bim.bim import cal_insert
+    assert 398 < cal_insert(stats, str(tmp_path), "gen0") < 402          # every fragment above is 400 bases long
     kept = {ln[1:].split()[0] for ln in open(o1).read().split("\n")[0::4] if ln}
     want = {f"p{i}" for i, t in enumerate(truth) if t}
     assert kept <= want                                  # no background pair survives
@@ -379,7 +381,7 @@ def test_bench_two_ranks_under_torchrun(tmp_path):
     port = 29000 + os.getpid() % 2000
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--reads", "2000000", "--no-exhaustive"], capture_output=True, timeout=900, cwd=str(tmp_path))
+                        "--reads", "2000000", "--no-exhaustive"], capture_output=True, timeout=300, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
