@@ -83,12 +83,14 @@ typedef struct {
 typedef struct {
     uint64_t n_reads;
     uint64_t n_pass;
-    uint64_t n_candidates;   /* reads handed to the exact kernel (screened mode) */
-    float    ms_total;       /* hipEvent time, first launch -> last kernel end  */
-    float    ms_screen;      /* screen kernel only (streams every packed byte once); the three kernel times come from
+    uint64_t n_candidates;   /* screened mode: reads handed to the exact kernel -- or, for threshold 1 without hit counts (the
+                                finish-kernel pass), stage-1 positives that were looked up (work items, not reads) */
+    float    ms_total;       /* hipEvent time per pass, first launch -> last kernel end, averaged over the passes of the call
+                                (consecutive threshold-1 passes overlap: finish kernels run under the next screen kernel) */
+    float    ms_screen;      /* screen kernel only (streams every packed byte once); the kernel times come from
                                 events attached to the dispatches themselves (hipExtLaunchKernelGGL start/stop) */
-    float    ms_mark;        /* mark kernel: finishes the screen's positives, sets candidate bits */
-    float    ms_exact;       /* exact kernel only */
+    float    ms_mark;        /* mark kernel: finishes the screen's positives, sets candidate bits (0 in the finish-kernel pass) */
+    float    ms_exact;       /* exact kernel -- or the first (run) phase of the finish kernel */
     uint64_t algorithmic_bytes; /* ceil(2*bases/8) + ceil(n_reads/8): SURVEY.md 8d byte model */
 } mf_filter_stats_t;
 

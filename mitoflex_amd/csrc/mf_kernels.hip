@@ -1,24 +1,26 @@
 // HIP kernels of libmitofilter_hip for gfx950 (MI355X, CDNA4; 64-wide waves).
 //
-//   screen_kernel   streams the dense 2-bit read stream once from HBM with
-//                   16-byte coalesced loads, probes stream-aligned s-mers in a
-//                   blocked bit table held in LDS, verifies the few positives
-//                   against an exact s-mer table in L2 and marks candidate
-//                   reads.  Pure integer/indexing work, HBM-bound by design.
-//   exact_kernel    one wave per candidate read: every lane extracts one
-//                   k-mer, canonicalises it, probes the open-address bait
-//                   table; hits are reduced with wave ballot + popcount and
-//                   compared with the threshold.  With no candidate bitmap it
-//                   scans every read (exhaustive mode).
-//   build_*         device-side bait set builder (history-independent table).
+//   screen_kernel   streams the dense 2-bit read stream once from HBM with 16-byte coalesced non-temporal loads and
+//                   tests every stream-aligned s-mer in a blocked bit table held in LDS (stage 1).  A lane with a
+//                   positive only RECORDS it (16 bytes: chunk, lane, hit mask) -- no dependent load, no returning
+//                   atomic, no division in the streaming loop.  Pure integer/indexing work, HBM-bound by design.
+//   finish_kernel   threshold 1, no hit counts (the default pass): one thread per record, two launches.  Phase 0 tries the
+//                   first run of neighbouring positives of every record -- one canonical k-mer, one probe of the
+//                   open-address bait table; phase 1 settles what is left (exact s-mer table, then the sixteen windows a
+//                   sample owns).  A pass is an atomicOr.  Runs on a second stream under the next pass's screen kernel.
+//   mark_kernel     any threshold / hit counts: groups a record's positives by read, verifies lone ones (stage 2: Bloom over
+//                   canonical s-mers in L2; stage 3 for large baits: exact s-mer table) and sets candidate bits.
+//   exact_kernel    any threshold / hit counts, and the exhaustive mode: k-mer extract -> canonicalise -> LDS bit table ->
+//                   open-address table in L2 -> threshold, for candidate reads (or every read); a candidate's k-mer positions
+//                   are dealt to the lanes of a wave sixteen at a time, per-read counts live in LDS.
+//   build_*         device-side bait set builder (history-independent table), screen tables, k-mer bit table.
+//   qualscan_kernel / seqhash_kernel   the FASTQ quality filter's counts and SipHash-1-3 (filter_v2 drop-in).
 //
-// Why the screen is exact (not a heuristic): a read can only have a k-mer hit
-// if some window of k bases equals a bait k-mer (either strand).  That window
-// fully contains a stream-aligned s-mer (k >= s + stride - 1), and that s-mer,
-// read as it lies in the stream, is an s-mer of the bait or of its reverse
-// complement -- both are in the s-mer set.  So "no sampled s-mer of the read
-// is in the set" proves hits == 0 < T.  Reads that survive the screen get the
-// full per-k-mer count, so the emitted bits equal the brute-force oracle's.
+// Why the screen is exact (not a heuristic): a read can only have a k-mer hit if some window of k bases equals a bait
+// k-mer (either strand).  That window fully contains a stream-aligned s-mer (k >= s + stride - 1), and that s-mer, read
+// as it lies in the stream, is an s-mer of the bait or of its reverse complement -- both are in the stage-1 table.  So
+// "no sampled s-mer of the read is positive" proves hits == 0 < T, and every read with a positive is decided exactly
+// (finish_kernel or exact_kernel), so the emitted bits equal the brute-force oracle's.
 #include "mf_common.h"
 #include "mf_kernels.h"
 #include <hip/hip_ext.h>
@@ -76,18 +78,13 @@ __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
 }
 
 // ------------------------------------------------------------ screen kernel
-// LDS image: [stage-1 blocks | stage-2 words].
-//   stage 1 (every sampled s-mer, in the hot loop): one ds_read_b128 of the
-//     s-mer's 128-bit block, test one bit in each dword.  Both strands of the
-//     bait are inserted, so the s-mer is used exactly as it lies in the stream.
-//   stage 2 (lanes with a stage-1 positive, a few per wave per chunk): classic
-//     Bloom probes of the canonical s-mer, still LDS only.
-//   stage 3 (what survives: true s-mer matches and ~1e-6 of the rest): exact
-//     ordered s-mer table in global memory, then the candidate bit of the read.
-// Global memory is therefore touched in the loop only by the streaming loads
-// and by (near-)true hits; an LDS false positive never costs a vmcnt stall.
+// LDS image: the stage-1 table only (up to 128 KiB of the CU's 160) and the record counter.
+//   stage 1 (every sampled s-mer, in the hot loop): one ds_read_b128 of the s-mer's 128-bit block, one bit tested in each
+//     dword.  Both strands of the bait are inserted, so the s-mer is used exactly as it lies in the stream.
+//   Positives are recorded, not followed up: the later stages (finish_kernel, or mark_kernel's stage 2 / 3) run in their
+//   own launches, so global memory is touched in the loop only by the streaming loads and the record stores.
 // SPW = samples per u32 word (1: stride 16 bases, 2: stride 8 bases)
-// U   = uint4 loads in flight per lane per chunk
+// U   = uint4 loads per lane per chunk (two chunks are in flight: the one being examined and the next)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // pointers that keep the LDS address space (a generic pointer to LDS compiles to flat_* instructions, which count
