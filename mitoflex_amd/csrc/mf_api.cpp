@@ -395,7 +395,11 @@ struct mf_reads {
     void *d_recs[2] = {nullptr, nullptr}; uint32_t *d_rec_counts[2] = {nullptr, nullptr};     // stage-1 positive records (screen -> finish / mark)
     unsigned long long *d_counters[2] = {nullptr, nullptr};                                    // 2 * EXACT_MAX_GRID tally pairs each
     hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_finish[2] = {nullptr, nullptr};           // ordering between the two streams
-    bool cand_clean = false, sample_pass = false;     // sample_pass: the latest pass was a screen + finish + park one
+    bool cand_clean = false, sample_pass = false;     // sample_pass: the latest pass was a screen + finish one
+    // Bait-rich input (more than a few per cent of the reads are bait reads -- what the `bim` loop enriches towards) is better
+    // served by the candidate-bitmap pass: one thread per stage-1 record means several records per bait read, and the screen
+    // writes them all.  The choice follows the work the last call of this read set (the last batch of this device) saw.
+    bool prefer_split = false;
     int cur = 0;
     size_t bitmap_bytes = 0;
     // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
@@ -620,7 +624,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         return MF_OK;
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
-    if (screened && pass_kind() != 1 && !force_split && thr == 1 && !count_all) {
+    if (screened && pass_kind() != 1 && !force_split && !r->prefer_split && thr == 1 && !count_all) {
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
@@ -693,6 +697,10 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     HIPCHK(hipStreamSynchronize(st));
     unsigned long long cnt[2] = {0, 0};
     for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
+    if (!T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && r->v.n_reads >= 100000) {
+        if (r->sample_pass) { if (cnt[1] > r->v.n_reads / 5) r->prefer_split = true; }            // work items per read: ~0.03 at 0.5 % bait reads, 0.5 at 10 %
+        else if (r->prefer_split && cnt[1] < r->v.n_reads / 25) r->prefer_split = false;           // candidate reads per read
+    }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         float tot = 0, scr = 0, mrk = 0, exa = 0, t;

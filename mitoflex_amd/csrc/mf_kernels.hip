@@ -1348,11 +1348,12 @@ hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *r
     if (lists == 0) return hipSuccess;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu);
     const ScreenRec *rc = static_cast<const ScreenRec *>(recs);
-    const KernelTiming *none = nullptr;
+    static const bool time_phase1 = getenv("MF_TIME_PHASE1") != nullptr;          // the one event pair goes to phase 0 unless asked otherwise
+    const KernelTiming *none = nullptr, *tm0 = time_phase1 ? none : tm, *tm1 = time_phase1 ? tm : none;
 #define MF_LAUNCH_FINISH(SPW, KW) do { \
-        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm, R, S, rc, cap, rec_counts, \
+        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm0, R, S, rc, cap, rec_counts, \
                   (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); \
-        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 1>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, none, R, S, rc, cap, rec_counts, \
+        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 1>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm1, R, S, rc, cap, rec_counts, \
                   (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); } while (0)
     if (S.stride == 16) { if (S.kw == 1) MF_LAUNCH_FINISH(1, 1); else MF_LAUNCH_FINISH(1, 2); }
     else                { if (S.kw == 1) MF_LAUNCH_FINISH(2, 1); else MF_LAUNCH_FINISH(2, 2); }
