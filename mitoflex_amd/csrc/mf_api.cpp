@@ -624,7 +624,8 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         return MF_OK;
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
-    if (screened && pass_kind() != 1 && !force_split && !r->prefer_split && thr == 1 && !count_all) {
+    // (stride-8 geometries, k < 28: twice the samples, several times the records -- measured faster through the candidate bitmap)
+    if (screened && pass_kind() != 1 && !force_split && !r->prefer_split && thr == 1 && !count_all && (S.stride == 16 || pass_kind() == 2)) {
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
