@@ -1,16 +1,19 @@
 #!/bin/bash
 # Round-end evidence run on the GPU box: gpu tests, bench line, rocprofv3 kernel stats, PMC traffic.
 # Usage (from the build container):  gpurun --timeout 2400 -- ./tools/profile_round.sh r01
-R=$GRAFT_REPO_ROOT; TAG=${1:-r01}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
-for k in 21 41; do timeout 300 python bench.py --k $k --steps 20 --cpu-sample 0 > $OUT/bench_k$k.json 2>> $OUT/bench.err; done
+for k in 21 41; do timeout 300 python bench.py --k $k --steps 20 --cpu-sample 0 --e2e-pairs 0 > $OUT/bench_k$k.json 2>> $OUT/bench.err; done
+MF_PASS=split timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-exhaustive > $OUT/bench_split_pass.json 2>> $OUT/bench.err
+MF_PASS=serial timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-exhaustive > $OUT/bench_serial_pass.json 2>> $OUT/bench.err
+timeout 300 python tools/bait_fraction_sweep.py > $OUT/bait_fraction.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 > $OUT/trace_bench.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null; cat $OUT/kernel_stats.csv
 pmc() { name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exhaustive > /dev/null 2> $OUT/pmc_$name.err
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 > /dev/null 2> $OUT/pmc_$name.err
   python3 - $(find $OUT/pmc_$name -name "*counter_collection.csv" | head -1) <<'PY' | tee -a $OUT/pmc_summary.txt
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -18,7 +21,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name'].split('(')[0].split('::')[-1][:40]
     agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
-    if any(x in k for x in ('screen_kernel', 'exact_kernel', 'mark_kernel')):
+    if any(x in k for x in ('screen_kernel', 'exact_kernel', 'mark_kernel', 'finish_kernel')):
         print(k, {c: '%.5g' % (sum(v)/len(v)) for c, v in d.items()}, 'launches=%d' % len(next(iter(d.values()))))
 PY
 }
