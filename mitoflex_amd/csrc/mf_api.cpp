@@ -53,10 +53,12 @@ static int fake_devices()
 static int physical_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 static int phys(int device) { const int n = physical_count(); return fake_devices() && n > 0 ? device % n : device; }
 
-static int get_ctx(int device, DevCtx **out)
+// lane: a device can have several independent contexts (own streams); the file pipeline runs two workers per device so
+// that the host-to-device copy of one batch overlaps the kernels and the read-back of the other
+static int get_ctx(int device, DevCtx **out, int lane = 0)
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    auto it = g_ctx.find(device);
+    auto it = g_ctx.find(device + 4096 * lane);
     if (it != g_ctx.end()) { *out = &it->second; hipError_t e = hipSetDevice(phys(device)); if (e != hipSuccess) return fail(MF_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return MF_OK; }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -76,8 +78,8 @@ static int get_ctx(int device, DevCtx **out)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
     }
-    g_ctx[device] = c;
-    *out = &g_ctx[device];
+    g_ctx[device + 4096 * lane] = c;
+    *out = &g_ctx[device + 4096 * lane];
     return MF_OK;
 }
 
@@ -384,7 +386,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 
 // -------------------------------------------------------------------- reads
 struct mf_reads {
-    int device = 0;
+    int device = 0, lane = 0;     // lane: which of the device's contexts (streams) this read set works on
     ReadsView v{};
     uint32_t *d_words = nullptr; uint64_t *d_offsets = nullptr, *d_npos = nullptr;
     uint32_t *d_has_n = nullptr, *d_hits = nullptr, *d_npos_blk = nullptr;
@@ -664,7 +666,7 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     if (thr < 1) return fail(MF_E_ARG, "threshold must be >= 1");
     if (mode != MF_MODE_SCREENED && mode != MF_MODE_EXHAUSTIVE) return fail(MF_E_ARG, "bad mode %d", mode);
     if (steps < 1) return fail(MF_E_ARG, "steps must be >= 1");
-    DevCtx *ctx; int rc = get_ctx(r->device, &ctx); if (rc) return rc;
+    DevCtx *ctx; int rc = get_ctx(r->device, &ctx, r->lane); if (rc) return rc;
     DevTables *T; rc = build_on_device(ks, r->device, &T); if (rc) return rc;
     hipStream_t st = ctx->stream;
     const bool count_all = hits_out != nullptr;
@@ -768,25 +770,34 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     pack_threads = (int)env_u32("MF_PACK_THREADS", (uint32_t)pack_threads);
     if (pack_threads < 1) pack_threads = 1;
     const uint64_t batch_reads = env_u32("MF_BATCH_READS", 2000000);
-    // one refillable device-side read set per device worker: steady-state batches do not touch the allocator
-    std::vector<mf_reads *> arena((size_t)n_devices, nullptr);
-    BatchFilterFn fn = [ks, threshold, &arena](int device, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
+    // Host-to-device overlap (configs[4]: "host-decompress overlapped with H2D on a side HIP stream").  The packers write
+    // straight into pinned memory (hipHostMalloc through mf_host's DMA allocator), so a batch goes up as one asynchronous DMA;
+    // and every device is served by TWO workers, each with its own stream pair and refillable device-side read set
+    // (steady-state batches do not touch the allocator): while one worker's batch is in its kernels and read-back, the
+    // other's is being copied up on its own stream -- and the readers, inflaters and packers of later batches run all along.
+    set_dma_allocator([](size_t bytes) -> void * { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess ? p : nullptr; },
+                      [](void *p) { (void)hipHostFree(p); });
+    const int lanes = (int)env_u32("MF_WORKERS_PER_DEVICE", 2) < 1 ? 1 : (int)env_u32("MF_WORKERS_PER_DEVICE", 2);
+    const int n_workers = n_devices * lanes;
+    std::vector<mf_reads *> arena((size_t)n_workers, nullptr);
+    BatchFilterFn fn = [ks, threshold, n_devices, &arena](int worker, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
         bits.assign((n + 31) / 32 + 1, 0);
         if (n == 0) return MF_OK;
-        DevCtx *ctx; int rc = get_ctx(device, &ctx);
-        if (rc == MF_OK && !arena[device]) {
-            arena[device] = new (std::nothrow) mf_reads();
-            if (!arena[device]) rc = fail(MF_E_NOMEM, "out of memory"); else arena[device]->device = device;
+        const int device = worker % n_devices, lane = worker / n_devices;
+        DevCtx *ctx; int rc = get_ctx(device, &ctx, lane);
+        if (rc == MF_OK && !arena[worker]) {
+            arena[worker] = new (std::nothrow) mf_reads();
+            if (!arena[worker]) rc = fail(MF_E_NOMEM, "out of memory"); else { arena[worker]->device = device; arena[worker]->lane = lane; }
         }
         if (rc == MF_OK)
-            rc = reads_fill(arena[device], true, P.words.data(), P.n_words, true, P.offsets.data(), n, P.offsets[n], P.uniform_len,
+            rc = reads_fill(arena[worker], true, P.words.data(), P.n_words, true, P.offsets.data(), n, P.offsets[n], P.uniform_len,
                             P.npos.data(), P.npos.size(), ctx);
-        if (rc == MF_OK) rc = filter_common(ks, arena[device], threshold, MF_MODE_SCREENED, bits.data(), nullptr, 1, nullptr);
+        if (rc == MF_OK) rc = filter_common(ks, arena[worker], threshold, MF_MODE_SCREENED, bits.data(), nullptr, 1, nullptr);
         if (rc != MF_OK) err = t_err;
         return rc;
     };
     PipelineStats ps; std::string perr;
-    const int rc = run_fastq_pipeline(fq1, fq2, out1, out2, pair_mode == MF_PAIR_BOTH, n_devices, pack_threads, batch_reads, fn, ps, perr);
+    const int rc = run_fastq_pipeline(fq1, fq2, out1, out2, pair_mode == MF_PAIR_BOTH, n_workers, pack_threads, batch_reads, fn, ps, perr);
     {
         const auto t0 = std::chrono::steady_clock::now();
         for (mf_reads *a : arena) reads_release(a);

@@ -1,5 +1,7 @@
 // Host-side parsing and packing for libmitofilter_hip.  See mf_host.h.
 #include "mf_host.h"
+#include <mutex>
+#include <unordered_set>
 #include "mf_kernels_cfg.h"
 
 #include <algorithm>
@@ -360,6 +362,35 @@ void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &ou
     std::vector<std::vector<uint64_t>> np(threads);
     run([&](int t) { pack_range(recs, lo_of(t), lo_of(t + 1), out.offsets.data(), W, np[t]); });
     for (auto &v : np) out.npos.insert(out.npos.end(), v.begin(), v.end());   // ranges ascend with t
+}
+
+// ------------------------------------------------------------------ DMA-able blocks
+static std::mutex g_dma_mu;
+static void *(*g_dma_alloc)(size_t) = nullptr;
+static void (*g_dma_release)(void *) = nullptr;
+static std::unordered_set<void *> g_dma_blocks;
+
+void set_dma_allocator(void *(*alloc)(size_t), void (*release)(void *))
+{
+    std::lock_guard<std::mutex> lk(g_dma_mu);
+    g_dma_alloc = alloc; g_dma_release = release;
+}
+void *dma_block_alloc(size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_dma_mu);
+    if (!g_dma_alloc) return nullptr;
+    void *p = g_dma_alloc(bytes);
+    if (p) g_dma_blocks.insert(p);
+    return p;
+}
+bool dma_block_free(void *p)
+{
+    std::lock_guard<std::mutex> lk(g_dma_mu);
+    auto it = g_dma_blocks.find(p);
+    if (it == g_dma_blocks.end()) return false;
+    g_dma_blocks.erase(it);
+    if (g_dma_release) g_dma_release(p);
+    return true;
 }
 
 // ------------------------------------------------------------------ output

@@ -75,8 +75,24 @@ template <class T> struct DefaultInitAlloc : std::allocator<T> {
     template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
 };
-using WordVec = std::vector<uint32_t, DefaultInitAlloc<uint32_t>>;
-using U64Vec = std::vector<uint64_t, DefaultInitAlloc<uint64_t>>;
+// Buffers the device reads by DMA (packed words, offsets): when the GPU library has registered a pinned-memory allocator
+// (hipHostMalloc; mf_api.cpp does, the CPU-only test builds do not) their large blocks come from it, so that the
+// host-to-device copy of a batch is an asynchronous DMA straight from where the packer wrote, not a staged pageable copy.
+void set_dma_allocator(void *(*alloc)(size_t), void (*release)(void *));
+void *dma_block_alloc(size_t bytes);        // nullptr: no allocator registered (or it failed) -- use the ordinary one
+bool dma_block_free(void *p);               // false: p is not one of ours
+template <class T> struct DmaInitAlloc : DefaultInitAlloc<T> {
+    template <class U> struct rebind { using other = DmaInitAlloc<U>; };
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= ((size_t)4 << 20)) { if (void *p = dma_block_alloc(bytes)) return static_cast<T *>(p); }
+        return DefaultInitAlloc<T>::allocate(n);
+    }
+    void deallocate(T *p, size_t n) noexcept { if (!dma_block_free(p)) DefaultInitAlloc<T>::deallocate(p, n); }
+};
+using WordVec = std::vector<uint32_t, DmaInitAlloc<uint32_t>>;
+using U64Vec = std::vector<uint64_t, DmaInitAlloc<uint64_t>>;
 
 struct PackedHost {
     WordVec words;                  // padded (see pad_words_for); every word is written by pack_records
