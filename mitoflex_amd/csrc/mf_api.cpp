@@ -385,6 +385,8 @@ int mf_kmerset_free(mf_kmerset *ks)
 } // extern "C"
 
 // -------------------------------------------------------------------- reads
+// Buffer sets a pipelined pass rotates through (a third set, or a second finish stream, changed nothing measurable).
+constexpr int NSETS = 2;
 struct mf_reads {
     int device = 0, lane = 0;     // lane: which of the device's contexts (streams) this read set works on
     ReadsView v{};
@@ -392,11 +394,11 @@ struct mf_reads {
     uint32_t *d_has_n = nullptr, *d_hits = nullptr, *d_npos_blk = nullptr;
     // Threshold-1 passes (screen_kernel + finish_kernel) are pipelined: the finish kernel of pass i runs on a second stream
     // under the screen kernel of pass i + 1, the way consecutive batches of a file do.  What a pass writes therefore
-    // exists twice and alternates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.
-    uint32_t *d_cand = nullptr, *d_bits[2] = {nullptr, nullptr};
-    void *d_recs[2] = {nullptr, nullptr}; uint32_t *d_rec_counts[2] = {nullptr, nullptr};     // stage-1 positive records (screen -> finish / mark)
-    unsigned long long *d_counters[2] = {nullptr, nullptr};                                    // 2 * EXACT_MAX_GRID tally pairs each
-    hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_finish[2] = {nullptr, nullptr};           // ordering between the two streams
+    // exists NSETS times and rotates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.
+    uint32_t *d_cand = nullptr, *d_bits[NSETS] = {};
+    void *d_recs[NSETS] = {}; uint32_t *d_rec_counts[NSETS] = {};     // stage-1 positive records (screen -> finish / mark)
+    unsigned long long *d_counters[NSETS] = {};                       // 2 * EXACT_MAX_GRID tally pairs each
+    hipEvent_t ev_screen[NSETS] = {}, ev_finish[NSETS] = {};          // ordering between the two streams
     bool cand_clean = false, sample_pass = false;     // sample_pass: the latest pass was a screen + finish one
     // Bait-rich input (more than a few per cent of the reads are bait reads -- what the `bim` loop enriches towards) is better
     // served by the candidate-bitmap pass: one thread per stage-1 record means several records per bait read, and the screen
@@ -423,7 +425,7 @@ static void reads_release(mf_reads *r)
     if (hipSetDevice(phys(r->device)) == hipSuccess) {
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
         hipFree(r->d_cand);
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < NSETS; i++) {
             hipFree(r->d_bits[i]); hipFree(r->d_recs[i]); hipFree(r->d_rec_counts[i]); hipFree(r->d_counters[i]);
             if (r->ev_screen[i]) hipEventDestroy(r->ev_screen[i]);
             if (r->ev_finish[i]) hipEventDestroy(r->ev_finish[i]);
@@ -472,10 +474,11 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     RCHK(launch_build_npos_blk(r->d_npos, n_npos, n_blk, r->d_npos_blk, st));
     r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;
     if (r->bitmap_bytes > r->cap_bitmap || !r->d_has_n) {     // the four bitmaps share one capacity
-        size_t c[4] = {0, 0, 0, 0};
-        uint32_t **bm[4] = {&r->d_has_n, &r->d_cand, &r->d_bits[0], &r->d_bits[1]};
+        size_t c[2 + NSETS] = {};
+        uint32_t **bm[2 + NSETS] = {&r->d_has_n, &r->d_cand};
+        for (int i = 0; i < NSETS; i++) bm[2 + i] = &r->d_bits[i];
         size_t least = ~(size_t)0;
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 2 + NSETS; i++) {
             if (*bm[i]) { hipFree(*bm[i]); *bm[i] = nullptr; }
             RCHK(dev_reserve(*bm[i], c[i], r->bitmap_bytes, reuse));
             if (c[i] < least) least = c[i];
@@ -485,12 +488,12 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
     RCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
     r->cand_clean = true;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NSETS; i++) {
         if (!r->d_counters[i]) RCHK(hipMalloc(&r->d_counters[i], 2 * EXACT_MAX_GRID * 16));
         RCHK(hipMemsetAsync(r->d_counters[i], 0, 2 * EXACT_MAX_GRID * 16, st));
         RCHK(hipMemsetAsync(r->d_bits[i], 0, r->bitmap_bytes, st));
-        if (!r->ev_screen[i]) RCHK(hipEventCreateWithFlags(&r->ev_screen[i], hipEventDisableTiming));
-        if (!r->ev_finish[i]) RCHK(hipEventCreateWithFlags(&r->ev_finish[i], hipEventDisableTiming));
+        if (!r->ev_screen[i]) RCHK(hipEventCreate(&r->ev_screen[i]));         // (attached to dispatches as completion events)
+        if (!r->ev_finish[i]) RCHK(hipEventCreate(&r->ev_finish[i]));
     }
     r->cur = 0;
     ReadsView &V = r->v;
@@ -506,9 +509,8 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
         size_t c0 = r->cap_recs, c1 = r->cap_rec_counts;
         RCHK(dev_reserve(r->d_recs[0], c0, (grid * cap ? grid * cap : 1) * 16, reuse));
         RCHK(dev_reserve(r->d_rec_counts[0], c1, (grid ? grid : 1) * 4, reuse));
-        if (r->d_recs[1] && (c0 != r->cap_recs || c1 != r->cap_rec_counts)) {   // grown: the twin follows on its next use
-            hipFree(r->d_recs[1]); hipFree(r->d_rec_counts[1]); r->d_recs[1] = nullptr; r->d_rec_counts[1] = nullptr;
-        }
+        if (c0 != r->cap_recs || c1 != r->cap_rec_counts)                        // grown: the other sets follow on their next use
+            for (int i = 1; i < NSETS; i++) { hipFree(r->d_recs[i]); hipFree(r->d_rec_counts[i]); r->d_recs[i] = nullptr; r->d_rec_counts[i] = nullptr; }
         r->cap_recs = c0; r->cap_rec_counts = c1;
     }
     RCHK(launch_mark_has_n(V, r->d_has_n, st));
@@ -631,7 +633,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
-        const int q = 1 - p;
+        const int q = (p + 1) % NSETS;
         if (!r->d_recs[q]) {
             size_t c0 = 0, c1 = 0;
             HIPCHK(dev_reserve(r->d_recs[q], c0, r->cap_recs, false));
@@ -639,12 +641,15 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         }
         const bool two = overlap && pass_kind() == 0;
         hipStream_t sf = two ? ctx->stream2 : st;
-        if (two) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[q], 0));           // the finish kernel of two passes ago read this set
-        HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, st, t0, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
-        if (two) { HIPCHK(hipEventRecord(r->ev_screen[q], st)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
-        HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], r->d_counters[q], n_cu, sf, t2));
+        if (two) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[q], 0));           // the finish kernels of NSETS passes ago read this set
+        // cross-stream order without marker packets in the screen's stream: the events ride on the dispatches themselves
+        // (hipExtLaunchKernelGGL completion events); a separately recorded event costs the next dispatch ~5 us
+        KernelTiming scr_done{nullptr, r->ev_screen[q]};
+        const KernelTiming *ts = t0 ? t0 : (two ? &scr_done : nullptr);
+        HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, st, ts, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
+        if (two) { if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], st)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
+        HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], r->d_counters[q], n_cu, sf, t2, two ? r->ev_finish[q] : nullptr));
         r->sample_pass = true;
-        if (two) HIPCHK(hipEventRecord(r->ev_finish[q], sf));
         r->cur = q;
         return MF_OK;
     }
@@ -689,8 +694,7 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         if (rc) return rc;
     }
     // join: finish kernels still running on the second stream belong to this call (unrecorded events are no-ops)
-    HIPCHK(hipStreamWaitEvent(st, r->ev_finish[0], 0));
-    HIPCHK(hipStreamWaitEvent(st, r->ev_finish[1], 0));
+    for (int i = 0; i < NSETS; i++) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[i], 0));
     HIPCHK(hipEventRecord(e_end, st));
     std::vector<unsigned long long> part(EXACT_MAX_GRID * 4, 0);
     const bool two_halves = r->sample_pass;

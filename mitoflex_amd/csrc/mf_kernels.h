@@ -25,8 +25,9 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, u
                          const KernelTiming *tm = nullptr, uint32_t *clear = nullptr, uint64_t clear_vec4 = 0);
 // threshold 1, no hit counts: two launches of finish_kernel (runs, then the rest) settle every stage-1 record and set the pass
 // bits (bits must be clean).  partials: 2 * EXACT_MAX_GRID tally pairs (first half phase 0, second half phase 1).
+// done (optional): an event that completes with the last finish kernel
 hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
-                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr);
+                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr, hipEvent_t done = nullptr);
 hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
                        hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,

@@ -1342,7 +1342,7 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, u
 }
 
 hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
-                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm)
+                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm, hipEvent_t done)
 {
     const uint64_t lists = screen_grid_for(R, n_cu);
     if (lists == 0) return hipSuccess;
@@ -1350,6 +1350,10 @@ hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *r
     const ScreenRec *rc = static_cast<const ScreenRec *>(recs);
     static const bool time_phase1 = getenv("MF_TIME_PHASE1") != nullptr;          // the one event pair goes to phase 0 unless asked otherwise
     const KernelTiming *none = nullptr, *tm0 = time_phase1 ? none : tm, *tm1 = time_phase1 ? tm : none;
+    // `done` rides on the last dispatch as its completion event (no marker packet of its own in the stream)
+    KernelTiming last{nullptr, done};
+    bool done_attached = false;
+    if (done && !tm1) { tm1 = &last; done_attached = true; }
 #define MF_LAUNCH_FINISH(SPW, KW) do { \
         MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm0, R, S, rc, cap, rec_counts, \
                   (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); \
@@ -1358,6 +1362,7 @@ hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *r
     if (S.stride == 16) { if (S.kw == 1) MF_LAUNCH_FINISH(1, 1); else MF_LAUNCH_FINISH(1, 2); }
     else                { if (S.kw == 1) MF_LAUNCH_FINISH(2, 1); else MF_LAUNCH_FINISH(2, 2); }
 #undef MF_LAUNCH_FINISH
+    if (done && !done_attached) (void)hipEventRecord(done, st);
     return hipGetLastError();
 }
 
