@@ -388,3 +388,17 @@ def test_bench_two_ranks_under_torchrun(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["extra"]["reads_per_gpu"] == 2000000 and 0.003 < d["extra"]["passed"] / 2000000 < 0.008
+
+
+@pytest.mark.parametrize("kind", ["split", "serial"])
+def test_other_pass_kinds_match_oracle(kind):
+    """MF_PASS selects how a screened threshold-1 pass is run (read once per process, hence the child process): `split` is
+    screen + mark + exact for every threshold, `serial` is screen + finish without the cross-pass overlap -- and with the
+    finish kernel for the stride-8 geometries (k < 28), which the default leaves to the candidate-bitmap pass."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MF_PASS=kind)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_kmer_golden.py"),
+                        "-m", "gpu", "-q", "-x", "-k", "test_filter_matches_oracle or test_edge_cases or test_gpu_matches_golden or test_synth_uniform"],
+                       capture_output=True, env=env, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
