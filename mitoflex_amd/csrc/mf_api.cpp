@@ -38,7 +38,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // --------------------------------------------------------------- device ctx
-struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr; int n_cu = 0; };    // stream2: finish kernels of pipelined passes
+struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; int n_cu = 0; };    // stream2: finish kernels of pipelined passes; stream3: every other screen
 static std::mutex g_ctx_mu;
 static std::map<int, DevCtx> g_ctx;
 
@@ -78,6 +78,7 @@ static int get_ctx(int device, DevCtx **out, int lane = 0)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
     }
+    HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
     g_ctx[device + 4096 * lane] = c;
     *out = &g_ctx[device + 4096 * lane];
     return MF_OK;
@@ -641,13 +642,17 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         }
         const bool two = overlap && pass_kind() == 0;
         hipStream_t sf = two ? ctx->stream2 : st;
-        if (two) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[q], 0));           // the finish kernels of NSETS passes ago read this set
+        // consecutive screens go to two streams in turn: nothing orders them against each other (different buffer sets), so the
+        // workgroups of the next screen take over the CUs as the last ones of this screen drain (MF_SCREEN_STREAMS=1: one stream)
+        static const bool alt = env_u32("MF_SCREEN_STREAMS", 2) == 2;
+        hipStream_t ss = (two && alt && (q & 1)) ? ctx->stream3 : st;
+        if (two) HIPCHK(hipStreamWaitEvent(ss, r->ev_finish[q], 0));           // the finish kernels of NSETS passes ago read this set
         // cross-stream order without marker packets in the screen's stream: the events ride on the dispatches themselves
         // (hipExtLaunchKernelGGL completion events); a separately recorded event costs the next dispatch ~5 us
         KernelTiming scr_done{nullptr, r->ev_screen[q]};
         const KernelTiming *ts = t0 ? t0 : (two ? &scr_done : nullptr);
-        HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, st, ts, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
-        if (two) { if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], st)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
+        HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, ss, ts, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
+        if (two) { if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], ss)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
         HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], r->d_counters[q], n_cu, sf, t2, two ? r->ev_finish[q] : nullptr));
         r->sample_pass = true;
         r->cur = q;
@@ -689,6 +694,7 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     hipEvent_t *ev = events.ev.data();
     const hipEvent_t e_begin = ev[(size_t)n_sampled * 6], e_end = ev[(size_t)n_sampled * 6 + 1];
     HIPCHK(hipEventRecord(e_begin, st));
+    HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
     for (int i = 0; i < steps; i++) {
         rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true);
         if (rc) return rc;

@@ -936,6 +936,12 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
             const uint32_t sh = (uint32_t)wbit & 31;
             constexpr int NKW = KW == 1 ? 3 : 5;
             uint32_t raw[NKW];
+            if (PHASE == 1) {          // nearly every record left over belongs to a read phase 0 has passed: look at its bit before fetching anything else
+                const uint32_t bw1 = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pend_bit && !(pend_old & pend_bit)) n_pass++;
+                pend_bit = 0;
+                if (bw1 & bitm) { passed_r2 = passed_r; passed_r = r; continue; }
+            }
 #pragma unroll
             for (int i = 0; i < NKW; i++) raw[i] = w[i];
             const uint32_t hn_w = R.has_n[r >> 5];
