@@ -87,7 +87,7 @@ static int get_ctx(int device, DevCtx **out, int lane = 0)
 // ------------------------------------------------------------------ kmerset
 struct DevTables {
     uint64_t *keys = nullptr;
-    uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr, *plut = nullptr;
+    uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr, *kbloom_co = nullptr, *plut = nullptr;    // kbloom_co: own allocation only when it differs from kbloom
     KmerSetView view{};
     uint64_t n_keys = 0, n_smers = 0;
 };
@@ -115,7 +115,7 @@ struct DevScratch {
 // tables under construction: released unless the build commits them
 struct TablesGuard {
     DevTables *t;
-    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->plut); } }
+    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->kbloom_co); hipFree(t->plut); } }
 };
 // events of one timing loop
 struct EventList {
@@ -160,7 +160,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
         T.n_keys = cnt[0];
         KmerSetView &V = T.view;
         V.k = ks->k; V.kw = 1; V.slot_mask = ks->slots - 1; V.keys = T.keys;
-        V.kb_log2w = ks->kb_log2w; V.kbloom = T.kbloom;
+        V.kb_log2w = ks->kb_log2w; V.kbloom = T.kbloom; V.kb_co_log2w = ks->kb_log2w; V.kbloom_co = T.kbloom;
         V.prot = 1; V.kb_in_lds = ks->kb_in_lds ? 1u : 0u; V.plut = T.plut;
         ks->dev[device] = T; guard.t = nullptr;
         *out = &ks->dev[device];
@@ -196,6 +196,11 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     HIPCHK(hipMalloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
     HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
     HIPCHK(launch_build_kbloom(T.keys, ks->slots, ks->kw, T.kbloom, ks->kb_log2w, st));
+    if (ks->kb_log2w > KB_CO_LOG2W) {        // the folded table of the co-resident exact kernel (pipelined passes)
+        HIPCHK(hipMalloc(&T.kbloom_co, sizeof(uint32_t) << KB_CO_LOG2W));
+        HIPCHK(hipMemsetAsync(T.kbloom_co, 0, sizeof(uint32_t) << KB_CO_LOG2W, st));
+        HIPCHK(launch_build_kbloom(T.keys, ks->slots, ks->kw, T.kbloom_co, KB_CO_LOG2W, st));
+    }
     HIPCHK(launch_count_keys(T.keys, ks->slots, ks->kw, T.stab, T.stab ? ks->stab_slots : 0, d_cnt, st));
     unsigned long long cnt[2] = {0, 0}; uint32_t flag = 0;
     HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
@@ -205,6 +210,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     KmerSetView &V = T.view;
     V.k = ks->k; V.kw = ks->kw; V.slot_mask = ks->slots - 1; V.keys = T.keys;
     V.kb_log2w = ks->kb_log2w; V.kbloom = T.kbloom;
+    V.kb_co_log2w = T.kbloom_co ? KB_CO_LOG2W : ks->kb_log2w; V.kbloom_co = T.kbloom_co ? T.kbloom_co : T.kbloom;
     V.s = ks->geom.s; V.stride = ks->geom.stride;
     V.smask = ks->geom.s >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ks->geom.s)) - 1);
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
@@ -377,7 +383,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 {
     if (!ks) return MF_OK;
     for (auto &kv : ks->dev) {
-        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.plut); }
+        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.kbloom_co); hipFree(kv.second.plut); }
     }
     delete ks;
     return MF_OK;
@@ -396,15 +402,16 @@ struct mf_reads {
     // Threshold-1 passes (screen_kernel + finish_kernel) are pipelined: the finish kernel of pass i runs on a second stream
     // under the screen kernel of pass i + 1, the way consecutive batches of a file do.  What a pass writes therefore
     // exists NSETS times and rotates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.
-    uint32_t *d_cand = nullptr, *d_bits[NSETS] = {};
+    uint32_t *d_cand[NSETS] = {}, *d_bits[NSETS] = {};
     void *d_recs[NSETS] = {}; uint32_t *d_rec_counts[NSETS] = {};     // stage-1 positive records (screen -> finish / mark)
     unsigned long long *d_counters[NSETS] = {};                       // 2 * EXACT_MAX_GRID tally pairs each
     hipEvent_t ev_screen[NSETS] = {}, ev_finish[NSETS] = {};          // ordering between the two streams
-    bool cand_clean = false, sample_pass = false;     // sample_pass: the latest pass was a screen + finish one
+    bool cand_clean[NSETS] = {}, sample_pass = false;     // sample_pass: the latest pass was a screen + finish one
     // Bait-rich input (more than a few per cent of the reads are bait reads -- what the `bim` loop enriches towards) is better
     // served by the candidate-bitmap pass: one thread per stage-1 record means several records per bait read, and the screen
     // writes them all.  The choice follows the work the last call of this read set (the last batch of this device) saw.
     bool prefer_split = false;
+    bool split_serial = false;      // ... and with very many candidates (> 5 % of the reads) its kernels do not fit beside the next screen: one stream
     int cur = 0;
     size_t bitmap_bytes = 0;
     // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
@@ -425,7 +432,7 @@ static void reads_release(mf_reads *r)
     if (!r) return;
     if (hipSetDevice(phys(r->device)) == hipSuccess) {
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
-        hipFree(r->d_cand);
+        for (int i = 0; i < NSETS; i++) hipFree(r->d_cand[i]);
         for (int i = 0; i < NSETS; i++) {
             hipFree(r->d_bits[i]); hipFree(r->d_recs[i]); hipFree(r->d_rec_counts[i]); hipFree(r->d_counters[i]);
             if (r->ev_screen[i]) hipEventDestroy(r->ev_screen[i]);
@@ -476,7 +483,7 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;
     if (r->bitmap_bytes > r->cap_bitmap || !r->d_has_n) {     // the four bitmaps share one capacity
         size_t c[2 + NSETS] = {};
-        uint32_t **bm[2 + NSETS] = {&r->d_has_n, &r->d_cand};
+        uint32_t **bm[2 + NSETS] = {&r->d_has_n, &r->d_cand[0]};
         for (int i = 0; i < NSETS; i++) bm[2 + i] = &r->d_bits[i];
         size_t least = ~(size_t)0;
         for (int i = 0; i < 2 + NSETS; i++) {
@@ -485,10 +492,12 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
             if (c[i] < least) least = c[i];
         }
         r->cap_bitmap = least;
+        for (int i = 1; i < NSETS; i++) { hipFree(r->d_cand[i]); r->d_cand[i] = nullptr; }      // (follow on their next use)
     }
     RCHK(hipMemsetAsync(r->d_has_n, 0, r->bitmap_bytes, st));
-    RCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st));
-    r->cand_clean = true;
+    RCHK(hipMemsetAsync(r->d_cand[0], 0, r->bitmap_bytes, st));
+    r->cand_clean[0] = true;
+    for (int i = 1; i < NSETS; i++) r->cand_clean[i] = false;          // (the twins are allocated and cleared on first use)
     for (int i = 0; i < NSETS; i++) {
         if (!r->d_counters[i]) RCHK(hipMalloc(&r->d_counters[i], 2 * EXACT_MAX_GRID * 16));
         RCHK(hipMemsetAsync(r->d_counters[i], 0, 2 * EXACT_MAX_GRID * 16, st));
@@ -615,8 +624,9 @@ static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_base
 // enqueue one pass.  ev (when non-null) holds six events that are attached to the kernels themselves (start/stop of
 // screen, mark, exact or finish): each pair reads that dispatch's own duration and the streams carry no extra packets.
 // `overlap`: a threshold-1 pass may leave its finish kernel running on the second stream (filter_common joins the streams).
+// `more`: another pass of the same call follows (its screen kernel is what this pass's later kernels run beside).
 static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, DevCtx *ctx, hipEvent_t *ev, bool overlap,
-                        bool force_split = false)   // (force_split: reserved for callers that want the three-kernel pass)
+                        bool more = false)
 {
     r->sample_pass = false;
     hipStream_t st = ctx->stream;
@@ -630,7 +640,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
     // (stride-8 geometries, k < 28: twice the samples, several times the records -- measured faster through the candidate bitmap)
-    if (screened && pass_kind() != 1 && !force_split && !r->prefer_split && thr == 1 && !count_all && (S.stride == 16 || pass_kind() == 2)) {
+    if (screened && pass_kind() != 1 && !r->prefer_split && thr == 1 && !count_all && (S.stride == 16 || pass_kind() == 2)) {
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
@@ -653,6 +663,8 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         const KernelTiming *ts = t0 ? t0 : (two ? &scr_done : nullptr);
         HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, ss, ts, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
         if (two) { if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], ss)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
+        static const uint32_t nofin = env_u32("MF_NO_FINISH", 0);
+        if (nofin) { if (two) HIPCHK(hipEventRecord(r->ev_finish[q], sf)); } else
         HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], r->d_counters[q], n_cu, sf, t2, two ? r->ev_finish[q] : nullptr));
         r->sample_pass = true;
         r->cur = q;
@@ -660,10 +672,38 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     }
     // split / exhaustive: no per-pass memsets -- the exact kernel clears the candidate words it consumes, writes every
     // result word and zeroes unused tally slots
-    if (screened && !r->cand_clean) { HIPCHK(hipMemsetAsync(r->d_cand, 0, r->bitmap_bytes, st)); r->cand_clean = true; }
+    static const bool split_pipe = env_u32("MF_SPLIT_PIPE", 1) != 0;
+    static const bool exact_co = env_u32("MF_EXACT_CO", 0) != 0;           // (tests: the co-resident exact kernel behind every screen)
+    if (screened && !count_all && overlap && split_pipe && pass_kind() != 2 && !r->split_serial) {
+        // The three-kernel pass, pipelined like the one above: pass i works on buffer set i mod 2 (records, candidate
+        // bitmap, result bitmap, tallies); its mark and exact kernels go to the second stream and run beside the screen of
+        // pass i + 1.  The exact kernel takes its co-resident form when a screen follows (a screen workgroup holds 128 KiB
+        // of every CU's LDS for the whole pass), its full form behind the last screen of the call.
+        const int q = (p + 1) % NSETS;
+        if (!r->d_recs[q]) {
+            size_t c0 = 0, c1 = 0;
+            HIPCHK(dev_reserve(r->d_recs[q], c0, r->cap_recs, false));
+            HIPCHK(dev_reserve(r->d_rec_counts[q], c1, r->cap_rec_counts, false));
+        }
+        if (!r->d_cand[q]) { size_t c = 0; HIPCHK(dev_reserve(r->d_cand[q], c, r->cap_bitmap, false)); r->cand_clean[q] = false; }
+        static const bool alt = env_u32("MF_SCREEN_STREAMS", 2) == 2;
+        hipStream_t ss = (alt && (q & 1)) ? ctx->stream3 : st, sf = ctx->stream2;
+        HIPCHK(hipStreamWaitEvent(ss, r->ev_finish[q], 0));                    // the exact kernel of NSETS passes ago worked on this set
+        if (!r->cand_clean[q]) { HIPCHK(hipMemsetAsync(r->d_cand[q], 0, r->bitmap_bytes, ss)); r->cand_clean[q] = true; }
+        KernelTiming scr_done{nullptr, r->ev_screen[q]};
+        HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, ss, t0 ? t0 : &scr_done));
+        if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], ss));
+        HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0));
+        HIPCHK(launch_mark(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_cand[q], n_cu, sf, t1));
+        HIPCHK(launch_exact(r->v, S, r->d_cand[q], thr, false, r->d_bits[q], nullptr, r->d_counters[q], n_cu, sf, t2, more || exact_co, r->ev_finish[q]));
+        r->cur = q;
+        return MF_OK;
+    }
+    // one stream, one buffer set (hit counts wanted, the exhaustive mode, MF_PASS=serial)
+    if (screened && !r->cand_clean[0]) { HIPCHK(hipMemsetAsync(r->d_cand[0], 0, r->bitmap_bytes, st)); r->cand_clean[0] = true; }
     if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs[0], r->d_rec_counts[0], n_cu, st, t0));
-    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs[0], r->d_rec_counts[0], r->d_cand, n_cu, st, t1));
-    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand : nullptr, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters[p], n_cu, st, t2));
+    if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs[0], r->d_rec_counts[0], r->d_cand[0], n_cu, st, t1));
+    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand[0] : nullptr, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters[p], n_cu, st, t2));
     return MF_OK;
 }
 
@@ -676,10 +716,14 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     if (thr < 1) return fail(MF_E_ARG, "threshold must be >= 1");
     if (mode != MF_MODE_SCREENED && mode != MF_MODE_EXHAUSTIVE) return fail(MF_E_ARG, "bad mode %d", mode);
     if (steps < 1) return fail(MF_E_ARG, "steps must be >= 1");
+    static const bool trace = getenv("MF_TRACE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (trace) fprintf(stderr, "[mf trace] %-10s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count()); };
     DevCtx *ctx; int rc = get_ctx(r->device, &ctx, r->lane); if (rc) return rc;
     DevTables *T; rc = build_on_device(ks, r->device, &T); if (rc) return rc;
     hipStream_t st = ctx->stream;
     const bool count_all = hits_out != nullptr;
+    lap("setup");
     if (count_all) {
         HIPCHK(dev_reserve(r->d_hits, r->cap_hits, (r->v.n_reads ? r->v.n_reads : 1) * 4, false));
         HIPCHK(hipMemsetAsync(r->d_hits, 0, (r->v.n_reads ? r->v.n_reads : 1) * 4, st));
@@ -693,12 +737,14 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     HIPCHK(events.create((size_t)n_sampled * 6 + 2));
     hipEvent_t *ev = events.ev.data();
     const hipEvent_t e_begin = ev[(size_t)n_sampled * 6], e_end = ev[(size_t)n_sampled * 6 + 1];
+    lap("events");
     HIPCHK(hipEventRecord(e_begin, st));
     HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
     for (int i = 0; i < steps; i++) {
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true, i + 1 < steps);
         if (rc) return rc;
     }
+    lap("enqueued");
     // join: finish kernels still running on the second stream belong to this call (unrecorded events are no-ops)
     for (int i = 0; i < NSETS; i++) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[i], 0));
     HIPCHK(hipEventRecord(e_end, st));
@@ -707,12 +753,18 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     HIPCHK(hipMemcpyAsync(part.data(), r->d_counters[r->cur], (two_halves ? 2 : 1) * EXACT_MAX_GRID * 16, hipMemcpyDeviceToHost, st));
     if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits[r->cur], ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
     if (hits_out && r->v.n_reads) HIPCHK(hipMemcpyAsync(hits_out, r->d_hits, r->v.n_reads * 4, hipMemcpyDeviceToHost, st));
+    lap("copies");
     HIPCHK(hipStreamSynchronize(st));
+    lap("synced");
     unsigned long long cnt[2] = {0, 0};
     for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
-    if (!T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && r->v.n_reads >= 100000) {
+    static const bool adapt = env_u32("MF_ADAPT", 1) != 0;          // (MF_ADAPT=0: measurements of the sample pass on bait-rich input)
+    if (adapt && !T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && r->v.n_reads >= 100000) {
         if (r->sample_pass) { if (cnt[1] > r->v.n_reads / 5) r->prefer_split = true; }            // work items per read: ~0.03 at 0.5 % bait reads, 0.5 at 10 %
-        else if (r->prefer_split && cnt[1] < r->v.n_reads / 25) r->prefer_split = false;           // candidate reads per read
+        else {                                                                                     // candidate reads per read
+            if (r->prefer_split && cnt[1] < r->v.n_reads / 25) r->prefer_split = false;
+            if (cnt[1] > r->v.n_reads / 20) r->split_serial = true; else if (cnt[1] < r->v.n_reads / 40) r->split_serial = false;
+        }
     }
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -731,6 +783,7 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         stats->ms_total = tot / steps; stats->ms_screen = scr / n_sampled; stats->ms_mark = mrk / n_sampled; stats->ms_exact = exa / n_sampled;
         stats->algorithmic_bytes = algorithmic_bytes(r->v);
     }
+    lap("stats");
     return MF_OK;
 }
 

@@ -175,6 +175,8 @@ struct KmerSetView {
     // LDS front of the table: blocked bit table over canonical k-mers (128-bit blocks, one bit per dword)
     uint32_t  kb_log2w;         // 1 << kb_log2w words
     const uint32_t *kbloom;
+    uint32_t  kb_co_log2w;      // the same table folded down to <= 16 KiB: what an exact kernel stages when it has to share the CU's LDS
+    const uint32_t *kbloom_co;  // with a screen workgroup of the next pass (pipelined passes); == kbloom when that is small already
     // screen
     int32_t   s, stride;        // s == 0: disabled
     uint32_t  smask;            // (1 << 2s) - 1

@@ -32,7 +32,7 @@ hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *rec
                        hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st,
-                        const KernelTiming *tm = nullptr);
+                        const KernelTiming *tm = nullptr, bool coresident = false, hipEvent_t done = nullptr);
 hipError_t launch_build_kbloom(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, uint64_t slots, uint32_t *postab_scratch,
                               hipStream_t st);

@@ -398,6 +398,7 @@ __device__ __forceinline__ bool table_contains(const KmerSetView &S, Key<2> v)
 // owning bitmap word through LDS and are stored coalesced.
 constexpr int ITEM_POS = 16;
 constexpr int EXACT_BLOCK = 1024;
+constexpr int EXACT_BLOCK_CO = 512;          // co-resident form: shares a CU with a screen workgroup (registers, wave slots, 32 KiB of LDS)
 
 __device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, int sh)   // (hi:lo >> sh), sh in [0,63]
 {
@@ -589,13 +590,13 @@ __device__ __forceinline__ void run_candidates(const ReadsView &R, const KmerSet
 constexpr int WC_PER_LANE = 4;                     // candidate-bitmap words per lane
 constexpr int WC_WORDS = 64 * WC_PER_LANE;         // ... per wave-chunk (8192 reads)
 
-template <int KW, bool COUNT_ALL>
-__global__ void __launch_bounds__(EXACT_BLOCK)
+template <int KW, bool COUNT_ALL, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t thr,
              uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out, unsigned long long *__restrict__ partials)
 {
     extern __shared__ uint4 s_mem4[];
-    constexpr int WAVES = EXACT_BLOCK / 64;
+    constexpr int WAVES = BLOCK / 64;
     uint32_t *s_res = reinterpret_cast<uint32_t *>(s_mem4);                  // [WAVES][WC_WORDS]
     uint32_t *s_cnt = s_res + WAVES * WC_WORDS;                              // [WAVES][64]
     constexpr int HEAD4 = (WAVES * WC_WORDS + WAVES * 64) / 4;
@@ -1380,25 +1381,34 @@ hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *rec
     return hipGetLastError();
 }
 
-hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
+hipError_t launch_exact(const ReadsView &R, const KmerSetView &S_, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st,
-                        const KernelTiming *tm)
+                        const KernelTiming *tm, bool coresident, hipEvent_t done)
 {
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
     const uint64_t n_wc = (n_bw + WC_WORDS - 1) / WC_WORDS;
-    if (n_wc == 0) return hipSuccess;
-    constexpr int WAVES = EXACT_BLOCK / 64;
-    const size_t lds = (sizeof(uint32_t) << S.kb_log2w) + (WAVES * WC_WORDS + WAVES * 64) * sizeof(uint32_t);
-    const int per_cu = 2 * lds <= 160 * 1024 ? 2 : 1;       // persistent: 1-2 workgroups of 1024 threads per CU
-    uint64_t grid = (n_wc + WAVES - 1) / WAVES;
+    if (n_wc == 0) { if (done) (void)hipEventRecord(done, st); return hipGetLastError(); }
+    // co-resident form (pipelined passes): half the threads and the folded bit table, so that a workgroup fits beside the
+    // screen workgroup of the next pass on every CU (32 KiB of LDS, eight wave slots, a quarter of the registers are free there)
+    KmerSetView S = S_;
+    if (coresident && !count_all) { S.kbloom = S_.kbloom_co; S.kb_log2w = S_.kb_co_log2w; } else coresident = false;
+    const int waves = (coresident ? EXACT_BLOCK_CO : EXACT_BLOCK) / 64;
+    const size_t lds = (sizeof(uint32_t) << S.kb_log2w) + (size_t)(waves * WC_WORDS + waves * 64) * sizeof(uint32_t);
+    const int per_cu = coresident ? 1 : 2 * lds <= 160 * 1024 ? 2 : 1;       // persistent: 1-2 workgroups per CU
+    uint64_t grid = (n_wc + waves - 1) / waves;
     if (grid > (uint64_t)n_cu * per_cu) grid = (uint64_t)n_cu * per_cu;
     if (grid > EXACT_MAX_GRID) grid = EXACT_MAX_GRID;
-#define MF_LAUNCH_EXACT(KW, CA) do { \
-        raise_lds_limit_once<&exact_kernel<KW, CA>>(160 * 1024); \
-        MF_LAUNCH((exact_kernel<KW, CA>), dim3((unsigned)grid), dim3(EXACT_BLOCK), lds, st, tm, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
-    if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true); else MF_LAUNCH_EXACT(1, false); }
-    else           { if (count_all) MF_LAUNCH_EXACT(2, true); else MF_LAUNCH_EXACT(2, false); }
+    // `done` rides on the dispatch as its completion event unless a timing pair is wanted
+    KernelTiming with_done{nullptr, done};
+    const KernelTiming *tmx = tm ? tm : (done ? &with_done : nullptr);
+#define MF_LAUNCH_EXACT(KW, CA, BLK) do { \
+        raise_lds_limit_once<&exact_kernel<KW, CA, BLK>>(160 * 1024); \
+        MF_LAUNCH((exact_kernel<KW, CA, BLK>), dim3((unsigned)grid), dim3(BLK), lds, st, tmx, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
+    if (coresident) { if (S.kw == 1) MF_LAUNCH_EXACT(1, false, EXACT_BLOCK_CO); else MF_LAUNCH_EXACT(2, false, EXACT_BLOCK_CO); }
+    else if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true, EXACT_BLOCK); else MF_LAUNCH_EXACT(1, false, EXACT_BLOCK); }
+    else                { if (count_all) MF_LAUNCH_EXACT(2, true, EXACT_BLOCK); else MF_LAUNCH_EXACT(2, false, EXACT_BLOCK); }
 #undef MF_LAUNCH_EXACT
+    if (done && tm) (void)hipEventRecord(done, st);
     return hipGetLastError();
 }
 

@@ -3,5 +3,6 @@
 namespace mf {
 constexpr int SCREEN_U = 2;            // uint4 loads in flight per lane per chunk
 constexpr int SCREEN_BLOCK = 1024;     // threads per screen workgroup
+constexpr unsigned KB_CO_LOG2W = 12;   // k-mer bit table of a co-resident exact kernel: at most 1 << 12 words (16 KiB)
 constexpr int EXACT_MAX_GRID = 1024;   // workgroups of the exact kernel (one (pass, candidate) partial pair each)
 }

@@ -390,15 +390,41 @@ def test_bench_two_ranks_under_torchrun(tmp_path):
     assert d["extra"]["reads_per_gpu"] == 2000000 and 0.003 < d["extra"]["passed"] / 2000000 < 0.008
 
 
-@pytest.mark.parametrize("kind", ["split", "serial"])
+@pytest.mark.parametrize("k", [21, 31, 41])
+def test_multi_pass_calls_match_oracle(mf, ol, bait_text, k):
+    """A call with several passes pipelines them: the later kernels of pass i run beside the screen of pass i + 1 on a second
+    stream, buffer sets rotate, and the exact kernel of all passes but the last takes its co-resident form.  What comes back
+    (the tally of the last pass, and the result bitmap a following single pass leaves) must not depend on any of that."""
+    n = 200_000
+    ks = mf.KmerSet.from_text(bait_text, k)
+    reads = mf.Reads.synth(n, 150, seed=11, bait_text=bait_text, keep_host=True)
+    off = np.arange(n + 1, dtype=np.uint64) * 150
+    R = ol.OracleReads.from_arrays(reads.host_words, off, reads.host_npos)
+    t = ol.OracleTable(bait_text, k)
+    for thr in (1, 2):
+        obits, _ = ol.filter_reads(t, R, thr, threads=os.cpu_count() or 1)
+        want = int(bits_to_bool(obits, n).sum())
+        for steps in (2, 3, 5):
+            st = mf.filter_resident(ks, reads, thr, mf.MODE_SCREENED, steps)
+            assert st.n_pass == want, (k, thr, steps)
+            bits, _, st1 = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED)
+            assert np.array_equal(bits, obits) and st1.n_pass == want, (k, thr, steps)
+
+
+@pytest.mark.parametrize("kind", ["split", "serial", "split-co", "split-one-stream", "one-screen-stream"])
 def test_other_pass_kinds_match_oracle(kind):
-    """MF_PASS selects how a screened threshold-1 pass is run (read once per process, hence the child process): `split` is
-    screen + mark + exact for every threshold, `serial` is screen + finish without the cross-pass overlap -- and with the
-    finish kernel for the stride-8 geometries (k < 28), which the default leaves to the candidate-bitmap pass."""
+    """Environment switches select how a screened pass is run (read once per process, hence the child process).  MF_PASS=split:
+    screen + mark + exact for every threshold; MF_PASS=serial: screen + finish without the cross-pass overlap -- and with the
+    finish kernel for the stride-8 geometries (k < 28), which the default leaves to the candidate-bitmap pass.  `split-co`
+    puts the co-resident form of the exact kernel (half the threads, folded bit table: what runs beside the next pass's screen
+    in a multi-pass call) behind every screen; `split-one-stream` is the three-kernel pass without the second stream;
+    `one-screen-stream` keeps all screens on one stream."""
     import subprocess
     import sys
-    env = dict(os.environ, MF_PASS=kind)
+    extra = {"split": dict(MF_PASS="split"), "serial": dict(MF_PASS="serial"), "split-co": dict(MF_PASS="split", MF_EXACT_CO="1"),
+             "split-one-stream": dict(MF_PASS="split", MF_SPLIT_PIPE="0"), "one-screen-stream": dict(MF_SCREEN_STREAMS="1")}[kind]
+    env = dict(os.environ, **extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_kmer_golden.py"),
-                        "-m", "gpu", "-q", "-x", "-k", "test_filter_matches_oracle or test_edge_cases or test_gpu_matches_golden or test_synth_uniform"],
+                        "-m", "gpu", "-q", "-x", "-k", "test_filter_matches_oracle or test_edge_cases or test_gpu_matches_golden or test_synth_uniform or test_multi_pass_calls"],
                        capture_output=True, env=env, cwd=ROOT, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
