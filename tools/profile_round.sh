@@ -5,8 +5,11 @@ R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err; cat $OUT/bench_driver_cmd.json
 for k in 21 41; do timeout 300 python bench.py --k $k --steps 20 --cpu-sample 0 --e2e-pairs 0 > $OUT/bench_k$k.json 2>> $OUT/bench.err; done
 MF_PASS=split timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-exhaustive > $OUT/bench_split_pass.json 2>> $OUT/bench.err
+MF_SCREEN_STREAMS=1 timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-exhaustive > $OUT/bench_one_screen_stream.json 2>> $OUT/bench.err
+MF_SPLIT_PIPE=0 timeout 300 python bench.py --k 21 --steps 20 --cpu-sample 0 --e2e-pairs 0 --no-exhaustive > $OUT/bench_k21_one_stream.json 2>> $OUT/bench.err
 MF_PASS=serial timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-exhaustive > $OUT/bench_serial_pass.json 2>> $OUT/bench.err
 timeout 300 python tools/bait_fraction_sweep.py > $OUT/bait_fraction.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
