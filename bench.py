@@ -198,11 +198,24 @@ def main():
              "ms_per_step_sampled_loop": round(sp.ms_total, 4), "kernel_samples": a.steps,
              "ms_pass_events": round(st.ms_total, 4), "work_items": int(st.n_candidates), "passed": int(st.n_pass),
              "reads_per_gpu": a.reads, "synth_seconds": round(t_gen, 2), "device": mf.device_name(dev),
-             "pipelined": "finish kernels of step i run under the screen kernel of step i+1 (second stream); "
-                          "ms_screen_kernel is measured under that overlap"}
+             "pipelined": "consecutive steps overlap: finish kernels of step i run under the screen kernel of step i+1 (second stream) and "
+                          "consecutive screen kernels go to two streams in turn, so the duration of a screen launch (ms_screen_kernel, "
+                          "roofline.achieved) includes time it shares the device with its neighbours; a step completes every ms_per_step"}
     if rank == 0 and world == 1:
         one = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, 1)    # a single step: nothing to overlap with
         extra["ms_single_pass_latency"] = round(one.ms_total, 4)
+        # the same kernel with the device to itself (MF_PASS=serial: one stream, no overlap between steps), every dispatch sampled
+        prev = os.environ.get("MF_PASS")
+        os.environ["MF_PASS"] = "serial"; os.environ["MF_EVENT_STRIDE"] = "1"
+        alone = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, min(a.steps, 20))
+        os.environ["MF_EVENT_STRIDE"] = "8"
+        if prev is None:
+            del os.environ["MF_PASS"]
+        else:
+            os.environ["MF_PASS"] = prev
+        if alone.ms_screen > 0:
+            extra["screen_kernel_alone"] = {"ms": round(alone.ms_screen, 4), "frac_of_hbm_peak": round(alg_bytes / (alone.ms_screen / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                            "ms_per_step_serial": round(alone.ms_total, 4)}
     extra["whole_pass_frac_of_hbm_peak"] = round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS, 4)
     if rank == 0 and not a.no_exhaustive:
         ex = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_EXHAUSTIVE, 1)

@@ -421,10 +421,10 @@ struct mf_reads {
 // How a screened pass is run.  Default: screen_kernel, then finish_kernel when the threshold is 1 and no hit counts are wanted
 // (mark_kernel + exact_kernel otherwise).  MF_PASS=split: always screen, mark, exact.  MF_PASS=serial: screen + finish
 // without overlapping consecutive passes (for comparison).
-static int pass_kind()
+static int pass_kind()          // (looked up on every pass: bench.py times the serial form next to the default one in one process)
 {
-    static const int kind = [] { const char *v = getenv("MF_PASS"); return v && strcmp(v, "split") == 0 ? 1 : (v && strcmp(v, "serial") == 0 ? 2 : 0); }();
-    return kind;
+    const char *v = getenv("MF_PASS");
+    return v && strcmp(v, "split") == 0 ? 1 : (v && strcmp(v, "serial") == 0 ? 2 : 0);
 }
 
 static void reads_release(mf_reads *r)

@@ -15,6 +15,8 @@ timeout 300 python tools/bait_fraction_sweep.py > $OUT/bait_fraction.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 > $OUT/trace_bench.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null; cat $OUT/kernel_stats.csv
+MF_PASS=serial timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 > $OUT/trace_serial_bench.json 2> $OUT/trace_serial.err
+cp $(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_serial.csv 2>/dev/null; head -4 $OUT/kernel_stats_serial.csv
 pmc() { name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 > /dev/null 2> $OUT/pmc_$name.err
   python3 - $(find $OUT/pmc_$name -name "*counter_collection.csv" | head -1) <<'PY' | tee -a $OUT/pmc_summary.txt
@@ -38,4 +40,4 @@ cd $R
 timeout 600 ./tools/e2e_bench.sh 8000000 > $OUT/e2e_files.log 2>&1; tail -12 $OUT/e2e_files.log
 timeout 600 ./tools/e2e_filter_v2.sh > $OUT/filter_v2_e2e.log 2>&1; tail -12 $OUT/filter_v2_e2e.log
 timeout 600 python tools/bench_protein.py > $OUT/protein_bench.json 2> $OUT/protein_bench.err; cat $OUT/protein_bench.json
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm
+rm -rf $OUT/trace $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm
