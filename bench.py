@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm-ms", type=float, default=100.0, help="keep the device busy with untimed passes for this long before the warm-up steps (clock ramp)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the 5 Gbp set; at 8 GPUs a 1/8 shard of the 50 Gbp set)")
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--cpu-sample", type=int, default=READS_5GBP,
@@ -173,6 +174,11 @@ def main():
             rdv.barrier()
 
     os.environ["MF_EVENT_STRIDE"] = "1000000000"        # the timed loop carries no per-kernel events
+    # W steps of this workload last about a millisecond, far less than the device needs to come out of its idle clocks after the
+    # (host-side) set-up above: keep it busy with the same passes for a fixed time first, untimed like the warm-up steps
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
+        mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, 20)
     if a.warmup > 0:
         mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, a.warmup)
     barrier()
@@ -197,7 +203,7 @@ def main():
     extra = {"ms_screen_kernel": round(sp.ms_screen, 4), "ms_mark_kernel": round(sp.ms_mark, 4), "ms_finish_kernel_phase0": round(sp.ms_exact, 4),
              "ms_per_step_sampled_loop": round(sp.ms_total, 4), "kernel_samples": a.steps,
              "ms_pass_events": round(st.ms_total, 4), "work_items": int(st.n_candidates), "passed": int(st.n_pass),
-             "reads_per_gpu": a.reads, "synth_seconds": round(t_gen, 2), "device": mf.device_name(dev),
+             "reads_per_gpu": a.reads, "synth_seconds": round(t_gen, 2), "prewarm_ms": a.prewarm_ms, "device": mf.device_name(dev),
              "pipelined": "consecutive steps overlap: finish kernels of step i run under the screen kernel of step i+1 (second stream) and "
                           "consecutive screen kernels go to two streams in turn, so the duration of a screen launch (ms_screen_kernel, "
                           "roofline.achieved) includes time it shares the device with its neighbours; a step completes every ms_per_step"}

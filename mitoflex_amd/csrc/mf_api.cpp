@@ -404,8 +404,10 @@ struct mf_reads {
     // exists NSETS times and rotates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.
     uint32_t *d_cand[NSETS] = {}, *d_bits[NSETS] = {};
     void *d_recs[NSETS] = {}; uint32_t *d_rec_counts[NSETS] = {};     // stage-1 positive records (screen -> finish / mark)
-    unsigned long long *d_counters[NSETS] = {};                       // 2 * EXACT_MAX_GRID tally pairs each
+    unsigned long long *d_counters[NSETS] = {};                       // 2 * EXACT_MAX_GRID tally pairs each, in pinned HOST memory: the kernels store
+                                                                      // their pair there directly and a call ends without a device-to-host copy
     hipEvent_t ev_screen[NSETS] = {}, ev_finish[NSETS] = {};          // ordering between the two streams
+    hipEvent_t ev_call[2] = {};                                       // begin / end of a call's passes
     bool cand_clean[NSETS] = {}, sample_pass = false;     // sample_pass: the latest pass was a screen + finish one
     // Bait-rich input (more than a few per cent of the reads are bait reads -- what the `bim` loop enriches towards) is better
     // served by the candidate-bitmap pass: one thread per stage-1 record means several records per bait read, and the screen
@@ -434,8 +436,9 @@ static void reads_release(mf_reads *r)
         hipFree(r->d_words); hipFree(r->d_offsets); hipFree(r->d_npos); hipFree(r->d_has_n);
         for (int i = 0; i < NSETS; i++) hipFree(r->d_cand[i]);
         for (int i = 0; i < NSETS; i++) {
-            hipFree(r->d_bits[i]); hipFree(r->d_recs[i]); hipFree(r->d_rec_counts[i]); hipFree(r->d_counters[i]);
+            hipFree(r->d_bits[i]); hipFree(r->d_recs[i]); hipFree(r->d_rec_counts[i]); if (r->d_counters[i]) hipHostFree(r->d_counters[i]);
             if (r->ev_screen[i]) hipEventDestroy(r->ev_screen[i]);
+            if (i < 2 && r->ev_call[i]) hipEventDestroy(r->ev_call[i]);
             if (r->ev_finish[i]) hipEventDestroy(r->ev_finish[i]);
         }
         hipFree(r->d_hits); hipFree(r->d_npos_blk);
@@ -499,8 +502,8 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     r->cand_clean[0] = true;
     for (int i = 1; i < NSETS; i++) r->cand_clean[i] = false;          // (the twins are allocated and cleared on first use)
     for (int i = 0; i < NSETS; i++) {
-        if (!r->d_counters[i]) RCHK(hipMalloc(&r->d_counters[i], 2 * EXACT_MAX_GRID * 16));
-        RCHK(hipMemsetAsync(r->d_counters[i], 0, 2 * EXACT_MAX_GRID * 16, st));
+        if (!r->d_counters[i]) RCHK(hipHostMalloc(reinterpret_cast<void **>(&r->d_counters[i]), 2 * EXACT_MAX_GRID * 16, hipHostMallocDefault));
+        memset(r->d_counters[i], 0, 2 * EXACT_MAX_GRID * 16);             // (no kernel of this handle is in flight: every call ends synchronised)
         RCHK(hipMemsetAsync(r->d_bits[i], 0, r->bitmap_bytes, st));
         if (!r->ev_screen[i]) RCHK(hipEventCreate(&r->ev_screen[i]));         // (attached to dispatches as completion events)
         if (!r->ev_finish[i]) RCHK(hipEventCreate(&r->ev_finish[i]));
@@ -732,25 +735,25 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     // cost a little command-processor work each); the whole loop is bracketed by its own pair of events
     int stride = steps <= 8 ? 1 : (int)env_u32("MF_EVENT_STRIDE", 8);
     if (stride < 1) stride = 1;
-    const int n_sampled = (steps + stride - 1) / stride;
+    const int n_sampled = stride > steps ? 0 : (steps + stride - 1) / stride;       // (a stride beyond the call: no per-kernel events at all)
     EventList events;
-    HIPCHK(events.create((size_t)n_sampled * 6 + 2));
+    HIPCHK(events.create((size_t)n_sampled * 6));
     hipEvent_t *ev = events.ev.data();
-    const hipEvent_t e_begin = ev[(size_t)n_sampled * 6], e_end = ev[(size_t)n_sampled * 6 + 1];
+    for (int i = 0; i < 2; i++) if (!r->ev_call[i]) HIPCHK(hipEventCreate(&r->ev_call[i]));
+    const hipEvent_t e_begin = r->ev_call[0], e_end = r->ev_call[1];
     lap("events");
     HIPCHK(hipEventRecord(e_begin, st));
     HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
     for (int i = 0; i < steps; i++) {
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true, i + 1 < steps);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, n_sampled && i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true, i + 1 < steps);
         if (rc) return rc;
     }
     lap("enqueued");
     // join: finish kernels still running on the second stream belong to this call (unrecorded events are no-ops)
     for (int i = 0; i < NSETS; i++) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[i], 0));
     HIPCHK(hipEventRecord(e_end, st));
-    std::vector<unsigned long long> part(EXACT_MAX_GRID * 4, 0);
     const bool two_halves = r->sample_pass;
-    HIPCHK(hipMemcpyAsync(part.data(), r->d_counters[r->cur], (two_halves ? 2 : 1) * EXACT_MAX_GRID * 16, hipMemcpyDeviceToHost, st));
+    const unsigned long long *part = r->d_counters[r->cur];          // pinned host memory, complete once the stream is
     if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits[r->cur], ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
     if (hits_out && r->v.n_reads) HIPCHK(hipMemcpyAsync(hits_out, r->d_hits, r->v.n_reads * 4, hipMemcpyDeviceToHost, st));
     lap("copies");
@@ -780,7 +783,8 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
         }
         stats->n_reads = r->v.n_reads; stats->n_pass = cnt[0];
         stats->n_candidates = (mode == MF_MODE_SCREENED && T->view.s > 0) ? cnt[1] : r->v.n_reads;
-        stats->ms_total = tot / steps; stats->ms_screen = scr / n_sampled; stats->ms_mark = mrk / n_sampled; stats->ms_exact = exa / n_sampled;
+        stats->ms_total = tot / steps;
+        if (n_sampled) { stats->ms_screen = scr / n_sampled; stats->ms_mark = mrk / n_sampled; stats->ms_exact = exa / n_sampled; }
         stats->algorithmic_bytes = algorithmic_bytes(r->v);
     }
     lap("stats");
