@@ -518,7 +518,9 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     V.npos = r->d_npos; V.n_npos = n_npos; V.npos_blk = r->d_npos_blk; V.has_n = r->d_has_n;
     {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %.  The second
         // list is only needed by pipelined threshold-1 passes and is allocated on first use (enqueue_pass).
-        const uint64_t grid = screen_grid_for(V, ctx->n_cu), cap = screen_rec_cap_for(V, ctx->n_cu);
+        // (the stride-16 and the stride-8 screens deal the chunks to different numbers of lists: room for either)
+        uint64_t grid = screen_grid_for(V, ctx->n_cu, 8), cap = screen_rec_cap_for(V, ctx->n_cu, 8);
+        { const uint64_t g2 = screen_grid_for(V, ctx->n_cu, 16), c2 = screen_rec_cap_for(V, ctx->n_cu, 16); if (g2 * c2 > grid * cap) cap = (g2 * c2 + grid - 1) / (grid ? grid : 1); }
         size_t c0 = r->cap_recs, c1 = r->cap_rec_counts;
         RCHK(dev_reserve(r->d_recs[0], c0, (grid * cap ? grid * cap : 1) * 16, reuse));
         RCHK(dev_reserve(r->d_rec_counts[0], c1, (grid ? grid : 1) * 4, reuse));

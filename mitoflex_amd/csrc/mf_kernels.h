@@ -18,8 +18,8 @@ struct BaitView {
 struct KernelTiming { hipEvent_t start, stop; };
 
 // screen = screen_kernel (records stage-1 positives) + mark_kernel (finishes them, sets candidate bits)
-uint64_t screen_grid_for(const ReadsView &R, int n_cu);
-uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu);          // 16-byte records per screen workgroup
+uint64_t screen_grid_for(const ReadsView &R, int n_cu, int stride);
+uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu, int stride);          // 16-byte records per screen workgroup
 // clear (optional): a result bitmap of clear_vec4 uint4 that the screen zeroes on the side (for the pass after this one)
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                          const KernelTiming *tm = nullptr, uint32_t *clear = nullptr, uint64_t clear_vec4 = 0);
