@@ -886,10 +886,13 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
     };
     const uint32_t stride_r = gridDim.x * FINISH_BLOCK;
     uint32_t ri = blockIdx.x * FINISH_BLOCK + threadIdx.x;
-    ScreenRec rec_next{0, 0, 0, 0};
+    const ScreenRec no_rec{0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
+    ScreenRec rec_next = no_rec;
     if (ri < total) rec_next = load_rec(ri);
-    for (; ri < total; ri += stride_r) {
+    // (whole waves stay in the loop -- a lane past the end holds an empty record --: phase 0 looks at the neighbouring lane)
+    for (uint32_t base = blockIdx.x * FINISH_BLOCK; base < total; base += stride_r, ri += stride_r) {
         const ScreenRec rec = rec_next;
+        rec_next = no_rec;
         if (ri + stride_r < total) rec_next = load_rec(ri + stride_r);        // the next record is on its way while this one is settled
         const uint64_t cb = (uint64_t)rec.chunk * chunk_bases;
         uint64_t rq = 0; uint32_t rrem = 0;
@@ -897,6 +900,23 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
         uint32_t m = rec.hitmask;
         uint32_t runs = fast ? m & run_ok : 0u;       // bit B (sample i) starts a run iff bits B, B-1, ..., B-(n_adj-1) are set
         for (uint32_t j = 1; j < n_adj; j++) runs &= m << j;
+        if (PHASE == 0 && SPW == 1 && KW == 2 && fast) {
+            // Runs across the lane border (k > 32; for shorter k a run is two samples and the extra arithmetic does not pay): the records of a list are in lane order, so the next record is usually the next lane
+            // of the same chunk, whose 16-byte pieces follow this lane's in the stream.  A run may then start in this lane's
+            // piece and end in that one's (a run of k > 32 is three or four samples long and rarely fits one piece: 0.252 -> 0.237 ms
+            // per step at k = 41).
+            const uint32_t nb_chunk = __shfl_down(rec.chunk, 1), nb_tid = __shfl_down(rec.tid, 1), nb_mask = __shfl_down(rec.hitmask, 1);
+            const bool nb = (threadIdx.x & 63) != 63 && nb_chunk == rec.chunk && nb_tid == rec.tid + 1 && rec.hitmask != 0;
+            runs = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int sh = 4 * (U - 1 - u);                               // piece u: samples 4u .. 4u+3 are bits sh+3 .. sh
+                const uint32_t e = (((rec.hitmask >> sh) & 15u) << 4) | (nb ? (nb_mask >> sh) & 15u : 0u);
+                uint32_t re = e;
+                for (uint32_t j = 1; j < n_adj; j++) re &= e << j;
+                runs |= ((re >> 4) & 15u) << sh;
+            }
+        }
         if (PHASE == 0) m = runs; else runs = 0;      // phase 0 looks at run starts only, phase 1 at every positive on its own
         uint64_t passed_r = ~0ULL, passed_r2 = ~0ULL; // the last two reads this record has passed
         while (m) {
