@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <immintrin.h>
 #include <zlib.h>               // crc32, crc32_combine only
 
 namespace mf {
@@ -224,14 +225,86 @@ size_t find_block(const uint8_t *data, size_t size, size_t from_bit, size_t to_b
     return SIZE_MAX;
 }
 
+} // namespace
+
+// CRC-32 (the gzip polynomial, reflected) by carry-less multiplication: four 128-bit accumulators are folded forward 64 bytes
+// at a time, then into one, then reduced to 32 bits (Barrett) -- the scheme of Intel's "Fast CRC computation for generic
+// polynomials using PCLMULQDQ"; the constants are x^(n) mod P for the fold distances, bit-reflected.  ~10x zlib's table walk,
+// which was a seventh of the parallel reader's CPU time.  Works on the raw register (no pre/post inversion), whole 16-byte blocks.
+__attribute__((target("pclmul,sse4.1"))) static inline __m128i crc_ld(const uint8_t *q) { return _mm_loadu_si128(reinterpret_cast<const __m128i *>(q)); }
+__attribute__((target("pclmul,sse4.1"))) static inline __m128i crc_fold(__m128i x, __m128i k, __m128i data)
+{
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x00), _mm_clmulepi64_si128(x, k, 0x11)), data);
+}
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t crc32_fold_pclmul(uint32_t reg, const uint8_t *p, size_t n)        // n >= 64, n % 16 == 0
+{
+#define ld crc_ld
+#define fold crc_fold
+    const __m128i k_r2r1 = _mm_set_epi64x(0x00000001c6e41596LL, 0x0000000154442bd4LL);
+    const __m128i k_r4r3 = _mm_set_epi64x(0x00000000ccaa009eLL, 0x00000001751997d0LL);
+    const __m128i k_r5 = _mm_set_epi64x(0, 0x0000000163cd6124LL);
+    const __m128i k_poly = _mm_set_epi64x(0x00000001F7011641LL, 0x00000001DB710641LL);
+    const __m128i mask32 = _mm_set_epi32(0, 0, 0, -1);
+    __m128i x1 = _mm_xor_si128(ld(p), _mm_cvtsi32_si128((int)reg)), x2 = ld(p + 16), x3 = ld(p + 32), x4 = ld(p + 48);
+    p += 64; n -= 64;
+    while (n >= 64) {
+        x1 = fold(x1, k_r2r1, ld(p)); x2 = fold(x2, k_r2r1, ld(p + 16)); x3 = fold(x3, k_r2r1, ld(p + 32)); x4 = fold(x4, k_r2r1, ld(p + 48));
+        p += 64; n -= 64;
+    }
+    x1 = fold(x1, k_r4r3, x2); x1 = fold(x1, k_r4r3, x3); x1 = fold(x1, k_r4r3, x4);
+    while (n >= 16) { x1 = fold(x1, k_r4r3, ld(p)); p += 16; n -= 16; }
+    // 128 -> 64 bits (this also appends the 32 zero bits of the CRC definition), 64 -> 32, Barrett
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), _mm_clmulepi64_si128(k_r4r3, x1, 0x01));
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 4), _mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k_r5, 0x00));
+    __m128i t = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k_poly, 0x10), mask32);
+    t = _mm_clmulepi64_si128(t, k_poly, 0x00);
+    return (uint32_t)_mm_extract_epi32(_mm_xor_si128(x1, t), 1);
+#undef ld
+#undef fold
+}
+
+// same contract as zlib's crc32()
+uint32_t crc32_fast(uint32_t crc, const uint8_t *p, size_t n)
+{
+    static const bool hw = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("MF_NO_SIMD");
+    if (hw && n >= 64) {
+        const size_t bulk = n & ~(size_t)15;
+        crc = ~crc32_fold_pclmul(~crc, p, bulk);
+        p += bulk; n -= bulk;
+    }
+    while (n) { const size_t k = n < ((size_t)1 << 30) ? n : ((size_t)1 << 30); crc = (uint32_t)crc32(crc, p, (uInt)k); p += k; n -= k; }
+    return crc;
+}
+
+// 16-bit symbols -> bytes: a marker (MARK | index) is looked up in the 32 KiB window the chunk did not know, anything else is
+// the byte itself.  Markers cluster (in FASTQ: the copied prefix of a header), so most 32-symbol blocks are plain narrowing.
+__attribute__((target("avx2")))
+static void resolve_symbols_avx2(const uint16_t *s, size_t n, const uint8_t *w, uint8_t *d)
+{
+    size_t k = 0;
+    for (; k + 32 <= n; k += 32) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k + 16));
+        if ((uint32_t)_mm256_movemask_epi8(_mm256_or_si256(a, b)) & 0xAAAAAAAAu) {          // a MARK bit (the top bit of a high byte) somewhere
+            for (size_t i = k; i < k + 32; i++) { const uint16_t v = s[i]; d[i] = (v & MARK) ? w[v & 0x7FFF] : (uint8_t)v; }
+        } else
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(d + k), _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8));
+    }
+    for (; k < n; k++) { const uint16_t v = s[k]; d[k] = (v & MARK) ? w[v & 0x7FFF] : (uint8_t)v; }
+}
+void resolve_symbols(const uint16_t *s, size_t n, const uint8_t *w, uint8_t *d)
+{
+    static const bool simd = __builtin_cpu_supports("avx2") && !getenv("MF_NO_SIMD");
+    if (simd) { resolve_symbols_avx2(s, n, w, d); return; }
+    for (size_t k = 0; k < n; k++) { const uint16_t v = s[k]; d[k] = (v & MARK) ? w[v & 0x7FFF] : (uint8_t)v; }
+}
+
+namespace {
+
 uint32_t crc32_parallel(uint32_t crc, const uint8_t *p, size_t n, int threads)
 {
     const size_t slice = (size_t)2 << 20;
-    if (n < 2 * slice || threads < 2) {
-        size_t off = 0;
-        while (off < n) { const size_t k = n - off < ((size_t)1 << 30) ? n - off : ((size_t)1 << 30); crc = (uint32_t)crc32(crc, p + off, (uInt)k); off += k; }
-        return crc;
-    }
+    if (n < 2 * slice || threads < 2) return crc32_fast(crc, p, n);
     size_t parts = n / slice; if (parts > (size_t)threads) parts = (size_t)threads;
     std::vector<uint32_t> c(parts); std::vector<size_t> len(parts);
     std::vector<std::thread> th;
@@ -336,7 +409,7 @@ bool ParallelGzReader::fill_bgzf(ByteBuf &obuf_, std::string &err, bool &handled
             if (o.v.size() < (size_t)m.isize + 1024) o.v.resize((size_t)m.isize + 1024);
             const char *why = nullptr;
             const Stop st = decode_until<uint8_t>(in, t, o, SIZE_MAX, SIZE_MAX, why);
-            if (st != MEMBER_END || o.n != m.isize || (uint32_t)crc32(0, o.v.data(), (uInt)o.n) != m.crc) { bad = 1; continue; }
+            if (st != MEMBER_END || o.n != m.isize || crc32_fast(0, o.v.data(), o.n) != m.crc) { bad = 1; continue; }
             memcpy(obuf_.data() + m.out_off, o.v.data(), o.n);
         }
     };
@@ -529,7 +602,7 @@ bool ParallelGzReader::fill(ByteBuf &obuf_, std::string &err)
                 uint8_t *d = obuf_.data() + p.out_off;
                 if (p.bytes) { memcpy(d, p.bytes, p.n); continue; }
                 const uint8_t *w = p.window.data();
-                for (size_t k = 0; k < p.n; k++) { const uint16_t s = p.syms[k]; d[k] = (s & MARK) ? w[s & 0x7FFF] : (uint8_t)s; }
+                resolve_symbols(p.syms, p.n, w, d);
             }
         };
         const size_t T = pieces.size() < (size_t)threads_ ? pieces.size() : (size_t)threads_;

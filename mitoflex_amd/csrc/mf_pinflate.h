@@ -26,6 +26,9 @@
 
 namespace mf {
 
+uint32_t crc32_fast(uint32_t crc, const uint8_t *p, size_t n);                       // zlib's crc32() contract; PCLMULQDQ folding where the CPU has it
+void resolve_symbols(const uint16_t *s, size_t n, const uint8_t *window, uint8_t *out);    // marker symbols -> bytes (see mf_pinflate.cpp)
+
 class ParallelGzReader {
     using ByteBuf = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;   // sized without being zero-filled
 public:

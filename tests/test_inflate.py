@@ -194,3 +194,19 @@ def test_bgzf_members_are_decoded_side_by_side(exe, tmp_path):
         f.write_bytes(bytes(dmg))
         out = subprocess.check_output([exe, str(f), "-", "65536", "--parallel", "4", "1048576"]).decode().strip()
         assert out.startswith("error"), (pos, out)
+
+
+@pytest.mark.parametrize("no_simd", [False, True])
+def test_crc_and_marker_resolution_match_their_definitions(built_lib, tmp_path, no_simd):
+    """The carry-less-multiplication CRC-32 of the parallel reader against zlib's, and the vectorised symbol-to-byte pass against
+    its scalar definition (both also with MF_NO_SIMD, the portable paths)."""
+    csrc = os.path.join(ROOT, "mitoflex_amd", "csrc")
+    out = str(tmp_path / "simd_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tests", "native", "simd_check.cpp"),
+                           os.path.join(csrc, "build", "mf_inflate.o"), os.path.join(csrc, "build", "mf_pinflate.o"), os.path.join(csrc, "build", "mf_host.o"),
+                           "-lz", "-lpthread", "-o", out])
+    env = dict(os.environ)
+    if no_simd:
+        env["MF_NO_SIMD"] = "1"
+    for seed in (1, 2, 3):
+        assert subprocess.check_output([out, str(seed)], env=env).decode().strip() == "ok"

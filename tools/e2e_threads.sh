@@ -5,7 +5,7 @@ PAIRS=${1:-8000000}
 python tools/make_fastq.py $T/s --pairs $PAIRS > /dev/null
 ( gzip -1 -c $T/s_1.fq > $T/s_1.fq.gz ) & ( gzip -1 -c $T/s_2.fq > $T/s_2.fq.gz ) & wait
 cat /sys/fs/cgroup/cpu.max 2>/dev/null
-for th in default 8 12 16 20 24 32 48; do
+for th in ${THREADS_LIST:-default 8 12 16 20 24 32 48}; do
 if [ $th = default ]; then unset MF_PACK_THREADS; else export MF_PACK_THREADS=$th; fi
 python - <<PY
 import time, os, sys
