@@ -372,22 +372,27 @@ def test_many_logical_devices_match_oracle(ol, bait_text, tmp_path, n_dev):
     assert open(g2, "rb").read() == open(o2, "rb").read()
 
 
-def test_bench_two_ranks_under_torchrun(tmp_path):
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with two ranks
-    sharing the one visible GPU: the launcher's environment, the /dev/shm rendezvous, per-rank shards and rank 0's JSON line."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_under_torchrun(tmp_path, world):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the ranks
+    sharing the one visible GPU: the launcher's environment, the /dev/shm rendezvous, per-rank shards and rank 0's JSON line
+    (eight ranks: the shape of the 8-GPU run, with a small shard instead of configs[3]'s 41.67 M reads per rank)."""
     import json
     import subprocess
     import sys
-    port = 29000 + os.getpid() % 2000
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--reads", "2000000", "--no-exhaustive"], capture_output=True, timeout=300, cwd=str(tmp_path))
+    port = 29000 + (os.getpid() + world) % 2000
+    reads = 2000000 if world == 2 else 600000
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+                        "--prewarm-ms", "5", "--reads", str(reads), "--no-exhaustive", "--cpu-sample", "0", "--e2e-pairs", "0"],
+                       capture_output=True, timeout=300, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["extra"]["reads_per_gpu"] == 2000000 and 0.003 < d["extra"]["passed"] / 2000000 < 0.008
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["extra"]["reads_per_gpu"] == reads and 0.003 < d["extra"]["passed"] / reads < 0.008
+    assert abs(d["value"] - world * reads * 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]        # whole-job rate over all ranks
 
 
 @pytest.mark.parametrize("k", [21, 31, 41])
