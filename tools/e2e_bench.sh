@@ -22,6 +22,13 @@ run("SE plain -> plain", T+"/s_1.fq", None, T+"/o_se.fq", None)
 run("PE gz -> plain", T+"/s_1.fq.gz", T+"/s_2.fq.gz", T+"/og_1.fq", T+"/og_2.fq")
 run("SE gz -> plain (configs[4])", T+"/s_1.fq.gz", None, T+"/og_se.fq", None)
 assert open(T+"/o_1.fq","rb").read() == open(T+"/og_1.fq","rb").read()
+# the same with four-bin quality strings (the default draws eighteen equiprobable values: twice the compressed size, mostly literals)
+import subprocess
+subprocess.check_call([sys.executable, "tools/make_fastq.py", T+"/b", "--pairs", str(pairs), "--qual", "binned"], stdout=subprocess.DEVNULL)
+subprocess.check_call("gzip -1 -c %s/b_1.fq > %s/b_1.fq.gz" % (T, T), shell=True)
+print("binned-quality .gz is %.2f x smaller than its text (uniform: %.2f x)" % (os.path.getsize(T+"/b_1.fq") / os.path.getsize(T+"/b_1.fq.gz"), os.path.getsize(T+"/s_1.fq") / os.path.getsize(T+"/s_1.fq.gz")))
+run("SE gz -> plain, binned quals", T+"/b_1.fq.gz", None, T+"/ob_se.fq", None)
+run("SE gz -> plain, binned quals", T+"/b_1.fq.gz", None, T+"/ob_se.fq", None)
 print("cpu cores", os.cpu_count())
 PY
 # the CLI path (what shell_call would run)

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util_data import bait_records, make_bait  # noqa: E402
 
 
-def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate):
+def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate, qual="uniform"):
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     seq = acgt[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
@@ -35,7 +35,11 @@ def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate):
     rec[:, hl] = 10
     rec[:, hl + 1: hl + 1 + L] = seq
     rec[:, hl + 1 + L: hl + 4 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-    rec[:, hl + 4 + L: hl + 4 + 2 * L] = rng.integers(ord("8"), ord("J"), size=(n, L), dtype=np.uint8)
+    if qual == "binned":          # four quality bins, mostly the top one (what current instruments write); the default is eighteen equiprobable values
+        bins = np.frombuffer(b"F:,#", dtype=np.uint8)
+        rec[:, hl + 4 + L: hl + 4 + 2 * L] = bins[np.searchsorted(np.array([0.88, 0.94, 0.98]), rng.random((n, L), dtype=np.float32))]
+    else:
+        rec[:, hl + 4 + L: hl + 4 + 2 * L] = rng.integers(ord("8"), ord("J"), size=(n, L), dtype=np.uint8)
     rec[:, -1] = 10
     rec.tofile(path)
 
@@ -44,9 +48,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("prefix"); ap.add_argument("--pairs", type=int, default=1_000_000); ap.add_argument("--len", type=int, default=150)
     ap.add_argument("--mito", type=float, default=0.005); ap.add_argument("--seed", type=int, default=12340)
+    ap.add_argument("--qual", choices=["uniform", "binned"], default="uniform")
     a = ap.parse_args()
     bait = make_bait()
     open(a.prefix + ".bait.fa", "w").write(bait)
     g = bait_records(bait)[0]
     for mate in (1, 2):
-        write_mate(f"{a.prefix}_{mate}.fq", a.pairs, a.len, a.seed + mate, mate, g, a.mito, 0.01)
+        write_mate(f"{a.prefix}_{mate}.fq", a.pairs, a.len, a.seed + mate, mate, g, a.mito, 0.01, a.qual)
