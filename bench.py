@@ -57,7 +57,9 @@ class ShmRendezvous:
 
     def __init__(self, rank, world):
         self.rank, self.world, self.n = rank, world, 0
-        key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "") or os.getppid())
+        # one directory per launch: the launcher (parent of every rank) is part of the name, so that what a crashed earlier launch
+        # with the same port and run id left behind is never read
+        key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", ""), os.getppid())
         self.dir = "/dev/shm/mf_bench_%s_%d" % (key, os.getuid())
         os.makedirs(self.dir, exist_ok=True)
 
