@@ -3,16 +3,21 @@
 //   screen_kernel   streams the dense 2-bit read stream once from HBM with 16-byte coalesced non-temporal loads and
 //                   tests every stream-aligned s-mer in a blocked bit table held in LDS (stage 1).  A lane with a
 //                   positive only RECORDS it (16 bytes: chunk, lane, hit mask) -- no dependent load, no returning
-//                   atomic, no division in the streaming loop.  Pure integer/indexing work, HBM-bound by design.
+//                   atomic, no division in the streaming loop.  Pure integer/indexing work, HBM-bound by design: persistent
+//                   workgroups on seven CUs out of eight (stride 16; every CU for the VALU-bound stride-8 geometries).
 //   finish_kernel   threshold 1, no hit counts (the default pass): one thread per record, two launches.  Phase 0 tries the
 //                   first run of neighbouring positives of every record -- one canonical k-mer, one probe of the
 //                   open-address bait table; phase 1 settles what is left (exact s-mer table, then the sixteen windows a
-//                   sample owns).  A pass is an atomicOr.  Runs on a second stream under the next pass's screen kernel.
+//                   sample owns; a read's pass bit is looked at before anything of the read is fetched).  For k > 32 a run may
+//                   continue in the next lane's piece.  A pass is an atomicOr.  Runs on a second stream under the next pass's
+//                   screen kernel; consecutive screens alternate between two streams.
 //   mark_kernel     any threshold / hit counts: groups a record's positives by read, verifies lone ones (stage 2: Bloom over
 //                   canonical s-mers in L2; stage 3 for large baits: exact s-mer table) and sets candidate bits.
 //   exact_kernel    any threshold / hit counts, and the exhaustive mode: k-mer extract -> canonicalise -> LDS bit table ->
 //                   open-address table in L2 -> threshold, for candidate reads (or every read); a candidate's k-mer positions
-//                   are dealt to the lanes of a wave sixteen at a time, per-read counts live in LDS.
+//                   are dealt to the lanes of a wave sixteen at a time, per-read counts live in LDS.  Pipelined like the default
+//                   pass when no hit counts are wanted; beside a screen workgroup the exact kernel runs in a co-resident form
+//                   (512 threads, bit table folded to 16 KiB).
 //   build_*         device-side bait set builder (history-independent table), screen tables, k-mer bit table.
 //   qualscan_kernel / seqhash_kernel   the FASTQ quality filter's counts and SipHash-1-3 (filter_v2 drop-in).
 //
