@@ -922,6 +922,16 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
                 runs |= ((re >> 4) & 15u) << sh;
             }
         }
+        // A bait read shows in the records of two or three neighbouring lanes, and one confirmed run passes it: a run start is
+        // left to the lane on the left when that lane (the record before this one, if it is the same chunk's previous lane) has a
+        // run start of its own inside the same read.  (Should that one fail -- rare: its two samples are bait s-mers -- the read
+        // goes to phase 1, which looks at every positive.)
+        uint32_t lf_runs = 0; bool lf = false;
+        if (PHASE == 0 && SPW == 1 && fast) {
+            const uint32_t lc = __shfl_up(rec.chunk, 1), lt = __shfl_up(rec.tid, 1);
+            lf_runs = __shfl_up(runs, 1);
+            lf = (threadIdx.x & 63) != 0 && lc == rec.chunk && lt + 1 == rec.tid;
+        }
         if (PHASE == 0) m = runs; else runs = 0;      // phase 0 looks at run starts only, phase 1 at every positive on its own
         uint64_t passed_r = ~0ULL, passed_r2 = ~0ULL; // the last two reads this record has passed
         while (m) {
@@ -945,6 +955,13 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
                     // straddles two reads / lies in the padding behind the last read: not a sample (or run) of any read
                     if (offr + span > R.uniform_len || g0 + span > R.total_bases) continue;
                     r = rq + dq;
+                    if (PHASE == 0 && SPW == 1 && lf) {
+                        const uint32_t nib = (lf_runs >> (4 * (U - 1 - su))) & 15u;           // the left lane's run starts in the same piece row
+                        if (nib) {
+                            const int qn = 3 - (__ffs(nib) - 1);                               // the one nearest to this lane
+                            if ((uint32_t)(64 + 16 * (sq - qn)) <= offr) continue;             // ... lies inside this read: that lane's job
+                        }
+                    }
                 } else {
                     r = read_holding(R, g0, span);
                     if (r == ~0ULL) continue;
