@@ -765,9 +765,12 @@ static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t
     for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
     static const bool adapt = env_u32("MF_ADAPT", 1) != 0;          // (MF_ADAPT=0: measurements of the sample pass on bait-rich input)
     if (adapt && !T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && r->v.n_reads >= 100000) {
-        if (r->sample_pass) { if (cnt[1] > r->v.n_reads / 5) r->prefer_split = true; }            // work items per read: ~0.03 at 0.5 % bait reads, 0.5 at 10 %
+        // work items per read: ~0.025 at 0.5 % bait reads, 0.4 at 10 %, 0.8 at 20 %.  (Since a run start is left to the first lane that
+        // holds one, the two kinds of pass are within 5 % of each other from 2 % to 100 % bait reads; the switch stays for inputs
+        // that are nearly all bait.)
+        if (r->sample_pass) { if (cnt[1] > r->v.n_reads) r->prefer_split = true; }
         else {                                                                                     // candidate reads per read
-            if (r->prefer_split && cnt[1] < r->v.n_reads / 25) r->prefer_split = false;
+            if (r->prefer_split && cnt[1] < r->v.n_reads / 8) r->prefer_split = false;
             if (cnt[1] > r->v.n_reads / 20) r->split_serial = true; else if (cnt[1] < r->v.n_reads / 40) r->split_serial = false;
         }
     }
