@@ -7,7 +7,9 @@ for san in "address,undefined" "thread"; do
   tag=${san%%,*}
   g++ -O1 -g -fsanitize=$san -fno-omit-frame-pointer -std=c++17 -I $C $R/tests/native/pack_check.cpp $C/mf_host.cpp -lz -lpthread -o $T/pack_$tag
   g++ -O1 -g -fsanitize=$san -fno-omit-frame-pointer -std=c++17 -I $C $R/tests/native/inflate_check.cpp $C/mf_inflate.cpp $C/mf_pinflate.cpp -lz -lpthread -o $T/inflate_$tag
+  g++ -O1 -g -fsanitize=$san -fno-omit-frame-pointer -std=c++17 -I $C $R/tests/native/simd_check.cpp $C/mf_inflate.cpp $C/mf_pinflate.cpp -lz -lpthread -o $T/simd_$tag
   $T/pack_$tag; MF_NO_SIMD=1 $T/pack_$tag
+  $T/simd_$tag 1; MF_NO_SIMD=1 $T/simd_$tag 2
   MF_REPO=$R python3 - "$T" "$tag" <<'PY'
 import sys, random, subprocess, zlib
 T, tag = sys.argv[1], sys.argv[2]
