@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=READS_5GBP,
                     help="reads timed on the CPU oracle, all host threads (default: the whole set, a few seconds; 0 = skip)")
     ap.add_argument("--no-exhaustive", action="store_true", help="skip the extra exhaustive-mode measurement")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--e2e-pairs", type=int, default=500_000, help="pairs of the bounded files-in/files-out run reported in extra (0 = skip)")
     return ap.parse_args()
 
@@ -108,6 +109,40 @@ def committed_traffic():
         return None, None
 
 
+def live_traffic(timeout_s=75.0):
+    """HBM bytes per screen-kernel launch of THIS workload on THIS box: two short child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE -- one counter a pass, as MI355X_MICROARCH.md prescribes; counters cannot be
+    read from inside a process), FETCH_SIZE doubled for gfx950.  (bytes, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mf_pmc_", dir="/tmp")
+        try:
+            # (the profiled program comes right after `--`: no shell, no env wrapper in between)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "0", "--prewarm-ms", "0", "--cpu-sample", "0", "--no-exhaustive", "--e2e-pairs", "0", "--no-live-traffic"]
+            subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                    if "mf::screen_kernel<" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]      # (not build_screen_kernel)
+            if not vals:
+                return None, f"no {counter} rows for screen_kernel"
+            kib[counter] = sum(vals) / len(vals)
+        except Exception as e:
+            return None, f"{counter} pass failed: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int((2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024), \
+        "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script on this box (FETCH_SIZE x 2 on gfx950, KiB counters)"
+
+
 def cpu_quota():
     """CPUs the container may actually use (cgroup v2 cpu.max), or None when unlimited / unknown: the oracle runs on
     every visible hardware thread, but a quota caps what those threads get."""
@@ -155,6 +190,11 @@ def main():
     if a.reads <= 0:
         a.reads = READS_50GBP_8 if world == 8 else READS_5GBP
     rdv = ShmRendezvous(rank, world) if world > 1 else None
+
+    # roofline.traffic, live (two short counter runs of this script as child processes, before this process touches the GPU)
+    live = (None, None)
+    if rank == 0 and world == 1 and not a.no_live_traffic and a.reads == READS_5GBP and a.k == K:
+        live = live_traffic()
 
     from mitoflex_amd import mitofilter as mf
     mf.load()
@@ -262,6 +302,10 @@ def main():
     traffic, traffic_src = committed_traffic()
     if a.reads != READS_5GBP or a.k != K:
         traffic, traffic_src = None, None              # the profile was taken on the default workload
+    elif live[0] is not None:
+        traffic, traffic_src = live
+    elif live[1] and traffic_src:
+        traffic_src += f" (live collection unavailable: {live[1]})"
     if rank == 0:
         out = {
             "metric": "filtered reads/sec on 5 Gbp PE150 k=31; achieved HBM GB/s vs peak",
