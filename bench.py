@@ -121,6 +121,8 @@ def live_traffic(timeout_s=75.0):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is being profiled itself"
     kib = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mf_pmc_", dir="/tmp")
