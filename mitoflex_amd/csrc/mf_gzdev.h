@@ -1,0 +1,47 @@
+// DEFLATE decoding on the device (mf_gzdev.hip): one gzip stream decoded by thousands of wavefronts.
+//
+// The scheme is the two-pass one of the host reader (mf_pinflate.h; pugz / rapidgzip in the literature), laid out for the GPU:
+//   * the compressed file is cut into chunks of `chunk_bytes`; ONE WAVEFRONT per chunk.  Chunk 0 starts at the first deflate
+//     block of the member; every other chunk SEARCHES its range for a dynamic-Huffman block header with complete codes --
+//     64 bit offsets are tested per step, one per lane -- and decodes from there up to the first block boundary at or behind
+//     the start of the next chunk's range, into 16-bit symbols: a byte, or MARK | index where a match reaches back into the
+//     32 KiB the chunk cannot know;
+//   * gz_chain_kernel (one workgroup) walks the chunks in order: a chunk is accepted only if it began exactly where the
+//     accepted data ends -- by induction from chunk 0 every accepted chunk starts at a true block boundary -- gives it its
+//     place in the text and resolves the last 32 KiB of its symbols, which are the window of the chunk behind it;
+//   * gz_resolve_kernel turns every other symbol into a byte, in parallel, reading the windows the chain left in the text.
+// Whatever does not link (a stored or fixed block at a seam, a false candidate, a member boundary) stops the chain with the
+// exact bit position and window; the host decodes across the gap with its serial decoder and restarts the chain.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mf {
+
+constexpr uint16_t GZ_MARK = 0x8000;            // symbol = GZ_MARK | index into the 32 KiB in front of the chunk
+constexpr uint32_t GZ_WINDOW = 32768;
+
+enum GzStatus : uint32_t {
+    GZ_NONE = 0,            // no block header found in the chunk's range / not decoded
+    GZ_AT_BOUNDARY = 1,     // stopped in front of a block that starts at or behind the stop position
+    GZ_MEMBER_END = 2,      // stopped behind the final block of the member
+    GZ_FAILED = 3,          // the data does not decode (from a speculative start: a false candidate)
+    GZ_OVERFLOW = 4         // symbol buffer full: stopped at the last block boundary that fitted (end_bit, n_sym are valid)
+};
+
+struct GzChunk {
+    uint64_t start_bit;     // first bit of the block header decoding began at
+    uint64_t end_bit;       // block boundary where it stopped
+    uint32_t n_sym;         // symbols written
+    uint32_t status;        // GzStatus
+};
+
+// Decode chunks [chunk_lo, chunk_lo + n_chunks) of the deflate data in d_data[0 .. size) (readable, zero padded, up to size + 64).
+// Chunk c covers the bits [(base_byte + c * chunk_bytes) * 8, (base_byte + (c + 1) * chunk_bytes) * 8).  exact_chunk /
+// exact_bit: that chunk starts at exactly that bit, a known block boundary (the first block of a member, or where a gap
+// fill ended); pass exact_chunk = ~0u for none.  Symbols of chunk c go to d_sym + (c - chunk_lo) * sym_cap.
+hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes, uint32_t chunk_lo,
+                            uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
+                            GzChunk *d_chunks, hipStream_t st);
+
+} // namespace mf

@@ -1,0 +1,660 @@
+// DEFLATE decoding on gfx950 (see mf_gzdev.h for the scheme).  One wavefront per chunk of the compressed stream.
+//
+// Inside a wavefront the work is split by what is serial and what is not:
+//   * the Huffman walk -- table lookup, drop the code's bits, next lookup -- is one dependent chain; lane 0 walks up to 64
+//     codes ("a round") and leaves table entries / (length, distance) pairs in an LDS list.  First-level tables of 2^10
+//     (literal/length) and 2^9 (distance) entries live in LDS; an entry holds TWO literals where both codes fit into the
+//     index; codes longer than the index are decoded canonically (first code / count per length), so there are no
+//     sub-tables and the LDS footprint is fixed;
+//   * everything else is done by all 64 lanes: the search for a block header (one bit offset per lane), building the decode
+//     tables from the code lengths (ranks by ballot, table fill by symbol), and turning a round's list into output -- a
+//     prefix sum gives every list entry its place, then every OUTPUT POSITION of the round finds its entry (binary search in
+//     LDS) and fetches its symbol: a literal, a symbol written in an earlier round (global memory, all loads of the round in
+//     flight together), a marker, or -- for a match that reaches into the round itself -- a reference that is chased
+//     through the LDS staging buffer afterwards.  The round leaves as coalesced 16-bit stores.
+// The kernel is bound by the issue rate of the walk (about a dozen vector instructions per code on one lane); what hides it
+// is occupancy: ~10 KiB of LDS per wavefront, so fifteen chunks are in flight per CU.
+#include "mf_gzdev.h"
+#include <stddef.h>
+
+namespace mf {
+namespace {
+
+constexpr int LIT_BITS = 10, DIST_BITS = 9, PRE_BITS = 7;
+constexpr uint32_t LIT_SIZE = 1u << LIT_BITS, DIST_SIZE = 1u << DIST_BITS, PRE_SIZE = 1u << PRE_BITS;
+constexpr uint32_t ROUND = 64;           // list entries per round
+constexpr uint32_t STG = 1024;           // output symbols per round (staging buffer)
+constexpr uint32_t RING = 512;           // dwords of input held in LDS
+
+// literal/length entry: bits 0-7 bits to drop; bit 31 set = not a literal (one signed compare in the walk).
+//   literal:  bits 8-15 first byte, 16-23 second byte, bit 24 = two literals
+//   other:    bits 29-30 kind; a length: bits 24-26 extra bits, bits 8-15 base - 3
+constexpr uint32_t E_OTHER = 1u << 31, E_DOUBLE = 1u << 24;
+constexpr uint32_t K_MASK = 3u << 29, K_LENGTH = 0u << 29, K_EOB = 1u << 29, K_LONG = 2u << 29, K_INVALID = 3u << 29;
+// distance entry: bits 0-7 bits to drop; bit 31 set = long code (bit 30 clear) or invalid (bit 30 set); bits 24-27 extra bits, 8-22 base - 1
+constexpr uint32_t D_INVALID = 1u << 30;
+// list entry of a match: bit 31 | (length - 3) | (distance - 1) << 9; of literals: the table entry itself
+constexpr uint32_t PENDING = 0x4000;     // staging value: reference to another staging slot (bit 15 clear, bit 14 set)
+
+struct Canon { uint16_t first[16], cnt[16], off[16]; };
+struct Lds {                             // the walk's inline assembly relies on lit at LDS offset 0 and ring at LIT_SIZE * 4
+    uint32_t lit[LIT_SIZE];
+    uint32_t ring[RING];
+    uint32_t dist[DIST_SIZE];
+    uint32_t pre[PRE_SIZE];
+    uint32_t sym[ROUND + 2 * 64];    // the round's list; behind it two slots per lane for the stores of the lanes that are not the writer
+    uint16_t soff[ROUND];
+    uint16_t stg[STG];
+    uint16_t sorted_lit[288], sorted_dist[32];
+    Canon clit, cdist;
+    uint8_t lens[328];
+    uint8_t plens[24];
+};
+
+// LSB-first bit reader.  The input reaches the wavefront through a ring of RING dwords in LDS that all 64 lanes top up
+// together (one 16-byte load per lane, 1 KiB a time); the walk itself only ever reads LDS.  Every value in here is
+// wave-uniform: all lanes execute the reader with the same state, so its branches are scalar branches.
+struct BitRd {
+    const uint4 *base; uint32_t vmax;        // vectors 0 .. vmax of the input are readable
+    uint32_t *ring;                          // LDS; holds the dwords [ring_hi - RING, ring_hi)
+    uint32_t rd_dw, ring_hi;                 // rd_dw: next dword to enter the bit buffer
+    uint32_t nd;                             // ring[rd_dw], read ahead
+    uint64_t bb; uint32_t bc;
+    __device__ __forceinline__ uint32_t next_dword()
+    {
+        const uint32_t d = nd;
+        rd_dw++;
+        nd = ring[rd_dw & (RING - 1)];
+        return d;
+    }
+    __device__ __forceinline__ void refill() { if (bc <= 30) { bb |= (uint64_t)next_dword() << bc; bc += 32; } }   // afterwards 31 <= bc <= 62
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1); }           // n <= 31
+    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
+    __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)rd_dw * 32 - bc; }
+    __device__ __forceinline__ void load_half(uint32_t lane)      // 256 more dwords behind ring_hi
+    {
+        const uint32_t v = ring_hi / 4 + lane;
+        const uint4 x = base[v < vmax ? v : vmax];
+        *reinterpret_cast<uint4 *>(&ring[(ring_hi + 4 * lane) & (RING - 1)]) = x;
+        ring_hi += RING / 2;
+    }
+    // at least RING / 2 dwords ahead of the reader afterwards: a block header needs ~150, a round of the walk at most 96
+    __device__ __forceinline__ void top_up(uint32_t lane)
+    {
+        if (ring_hi - rd_dw < RING / 2) { load_half(lane); __syncthreads(); nd = ring[rd_dw & (RING - 1)]; }
+    }
+    __device__ __forceinline__ void seek(uint64_t bit, uint32_t lane)
+    {
+        const uint32_t d = (uint32_t)(bit >> 5);
+        if (!(d + RING / 2 <= ring_hi && d + RING >= ring_hi)) {
+            __syncthreads();
+            ring_hi = d & ~3u;
+            load_half(lane); load_half(lane);
+            __syncthreads();
+        }
+        rd_dw = d; bb = 0; bc = 0;
+        nd = ring[rd_dw & (RING - 1)];
+        refill();
+        drop((uint32_t)bit & 31);
+        refill();
+    }
+};
+
+__device__ __forceinline__ uint32_t lit_entry(uint32_t s)
+{
+    if (s < 256) return s << 8;
+    if (s == 256) return E_OTHER | K_EOB;
+    if (s < 286) {
+        const uint32_t k = s - 257;
+        uint32_t extra = 0, base = 3 + k;
+        if (k == 28) base = 258;
+        else if (k >= 8) { extra = (k >> 2) - 1; base = 3 + ((4 + (k & 3)) << extra); }
+        return E_OTHER | K_LENGTH | (extra << 24) | ((base - 3) << 8);      // the base is stored less 3 (what the list entry holds)
+    }
+    return E_OTHER | K_INVALID;
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t d)
+{
+    if (d >= 30) return E_OTHER | D_INVALID;
+    uint32_t extra = 0, base = 1 + d;
+    if (d >= 4) { extra = (d >> 1) - 1; base = 1 + ((2 + (d & 1)) << extra); }
+    return (extra << 24) | ((base - 1) << 8);                                     // the base is stored less 1
+}
+
+// Canonical Huffman decode table from code lengths, by the whole wavefront.  KIND 0: precode, 1: literal/length, 2: distance.
+// Returns the Kraft sum in units of 2^-15 (32768 = complete; more = over-subscribed, nothing is built); *n_codes = codes in use.
+template <int BITS, int KIND>
+__device__ __forceinline__ uint32_t build_table(const uint8_t *lens, uint32_t n, uint32_t *tab, uint16_t *sorted, Canon &cn, uint32_t lane, uint32_t *n_codes)
+{
+    constexpr int R = KIND == 1 ? 5 : 1;
+    constexpr uint32_t SIZE = 1u << BITS;
+    uint32_t myl[R], rank[R], c[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) c[l] = 0;
+    const uint64_t below = (1ull << lane) - 1;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t s = lane + 64 * r;
+        myl[r] = s < n ? lens[s] : 0;
+        rank[r] = 0;
+#pragma unroll
+        for (int l = 1; l < 16; l++) {
+            const uint64_t m = __ballot(myl[r] == (uint32_t)l);
+            if (myl[r] == (uint32_t)l) rank[r] = c[l] + __popcll(m & below);
+            c[l] += __popcll(m);
+        }
+    }
+    uint32_t code = 0, kraft = 0, o = 0, used = 0, fst[16], ofs[16];
+    fst[0] = ofs[0] = 0;
+#pragma unroll
+    for (int l = 1; l < 16; l++) {
+        code = (code + c[l - 1]) << 1; fst[l] = code; ofs[l] = o;
+        kraft += c[l] << (15 - l); o += c[l]; used += c[l];
+    }
+    if (n_codes) *n_codes = used;
+    if (kraft > 32768) return kraft;
+    if (lane < 16) {
+        uint32_t f = 0, cc = 0, oo = 0;
+#pragma unroll
+        for (int l = 1; l < 16; l++) if (lane == (uint32_t)l) { f = fst[l]; cc = c[l]; oo = ofs[l]; }
+        cn.first[lane] = (uint16_t)f; cn.cnt[lane] = (uint16_t)cc; cn.off[lane] = (uint16_t)oo;
+    }
+    const uint32_t invalid = KIND == 1 ? (E_OTHER | K_INVALID) : (KIND == 2 ? (E_OTHER | D_INVALID) : 0u);
+    for (uint32_t i = lane; i < SIZE; i += 64) tab[i] = invalid;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t l = myl[r], s = lane + 64 * r;
+        if (l) {
+            const uint32_t cd = (uint32_t)cn.first[l] + rank[r];
+            if (KIND != 0) sorted[cn.off[l] + rank[r]] = (uint16_t)s;
+            const uint32_t rev = __brev(cd) >> (32 - l);
+            if (l <= (uint32_t)BITS) {
+                const uint32_t e = (KIND == 1 ? lit_entry(s) : (KIND == 2 ? dist_entry(s) : (s << 8))) | l;
+                for (uint32_t i = rev; i < SIZE; i += 1u << l) tab[i] = e;
+            } else tab[rev & (SIZE - 1)] = KIND == 1 ? (E_OTHER | K_LONG) : E_OTHER;
+        }
+    }
+    __syncthreads();
+    return kraft;
+}
+
+// two literals per entry where both codes fit into the index (the entry of the second code is read from the single table)
+__device__ __forceinline__ void pair_literals(uint32_t *lit, uint32_t lane)
+{
+    uint32_t ne[LIT_SIZE / 64];
+#pragma unroll
+    for (uint32_t j = 0; j < LIT_SIZE / 64; j++) {
+        const uint32_t i = lane + 64 * j, e1 = lit[i];
+        ne[j] = e1;
+        if (!(e1 & E_OTHER)) {
+            const uint32_t l1 = e1 & 255;
+            if (l1 < (uint32_t)LIT_BITS) {
+                const uint32_t e2 = lit[i >> l1];
+                if (!(e2 & E_OTHER) && l1 + (e2 & 255) <= (uint32_t)LIT_BITS)
+                    ne[j] = (l1 + (e2 & 255)) | E_DOUBLE | (e1 & 0xFF00u) | ((e2 & 0xFF00u) << 8);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < LIT_SIZE / 64; j++) lit[lane + 64 * j] = ne[j];
+    __syncthreads();
+}
+
+__device__ const uint8_t PRE_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// Dynamic block header behind the three type bits: the code lengths of both alphabets into L.lens (uniform code; only the
+// LDS stores are left to lane 0).  strict: only what a compressor emits (a complete precode).
+__device__ __forceinline__ bool read_code_lengths(Lds &L, BitRd &rd, bool strict, uint32_t lane, uint32_t &hlit, uint32_t &hdist)
+{
+    rd.top_up(lane);
+    rd.refill();
+    hlit = rd.peek(5) + 257; rd.drop(5);
+    hdist = rd.peek(5) + 1; rd.drop(5);
+    const uint32_t hclen = rd.peek(4) + 4; rd.drop(4);
+    if (hlit > 286 || hdist > 30) return false;
+    if (lane < 24) L.plens[lane] = 0;
+    __syncthreads();
+    for (uint32_t i = 0; i < hclen; i++) { rd.refill(); const uint32_t v = rd.peek(3); rd.drop(3); if (lane == 0) L.plens[PRE_ORDER[i]] = (uint8_t)v; }
+    __syncthreads();
+    const uint32_t kraft = build_table<PRE_BITS, 0>(L.plens, 19, L.pre, nullptr, L.cdist, lane, nullptr);
+    if (kraft > 32768 || (strict && kraft != 32768)) return false;
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0;
+    // Running Kraft sums (units of 2^-15) of the two alphabets.  A speculative header is dropped the moment one of them passes 1:
+    // nearly every false candidate -- there are hundreds per chunk -- dies within its first few dozen code lengths instead of
+    // being parsed to the end and having its tables built.
+    uint32_t kl = 0, kd = 0;
+    while (i < total) {
+        rd.refill();
+        const uint32_t e = L.pre[(uint32_t)rd.bb & (PRE_SIZE - 1)];
+        if ((e & 255) == 0) return false;
+        rd.drop(e & 255);
+        const uint32_t s = e >> 8;
+        uint32_t rep = 1, val = s;
+        if (s >= 16) {
+            val = 0;
+            if (s == 16) { if (i == 0) return false; val = prev; rep = 3 + rd.peek(2); rd.drop(2); }
+            else if (s == 17) { rep = 3 + rd.peek(3); rd.drop(3); }
+            else { rep = 11 + rd.peek(7); rd.drop(7); }
+            if (i + rep > total) return false;
+        }
+        if (val) {
+            const uint32_t in_lit = i >= hlit ? 0 : (i + rep <= hlit ? rep : hlit - i);
+            kl += in_lit * (32768u >> val); kd += (rep - in_lit) * (32768u >> val);
+            if (strict && (kl > 32768u || kd > 32768u)) return false;
+        }
+        if (lane < rep) L.lens[i + lane] = (uint8_t)val;
+        if (lane + 64 < rep) L.lens[i + lane + 64] = (uint8_t)val;
+        if (lane + 128 < rep) L.lens[i + lane + 128] = (uint8_t)val;
+        i += rep; prev = val;
+    }
+    if (strict && kl != 32768u) return false;
+    __syncthreads();
+    return L.lens[256] != 0;
+}
+
+// both decode tables from L.lens[0 .. hlit + hdist)
+__device__ __forceinline__ bool build_tables(Lds &L, uint32_t hlit, uint32_t hdist, bool strict, uint32_t lane)
+{
+    uint32_t kraft = build_table<LIT_BITS, 1>(L.lens, hlit, L.lit, L.sorted_lit, L.clit, lane, nullptr);
+    if (kraft > 32768 || (strict && kraft != 32768)) return false;
+    uint32_t nd = 0;
+    kraft = build_table<DIST_BITS, 2>(L.lens + hlit, hdist, L.dist, L.sorted_dist, L.cdist, lane, &nd);
+    if (kraft > 32768 || (strict && nd > 1 && kraft != 32768)) return false;
+    pair_literals(L.lit, lane);
+    return true;
+}
+
+// Candidates for a block start: the bit offsets in [pos, to_bit) that look like the header of a non-final dynamic block --
+// type bits, symbol counts, Kraft sum of the precode -- 64 offsets a step, one per lane.  Returns the next one (~0: none) and
+// keeps the rest of the current step in `mask`.
+struct Search { uint64_t b0, mask; };
+__device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *words, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
+{
+    for (;;) {
+        if (S.mask) {
+            const int idx = __ffsll((unsigned long long)S.mask) - 1;
+            S.mask &= S.mask - 1;
+            return S.b0 + (uint64_t)idx;
+        }
+        S.b0 += 64;
+        if (S.b0 >= to_bit) return ~0ull;
+        const uint64_t bit = S.b0 + lane;
+        bool ok = bit < to_bit && bit + 128 <= size_bits;
+        if (ok) {
+            const uint64_t wi = bit >> 5; const uint32_t s = (uint32_t)bit & 31;
+            const uint32_t w0 = words[wi], w1 = words[wi + 1], w2 = words[wi + 2], w3 = words[wi + 3];
+            const uint32_t h0 = __funnelshift_r(w0, w1, s), h1 = __funnelshift_r(w1, w2, s), h2 = __funnelshift_r(w2, w3, s);
+            ok = (h0 & 7u) == 4u && ((h0 >> 3) & 31u) <= 29u && ((h0 >> 8) & 31u) <= 29u;      // BFINAL = 0, BTYPE = 10b
+            if (ok) {
+                const uint32_t hclen = ((h0 >> 13) & 15u) + 4;
+                const uint64_t a = h0 | ((uint64_t)h1 << 32), b = h1 | ((uint64_t)h2 << 32);
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 19; i++) {
+                    const uint32_t pos = 17 + 3 * i;
+                    const uint32_t l = (uint32_t)(pos < 32 ? (a >> pos) : (b >> (pos - 32))) & 7u;
+                    if (i < hclen && l) k += 128u >> l;
+                }
+                ok = k == 128u;
+            }
+        }
+        S.mask = __ballot(ok);
+    }
+}
+
+enum WalkEnd : uint32_t { W_MORE = 0, W_EOB = 1, W_ERROR = 2 };
+
+// Walk codes until the round is full, the block ends or something is wrong.  One dependent chain.  Every lane runs it with
+// the same values, but in VECTOR registers: a CU has one scalar unit for its four SIMDs, and a walk the compiler had moved
+// to it (the values are wave-uniform) ran all the CU's wavefronts through that one port.  `z` is a zero the compiler cannot
+// see through; branch conditions go through a ballot, which makes them scalar branches without exec-mask juggling.  Only
+// lane 0's stores reach the list -- the other lanes store to slots of their own.
+// The bit buffer is kept two bits up (lo & 0xFFC is the byte offset of a literal/length table entry) and the run of
+// literal codes -- nearly all of FASTQ -- is a hand-written loop: two lookups per pass, 12 instructions per lookup.
+#define GZ_UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(size_t)p; }
+__device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint32_t &n_out)
+{
+    static_assert(LIT_SIZE * 4 == 4096 && RING * 4 == 2048, "the assembly below has these sizes in its masks and offsets");
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    uint32_t lo = (uint32_t)(rd.bb << 2) | z, hi = (uint32_t)(rd.bb >> 30) | z;
+    uint32_t bc = rd.bc | z, nd = rd.nd | z, mtot = z;
+    const uint32_t r4_in = (rd.rd_dw << 2);
+    uint32_t r4 = r4_in | z;                    // 4 * (index of the dword nd holds), low 32 bits: the ring address and, by difference, the dwords taken
+    uint32_t n = 0, end = W_MORE;
+    uint32_t la = lds_off(L.sym) + (lane == 0 ? 0 : (ROUND + 2 * lane) * 4);
+    const uint32_t step1 = lane == 0 ? 4 : 0, step2 = 2 * step1;
+    // refill below 30 valid bits (so that the shift of the incoming dword, bc + 2, stays below 32): 30 <= bc <= 61 afterwards
+#define GZ_REFILL() do { if (GZ_UNI(bc < 30u)) { lo |= nd << (bc + 2); hi |= nd >> (30 - bc); bc += 32; r4 += 4; nd = L.ring[(r4 >> 2) & (RING - 1)] | z; } } while (0)
+#define GZ_DROP(x) do { const uint32_t x_ = (x); lo = __builtin_amdgcn_alignbit(hi, lo, x_); hi >>= (x_ & 31u); bc -= x_; } while (0)
+#define GZ_PEEK(nb) __builtin_amdgcn_ubfe(lo, 2u, (nb))
+    const uint32_t k_len = 0xA0000000u, k_sign = 0x80000000u, k_limit = STG - 260 - 2 * ROUND;
+    static_assert(offsetof(Lds, lit) == 0 && offsetof(Lds, ring) == 4096 && offsetof(Lds, dist) == 6144, "offsets used by the assembly");
+    while (n < ROUND - 1) {
+        uint32_t e, t, d, x, lenm3, reason;
+        n = (uint32_t)__builtin_amdgcn_readfirstlane(n);
+        // The walk proper.  Literal entries two lookups per pass; a length entry takes its extra bits, the distance code and its
+        // extra bits and leaves one list entry; the refill (ring read of the NEXT dword issued when the current one is taken)
+        // is part of the loop.  It leaves for what is rare: reason 0 = the list (or the staging buffer) is full; 2 = e is an
+        // end of block, a long code or invalid, nothing of it dropped; 3 = d is a long or invalid distance code, the length
+        // (less 3, in lenm3) already taken.
+#define GZ_A_REFILL \
+            "v_add_u32 %[t], 2, %[bc]\n\t" \
+            "v_lshl_or_b32 %[lo], %[nd], %[t], %[lo]\n\t" \
+            "v_sub_u32 %[t], 30, %[bc]\n\t" \
+            "v_lshrrev_b32 %[t], %[t], %[nd]\n\t" \
+            "v_or_b32 %[hi], %[hi], %[t]\n\t" \
+            "v_add_u32 %[bc], 32, %[bc]\n\t" \
+            "v_add_u32 %[r4], 4, %[r4]\n\t" \
+            "v_and_b32 %[t], 0x7fc, %[r4]\n\t" \
+            "ds_read_b32 %[nd], %[t] offset:4096\n"
+#define GZ_A_DROP(r) \
+            "v_alignbit_b32 %[lo], %[hi], %[lo], %[" r "]\n\t" \
+            "v_lshrrev_b32 %[hi], %[" r "], %[hi]\n\t" \
+            "v_sub_u32_sdwa %[bc], %[bc], %[" r "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        asm volatile(
+            "s_mov_b32 %[reason], 0\n"
+            ".Lgz_top_%=:\n\t"
+            "v_cmp_gt_u32 vcc, 30, %[bc]\n\t"
+            "s_cbranch_vccz .Lgz_pair_%=\n\t"
+            GZ_A_REFILL
+            ".Lgz_pair_%=:\n\t"
+            "v_and_b32 %[t], 0xffc, %[lo]\n\t"
+            "ds_read_b32 %[e], %[t]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_i32 vcc, 0, %[e]\n\t"
+            "s_cbranch_vccnz .Lgz_nl1_%=\n\t"
+            "ds_write_b32 %[la], %[e]\n\t"
+            GZ_A_DROP("e")
+            "v_and_b32 %[t], 0xffc, %[lo]\n\t"
+            "ds_read_b32 %[e], %[t]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_i32 vcc, 0, %[e]\n\t"
+            "s_cbranch_vccnz .Lgz_nl2_%=\n\t"
+            "ds_write_b32 %[la], %[e] offset:4\n\t"
+            "v_add_u32 %[la], %[la], %[step2]\n\t"
+            GZ_A_DROP("e")
+            "s_add_u32 %[n], %[n], 2\n\t"
+            "s_cmp_lt_u32 %[n], 63\n\t"
+            "s_cbranch_scc1 .Lgz_top_%=\n\t"
+            "s_branch .Lgz_done_%=\n"
+            ".Lgz_nl2_%=:\n\t"
+            "v_add_u32 %[la], %[la], %[step1]\n\t"
+            "s_add_u32 %[n], %[n], 1\n"
+            ".Lgz_nl1_%=:\n\t"
+            "v_cmp_gt_u32 vcc, %[klen], %[e]\n\t"
+            "s_cbranch_vccz .Lgz_other_%=\n\t"
+            GZ_A_DROP("e")
+            "v_bfe_u32 %[x], %[e], 24, 3\n\t"
+            "v_bfe_u32 %[t], %[lo], 2, %[x]\n\t"
+            "v_bfe_u32 %[len], %[e], 8, 8\n\t"
+            "v_add_u32 %[len], %[len], %[t]\n\t"
+            GZ_A_DROP("x")
+            "v_cmp_gt_u32 vcc, 30, %[bc]\n\t"
+            "s_cbranch_vccz .Lgz_dist_%=\n\t"
+            GZ_A_REFILL
+            ".Lgz_dist_%=:\n\t"
+            "v_and_b32 %[t], 0x7fc, %[lo]\n\t"
+            "ds_read_b32 %[d], %[t] offset:6144\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_i32 vcc, 0, %[d]\n\t"
+            "s_cbranch_vccnz .Lgz_dlong_%=\n\t"
+            GZ_A_DROP("d")
+            "v_bfe_u32 %[x], %[d], 24, 4\n\t"
+            "v_bfe_u32 %[t], %[lo], 2, %[x]\n\t"
+            "v_bfe_u32 %[d], %[d], 8, 15\n\t"
+            "v_add_u32 %[d], %[d], %[t]\n\t"
+            GZ_A_DROP("x")
+            "v_lshl_or_b32 %[t], %[d], 9, %[len]\n\t"
+            "v_or_b32 %[t], %[sign], %[t]\n\t"
+            "ds_write_b32 %[la], %[t]\n\t"
+            "v_add_u32 %[la], %[la], %[step1]\n\t"
+            "v_add3_u32 %[mtot], %[mtot], %[len], 3\n\t"
+            "s_add_u32 %[n], %[n], 1\n\t"
+            "v_cmp_lt_u32 vcc, %[limit], %[mtot]\n\t"
+            "s_cbranch_vccnz .Lgz_done_%=\n\t"
+            "s_cmp_lt_u32 %[n], 63\n\t"
+            "s_cbranch_scc1 .Lgz_top_%=\n\t"
+            "s_branch .Lgz_done_%=\n"
+            ".Lgz_dlong_%=:\n\t"
+            "s_mov_b32 %[reason], 3\n\t"
+            "s_branch .Lgz_done_%=\n"
+            ".Lgz_other_%=:\n\t"
+            "s_mov_b32 %[reason], 2\n"
+            ".Lgz_done_%=:\n"
+            : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [nd] "+v"(nd), [r4] "+v"(r4), [la] "+v"(la), [mtot] "+v"(mtot), [n] "+s"(n),
+              [e] "=&v"(e), [t] "=&v"(t), [d] "=&v"(d), [x] "=&v"(x), [len] "=&v"(lenm3), [reason] "=&s"(reason)
+            : [step1] "v"(step1), [step2] "v"(step2), [klen] "s"(k_len), [sign] "s"(k_sign), [limit] "s"(k_limit)
+            : "vcc", "scc", "memory");
+#undef GZ_A_REFILL
+#undef GZ_A_DROP
+        if (reason == 0) break;
+        if (reason == 2) {
+            GZ_REFILL();                             // (a second lookup may leave as few as 20 bits; a long code and its extra bits need 20)
+            if (GZ_UNI((e & K_MASK) == K_LONG)) {
+                const uint32_t rev = __brev(lo >> 2);
+                uint32_t s = 0xFFFFu, len = 0;
+                for (int l = LIT_BITS + 1; l <= 15; l++) {
+                    const uint32_t idx = (rev >> (32 - l)) - L.clit.first[l];
+                    if (GZ_UNI(idx < L.clit.cnt[l])) { len = (uint32_t)l; s = L.sorted_lit[L.clit.off[l] + idx]; break; }
+                }
+                if (GZ_UNI(s == 0xFFFFu)) { end = W_ERROR; break; }
+                GZ_DROP(len);
+                e = lit_entry(s);
+                if (!GZ_UNI((int32_t)e < 0)) { asm volatile("ds_write_b32 %0, %1" :: "v"(la), "v"(e) : "memory"); la += step1; n++; continue; }
+            } else GZ_DROP(e & 255u);
+            const uint32_t kind = e & K_MASK;
+            if (GZ_UNI(kind == K_EOB)) { end = W_EOB; break; }
+            if (GZ_UNI(kind != K_LENGTH)) { end = W_ERROR; break; }
+            const uint32_t xl = (e >> 24) & 7u;
+            lenm3 = ((e >> 8) & 0xFFu) + GZ_PEEK(xl); GZ_DROP(xl);
+            GZ_REFILL();
+            d = L.dist[(lo >> 2) & (DIST_SIZE - 1)];
+        }
+        if (GZ_UNI((int32_t)d < 0)) {
+            if (GZ_UNI((d & D_INVALID) != 0)) { end = W_ERROR; break; }
+            const uint32_t rev = __brev(lo >> 2);
+            uint32_t s = 0xFFFFu, dl = 0;
+            for (int l = DIST_BITS + 1; l <= 15; l++) {
+                const uint32_t idx = (rev >> (32 - l)) - L.cdist.first[l];
+                if (GZ_UNI(idx < L.cdist.cnt[l])) { dl = (uint32_t)l; s = L.sorted_dist[L.cdist.off[l] + idx]; break; }
+            }
+            if (GZ_UNI(s == 0xFFFFu)) { end = W_ERROR; break; }
+            GZ_DROP(dl);
+            d = dist_entry(s);
+            if (GZ_UNI((int32_t)d < 0)) { end = W_ERROR; break; }
+        } else GZ_DROP(d & 255u);
+        const uint32_t xd = (d >> 24) & 15u;
+        const uint32_t distm1 = ((d >> 8) & 0x7FFFu) + GZ_PEEK(xd); GZ_DROP(xd);
+        const uint32_t m = 0x80000000u | lenm3 | (distm1 << 9);
+        asm volatile("ds_write_b32 %0, %1" :: "v"(la), "v"(m) : "memory");
+        la += step1; n++;
+        mtot += lenm3 + 3;
+        if (GZ_UNI(mtot > k_limit)) break;           // the staging buffer takes what is listed so far plus a round of literals
+    }
+#undef GZ_REFILL
+#undef GZ_DROP
+#undef GZ_PEEK
+    // (the builtin returns int: without the casts the low half is sign-extended over the high one)
+    const uint64_t bb4 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(lo);
+    rd.bb = bb4 >> 2;
+    rd.bc = (uint32_t)__builtin_amdgcn_readfirstlane(bc); rd.nd = (uint32_t)__builtin_amdgcn_readfirstlane(nd);
+    rd.rd_dw += ((uint32_t)__builtin_amdgcn_readfirstlane(r4) - r4_in) >> 2;
+    n_out = (uint32_t)__builtin_amdgcn_readfirstlane(n);
+    return (uint32_t)__builtin_amdgcn_readfirstlane(end);
+}
+
+// all lanes: the round's list -> symbols at out[opos ..]
+// returns the number of symbols written
+__device__ __forceinline__ uint32_t expand(Lds &L, uint32_t n, uint16_t *out, uint64_t opos, uint32_t lane)
+{
+    const uint32_t s0 = lane < n ? L.sym[lane] : 0;
+    const uint32_t cnt = lane < n ? ((s0 >> 31) ? (s0 & 0x1FFu) + 3 : 1 + ((s0 >> 24) & 1u)) : 0;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
+    const uint32_t tot = __shfl(inc, 63);
+    if (__ballot(s0 >> 31) == 0) {               // literals only (most rounds of FASTQ): every entry stores its one or two symbols itself
+        if (lane < n) { out[opos + inc - cnt] = (uint16_t)((s0 >> 8) & 0xFFu); if (cnt == 2) out[opos + inc - 1] = (uint16_t)((s0 >> 16) & 0xFFu); }
+        return tot;
+    }
+    L.soff[lane] = (uint16_t)(inc - cnt);
+    __syncthreads();
+    bool pending = false;
+    for (uint32_t p = lane; p < tot; p += 64) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1) { const uint32_t j = lo + step; if (j < n && L.soff[j] <= p) lo = j; }
+        const uint32_t s = L.sym[lo], o = L.soff[lo];
+        uint32_t v;
+        if (!(s >> 31)) v = (p == o ? (s >> 8) : (s >> 16)) & 0xFFu;
+        else {
+            const uint32_t len = (s & 0x1FFu) + 3, D = ((s >> 9) & 0x7FFFu) + 1, t = p - o;
+            const uint32_t r = D < len ? t % D : t;
+            const int32_t srel = (int32_t)o - (int32_t)D + (int32_t)r;
+            if (srel >= 0) { v = PENDING | (uint32_t)srel; pending = true; }
+            else {
+                const int64_t g = (int64_t)opos + srel;
+                v = g >= 0 ? out[g] : (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g));
+            }
+        }
+        L.stg[p] = (uint16_t)v;
+    }
+    __syncthreads();
+    while (__any(pending)) {                     // references into the round itself: they point strictly backwards
+        pending = false;
+        for (uint32_t p = lane; p < tot; p += 64) {
+            const uint32_t v = L.stg[p];
+            if ((v & 0xC000u) == PENDING) {
+                const uint32_t w = L.stg[v & 0x3FFFu];
+                if ((w & 0xC000u) == PENDING) pending = true; else L.stg[p] = (uint16_t)w;
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t p = lane; p < tot; p += 64) out[opos + p] = L.stg[p];
+    return tot;
+}
+
+__global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes,
+                                                       uint32_t chunk_lo, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *sym,
+                                                       uint64_t sym_cap, GzChunk *chunks)
+{
+    __shared__ Lds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = chunk_lo + blockIdx.x;
+    uint16_t *out = sym + (uint64_t)blockIdx.x * sym_cap;
+    const uint64_t size_bits = size * 8;
+    const uint64_t nominal = (base_byte + (uint64_t)c * chunk_bytes) * 8, stop_bit = nominal + chunk_bytes * 8;
+    const uint64_t search_end = stop_bit < size_bits ? stop_bit : size_bits;
+    GzChunk res; res.start_bit = 0; res.end_bit = 0; res.n_sym = 0; res.status = GZ_NONE;
+    BitRd rd; rd.base = reinterpret_cast<const uint4 *>(data); rd.vmax = (uint32_t)((size + 48) / 16);      // readable (and zero) up to size + 64
+    rd.ring = L.ring; rd.rd_dw = 0; rd.ring_hi = 0; rd.nd = 0; rd.bb = 0; rd.bc = 0;
+    // A speculative chunk tries the candidates of its range in order: one whose header parses strictly is decoded; if the data
+    // behind it turns out not to decode (a false candidate) the search goes on behind it.
+    bool searching = c != exact_chunk;
+    Search S; S.b0 = nominal - 64; S.mask = 0;
+    uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
+    uint32_t status = GZ_NONE;
+    if (!searching) rd.seek(start, lane);
+    else if (nominal >= size_bits) { if (lane == 0) chunks[c] = res; return; }
+    uint32_t why = 0;                               // what stopped a decode that failed (reported in n_sym of a GZ_FAILED chunk)
+    for (;;) {
+        uint32_t final = 0, type = 2;
+        bool strict = false;
+        why = 0;
+        if (searching) {
+            start = next_candidate(S, reinterpret_cast<const uint32_t *>(data), search_end, size_bits, lane);
+            if (start == ~0ull) { status = GZ_NONE; break; }
+            rd.seek(start + 3, lane);
+            strict = true; opos = 0; blk_pos = start; blk_opos = 0;
+        } else {
+            blk_pos = rd.bitpos(); blk_opos = opos;
+            if (blk_pos >= stop_bit) { status = GZ_AT_BOUNDARY; break; }
+            if (blk_pos + 3 > size_bits) why = 1;
+            else {
+                rd.top_up(lane);
+                rd.refill(); final = rd.peek(1); type = rd.peek(3) >> 1; rd.drop(3);
+                if (type == 3) why = 2;
+            }
+            if (!why && type == 0) {               // stored block: byte aligned LEN, ~LEN, then the bytes
+                rd.drop(rd.bc & 7); rd.refill();
+                const uint32_t len = rd.peek(16); rd.drop(16); rd.refill();
+                const uint32_t nlen = rd.peek(16); rd.drop(16);
+                const uint64_t byte = rd.bitpos() >> 3;
+                if ((len ^ nlen) != 0xFFFFu || byte + len > size) why = 3;
+                else {
+                    if (opos + len > sym_cap) { status = GZ_OVERFLOW; break; }
+                    for (uint32_t i = lane; i < len; i += 64) out[opos + i] = data[byte + i];
+                    opos += len;
+                    rd.seek((byte + len) * 8, lane);
+                    if (final) { status = GZ_MEMBER_END; break; }
+                    continue;
+                }
+            }
+        }
+        if (!why) {
+            uint32_t hlit = 288, hdist = 32;
+            bool ok = true;
+            if (type == 1) {
+                for (uint32_t i = lane; i < 320; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : (i < 288 ? 8 : 5)));
+                __syncthreads();
+            } else ok = read_code_lengths(L, rd, strict, lane, hlit, hdist);
+            if (!ok) why = 4;
+            else if (!build_tables(L, hlit, hdist, strict, lane)) why = 5;
+        }
+        if (!why) {
+            searching = false;
+            uint32_t end = W_MORE;
+            while (end == W_MORE) {
+                if (opos + STG > sym_cap) { status = GZ_OVERFLOW; break; }
+                rd.top_up(lane);
+                uint32_t n = 0;
+                end = walk(L, rd, lane, n);
+                if (end == W_ERROR) why = 6;
+                if (rd.bitpos() > size_bits) { end = W_ERROR; why = 7; }
+                __syncthreads();
+                if (end == W_ERROR) break;
+                opos += expand(L, n, out, opos, lane);
+                __syncthreads();
+            }
+            if (status == GZ_OVERFLOW) break;
+        }
+        if (why) {
+            // not deflate data.  From a speculative start that only says the candidate was false: the search goes on behind it
+            // (S still holds the rest of the candidates of its step)
+            if (c != exact_chunk) { searching = true; continue; }
+            status = GZ_FAILED; break;
+        }
+        if (final) { status = GZ_MEMBER_END; break; }
+    }
+    if (lane == 0) {
+        res.start_bit = start;
+        if (status == GZ_OVERFLOW) { res.end_bit = blk_pos; res.n_sym = (uint32_t)blk_opos; }
+        else if (status == GZ_AT_BOUNDARY) { res.end_bit = blk_pos; res.n_sym = (uint32_t)opos; }
+        else { res.end_bit = rd.bitpos(); res.n_sym = (uint32_t)opos; }
+        if (status == GZ_NONE) res.n_sym = 0;
+        if (status == GZ_FAILED) res.n_sym = why;
+        res.status = status;
+        chunks[c] = res;
+    }
+}
+
+} // namespace
+
+
+hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes, uint32_t chunk_lo,
+                            uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
+                            GzChunk *d_chunks, hipStream_t st)
+{
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, size, base_byte, chunk_bytes, chunk_lo, exact_chunk,
+                       exact_bit, d_sym, sym_cap, d_chunks);
+    return hipGetLastError();
+}
+
+} // namespace mf

@@ -1,0 +1,119 @@
+// Stand-alone check and timing of the device DEFLATE decoder (mitoflex_amd/csrc/mf_gzdev.hip) against zlib.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip tools/gzdev_check.cpp mitoflex_amd/csrc/mf_gzdev.hip -lz -o tools/gzdev_check
+//   tools/gzdev_check file.gz [chunk_KiB=256] [expansion=8] [reps=3]
+// Decodes every chunk on the GPU, links the chunks on the host the way gz_chain_kernel does, resolves markers from the
+// reference text and compares every byte with zlib's output.
+#include "../mitoflex_amd/csrc/mf_gzdev.h"
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <zlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s file.gz [chunk_KiB] [expansion] [reps]\n", argv[0]); return 2; }
+    const size_t chunk = (argc > 2 ? strtoull(argv[2], 0, 10) : 256) << 10;
+    const size_t expansion = argc > 3 ? strtoull(argv[3], 0, 10) : 8;
+    const int reps = argc > 4 ? atoi(argv[4]) : 3;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    fseek(f, 0, SEEK_END); const size_t size = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> gz(size + 64, 0);
+    if (fread(gz.data(), 1, size, f) != size) { perror("read"); return 2; }
+    fclose(f);
+    // gzip header -> first deflate bit
+    if (size < 18 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8) { fprintf(stderr, "not gzip\n"); return 2; }
+    size_t p = 10; const unsigned flg = gz[3];
+    if (flg & 4) { p += 2 + (gz[p] | (gz[p + 1] << 8)); }
+    if (flg & 8) { while (gz[p]) p++; p++; }
+    if (flg & 16) { while (gz[p]) p++; p++; }
+    if (flg & 2) p += 2;
+    // reference text (first member only)
+    std::vector<uint8_t> ref;
+    {
+        z_stream z; memset(&z, 0, sizeof z);
+        inflateInit2(&z, -15);
+        z.next_in = gz.data() + p; z.avail_in = (uInt)(size - p > 0xFFFFFFFFu ? 0xFFFFFFFFu : size - p);
+        ref.resize(size * 3 + (1 << 20));
+        size_t got = 0; int rc;
+        for (;;) {
+            if (ref.size() - got < (1u << 20)) ref.resize(ref.size() * 2);
+            z.next_out = ref.data() + got; z.avail_out = (uInt)((ref.size() - got) > 0x40000000u ? 0x40000000u : (ref.size() - got));
+            const size_t before = z.total_out;
+            rc = inflate(&z, Z_NO_FLUSH);
+            got += z.total_out - before;
+            if (rc != Z_OK) break;
+        }
+        if (rc != Z_STREAM_END) { fprintf(stderr, "zlib: %d\n", rc); return 2; }
+        ref.resize(got);
+        inflateEnd(&z);
+    }
+    const size_t base_byte = p;
+    const uint32_t n_chunks = (uint32_t)((size - base_byte + chunk - 1) / chunk);
+    const size_t cap = chunk * expansion + 4096;
+    printf("%s: %zu bytes -> %zu bytes of text (%.2fx), %u chunks of %zu KiB, %zu symbols of room each\n", argv[1], size, ref.size(),
+           (double)ref.size() / size, n_chunks, chunk >> 10, cap);
+    uint8_t *d_data; uint16_t *d_sym; mf::GzChunk *d_chunks;
+    CK(hipMalloc(&d_data, size + 64)); CK(hipMemcpy(d_data, gz.data(), size + 64, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_sym, (size_t)n_chunks * cap * 2));
+    CK(hipMalloc(&d_chunks, n_chunks * sizeof(mf::GzChunk)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < reps; r++) {
+        CK(hipMemset(d_chunks, 0, n_chunks * sizeof(mf::GzChunk)));
+        CK(hipEventRecord(e0, 0));
+        CK(mf::launch_gz_decode(d_data, size, base_byte, chunk, 0, n_chunks, 0, (uint64_t)base_byte * 8, d_sym, cap, d_chunks, 0));
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+        printf("  decode kernel: %.3f ms\n", ms);
+    }
+    std::vector<mf::GzChunk> ch(n_chunks);
+    CK(hipMemcpy(ch.data(), d_chunks, n_chunks * sizeof(mf::GzChunk), hipMemcpyDeviceToHost));
+    std::vector<uint16_t> sym(cap);
+    uint64_t cur = (uint64_t)base_byte * 8, total = 0, linked = 0, sym_total = 0; bool ok = true, ended = false;
+    uint32_t hist[5] = {0, 0, 0, 0, 0};
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        hist[ch[c].status < 5 ? ch[c].status : 0]++;
+        if (ch[c].status == mf::GZ_FAILED) printf("chunk %u failed: reason %u at bit %llu (started at %llu)\n", c, ch[c].n_sym, (unsigned long long)ch[c].end_bit, (unsigned long long)ch[c].start_bit);
+        else sym_total += ch[c].n_sym;
+    }
+    for (uint32_t c = 0; c < n_chunks && ok && !ended; c++) {
+        const mf::GzChunk &k = ch[c];
+        if (k.status == mf::GZ_NONE || k.status == mf::GZ_FAILED || k.start_bit != cur) {
+            if (k.start_bit < cur && k.status != mf::GZ_NONE) continue;          // lies inside accepted data: discarded
+            printf("chunk %u does not link: status %u start %llu, accepted data ends at %llu (gap of %lld bits)\n", c, k.status,
+                   (unsigned long long)k.start_bit, (unsigned long long)cur, (long long)(k.start_bit - cur));
+            ok = false; break;
+        }
+        CK(hipMemcpy(sym.data(), d_sym + (size_t)c * cap, (size_t)k.n_sym * 2, hipMemcpyDeviceToHost));
+        if (total + k.n_sym > ref.size()) { printf("chunk %u: more output than the reference holds\n", c); ok = false; break; }
+        for (uint32_t i = 0; i < k.n_sym; i++) {
+            const uint16_t v = sym[i];
+            uint8_t b;
+            if (v & mf::GZ_MARK) {
+                const int64_t src = (int64_t)total - 32768 + (v & 0x7FFF);
+                if (src < 0) { printf("chunk %u symbol %u: marker reaches in front of the text\n", c, i); ok = false; break; }
+                b = ref[(size_t)src];
+            } else b = (uint8_t)v;
+            if (v < 0x8000 && v > 255) { printf("chunk %u symbol %u: stray value %04x\n", c, i, v); ok = false; break; }
+            if (b != ref[total + i]) { printf("chunk %u symbol %u (text offset %llu): %02x, expected %02x\n", c, i, (unsigned long long)(total + i), b, ref[total + i]); ok = false; break; }
+        }
+        total += k.n_sym; cur = k.end_bit; linked++;
+        if (k.status == mf::GZ_MEMBER_END) ended = true;
+        if (k.status == mf::GZ_OVERFLOW) { printf("chunk %u overflowed its symbol buffer\n", c); ok = false; }
+    }
+    printf("status histogram: none %u, boundary %u, member end %u, failed %u, overflow %u\n", hist[0], hist[1], hist[2], hist[3], hist[4]);
+    printf("linked %llu of %u chunks, %llu of %zu bytes verified, member end %s\n", (unsigned long long)linked, n_chunks,
+           (unsigned long long)total, ref.size(), ended ? "reached" : "NOT reached");
+    printf("kernel %.3f ms: %.2f GB/s of text, %.2f GB/s of compressed input (%llu symbols written)\n", best, sym_total / best / 1e6, size / best / 1e6,
+           (unsigned long long)sym_total);
+    const bool pass = ok && ended && total == ref.size();
+    printf(pass ? "PASS\n" : "FAIL\n");
+    return pass ? 0 : 1;
+}
