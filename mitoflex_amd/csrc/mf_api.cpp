@@ -8,6 +8,8 @@
 #include "mf_kernels.h"
 #include "mf_pipeline.h"
 #include "mf_synth.h"
+#include "mf_api_internal.h"
+#include "mf_devingest.h"
 
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -25,7 +27,8 @@ using namespace mf;
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string t_err;
-static int fail(int code, const char *fmt, ...)
+const std::string &mf_thread_error() { return t_err; }
+int fail(int code, const char *fmt, ...)
 {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -38,7 +41,6 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // --------------------------------------------------------------- device ctx
-struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; int n_cu = 0; };    // stream2: finish kernels of pipelined passes; stream3: every other screen
 static std::mutex g_ctx_mu;
 static std::map<int, DevCtx> g_ctx;
 
@@ -51,11 +53,11 @@ static int fake_devices()
     return n;
 }
 static int physical_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
-static int phys(int device) { const int n = physical_count(); return fake_devices() && n > 0 ? device % n : device; }
+int phys(int device) { const int n = physical_count(); return fake_devices() && n > 0 ? device % n : device; }
 
 // lane: a device can have several independent contexts (own streams); the file pipeline runs two workers per device so
 // that the host-to-device copy of one batch overlaps the kernels and the read-back of the other
-static int get_ctx(int device, DevCtx **out, int lane = 0)
+int get_ctx(int device, DevCtx **out, int lane)
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     auto it = g_ctx.find(device + 4096 * lane);
@@ -392,34 +394,6 @@ int mf_kmerset_free(mf_kmerset *ks)
 } // extern "C"
 
 // -------------------------------------------------------------------- reads
-// Buffer sets a pipelined pass rotates through (a third set, or a second finish stream, changed nothing measurable).
-constexpr int NSETS = 2;
-struct mf_reads {
-    int device = 0, lane = 0;     // lane: which of the device's contexts (streams) this read set works on
-    ReadsView v{};
-    uint32_t *d_words = nullptr; uint64_t *d_offsets = nullptr, *d_npos = nullptr;
-    uint32_t *d_has_n = nullptr, *d_hits = nullptr, *d_npos_blk = nullptr;
-    // Threshold-1 passes (screen_kernel + finish_kernel) are pipelined: the finish kernel of pass i runs on a second stream
-    // under the screen kernel of pass i + 1, the way consecutive batches of a file do.  What a pass writes therefore
-    // exists NSETS times and rotates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.
-    uint32_t *d_cand[NSETS] = {}, *d_bits[NSETS] = {};
-    void *d_recs[NSETS] = {}; uint32_t *d_rec_counts[NSETS] = {};     // stage-1 positive records (screen -> finish / mark)
-    unsigned long long *d_counters[NSETS] = {};                       // 2 * EXACT_MAX_GRID tally pairs each, in pinned HOST memory: the kernels store
-                                                                      // their pair there directly and a call ends without a device-to-host copy
-    hipEvent_t ev_screen[NSETS] = {}, ev_finish[NSETS] = {};          // ordering between the two streams
-    hipEvent_t ev_call[2] = {};                                       // begin / end of a call's passes
-    bool cand_clean[NSETS] = {}, sample_pass = false;     // sample_pass: the latest pass was a screen + finish one
-    // Bait-rich input (more than a few per cent of the reads are bait reads -- what the `bim` loop enriches towards) is better
-    // served by the candidate-bitmap pass: one thread per stage-1 record means several records per bait read, and the screen
-    // writes them all.  The choice follows the work the last call of this read set (the last batch of this device) saw.
-    bool prefer_split = false;
-    bool split_serial = false;      // ... and with very many candidates (> 5 % of the reads) its kernels do not fit beside the next screen: one stream
-    int cur = 0;
-    size_t bitmap_bytes = 0;
-    // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
-    size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0, cap_npos_blk = 0;
-};
-
 // How a screened pass is run.  Default: screen_kernel, then finish_kernel when the threshold is 1 and no hit counts are wanted
 // (mark_kernel + exact_kernel otherwise).  MF_PASS=split: always screen, mark, exact.  MF_PASS=serial: screen + finish
 // without overlapping consecutive passes (for comparison).
@@ -429,7 +403,7 @@ static int pass_kind()          // (looked up on every pass: bench.py times the 
     return v && strcmp(v, "split") == 0 ? 1 : (v && strcmp(v, "serial") == 0 ? 2 : 0);
 }
 
-static void reads_release(mf_reads *r)
+void reads_release(mf_reads *r)
 {
     if (!r) return;
     if (hipSetDevice(phys(r->device)) == hipSuccess) {
@@ -446,39 +420,21 @@ static void reads_release(mf_reads *r)
     delete r;
 }
 
-// grow a device buffer to at least `bytes` (with some slack when it is being re-used)
-template <class T> static hipError_t dev_reserve(T *&p, size_t &cap, size_t bytes, bool slack)
+#define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(MF_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+int reads_reserve(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, uint32_t uniform_len, uint64_t npos_cap, DevCtx *ctx)
 {
-    if (bytes <= cap && p) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-    const size_t want = slack ? bytes + bytes / 4 + 4096 : (bytes ? bytes : 16);
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
+    const uint64_t padded = padded_words_for(n_words);                                   // readable and zero past the data
+    RCHK(dev_reserve(r->d_words, r->cap_words, padded * 4, reuse));
+    if (padded > n_words) RCHK(hipMemsetAsync(r->d_words + n_words, 0, (padded - n_words) * 4, ctx->stream));
+    if (!uniform_len) RCHK(dev_reserve(r->d_offsets, r->cap_offsets, (n_reads + 1) * 8, reuse));
+    RCHK(dev_reserve(r->d_npos, r->cap_npos, (npos_cap ? npos_cap : 1) * 8, reuse));
+    return MF_OK;
 }
 
-// Fill `r` (fresh, or holding buffers of an earlier batch on the same device) with one packed read set.
-// words: host buffer; already_padded = it extends to padded_words_for(n_words) with a zero tail.
-static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets,
-                      uint64_t n_reads, uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos,
-                      DevCtx *ctx)
+int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, uint64_t total_bases, uint32_t uniform_len, uint64_t n_npos, DevCtx *ctx)
 {
     hipStream_t st = ctx->stream;
     const uint64_t padded = padded_words_for(n_words);
-    const uint64_t dev_words = padded;                                                   // readable and zero past the data
-#define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(MF_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
-    RCHK(dev_reserve(r->d_words, r->cap_words, dev_words * 4, reuse));
-    {
-        const uint64_t copied = already_padded ? padded : n_words;
-        if (dev_words > copied) RCHK(hipMemsetAsync(r->d_words + copied, 0, (dev_words - copied) * 4, st));
-        if (copied) RCHK(hipMemcpyAsync(r->d_words, words, copied * 4, hipMemcpyHostToDevice, st));
-    }
-    if (!uniform_len) {
-        RCHK(dev_reserve(r->d_offsets, r->cap_offsets, (n_reads + 1) * 8, reuse));
-        RCHK(hipMemcpyAsync(r->d_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-    }
-    RCHK(dev_reserve(r->d_npos, r->cap_npos, (n_npos ? n_npos : 1) * 8, reuse));
-    if (n_npos) RCHK(hipMemcpyAsync(r->d_npos, npos, n_npos * 8, hipMemcpyHostToDevice, st));
     if (n_npos >= 0xFFFFFFFFull) return fail(MF_E_ARG, "more than 2^32 invalid bases in one read set");
     const uint64_t n_blk = (total_bases >> NPOS_BLK_SHIFT) + 3;
     RCHK(dev_reserve(r->d_npos_blk, r->cap_npos_blk, n_blk * 4, reuse));
@@ -530,9 +486,25 @@ static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n
     }
     RCHK(launch_mark_has_n(V, r->d_has_n, st));
     RCHK(hipStreamSynchronize(st));
-#undef RCHK
     return MF_OK;
 }
+
+// Fill `r` (fresh, or holding buffers of an earlier batch on the same device) with one packed read set from host memory.
+// words: host buffer; already_padded = it extends to padded_words_for(n_words) with a zero tail.
+static int reads_fill(mf_reads *r, bool reuse, const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets,
+                      uint64_t n_reads, uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos,
+                      DevCtx *ctx)
+{
+    hipStream_t st = ctx->stream;
+    int rc = reads_reserve(r, reuse, n_words, n_reads, uniform_len, n_npos, ctx);
+    if (rc) return rc;
+    const uint64_t copied = already_padded ? padded_words_for(n_words) : n_words;
+    if (copied) RCHK(hipMemcpyAsync(r->d_words, words, copied * 4, hipMemcpyHostToDevice, st));
+    if (!uniform_len) RCHK(hipMemcpyAsync(r->d_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    if (n_npos) RCHK(hipMemcpyAsync(r->d_npos, npos, n_npos * 8, hipMemcpyHostToDevice, st));
+    return reads_finish(r, reuse, n_words, n_reads, total_bases, uniform_len, n_npos, ctx);
+}
+#undef RCHK
 
 static int reads_upload(const uint32_t *words, uint64_t n_words, bool already_padded, const uint64_t *offsets, uint64_t n_reads,
                         uint64_t total_bases, uint32_t uniform_len, const uint64_t *npos, uint64_t n_npos, int device,
@@ -712,8 +684,8 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     return MF_OK;
 }
 
-static int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, int mode, uint32_t *out_bits,
-                         uint32_t *hits_out, int steps, mf_filter_stats_t *stats)
+int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, int mode, uint32_t *out_bits,
+                  uint32_t *hits_out, int steps, mf_filter_stats_t *stats)
 {
     mf_kmerset *ks = const_cast<mf_kmerset *>(ks_);
     mf_reads *r = const_cast<mf_reads *>(reads_);
@@ -836,6 +808,18 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     if (n_devices < 1) n_devices = 1;
     if (n_devices > have) n_devices = have;
 
+    // One device and regular files: the bytes go to the GPU as they are and inflate, line indexing, packing, filter and the copy
+    // of the survivors run there (mf_devingest.cpp).  MF_INGEST=host keeps the host pipeline (readers, inflaters and packers
+    // on host threads); pipes, BGZF files and several devices always take it.
+    {
+        const char *ing = getenv("MF_INGEST");
+        if (n_devices == 1 && !(ing && strcmp(ing, "host") == 0)) {
+            std::string derr;
+            const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, 0, kept, total, derr);
+            if (drc == MF_OK) return MF_OK;
+            if (drc != MF_DEVINGEST_DECLINED) return fail(drc, "%s", derr.c_str());
+        }
+    }
     const int hw = (int)std::thread::hardware_concurrency();
     // pack threads: what is left after the readers, writers and device workers
     int pack_threads = hw - 4 - n_devices; if (pack_threads < 1) pack_threads = 1; if (pack_threads > 64) pack_threads = 64;

@@ -44,4 +44,37 @@ hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_
                             uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
                             GzChunk *d_chunks, hipStream_t st);
 
+// ---- linking the chunks (one workgroup, in stream order) and turning symbols into text
+enum GzStop : uint32_t {
+    GZ_STOP_NONE = 0,       // every chunk of the range was looked at
+    GZ_STOP_GAP = 1,        // chunk `next` does not begin where the accepted data ends (or has no data): the host decodes across the gap
+    GZ_STOP_MEMBER_END = 2  // the chunk before `next` ended behind the final block of a member (cur_bit: first bit behind it)
+};
+struct GzChain {
+    uint64_t cur_bit;       // block boundary where the accepted data ends
+    uint64_t total;         // bytes of text accepted so far (offset of the next byte in the member's text)
+    uint32_t next;          // first chunk not yet accepted or discarded
+    uint32_t stop;          // GzStop
+    uint32_t linked, discarded;
+    uint32_t wlen, pad;     // valid bytes in `window` (right-aligned)
+    uint8_t window[GZ_WINDOW];   // the last 32 KiB of accepted text
+};
+// Walks chunks [chain->next, chunk_hi) in order.  A chunk is accepted iff its status is GZ_AT_BOUNDARY / GZ_MEMBER_END and it starts
+// at chain->cur_bit; chunks that start inside accepted data are discarded.  For an accepted chunk c: out_off[c] = its text offset,
+// and the last min(n_sym, 32 KiB) of its symbols are written as bytes to text[out_off[c] + ...] (text is addressed by absolute
+// offset minus text_base; the 32 KiB in front of the first accepted chunk are written too, from chain->window).  out_off of
+// chunks that are not accepted is set to ~0.
+hipError_t launch_gz_chain(GzChain *d_chain, const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym,
+                           uint64_t sym_cap, uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, hipStream_t st);
+// Every symbol of the accepted chunks of [chunk_lo, chunk_hi) that the chain did not already write becomes a byte of text.
+// max_sym: the largest n_sym among them (grid sizing).
+hipError_t launch_gz_resolve(const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym, uint64_t sym_cap,
+                             const uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, uint32_t max_sym, hipStream_t st);
+// CRC-32 (gzip) of d_text[0 .. n) as 64 KiB pieces: d_piece[i] = the pure polynomial remainder (register starts at 0, no final
+// inversion) of piece i; gz_crc_finish() on the host folds them into zlib's crc32() value.
+constexpr uint32_t GZ_CRC_PIECE = 65536;
+hipError_t launch_gz_crc(const uint8_t *d_text, uint64_t n, uint32_t *d_piece, hipStream_t st);
+uint32_t gz_crc_finish(const uint32_t *piece, uint64_t n);                 // crc32(0, text, n)
+uint32_t gz_crc_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);   // crc32 of A||B from crc32(A), crc32(B)
+
 } // namespace mf

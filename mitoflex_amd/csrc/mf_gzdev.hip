@@ -644,8 +644,142 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
     }
 }
 
-} // namespace
+// ---------------------------------------------------------------------------------------------------------- chain
+// One workgroup walks the chunks in stream order.  The last 32 KiB of accepted text live in LDS (two buffers: the tail of a
+// chunk is resolved against the window in front of the chunk while the window behind it is being written).
+__global__ __launch_bounds__(1024) void gz_chain_kernel(GzChain *chain, const GzChunk *chunks, uint32_t chunk_lo, uint32_t chunk_hi,
+                                                        const uint16_t *sym, uint64_t sym_cap, uint64_t *out_off, uint8_t *text,
+                                                        uint64_t text_base)
+{
+    __shared__ uint8_t win[2][GZ_WINDOW];
+    const uint32_t tid = threadIdx.x;
+    uint64_t cur = chain->cur_bit, total = chain->total;
+    uint32_t c = chain->next, wlen = chain->wlen, linked = chain->linked, discarded = chain->discarded, stop = GZ_STOP_NONE;
+    for (uint32_t i = tid * 16; i < GZ_WINDOW; i += 1024 * 16)
+        *reinterpret_cast<uint4 *>(&win[0][i]) = *reinterpret_cast<const uint4 *>(&chain->window[i]);
+    __syncthreads();
+    // the window is text too: a chunk's markers are looked up there by the resolve kernel
+    for (uint32_t i = tid; i < wlen; i += 1024) text[(int64_t)(total - text_base) - (int64_t)wlen + i] = win[0][GZ_WINDOW - wlen + i];
+    uint32_t a = 0;
+    for (; c < chunk_hi; c++) {
+        const GzChunk ch = chunks[c];
+        const bool ok = ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END;
+        if (!ok || ch.start_bit < cur) { if (tid == 0) out_off[c] = ~0ull; discarded++; continue; }
+        if (ch.start_bit > cur) { stop = GZ_STOP_GAP; break; }
+        if (tid == 0) out_off[c] = total;
+        const uint32_t n = ch.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW, keep = GZ_WINDOW - tail;
+        const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap + (n - tail);
+        uint8_t *tp = text + (int64_t)(total - text_base) + (n - tail);
+        const uint8_t *wa = win[a]; uint8_t *wb = win[a ^ 1];
+        for (uint32_t i = tid; i < keep; i += 1024) wb[i] = wa[i + tail];          // (a chunk shorter than the window: the rest slides)
+        for (uint32_t i = tid * 8; i < tail; i += 1024 * 8) {
+            uint16_t v[8];
+            const uint32_t m = tail - i < 8 ? tail - i : 8;
+            if (m == 8) __builtin_memcpy(v, sp + i, 16); else for (uint32_t k = 0; k < m; k++) v[k] = sp[i + k];
+            for (uint32_t k = 0; k < m; k++) {
+                const uint8_t b = (v[k] & GZ_MARK) ? wa[v[k] & 0x7FFFu] : (uint8_t)v[k];
+                wb[keep + i + k] = b; tp[i + k] = b;
+            }
+        }
+        __syncthreads();
+        a ^= 1;
+        total += n; cur = ch.end_bit; linked++;
+        wlen = wlen + n < GZ_WINDOW ? wlen + n : GZ_WINDOW;
+        if (ch.status == GZ_MEMBER_END) { c++; stop = GZ_STOP_MEMBER_END; break; }
+    }
+    for (uint32_t i = tid * 16; i < GZ_WINDOW; i += 1024 * 16)
+        *reinterpret_cast<uint4 *>(&chain->window[i]) = *reinterpret_cast<const uint4 *>(&win[a][i]);
+    if (tid == 0) {
+        chain->cur_bit = cur; chain->total = total; chain->next = c; chain->stop = stop;
+        chain->linked = linked; chain->discarded = discarded; chain->wlen = wlen;
+    }
+}
 
+// ---------------------------------------------------------------------------------------------------------- resolve
+constexpr uint32_t RESOLVE_SEG = 8192;            // symbols per workgroup
+__global__ __launch_bounds__(256) void gz_resolve_kernel(const GzChunk *chunks, uint32_t chunk_lo, const uint16_t *sym, uint64_t sym_cap,
+                                                         const uint64_t *out_off, uint8_t *text, uint64_t text_base)
+{
+    const uint32_t c = chunk_lo + blockIdx.y;
+    const uint64_t off = out_off[c];
+    if (off == ~0ull) return;
+    const uint32_t n = chunks[c].n_sym;
+    const uint32_t body = n > GZ_WINDOW ? n - GZ_WINDOW : 0;      // the chain has written the rest
+    const uint32_t s0 = blockIdx.x * RESOLVE_SEG;
+    if (s0 >= body) return;
+    const uint32_t s1 = s0 + RESOLVE_SEG < body ? s0 + RESOLVE_SEG : body;
+    const uint16_t *sp = sym + (uint64_t)blockIdx.y * sym_cap;
+    uint8_t *tp = text + (int64_t)(off - text_base);
+    const uint8_t *wp = tp - GZ_WINDOW;                            // the 32 KiB in front of the chunk
+    for (uint32_t i = s0 + threadIdx.x * 8; i < s1; i += 256 * 8) {
+        const uint32_t m = s1 - i < 8 ? s1 - i : 8;
+        uint16_t v[8];
+        if (m == 8) __builtin_memcpy(v, sp + i, 16); else for (uint32_t k = 0; k < m; k++) v[k] = sp[i + k];
+        uint8_t b[8];
+        for (uint32_t k = 0; k < m; k++) b[k] = (v[k] & GZ_MARK) ? wp[v[k] & 0x7FFFu] : (uint8_t)v[k];
+        if (m == 8) __builtin_memcpy(tp + i, b, 8); else for (uint32_t k = 0; k < m; k++) tp[i + k] = b[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- CRC-32
+// The gzip polynomial, reflected.  A thread takes 256 bytes with four table lookups per dword (tables built in LDS by the
+// workgroup), then moves its remainder to the end of the 64 KiB piece -- multiplication by x^(8 * bytes behind it) modulo the
+// polynomial, 32 shift-and-add steps -- and the workgroup XORs the 256 results: CRCs are linear once the register starts at 0.
+constexpr uint32_t CRC_POLY = 0xEDB88320u, CRC_RUN = 256;
+__host__ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)       // a * b mod P; bit 31 is the coefficient of x^0
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t crc_xpow8(uint64_t n_bytes)              // x^(8 * n_bytes) mod P
+{
+    uint32_t r = 0x80000000u, sq = 0x00800000u;                               // x^0, x^8
+    for (; n_bytes; n_bytes >>= 1) { if (n_bytes & 1) r = crc_mulmod(r, sq); sq = crc_mulmod(sq, sq); }
+    return r;
+}
+__global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *text, uint64_t n, uint32_t *piece, uint32_t run_mult)
+{
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t part[4];
+    const uint32_t tid = threadIdx.x;
+    {
+        uint32_t r = tid;
+        for (int k = 0; k < 8; k++) r = (r & 1u) ? (r >> 1) ^ CRC_POLY : r >> 1;
+        T[0][tid] = r;
+    }
+    __syncthreads();
+    for (int j = 1; j < 4; j++) { const uint32_t p = T[j - 1][tid]; T[j][tid] = T[0][p & 0xFFu] ^ (p >> 8); __syncthreads(); }
+    const uint64_t p0 = (uint64_t)blockIdx.x * GZ_CRC_PIECE, pn = n - p0 < GZ_CRC_PIECE ? n - p0 : GZ_CRC_PIECE;
+    const uint64_t b0 = (uint64_t)tid * CRC_RUN;
+    uint32_t r = 0;
+    if (b0 < pn) {
+        const uint8_t *q = text + p0 + b0;
+        uint32_t len = pn - b0 < CRC_RUN ? (uint32_t)(pn - b0) : CRC_RUN;
+        while (len && ((size_t)q & 3)) { r = T[0][(r ^ *q++) & 0xFFu] ^ (r >> 8); len--; }
+        for (; len >= 4; len -= 4, q += 4) {
+            r ^= *reinterpret_cast<const uint32_t *>(q);
+            r = T[3][r & 0xFFu] ^ T[2][(r >> 8) & 0xFFu] ^ T[1][(r >> 16) & 0xFFu] ^ T[0][r >> 24];
+        }
+        while (len) { r = T[0][(r ^ *q++) & 0xFFu] ^ (r >> 8); len--; }
+        // bytes of the piece behind this thread's run
+        const uint64_t behind = pn - (b0 + CRC_RUN < pn ? b0 + CRC_RUN : pn);
+        if (pn == GZ_CRC_PIECE) {                                    // whole piece: x^(8 * 256 * (255 - tid)) by repeated multiplication with x^(8 * 256)
+            uint32_t mlt = 0x80000000u, sq = run_mult;
+            for (uint32_t e = 255 - tid; e; e >>= 1) { if (e & 1) mlt = crc_mulmod(mlt, sq); sq = crc_mulmod(sq, sq); }
+            r = crc_mulmod(r, mlt);
+        } else r = crc_mulmod(r, crc_xpow8(behind));
+    }
+    for (int d = 32; d; d >>= 1) r ^= __shfl_xor(r, d);
+    if ((tid & 63) == 0) part[tid >> 6] = r;
+    __syncthreads();
+    if (tid == 0) piece[blockIdx.x] = part[0] ^ part[1] ^ part[2] ^ part[3];
+}
+
+} // namespace
 
 hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes, uint32_t chunk_lo,
                             uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
@@ -655,6 +789,48 @@ hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_
     hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, size, base_byte, chunk_bytes, chunk_lo, exact_chunk,
                        exact_bit, d_sym, sym_cap, d_chunks);
     return hipGetLastError();
+}
+
+hipError_t launch_gz_chain(GzChain *d_chain, const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym,
+                           uint64_t sym_cap, uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, hipStream_t st)
+{
+    hipLaunchKernelGGL(gz_chain_kernel, dim3(1), dim3(1024), 0, st, d_chain, d_chunks, chunk_lo, chunk_hi, d_sym, sym_cap, d_out_off, d_text, text_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_gz_resolve(const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym, uint64_t sym_cap,
+                             const uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, uint32_t max_sym, hipStream_t st)
+{
+    if (chunk_hi <= chunk_lo || max_sym <= GZ_WINDOW) return hipSuccess;
+    const uint32_t gx = (max_sym - GZ_WINDOW + RESOLVE_SEG - 1) / RESOLVE_SEG;
+    hipLaunchKernelGGL(gz_resolve_kernel, dim3(gx, chunk_hi - chunk_lo), dim3(256), 0, st, d_chunks, chunk_lo, d_sym, sym_cap, d_out_off, d_text, text_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_gz_crc(const uint8_t *d_text, uint64_t n, uint32_t *d_piece, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    static const uint32_t run_mult = crc_xpow8(CRC_RUN);
+    hipLaunchKernelGGL(gz_crc_kernel, dim3((uint32_t)((n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE)), dim3(256), 0, st, d_text, n, d_piece, run_mult);
+    return hipGetLastError();
+}
+
+// crc32(A || B) = crc32(A) * x^(8 |B|) + crc32(B): the pre- and post-conditioning of the two values cancel out
+uint32_t gz_crc_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return crc_mulmod(crc_a, crc_xpow8(len_b)) ^ crc_b; }
+
+uint32_t gz_crc_finish(const uint32_t *piece, uint64_t n)
+{
+    // pure remainders of the pieces -> pure remainder of the text (Horner), then zlib's conditioning: a register that starts at
+    // all ones and is inverted at the end adds the CRC of n zero bytes, which is a function of n alone
+    if (!n) return 0;
+    const uint64_t np = (n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE, last = n - (np - 1) * GZ_CRC_PIECE;
+    const uint32_t full = crc_xpow8(GZ_CRC_PIECE);
+    uint32_t r = 0;
+    for (uint64_t i = 0; i + 1 < np; i++) r = (i ? crc_mulmod(r, full) : 0u) ^ piece[i];
+    r = (np > 1 ? crc_mulmod(r, crc_xpow8(last)) : 0u) ^ piece[np - 1];
+    // crc32 of n zero bytes: the all-ones start value moved n bytes along, inverted
+    const uint32_t zeros = crc_mulmod(0xFFFFFFFFu, crc_xpow8(n)) ^ 0xFFFFFFFFu;
+    return r ^ zeros;
 }
 
 } // namespace mf

@@ -1,0 +1,40 @@
+// FASTQ text that is already in device memory -> line index -> 2-bit packed read set -> survivors' text (mf_ingest.hip).
+// The device-side counterpart of the host readers and packer (mf_pipeline.cpp, mf_host.cpp pack_records): same conventions --
+// the reference's (filter/filter_bin/src/main.rs:287-321): strict 4-line records, line 3 ignored, a CR in front of the LF
+// stripped, a partial record at the very end dropped; Spec B's alphabet: A/a C/c G/g T/t, anything else invalid
+// (stored as 0 and listed).  Used by the device ingest path of mf_filter_fastq_files (mf_devingest.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mf {
+
+constexpr uint32_t INGEST_TILE = 4096;          // bytes of text per workgroup of the line kernels
+
+// exclusive prefix sums, u32 -> u64: out[0 .. n] (n + 1 values, out[n] = total).  scratch: (n / 4096 + 2) u64
+hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *scratch, hipStream_t st);
+
+// newlines per tile of INGEST_TILE bytes of text[0 .. n); text must be readable up to n + 16
+hipError_t launch_count_newlines(const uint8_t *text, uint64_t n, uint32_t *tile_cnt, hipStream_t st);
+// line_start[k] = offset of the first byte of line k (line 0 starts at 0; line k + 1 starts behind the k-th newline);
+// tile_base = exclusive scan of tile_cnt
+hipError_t launch_line_starts(const uint8_t *text, uint64_t n, const uint64_t *tile_base, uint64_t *line_start, hipStream_t st);
+// sequence length of records [0, n_rec): line 4r+1 without its LF and without a CR in front of it; minmax[0] = min, [1] = max
+// (preset to ~0, 0).  line_start must have 4 * n_rec + 1 entries.
+hipError_t launch_seq_lens(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint32_t *seq_len, uint32_t *minmax, hipStream_t st);
+// 2-bit pack: words[w] holds bases 16w .. 16w+15 of the concatenated sequences.  offsets: n_rec + 1 base offsets (nullptr when
+// every read has uniform_len bases).  MODE 0 (npos == nullptr): writes words and, per workgroup of 256 words, the number of
+// invalid bases to inv_cnt.  MODE 1: inv_base = exclusive scan of inv_cnt; writes the positions of the invalid bases, ascending, to npos.
+hipError_t launch_pack(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_rec,
+                       uint64_t total_bases, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st);
+// pass bits of one batch (bit i = record i of the batch) into the file-wide bitmap at record index rec_base
+hipError_t launch_store_bits(const uint32_t *batch_bits, uint64_t n_rec, uint32_t *file_bits, uint64_t rec_base, hipStream_t st);
+// output bytes of records [0, n_rec) of a batch whose first record has file index rec_base: header + seq + "+" + qual with LF
+// line ends when kept (bits_a[r] | bits_b[r], or & when both; bits_b may be nullptr), else 0
+hipError_t launch_out_lens(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t rec_base, const uint32_t *bits_a,
+                           const uint32_t *bits_b, int both, uint32_t *out_len, hipStream_t st);
+// copies the kept records to out[out_off[r] ..] (out_off = exclusive scan of out_len)
+hipError_t launch_gather(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, const uint32_t *out_len, const uint64_t *out_off,
+                         uint8_t *out, hipStream_t st);
+
+} // namespace mf

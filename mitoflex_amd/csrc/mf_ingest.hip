@@ -1,0 +1,336 @@
+// FASTQ text in device memory -> line index -> packed read set -> survivors (see mf_ingest.h).
+// Every kernel here streams its input once at 16 bytes per lane; none of them is a hot spot next to the decoder that
+// produces the text (mf_gzdev.hip) -- they exist so that the text never has to leave the device.
+#include "mf_ingest.h"
+
+namespace mf {
+namespace {
+
+__device__ __forceinline__ uint4 load16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }   // (unaligned: one global_load_dwordx4)
+
+// 0x80 in every byte of w that equals the byte replicated in c4 (exact per byte, no borrow between bytes)
+__device__ __forceinline__ uint32_t eq_flags(uint32_t w, uint32_t c4)
+{
+    const uint32_t x = w ^ c4, t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// sum of v over the workgroup (blockDim.x a multiple of 64, at most 1024); result valid in every thread
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *lds)
+{
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    const uint32_t w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[w] = v;
+    __syncthreads();
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < nw; i++) s += lds[i];
+    return s;
+}
+// exclusive prefix of v over the workgroup in thread order; *total = the workgroup's sum
+template <class T> __device__ __forceinline__ T block_exclusive(T v, T *lds, T *total)
+{
+    T inc = v;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const T t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
+    __syncthreads();
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    T base = 0, sum = 0;
+    for (uint32_t i = 0; i < nw; i++) { if (i < w) base += lds[i]; sum += lds[i]; }
+    if (total) *total = sum;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------------------ scan
+constexpr uint32_t SCAN_BLOCK = 1024, SCAN_ITEMS = 4, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const uint32_t *in, uint64_t n, uint64_t *partial)
+{
+    __shared__ uint64_t lds[16];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; k++) if (i0 + k < n) s += in[i0 + k];
+    uint64_t tot;
+    (void)block_exclusive<uint64_t>(s, lds, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_partials_kernel(uint64_t *partial, uint64_t nb)      // in place, exclusive; partial[nb] = total
+{
+    __shared__ uint64_t lds[16];
+    uint64_t carry = 0;
+    for (uint64_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
+        const uint64_t i = b0 + threadIdx.x;
+        const uint64_t v = i < nb ? partial[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = block_exclusive<uint64_t>(v, lds, &tot);
+        if (i < nb) partial[i] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[nb] = carry;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_final_kernel(const uint32_t *in, uint64_t n, const uint64_t *partial, uint64_t *out, uint64_t nb)
+{
+    __shared__ uint64_t lds[16];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS]; uint64_t s = 0;
+    for (uint32_t k = 0; k < SCAN_ITEMS; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0; s += v[k]; }
+    uint64_t run = partial[blockIdx.x] + block_exclusive<uint64_t>(s, lds, nullptr);
+    for (uint32_t k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nb];
+}
+
+// ------------------------------------------------------------------------------------------------------------ lines
+// newline flags of the 16 bytes at `off` (bytes at or behind n do not count): 0x80 per byte, four dwords
+__device__ __forceinline__ void nl16(const uint8_t *text, uint64_t off, uint64_t n, uint32_t f[4])
+{
+    f[0] = f[1] = f[2] = f[3] = 0;
+    if (off >= n) return;
+    const uint4 v = load16(text + off);
+    f[0] = eq_flags(v.x, 0x0A0A0A0Au); f[1] = eq_flags(v.y, 0x0A0A0A0Au); f[2] = eq_flags(v.z, 0x0A0A0A0Au); f[3] = eq_flags(v.w, 0x0A0A0A0Au);
+    const uint64_t left = n - off;
+    if (left < 16) for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t valid = left > 4 * j ? (uint32_t)(left - 4 * j) : 0;           // bytes of dword j in front of n
+        if (valid < 4) f[j] &= valid ? (0xFFFFFFFFu >> (8 * (4 - valid))) : 0u;
+    }
+}
+__global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *text, uint64_t n, uint32_t *tile_cnt)
+{
+    __shared__ uint32_t lds[4];
+    uint32_t f[4];
+    nl16(text, (uint64_t)blockIdx.x * INGEST_TILE + threadIdx.x * 16, n, f);
+    const uint32_t c = __popc(f[0]) + __popc(f[1]) + __popc(f[2]) + __popc(f[3]);
+    const uint32_t s = block_sum(c, lds);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void line_starts_kernel(const uint8_t *text, uint64_t n, const uint64_t *tile_base, uint64_t *line_start)
+{
+    __shared__ uint32_t lds[4];
+    const uint64_t off = (uint64_t)blockIdx.x * INGEST_TILE + threadIdx.x * 16;
+    uint32_t f[4];
+    nl16(text, off, n, f);
+    const uint32_t c = __popc(f[0]) + __popc(f[1]) + __popc(f[2]) + __popc(f[3]);
+    uint64_t k = tile_base[blockIdx.x] + block_exclusive<uint32_t>(c, lds, nullptr);      // newlines in front of this thread's bytes
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
+    if (!c) return;
+    for (uint32_t j = 0; j < 4; j++)
+        for (uint32_t m = f[j]; m; m &= m - 1) {
+            const uint32_t byte = (uint32_t)(__ffs(m) - 1) >> 3;
+            line_start[++k] = off + 4 * j + byte + 1;
+        }
+}
+__global__ __launch_bounds__(256) void seq_lens_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint32_t *seq_len, uint32_t *minmax)
+{
+    __shared__ uint32_t lmin[4], lmax[4];
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t L = 0, mn = ~0u, mx = 0;
+    if (r < n_rec) {
+        const uint64_t s = line_start[4 * r + 1], e = line_start[4 * r + 2];
+        uint64_t l = e - s - 1;
+        if (l && text[e - 2] == '\r') l--;
+        L = l > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)l;
+        seq_len[r] = L; mn = mx = L;
+    }
+    for (int d = 32; d; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor(mn, d)); mx = max(mx, (uint32_t)__shfl_xor(mx, d)); }
+    if ((threadIdx.x & 63) == 0) { lmin[threadIdx.x >> 6] = mn; lmax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&minmax[0], min(min(lmin[0], lmin[1]), min(lmin[2], lmin[3])));
+        atomicMax(&minmax[1], max(max(lmax[0], lmax[1]), max(lmax[2], lmax[3])));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ pack
+// four text bytes -> four 2-bit codes in the low byte (first base lowest) + a 4-bit mask of the invalid ones.
+// Bits 1-2 of a letter tell A, C, T, G apart and x ^ (x >> 1) puts them in order (the host packer's trick, mf_host.cpp).
+__device__ __forceinline__ uint32_t pack4(uint32_t w, uint32_t &invalid4)
+{
+    const uint32_t u = w & 0xDFDFDFDFu;                                   // case folded
+    const uint32_t ok = eq_flags(u, 0x41414141u) | eq_flags(u, 0x43434343u) | eq_flags(u, 0x47474747u) | eq_flags(u, 0x54545454u);
+    uint32_t code = ((w >> 1) & 0x03030303u) ^ ((w >> 2) & 0x01010101u);
+    code &= (ok >> 7) * 3u;                                               // invalid bases are stored as 0
+    const uint32_t bad = ~ok & 0x80808080u;
+    invalid4 = ((bad >> 7) | (bad >> 14) | (bad >> 21) | (bad >> 28)) & 0xFu;
+    return (code | (code >> 6) | (code >> 12) | (code >> 18)) & 0xFFu;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len,
+                                                   uint64_t n_rec, uint64_t total_bases, uint32_t *words, uint32_t *inv_cnt,
+                                                   const uint64_t *inv_base, uint64_t *npos)
+{
+    __shared__ uint32_t lds[4];
+    if (MODE == 1 && inv_cnt[blockIdx.x] == 0) return;                    // (nearly every workgroup: invalid bases are rare)
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x, g0 = w * 16;
+    uint32_t word = 0, inv = 0;
+    if (g0 < total_bases) {
+        uint64_t r, pos, len;
+        if (uniform_len) { r = g0 / uniform_len; pos = g0 - r * uniform_len; len = uniform_len; }
+        else {
+            uint64_t lo = 0, hi = n_rec;                                  // last r with offsets[r] <= g0 (an empty read never is: its successor has the same offset)
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= g0) lo = mid; else hi = mid; }
+            r = lo; pos = g0 - offsets[r]; len = offsets[r + 1] - offsets[r];
+        }
+        const uint8_t *src = text + line_start[4 * r + 1];
+        const uint32_t nb = total_bases - g0 < 16 ? (uint32_t)(total_bases - g0) : 16;
+        if (pos + 16 <= len) {                                            // the whole word lies in one read: one 16-byte load
+            const uint4 v = load16(src + pos);
+            uint32_t i0, i1, i2, i3;
+            word = pack4(v.x, i0) | (pack4(v.y, i1) << 8) | (pack4(v.z, i2) << 16) | (pack4(v.w, i3) << 24);
+            inv = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+        } else {
+            for (uint32_t k = 0; k < nb; k++) {
+                while (pos >= len) {                                      // next read that has bases
+                    r++; pos = 0;
+                    len = uniform_len ? uniform_len : offsets[r + 1] - offsets[r];
+                    src = text + line_start[4 * r + 1];
+                }
+                uint32_t i1;
+                const uint32_t c = pack4(src[pos], i1) & 3u;
+                word |= c << (2 * k); inv |= (i1 & 1u) << k;
+                pos++;
+            }
+        }
+    }
+    if (MODE == 0) {
+        if (g0 < total_bases) words[w] = word;
+        const uint32_t s = block_sum(__popc(inv), lds);
+        if (threadIdx.x == 0) inv_cnt[blockIdx.x] = s;
+    } else {
+        uint64_t k = inv_base[blockIdx.x] + block_exclusive<uint32_t>(__popc(inv), lds, nullptr);
+        for (uint32_t m = inv; m; m &= m - 1) npos[k++] = g0 + (uint32_t)(__ffs(m) - 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ survivors
+__global__ __launch_bounds__(256) void store_bits_kernel(const uint32_t *batch_bits, uint64_t n_rec, uint32_t *file_bits, uint64_t rec_base)
+{
+    // one thread per destination word of the file-wide bitmap that the batch touches; the first and the last are shared with
+    // the neighbouring batches (atomic), the ones in between are written whole
+    const uint64_t w_first = rec_base >> 5, w_last = (rec_base + n_rec - 1) >> 5;
+    const uint64_t w = w_first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w > w_last) return;
+    const uint32_t sh = (uint32_t)rec_base & 31u;
+    const int64_t j = (int64_t)(w - w_first);                             // destination word j takes batch bits [32 j - sh, 32 j - sh + 32)
+    const uint64_t nw = (n_rec + 31) >> 5;
+    const uint32_t a = j >= 1 && (uint64_t)(j - 1) < nw ? batch_bits[j - 1] : 0, b = (uint64_t)j < nw ? batch_bits[j] : 0;
+    uint32_t v = sh ? (a >> (32 - sh)) | (b << sh) : b;
+    // bits of the destination word that belong to this batch
+    const uint64_t lo = w * 32 > rec_base ? w * 32 : rec_base, hi = (w + 1) * 32 < rec_base + n_rec ? (w + 1) * 32 : rec_base + n_rec;
+    const uint32_t nbits = (uint32_t)(hi - lo), first = (uint32_t)(lo - w * 32);
+    const uint32_t mask = nbits == 32 ? 0xFFFFFFFFu : (((1u << nbits) - 1) << first);
+    v &= mask;
+    if (nbits == 32) file_bits[w] = v; else if (v) atomicOr(&file_bits[w], v);
+}
+
+struct RecSpan { uint64_t h, s, q; uint32_t hl, sl, ql; };
+__device__ __forceinline__ uint32_t line_len(const uint8_t *text, uint64_t a, uint64_t b)     // line [a, b - 1) less a CR in front of the LF
+{
+    uint64_t l = b - a - 1;
+    if (l && text[b - 2] == '\r') l--;
+    return (uint32_t)l;
+}
+__device__ __forceinline__ RecSpan rec_span(const uint8_t *text, const uint64_t *ls, uint64_t r)
+{
+    RecSpan x;
+    const uint64_t l0 = ls[4 * r], l1 = ls[4 * r + 1], l2 = ls[4 * r + 2], l3 = ls[4 * r + 3], l4 = ls[4 * r + 4];
+    x.h = l0; x.s = l1; x.q = l3;
+    x.hl = line_len(text, l0, l1); x.sl = line_len(text, l1, l2); x.ql = line_len(text, l3, l4);
+    return x;
+}
+__global__ __launch_bounds__(256) void out_lens_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t rec_base,
+                                                       const uint32_t *bits_a, const uint32_t *bits_b, int both, uint32_t *out_len)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint64_t g = rec_base + r;
+    const uint32_t a = (bits_a[g >> 5] >> (g & 31)) & 1u, b = bits_b ? (bits_b[g >> 5] >> (g & 31)) & 1u : a;
+    const uint32_t keep = both ? (a & b) : (a | b);
+    uint32_t n = 0;
+    if (keep) { const RecSpan x = rec_span(text, line_start, r); n = x.hl + x.sl + x.ql + 5; }      // header LF seq LF '+' LF qual LF
+    out_len[r] = n;
+}
+__global__ __launch_bounds__(256) void gather_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, const uint32_t *out_len,
+                                                     const uint64_t *out_off, uint8_t *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // one wavefront per record
+    if (r >= n_rec || out_len[r] == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const RecSpan x = rec_span(text, line_start, r);
+    uint8_t *o = out + out_off[r];
+    for (uint32_t i = lane; i < x.hl; i += 64) o[i] = text[x.h + i];
+    o += x.hl;
+    for (uint32_t i = lane; i < x.sl; i += 64) o[1 + i] = text[x.s + i];
+    if (lane == 0) { o[0] = '\n'; o[1 + x.sl] = '\n'; o[2 + x.sl] = '+'; o[3 + x.sl] = '\n'; o[4 + x.sl + x.ql] = '\n'; }
+    o += x.sl + 4;
+    for (uint32_t i = lane; i < x.ql; i += 64) o[i] = text[x.q + i];
+}
+
+} // namespace
+
+hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *scratch, hipStream_t st)
+{
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb) hipLaunchKernelGGL(scan_reduce_kernel, dim3((uint32_t)nb), dim3(SCAN_BLOCK), 0, st, in, n, scratch);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, scratch, nb);
+    hipLaunchKernelGGL(scan_final_kernel, dim3((uint32_t)(nb ? nb : 1)), dim3(SCAN_BLOCK), 0, st, in, n, scratch, out, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_newlines(const uint8_t *text, uint64_t n, uint32_t *tile_cnt, hipStream_t st)
+{
+    const uint64_t nt = (n + INGEST_TILE - 1) / INGEST_TILE;
+    if (!nt) return hipSuccess;
+    hipLaunchKernelGGL(count_newlines_kernel, dim3((uint32_t)nt), dim3(256), 0, st, text, n, tile_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_line_starts(const uint8_t *text, uint64_t n, const uint64_t *tile_base, uint64_t *line_start, hipStream_t st)
+{
+    const uint64_t nt = (n + INGEST_TILE - 1) / INGEST_TILE;
+    if (!nt) return hipSuccess;
+    hipLaunchKernelGGL(line_starts_kernel, dim3((uint32_t)nt), dim3(256), 0, st, text, n, tile_base, line_start);
+    return hipGetLastError();
+}
+
+hipError_t launch_seq_lens(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint32_t *seq_len, uint32_t *minmax, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    hipLaunchKernelGGL(seq_lens_kernel, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, text, line_start, n_rec, seq_len, minmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_rec,
+                       uint64_t total_bases, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st)
+{
+    const uint64_t nw = (total_bases + 15) / 16, nb = (nw + 255) / 256;
+    if (!nb) return hipSuccess;
+    if (!npos) hipLaunchKernelGGL(pack_kernel<0>, dim3((uint32_t)nb), dim3(256), 0, st, text, line_start, offsets, uniform_len, n_rec, total_bases, words, inv_cnt, inv_base, npos);
+    else hipLaunchKernelGGL(pack_kernel<1>, dim3((uint32_t)nb), dim3(256), 0, st, text, line_start, offsets, uniform_len, n_rec, total_bases, words, inv_cnt, inv_base, npos);
+    return hipGetLastError();
+}
+
+hipError_t launch_store_bits(const uint32_t *batch_bits, uint64_t n_rec, uint32_t *file_bits, uint64_t rec_base, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    const uint64_t nw = ((rec_base + n_rec - 1) >> 5) - (rec_base >> 5) + 1;
+    hipLaunchKernelGGL(store_bits_kernel, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st, batch_bits, n_rec, file_bits, rec_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_out_lens(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t rec_base, const uint32_t *bits_a,
+                           const uint32_t *bits_b, int both, uint32_t *out_len, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    hipLaunchKernelGGL(out_lens_kernel, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, text, line_start, n_rec, rec_base, bits_a, bits_b, both, out_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, const uint32_t *out_len, const uint64_t *out_off,
+                         uint8_t *out, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    hipLaunchKernelGGL(gather_kernel, dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st, text, line_start, n_rec, out_len, out_off, out);
+    return hipGetLastError();
+}
+
+} // namespace mf

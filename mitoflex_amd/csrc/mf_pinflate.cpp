@@ -330,6 +330,24 @@ void slide_window(std::vector<uint8_t> &window, size_t &wlen, const uint8_t *byt
 
 } // namespace
 
+// Serial decode across a gap for the device decoder (mf_devingest.cpp): from a known block boundary with the known window up
+// to the first block boundary at or behind to_bit, the end of the member, or ~256 MB of output, whichever comes first.
+bool inflate_gap(const uint8_t *data, size_t size, uint64_t from_bit, uint64_t to_bit, const uint8_t *window, size_t wlen,
+                 std::vector<uint8_t> &out, uint64_t &end_bit, bool &member_end, std::string &err)
+{
+    Out<uint8_t> f;
+    f.v.resize(wlen + ((size_t)1 << 20));
+    if (wlen) memcpy(f.v.data(), window + WINDOW - wlen, wlen);
+    f.n = f.prefix = wlen;
+    Bits in(data, size); in.seek((size_t)from_bit);
+    Tables t; const char *why = nullptr;
+    const Stop st = decode_until<uint8_t>(in, t, f, (size_t)to_bit, (size_t)256 << 20, why);
+    if (st == FAILED) { err = why ? why : "damaged deflate stream"; return false; }
+    out.assign(f.v.begin() + (ptrdiff_t)f.prefix, f.v.begin() + (ptrdiff_t)f.n);
+    end_bit = in.bitpos(); member_end = st == MEMBER_END;
+    return true;
+}
+
 struct ChunkResult { bool valid = false; size_t start = 0, end = 0; Stop stop = FAILED; Out<uint16_t> sym; };
 struct ParallelGzReader::Scratch { std::vector<ChunkResult> res; Out<uint8_t> first; };
 

@@ -29,6 +29,10 @@ namespace mf {
 uint32_t crc32_fast(uint32_t crc, const uint8_t *p, size_t n);                       // zlib's crc32() contract; PCLMULQDQ folding where the CPU has it
 void resolve_symbols(const uint16_t *s, size_t n, const uint8_t *window, uint8_t *out);    // marker symbols -> bytes (see mf_pinflate.cpp)
 
+// decode across a gap with the serial decoder (used by the device decoder for what does not link); window: 32 KiB, the last wlen valid
+bool inflate_gap(const uint8_t *data, size_t size, uint64_t from_bit, uint64_t to_bit, const uint8_t *window, size_t wlen,
+                 std::vector<uint8_t> &out, uint64_t &end_bit, bool &member_end, std::string &err);
+
 class ParallelGzReader {
     using ByteBuf = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;   // sized without being zero-filled
 public:
