@@ -808,12 +808,15 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     if (n_devices < 1) n_devices = 1;
     if (n_devices > have) n_devices = have;
 
-    // One device and regular files: the bytes go to the GPU as they are and inflate, line indexing, packing, filter and the copy
-    // of the survivors run there (mf_devingest.cpp).  MF_INGEST=host keeps the host pipeline (readers, inflaters and packers
-    // on host threads); pipes, BGZF files and several devices always take it.
+    // One device and a regular .gz file: the bytes go to the GPU as they are and inflate, line indexing, packing, filter and the
+    // copy of the survivors run there (mf_devingest.cpp) -- the host's inflate is what bounds the host pipeline on compressed
+    // input.  Plain files stay with the host pipeline by default (it packs them to a quarter of their size before the copy to
+    // the device, and at ~45 GB/s of text); MF_INGEST=device sends them the same way, MF_INGEST=host keeps everything on the
+    // host pipeline.  Pipes, BGZF files and several devices always take the host pipeline.
     {
         const char *ing = getenv("MF_INGEST");
-        if (n_devices == 1 && !(ing && strcmp(ing, "host") == 0)) {
+        const bool force = ing && strcmp(ing, "device") == 0, any_gz = has_gz_ext(fq1) || (fq2 && has_gz_ext(fq2));
+        if (n_devices == 1 && !(ing && strcmp(ing, "host") == 0) && (force || any_gz)) {
             std::string derr;
             const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, 0, kept, total, derr);
             if (drc == MF_OK) return MF_OK;

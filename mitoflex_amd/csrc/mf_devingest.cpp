@@ -1,6 +1,6 @@
 // Device ingest path of mf_filter_fastq_files (see mf_devingest.h).
 //
-// Per input file ("mate"): the mapped file is copied to the device by an uploader thread (pinned staging, its own copy stream).
+
 // A plain FASTQ file then IS the text; a .gz is decoded in slabs of a few thousand speculative chunks (mf_gzdev.h): decode of
 // slab k + 1 and k + 2 run on their own streams while slab k is linked, resolved, CRC-checked, indexed, packed, filtered and
 // its survivors copied out.  Text is cut into records where it lies (mf_ingest.h); what is behind the last complete record of
@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <deque>
 #include <fcntl.h>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdio.h>
@@ -36,20 +37,77 @@ namespace {
 #define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + " failed: " + hipGetErrorString(e_); return MF_E_HIP; } } while (0)
 
 uint64_t env_u64(const char *name, uint64_t dflt) { const char *v = getenv(name); return v && *v ? strtoull(v, nullptr, 10) : dflt; }
+static const bool g_trace = getenv("MF_DEVINGEST_TRACE") != nullptr;
+#define TRACE(...) do { if (g_trace) { fprintf(stderr, "[devingest %.3f] ", now_s() - (double)(long)now_s() + ((long)now_s() % 1000)); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
+double now_s();
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Device memory of this path comes from a pool that outlives the call.  Two reasons.  hipFree waits for the whole device to go
+// idle -- with decode kernels in flight on other streams that is tens of milliseconds a call -- so nothing is freed while a
+// file is being processed: outgrown buffers go back to the pool.  And allocating (and later releasing) the tens of gigabytes a
+// large file takes costs more than a second, which a caller that filters file after file (the bim loop) would pay every
+// time: a call's buffers are kept for the next one, up to MF_DEVPOOL_GB (default 96; MF_KEEP_BUFFERS=0: nothing is kept).
+class DevPool {
+public:
+    static size_t round_up(size_t bytes)
+    {
+        size_t unit = (size_t)1 << 20;
+        while (unit * 16 < bytes && unit < ((size_t)256 << 20)) unit <<= 1;         // 1 MiB steps for small blocks, up to 256 MiB steps
+        return (bytes + unit - 1) / unit * unit;
+    }
+    hipError_t get(void **p, size_t bytes, size_t *got)
+    {
+        const size_t want = round_up(bytes ? bytes : 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = free_.lower_bound(want);
+            if (it != free_.end() && it->first <= want + want / 2 + ((size_t)64 << 20)) { *p = it->second; *got = it->first; held_ -= it->first; free_.erase(it); return hipSuccess; }
+        }
+        hipError_t e = hipMalloc(p, want);
+        if (e != hipSuccess) {                      // make room: release what the pool holds and try once more
+            (void)hipGetLastError();
+            trim(0);
+            e = hipMalloc(p, want);
+        }
+        *got = want;
+        return e;
+    }
+    void put(void *p, size_t bytes) { if (!p) return; std::lock_guard<std::mutex> lk(mu_); free_.emplace(bytes, p); held_ += bytes; }
+    void trim(size_t keep)                          // (only when no kernel of this path is in flight)
+    {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (held_ > keep && !free_.empty()) { auto it = free_.begin(); drop.push_back(it->second); held_ -= it->first; free_.erase(it); }
+        }
+        for (void *q : drop) (void)hipFree(q);
+    }
+private:
+    std::mutex mu_; std::multimap<size_t, void *> free_; size_t held_ = 0;
+};
+DevPool g_pool;
+// (buffers that an mf_reads owns are hipMalloc'ed; outgrown ones are parked here and freed when the call is over)
+struct Trash {
+    std::mutex mu; std::vector<void *> v;
+    void add(void *p) { if (p) { std::lock_guard<std::mutex> lk(mu); v.push_back(p); } }
+    void empty() { std::lock_guard<std::mutex> lk(mu); for (void *p : v) (void)hipFree(p); v.clear(); }
+};
+Trash g_trash;
 
 template <class T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;                      // cap in elements
+    size_t bytes_ = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { g_pool.put(p, bytes_); }
     hipError_t need(size_t n, bool slack = true)          // contents are NOT kept
     {
         if (n <= cap && p) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        const size_t want = slack ? n + n / 8 + 1024 : (n ? n : 1);
-        hipError_t e = hipMalloc(&p, want * sizeof(T));
-        if (e == hipSuccess) cap = want;
+        g_pool.put(p, bytes_); p = nullptr; cap = 0; bytes_ = 0;
+        const size_t want = slack ? n + n / 2 + 1024 : (n ? n : 1);
+        void *q = nullptr; size_t got = 0;
+        hipError_t e = g_pool.get(&q, want * sizeof(T), &got);
+        if (e == hipSuccess) { p = (T *)q; bytes_ = got; cap = got / sizeof(T); }
         return e;
     }
 };
@@ -84,8 +142,10 @@ public:
     static constexpr size_t PIECE = (size_t)32 << 20;
     ~Uploader()
     {
+        TRACE("~Uploader");
         stop_ = true;
         if (th_.joinable()) th_.join();
+        TRACE("uploader joined");
         for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
         for (auto &e : free_ev_) if (e) (void)hipEventDestroy(e);
         for (auto &s : stage_) if (s) (void)hipHostFree(s);
@@ -104,6 +164,14 @@ public:
         }
         th_ = std::thread([this] { run(); });
         return MF_OK;
+    }
+    // the copy of bytes [0, upto) has been issued (so wait_for would not block the host)
+    bool issued(size_t upto)
+    {
+        if (n_ == 0 || upto == 0) return true;
+        if (upto > n_) upto = n_;
+        std::lock_guard<std::mutex> lk(mu_);
+        return failed_ || enqueued_ > (upto - 1) / PIECE;
     }
     // make `st` wait until bytes [0, upto) are on the device (upto is clamped to the file).  false: the uploader failed
     bool wait_for(hipStream_t st, size_t upto)
@@ -146,32 +214,84 @@ private:
     std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; bool failed_ = false; std::atomic<bool> stop_{false};
 };
 
-// ---- text of one slab on the device.  base[0 .. len) are the new bytes; base[-front .. 0) is the text in front of them.
-struct Slab {
-    DevBuf<uint8_t> buf;                 // owns the text of a .gz slab (a plain file's text is the resident file)
-    uint8_t *base = nullptr; uint64_t len = 0; size_t front = 0;
-    uint64_t carry = 0;                  // bytes in front of base that open the first record of this slab
-    DevBuf<uint64_t> line_start;         // offsets from (base - carry)
-    uint64_t n_rec = 0, rec_base = 0;
-    bool last = false;                   // the input ends with this slab
+// ---- the decoder's streams.  The link step is the decoder's one serial path, and its workgroup wants 64 KiB of LDS -- on a chip
+// whose LDS the decode wavefronts of the slabs ahead have filled it would wait tens of milliseconds for a CU to drain.  So a few
+// CUs (one per XCD: mask bit b is a CU of XCD b mod 8) are kept free of decode work: the decode streams are masked off them, the
+// link stream runs only there.  Where CU masks are not to be had, ordinary streams.  The sets are made once and handed from
+// call to call: destroying a CU-masked stream right after use was seen to hang inside the runtime (ROCm 7.2), and they cost a
+// few milliseconds to make.
+constexpr uint32_t GZ_NSTREAM = 7;
+struct StreamSet { int device = -1; hipStream_t sd[GZ_NSTREAM] = {}, link = nullptr, rest = nullptr; };
+class StreamSets {
+public:
+    StreamSet *take(int device, std::string &err)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < free_.size(); i++) if (free_[i]->device == device) { StreamSet *s = free_[i]; free_.erase(free_.begin() + (long)i); return s; }
+        }
+        std::unique_ptr<StreamSet> s(new StreamSet());
+        s->device = device;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
+        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+        std::vector<uint32_t> m_dec((size_t)words, 0), m_link((size_t)words, 0);
+        for (int b = 0; b < n_cu; b++) (b >= n_cu - 8 ? m_link : m_dec)[b / 32] |= 1u << (b % 32);
+        const bool masks = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
+        bool ok = true;
+        for (auto &q : s->sd)
+            if (!masks || hipExtStreamCreateWithCUMask(&q, (uint32_t)words, m_dec.data()) != hipSuccess) { (void)hipGetLastError(); ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess; }
+        if (!masks || hipExtStreamCreateWithCUMask(&s->link, (uint32_t)words, m_link.data()) != hipSuccess) { (void)hipGetLastError(); ok = ok && hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess; }
+        ok = ok && hipStreamCreateWithFlags(&s->rest, hipStreamNonBlocking) == hipSuccess;
+        if (!ok) { err = "hipStreamCreate failed"; return nullptr; }           // (what was made stays behind: never destroyed, see above)
+        return s.release();
+    }
+    void give(StreamSet *s) { if (s) { std::lock_guard<std::mutex> lk(mu_); free_.push_back(s); } }
+private:
+    std::mutex mu_; std::vector<StreamSet *> free_;
+};
+StreamSets g_streams;
+
+// ---- the text of one input file on the device: ONE contiguous arena per mate, so that a record that spans two slabs, or the
+// 32 KiB deflate window in front of a chunk, is simply the bytes in front.  A plain file's arena is the uploaded file; a .gz's
+// grows (rarely) as the text does.  The producer thread writes behind `ready`, the consumer reads in front of it.
+struct Arena {
+    static constexpr size_t FRONT = 32768 + 256; // readable bytes in front of p: a damaged stream may point a full window back from its first byte
+    uint8_t *p = nullptr; size_t cap = 0;       // cap bytes usable (+ 64 readable behind)
+    uint8_t *raw = nullptr; size_t raw_bytes = 0; // the allocation, when the arena owns one
+    std::mutex mu;                               // held by the consumer while its kernels read the arena, by the producer while it moves it
+    ~Arena() { g_pool.put(raw, raw_bytes); }
 };
 
-// ---- one gzip member stream decoded on the device
+// a range of an input's text that has become available, in order
+struct TextPiece { uint64_t T0 = 0, len = 0; bool last = false; };
+
+// ---- one gzip file decoded on the device (runs on the mate's producer thread, on its own streams)
 class GzStream {
 public:
     ~GzStream()
     {
+        TRACE("~GzStream");
         for (auto &s : sym_) { if (s.ev) (void)hipEventDestroy(s.ev); }
-        for (auto &s : sd_) if (s) (void)hipStreamDestroy(s);
+        if (streams_) {                           // nothing of this decoder may be in flight when its buffers go back to the pool
+            for (auto &s : sd_) if (s) (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(sp_); (void)hipStreamSynchronize(sr_);
+            g_streams.give(streams_);
+        }
+        if (ev_link_) (void)hipEventDestroy(ev_link_);
+        TRACE("streams destroyed");
         if (h_chain_) (void)hipHostFree(h_chain_);
+        TRACE("~GzStream done");
     }
     // data: the mapped file; d_file: its copy on the device (size + 64 readable, being filled by `up`)
-    int open(const uint8_t *data, size_t size, uint8_t *d_file, Uploader *up, const std::string &path, std::string &err)
+    int open(const uint8_t *data, size_t size, uint8_t *d_file, Uploader *up, Arena *arena, const std::string &path, std::string &err)
     {
-        data_ = data; size_ = size; d_file_ = d_file; up_ = up; path_ = path;
-        chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", (size_t)128 << 10);
+        data_ = data; size_ = size; d_file_ = d_file; up_ = up; arena_ = arena; path_ = path;
+        // chunks: large enough that the serial link step (a fixed cost per chunk) stays small, small enough that a file keeps the chip busy
+        size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)256 << 10) & ~(size_t)4095;
+        chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", dflt);
         if (chunk_ < 1024) chunk_ = 1024;
-        cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", 4096);
+        cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", std::max<uint64_t>(256, ((uint64_t)128 << 20) / chunk_));
         if (cps_ < 1) cps_ = 1;
         expand_ = env_u64("MF_GZDEV_EXPAND", 8);
         size_t pos = 0;
@@ -189,20 +309,34 @@ public:
         memset(h_chain_, 0, sizeof(GzChain));
         h_chain_->cur_bit = (uint64_t)base_byte_ * 8;
         DCHK(hipMemcpy(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice));
-        for (auto &s : sd_) DCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        {
+            int dev = 0;
+            DCHK(hipGetDevice(&dev));
+            streams_ = g_streams.take(dev, err);
+            if (!streams_) return MF_E_HIP;
+            for (uint32_t i = 0; i < NSTREAM; i++) sd_[i] = streams_->sd[i];
+            sp_ = streams_->link; sr_ = streams_->rest;
+            DCHK(hipEventCreateWithFlags(&ev_link_, hipEventDisableTiming));
+        }
         for (auto &s : sym_) { DCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)); s.slab = ~0u; }
         h_chunks_.resize(n_chunks_);
+        // the arena: a first guess at the size of the text (FASTQ compresses three- to fivefold); it is moved when it proves too small
+        const int rc = grow_arena(std::max<size_t>(size_ * 4, (size_t)64 << 20), err);
+        if (rc) return rc;
         in_member_ = true;
         return MF_OK;
     }
-    bool done() const { return done_; }
-    // text of the next slab (possibly empty) into `out`; sp: the stream the text is produced on.  Sets out.last at the end of the input.
-    int next(Slab &out, hipStream_t sp, std::string &err)
+    // text of the next slab (possibly nothing) is in the arena when this returns
+    int next(TextPiece &out, std::string &err)
     {
+        hipStream_t sp = sp_;
         const uint32_t k = next_slab_;
-        for (uint32_t j = k; j < k + 3 && j < n_slabs_; j++) { const int rc = launch_decode(j, err); if (rc) return rc; }
+        // decode runs ahead of the text: this slab (waiting for its bytes if need be) and as many of the following ones as there are
+        // symbol buffers and uploaded bytes for
+        for (uint32_t j = k; j < k + NSYM && j < n_slabs_; j++) { const int rc = launch_decode(j, j == k, err); if (rc) return rc; }
         const uint32_t lo = k * cps_, hi = std::min(n_chunks_, lo + cps_);
-        Sym &S = sym_[k % 3];
+        Sym &S = sym_[k % NSYM];
+        TRACE("slab %u: chunks %u..%u, waiting for decode", k, lo, hi);
         DCHK(hipStreamWaitEvent(sp, S.ev, 0));
         DCHK(hipMemcpyAsync(h_chunks_.data() + lo, d_chunks_.p + lo, (hi - lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sp));
         DCHK(hipStreamSynchronize(sp));
@@ -215,37 +349,31 @@ public:
                 if (ch.status == GZ_OVERFLOW) overflow = true;
                 if (ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END) { sum += ch.n_sym; max_sym = std::max(max_sym, ch.n_sym); }
             }
+            TRACE("slab %u decoded: %llu symbols, overflow %d", k, (unsigned long long)sum, (int)overflow);
             if (!overflow) break;
             // text that expands more than the symbol buffers allow for (a run of identical reads, say): this slab again, with four times the room
             if (S.cap > chunk_ * 2048) { err = "gzip data in " + path_ + " expands more than a thousandfold: not decoded on the device"; return MF_E_FORMAT; }
             S.cap *= 4;
             DCHK(S.p.need((size_t)(hi - lo) * S.cap, false));
-            DCHK(launch_gz_decode(d_file_, size_, base_byte_, chunk_, lo, hi - lo, 0, (uint64_t)base_byte_ * 8, S.p.p, S.cap, d_chunks_.p, sp));
-            DCHK(hipMemcpyAsync(h_chunks_.data() + lo, d_chunks_.p + lo, (hi - lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sp));
-            DCHK(hipStreamSynchronize(sp));
+            DCHK(launch_gz_decode(d_file_, size_, base_byte_, chunk_, lo, hi - lo, 0, (uint64_t)base_byte_ * 8, S.p.p, S.cap, d_chunks_.p, sd_[0]));
+            DCHK(hipMemcpyAsync(h_chunks_.data() + lo, d_chunks_.p + lo, (hi - lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd_[0]));
+            DCHK(hipStreamSynchronize(sd_[0]));
         }
-        // the text buffer: the 32 KiB window (or the longer carry) in front, room for what the chunks hold and for gap fills
-        const size_t front = ((std::max<uint64_t>(GZ_WINDOW, carry_in_) + 255) & ~(size_t)255) + 256;
-        size_t room = front + sum + ((size_t)16 << 20);
-        DCHK(out.buf.need(room + 64, false));
-        room = out.buf.cap - 64;
-        out.front = front; out.base = out.buf.p + front; out.len = 0;
         const uint64_t T0 = h_chain_->total;
-        if (carry_in_ > GZ_WINDOW) {            // a record longer than the window: its head comes from the previous slab's buffer
-            if (!prev_base_) { err = "internal: carry without a previous slab"; return MF_E_HIP; }
-            DCHK(hipMemcpyAsync(out.base - carry_in_, prev_base_ + prev_len_ - carry_in_, carry_in_ - GZ_WINDOW, hipMemcpyDeviceToDevice, sp));
-        }
+        int rc = grow_arena(T0 + sum + ((size_t)1 << 20), err);
+        if (rc) return rc;
         const bool last_slab = k + 1 == n_slabs_;
         // link; the host steps in where the chain stops
         for (;;) {
             if (!done_ && in_member_) {
-                DCHK(launch_gz_chain(d_chain_.p, d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, out.base, T0, sp));
+                DCHK(launch_gz_chain(d_chain_.p, d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, arena_->p, 0, sp));
                 DCHK(hipMemcpyAsync(h_chain_, d_chain_.p, offsetof(GzChain, window), hipMemcpyDeviceToHost, sp));
                 DCHK(hipStreamSynchronize(sp));
             }
+            TRACE("chain: stop %u next %u cur_bit %llu total %llu linked %u", h_chain_->stop, h_chain_->next, (unsigned long long)h_chain_->cur_bit, (unsigned long long)h_chain_->total, h_chain_->linked);
             if (done_) break;
             uint64_t to_bit = 0;
-            if (h_chain_->stop == GZ_STOP_MEMBER_END) { const int rc = member_end(out, T0, sp, err); if (rc) return rc; if (done_) break; }
+            if (h_chain_->stop == GZ_STOP_MEMBER_END) { rc = member_end(max_sym, sp, err); if (rc) return rc; if (done_) break; }
             if (h_chain_->stop == GZ_STOP_GAP) to_bit = h_chunks_[h_chain_->next].start_bit;
             else if (h_chain_->stop == GZ_STOP_NONE) {
                 if (!last_slab) break;
@@ -258,15 +386,10 @@ public:
                 err = "gzip read error in " + path_ + ": " + why; return MF_E_FORMAT;
             }
             gap_bytes_ += bytes.size();
-            const uint64_t at = h_chain_->total - T0;
-            if (front + at + bytes.size() > room) {       // (rare: a long gap) a larger buffer, what is there moves over
-                DevBuf<uint8_t> nb; const size_t nroom = front + at + bytes.size() + sum + ((size_t)64 << 20);
-                DCHK(nb.need(nroom + 64, false));
-                DCHK(hipMemcpy(nb.p, out.buf.p, front + at, hipMemcpyDeviceToDevice));
-                std::swap(nb.p, out.buf.p); std::swap(nb.cap, out.buf.cap);
-                room = out.buf.cap - 64; out.base = out.buf.p + front;
-            }
-            if (!bytes.empty()) DCHK(hipMemcpy(out.base + at, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            TRACE("gap: %zu bytes, ends at bit %llu (wanted %llu), member end %d", bytes.size(), (unsigned long long)end_bit, (unsigned long long)to_bit, (int)mend);
+            rc = grow_arena(h_chain_->total + bytes.size() + sum + ((size_t)1 << 20), err);
+            if (rc) return rc;
+            if (!bytes.empty()) DCHK(hipMemcpy(arena_->p + h_chain_->total, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
             // the window behind the gap
             if (bytes.size() >= GZ_WINDOW) { memcpy(h_chain_->window, bytes.data() + bytes.size() - GZ_WINDOW, GZ_WINDOW); h_chain_->wlen = GZ_WINDOW; }
             else {
@@ -279,37 +402,55 @@ public:
             if (h_chain_->stop == GZ_STOP_NONE && last_slab && !mend && bytes.empty()) { err = "gzip read error in " + path_ + ": truncated deflate stream"; return MF_E_FORMAT; }
             h_chain_->stop = mend ? GZ_STOP_MEMBER_END : GZ_STOP_NONE;
             DCHK(hipMemcpy(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice));
-            if (mend) { const int rc = member_end(out, T0, sp, err); if (rc) return rc; if (done_) break; }
+            if (mend) { rc = member_end(max_sym, sp, err); if (rc) return rc; if (done_) break; }
         }
-        DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, out.base, T0, max_sym, sp));
-        out.len = h_chain_->total - T0;
+        DCHK(hipEventRecord(ev_link_, sp)); DCHK(hipStreamWaitEvent(sr_, ev_link_, 0));
+        DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, arena_->p, 0, max_sym, sr_));
         // the rest of the member's CRC over this slab
-        if (out.len > crc_done_ - T0) { const int rc = crc_over(out, T0, crc_done_, h_chain_->total, sp, err); if (rc) return rc; }
-        DCHK(hipStreamSynchronize(sp));
+        if (h_chain_->total > crc_done_) { rc = crc_over(crc_done_, h_chain_->total, sr_, err); if (rc) return rc; }
+        DCHK(hipStreamSynchronize(sr_));
         S.slab = ~0u;                                     // (its symbols are text now)
         next_slab_ = k + 1;
-        if (next_slab_ == n_slabs_ && !done_) {           // the data ran out inside a member
-            err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT;
-        }
-        out.last = done_;
-        prev_base_ = out.base; prev_len_ = out.len;
+        if (next_slab_ == n_slabs_ && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
+        out.T0 = T0; out.len = h_chain_->total - T0; out.last = done_;
         return MF_OK;
     }
-    void set_carry(uint64_t c) { carry_in_ = c; }
     uint64_t gap_bytes() const { return gap_bytes_; }
     uint64_t chunks_linked() const { return h_chain_ ? h_chain_->linked : 0; }
+    uint32_t chunks() const { return n_chunks_; }
+    size_t chunk_bytes() const { return chunk_; }
 private:
     struct Sym { DevBuf<uint16_t> p; size_t cap = 0; hipEvent_t ev = nullptr; uint32_t slab = ~0u; };     // cap: symbols of room per chunk
-    int launch_decode(uint32_t j, std::string &err)
+    // the arena holds at least `need` bytes (what is in it moves along)
+    int grow_arena(size_t need, std::string &err)
     {
-        Sym &S = sym_[j % 3];
+        if (need <= arena_->cap) return MF_OK;
+        const size_t cap = std::max(need + need / 2, (size_t)64 << 20);
+        uint8_t *raw = nullptr; size_t raw_bytes = 0;
+        DCHK(g_pool.get((void **)&raw, Arena::FRONT + cap + 64, &raw_bytes));
+        DCHK(hipMemsetAsync(raw, 0, Arena::FRONT, sr_)); DCHK(hipStreamSynchronize(sr_));
+        uint8_t *p = raw + Arena::FRONT;
+        std::lock_guard<std::mutex> lk(arena_->mu);       // (no kernel of the consumer is reading the old one)
+        const uint64_t have = h_chain_ ? h_chain_->total : 0;
+        if (arena_->raw) {
+            if (have) { DCHK(hipMemcpyAsync(p, arena_->p, have, hipMemcpyDeviceToDevice, sr_)); DCHK(hipStreamSynchronize(sr_)); }
+            g_pool.put(arena_->raw, arena_->raw_bytes);       // (link, resolve and CRC of this stream are between slabs here; the consumer is held off by the lock)
+        }
+        arena_->raw = raw; arena_->raw_bytes = raw_bytes; arena_->p = p; arena_->cap = raw_bytes - Arena::FRONT - 64;
+        return MF_OK;
+    }
+    int launch_decode(uint32_t j, bool must, std::string &err)
+    {
+        Sym &S = sym_[j % NSYM];
         if (j != launched_ || S.slab != ~0u) return MF_OK;     // launched already -- or its buffer still holds an earlier slab: launched when that one has become text
         const uint32_t lo = j * cps_, hi = std::min(n_chunks_, lo + cps_);
+        hipStream_t st = sd_[j % NSTREAM];
+        // the chunks read past their own range up to the end of a block, and the reader's ring a little further
+        const size_t upto = base_byte_ + (size_t)hi * chunk_ + ((size_t)8 << 20);
+        if (!must && !up_->issued(upto)) return MF_OK;
         S.cap = sym_cap_;
         DCHK(S.p.need((size_t)(hi - lo) * S.cap, false));
-        hipStream_t st = sd_[j % 2];
-        // the chunks read past their own range up to the end of a block, and the reader's ring a little further
-        if (!up_->wait_for(st, base_byte_ + (size_t)hi * chunk_ + ((size_t)8 << 20))) { err = "upload of " + path_ + " failed"; return MF_E_HIP; }
+        if (!up_->wait_for(st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_HIP; }
         DCHK(launch_gz_decode(d_file_, size_, base_byte_, chunk_, lo, hi - lo, 0, (uint64_t)base_byte_ * 8, S.p.p, S.cap, d_chunks_.p, st));
         DCHK(hipEventRecord(S.ev, st));
         S.slab = j; launched_ = j + 1;
@@ -335,7 +476,7 @@ private:
         return false;
     }
     // the chain stands behind the final block of a member: check the trailer, look for another member
-    int member_end(Slab &out, uint64_t T0, hipStream_t sp, std::string &err)
+    int member_end(uint32_t max_sym, hipStream_t sp, std::string &err)
     {
         const size_t pos = (size_t)((h_chain_->cur_bit + 7) >> 3);
         if (pos + 8 > size_) { err = "gzip read error in " + path_ + ": truncated gzip trailer"; return MF_E_FORMAT; }
@@ -343,10 +484,12 @@ private:
         // CRC of the member's text up to here (the resolve kernel has not run yet for this slab: do it for what is accepted)
         {
             const uint32_t k = next_slab_, lo = k * cps_, hi = std::min(n_chunks_, lo + cps_);
-            uint32_t max_sym = 0; for (uint32_t c = lo; c < hi; c++) max_sym = std::max(max_sym, h_chunks_[c].n_sym);
-            DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, sym_[k % 3].p.p, sym_[k % 3].cap, d_out_off_.p, out.base, T0, max_sym, sp));
+            DCHK(hipEventRecord(ev_link_, sp)); DCHK(hipStreamWaitEvent(sr_, ev_link_, 0));
+            DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, sym_[k % NSYM].p.p, sym_[k % NSYM].cap, d_out_off_.p, arena_->p, 0, max_sym, sr_));
         }
-        if (h_chain_->total > crc_done_) { const int rc = crc_over(out, T0, crc_done_, h_chain_->total, sp, err); if (rc) return rc; }
+        if (h_chain_->total > crc_done_) { const int rc = crc_over(crc_done_, h_chain_->total, sr_, err); if (rc) return rc; }
+        DCHK(hipStreamSynchronize(sr_));
+        TRACE("member end: crc %08x want %08x", crc_, want_crc);
         if (crc_ != want_crc) { err = "gzip read error in " + path_ + ": incorrect data check"; return MF_E_FORMAT; }
         if ((uint32_t)(h_chain_->total - member_T0_) != want_len) { err = "gzip read error in " + path_ + ": incorrect length check"; return MF_E_FORMAT; }
         crc_ = 0; member_T0_ = h_chain_->total;
@@ -357,14 +500,15 @@ private:
         DCHK(hipMemcpy(d_chain_.p, h_chain_, offsetof(GzChain, window), hipMemcpyHostToDevice));
         return MF_OK;
     }
-    // running CRC of the member over the text [from, to) of this slab
-    int crc_over(Slab &out, uint64_t T0, uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
+    // running CRC of the member over the text [from, to)
+    int crc_over(uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
     {
         const uint64_t n = to - from;
         const size_t np = (size_t)((n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
         DCHK(d_crc_.need(np));
         h_crc_.resize(np);
-        DCHK(launch_gz_crc(out.base + (from - T0), n, d_crc_.p, sp));
+        TRACE("crc over %llu bytes", (unsigned long long)n);
+        DCHK(launch_gz_crc(arena_->p + from, n, d_crc_.p, sp));
         DCHK(hipMemcpyAsync(h_crc_.data(), d_crc_.p, np * 4, hipMemcpyDeviceToHost, sp));
         DCHK(hipStreamSynchronize(sp));
         crc_ = gz_crc_combine(crc_, gz_crc_finish(h_crc_.data(), n), n);
@@ -372,18 +516,18 @@ private:
         return MF_OK;
     }
 
-    const uint8_t *data_ = nullptr; size_t size_ = 0; uint8_t *d_file_ = nullptr; Uploader *up_ = nullptr; std::string path_;
+    const uint8_t *data_ = nullptr; size_t size_ = 0; uint8_t *d_file_ = nullptr; Uploader *up_ = nullptr; Arena *arena_ = nullptr; std::string path_;
     size_t chunk_ = 0, base_byte_ = 0, sym_cap_ = 0; uint64_t expand_ = 8;
     uint32_t cps_ = 0, n_chunks_ = 0, n_slabs_ = 0, next_slab_ = 0, launched_ = 0;
     DevBuf<GzChunk> d_chunks_; DevBuf<uint64_t> d_out_off_; DevBuf<GzChain> d_chain_; DevBuf<uint32_t> d_crc_;
     GzChain *h_chain_ = nullptr; std::vector<GzChunk> h_chunks_; std::vector<uint32_t> h_crc_;
-    Sym sym_[3]; hipStream_t sd_[2] = {nullptr, nullptr};
+    static constexpr uint32_t NSYM = 9, NSTREAM = GZ_NSTREAM;      // decode kernels in flight: enough wavefronts to fill the chip (a slab is a few hundred chunks)
+    Sym sym_[NSYM]; StreamSet *streams_ = nullptr; hipStream_t sd_[NSTREAM] = {}, sp_ = nullptr, sr_ = nullptr; hipEvent_t ev_link_ = nullptr;     // sp_: the link stream (reserved CUs); sr_: resolve and CRC (the whole chip)
     bool in_member_ = false, done_ = false;
-    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, carry_in_ = 0, gap_bytes_ = 0;
-    uint8_t *prev_base_ = nullptr; uint64_t prev_len_ = 0;
+    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0;
 };
 
-// ---- survivors on their way to the output file (one writer thread per mate; slabs arrive in order)
+// ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
 class Writer {
 public:
     bool open(const char *path) { ok_ = of_.open(path); if (ok_) th_ = std::thread([this] { run(); }); return ok_; }
@@ -407,65 +551,90 @@ private:
     std::thread th_; std::mutex mu_; std::condition_variable cv_; std::deque<std::vector<char>> q_;
 };
 
+// records of one piece of text, cut where they lie
+struct Batch {
+    uint64_t start = 0;                  // arena offset of the first record's header (the piece's T0 less the carry)
+    DevBuf<uint64_t> line_start;         // offsets from `start`
+    uint64_t n_rec = 0, rec_base = 0;
+};
+
 struct Mate {
     std::string path; Mapped map; bool gz = false;
-    DevBuf<uint8_t> d_file; Uploader up; std::unique_ptr<GzStream> gzs;
-    uint64_t text_pos = 0;               // plain files: bytes of the file handed out so far
-    uint64_t carry = 0;                  // bytes in front of the next slab's text that belong to its first record
-    uint64_t rec_done = 0; bool eof = false;
-    std::deque<std::unique_ptr<Slab>> pending;      // filtered, waiting for the other mate / to be written
-    std::vector<std::unique_ptr<Slab>> spare;
-    DevBuf<uint32_t> file_bits; uint64_t bits_cap = 0;   // pass bit per record of the file
-    mf_reads *reads = nullptr;
+    DevBuf<uint8_t> d_file; Uploader up; Arena arena; std::unique_ptr<GzStream> gzs;
+    // producer: text pieces in order (a plain file: one piece per uploaded slab)
+    std::thread prod; std::mutex mu; std::condition_variable cv; std::deque<TextPiece> ready; int prod_rc = MF_OK; std::string prod_err; bool prod_done = false;
+    std::atomic<bool> stop{false};
+    // consumer
+    uint64_t carry = 0, rec_done = 0, bases = 0, n_npos = 0; bool eof = false;
+    uint32_t min_len = ~0u, max_len = 0;
+    std::vector<std::unique_ptr<Batch>> batches;
+    mf_reads *reads = nullptr;           // the read set of the whole file, appended to batch by batch
     Writer out;
-    // scratch of the ingest kernels
     DevBuf<uint32_t> tile_cnt, seq_len, inv_cnt, out_len, minmax; DevBuf<uint64_t> tile_base, scan_tmp, inv_base, out_off, offsets_tmp; DevBuf<uint8_t> d_out;
-    ~Mate() { reads_release(reads); }
+    ~Mate() { TRACE("~Mate"); stop = true; if (prod.joinable()) prod.join(); reads_release(reads); TRACE("~Mate body done"); }
 };
+
+// grow a device buffer, keeping what is in it (bytes)
+template <class T> int grow_keep(T *&p, size_t &cap_bytes, size_t used_bytes, size_t need_bytes, hipStream_t st, std::string &err)
+{
+    if (need_bytes <= cap_bytes && p) return MF_OK;
+    const size_t cap = need_bytes + need_bytes / 2 + 4096;
+    T *q = nullptr;
+    DCHK(hipMalloc(&q, cap));
+    if (p) { if (used_bytes) DCHK(hipMemcpyAsync(q, p, used_bytes, hipMemcpyDeviceToDevice, st)); DCHK(hipStreamSynchronize(st)); g_trash.add(p); }      // (hipMalloc'ed: an mf_reads owns these)
+    p = q; cap_bytes = cap;
+    return MF_OK;
+}
 
 struct Ingest {
     mf_kmerset *ks; uint32_t threshold; bool pair_both; int device; DevCtx *ctx; hipStream_t sp;
     Mate m[2]; int nm = 1;
     uint64_t kept = 0, total = 0;
-    bool timing = false; double t_text = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;
+    bool timing = false; double t_wait = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;
 
-    int grow_bits(Mate &M, uint64_t n_rec, std::string &err)
+    void producer(Mate &M)
     {
-        if (n_rec <= M.bits_cap) return MF_OK;
-        uint64_t cap = std::max<uint64_t>(n_rec + n_rec / 2, (uint64_t)1 << 22);
-        cap = (cap + 1023) & ~(uint64_t)1023;
-        uint32_t *p = nullptr;
-        DCHK(hipMalloc(&p, cap / 8 + 64));
-        DCHK(hipMemsetAsync(p, 0, cap / 8 + 64, sp));
-        if (M.file_bits.p) { DCHK(hipMemcpyAsync(p, M.file_bits.p, M.bits_cap / 8, hipMemcpyDeviceToDevice, sp)); DCHK(hipStreamSynchronize(sp)); (void)hipFree(M.file_bits.p); }
-        M.file_bits.p = p; M.file_bits.cap = cap / 32; M.bits_cap = cap;
-        return MF_OK;
-    }
-
-    // text of the next slab of mate M
-    int next_text(Mate &M, Slab &S, std::string &err)
-    {
-        S.carry = M.carry; S.n_rec = 0; S.rec_base = M.rec_done; S.last = false;
+        (void)hipSetDevice(phys(device));
+        std::string err; int rc = MF_OK;
         if (M.gz) {
-            M.gzs->set_carry(M.carry);
-            const int rc = M.gzs->next(S, sp, err);
-            if (rc) return rc;
-            return MF_OK;
+            for (;;) {
+                TextPiece t;
+                rc = M.gzs->next(t, err);
+                if (rc || M.stop) break;
+                { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(t); }
+                M.cv.notify_all();
+                if (t.last) break;
+            }
+        } else {
+            // a plain file is its own text: pieces become available as they are uploaded
+            const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)256 << 20), 64);
+            hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = MF_E_HIP; err = "hipStreamCreate failed"; }
+            for (uint64_t T0 = 0; !rc && T0 < M.map.n && !M.stop;) {
+                const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
+                if (!M.up.wait_for(st, T1) || hipStreamSynchronize(st) != hipSuccess) { rc = MF_E_HIP; err = "upload of " + M.path + " failed"; break; }
+                TextPiece t; t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n;
+                { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(t); }
+                M.cv.notify_all();
+                T0 = T1;
+            }
+            if (ev) (void)hipEventDestroy(ev);
+            if (st) (void)hipStreamDestroy(st);
         }
-        const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)1 << 30), 64);
-        const uint64_t T0 = M.text_pos, T1 = std::min<uint64_t>(M.map.n, T0 + slab);
-        if (!M.up.wait_for(sp, T1)) { err = "upload of " + M.path + " failed"; return MF_E_HIP; }
-        S.base = M.d_file.p + T0; S.len = T1 - T0; S.front = T0;
-        M.text_pos = T1; S.last = T1 == M.map.n;
-        return MF_OK;
+        TRACE("producer done rc %d", rc);
+        { std::lock_guard<std::mutex> lk(M.mu); M.prod_rc = rc; M.prod_err = err; M.prod_done = true; }
+        M.cv.notify_all();
     }
 
-    // lines -> records -> packed read set -> pass bits in the file-wide bitmap
-    int ingest(Mate &M, Slab &S, std::string &err)
+    // lines -> records -> appended to the mate's packed read set
+    int ingest(Mate &M, const TextPiece &P, std::string &err)
     {
         const double t0 = now_s();
-        const uint8_t *text = S.base - S.carry;
-        const uint64_t n = S.carry + S.len;
+        std::lock_guard<std::mutex> alk(M.arena.mu);                 // the arena stays where it is while these kernels read it
+        std::unique_ptr<Batch> B(new Batch());
+        B->start = P.T0 - M.carry; B->rec_base = M.rec_done;
+        const uint8_t *text = M.arena.p + B->start;
+        const uint64_t n = M.carry + P.len;
         const uint64_t tiles = (n + INGEST_TILE - 1) / INGEST_TILE;
         uint64_t n_lines = 0, used = 0;
         if (n) {
@@ -476,88 +645,102 @@ struct Ingest {
             DCHK(hipMemcpyAsync(&newlines, M.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipMemcpyAsync(&last_byte, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
-            const bool open_line = S.last && last_byte != '\n';      // lines() yields an unterminated last line
+            const bool open_line = P.last && last_byte != '\n';      // lines() yields an unterminated last line
             n_lines = newlines + (open_line ? 1 : 0);
-            DCHK(S.line_start.need(n_lines + 2));
-            DCHK(launch_line_starts(text, n, M.tile_base.p, S.line_start.p, sp));
-            if (open_line) { const uint64_t v = n + 1; DCHK(hipMemcpyAsync(S.line_start.p + n_lines, &v, 8, hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
-            S.n_rec = n_lines / 4;
-            DCHK(hipMemcpyAsync(&used, S.line_start.p + 4 * S.n_rec, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(B->line_start.need(n_lines + 2, false));
+            DCHK(launch_line_starts(text, n, M.tile_base.p, B->line_start.p, sp));
+            if (open_line) { const uint64_t v = n + 1; DCHK(hipMemcpyAsync(B->line_start.p + n_lines, &v, 8, hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
+            B->n_rec = n_lines / 4;
+            DCHK(hipMemcpyAsync(&used, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
             if (used > n) used = n;                                   // (the virtual line end of an unterminated last line)
         }
-        M.carry = S.last ? 0 : n - used;                              // a partial record at the very end is dropped
-        if (timing) { DCHK(hipStreamSynchronize(sp)); t_index += now_s() - t0; }
+        M.carry = P.last ? 0 : n - used;                              // a partial record at the very end is dropped
+        if (timing) t_index += now_s() - t0;
         const double t1 = now_s();
-        const uint64_t n_rec = S.n_rec;
-        int rc = grow_bits(M, S.rec_base + n_rec + 64, err);
-        if (rc) return rc;
-        if (n_rec == 0) return MF_OK;
-        // sequence lengths, offsets
-        DCHK(M.seq_len.need(n_rec)); DCHK(M.minmax.need(2)); DCHK(M.offsets_tmp.need(n_rec + 1)); DCHK(M.scan_tmp.need(n_rec / 4096 + 4));
-        { const uint32_t init[2] = {~0u, 0u}; DCHK(hipMemcpyAsync(M.minmax.p, init, 8, hipMemcpyHostToDevice, sp)); }
-        DCHK(launch_seq_lens(text, S.line_start.p, n_rec, M.seq_len.p, M.minmax.p, sp));
-        DCHK(launch_scan_u32(M.seq_len.p, n_rec, M.offsets_tmp.p, M.scan_tmp.p, sp));
-        uint64_t total_bases = 0; uint32_t mm[2] = {0, 0};
-        DCHK(hipMemcpyAsync(&total_bases, M.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
-        DCHK(hipMemcpyAsync(mm, M.minmax.p, 8, hipMemcpyDeviceToHost, sp));
-        DCHK(hipStreamSynchronize(sp));
-        const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
-        const uint64_t n_words = (total_bases + 15) / 16;
-        if (!M.reads) { M.reads = new (std::nothrow) mf_reads(); if (!M.reads) { err = "out of memory"; return MF_E_NOMEM; } M.reads->device = device; M.reads->lane = 0; }
-        mf_reads *R = M.reads;
-        rc = reads_reserve(R, true, n_words, n_rec, uniform, 0, ctx);
-        if (rc) { err = mf_thread_error(); return rc; }
-        if (!uniform) DCHK(hipMemcpyAsync(R->d_offsets, M.offsets_tmp.p, (n_rec + 1) * 8, hipMemcpyDeviceToDevice, sp));
-        const uint64_t pack_blocks = (n_words + 255) / 256;
-        uint64_t n_npos = 0;
-        if (pack_blocks) {
-            DCHK(M.inv_cnt.need(pack_blocks)); DCHK(M.inv_base.need(pack_blocks + 1)); DCHK(M.scan_tmp.need(pack_blocks / 4096 + 4));
-            DCHK(launch_pack(text, S.line_start.p, uniform ? nullptr : R->d_offsets, uniform, n_rec, total_bases, R->d_words, M.inv_cnt.p, nullptr, nullptr, sp));
-            DCHK(launch_scan_u32(M.inv_cnt.p, pack_blocks, M.inv_base.p, M.scan_tmp.p, sp));
-            DCHK(hipMemcpyAsync(&n_npos, M.inv_base.p + pack_blocks, 8, hipMemcpyDeviceToHost, sp));
+        const uint64_t n_rec = B->n_rec;
+        if (n_rec) {
+            if (!M.reads) { M.reads = new (std::nothrow) mf_reads(); if (!M.reads) { err = "out of memory"; return MF_E_NOMEM; } M.reads->device = device; M.reads->lane = 0; }
+            mf_reads *R = M.reads;
+            // sequence lengths, the batch's own offsets
+            DCHK(M.seq_len.need(n_rec)); DCHK(M.minmax.need(2)); DCHK(M.offsets_tmp.need(n_rec + 1)); DCHK(M.scan_tmp.need(n_rec / 4096 + 4));
+            { const uint32_t init[2] = {~0u, 0u}; DCHK(hipMemcpyAsync(M.minmax.p, init, 8, hipMemcpyHostToDevice, sp)); }
+            DCHK(launch_seq_lens(text, B->line_start.p, n_rec, M.seq_len.p, M.minmax.p, sp));
+            DCHK(launch_scan_u32(M.seq_len.p, n_rec, M.offsets_tmp.p, M.scan_tmp.p, sp));
+            uint64_t nb = 0; uint32_t mm[2] = {0, 0};
+            DCHK(hipMemcpyAsync(&nb, M.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(mm, M.minmax.p, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
-            if (n_npos) {
-                DCHK(dev_reserve(R->d_npos, R->cap_npos, n_npos * 8, true));
-                DCHK(launch_pack(text, S.line_start.p, uniform ? nullptr : R->d_offsets, uniform, n_rec, total_bases, R->d_words, M.inv_cnt.p, M.inv_base.p, R->d_npos, sp));
+            M.min_len = std::min(M.min_len, mm[0]); M.max_len = std::max(M.max_len, mm[1]);
+            const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
+            // room in the file's read set: words (with the screen's padding), offsets, then pack behind what is there
+            const uint64_t words_after = (M.bases + nb + 15) / 16;
+            int rc = grow_keep(R->d_words, R->cap_words, ((M.bases + 15) / 16) * 4, padded_words_for(words_after) * 4, sp, err);
+            if (rc) return rc;
+            rc = grow_keep(R->d_offsets, R->cap_offsets, (M.rec_done + 1) * 8, (M.rec_done + n_rec + 1) * 8, sp, err);
+            if (rc) return rc;
+            DCHK(launch_add_base(R->d_offsets + M.rec_done, M.offsets_tmp.p, n_rec + 1, M.bases, sp));
+            const uint64_t pb = pack_blocks(nb, M.bases);
+            uint64_t inv = 0;
+            if (pb) {
+                DCHK(M.inv_cnt.need(pb)); DCHK(M.inv_base.need(pb + 1)); DCHK(M.scan_tmp.need(pb / 4096 + 4));
+                DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : M.offsets_tmp.p, uniform, n_rec, nb, M.bases, R->d_words, M.inv_cnt.p, nullptr, nullptr, sp));
+                DCHK(launch_scan_u32(M.inv_cnt.p, pb, M.inv_base.p, M.scan_tmp.p, sp));
+                DCHK(hipMemcpyAsync(&inv, M.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
+                DCHK(hipStreamSynchronize(sp));
+                if (inv) {
+                    rc = grow_keep(R->d_npos, R->cap_npos, M.n_npos * 8, (M.n_npos + inv) * 8, sp, err);
+                    if (rc) return rc;
+                    DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : M.offsets_tmp.p, uniform, n_rec, nb, M.bases, R->d_words, M.inv_cnt.p, M.inv_base.p, R->d_npos + M.n_npos, sp));
+                }
             }
+            DCHK(hipStreamSynchronize(sp));
+            M.bases += nb; M.n_npos += inv;
         }
-        rc = reads_finish(R, true, n_words, n_rec, total_bases, uniform, n_npos, ctx);
-        if (rc) { err = mf_thread_error(); return rc; }
+        M.rec_done += n_rec;
+        M.batches.push_back(std::move(B));
         if (timing) t_pack += now_s() - t1;
-        const double t2 = now_s();
-        rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, nullptr, nullptr, 1, nullptr);
-        if (rc) { err = mf_thread_error(); return rc; }
-        DCHK(launch_store_bits(R->d_bits[R->cur], n_rec, M.file_bits.p, S.rec_base, sp));
-        DCHK(hipStreamSynchronize(sp));
-        if (timing) t_filter += now_s() - t2;
         return MF_OK;
     }
 
-    // survivors of the first n_emit records of S -> the mate's writer
-    int emit(Mate &M, Slab &S, uint64_t n_emit, std::string &err)
+    // the whole file's read set through the filter: pass bits stay on the device (R->d_bits[R->cur])
+    int filter(Mate &M, std::string &err)
     {
-        const double t0 = now_s();
-        if (n_emit > S.n_rec) n_emit = S.n_rec;
-        if (n_emit) {
-            const uint8_t *text = S.base - S.carry;
-            DCHK(M.out_len.need(n_emit)); DCHK(M.out_off.need(n_emit + 1)); DCHK(M.scan_tmp.need(n_emit / 4096 + 4));
-            const uint32_t *other = nm == 2 ? m[&M == &m[0] ? 1 : 0].file_bits.p : nullptr;
-            DCHK(launch_out_lens(text, S.line_start.p, n_emit, S.rec_base, M.file_bits.p, other, pair_both ? 1 : 0, M.out_len.p, sp));
-            DCHK(launch_scan_u32(M.out_len.p, n_emit, M.out_off.p, M.scan_tmp.p, sp));
-            uint64_t bytes = 0;
-            DCHK(hipMemcpyAsync(&bytes, M.out_off.p + n_emit, 8, hipMemcpyDeviceToHost, sp));
+        if (!M.rec_done) return MF_OK;
+        mf_reads *R = M.reads;
+        const uint64_t n_words = (M.bases + 15) / 16, padded = padded_words_for(n_words);
+        int rc = grow_keep(R->d_words, R->cap_words, n_words * 4, padded * 4, sp, err);
+        if (rc) return rc;
+        DCHK(hipMemsetAsync(R->d_words + n_words, 0, (padded - n_words) * 4, sp));
+        if (!R->d_npos) { rc = grow_keep(R->d_npos, R->cap_npos, 0, 8, sp, err); if (rc) return rc; }
+        const uint32_t uniform = (M.min_len == M.max_len && M.min_len > 0) ? M.min_len : 0;
+        rc = reads_finish(R, false, n_words, M.rec_done, M.bases, uniform, M.n_npos, ctx);
+        if (rc) { err = mf_thread_error(); return rc; }
+        rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, nullptr, nullptr, 1, nullptr);
+        if (rc) { err = mf_thread_error(); return rc; }
+        return MF_OK;
+    }
+
+    // survivors of the first n_emit records of batch B -> the mate's writer
+    int emit(Mate &M, Batch &B, uint64_t n_emit, const uint32_t *bits_other, std::string &err)
+    {
+        if (n_emit > B.n_rec) n_emit = B.n_rec;
+        if (!n_emit) return MF_OK;
+        const uint8_t *text = M.arena.p + B.start;
+        DCHK(M.out_len.need(n_emit)); DCHK(M.out_off.need(n_emit + 1)); DCHK(M.scan_tmp.need(n_emit / 4096 + 4));
+        DCHK(launch_out_lens(text, B.line_start.p, n_emit, B.rec_base, M.reads->d_bits[M.reads->cur], bits_other, pair_both ? 1 : 0, M.out_len.p, sp));
+        DCHK(launch_scan_u32(M.out_len.p, n_emit, M.out_off.p, M.scan_tmp.p, sp));
+        uint64_t bytes = 0;
+        DCHK(hipMemcpyAsync(&bytes, M.out_off.p + n_emit, 8, hipMemcpyDeviceToHost, sp));
+        DCHK(hipStreamSynchronize(sp));
+        if (bytes) {
+            DCHK(M.d_out.need(bytes));
+            DCHK(launch_gather(text, B.line_start.p, n_emit, M.out_len.p, M.out_off.p, M.d_out.p, sp));
+            std::vector<char> host(bytes);
+            DCHK(hipMemcpyAsync(host.data(), M.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
-            if (bytes) {
-                DCHK(M.d_out.need(bytes));
-                DCHK(launch_gather(text, S.line_start.p, n_emit, M.out_len.p, M.out_off.p, M.d_out.p, sp));
-                std::vector<char> host(bytes);
-                DCHK(hipMemcpyAsync(host.data(), M.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
-                DCHK(hipStreamSynchronize(sp));
-                M.out.push(std::move(host));
-            }
+            M.out.push(std::move(host));
         }
-        if (timing) t_emit += now_s() - t0;
         return MF_OK;
     }
 
@@ -569,8 +752,8 @@ struct Ingest {
         std::vector<uint32_t> a((size_t)std::min<uint64_t>(nw, (uint64_t)1 << 22)), b(a.size());
         for (uint64_t w0 = 0; w0 < nw; w0 += a.size()) {
             const uint64_t k = std::min<uint64_t>(a.size(), nw - w0);
-            DCHK(hipMemcpy(a.data(), m[0].file_bits.p + w0, k * 4, hipMemcpyDeviceToHost));
-            if (nm == 2) DCHK(hipMemcpy(b.data(), m[1].file_bits.p + w0, k * 4, hipMemcpyDeviceToHost));
+            DCHK(hipMemcpy(a.data(), m[0].reads->d_bits[m[0].reads->cur] + w0, k * 4, hipMemcpyDeviceToHost));
+            if (nm == 2) DCHK(hipMemcpy(b.data(), m[1].reads->d_bits[m[1].reads->cur] + w0, k * 4, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < k; i++) {
                 uint32_t v = nm == 2 ? (pair_both ? (a[i] & b[i]) : (a[i] | b[i])) : a[i];
                 const uint64_t first = (w0 + i) * 32;
@@ -583,46 +766,61 @@ struct Ingest {
 
     int run(std::string &err)
     {
+        for (int i = 0; i < nm; i++) m[i].prod = std::thread([this, i] { producer(m[i]); });
+        // ---- ingest the text as it becomes available, the mate that is behind first
         for (;;) {
-            // the mate that is behind in records goes next
             int pick = -1;
             for (int i = 0; i < nm; i++) if (!m[i].eof && (pick < 0 || m[i].rec_done < m[pick].rec_done)) pick = i;
             if (pick < 0) break;
-            Mate &M = m[pick];
-            std::unique_ptr<Slab> S;
-            if (!M.spare.empty()) { S = std::move(M.spare.back()); M.spare.pop_back(); } else S.reset(new Slab());
-            const double t0 = now_s();
-            int rc = next_text(M, *S, err);
-            if (rc) return rc;
-            if (timing) t_text += now_s() - t0;
-            rc = ingest(M, *S, err);
-            if (rc) return rc;
-            M.rec_done += S->n_rec;
-            if (S->last) M.eof = true;
-            M.pending.push_back(std::move(S));
-            // write what both mates have decided
-            for (int i = 0; i < nm; i++) {
-                Mate &A = m[i]; const Mate *B = nm == 2 ? &m[1 - i] : nullptr;
-                while (!A.pending.empty()) {
-                    Slab &P = *A.pending.front();
-                    uint64_t n_emit = P.n_rec;
-                    if (B) {
-                        const uint64_t end = P.rec_base + P.n_rec;
-                        if (B->rec_done < end) { if (!B->eof) break; n_emit = B->rec_done > P.rec_base ? B->rec_done - P.rec_base : 0; }     // pairs end with the shorter file
+            // (a mate whose text is not there yet does not hold up the other)
+            bool got = false; TextPiece P;
+            const double tw = now_s();
+            for (;;) {
+                for (int step = 0; step < nm && !got; step++) {
+                    Mate &M = m[(pick + step) % nm];
+                    if (M.eof) continue;
+                    std::unique_lock<std::mutex> lk(M.mu);
+                    if (!M.ready.empty()) { P = M.ready.front(); M.ready.pop_front(); got = true; pick = (pick + step) % nm; }
+                    else if (M.prod_done) {
+                        if (M.prod_rc) { err = M.prod_err; return M.prod_rc; }
+                        M.eof = true;                                  // (an input without text: an empty file cannot get here, but a .gz of nothing can)
                     }
-                    // the text in front of the NEXT slab of this mate may still be this slab's (a .gz slab's buffer is its own;
-                    // a carry longer than the window is copied from it when the next slab is made): keep the newest slab until then
-                    if (A.gz && A.pending.size() == 1 && !A.eof && A.carry > GZ_WINDOW) break;
-                    rc = emit(A, P, n_emit, err);
+                }
+                if (got) break;
+                bool any = false; for (int i = 0; i < nm; i++) any = any || !m[i].eof;
+                if (!any) break;
+                std::unique_lock<std::mutex> lk(m[pick].mu);
+                m[pick].cv.wait_for(lk, std::chrono::milliseconds(1));
+            }
+            if (timing) t_wait += now_s() - tw;
+            if (!got) continue;
+            Mate &M = m[pick];
+            const int rc = ingest(M, P, err);
+            if (rc) return rc;
+            if (P.last) M.eof = true;
+        }
+        for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (M.prod.joinable()) M.prod.join(); if (M.prod_rc) { err = M.prod_err; return M.prod_rc; } }
+        // ---- filter, then write the survivors batch by batch
+        const double tf = now_s();
+        total = nm == 2 ? std::min(m[0].rec_done, m[1].rec_done) : m[0].rec_done;
+        for (int i = 0; i < nm; i++) { const int rc = filter(m[i], err); if (rc) return rc; }
+        if (timing) t_filter += now_s() - tf;
+        const double te = now_s();
+        if (total) {
+            for (int i = 0; i < nm; i++) {
+                Mate &M = m[i];
+                const uint32_t *other = nm == 2 ? m[1 - i].reads->d_bits[m[1 - i].reads->cur] : nullptr;
+                for (auto &B : M.batches) {
+                    if (B->rec_base >= total) break;                  // pairs end with the shorter file
+                    const int rc = emit(M, *B, total - B->rec_base, other, err);
                     if (rc) return rc;
-                    A.spare.push_back(std::move(A.pending.front())); A.pending.pop_front();
-                    if (A.spare.size() > 2) A.spare.erase(A.spare.begin());
                 }
             }
+            const int rc = count_kept(total, err);
+            if (rc) return rc;
         }
-        for (int i = 0; i < nm; i++) if (!m[i].pending.empty()) { err = "internal: slabs left unwritten"; return MF_E_HIP; }
-        total = nm == 2 ? std::min(m[0].rec_done, m[1].rec_done) : m[0].rec_done;
-        return count_kept(total, err);
+        if (timing) t_emit += now_s() - te;
+        return MF_OK;
     }
 };
 
@@ -631,26 +829,34 @@ struct Ingest {
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
                       bool pair_both, int device, uint64_t *kept, uint64_t *total, std::string &err)
 {
+    struct EndOfCall { ~EndOfCall() { g_trash.empty(); const char *kb = getenv("MF_KEEP_BUFFERS"); g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 96) << 30); } } end_of_call;     // (declared first: runs after everything of this call is gone)
     Ingest I;
     I.ks = ks; I.threshold = threshold; I.pair_both = pair_both; I.device = device; I.nm = fq2 ? 2 : 1;
     I.timing = getenv("MF_PIPE_TIMING") != nullptr;
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
-    // ---- is this an input for the device path?
+    // ---- is this an input for the device path?  Everything of a file stays resident until its survivors are written: the
+    // compressed bytes, the text, the line index, the packed reads.
+    size_t need = (size_t)4 << 30;
     for (int i = 0; i < I.nm; i++) {
         Mate &M = I.m[i];
         M.path = in_path[i]; M.gz = has_gz_ext(in_path[i]);
         bool regular = false;
         if (!M.map.open(in_path[i], regular)) { err = std::string("Cannot open file ") + in_path[i]; return MF_E_IO; }
-        if (!regular || M.map.n == 0 || M.map.n > ((size_t)48 << 30)) return MF_DEVINGEST_DECLINED;
+        if (!regular || M.map.n == 0) return MF_DEVINGEST_DECLINED;
         if (M.gz) {
             const uint8_t *d = M.map.p;
             if (M.map.n < 18 || d[0] != 0x1f || d[1] != 0x8b) return MF_DEVINGEST_DECLINED;      // (gzread hands such a file through; so does the host reader)
             if ((d[3] & 4) && M.map.n >= 18 && d[12] == 'B' && d[13] == 'C') return MF_DEVINGEST_DECLINED;   // BGZF: the host reader decodes its members side by side
         }
+        need += M.gz ? M.map.n * 8 + ((size_t)20 << 30) : M.map.n + M.map.n / 2;
     }
-    const double t_begin = now_s();
     int rc = get_ctx(device, &I.ctx, 0);
     if (rc) { err = mf_thread_error(); return rc; }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) return MF_DEVINGEST_DECLINED;       // too large to keep resident: the host pipeline streams it
+    }
+    const double t_begin = now_s();
     I.sp = I.ctx->stream;
     for (int i = 0; i < I.nm; i++) {
         Mate &M = I.m[i];
@@ -661,12 +867,15 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
         if (rc) return rc;
         if (M.gz) {
             M.gzs.reset(new GzStream());
-            rc = M.gzs->open(M.map.p, M.map.n, M.d_file.p, &M.up, M.path, err);
+            rc = M.gzs->open(M.map.p, M.map.n, M.d_file.p, &M.up, &M.arena, M.path, err);
             if (rc) return rc;
-        }
+        } else { M.arena.p = M.d_file.p; M.arena.cap = M.map.n; }
     }
     for (int i = 0; i < I.nm; i++) if (!I.m[i].out.open(out_path[i])) { err = std::string("Cannot open file ") + out_path[i]; return MF_E_IO; }
+    const double t_setup = now_s() - t_begin;
     rc = I.run(err);
+    TRACE("run returned %d", rc);
+    for (int i = 0; i < I.nm; i++) I.m[i].stop = true;
     bool wrote = true;
     for (int i = 0; i < I.nm; i++) wrote = I.m[i].out.close() && wrote;
     if (rc) return rc;
@@ -674,9 +883,11 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     if (kept) *kept = I.kept;
     if (total) *total = I.total;
     if (I.timing) {
-        fprintf(stderr, "[mf device ingest] wall %.3f s | text (upload wait, inflate, link, CRC) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f", now_s() - t_begin,
-                I.t_text, I.t_index, I.t_pack, I.t_filter, I.t_emit);
-        for (int i = 0; i < I.nm; i++) if (I.m[i].gzs) fprintf(stderr, " | %s: %llu chunks linked, %llu bytes decoded on the host", i ? "mate 2" : "mate 1", (unsigned long long)I.m[i].gzs->chunks_linked(), (unsigned long long)I.m[i].gzs->gap_bytes());
+        fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f",
+                now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit);
+        for (int i = 0; i < I.nm; i++)
+            if (I.m[i].gzs) fprintf(stderr, " | mate %d: %llu of %u chunks of %zu KiB linked, %llu bytes decoded on the host", i + 1, (unsigned long long)I.m[i].gzs->chunks_linked(),
+                                    I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gap_bytes());
         fprintf(stderr, "\n");
     }
     return MF_OK;

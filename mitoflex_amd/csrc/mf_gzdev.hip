@@ -646,7 +646,9 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
 
 // ---------------------------------------------------------------------------------------------------------- chain
 // One workgroup walks the chunks in stream order.  The last 32 KiB of accepted text live in LDS (two buffers: the tail of a
-// chunk is resolved against the window in front of the chunk while the window behind it is being written).
+// chunk is resolved against the window in front of the chunk while the window behind it is being written).  The 64 KiB are why
+// the caller launches it on a stream whose CU mask keeps a few CUs free of decode wavefronts: those fill every CU's LDS, and a
+// workgroup that has to wait for 64 KiB to come free waits for tens of milliseconds -- on the one serial path of the decoder.
 __global__ __launch_bounds__(1024) void gz_chain_kernel(GzChain *chain, const GzChunk *chunks, uint32_t chunk_lo, uint32_t chunk_hi,
                                                         const uint16_t *sym, uint64_t sym_cap, uint64_t *out_off, uint8_t *text,
                                                         uint64_t text_base)
@@ -676,10 +678,13 @@ __global__ __launch_bounds__(1024) void gz_chain_kernel(GzChain *chain, const Gz
             uint16_t v[8];
             const uint32_t m = tail - i < 8 ? tail - i : 8;
             if (m == 8) __builtin_memcpy(v, sp + i, 16); else for (uint32_t k = 0; k < m; k++) v[k] = sp[i + k];
-            for (uint32_t k = 0; k < m; k++) {
-                const uint8_t b = (v[k] & GZ_MARK) ? wa[v[k] & 0x7FFFu] : (uint8_t)v[k];
-                wb[keep + i + k] = b; tp[i + k] = b;
-            }
+            uint8_t b[8];
+            for (uint32_t k = 0; k < m; k++) b[k] = (v[k] & GZ_MARK) ? wa[v[k] & 0x7FFFu] : (uint8_t)v[k];
+            if (m == 8 && ((keep + i) & 7) == 0) {                          // eight bytes at a time to the new window and to the text
+                uint64_t q; __builtin_memcpy(&q, b, 8);
+                *reinterpret_cast<uint64_t *>(wb + keep + i) = q;
+                __builtin_memcpy(tp + i, &q, 8);
+            } else for (uint32_t k = 0; k < m; k++) { wb[keep + i + k] = b[k]; tp[i + k] = b[k]; }
         }
         __syncthreads();
         a ^= 1;

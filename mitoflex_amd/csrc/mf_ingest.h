@@ -22,11 +22,16 @@ hipError_t launch_line_starts(const uint8_t *text, uint64_t n, const uint64_t *t
 // sequence length of records [0, n_rec): line 4r+1 without its LF and without a CR in front of it; minmax[0] = min, [1] = max
 // (preset to ~0, 0).  line_start must have 4 * n_rec + 1 entries.
 hipError_t launch_seq_lens(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint32_t *seq_len, uint32_t *minmax, hipStream_t st);
-// 2-bit pack: words[w] holds bases 16w .. 16w+15 of the concatenated sequences.  offsets: n_rec + 1 base offsets (nullptr when
-// every read has uniform_len bases).  MODE 0 (npos == nullptr): writes words and, per workgroup of 256 words, the number of
-// invalid bases to inv_cnt.  MODE 1: inv_base = exclusive scan of inv_cnt; writes the positions of the invalid bases, ascending, to npos.
+// 2-bit pack of a batch of records, APPENDED to a read set: the batch's bases take the places base .. base + total_bases - 1 of
+// the stream (words[g >> 4] holds base g; the word the batch shares with its predecessor is completed, the words behind must
+// not hold anything yet).  offsets: the batch's own n_rec + 1 base offsets, starting at 0 (nullptr when every read of the batch
+// has uniform_len bases).  MODE 0 (npos == nullptr): writes words and, per workgroup of 256 words, the number of invalid bases
+// to inv_cnt (pack_blocks() entries).  MODE 1: inv_base = exclusive scan of inv_cnt; writes the stream positions of the invalid
+// bases, ascending, to npos[0 ..].
+uint64_t pack_blocks(uint64_t total_bases, uint64_t base);
 hipError_t launch_pack(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_rec,
-                       uint64_t total_bases, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st);
+                       uint64_t total_bases, uint64_t base, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st);
+hipError_t launch_add_base(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t st);       // dst[i] = src[i] + base
 // pass bits of one batch (bit i = record i of the batch) into the file-wide bitmap at record index rec_base
 hipError_t launch_store_bits(const uint32_t *batch_bits, uint64_t n_rec, uint32_t *file_bits, uint64_t rec_base, hipStream_t st);
 // output bytes of records [0, n_rec) of a batch whose first record has file index rec_base: header + seq + "+" + qual with LF

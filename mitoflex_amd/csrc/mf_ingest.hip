@@ -155,30 +155,34 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w, uint32_t &invalid4)
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len,
-                                                   uint64_t n_rec, uint64_t total_bases, uint32_t *words, uint32_t *inv_cnt,
+                                                   uint64_t n_rec, uint64_t total_bases, uint64_t base, uint32_t *words, uint32_t *inv_cnt,
                                                    const uint64_t *inv_base, uint64_t *npos)
 {
+    // The batch's bases take the places base .. base + total_bases - 1 of the read set's stream (a read set is appended to batch
+    // by batch); offsets are the batch's own (they start at 0).  One thread per word of the stream that the batch touches.
     __shared__ uint32_t lds[4];
     if (MODE == 1 && inv_cnt[blockIdx.x] == 0) return;                    // (nearly every workgroup: invalid bases are rare)
-    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x, g0 = w * 16;
+    const uint64_t w = (base >> 4) + (uint64_t)blockIdx.x * 256 + threadIdx.x, g0 = w * 16;
+    const uint64_t lo_g = g0 > base ? g0 : base, hi_g = g0 + 16 < base + total_bases ? g0 + 16 : base + total_bases;
     uint32_t word = 0, inv = 0;
-    if (g0 < total_bases) {
+    if (lo_g < hi_g) {
+        const uint64_t l0 = lo_g - base;                                  // first base of this word, counted in the batch
+        const uint32_t k0 = (uint32_t)(lo_g - g0), nb = (uint32_t)(hi_g - lo_g);
         uint64_t r, pos, len;
-        if (uniform_len) { r = g0 / uniform_len; pos = g0 - r * uniform_len; len = uniform_len; }
+        if (uniform_len) { r = l0 / uniform_len; pos = l0 - r * uniform_len; len = uniform_len; }
         else {
-            uint64_t lo = 0, hi = n_rec;                                  // last r with offsets[r] <= g0 (an empty read never is: its successor has the same offset)
-            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= g0) lo = mid; else hi = mid; }
-            r = lo; pos = g0 - offsets[r]; len = offsets[r + 1] - offsets[r];
+            uint64_t lo = 0, hi = n_rec;                                  // last r with offsets[r] <= l0 (an empty read never is: its successor has the same offset)
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= l0) lo = mid; else hi = mid; }
+            r = lo; pos = l0 - offsets[r]; len = offsets[r + 1] - offsets[r];
         }
         const uint8_t *src = text + line_start[4 * r + 1];
-        const uint32_t nb = total_bases - g0 < 16 ? (uint32_t)(total_bases - g0) : 16;
-        if (pos + 16 <= len) {                                            // the whole word lies in one read: one 16-byte load
+        if (nb == 16 && pos + 16 <= len) {                                // the whole word lies in one read: one 16-byte load
             const uint4 v = load16(src + pos);
             uint32_t i0, i1, i2, i3;
             word = pack4(v.x, i0) | (pack4(v.y, i1) << 8) | (pack4(v.z, i2) << 16) | (pack4(v.w, i3) << 24);
             inv = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
         } else {
-            for (uint32_t k = 0; k < nb; k++) {
+            for (uint32_t k = k0; k < k0 + nb; k++) {
                 while (pos >= len) {                                      // next read that has bases
                     r++; pos = 0;
                     len = uniform_len ? uniform_len : offsets[r + 1] - offsets[r];
@@ -192,13 +196,18 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *text, const ui
         }
     }
     if (MODE == 0) {
-        if (g0 < total_bases) words[w] = word;
+        if (lo_g < hi_g) { if (g0 < base) words[w] |= word; else words[w] = word; }      // (the first word may be shared with the batch before: that one is complete)
         const uint32_t s = block_sum(__popc(inv), lds);
         if (threadIdx.x == 0) inv_cnt[blockIdx.x] = s;
     } else {
         uint64_t k = inv_base[blockIdx.x] + block_exclusive<uint32_t>(__popc(inv), lds, nullptr);
         for (uint32_t m = inv; m; m &= m - 1) npos[k++] = g0 + (uint32_t)(__ffs(m) - 1);
     }
+}
+__global__ __launch_bounds__(256) void add_base_kernel(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i] + base;
 }
 
 // ------------------------------------------------------------------------------------------------------------ survivors
@@ -267,6 +276,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *text, const 
 
 } // namespace
 
+uint64_t pack_blocks(uint64_t total_bases, uint64_t base)
+{
+    if (!total_bases) return 0;
+    const uint64_t nw = ((base + total_bases + 15) >> 4) - (base >> 4);
+    return (nw + 255) / 256;
+}
+
 hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *scratch, hipStream_t st)
 {
     const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -300,12 +316,19 @@ hipError_t launch_seq_lens(const uint8_t *text, const uint64_t *line_start, uint
 }
 
 hipError_t launch_pack(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_rec,
-                       uint64_t total_bases, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st)
+                       uint64_t total_bases, uint64_t base, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st)
 {
-    const uint64_t nw = (total_bases + 15) / 16, nb = (nw + 255) / 256;
+    const uint64_t nb = pack_blocks(total_bases, base);
     if (!nb) return hipSuccess;
-    if (!npos) hipLaunchKernelGGL(pack_kernel<0>, dim3((uint32_t)nb), dim3(256), 0, st, text, line_start, offsets, uniform_len, n_rec, total_bases, words, inv_cnt, inv_base, npos);
-    else hipLaunchKernelGGL(pack_kernel<1>, dim3((uint32_t)nb), dim3(256), 0, st, text, line_start, offsets, uniform_len, n_rec, total_bases, words, inv_cnt, inv_base, npos);
+    if (!npos) hipLaunchKernelGGL(pack_kernel<0>, dim3((uint32_t)nb), dim3(256), 0, st, text, line_start, offsets, uniform_len, n_rec, total_bases, base, words, inv_cnt, inv_base, npos);
+    else hipLaunchKernelGGL(pack_kernel<1>, dim3((uint32_t)nb), dim3(256), 0, st, text, line_start, offsets, uniform_len, n_rec, total_bases, base, words, inv_cnt, inv_base, npos);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_base(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(add_base_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, dst, src, n, base);
     return hipGetLastError();
 }
 

@@ -1,0 +1,208 @@
+"""The device ingest path of mf_filter_fastq_files (mitoflex_amd/csrc/mf_devingest.cpp, mf_gzdev.hip, mf_ingest.hip): the
+file's bytes go to the GPU as they are; inflate, line indexing, 2-bit packing, the filter and the copy of the survivors run
+there.  Held to the oracle (output bytes, kept / total counts) and to the host pipeline (MF_INGEST=host) on inputs that put a
+seam everywhere: tiny speculative chunks and slabs, every gzip level incl. stored blocks, several members, CRLF, an
+unterminated last line, a partial record at the end, records longer than the deflate window, mates out of step.
+Reference conventions: filter/filter_bin/src/helper.rs:14-31 (.gz by extension), main.rs:287-321 (4-line records)."""
+import gzip
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from tests.util_data import make_reads, write_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mf():
+    from mitoflex_amd import mitofilter
+    mitofilter.load()
+    return mitofilter
+
+
+@pytest.fixture(scope="module")
+def ol():
+    from oracle import oracle_lib
+    return oracle_lib
+
+
+@pytest.fixture(scope="module")
+def bait_text():
+    from tests.util_data import make_bait
+    return make_bait()
+
+
+def fastq_text(seqs, prefix, crlf=False, tail=b"", last_newline=True, seed=7):
+    rng = random.Random(seed)
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i, s in enumerate(seqs):
+        q = "".join(rng.choice("#,:FI") for _ in s)
+        out.append(b"@" + f"{prefix}.{i} some comment".encode() + nl + s.encode() + nl + b"+" + (b"anything" if i % 3 == 0 else b"") + nl + q.encode() + nl)
+    t = b"".join(out) + tail
+    if not last_newline and t.endswith(nl):
+        t = t[:-len(nl)]
+    return t
+
+
+def gz_bytes(text, level, members=1):
+    """one or several gzip members; level 0 = stored blocks only"""
+    if members == 1:
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(text) + c.flush()
+    cut = [len(text) * i // members for i in range(members + 1)]
+    return b"".join(gz_bytes(text[cut[i]:cut[i + 1]], level) for i in range(members))
+
+
+def run_both(mf, ol, bait_path, ks, fq1, fq2, tmp_path, thr=1, pair_mode=0):
+    o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+    g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
+    ok, ot = ol.filter_fastq_files(bait_path, 31, thr, pair_mode, fq1, fq2, o1, o2 if fq2 else None, threads=2)
+    gk, gt = mf.filter_fastq_files(ks, fq1, fq2, g1, g2 if fq2 else None, thr, pair_mode)
+    assert (gk, gt) == (ok, ot)
+    assert open(g1, "rb").read() == open(o1, "rb").read()
+    if fq2:
+        assert open(g2, "rb").read() == open(o2, "rb").read()
+    return gk, gt
+
+
+SEAMS = {"MF_GZDEV_CHUNK_BYTES": "4096", "MF_GZDEV_SLAB_CHUNKS": "3", "MF_INGEST_SLAB_BYTES": "70001"}
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+@pytest.mark.parametrize("seams", [False, True])
+def test_gz_levels_and_seams(mf, ol, bait_text, tmp_path, monkeypatch, level, seams):
+    if seams:
+        for k, v in SEAMS.items():
+            monkeypatch.setenv(k, v)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s1 = make_reads(bait_text, 4000, seed=31)
+    s2 = make_reads(bait_text, 4100, seed=32)
+    fq1, fq2 = str(tmp_path / "a_1.fq.gz"), str(tmp_path / "a_2.fq.gz")
+    open(fq1, "wb").write(gz_bytes(fastq_text(s1, "a", tail=b"@partial\nACGT\n"), level))
+    open(fq2, "wb").write(gz_bytes(fastq_text(s2, "b", crlf=True, last_newline=False), level))
+    for pair_mode in (mf.PAIR_EITHER, mf.PAIR_BOTH):
+        k, t = run_both(mf, ol, bait, ks, fq1, fq2, tmp_path, 1, pair_mode)
+        assert t == 4000 and 0 < k < t
+    run_both(mf, ol, bait, ks, fq2, None, tmp_path, 2)
+
+
+@pytest.mark.parametrize("seams", [False, True])
+def test_plain_files_and_seams(mf, ol, bait_text, tmp_path, monkeypatch, seams):
+    if seams:
+        for k, v in SEAMS.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("MF_INGEST_SLAB_BYTES", "333")       # about one record per slab: every slab carries a partial record
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    n = 600 if seams else 5000
+    s1 = make_reads(bait_text, n, seed=41)
+    s2 = make_reads(bait_text, n + 7, seed=42)
+    fq1, fq2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    open(fq1, "wb").write(fastq_text(s1, "a", crlf=True, tail=b"@partial\r\nAC"))
+    open(fq2, "wb").write(fastq_text(s2, "b", last_newline=False))
+    k, t = run_both(mf, ol, bait, ks, fq1, fq2, tmp_path)
+    assert t == n
+    run_both(mf, ol, bait, ks, fq1, None, tmp_path)
+    run_both(mf, ol, bait, ks, fq2, None, tmp_path, 3)
+
+
+def test_records_longer_than_the_window(mf, ol, bait_text, tmp_path, monkeypatch):
+    """A carry longer than 32 KiB: the head of the record comes from the previous slab's buffer."""
+    for k, v in SEAMS.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("MF_INGEST_SLAB_BYTES", "50000")
+    from tests.util_data import bait_records
+    g = bait_records(bait_text)[0]
+    rng = random.Random(5)
+    seqs = []
+    for i in range(40):
+        if i % 4 == 0:
+            seqs.append("".join(rng.choice("ACGT") for _ in range(rng.randrange(40000, 120000))) + (g[100:400] if i % 8 == 0 else ""))
+        else:
+            seqs.append(g[rng.randrange(0, 8000):][:150] if i % 3 else "".join(rng.choice("ACGT") for _ in range(150)))
+    text = fastq_text(seqs, "long")
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    fq, fqgz = str(tmp_path / "l.fq"), str(tmp_path / "l.fq.gz")
+    open(fq, "wb").write(text)
+    open(fqgz, "wb").write(gz_bytes(text, 6))
+    k1, t1 = run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    k2, t2 = run_both(mf, ol, bait, ks, fqgz, None, tmp_path)
+    assert (k1, t1) == (k2, t2) and t1 == 40 and k1 >= 5
+
+
+@pytest.mark.parametrize("members", [2, 5])
+def test_several_members(mf, ol, bait_text, tmp_path, monkeypatch, members):
+    """gzread (and this reader) decode every member of a multi-member file; member boundaries fall inside records."""
+    for k, v in SEAMS.items():
+        monkeypatch.setenv(k, v)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s = make_reads(bait_text, 3000, seed=51)
+    fq = str(tmp_path / "m.fq.gz")
+    open(fq, "wb").write(gz_bytes(fastq_text(s, "m"), 6, members) + b"trailing garbage that is not a member")
+    k, t = run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    assert t == 3000
+
+
+def test_same_as_host_pipeline(mf, bait_text, tmp_path, monkeypatch):
+    """the two ingest paths of the library write the same bytes (gz output included)"""
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s1, s2 = make_reads(bait_text, 20000, seed=61), make_reads(bait_text, 20000, seed=62)
+    fq1, fq2 = str(tmp_path / "a_1.fq.gz"), str(tmp_path / "a_2.fq.gz")
+    write_fastq(fq1, s1, "a", gz=True)
+    write_fastq(fq2, s2, "b", crlf=True, gz=True)
+    d1, d2, h1, h2 = (str(tmp_path / x) for x in ("d1.fq.gz", "d2.fq.gz", "h1.fq.gz", "h2.fq.gz"))
+    a = mf.filter_fastq_files(ks, fq1, fq2, d1, d2, 1, mf.PAIR_EITHER)
+    monkeypatch.setenv("MF_INGEST", "host")
+    b = mf.filter_fastq_files(ks, fq1, fq2, h1, h2, 1, mf.PAIR_EITHER)
+    assert a == b and a[1] == 20000
+    assert gzip.open(d1).read() == gzip.open(h1).read() and gzip.open(d2).read() == gzip.open(h2).read()
+
+
+def test_damaged_gz_is_an_error(mf, bait_text, tmp_path):
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s = make_reads(bait_text, 3000, seed=71)
+    good = gz_bytes(fastq_text(s, "d"), 6)
+    out = str(tmp_path / "o.fq")
+    # a flipped bit in the middle (CRC or code error), a wrong CRC, a wrong length, a truncated file
+    cases = {"flip": bytearray(good), "crc": bytearray(good), "len": bytearray(good), "cut": bytearray(good[:len(good) * 2 // 3])}
+    cases["flip"][len(good) // 2] ^= 0x10
+    cases["crc"][-8] ^= 1
+    cases["len"][-1] ^= 1
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".fq.gz"))
+        open(p, "wb").write(bytes(data))
+        with pytest.raises(mf.MitoFilterError):
+            mf.filter_fastq_files(ks, p, None, out, None)
+
+
+def test_highly_compressible_input_grows_the_symbol_buffers(mf, ol, bait_text, tmp_path):
+    """identical reads compress several hundredfold: the decoder's per-chunk symbol room is enlarged and the slab decoded again"""
+    from tests.util_data import bait_records
+    g = bait_records(bait_text)[0]
+    seqs = [g[500:650]] * 30000 + ["ACGT" * 30] * 30000
+    rng = random.Random(3)
+    text = b"".join(b"@same\n" + s.encode() + b"\n+\n" + b"F" * len(s) + b"\n" for s in seqs)
+    fq = str(tmp_path / "same.fq.gz")
+    open(fq, "wb").write(gz_bytes(text, 9))
+    assert os.path.getsize(fq) * 100 < len(text)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    k, t = run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    assert (k, t) == (30000, 60000)

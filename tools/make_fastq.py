@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util_data import bait_records, make_bait  # noqa: E402
 
 
-def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate, qual="uniform"):
+def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate, qual="uniform", first=0, append=False):
+    """records first .. first + n - 1 (written in blocks: the generator is not the same stream as one big call)"""
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     seq = acgt[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
@@ -28,7 +29,7 @@ def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate, qual="unif
     seq[idx] = win
     nmask = rng.random(n) < 0.01
     seq[np.nonzero(nmask)[0], rng.integers(0, L, size=int(nmask.sum()))] = ord("N")
-    hdr = np.char.add(np.char.add("@syn.", np.char.zfill(np.arange(n).astype(str), 9)), "/%d" % mate).astype("S")
+    hdr = np.char.add(np.char.add("@syn.", np.char.zfill((first + np.arange(n)).astype(str), 9)), "/%d" % mate).astype("S")
     hl = hdr.dtype.itemsize
     rec = np.empty((n, hl + 1 + L + 3 + L + 1), dtype=np.uint8)
     rec[:, :hl] = hdr.view(np.uint8).reshape(n, hl)
@@ -41,7 +42,8 @@ def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate, qual="unif
     else:
         rec[:, hl + 4 + L: hl + 4 + 2 * L] = rng.integers(ord("8"), ord("J"), size=(n, L), dtype=np.uint8)
     rec[:, -1] = 10
-    rec.tofile(path)
+    with open(path, "ab" if append else "wb") as f:
+        rec.tofile(f)
 
 
 if __name__ == "__main__":
@@ -49,9 +51,16 @@ if __name__ == "__main__":
     ap.add_argument("prefix"); ap.add_argument("--pairs", type=int, default=1_000_000); ap.add_argument("--len", type=int, default=150)
     ap.add_argument("--mito", type=float, default=0.005); ap.add_argument("--seed", type=int, default=12340)
     ap.add_argument("--qual", choices=["uniform", "binned"], default="uniform")
+    ap.add_argument("--mates", type=int, default=2, help="1: only mate 1 (single-end sets)")
+    ap.add_argument("--block", type=int, default=0, help="write in blocks of this many records (memory bound for large sets)")
     a = ap.parse_args()
     bait = make_bait()
     open(a.prefix + ".bait.fa", "w").write(bait)
     g = bait_records(bait)[0]
-    for mate in (1, 2):
-        write_mate(f"{a.prefix}_{mate}.fq", a.pairs, a.len, a.seed + mate, mate, g, a.mito, 0.01, a.qual)
+    for mate in (1, 2)[:a.mates]:
+        if a.block and a.pairs > a.block:          # big files: block by block (a block's seed follows from its index)
+            for b, first in enumerate(range(0, a.pairs, a.block)):
+                write_mate(f"{a.prefix}_{mate}.fq", min(a.block, a.pairs - first), a.len, a.seed + mate + 1000 * (b + 1), mate, g, a.mito, 0.01, a.qual,
+                           first=first, append=b > 0)
+        else:
+            write_mate(f"{a.prefix}_{mate}.fq", a.pairs, a.len, a.seed + mate, mate, g, a.mito, 0.01, a.qual)
