@@ -18,6 +18,11 @@ host cores and checks every GPU pass bit against it.
 
 Ranks are independent (each filters its own shard, no collective); the launcher's RANK / WORLD_SIZE are all this
 script needs, so torch is never imported: the barrier and the max over ranks go through a directory in /dev/shm.
+
+Beside the headline, at N = 1 (`extra`): files in / files out -- a bounded PE / SE run and configs[4] at its stated size
+(33 333 334 single-end reads, one gzip member, device ingest: inflate, line index, pack, filter on the GPU) -- and the
+Group-A row of BASELINE.md (the contig filter CLI on the 1 M-record generator file of SURVEY.md 8c).  Every input file is made
+BEFORE this process touches the GPU, by child processes that do not inherit a profiler's environment.
 """
 import argparse
 import json
@@ -50,6 +55,9 @@ def parse():
     ap.add_argument("--no-exhaustive", action="store_true", help="skip the extra exhaustive-mode measurement")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--e2e-pairs", type=int, default=500_000, help="pairs of the bounded files-in/files-out run reported in extra (0 = skip)")
+    ap.add_argument("--e2e-full-reads", type=int, default=READS_5GBP,
+                    help="reads of the single-end .gz file of configs[4] that is filtered file to file (default: its stated size, 5 Gbp; 0 = skip)")
+    ap.add_argument("--no-group-a", action="store_true", help="skip the Group-A row (contig filter CLI on the 1 M-record generator file)")
     return ap.parse_args()
 
 
@@ -82,6 +90,23 @@ class ShmRendezvous:
 
     barrier = allmax
 
+    def gather(self, value, timeout=600.0):
+        """every rank's value, by rank"""
+        self.n += 1
+        mine = os.path.join(self.dir, "%d.%d" % (self.n, self.rank))
+        with open(mine + ".tmp", "w") as f:
+            f.write(repr(float(value)))
+        os.rename(mine + ".tmp", mine)
+        vals, t0 = [], time.time()
+        for r in range(self.world):
+            p = os.path.join(self.dir, "%d.%d" % (self.n, r))
+            while not os.path.exists(p):
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("rank %d: rank %d did not reach gather %d" % (self.rank, r, self.n))
+                time.sleep(0.0005)
+            vals.append(float(open(p).read()))
+        return vals
+
     def close(self, timeout=120.0):
         self.allmax()
         open(os.path.join(self.dir, "done.%d" % self.rank), "w").close()       # this rank has read everything it will ever read here
@@ -109,39 +134,70 @@ def committed_traffic():
         return None, None
 
 
-def live_traffic(timeout_s=75.0):
-    """HBM bytes per screen-kernel launch of THIS workload on THIS box: two short child runs of this script under
-    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE -- one counter a pass, as MI355X_MICROARCH.md prescribes; counters cannot be
-    read from inside a process), FETCH_SIZE doubled for gfx950.  (bytes, description) or (None, reason)."""
+def being_profiled():
+    return any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def child_env(**extra):
+    """environment for child processes: nothing of a profiler that may be wrapped around this process (a child that inherits
+    its preloaded library is a GPU-initialised fork that execs -- the hop the pool forbids)"""
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER", "HSA_TOOLS"))}
+    env.update(extra)
+    return env
+
+
+def live_counters(counters, k, timeout_s=75.0):
+    """Per-launch averages of PMC counters of the dominant kernel of THIS workload on THIS box: one short child run of this
+    script under `rocprofv3 --pmc` per counter (one counter a pass, as MI355X_MICROARCH.md prescribes; counters cannot be read
+    from inside a process).  ({counter: value}, None) or (None, reason).  A child that overruns is killed with its whole
+    process group, and waited for, before this process goes on to the GPU."""
     import csv
     import glob
     import shutil
-    import subprocess
+    import signal
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
-    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+    if being_profiled():
         return None, "this process is being profiled itself"
-    kib = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    out = {}
+    for counter in counters:
         d = tempfile.mkdtemp(prefix="mf_pmc_", dir="/tmp")
         try:
             # (the profiled program comes right after `--`: no shell, no env wrapper in between)
-            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "0", "--prewarm-ms", "0", "--cpu-sample", "0", "--no-exhaustive", "--e2e-pairs", "0", "--no-live-traffic"]
-            subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--k", str(k),
+                   "--steps", "2", "--warmup", "0", "--prewarm-ms", "0", "--cpu-sample", "0", "--no-exhaustive", "--e2e-pairs", "0",
+                   "--e2e-full-reads", "0", "--no-group-a", "--no-live-traffic"]
+            p = subprocess.Popen(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)          # the launcher AND the profiled script: nothing of it may share the GPU with the timed loop
+                except ProcessLookupError:
+                    pass
+                p.wait()
+                return None, f"live collection timed out ({counter})"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
                     if "mf::screen_kernel<" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]      # (not build_screen_kernel)
             if not vals:
                 return None, f"no {counter} rows for screen_kernel"
-            kib[counter] = sum(vals) / len(vals)
+            out[counter] = sum(vals) / len(vals)
         except Exception as e:
             return None, f"{counter} pass failed: {str(e)[:120]}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return int((2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024), \
+    return out, None
+
+
+def live_traffic(k):
+    """HBM bytes per screen-kernel launch: FETCH_SIZE doubled for gfx950 + WRITE_SIZE (KiB counters).  (bytes, description) or (None, reason)."""
+    c, why = live_counters(("FETCH_SIZE", "WRITE_SIZE"), k)
+    if c is None:
+        return None, why
+    return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), \
         "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script on this box (FETCH_SIZE x 2 on gfx950, KiB counters)"
 
 
@@ -155,29 +211,125 @@ def cpu_quota():
         return None
 
 
-def e2e_files(mf, ks, pairs):
-    """Bounded files-in / files-out run (host bound by construction: parse, pack, PCIe, write): reads/s of the
-    whole mf_filter_fastq_files call, best of three, for plain PE and gzipped SE input (configs[4] shape)."""
-    import tempfile
-    out = {}
-    with tempfile.TemporaryDirectory(prefix="mf_e2e_") as t:
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(t, "s"), "--pairs", str(pairs)],
-                              stdout=subprocess.DEVNULL)
-        f1, f2 = os.path.join(t, "s_1.fq"), os.path.join(t, "s_2.fq")
-        with open(f1 + ".gz", "wb") as g:
-            subprocess.check_call(["gzip", "-1", "-c", f1], stdout=g)
+G20_COUNT, G20_MD5 = 398188, "59347e825357644e5116d9f8b988cb82"       # SURVEY.md 8c, captured from the reference's ELF
+G20_GENERATOR = """
+import random, sys
+random.seed(20261003)
+with open(sys.argv[1], "w") as f:
+    for i in range(1_000_000):
+        L = random.randint(60, 600)
+        multi = random.choice([1.0, 2.0, 3.5, 9.9999, 10.0, 25.25, 300.0]) * random.random() * 2
+        f.write(f">k31_{i} flag={random.randint(0, 2)} multi={multi:.4f} len={L}\\n")
+        f.write(''.join(random.choices('ACGT', k=L)) + "\\n")
+"""
 
-        def run(a, b, o1, o2, n_reads):
-            best = 1e9
-            for _ in range(3):
-                t0 = time.perf_counter()
-                mf.filter_fastq_files(ks, a, b, o1, o2)
-                best = min(best, time.perf_counter() - t0)
-            return n_reads / best
-        out["pe_plain_reads_per_s"] = run(f1, f2, os.path.join(t, "o1.fq"), os.path.join(t, "o2.fq"), 2 * pairs)
-        out["se_gz_reads_per_s"] = run(f1 + ".gz", None, os.path.join(t, "og.fq"), None, pairs)
-        out["pairs"] = pairs
+
+def md5_of(path):
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for b in iter(lambda: f.read(1 << 24), b""):
+            h.update(b)
+    return h.hexdigest()
+
+
+def prepare_inputs(a, tmp):
+    """Every file the file-level measurements read, made by child processes BEFORE this process initialises the GPU (and not
+    at all when this process is being profiled: the children would inherit the profiler).  -> {name: path or note}"""
+    import shutil
+    files = {}
+    if being_profiled():
+        return {"skipped": "this process is being profiled: no child processes, no file-level runs"}
+    env = child_env()
+    run = lambda cmd, **kw: subprocess.check_call(cmd, env=env, stdout=subprocess.DEVNULL, **kw)
+    try:
+        if a.e2e_pairs > 0:
+            run([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(tmp, "s"), "--pairs", str(a.e2e_pairs)])
+            with open(os.path.join(tmp, "s_1.fq.gz"), "wb") as g:
+                subprocess.check_call(["gzip", "-1", "-c", os.path.join(tmp, "s_1.fq")], stdout=g, env=env)
+            files["small"] = os.path.join(tmp, "s")
+        if a.e2e_full_reads > 0:
+            need = a.e2e_full_reads * 321 * 1.7
+            if shutil.disk_usage(tmp).free < need:
+                files["full_note"] = "not enough scratch space for the configs[4] file"
+            else:
+                t0 = time.time()
+                run([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(tmp, "f"), "--pairs", str(a.e2e_full_reads), "--mates", "1", "--block", "2000000"])
+                t1 = time.time()
+                run([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), os.path.join(tmp, "f_1.fq"), os.path.join(tmp, "f_1.fq.gz"), "--level", "6"])
+                files["full"] = os.path.join(tmp, "f")
+                files["full_prep_seconds"] = {"generate": round(t1 - t0, 1), "compress": round(time.time() - t1, 1)}
+        if not a.no_group_a:
+            run([sys.executable, "-c", G20_GENERATOR, os.path.join(tmp, "g20.fa")])
+            files["g20"] = os.path.join(tmp, "g20.fa")
+    except Exception as e:
+        files["error"] = str(e)[:200]
+    return files
+
+
+def e2e_files(mf, ks, files, a):
+    """Files in / files out (mf_filter_fastq_files), reads/s of the whole call, best of three."""
+    out = {}
+
+    def run(f1, f2, o1, o2, n_reads, reps=3):
+        best, res = 1e9, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = mf.filter_fastq_files(ks, f1, f2, o1, o2)
+            best = min(best, time.perf_counter() - t0)
+        return n_reads / best, best, res
+    if "small" in files:
+        t = files["small"]
+        out["pe_plain_reads_per_s"] = run(t + "_1.fq", t + "_2.fq", t + "_o1.fq", t + "_o2.fq", 2 * a.e2e_pairs)[0]
+        out["se_gz_reads_per_s"] = run(t + "_1.fq.gz", None, t + "_og.fq", None, a.e2e_pairs)[0]
+        out["pairs"] = a.e2e_pairs
+    if "full" in files:
+        # configs[4] at its stated size: one gzip member of single-end reads, device ingest (inflate, line index, 2-bit pack, filter
+        # and survivor copy on the GPU).  Checked against the host pipeline on the plain text of the same reads, byte for byte.
+        t = files["full"]
+        n = a.e2e_full_reads
+        prev = os.environ.get("MF_INGEST")
+        os.environ["MF_INGEST"] = "host"
+        host_rate, _, host_res = run(t + "_1.fq", None, t + "_oh.fq", None, n, reps=1)
+        host_gz_rate = run(t + "_1.fq.gz", None, t + "_ohg.fq", None, n, reps=1)[0]
+        if prev is None:
+            del os.environ["MF_INGEST"]
+        else:
+            os.environ["MF_INGEST"] = prev
+        rate, secs, res = run(t + "_1.fq.gz", None, t + "_od.fq", None, n)
+        md5 = md5_of(t + "_od.fq")
+        out["configs4_se_gz"] = {
+            "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), "kept": int(res[0]), "total": int(res[1]),
+            "gz_bytes": os.path.getsize(t + "_1.fq.gz"), "text_bytes": os.path.getsize(t + "_1.fq"),
+            "input": "synthetic single-end FASTQ (tools/make_fastq.py), ONE gzip member written by tools/pgzip.py at level 6 (8 MiB slices)",
+            "ingest": "device: compressed bytes uploaded as they are; inflate, line index, 2-bit pack, filter, survivor copy on the GPU",
+            "output_md5": md5, "output_equals_host_pipeline_on_plain_text": bool(md5 == md5_of(t + "_oh.fq") and tuple(res) == tuple(host_res)),
+            "host_pipeline_plain_reads_per_s": host_rate, "host_pipeline_gz_reads_per_s": host_gz_rate,
+            "prep_seconds": files.get("full_prep_seconds")}
+    elif "full_note" in files:
+        out["configs4_se_gz"] = {"skipped": files["full_note"]}
     return out
+
+
+def group_a(files):
+    """the contig filter CLI (the reference's real `fastfilter`) on the 1 M-record generator file."""
+    exe = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
+    src = files["g20"]
+    dst = src + ".filtered"
+    best, count = 1e9, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        count = int(subprocess.check_output([exe, "-i", src, "-o", dst, "-l", "0,20000", "-d", "10"], env=child_env()).decode())
+        best = min(best, time.perf_counter() - t0)
+    size = os.path.getsize(src)
+    return {"seconds": round(best, 4), "MB_per_s": round(size / best / 1e6, 1), "input_bytes": size, "count": count,
+            "count_matches_reference": count == G20_COUNT, "output_md5_matches_reference": md5_of(dst) == G20_MD5,
+            "reference_elf_seconds_build_container": 0.571,
+            "note": "argv: -l 0,20000 -d 10 (SURVEY.md 8c case G20); the reference figure was taken with its prebuilt ELF on one core of the build "
+                    "container (the ELF cannot travel to this box), so the two are not same-host timings"}
+
+
+VALU_PEAK_GINST = 1024 * 2.4 / 4        # wave-instructions per ns the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles per wave stream at 2.4 GHz
 
 
 def main():
@@ -185,6 +337,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -192,19 +345,33 @@ def main():
     if a.reads <= 0:
         a.reads = READS_50GBP_8 if world == 8 else READS_5GBP
     rdv = ShmRendezvous(rank, world) if world > 1 else None
+    solo = rank == 0 and world == 1
 
-    # roofline.traffic, live (two short counter runs of this script as child processes, before this process touches the GPU)
-    live = (None, None)
-    if rank == 0 and world == 1 and not a.no_live_traffic and a.reads == READS_5GBP and a.k == K:
-        live = live_traffic()
+    # ---- everything that needs child processes happens before this process touches the GPU
+    import tempfile
+    tmpdir = tempfile.TemporaryDirectory(prefix="mf_bench_", dir="/tmp") if solo else None
+    files = prepare_inputs(a, tmpdir.name) if solo else {}
+    live, valu = (None, None), (None, None)
+    default_set = a.reads == READS_5GBP
+    if solo and not a.no_live_traffic and default_set:
+        live = live_traffic(a.k)
+        if a.k < 28 and live[0] is not None:                  # the stride-8 screen is bound by vector issue, not by HBM: count its instructions too
+            valu = live_counters(("SQ_INSTS_VALU",), a.k)
 
+    # every rank packs its own synthetic shard on the host first: share the host's threads between the ranks of the node
+    if local_world > 1 and "MF_HOST_THREADS" not in os.environ:
+        os.environ["MF_HOST_THREADS"] = str(max(1, (os.cpu_count() or 1) // local_world))
     from mitoflex_amd import mitofilter as mf
     mf.load()
     from tests.util_data import make_bait
     bait = make_bait()
-    dev = local_rank % max(1, mf.device_count())      # one rank per GPU; wraps only when ranks outnumber GPUs (tests)
+    n_dev = mf.device_count()
+    if local_world > max(1, n_dev) and os.environ.get("MF_BENCH_SHARE_GPU") != "1":
+        sys.exit(f"bench.py: {local_world} ranks on this node but {n_dev} visible GPU(s): one rank per GPU "
+                 "(MF_BENCH_SHARE_GPU=1 lets ranks share a device -- tests only, the figures mean nothing then)")
+    dev = local_rank % max(1, n_dev)
     ks = mf.KmerSet.from_text(bait, a.k, dev)
-    want_cpu = rank == 0 and world == 1 and a.cpu_sample > 0
+    want_cpu = solo and a.cpu_sample > 0
     t0 = time.time()
     # every rank owns its own shard of whole pairs (weak scaling: fixed reads per GPU), no collective
     reads = mf.Reads.synth(a.reads, READ_LEN, seed=20261003 + rank, bait_text=bait,
@@ -229,9 +396,12 @@ def main():
     t0 = time.perf_counter()
     st = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, a.steps)
     mf.device_synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    mine = time.perf_counter() - t0
+    elapsed = mine
+    per_rank = [mine]
     if rdv is not None:
-        elapsed = rdv.allmax(elapsed)
+        elapsed = rdv.allmax(mine)
+        per_rank = rdv.gather(mine)
 
     # kernel durations: the same K steps again, every dispatch sampled
     os.environ["MF_EVENT_STRIDE"] = "1"
@@ -248,10 +418,14 @@ def main():
              "ms_per_step_sampled_loop": round(sp.ms_total, 4), "kernel_samples": a.steps,
              "ms_pass_events": round(st.ms_total, 4), "work_items": int(st.n_candidates), "passed": int(st.n_pass),
              "reads_per_gpu": a.reads, "synth_seconds": round(t_gen, 2), "prewarm_ms": a.prewarm_ms, "device": mf.device_name(dev),
+             # configs[3]: "per-GPU + aggregate reads/s" -- every rank's own rate over its own K steps (the aggregate uses the slowest)
+             "per_gpu_reads_per_s": [a.reads * a.steps / t for t in per_rank],
+             "per_rank_ms_per_step": [round(t / a.steps * 1e3, 4) for t in per_rank],
              "pipelined": "consecutive steps overlap: finish kernels of step i run under the screen kernel of step i+1 (second stream) and "
                           "consecutive screen kernels go to two streams in turn, so the duration of a screen launch (ms_screen_kernel, "
                           "roofline.achieved) includes time it shares the device with its neighbours; a step completes every ms_per_step"}
-    if rank == 0 and world == 1:
+    alone_frac = None
+    if solo:
         one = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, 1)    # a single step: nothing to overlap with
         extra["ms_single_pass_latency"] = round(one.ms_total, 4)
         # the same kernel with the device to itself (MF_PASS=serial: one stream, no overlap between steps), every dispatch sampled
@@ -264,9 +438,11 @@ def main():
         else:
             os.environ["MF_PASS"] = prev
         if alone.ms_screen > 0:
-            extra["screen_kernel_alone"] = {"ms": round(alone.ms_screen, 4), "frac_of_hbm_peak": round(alg_bytes / (alone.ms_screen / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+            alone_frac = alg_bytes / (alone.ms_screen / 1e3) / 1e9 / HBM_PEAK_GBPS
+            extra["screen_kernel_alone"] = {"ms": round(alone.ms_screen, 4), "frac_of_hbm_peak": round(alone_frac, 4),
                                             "ms_per_step_serial": round(alone.ms_total, 4)}
-    extra["whole_pass_frac_of_hbm_peak"] = round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS, 4)
+    whole_pass_frac = alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS
+    extra["whole_pass_frac_of_hbm_peak"] = round(whole_pass_frac, 4)
     if rank == 0 and not a.no_exhaustive:
         ex = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_EXHAUSTIVE, 1)
         extra["exhaustive_reads_per_s"] = a.reads / (ex.ms_total / 1e3)
@@ -295,20 +471,51 @@ def main():
         nw = n // 32
         extra["sample_bits_match_oracle"] = bool(np.array_equal(gbits[:nw], obits[:nw]))
         extra["sample_reads_checked"] = nw * 32
-    if rank == 0 and world == 1 and a.e2e_pairs > 0:
-        try:
-            extra["e2e_files"] = e2e_files(mf, ks, a.e2e_pairs)
-        except Exception as e:           # the headline numbers do not depend on scratch space for files
-            extra["e2e_files"] = {"error": str(e)[:200]}
+    if solo:
+        reads.close()                                    # (the file-level runs want the device memory)
+        if "skipped" in files or "error" in files:
+            extra["e2e_files"] = {k: v for k, v in files.items() if k in ("skipped", "error")}
+        else:
+            try:
+                extra["e2e_files"] = e2e_files(mf, ks, files, a)
+            except Exception as e:           # the headline numbers do not depend on scratch space for files
+                extra["e2e_files"] = {"error": str(e)[:200]}
+            if "g20" in files:
+                try:
+                    extra["group_a"] = group_a(files)
+                except Exception as e:
+                    extra["group_a"] = {"error": str(e)[:200]}
+    if tmpdir is not None:
+        tmpdir.cleanup()
 
     traffic, traffic_src = committed_traffic()
-    if a.reads != READS_5GBP or a.k != K:
-        traffic, traffic_src = None, None              # the profile was taken on the default workload
-    elif live[0] is not None:
+    if not default_set or a.k != K:
+        traffic, traffic_src = None, None              # the committed profile was taken on the default workload
+    if live[0] is not None:
         traffic, traffic_src = live
     elif live[1] and traffic_src:
         traffic_src += f" (live collection unavailable: {live[1]})"
     if rank == 0:
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS}
+        roofline = {"bound": "hbm", **hbm, "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "screen_kernel", "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "avg_kernel_ms": sp.ms_screen, "kernel_launches_averaged": a.steps,
+                    # `frac` is the kernel's launch duration inside the pipelined loop (it shares the device with its neighbours there):
+                    # beside it the same kernel with the device to itself, and the whole pass (all kernels, alg. bytes / time per step)
+                    "kernel_alone_frac": alone_frac, "whole_pass_frac": whole_pass_frac}
+        if a.k < 28:
+            # the stride-8 screen (k < 28) tests twice the samples and is bound by vector-instruction issue, not by HBM: price it
+            # against the issue rate (SQ_INSTS_VALU wave-instructions per launch, one per 4 cycles per wave stream, 1024 SIMDs)
+            roofline["hbm"] = hbm
+            roofline["bound"] = "valu"
+            if valu[0] is not None and screen_s > 0:
+                ginst = valu[0]["SQ_INSTS_VALU"] / screen_s / 1e9
+                roofline.update({"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST,
+                                 "valu_wave_instructions_per_launch": valu[0]["SQ_INSTS_VALU"],
+                                 "valu_source": "live: rocprofv3 --pmc SQ_INSTS_VALU pass of this script on this box; peak = 1024 SIMDs x 2.4 GHz / 4 cycles"})
+            else:
+                roofline.update({"achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": None,
+                                 "valu_source": f"no live SQ_INSTS_VALU reading ({valu[1] or live[1] or 'not collected'}); see profiles/ for the committed one"})
         out = {
             "metric": "filtered reads/sec on 5 Gbp PE150 k=31; achieved HBM GB/s vs peak",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -320,10 +527,7 @@ def main():
                                    f"k={a.k}, threshold={THRESHOLD}, bait = synthetic 16 569 bp mitogenome + 1.2 kbp record; "
                                    "reads packed 2 bit/base and resident in HBM",
                        "sharding": f"{world} rank(s), one per GPU, independent shards of whole pairs, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "screen_kernel", "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "avg_kernel_ms": sp.ms_screen, "kernel_launches_averaged": a.steps},
+            "roofline": roofline,
             "cpu_baseline": cpu,
             "extra": extra,
         }

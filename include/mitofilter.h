@@ -171,6 +171,13 @@ int mf_filter(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, i
 int mf_filter_resident(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
                        int steps, mf_filter_stats_t *stats);
 
+/* Same as mf_filter_resident, and the number of passing reads of EVERY one of the `steps` passes in n_pass_per_step[0 .. steps)
+ * (each pass tallies into a block of its own): consecutive passes of a call overlap on two buffer sets, and a fault that
+ * touched only the middle passes would not show in the tally of the last one.  No reference counterpart (test support for
+ * the pipelined pass). */
+int mf_filter_resident_passes(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode,
+                              int steps, uint64_t *n_pass_per_step, mf_filter_stats_t *stats);
+
 /* One-shot over host buffers (SURVEY.md 8b name): H2D, filter, D2H. */
 int mf_filter_packed(const mf_kmerset *ks, int device,
                      const uint32_t *words, const uint64_t *offsets, uint64_t n_reads,

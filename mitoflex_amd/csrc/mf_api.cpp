@@ -126,6 +126,15 @@ struct EventList {
     ~EventList() { for (hipEvent_t e : ev) hipEventDestroy(e); }
 };
 
+// host threads for the one-shot host-side jobs (synthetic read sets, packing a FASTQ file): every hardware thread unless
+// MF_HOST_THREADS says otherwise (bench.py sets it to its share when several ranks of one node pack their shards at once)
+static int host_threads()
+{
+    const char *v = getenv("MF_HOST_THREADS");
+    const int n = v && *v ? atoi(v) : (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : n;
+}
+
 static uint32_t env_u32(const char *name, uint32_t dflt)
 {
     const char *v = getenv(name);
@@ -218,7 +227,10 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
     // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
-    V.use_stab = (T.n_smers / 2 * STAGE2_K > ((uint64_t)32 << ks->stage2_log2w) * 7 / 10) || getenv("MF_USE_STAB") ? 1u : 0u;
+    V.use_stab = (T.n_smers / 2 * STAGE2_K > ((uint64_t)32 << ks->stage2_log2w) * 7 / 10) ? 1u : 0u;
+#ifdef MF_DEBUG_KNOBS              // (experiment builds only: `make variant VARFLAGS=-DMF_DEBUG_KNOBS`)
+    if (getenv("MF_USE_STAB")) V.use_stab = 1u;
+#endif
     ks->dev[device] = T; guard.t = nullptr;
     *out = &ks->dev[device];
     return MF_OK;
@@ -243,7 +255,9 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         if (ks->kb_log2w > 15) ks->kb_log2w = 15;
     }
     ks->geom = screen_geom_for(k);
+#ifdef MF_DEBUG_KNOBS
     if (getenv("MF_NO_SCREEN")) ks->geom = ScreenGeom{0, 0};
+#endif
     if (ks->geom.s) {
         const uint64_t bound = 2 * ks->bait.n_swindows(ks->geom.s);
         // stage 1: about one inserted s-mer per 32 bits (4 per 128-bit block), 1 KiB .. 128 KiB of LDS
@@ -546,7 +560,7 @@ int mf_reads_from_fastq(const char *path, int device, mf_reads **out)
     std::vector<char> buf; std::string err;
     if (!slurp_file(path, buf, err)) return fail(MF_E_IO, "%s", err.c_str());
     std::vector<FqRec> recs; parse_fastq(buf.data(), buf.size(), recs);
-    PackedHost P; pack_records(recs.data(), recs.size(), (int)std::thread::hardware_concurrency(), P);
+    PackedHost P; pack_records(recs.data(), recs.size(), host_threads(), P);
     return reads_upload(P.words.data(), P.n_words, true, P.offsets.data(), recs.size(), P.offsets.back(), P.uniform_len,
                         P.npos.data(), P.npos.size(), device, out);
 }
@@ -562,7 +576,7 @@ int mf_reads_synth(uint64_t n_reads, uint32_t read_len, uint64_t seed, const cha
     SynthOut S;
     std::string err;
     if (!synth_reads(n_reads, read_len, seed, B, mito_ppm, sub_ppm, n_read_ppm, n_base_ppm,
-                     (int)std::thread::hardware_concurrency(), S, err)) return fail(MF_E_ARG, "%s", err.c_str());
+                     host_threads(), S, err)) return fail(MF_E_ARG, "%s", err.c_str());
     int rc = reads_upload(S.words.data(), S.n_words, true, nullptr, n_reads, n_reads * (uint64_t)read_len, read_len,
                           S.npos.data(), S.npos.size(), device, out);
     if (rc) return rc;
@@ -602,6 +616,10 @@ static uint64_t algorithmic_bytes(const ReadsView &V) { return (2 * V.total_base
 // screen, mark, exact or finish): each pair reads that dispatch's own duration and the streams carry no extra packets.
 // `overlap`: a threshold-1 pass may leave its finish kernel running on the second stream (filter_common joins the streams).
 // `more`: another pass of the same call follows (its screen kernel is what this pass's later kernels run beside).
+// where the kernels of a pass leave their tallies: the buffer set's pinned block -- or, when the caller wants every pass's
+// tally (mf_filter_resident_passes), a block of that pass's own
+static unsigned long long *tally_of(mf_reads *r, int set) { return r->tally_override ? r->tally_override : r->d_counters[set]; }
+
 static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mode, bool count_all, DevCtx *ctx, hipEvent_t *ev, bool overlap,
                         bool more = false)
 {
@@ -612,7 +630,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     if (ev) { for (int i = 0; i < 3; i++) tm[i] = KernelTiming{ev[2 * i], ev[2 * i + 1]}; t0 = &tm[0]; t1 = &tm[1]; t2 = &tm[2]; }
     const int p = r->cur;
     if (S.prot) {          // protein-space set: one kernel translates and probes every read (no screen exists in residue space)
-        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters[p], n_cu, st, t2));
+        HIPCHK(launch_pfilter(r->v, S, thr, count_all, r->d_bits[p], r->d_hits, tally_of(r, p), n_cu, st, t2));
         return MF_OK;
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
@@ -640,9 +658,11 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         const KernelTiming *ts = t0 ? t0 : (two ? &scr_done : nullptr);
         HIPCHK(launch_screen(r->v, S, r->d_recs[q], r->d_rec_counts[q], n_cu, ss, ts, r->d_bits[q], ((r->v.n_reads + 31) / 32 + 3) / 4));
         if (two) { if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], ss)); HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0)); }
+#ifdef MF_DEBUG_KNOBS              // timing experiment: the pass without its finish kernels (WRONG result bits)
         static const uint32_t nofin = env_u32("MF_NO_FINISH", 0);
         if (nofin) { if (two) HIPCHK(hipEventRecord(r->ev_finish[q], sf)); } else
-        HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], r->d_counters[q], n_cu, sf, t2, two ? r->ev_finish[q] : nullptr));
+#endif
+        HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], tally_of(r, q), n_cu, sf, t2, two ? r->ev_finish[q] : nullptr));
         r->sample_pass = true;
         r->cur = q;
         return MF_OK;
@@ -672,7 +692,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         if (t0) HIPCHK(hipEventRecord(r->ev_screen[q], ss));
         HIPCHK(hipStreamWaitEvent(sf, r->ev_screen[q], 0));
         HIPCHK(launch_mark(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_cand[q], n_cu, sf, t1));
-        HIPCHK(launch_exact(r->v, S, r->d_cand[q], thr, false, r->d_bits[q], nullptr, r->d_counters[q], n_cu, sf, t2, more || exact_co, r->ev_finish[q]));
+        HIPCHK(launch_exact(r->v, S, r->d_cand[q], thr, false, r->d_bits[q], nullptr, tally_of(r, q), n_cu, sf, t2, more || exact_co, r->ev_finish[q]));
         r->cur = q;
         return MF_OK;
     }
@@ -680,12 +700,12 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     if (screened && !r->cand_clean[0]) { HIPCHK(hipMemsetAsync(r->d_cand[0], 0, r->bitmap_bytes, st)); r->cand_clean[0] = true; }
     if (screened) HIPCHK(launch_screen(r->v, S, r->d_recs[0], r->d_rec_counts[0], n_cu, st, t0));
     if (screened) HIPCHK(launch_mark(r->v, S, r->d_recs[0], r->d_rec_counts[0], r->d_cand[0], n_cu, st, t1));
-    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand[0] : nullptr, thr, count_all, r->d_bits[p], r->d_hits, r->d_counters[p], n_cu, st, t2));
+    HIPCHK(launch_exact(r->v, S, screened ? r->d_cand[0] : nullptr, thr, count_all, r->d_bits[p], r->d_hits, tally_of(r, p), n_cu, st, t2));
     return MF_OK;
 }
 
 int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, int mode, uint32_t *out_bits,
-                  uint32_t *hits_out, int steps, mf_filter_stats_t *stats)
+                  uint32_t *hits_out, int steps, mf_filter_stats_t *stats, uint64_t *pass_per_step)
 {
     mf_kmerset *ks = const_cast<mf_kmerset *>(ks_);
     mf_reads *r = const_cast<mf_reads *>(reads_);
@@ -718,7 +738,17 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     lap("events");
     HIPCHK(hipEventRecord(e_begin, st));
     HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
+    // every pass's own tally block when the caller wants them all (tests: a buffer-set race that corrupted only the middle passes
+    // of a pipelined call would not show in the last pass's tally)
+    constexpr size_t TALLY_WORDS = 2 * (size_t)EXACT_MAX_GRID * 2;
+    struct PinnedTmp { unsigned long long *p = nullptr; ~PinnedTmp() { if (p) (void)hipHostFree(p); } } all_tallies;
+    if (pass_per_step) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&all_tallies.p), (size_t)steps * TALLY_WORDS * 8, hipHostMallocDefault));
+        memset(all_tallies.p, 0, (size_t)steps * TALLY_WORDS * 8);
+    }
+    struct OverrideReset { mf_reads *r; ~OverrideReset() { r->tally_override = nullptr; } } override_reset{r};
     for (int i = 0; i < steps; i++) {
+        if (pass_per_step) r->tally_override = all_tallies.p + (size_t)i * TALLY_WORDS;
         rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, n_sampled && i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true, i + 1 < steps);
         if (rc) return rc;
     }
@@ -727,7 +757,7 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     for (int i = 0; i < NSETS; i++) HIPCHK(hipStreamWaitEvent(st, r->ev_finish[i], 0));
     HIPCHK(hipEventRecord(e_end, st));
     const bool two_halves = r->sample_pass;
-    const unsigned long long *part = r->d_counters[r->cur];          // pinned host memory, complete once the stream is
+    const unsigned long long *part = pass_per_step ? all_tallies.p + (size_t)(steps - 1) * TALLY_WORDS : r->d_counters[r->cur];          // pinned host memory, complete once the stream is
     if (out_bits) HIPCHK(hipMemcpyAsync(out_bits, r->d_bits[r->cur], ((r->v.n_reads + 31) / 32) * 4, hipMemcpyDeviceToHost, st));
     if (hits_out && r->v.n_reads) HIPCHK(hipMemcpyAsync(hits_out, r->d_hits, r->v.n_reads * 4, hipMemcpyDeviceToHost, st));
     lap("copies");
@@ -735,6 +765,13 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     lap("synced");
     unsigned long long cnt[2] = {0, 0};
     for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
+    if (pass_per_step)
+        for (int s = 0; s < steps; s++) {
+            const unsigned long long *q = all_tallies.p + (size_t)s * TALLY_WORDS;
+            uint64_t n = 0;
+            for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) n += q[2 * i];
+            pass_per_step[s] = n;
+        }
     static const bool adapt = env_u32("MF_ADAPT", 1) != 0;          // (MF_ADAPT=0: measurements of the sample pass on bait-rich input)
     if (adapt && !T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && r->v.n_reads >= 100000) {
         // work items per read: ~0.025 at 0.5 % bait reads, 0.4 at 10 %, 0.8 at 20 %.  (Since a run start is left to the first lane that
@@ -781,6 +818,13 @@ int mf_filter_resident(const mf_kmerset *ks, const mf_reads *reads, uint32_t thr
                        mf_filter_stats_t *stats)
 {
     return filter_common(ks, reads, threshold, mode, nullptr, nullptr, steps, stats);
+}
+
+int mf_filter_resident_passes(const mf_kmerset *ks, const mf_reads *reads, uint32_t threshold, int mode, int steps,
+                              uint64_t *n_pass_per_step, mf_filter_stats_t *stats)
+{
+    if (!n_pass_per_step) return fail(MF_E_ARG, "n_pass_per_step is NULL");
+    return filter_common(ks, reads, threshold, mode, nullptr, nullptr, steps, stats, n_pass_per_step);
 }
 
 int mf_filter_packed(const mf_kmerset *ks, int device, const uint32_t *words, const uint64_t *offsets, uint64_t n_reads,
@@ -834,8 +878,10 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     // and every device is served by TWO workers, each with its own stream pair and refillable device-side read set
     // (steady-state batches do not touch the allocator): while one worker's batch is in its kernels and read-back, the
     // other's is being copied up on its own stream -- and the readers, inflaters and packers of later batches run all along.
+    // (for the time of this call only: other users of the host code in this process keep ordinary memory)
     set_dma_allocator([](size_t bytes) -> void * { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess ? p : nullptr; },
                       [](void *p) { (void)hipHostFree(p); });
+    struct DmaScope { ~DmaScope() { set_dma_allocator(nullptr, nullptr); } } dma_scope;
     const int lanes = (int)env_u32("MF_WORKERS_PER_DEVICE", 2) < 1 ? 1 : (int)env_u32("MF_WORKERS_PER_DEVICE", 2);
     const int n_workers = n_devices * lanes;
     std::vector<mf_reads *> arena((size_t)n_workers, nullptr);

@@ -50,6 +50,7 @@ struct mf_reads {
     bool prefer_split = false;
     bool split_serial = false;      // ... and with very many candidates (> 5 % of the reads) its kernels do not fit beside the next screen: one stream
     int cur = 0;
+    unsigned long long *tally_override = nullptr;       // set per pass by filter_common when every pass's tally is wanted
     size_t bitmap_bytes = 0;
     // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
     size_t cap_words = 0, cap_offsets = 0, cap_npos = 0, cap_bitmap = 0, cap_recs = 0, cap_rec_counts = 0, cap_hits = 0, cap_npos_blk = 0;
@@ -65,4 +66,4 @@ int reads_reserve(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, u
 int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, uint64_t total_bases, uint32_t uniform_len, uint64_t n_npos, DevCtx *ctx);
 // one or more passes of the filter over a resident read set; out_bits / hits_out may be null (the result stays in r->d_bits[r->cur])
 int filter_common(const mf_kmerset *ks, const mf_reads *reads, uint32_t thr, int mode, uint32_t *out_bits, uint32_t *hits_out, int steps,
-                  mf_filter_stats_t *stats);
+                  mf_filter_stats_t *stats, uint64_t *pass_per_step = nullptr);

@@ -1,7 +1,7 @@
 // Host-side parsing and packing for libmitofilter_hip.  See mf_host.h.
 #include "mf_host.h"
 #include <mutex>
-#include <unordered_set>
+#include <unordered_map>
 #include "mf_kernels_cfg.h"
 
 #include <algorithm>
@@ -368,7 +368,7 @@ void pack_records(const FqRec *recs, uint64_t count, int threads, PackedHost &ou
 static std::mutex g_dma_mu;
 static void *(*g_dma_alloc)(size_t) = nullptr;
 static void (*g_dma_release)(void *) = nullptr;
-static std::unordered_set<void *> g_dma_blocks;
+static std::unordered_map<void *, void (*)(void *)> g_dma_blocks;      // block -> how to release it (the allocator may have been taken away since)
 
 void set_dma_allocator(void *(*alloc)(size_t), void (*release)(void *))
 {
@@ -377,19 +377,24 @@ void set_dma_allocator(void *(*alloc)(size_t), void (*release)(void *))
 }
 void *dma_block_alloc(size_t bytes)
 {
-    std::lock_guard<std::mutex> lk(g_dma_mu);
-    if (!g_dma_alloc) return nullptr;
-    void *p = g_dma_alloc(bytes);
-    if (p) g_dma_blocks.insert(p);
+    void *(*alloc)(size_t); void (*release)(void *);
+    { std::lock_guard<std::mutex> lk(g_dma_mu); alloc = g_dma_alloc; release = g_dma_release; }
+    if (!alloc) return nullptr;
+    void *p = alloc(bytes);                         // (pinning memory takes a while: not under the lock)
+    if (p) { std::lock_guard<std::mutex> lk(g_dma_mu); g_dma_blocks.emplace(p, release); }
     return p;
 }
 bool dma_block_free(void *p)
 {
-    std::lock_guard<std::mutex> lk(g_dma_mu);
-    auto it = g_dma_blocks.find(p);
-    if (it == g_dma_blocks.end()) return false;
-    g_dma_blocks.erase(it);
-    if (g_dma_release) g_dma_release(p);
+    void (*release)(void *) = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_dma_mu);
+        auto it = g_dma_blocks.find(p);
+        if (it == g_dma_blocks.end()) return false;
+        release = it->second;
+        g_dma_blocks.erase(it);
+    }
+    if (release) release(p);
     return true;
 }
 

@@ -78,7 +78,7 @@ template <class T> struct DefaultInitAlloc : std::allocator<T> {
 // Buffers the device reads by DMA (packed words, offsets): when the GPU library has registered a pinned-memory allocator
 // (hipHostMalloc; mf_api.cpp does, the CPU-only test builds do not) their large blocks come from it, so that the
 // host-to-device copy of a batch is an asynchronous DMA straight from where the packer wrote, not a staged pageable copy.
-void set_dma_allocator(void *(*alloc)(size_t), void (*release)(void *));
+void set_dma_allocator(void *(*alloc)(size_t), void (*release)(void *));     // (nullptr, nullptr): none; blocks handed out before stay valid
 void *dma_block_alloc(size_t bytes);        // nullptr: no allocator registered (or it failed) -- use the ordinary one
 bool dma_block_free(void *p);               // false: p is not one of ours
 template <class T> struct DmaInitAlloc : DefaultInitAlloc<T> {
@@ -89,7 +89,8 @@ template <class T> struct DmaInitAlloc : DefaultInitAlloc<T> {
         if (bytes >= ((size_t)4 << 20)) { if (void *p = dma_block_alloc(bytes)) return static_cast<T *>(p); }
         return DefaultInitAlloc<T>::allocate(n);
     }
-    void deallocate(T *p, size_t n) noexcept { if (!dma_block_free(p)) DefaultInitAlloc<T>::deallocate(p, n); }
+    // (only blocks of at least 4 MiB can be DMA blocks: everything smaller skips the lock and the lookup)
+    void deallocate(T *p, size_t n) noexcept { if (n * sizeof(T) < ((size_t)4 << 20) || !dma_block_free(p)) DefaultInitAlloc<T>::deallocate(p, n); }
 };
 using WordVec = std::vector<uint32_t, DmaInitAlloc<uint32_t>>;
 using U64Vec = std::vector<uint64_t, DmaInitAlloc<uint64_t>>;

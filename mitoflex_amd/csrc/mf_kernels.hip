@@ -624,30 +624,32 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
     const uint64_t wc_step = (uint64_t)gridDim.x * WAVES;
     // a lane owns WC_PER_LANE consecutive bitmap words (the buffers are padded past n_bw)
     // (candidate words are cleared as they are consumed, so the next pass needs no memset)
-    auto load_cw = [&](uint64_t wc, uint32_t (&w)[WC_PER_LANE]) {
+    // (the four words travel as a uint4 by value: as an array handed to the lambda by reference they lived in scratch memory)
+    static_assert(WC_PER_LANE == 4, "a lane's words are a uint4");
+    auto load_cw = [&](uint64_t wc) -> uint4 {
         const uint64_t wi = wc * WC_WORDS + (uint64_t)lane * WC_PER_LANE;
+        uint32_t w[WC_PER_LANE];
 #pragma unroll
         for (int j = 0; j < WC_PER_LANE; j++) {
             const bool in = wc < n_wc && wi + j < n_bw;
             w[j] = in ? (cand ? cand[wi + j] : 0xFFFFFFFFu) : 0u;
             if (in && cand && w[j]) cand[wi + j] = 0;
         }
+        return make_uint4(w[0], w[1], w[2], w[3]);
     };
-    uint32_t cw_next[WC_PER_LANE];
-    load_cw((uint64_t)blockIdx.x * WAVES + wid, cw_next);
+    uint4 cw_next = load_cw((uint64_t)blockIdx.x * WAVES + wid);
     for (uint64_t wc = (uint64_t)blockIdx.x * WAVES + wid; wc < n_wc; wc += wc_step) {
         const uint64_t wbase = wc * WC_WORDS;
-        uint32_t cw[WC_PER_LANE], pre[WC_PER_LANE + 1];
+        uint32_t cw[WC_PER_LANE] = {cw_next.x, cw_next.y, cw_next.z, cw_next.w}, pre[WC_PER_LANE + 1];
         pre[0] = 0;
 #pragma unroll
         for (int j = 0; j < WC_PER_LANE; j++) {
-            cw[j] = cw_next[j];
             const uint64_t wi = wbase + (uint64_t)lane * WC_PER_LANE + j;
             if (wi < n_bw) { const uint64_t rem = R.n_reads - wi * 32; if (rem < 32) cw[j] &= (1u << rem) - 1; }
             pre[j + 1] = pre[j] + __popc(cw[j]);
             my_res[lane * WC_PER_LANE + j] = 0;
         }
-        load_cw(wc + wc_step, cw_next);                                      // next chunk's words, a whole chunk early
+        cw_next = load_cw(wc + wc_step);                                      // next chunk's words, a whole chunk early
         tot_cand += pre[WC_PER_LANE];
         // inclusive scan of the per-lane candidate counts
         uint32_t incl = pre[WC_PER_LANE];
@@ -1400,7 +1402,11 @@ hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *r
                          unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm, hipEvent_t done)
 {
     const uint64_t lists = screen_grid_for(R, n_cu, S.stride);
-    if (lists == 0) return hipSuccess;
+    if (lists == 0) {               // (an empty read set) nothing to settle: the tallies read zero and `done` still completes, as in launch_exact
+        (void)hipMemsetAsync(partials, 0, 2 * EXACT_MAX_GRID * 16, st);
+        if (done) (void)hipEventRecord(done, st);
+        return hipGetLastError();
+    }
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, S.stride);
     const ScreenRec *rc = static_cast<const ScreenRec *>(recs);
     static const bool time_phase1 = getenv("MF_TIME_PHASE1") != nullptr;          // the one event pair goes to phase 0 unless asked otherwise

@@ -183,14 +183,15 @@ public:
                 }
             }
             if (full || eof_) break;
-            // a pipe or stdin whose producer has nothing more right now: hand over the complete records (see next_stream_indexed)
+            // a pipe or stdin whose producer has had nothing more for a while: hand over the complete records (see read_some)
             if (short_read && !off.empty()) { cut = rec_end; full = true; break; }
             if (stopped()) return false;
             if (!b.reserve(b.len + blk)) { err = "out of memory"; return false; }
             bool failed = false;
+            idle_ = false;
             const size_t got = read_some(b.text + b.len, blk, err, failed);
             if (failed) return false;
-            short_read = !gz_ && !gzmap_ && got > 0 && got < blk;
+            short_read = idle_;
             b.len += got;
             if (got == 0) eof_ = true;
         }
@@ -304,15 +305,19 @@ private:
             return (size_t)n;
         }
         if (gz_) { const int n = gzread(g_, dst, (unsigned)std::min<size_t>(want, (size_t)1 << 30)); if (n < 0) { err = "gzip read error in " + path_; failed = true; return 0; } return (size_t)n; }
-        // plain stream (pipe, stdin; the stream is unbuffered): read() returns what a slow producer has written so far instead
-        // of blocking until `want` bytes are there, so the stop flag is looked at again in good time
+        // plain stream (pipe, stdin; the stream is unbuffered).  A pipe hands over at most 64 KiB per read(): keep reading until the
+        // block is full, so that batch boundaries do not depend on how the producer's writes happen to arrive -- but if the
+        // producer has had nothing for 50 ms, return what is there (idle_ set): the reference works line by line, and with a -t
+        // budget it may never need the rest of a slow stream.  The poll also lets the stop flag be seen in good time.
+        size_t total = 0;
         for (;;) {
             struct pollfd pfd; pfd.fd = fileno(f_); pfd.events = POLLIN; pfd.revents = 0;
             const int pr = poll(&pfd, 1, 50);                 // a blocked read() cannot be told to stop; a poll that times out can
             if (stopped()) { failed = true; return 0; }       // (no error text: the pipeline is winding down for its own reasons)
-            if (pr == 0) continue;
-            const ssize_t n = ::read(fileno(f_), dst, std::min<size_t>(want, (size_t)1 << 30));
-            if (n >= 0) return (size_t)n;
+            if (pr == 0) { if (total) { idle_ = true; return total; } continue; }
+            const ssize_t n = ::read(fileno(f_), dst + total, std::min<size_t>(want - total, (size_t)1 << 30));
+            if (n > 0) { total += (size_t)n; if (total == want) return total; continue; }
+            if (n == 0) return total;                         // end of the stream (the next call returns 0)
             if (errno != EINTR && errno != EAGAIN) { err = "read error in " + path_; failed = true; return 0; }
         }
     }
@@ -332,13 +337,14 @@ private:
                 const size_t want = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)1 << 16, target - b.len));
                 if (!b.reserve(b.len + want)) { err = "out of memory"; return false; }
                 bool failed = false;
+                idle_ = false;
                 const size_t got = read_some(b.text + b.len, want, err, failed);
                 if (failed) return false;
                 b.len += got;
                 if (got == 0) eof_ = true;
-                // the producer has nothing more right now: hand over the records that are complete instead of waiting for a
+                // the producer has had nothing more for a while: hand over the records that are complete instead of waiting for a
                 // whole batch (the reference works line by line -- with a -t budget it may never need the rest)
-                if (live && got < want && got > 0) { short_read = true; break; }
+                if (live && idle_ && got > 0) { short_read = true; break; }
             }
             build_index(b.text, b.len, eof_, ix);
             if (ix.n_records >= max_records || eof_ || (short_read && ix.n_records > 0)) break;
@@ -374,14 +380,16 @@ private:
     LineIndex map_ix_; bool indexed_ = false;
     uint64_t rec_pos_ = 0;
     double rec_bytes_est_ = 350.0;                      // bytes per record seen so far (stream mode read-ahead)
+    bool idle_ = false;                                 // read_some returned early because a live producer had nothing for a while
 };
 
 struct PairBatch {
     uint64_t index = 0, n = 0;
     std::shared_ptr<MateBatch> mate[2];
+    uint64_t first[2] = {0, 0};            // the pair batch holds records first[m] .. first[m] + n - 1 of mate[m]
     PackedHost packed[2];
     std::vector<uint8_t> keep;
-    void recycle() { mate[0].reset(); mate[1].reset(); keep.clear(); index = n = 0; }
+    void recycle() { mate[0].reset(); mate[1].reset(); keep.clear(); index = n = 0; first[0] = first[1] = 0; }
 };
 using PairPtr = std::shared_ptr<PairBatch>;
 
@@ -438,28 +446,32 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
             q_read[m].finish();
         });
 
-    // ---- zip mates, pack, deal to devices (whole pairs stay together)
+    // ---- zip mates, pack, deal to devices (whole pairs stay together).  Mates are paired BY RECORD COUNT: the batches of the two
+    // readers need not be of equal size (a pipe whose producer pauses hands over what it has), so what is left of the longer
+    // batch is paired with the other mate's next one.  A mate has run out only when its reader has (zip semantics: the shorter
+    // file bounds the pair count, filter/filter_bin/src/main.rs:214).
     threads.emplace_back([&] {
         uint64_t idx = 0;
+        std::shared_ptr<MateBatch> cur[2]; uint64_t pos[2] = {0, 0};
         for (;;) {
-            auto pb = pair_pool->get();
             bool ok = true;
-            for (int m = 0; m < nm; m++) ok = q_read[m].pop(pb->mate[m]) && ok;
-            if (!ok) break;                               // the shorter file bounds the pair count (zip semantics)
-            pb->n = pb->mate[0]->recs.size();
-            if (nm == 2 && pb->mate[1]->recs.size() < pb->n) pb->n = pb->mate[1]->recs.size();
+            for (int m = 0; m < nm && ok; m++)
+                while (ok && (!cur[m] || pos[m] == cur[m]->recs.size())) { cur[m].reset(); pos[m] = 0; ok = q_read[m].pop(cur[m]); }
+            if (!ok) break;
+            auto pb = pair_pool->get();
+            pb->n = cur[0]->recs.size() - pos[0];
+            if (nm == 2 && cur[1]->recs.size() - pos[1] < pb->n) pb->n = cur[1]->recs.size() - pos[1];
+            for (int m = 0; m < nm; m++) { pb->mate[m] = cur[m]; pb->first[m] = pos[m]; pos[m] += pb->n; }
             pb->index = idx;
             const uint64_t t0 = now_us();
             if (nm == 2) {
-                std::thread t([&] { pack_records(pb->mate[1]->recs.data(), pb->n, pack_threads > 1 ? pack_threads / 2 : 1, pb->packed[1]); });
-                pack_records(pb->mate[0]->recs.data(), pb->n, pack_threads > 1 ? pack_threads - pack_threads / 2 : 1, pb->packed[0]);
+                std::thread t([&] { pack_records(pb->mate[1]->recs.data() + pb->first[1], pb->n, pack_threads > 1 ? pack_threads / 2 : 1, pb->packed[1]); });
+                pack_records(pb->mate[0]->recs.data() + pb->first[0], pb->n, pack_threads > 1 ? pack_threads - pack_threads / 2 : 1, pb->packed[0]);
                 t.join();
-            } else pack_records(pb->mate[0]->recs.data(), pb->n, pack_threads, pb->packed[0]);
+            } else pack_records(pb->mate[0]->recs.data() + pb->first[0], pb->n, pack_threads, pb->packed[0]);
             t_pack += now_us() - t0;
-            const bool last = nm == 2 && pb->mate[0]->recs.size() != pb->mate[1]->recs.size();
             if (!q_dev[idx % n_devices]->push(pb)) break;
             idx++;
-            if (last) break;                              // mate files of different length: stop at the shorter
         }
         winding_down = true;                              // readers may still be producing past the end of the shorter file
         for (auto &q : q_read) q.abort();
@@ -516,7 +528,7 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
                     const uint64_t t0w = now_us();
                     struct Acc { std::atomic<uint64_t> &a; uint64_t t0; std::function<uint64_t()> now; ~Acc() { a += now() - t0; } } acc{t_write[m], t0w, now_us};
                     PairPtr cur = pending.begin()->second; pending.erase(pending.begin()); next++;
-                    const FqRec *recs = cur->mate[m]->recs.data();
+                    const FqRec *recs = cur->mate[m]->recs.data() + cur->first[m];
                     for (uint64_t i = 0; i < cur->n && ok; i++) {
                         if (!cur->keep[i]) continue;
                         const FqRec &r = recs[i];                 // header / seq / "+" / qual (filter_bin main.rs:261-268)
@@ -597,9 +609,10 @@ bool utf8_ok(const char *p, size_t n)
 struct QualBatch {
     uint64_t index = 0, n = 0;
     std::shared_ptr<MateBatch> mate[2];
+    uint64_t first[2] = {0, 0};            // records first[m] .. of mate[m] (mates are paired by record count, see run_fastq_pipeline)
     std::vector<uint8_t> keep;
     bool last = false;
-    void recycle() { mate[0].reset(); mate[1].reset(); keep.clear(); index = n = 0; last = false; }
+    void recycle() { mate[0].reset(); mate[1].reset(); keep.clear(); index = n = 0; last = false; first[0] = first[1] = 0; }
 };
 
 // fn(lo, hi) over [0, n) cut into one contiguous chunk per worker
@@ -662,14 +675,17 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
         const uint64_t L = P.end - P.start;
         std::vector<uint32_t> nc[2], bc[2]; std::vector<uint64_t> hs;      // per-batch scratch, capacity kept
         std::vector<QualSpan, DefaultInitAlloc<QualSpan>> sp;
+        std::shared_ptr<MateBatch> cur[2]; uint64_t pos[2] = {0, 0};
         while (!stop) {
-            auto qb = qual_pool->get();
             bool ok = true;
-            for (int m = 0; m < nm; m++) ok = q_read[m].pop(qb->mate[m]) && ok;
-            if (!ok) break;
-            uint64_t n = qb->mate[0]->recs.size();
-            if (nm == 2 && qb->mate[1]->recs.size() < n) n = qb->mate[1]->recs.size();
-            const bool short_mate = nm == 2 && qb->mate[0]->recs.size() != qb->mate[1]->recs.size();
+            for (int m = 0; m < nm && ok; m++)
+                while (ok && (!cur[m] || pos[m] == cur[m]->recs.size())) { cur[m].reset(); pos[m] = 0; ok = q_read[m].pop(cur[m]); }
+            if (!ok) break;                                   // a reader has run out: the shorter file bounds the pair count
+            auto qb = qual_pool->get();
+            uint64_t n = cur[0]->recs.size() - pos[0];
+            if (nm == 2 && cur[1]->recs.size() - pos[1] < n) n = cur[1]->recs.size() - pos[1];
+            for (int m = 0; m < nm; m++) { qb->mate[m] = cur[m]; qb->first[m] = pos[m]; pos[m] += n; }
+            FqRec *const mrec[2] = {qb->mate[0]->recs.data() + qb->first[0], nm == 2 ? qb->mate[1]->recs.data() + qb->first[1] : nullptr};
             // the cut (main.rs:222-233, 291-299) and the first record at which the reference would panic:
             // `drain(..start)` past the end of a string, or a line that is not valid UTF-8
             // Records are independent here, so the batch is cut into chunks; each chunk stops at its first
@@ -680,14 +696,14 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                 for (uint64_t i = lo; i < hi; i++) {
                     bool bad = false;
                     for (int m = 0; m < nm && !bad; m++) {
-                        const FqRec &r = qb->mate[m]->recs[i];
+                        const FqRec &r = mrec[m][i];
                         // header, sequence and quality are unwrapped (main.rs:214-216, 287-289) and panic on invalid UTF-8; the
                         // '+' line is bound to `_` and never unwrapped: lines() yields an Err for it and carries on
                         bad = !utf8_ok(r.h, r.hl) || !utf8_ok(r.s, r.sl) || !utf8_ok(r.q, r.ql);
                     }
                     if (!bad && P.start) {
-                        for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].sl;      // seq1, seq2 first
-                        for (int m = 0; m < nm; m++) bad = bad || P.start > qb->mate[m]->recs[i].ql;      // then qua1, qua2
+                        for (int m = 0; m < nm; m++) bad = bad || P.start > mrec[m][i].sl;      // seq1, seq2 first
+                        for (int m = 0; m < nm; m++) bad = bad || P.start > mrec[m][i].ql;      // then qua1, qua2
                     }
                     if (bad) {
                         uint64_t cur = first_bad.load();
@@ -695,7 +711,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                         return;
                     }
                     for (int m = 0; m < nm; m++) {
-                        FqRec &r = qb->mate[m]->recs[i];
+                        FqRec &r = mrec[m][i];
                         if (P.start) { r.s += P.start; r.sl -= (uint32_t)P.start; r.q += P.start; r.ql -= (uint32_t)P.start; }
                         if (P.end) { if (r.sl > L) r.sl = (uint32_t)L; if (r.ql > L) r.ql = (uint32_t)L; }
                     }
@@ -708,7 +724,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             // GPU: counts (and hashes of mate 1 when deduplicating)
             if (!P.trunc && n_ok) {
                 for (int m = 0; m < nm && ok; m++) {
-                    const RecVec &recs = qb->mate[m]->recs;
+                    const FqRec *recs = mrec[m];
                     const char *base = recs[0].h, *endp = recs[n_ok - 1].q + recs[n_ok - 1].ql;
                     if ((size_t)(endp - base) >= 0xFFFFFFF0ull) { set_err(MF_E_ARG, "batch larger than 4 GiB: lower MF_BATCH_READS"); ok = false; break; }
                     sp.resize(n_ok);
@@ -729,7 +745,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             const uint64_t td0 = now_us();
             qb->keep.assign(n ? n : 1, 0);
             for (uint64_t i = 0; i < n_ok; i++) {
-                const FqRec &r1 = qb->mate[0]->recs[i];
+                const FqRec &r1 = mrec[0][i];
                 if (P.dedup && !P.trunc && i + 16 < n_ok) seen.prefetch(hs[i + 16]);
                 if (!P.trunc) {
                     bool drop = nc[0][i] > P.ns || (nm == 2 && nc[1][i] > P.ns);                       // main.rs:236, 302
@@ -749,7 +765,6 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             t_decide += now_us() - td0;
             qb->n = n_ok; qb->index = idx++;
             if (panicked) { stats.panicked = true; stop = true; }
-            if (short_mate) stop = true;
             for (int m = 0; m < nm; m++) if (!q_write[m].push(qb)) { stop = true; break; }
         }
         winding_down = true;
@@ -774,7 +789,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             while (ok && q_write[m].pop(qb)) {
                 const uint64_t tw0 = now_us();
                 struct Acc { std::atomic<uint64_t> &a; uint64_t t0; std::function<uint64_t()> now; ~Acc() { a += now() - t0; } } acc{t_write[m], tw0, now_us};
-                const FqRec *recs = qb->mate[m]->recs.data();
+                const FqRec *recs = qb->mate[m]->recs.data() + qb->first[m];
                 for (uint64_t i = 0; i < qb->n && ok; i++) {
                     if (!qb->keep[i]) continue;
                     const FqRec &r = recs[i];

@@ -28,7 +28,7 @@ EXPORTS = (
     "mf_kmerset_build_from_fasta", "mf_kmerset_build_from_text", "mf_kmerset_build_protein_from_fasta",
     "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
-    "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_packed",
+    "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_resident_passes", "mf_filter_packed",
     "mf_filter_fastq_files", "mf_qualfilter_files",
 )
 
@@ -95,6 +95,7 @@ def load(path: Optional[str] = None):
     L.mf_reads_free.argtypes = [vp]
     L.mf_filter.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp, C.POINTER(FilterStats)]
     L.mf_filter_resident.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.POINTER(FilterStats)]
+    L.mf_filter_resident_passes.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.POINTER(FilterStats)]
     L.mf_filter_packed.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, vp]
     L.mf_filter_fastq_files.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
                                         C.c_int, u64p, u64p]
@@ -266,6 +267,14 @@ def filter_resident(ks: KmerSet, reads: Reads, threshold: int = 1, mode: int = M
     st = FilterStats()
     _chk(load().mf_filter_resident(ks._h, reads._h, threshold, mode, steps, C.byref(st)))
     return st
+
+
+def filter_resident_passes(ks: KmerSet, reads: Reads, threshold: int = 1, mode: int = MODE_SCREENED, steps: int = 1):
+    """`steps` passes back to back; -> (passing reads of every pass, stats)"""
+    st = FilterStats()
+    per = np.zeros(steps, dtype=np.uint64)
+    _chk(load().mf_filter_resident_passes(ks._h, reads._h, threshold, mode, steps, per.ctypes.data, C.byref(st)))
+    return per, st
 
 
 def filter_packed(ks: KmerSet, words, offsets, npos, threshold: int = 1, device: int = 0) -> np.ndarray:

@@ -385,7 +385,7 @@ def test_bench_ranks_under_torchrun(tmp_path, world):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
                         "--prewarm-ms", "5", "--reads", str(reads), "--no-exhaustive", "--cpu-sample", "0", "--e2e-pairs", "0"],
-                       capture_output=True, timeout=300, cwd=str(tmp_path))
+                       capture_output=True, timeout=300, cwd=str(tmp_path), env=dict(os.environ, MF_BENCH_SHARE_GPU="1"))
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -393,6 +393,24 @@ def test_bench_ranks_under_torchrun(tmp_path, world):
     assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["extra"]["reads_per_gpu"] == reads and 0.003 < d["extra"]["passed"] / reads < 0.008
     assert abs(d["value"] - world * reads * 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]        # whole-job rate over all ranks
+    # configs[3]: per-GPU figures beside the aggregate (the aggregate is priced on the slowest rank)
+    per, ms = d["extra"]["per_gpu_reads_per_s"], d["extra"]["per_rank_ms_per_step"]
+    assert len(per) == len(ms) == world and all(x > 0 for x in per)
+    assert abs(max(ms) - d["ms_per_step"]) < 1e-3 and sum(per) >= d["value"] * (1 - 1e-9)
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["whole_pass_frac"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus(tmp_path):
+    """outside tests, ranks are never wrapped onto one device silently"""
+    import subprocess
+    import sys
+    port = 27000 + os.getpid() % 2000
+    env = {k: v for k, v in os.environ.items() if k != "MF_BENCH_SHARE_GPU"}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--reads", "100000", "--no-exhaustive", "--cpu-sample", "0", "--e2e-pairs", "0"],
+                       capture_output=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert p.returncode != 0 and b"one rank per GPU" in p.stderr
 
 
 @pytest.mark.parametrize("k", [21, 31, 41])
@@ -414,6 +432,9 @@ def test_multi_pass_calls_match_oracle(mf, ol, bait_text, k):
             assert st.n_pass == want, (k, thr, steps)
             bits, _, st1 = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED)
             assert np.array_equal(bits, obits) and st1.n_pass == want, (k, thr, steps)
+        # every pass of a pipelined call, not only the last: each tallies into a block of its own
+        per, st = mf.filter_resident_passes(ks, reads, thr, mf.MODE_SCREENED, 7)
+        assert per.tolist() == [want] * 7 and st.n_pass == want, (k, thr, per.tolist())
 
 
 @pytest.mark.parametrize("kind", ["split", "serial", "split-co", "split-one-stream", "one-screen-stream"])

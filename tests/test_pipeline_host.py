@@ -106,3 +106,44 @@ def test_pipeline_many_devices(data, tmp_path, flags):
     p = subprocess.run([exe, str(d / "a_1.fq"), "-", o, "-", "250", "3", "either", "5"], capture_output=True)
     assert "Sanitizer" not in p.stderr.decode()
     assert p.stdout.decode().split() == [str(sum(s[:1] in ("A", "a") for s in s1)), str(len(s1))]
+
+
+@pytest.mark.parametrize("flags", [(), ("-fsanitize=thread",)], ids=["plain", "tsan"])
+def test_pipeline_mates_through_fifos(data, tmp_path, flags):
+    """Paired-end input from pipes: a pipe hands over at most 64 KiB per read() and a producer may pause, so the two readers'
+    batches differ in size.  Mates are paired by record count (what is left of the longer batch meets the other mate's next
+    one); a mate has run out only when its reader has.  One of the writers trickles its file in bursts with pauses longer
+    than the reader's idle time-out, so that batches are handed over early on that side only."""
+    import threading
+    import time
+    d, s1, s2 = data
+    exe = build(str(tmp_path), flags)
+    kept, total, w1, w2 = expected(d, s1, s2, False)
+    for slow in (None, 0, 1):
+        f1, f2 = str(tmp_path / "p1.fifo"), str(tmp_path / "p2.fifo")
+        for f in (f1, f2):
+            if os.path.exists(f):
+                os.unlink(f)
+            os.mkfifo(f)
+        def feed(src, dst, bursts):
+            data_ = open(src, "rb").read()
+            with open(dst, "wb", buffering=0) as w:
+                if not bursts:
+                    w.write(data_)
+                else:
+                    step = len(data_) // 5 + 1
+                    for a in range(0, len(data_), step):
+                        w.write(data_[a:a + step])
+                        time.sleep(0.12)
+        th = [threading.Thread(target=feed, args=(str(d / "a_1.fq"), f1, slow == 0)),
+              threading.Thread(target=feed, args=(str(d / "a_2.fq"), f2, slow == 1))]
+        for t in th:
+            t.start()
+        o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+        p = subprocess.run([exe, f1, f2, o1, o2, "1500", "4", "either"], capture_output=True, timeout=120)
+        for t in th:
+            t.join()
+        err = p.stderr.decode()
+        assert "Sanitizer" not in err and "runtime error" not in err, err[:2000]
+        assert p.stdout.decode().split() == [str(kept), str(total)], (slow, p.stdout, err[:500])
+        assert open(o1, newline="").read() == w1 and open(o2, newline="").read() == w2, slow

@@ -22,6 +22,7 @@ def _worker(rank, world, port, q):
     for i in range(5):
         got.append(r.allmax(float(rank * 10 + i)))       # max over ranks of a rank-dependent value
         r.barrier()
+    got.append(r.gather(float(rank) + 0.5))              # every rank's value, by rank (per-GPU figures of the bench line)
     r.close()
     q.put((rank, got))
 
@@ -39,7 +40,7 @@ def test_shm_rendezvous(world):
         p.join(60)
         assert p.exitcode == 0
     for r in range(world):
-        assert res[r] == [float((world - 1) * 10 + i) for i in range(5)]
+        assert res[r] == [float((world - 1) * 10 + i) for i in range(5)] + [[q + 0.5 for q in range(world)]]
     assert not any(n.startswith("mf_bench_%d_pytest%d" % (port, port)) for n in os.listdir("/dev/shm"))
 
 
@@ -48,3 +49,22 @@ def test_bench_workloads_follow_baseline_configs():
     import bench
     assert bench.READS_5GBP * 150 == pytest.approx(5e9, rel=1e-6) and bench.READS_5GBP % 2 == 0
     assert bench.READS_50GBP_8 * 8 * 150 == pytest.approx(50e9, rel=1e-6) and bench.READS_50GBP_8 % 2 == 0
+
+
+def test_bench_line_shapes():
+    """The three shapes of the bench line's roofline object (HBM-bound default, VALU-bound k < 28, multi-rank) as committed
+    under profiles/r03/ carry the fields the review asks for."""
+    import glob
+    import json
+    d = os.path.join(ROOT, "profiles", "r03")
+    shapes = {os.path.basename(f): json.load(open(f)) for f in glob.glob(os.path.join(d, "bench_shape_*.json"))}
+    if not shapes:
+        pytest.skip("profiles/r03/bench_shape_*.json not committed yet")
+    for name, line in shapes.items():
+        r = line["roofline"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_alone_frac", "whole_pass_frac"} <= set(r), name
+        assert len(line["extra"]["per_gpu_reads_per_s"]) == line["n_gpus"] == len(line["extra"]["per_rank_ms_per_step"]), name
+        if "k21" in name:
+            assert r["bound"] == "valu" and "hbm" in r and r["hbm"]["unit"] == "GB/s", name
+        else:
+            assert r["bound"] == "hbm" and r["unit"] == "GB/s", name
