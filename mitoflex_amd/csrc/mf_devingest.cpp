@@ -303,12 +303,6 @@ public:
         n_slabs_ = (n_chunks_ + cps_ - 1) / cps_;
         sym_cap_ = chunk_ * expand_ + 262144;
         DCHK(d_chunks_.need(n_chunks_, false)); DCHK(d_out_off_.need(n_chunks_, false)); DCHK(d_chain_.need(1, false));
-        DCHK(hipMemset(d_chunks_.p, 0, n_chunks_ * sizeof(GzChunk)));
-        DCHK(hipMemset(d_out_off_.p, 0xFF, n_chunks_ * sizeof(uint64_t)));
-        DCHK(hipHostMalloc((void **)&h_chain_, sizeof(GzChain), hipHostMallocDefault));
-        memset(h_chain_, 0, sizeof(GzChain));
-        h_chain_->cur_bit = (uint64_t)base_byte_ * 8;
-        DCHK(hipMemcpy(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice));
         {
             int dev = 0;
             DCHK(hipGetDevice(&dev));
@@ -318,6 +312,15 @@ public:
             sp_ = streams_->link; sr_ = streams_->rest;
             DCHK(hipEventCreateWithFlags(&ev_link_, hipEventDisableTiming));
         }
+        // (never the null stream: the CU-masked streams are blocking ones, a copy on the null stream would wait for every decode
+        // kernel in flight -- of the other mate's file too)
+        DCHK(hipMemsetAsync(d_chunks_.p, 0, n_chunks_ * sizeof(GzChunk), sr_));
+        DCHK(hipMemsetAsync(d_out_off_.p, 0xFF, n_chunks_ * sizeof(uint64_t), sr_));
+        DCHK(hipHostMalloc((void **)&h_chain_, sizeof(GzChain), hipHostMallocDefault));
+        memset(h_chain_, 0, sizeof(GzChain));
+        h_chain_->cur_bit = (uint64_t)base_byte_ * 8;
+        DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sr_));
+        DCHK(hipStreamSynchronize(sr_));
         for (auto &s : sym_) { DCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)); s.slab = ~0u; }
         h_chunks_.resize(n_chunks_);
         // the arena: a first guess at the size of the text (FASTQ compresses three- to fivefold); it is moved when it proves too small
@@ -380,16 +383,16 @@ public:
                 to_bit = (uint64_t)size_ * 8;             // behind the last chunk: the host decodes to the end of the member
             }
             // ---- decode across the gap on the host, with the window the chain left
-            DCHK(hipMemcpy(h_chain_->window, d_chain_.p->window, GZ_WINDOW, hipMemcpyDeviceToHost));
+            DCHK(hipMemcpyAsync(h_chain_->window, d_chain_.p->window, GZ_WINDOW, hipMemcpyDeviceToHost, sp)); DCHK(hipStreamSynchronize(sp));
             std::vector<uint8_t> bytes; uint64_t end_bit = 0; bool mend = false; std::string why;
             if (!inflate_gap(data_, size_, h_chain_->cur_bit, to_bit, h_chain_->window, h_chain_->wlen, bytes, end_bit, mend, why)) {
                 err = "gzip read error in " + path_ + ": " + why; return MF_E_FORMAT;
             }
-            gap_bytes_ += bytes.size();
+            gap_bytes_ += bytes.size(); n_gaps_++;
             TRACE("gap: %zu bytes, ends at bit %llu (wanted %llu), member end %d", bytes.size(), (unsigned long long)end_bit, (unsigned long long)to_bit, (int)mend);
             rc = grow_arena(h_chain_->total + bytes.size() + sum + ((size_t)1 << 20), err);
             if (rc) return rc;
-            if (!bytes.empty()) DCHK(hipMemcpy(arena_->p + h_chain_->total, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            if (!bytes.empty()) { DCHK(hipMemcpyAsync(arena_->p + h_chain_->total, bytes.data(), bytes.size(), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
             // the window behind the gap
             if (bytes.size() >= GZ_WINDOW) { memcpy(h_chain_->window, bytes.data() + bytes.size() - GZ_WINDOW, GZ_WINDOW); h_chain_->wlen = GZ_WINDOW; }
             else {
@@ -401,7 +404,7 @@ public:
             h_chain_->cur_bit = end_bit; h_chain_->total += bytes.size();
             if (h_chain_->stop == GZ_STOP_NONE && last_slab && !mend && bytes.empty()) { err = "gzip read error in " + path_ + ": truncated deflate stream"; return MF_E_FORMAT; }
             h_chain_->stop = mend ? GZ_STOP_MEMBER_END : GZ_STOP_NONE;
-            DCHK(hipMemcpy(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice));
+            DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp));
             if (mend) { rc = member_end(max_sym, sp, err); if (rc) return rc; if (done_) break; }
         }
         DCHK(hipEventRecord(ev_link_, sp)); DCHK(hipStreamWaitEvent(sr_, ev_link_, 0));
@@ -416,6 +419,7 @@ public:
         return MF_OK;
     }
     uint64_t gap_bytes() const { return gap_bytes_; }
+    uint64_t gaps() const { return n_gaps_; }
     uint64_t chunks_linked() const { return h_chain_ ? h_chain_->linked : 0; }
     uint32_t chunks() const { return n_chunks_; }
     size_t chunk_bytes() const { return chunk_; }
@@ -497,7 +501,7 @@ private:
         if (p >= size_ || size_ - p < 2 || data_[p] != 0x1f || data_[p + 1] != 0x8b) { done_ = true; in_member_ = false; return MF_OK; }   // trailing bytes that are no member: ignored
         if (!member_header(p, err)) return MF_E_FORMAT;
         h_chain_->cur_bit = (uint64_t)p * 8; h_chain_->wlen = 0; h_chain_->stop = GZ_STOP_NONE;
-        DCHK(hipMemcpy(d_chain_.p, h_chain_, offsetof(GzChain, window), hipMemcpyHostToDevice));
+        DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, offsetof(GzChain, window), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp));
         return MF_OK;
     }
     // running CRC of the member over the text [from, to)
@@ -524,7 +528,7 @@ private:
     static constexpr uint32_t NSYM = 9, NSTREAM = GZ_NSTREAM;      // decode kernels in flight: enough wavefronts to fill the chip (a slab is a few hundred chunks)
     Sym sym_[NSYM]; StreamSet *streams_ = nullptr; hipStream_t sd_[NSTREAM] = {}, sp_ = nullptr, sr_ = nullptr; hipEvent_t ev_link_ = nullptr;     // sp_: the link stream (reserved CUs); sr_: resolve and CRC (the whole chip)
     bool in_member_ = false, done_ = false;
-    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0;
+    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
 };
 
 // ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
@@ -886,8 +890,8 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
         fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f",
                 now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit);
         for (int i = 0; i < I.nm; i++)
-            if (I.m[i].gzs) fprintf(stderr, " | mate %d: %llu of %u chunks of %zu KiB linked, %llu bytes decoded on the host", i + 1, (unsigned long long)I.m[i].gzs->chunks_linked(),
-                                    I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gap_bytes());
+            if (I.m[i].gzs) fprintf(stderr, " | mate %d: %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there", i + 1, (unsigned long long)I.m[i].gzs->chunks_linked(),
+                                    I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes());
         fprintf(stderr, "\n");
     }
     return MF_OK;

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
     uint32_t status = GZ_NONE;
     if (!searching) rd.seek(start, lane);
     else if (nominal >= size_bits) { if (lane == 0) chunks[c] = res; return; }
+    uint64_t behind_from = ~0ull;                   // the first block boundary behind the chunk's own range
     uint32_t why = 0;                               // what stopped a decode that failed (reported in n_sym of a GZ_FAILED chunk)
     for (;;) {
         uint32_t final = 0, type = 2;
@@ -574,11 +575,19 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
             strict = true; opos = 0; blk_pos = start; blk_opos = 0;
         } else {
             blk_pos = rd.bitpos(); blk_opos = opos;
-            if (blk_pos >= stop_bit) { status = GZ_AT_BOUNDARY; break; }
+            // Behind its own range a chunk stops in front of the block its successor has started at -- and that can only be a
+            // non-final dynamic block (what next_candidate looks for): stored and fixed blocks and the member's final block are
+            // decoded here too (the empty stored blocks pigz and Z_SYNC_FLUSH writers leave every few ten kilobytes would each be
+            // a gap for the host to bridge otherwise), for at most one chunk's worth of input behind the range.
+            const bool behind = blk_pos >= stop_bit;
+            if (behind && behind_from == ~0ull) behind_from = blk_pos;
+            if (behind && (blk_pos + 3 > size_bits || blk_pos - behind_from >= chunk_bytes * 8)) { status = GZ_AT_BOUNDARY; break; }
             if (blk_pos + 3 > size_bits) why = 1;
             else {
                 rd.top_up(lane);
-                rd.refill(); final = rd.peek(1); type = rd.peek(3) >> 1; rd.drop(3);
+                rd.refill(); final = rd.peek(1); type = rd.peek(3) >> 1;
+                if (behind && !final && type == 2) { status = GZ_AT_BOUNDARY; break; }
+                rd.drop(3);
                 if (type == 3) why = 2;
             }
             if (!why && type == 0) {               // stored block: byte aligned LEN, ~LEN, then the bytes

@@ -17,6 +17,12 @@ from tests.util_data import make_reads, write_fastq
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def device_ingest(monkeypatch):
+    """plain files take the host pipeline by default (only .gz input goes to the device path): here everything is to go the device way"""
+    monkeypatch.setenv("MF_INGEST", "device")
+
+
 @pytest.fixture(scope="module")
 def mf():
     from mitoflex_amd import mitofilter
@@ -155,6 +161,44 @@ def test_several_members(mf, ol, bait_text, tmp_path, monkeypatch, members):
     assert t == 3000
 
 
+@pytest.mark.parametrize("flush", ["sync", "full", "mixed"])
+def test_flush_points_are_not_gaps(mf, ol, bait_text, tmp_path, monkeypatch, capfd, flush):
+    """pigz, bgzip-less parallel compressors and anything written with Z_SYNC_FLUSH put an empty stored block behind every few
+    ten kilobytes of input: the chunk in front decodes across them on the device --
+    the host bridges (next to) nothing."""
+    monkeypatch.setenv("MF_GZDEV_CHUNK_BYTES", "16384")
+    monkeypatch.setenv("MF_GZDEV_SLAB_CHUNKS", "7")
+    monkeypatch.setenv("MF_PIPE_TIMING", "1")
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    text = fastq_text(make_reads(bait_text, 30000, seed=61), "f")
+    rng = random.Random(9)
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)
+    out, pos, n_flush = [], 0, 0
+    while pos < len(text):
+        n = rng.randrange(20000, 140000)
+        out.append(c.compress(text[pos:pos + n]))
+        pos += n
+        kind = flush if flush != "mixed" else rng.choice(["sync", "full", "none"])
+        if kind != "none":
+            out.append(c.flush(zlib.Z_SYNC_FLUSH if kind == "sync" else zlib.Z_FULL_FLUSH))
+            n_flush += 1
+    out.append(c.flush())
+    fq = str(tmp_path / "f.fq.gz")
+    open(fq, "wb").write(b"".join(out))
+    capfd.readouterr()
+    k, t = run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    assert t == 30000 and n_flush > 20
+    err = capfd.readouterr().err
+    import re
+    m = re.search(r"(\d+) of (\d+) chunks of \d+ KiB linked, (\d+) gaps bridged on the host, (\d+) bytes decoded there", err)
+    assert m, err
+    linked, chunks, gaps, gap_bytes = map(int, m.groups())
+    assert chunks > 50 and linked > chunks // 2             # (a 16 KiB chunk no block starts in is passed over, not linked)
+    assert gaps <= 2 and gap_bytes < 200000, err            # (the end of the file, at most)
+
+
 def test_same_as_host_pipeline(mf, bait_text, tmp_path, monkeypatch):
     """the two ingest paths of the library write the same bytes (gz output included)"""
     bait = str(tmp_path / "bait.fa")
@@ -206,3 +250,56 @@ def test_highly_compressible_input_grows_the_symbol_buffers(mf, ol, bait_text, t
     ks = mf.KmerSet.from_fasta(bait, 31)
     k, t = run_both(mf, ol, bait, ks, fq, None, tmp_path)
     assert (k, t) == (30000, 60000)
+
+
+@pytest.mark.parametrize("level", [1, 6])
+def test_configs4_at_full_size(mf, ol, bait_text, tmp_path_factory, level):
+    """BASELINE.json configs[4] at its stated size: 33 333 334 single-end reads of 150 bases in ONE gzip member, filtered file to
+    file on one GPU.  The file is generated on the box (tools/make_fastq.py, 2 M-read blocks) and compressed by tools/pgzip.py
+    (one member, 8 MiB slices).  Checked: the totals; the survivors of the first million reads byte for byte against the oracle
+    run on that window of the text; the whole output byte for byte against the host pipeline (MF_INGEST=host) on the plain text."""
+    import hashlib
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 33_333_334
+    d = tmp_path_factory.getbasetemp() / "configs4"          # (both levels share the text and the host pipeline's output)
+    d.mkdir(exist_ok=True)
+    fq, bait = str(d / "s_1.fq"), str(d / "s.bait.fa")
+    if not os.path.exists(str(d / "host.md5")):
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_fastq.py"), str(d / "s"), "--pairs", str(n), "--mates", "1", "--block", "2000000"],
+                              stdout=subprocess.DEVNULL)
+        os.environ["MF_INGEST"] = "host"
+        try:
+            ks = mf.KmerSet.from_fasta(bait, 31)
+            res = mf.filter_fastq_files(ks, fq, None, str(d / "host.fq"), None)
+        finally:
+            os.environ["MF_INGEST"] = "device"
+        assert res[1] == n
+        open(str(d / "host.md5"), "w").write(hashlib.md5(open(str(d / "host.fq"), "rb").read()).hexdigest() + " %d %d" % res)
+        # the oracle on a window: the first million reads
+        with open(fq, "rb") as f, open(str(d / "win.fq"), "wb") as w:
+            w.write(f.read(1_000_000 * 321))
+        ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, str(d / "win.fq"), None, str(d / "win.out"), None, threads=os.cpu_count() or 1)
+        assert ot == 1_000_000 and ok > 1000
+    want_md5, want_kept, want_total = open(str(d / "host.md5")).read().split()
+    gz = str(d / ("s.l%d.fq.gz" % level))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "pgzip.py"), fq, gz, "--level", str(level)])
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    out = str(d / "dev.fq")
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        kept, total = mf.filter_fastq_files(ks, gz, None, out, None)
+        best = min(best, time.perf_counter() - t0)
+    assert (kept, total) == (int(want_kept), int(want_total)) and total == n
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == want_md5
+    win = open(str(d / "win.out"), "rb").read()
+    assert got[:len(win)] == win and got[len(win):len(win) + 5] == b"@syn."          # the window's survivors open the output
+    print("configs[4] level %d: %.3f s, %.1f M reads/s" % (level, best, n / best / 1e6))
+    os.unlink(gz)
+    if level == 6:
+        for f in os.listdir(str(d)):
+            os.unlink(os.path.join(str(d), f))
