@@ -54,22 +54,14 @@ MF_HD uint64_t hash_key2(uint64_t lo, uint64_t hi)
 // stage-1 hash: (low 24 bits of the s-mer) * 0x9E3779 + s-mer -- one full-rate v_mad_u32_u24 (a full 32-bit multiply is a
 // quarter-rate instruction on CDNA).  The block index is the top bits of h.
 MF_HD uint32_t bloom_hash(uint32_t smer) { return (smer & 0xFFFFFFu) * 0x9E3779u + smer; }
-// stage-1 bit of dword i of the 128-bit block: 31 - field_i, where field_i is the low five bits of
-// byte i of g = (h:smer) >> 11 (one funnel shift).  Simulated on the synthetic mitogenome (35 250 s-mers, both strands,
-// 8192 blocks): 0.059 % false positives, what four independent ideal fields give (0.062 %); shifts of 5, 7, 13 or 15
-// give 0.11 %, bytes of h alone 0.19 %.  The kernel tests a bit by shifting the dword LEFT by field_i -- the bit lands in
-// the sign position -- with the field taken straight from its byte through an SDWA operand selector.
-constexpr uint32_t STAGE1_MIX_SHIFT = 11;
-// stage-1 block size.  128-bit blocks (ds_read_b128, one tested bit per dword: 0.059 % false positives on the synthetic
-// mitogenome) or 64-bit blocks (ds_read_b64, two tested bits per dword: 0.104 %, half the LDS bytes per sample -- a random
-// 16-byte read per lane runs into ~3-way bank conflicts, and at 128 bytes a clock that made LDS, not HBM, the pacing
-// resource of the screen).
-#ifndef MF_STAGE1_B64
-#define MF_STAGE1_B64 0
-#endif
-constexpr int STAGE1_BLOCK_DWORDS = MF_STAGE1_B64 ? 2 : 4;
-MF_HD uint32_t stage1_mix(uint32_t smer, uint32_t h) { return (smer >> STAGE1_MIX_SHIFT) | (h << (32 - STAGE1_MIX_SHIFT)); }
-MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return (stage1_mix(smer, h) >> (8 * i)) & 31u; }
+// stage-1 bit of dword i of the 128-bit block: 31 - field_i.  The fields are the low five bits of bytes 0, 1, 2 of the s-mer
+// itself and of byte 1 of h -- every one a byte of a value the kernel already holds, so a field costs nothing: the kernel tests
+// a bit by shifting the dword LEFT by field_i (the bit lands in the sign position) with the field taken straight from its byte
+// through an SDWA operand selector.  Simulated on a random 16.5 kbp bait (32 969 s-mers, both strands, 8192 blocks): 0.052 %
+// false positives for 14-base samples, 0.056 % for 16-base ones.  (Rounds 1-2 took the fields from the bytes of (h:smer) >> 11:
+// the same 0.05 % for 16-base samples, but 0.27 % for 14-base ones -- byte 2 was smer[31:27], one live bit when s = 14 -- and one
+// more instruction per sample.)
+MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return ((i < 3 ? smer >> (8 * i) : h >> 8)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
 constexpr int STAGE2_K = 4;
 MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }

@@ -165,15 +165,8 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                 for (int j = 0; j < SPW; j++) {
                     const uint32_t sm = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
                     const uint32_t h = bloom_hash(sm);
-                    const uint32_t g = alignbit(h, sm, STAGE1_MIX_SHIFT);   // stage1_mix
-                    uint32_t t;
-                    if (MF_STAGE1_B64) {
-                        const uint2 blk = reinterpret_cast<const uint2 *>(s_tab4)[h >> (blk_shift - 1)];
-                        t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.x) & lshl_by_byte<2>(g, blk.y) & lshl_by_byte<3>(g, blk.y);
-                    } else {
-                        const uint4 blk = s_tab4[h >> blk_shift];
-                        t = lshl_by_byte<0>(g, blk.x) & lshl_by_byte<1>(g, blk.y) & lshl_by_byte<2>(g, blk.z) & lshl_by_byte<3>(g, blk.w);
-                    }
+                    const uint4 blk = s_tab4[h >> blk_shift];
+                    const uint32_t t = lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);   // stage1_field
                     hitmask = alignbit(hitmask, t, 31);             // (hitmask << 1) | sign(t)
                 }
             }
@@ -1097,12 +1090,6 @@ __global__ void materialize2_kernel(BaitView B, int k, const uint32_t *postab, u
 __device__ __forceinline__ void stage1_insert(uint32_t sm, uint32_t *bloom, uint32_t log2w)
 {
     const uint32_t h = bloom_hash(sm);
-    if (MF_STAGE1_B64) {
-        uint32_t *blk = bloom + 2 * (size_t)(h >> (32 - (log2w - 1)));
-#pragma unroll
-        for (int i = 0; i < 4; i++) atomicOr(&blk[i >> 1], 1u << stage1_bit(sm, h, i));
-        return;
-    }
     uint32_t *blk = bloom + 4 * (size_t)(h >> (32 - (log2w - 2)));
 #pragma unroll
     for (int i = 0; i < 4; i++) atomicOr(&blk[i], 1u << stage1_bit(sm, h, i));
