@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int U, bool NT, bool CONTIG>
 __global__ void rd(const u32x4* __restrict__ p, uint64_t n_vec, uint32_t* out)
@@ -22,6 +23,25 @@ __global__ void rd(const u32x4* __restrict__ p, uint64_t n_vec, uint32_t* out)
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
+// the screen kernel's own shape: the grid, block, loads per lane and LDS footprint it runs with (nothing else of it)
+template <int U>
+__global__ void __launch_bounds__(1024) rd_screen_shape(const u32x4* __restrict__ p, uint64_t n_vec, uint32_t* out)
+{
+    extern __shared__ uint4 lds[];
+    const uint64_t chunk = (uint64_t)blockDim.x * U, n_chunks = n_vec / chunk, step = gridDim.x;
+    if (threadIdx.x == 0) lds[0] = make_uint4(0, 0, 0, 0);
+    uint32_t acc = 0;
+    u32x4 cur[U];
+    uint64_t c = blockIdx.x;
+    if (c < n_chunks) for (int u = 0; u < U; u++) cur[u] = __builtin_nontemporal_load(&p[c * chunk + (uint64_t)u * blockDim.x + threadIdx.x]);
+    for (; c < n_chunks; c += step) {
+        u32x4 nxt[U];
+        if (c + step < n_chunks) for (int u = 0; u < U; u++) nxt[u] = __builtin_nontemporal_load(&p[(c + step) * chunk + (uint64_t)u * blockDim.x + threadIdx.x]);
+        for (int u = 0; u < U; u++) acc += cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    if (acc == 0x12345678u) out[0] = acc + lds[0].x;
+}
 template <int U, bool NT, bool CONTIG>
 void run(const char* name, const u32x4* buf, uint64_t n_vec, uint32_t* out, int grid, int block)
 {
@@ -37,6 +57,19 @@ int main()
 {
     const uint64_t n_vec = 78125056 / 4096 * 4096;   // ~1.25 GB
     u32x4* buf; uint32_t* out; hipMalloc(&buf, n_vec * 16); hipMemset(buf, 1, n_vec * 16); hipMalloc(&out, 64);
+    {   // U = 2, 1024 threads, 128 KiB of LDS (one workgroup per CU), 224 workgroups: what screen_kernel<1, 2, false> launches with
+        hipFuncSetAttribute((const void*)rd_screen_shape<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 16);
+        for (int grid : {224, 256}) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            float best = 1e9;
+            for (int r = 0; r < 8; r++) {
+                hipEventRecord(a); hipLaunchKernelGGL((rd_screen_shape<2>), dim3(grid), dim3(1024), 131072 + 16, 0, buf, n_vec, out); hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+            }
+            printf("%-44s grid %5d block %4d : %.4f ms  %.0f GB/s\n", "screen shape: U2 nt, 128 KiB LDS", grid, 1024, best, n_vec * 16.0 / best / 1e6);
+        }
+    }
+    if (getenv("READBW_SHAPE_ONLY")) return 0;
     run<4, true, false>("U4 nt interleaved (screen kernel shape)", buf, n_vec, out, 256, 1024);
     run<4, false, false>("U4 plain interleaved", buf, n_vec, out, 256, 1024);
     run<4, true, true>("U4 nt contiguous per block", buf, n_vec, out, 256, 1024);
