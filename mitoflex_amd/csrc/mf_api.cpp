@@ -79,6 +79,7 @@ int get_ctx(int device, DevCtx **out, int lane)
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&c.stream4, hipStreamNonBlocking, hi));
     }
     HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
     g_ctx[device + 4096 * lane] = c;
@@ -646,7 +647,13 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
             HIPCHK(dev_reserve(r->d_rec_counts[q], c1, r->cap_rec_counts, false));
         }
         const bool two = overlap && pass_kind() == 0;
-        hipStream_t sf = two ? ctx->stream2 : st;
+        // The finish kernels are chains of memory latencies.  With few records (the benchmark's 0.5 % bait reads) they are over long
+        // before the next screen is and one stream carries them all; when they are what a pass waits for (bait-rich input: 2 % bait
+        // reads and more, seen in the last call's tallies) those of consecutive passes go to two streams and run side by side --
+        // 2 %: 0.303 -> 0.280 ms per pass, 10 %: 0.666 -> 0.596; at 0.5 % the same costs 2 % (0.208 -> 0.213).  MF_FINISH_STREAMS=1 / 2 forces.
+        static const uint32_t fin_streams = env_u32("MF_FINISH_STREAMS", 0);
+        const bool fin2 = fin_streams == 2 || (fin_streams == 0 && r->finish_two);
+        hipStream_t sf = two ? ((fin2 && (q & 1)) ? ctx->stream4 : ctx->stream2) : st;
         // consecutive screens go to two streams in turn: nothing orders them against each other (different buffer sets), so the
         // workgroups of the next screen take over the CUs as the last ones of this screen drain (MF_SCREEN_STREAMS=1: one stream)
         static const bool alt = env_u32("MF_SCREEN_STREAMS", 2) == 2;
@@ -777,7 +784,7 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
         // work items per read: ~0.025 at 0.5 % bait reads, 0.4 at 10 %, 0.8 at 20 %.  (Since a run start is left to the first lane that
         // holds one, the two kinds of pass are within 5 % of each other from 2 % to 100 % bait reads; the switch stays for inputs
         // that are nearly all bait.)
-        if (r->sample_pass) { if (cnt[1] > r->v.n_reads) r->prefer_split = true; }
+        if (r->sample_pass) { if (cnt[1] > r->v.n_reads) r->prefer_split = true; r->finish_two = cnt[1] > r->v.n_reads / 20; }
         else {                                                                                     // candidate reads per read
             if (r->prefer_split && cnt[1] < r->v.n_reads / 8) r->prefer_split = false;
             if (cnt[1] > r->v.n_reads / 20) r->split_serial = true; else if (cnt[1] < r->v.n_reads / 40) r->split_serial = false;

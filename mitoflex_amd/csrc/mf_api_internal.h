@@ -7,8 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <string>
 
-// stream2: finish kernels of pipelined passes; stream3: every other screen
-struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; int n_cu = 0; };
+// stream2: finish kernels of pipelined passes (stream4: those of every other pass when the finish kernels are what a pass waits for); stream3: every other screen
+struct DevCtx { int device = -1; hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; int n_cu = 0; };
 
 int fail(int code, const char *fmt, ...);               // sets the thread's error message, returns code
 const std::string &mf_thread_error();
@@ -48,6 +48,7 @@ struct mf_reads {
     // served by the candidate-bitmap pass: one thread per stage-1 record means several records per bait read, and the screen
     // writes them all.  The choice follows the work the last call of this read set (the last batch of this device) saw.
     bool prefer_split = false;
+    bool finish_two = false;          // bait-rich input (from the last call's tallies): the finish kernels of consecutive passes go to two streams
     bool split_serial = false;      // ... and with very many candidates (> 5 % of the reads) its kernels do not fit beside the next screen: one stream
     int cur = 0;
     unsigned long long *tally_override = nullptr;       // set per pass by filter_common when every pass's tally is wanted

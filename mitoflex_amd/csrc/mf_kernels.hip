@@ -30,6 +30,7 @@
 #include "mf_kernels.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
 
 namespace mf {
@@ -837,7 +838,7 @@ __device__ __forceinline__ bool sample_item(const ReadsView &R, const KmerSetVie
 //                     end at one look at their read's bit.  What is left (mostly stage-1 false positives) is looked up in the
 //                     exact s-mer table, and a true bait s-mer outside any run gets its sixteen windows counted (sample_item).
 constexpr int FINISH_BLOCK = 256;
-constexpr int FINISH_GRID = 1024;            // one tally pair per workgroup in the first half of the tally buffer
+constexpr int FINISH_GRID = 1024;            // one tally pair per workgroup in the first half of the tally buffer (MF_FINISH_GRID: up to EXACT_MAX_GRID; 2048 measured the same)
 static_assert(FINISH_GRID <= EXACT_MAX_GRID, "tally buffer");          // phase 1's pairs go to the second half
 
 template <int SPW, int U, int KW, int PHASE>
@@ -975,7 +976,9 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
             constexpr int NKW = KW == 1 ? 3 : 5;
             uint32_t raw[NKW];
             if (PHASE == 1) {          // nearly every record left over belongs to a read phase 0 has passed: look at its bit before fetching anything else
-                const uint32_t bw1 = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (an ordinary cached load: phase 0 ended at a kernel boundary, so what it passed is visible; a read that another record
+                // of this launch passes meanwhile may be missed -- that costs the work below, not correctness)
+                const uint32_t bw1 = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (pend_bit && !(pend_old & pend_bit)) n_pass++;
                 pend_bit = 0;
                 if (bw1 & bitm) { passed_r2 = passed_r; passed_r = r; continue; }
@@ -983,7 +986,7 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
 #pragma unroll
             for (int i = 0; i < NKW; i++) raw[i] = w[i];
             const uint32_t hn_w = R.has_n[r >> 5];
-            const uint32_t bw = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-coherent: other records pass reads meanwhile
+            const uint32_t bw = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (cached: other records pass reads meanwhile, seeing that late only costs a probe)
             if (pend_bit && !(pend_old & pend_bit)) n_pass++;
             pend_bit = 0;
             if (bw & bitm) { passed_r2 = passed_r; passed_r = r; continue; }     // passed meanwhile
@@ -1402,10 +1405,11 @@ hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *r
     KernelTiming last{nullptr, done};
     bool done_attached = false;
     if (done && !tm1) { tm1 = &last; done_attached = true; }
+    static const unsigned fgrid = std::min<unsigned>(EXACT_MAX_GRID, std::max<unsigned>(64, getenv("MF_FINISH_GRID") ? (unsigned)atoi(getenv("MF_FINISH_GRID")) : FINISH_GRID));
 #define MF_LAUNCH_FINISH(SPW, KW) do { \
-        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm0, R, S, rc, cap, rec_counts, \
+        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(fgrid), dim3(FINISH_BLOCK), 0, st, tm0, R, S, rc, cap, rec_counts, \
                   (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); \
-        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 1>), dim3(FINISH_GRID), dim3(FINISH_BLOCK), 0, st, tm1, R, S, rc, cap, rec_counts, \
+        MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 1>), dim3(fgrid), dim3(FINISH_BLOCK), 0, st, tm1, R, S, rc, cap, rec_counts, \
                   (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); } while (0)
     if (S.stride == 16) { if (S.kw == 1) MF_LAUNCH_FINISH(1, 1); else MF_LAUNCH_FINISH(1, 2); }
     else                { if (S.kw == 1) MF_LAUNCH_FINISH(2, 1); else MF_LAUNCH_FINISH(2, 2); }

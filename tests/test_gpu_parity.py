@@ -437,18 +437,20 @@ def test_multi_pass_calls_match_oracle(mf, ol, bait_text, k):
         assert per.tolist() == [want] * 7 and st.n_pass == want, (k, thr, per.tolist())
 
 
-@pytest.mark.parametrize("kind", ["split", "serial", "split-co", "split-one-stream", "one-screen-stream"])
+@pytest.mark.parametrize("kind", ["split", "serial", "split-co", "split-one-stream", "one-screen-stream", "two-finish-streams"])
 def test_other_pass_kinds_match_oracle(kind):
     """Environment switches select how a screened pass is run (read once per process, hence the child process).  MF_PASS=split:
     screen + mark + exact for every threshold; MF_PASS=serial: screen + finish without the cross-pass overlap -- and with the
     finish kernel for the stride-8 geometries (k < 28), which the default leaves to the candidate-bitmap pass.  `split-co`
     puts the co-resident form of the exact kernel (half the threads, folded bit table: what runs beside the next pass's screen
     in a multi-pass call) behind every screen; `split-one-stream` is the three-kernel pass without the second stream;
-    `one-screen-stream` keeps all screens on one stream."""
+    `one-screen-stream` keeps all screens on one stream; `two-finish-streams` puts the finish kernels of consecutive passes on
+    two streams for every input (the library does that by itself for bait-rich read sets only)."""
     import subprocess
     import sys
     extra = {"split": dict(MF_PASS="split"), "serial": dict(MF_PASS="serial"), "split-co": dict(MF_PASS="split", MF_EXACT_CO="1"),
-             "split-one-stream": dict(MF_PASS="split", MF_SPLIT_PIPE="0"), "one-screen-stream": dict(MF_SCREEN_STREAMS="1")}[kind]
+             "split-one-stream": dict(MF_PASS="split", MF_SPLIT_PIPE="0"), "one-screen-stream": dict(MF_SCREEN_STREAMS="1"),
+             "two-finish-streams": dict(MF_FINISH_STREAMS="2")}[kind]
     env = dict(os.environ, **extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_kmer_golden.py"),
                         "-m", "gpu", "-q", "-x", "-k", "test_filter_matches_oracle or test_edge_cases or test_gpu_matches_golden or test_synth_uniform or test_multi_pass_calls"],

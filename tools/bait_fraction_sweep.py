@@ -6,7 +6,8 @@ from tests.util_data import make_bait
 bait = make_bait()
 ks = mf.KmerSet.from_text(bait, 31)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 33_333_334
-for ppm in (0, 500, 5000, 20000, 100000):
+ppms = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 500, 5000, 20000, 100000)
+for ppm in ppms:
     reads = mf.Reads.synth(n, 150, 1, bait, mito_ppm=ppm, n_read_ppm=0)
     for _ in range(3):                       # (the pass kind follows what the previous calls of this read set saw)
         mf.filter_resident(ks, reads, 1, mf.MODE_SCREENED, 3)

@@ -23,8 +23,9 @@ __global__ void rd(const u32x4* __restrict__ p, uint64_t n_vec, uint32_t* out)
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
-// the screen kernel's own shape: the grid, block, loads per lane and LDS footprint it runs with (nothing else of it)
-template <int U>
+// the screen kernel's own shape: the grid, block, loads per lane and LDS footprint it runs with (nothing else of it).
+// LANE_CONTIG: a lane's U loads are neighbours in memory (32 contiguous bytes per lane for U = 2) instead of blockDim * 16 bytes apart
+template <int U, bool LANE_CONTIG>
 __global__ void __launch_bounds__(1024) rd_screen_shape(const u32x4* __restrict__ p, uint64_t n_vec, uint32_t* out)
 {
     extern __shared__ uint4 lds[];
@@ -33,10 +34,11 @@ __global__ void __launch_bounds__(1024) rd_screen_shape(const u32x4* __restrict_
     uint32_t acc = 0;
     u32x4 cur[U];
     uint64_t c = blockIdx.x;
-    if (c < n_chunks) for (int u = 0; u < U; u++) cur[u] = __builtin_nontemporal_load(&p[c * chunk + (uint64_t)u * blockDim.x + threadIdx.x]);
+    auto at = [&](uint64_t cc, int u) { return LANE_CONTIG ? cc * chunk + (uint64_t)threadIdx.x * U + u : cc * chunk + (uint64_t)u * blockDim.x + threadIdx.x; };
+    if (c < n_chunks) for (int u = 0; u < U; u++) cur[u] = __builtin_nontemporal_load(&p[at(c, u)]);
     for (; c < n_chunks; c += step) {
         u32x4 nxt[U];
-        if (c + step < n_chunks) for (int u = 0; u < U; u++) nxt[u] = __builtin_nontemporal_load(&p[(c + step) * chunk + (uint64_t)u * blockDim.x + threadIdx.x]);
+        if (c + step < n_chunks) for (int u = 0; u < U; u++) nxt[u] = __builtin_nontemporal_load(&p[at(c + step, u)]);
         for (int u = 0; u < U; u++) acc += cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
         for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
@@ -58,16 +60,20 @@ int main()
     const uint64_t n_vec = 78125056 / 4096 * 4096;   // ~1.25 GB
     u32x4* buf; uint32_t* out; hipMalloc(&buf, n_vec * 16); hipMemset(buf, 1, n_vec * 16); hipMalloc(&out, 64);
     {   // U = 2, 1024 threads, 128 KiB of LDS (one workgroup per CU), 224 workgroups: what screen_kernel<1, 2, false> launches with
-        hipFuncSetAttribute((const void*)rd_screen_shape<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 16);
-        for (int grid : {224, 256}) {
-            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-            float best = 1e9;
-            for (int r = 0; r < 8; r++) {
-                hipEventRecord(a); hipLaunchKernelGGL((rd_screen_shape<2>), dim3(grid), dim3(1024), 131072 + 16, 0, buf, n_vec, out); hipEventRecord(b); hipEventSynchronize(b);
-                float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+        auto shape = [&](auto kern, const char* name) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 16);
+            for (int grid : {224, 256}) {
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+                float best = 1e9;
+                for (int r = 0; r < 8; r++) {
+                    hipEventRecord(a); hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 131072 + 16, 0, buf, n_vec, out); hipEventRecord(b); hipEventSynchronize(b);
+                    float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+                }
+                printf("%-44s grid %5d block %4d : %.4f ms  %.0f GB/s\n", name, grid, 1024, best, n_vec * 16.0 / best / 1e6);
             }
-            printf("%-44s grid %5d block %4d : %.4f ms  %.0f GB/s\n", "screen shape: U2 nt, 128 KiB LDS", grid, 1024, best, n_vec * 16.0 / best / 1e6);
-        }
+        };
+        shape(rd_screen_shape<2, false>, "screen shape: U2 nt, 128 KiB LDS");
+        shape(rd_screen_shape<2, true>, "same, 32 contiguous bytes per lane");
     }
     if (getenv("READBW_SHAPE_ONLY")) return 0;
     run<4, true, false>("U4 nt interleaved (screen kernel shape)", buf, n_vec, out, 256, 1024);
