@@ -931,9 +931,18 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     if (!out1) return fail(MF_E_ARG, "out1 is NULL");
     if (start > end) return fail(MF_E_ARG, "start comes after end");
     if (quality == 0 || quality > 100) return fail(MF_E_ARG, "quality must be in 1..100");
-    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;      // no CPU fallback: needs the GPU
-    hipStream_t st = ctx->stream;
-    struct Scratch { void *p = nullptr; size_t cap = 0; } d_text, d_recs, d_cnt, d_hash;
+    // The device is set up by the first batch that needs it (the decision thread), while the readers are already parsing: HIP's
+    // start-up is a third of a second, as long as the whole pipeline takes for a few million records.  Without a gfx950 device the
+    // call fails there with MF_E_NO_DEVICE (no CPU fallback) -- the output files have been created by then.
+    DevCtx *ctx = nullptr; hipStream_t st = nullptr; int rc = MF_OK;
+    auto ensure_device = [&](std::string &err) -> int {
+        if (ctx) return MF_OK;
+        const int r = get_ctx(device, &ctx);
+        if (r) { ctx = nullptr; err = mf_last_error(); return r; }
+        st = ctx->stream;
+        return MF_OK;
+    };
+    struct Scratch { void *p = nullptr; size_t cap = 0; } d_text, d_recs, d_cnt, d_hash, d_flags;
     auto need = [&](Scratch &s, size_t bytes) -> hipError_t {
         if (bytes <= s.cap) return hipSuccess;
         if (s.p) hipFree(s.p);
@@ -942,30 +951,67 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
         if (e == hipSuccess) s.cap = bytes + bytes / 4 + 4096;
         return e;
     };
-    QualScanFn scan = [&](const char *text, size_t len, const QualSpan *recs, uint32_t n, uint32_t q, uint32_t *n_count,
-                          uint32_t *bad_count, uint64_t *hashes, std::string &err) -> int {
 #define QCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return MF_E_HIP; } } while (0)
+    QualScanFn scan = [&](const char *text, size_t len, const QualSpan *recs, uint32_t n, uint32_t q, uint32_t *n_count,
+                          uint32_t *bad_count, bool want_hashes, std::string &err) -> int {
+        { const int r = ensure_device(err); if (r) return r; }
         QCHK(hipSetDevice(phys(device)));
         QCHK(need(d_text, len + 64)); QCHK(need(d_recs, (size_t)n * sizeof(QualSpan))); QCHK(need(d_cnt, (size_t)n * 8));
-        if (hashes) QCHK(need(d_hash, (size_t)n * 8));
+        if (want_hashes) QCHK(need(d_hash, (size_t)n * 8));
         QCHK(hipMemcpyAsync(d_text.p, text, len, hipMemcpyHostToDevice, st));
         QCHK(hipMemcpyAsync(d_recs.p, recs, (size_t)n * sizeof(QualSpan), hipMemcpyHostToDevice, st));
         uint32_t *dn = (uint32_t *)d_cnt.p, *db = dn + n;
-        QCHK(launch_qualscan((const uint8_t *)d_text.p, (const QualRec *)d_recs.p, n, q, dn, db, hashes ? (uint64_t *)d_hash.p : nullptr, st));
+        QCHK(launch_qualscan((const uint8_t *)d_text.p, (const QualRec *)d_recs.p, n, q, dn, db, want_hashes ? (uint64_t *)d_hash.p : nullptr, st));
         QCHK(hipMemcpyAsync(n_count, dn, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         QCHK(hipMemcpyAsync(bad_count, db, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        if (hashes) QCHK(hipMemcpyAsync(hashes, d_hash.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-        QCHK(hipStreamSynchronize(st));
-#undef QCHK
+        QCHK(hipStreamSynchronize(st));                   // (the hashes stay on the device for the dedup call)
         return MF_OK;
     };
+    // The de-duplication set lives on the device for the whole file: keys + smallest file index per key.  Sized for the first batches
+    // and doubled (rehashed by a kernel) before a batch that could fill it beyond a half.
+    struct DedupSet { unsigned long long *keys = nullptr, *first = nullptr, *small = nullptr; uint64_t slots = 0, n_keys = 0, base = 0; } ds;     // small: [0] zero_idx, [1] n_keys
+    auto ds_alloc = [&](uint64_t slots, unsigned long long **keys, unsigned long long **first, std::string &err) -> int {
+        QCHK(hipMalloc((void **)keys, slots * 8)); QCHK(hipMalloc((void **)first, slots * 8));
+        QCHK(hipMemsetAsync(*keys, 0, slots * 8, st)); QCHK(hipMemsetAsync(*first, 0xFF, slots * 8, st));
+        return MF_OK;
+    };
+    QualDedupFn dedup_fn = [&](const uint8_t *alive, uint32_t n, uint8_t *dup, std::string &err) -> int {
+        QCHK(hipSetDevice(phys(device)));
+        if (!ds.keys) {
+            uint64_t lg = env_u32("MF_DEDUP_LOG2_SLOTS", 24);
+            if (lg < 4) lg = 4; if (lg > 34) lg = 34;
+            ds.slots = (uint64_t)1 << lg;
+            const int rc2 = ds_alloc(ds.slots, &ds.keys, &ds.first, err); if (rc2) return rc2;
+            QCHK(hipMalloc((void **)&ds.small, 16));
+            QCHK(hipMemsetAsync(ds.small, 0xFF, 8, st)); QCHK(hipMemsetAsync(ds.small + 1, 0, 8, st));
+        }
+        while (2 * (ds.n_keys + n) > ds.slots) {          // (every record of the batch may be a new key)
+            unsigned long long *k2 = nullptr, *f2 = nullptr;
+            const int rc2 = ds_alloc(ds.slots * 2, &k2, &f2, err); if (rc2) return rc2;
+            QCHK(launch_dedup_rehash(ds.keys, ds.first, ds.slots, k2, f2, ds.slots * 2, st));
+            QCHK(hipStreamSynchronize(st));
+            QCHK(hipFree(ds.keys)); QCHK(hipFree(ds.first));
+            ds.keys = k2; ds.first = f2; ds.slots *= 2;
+        }
+        QCHK(need(d_flags, (size_t)n * 2));
+        uint8_t *d_alive = (uint8_t *)d_flags.p, *d_dup = d_alive + n;
+        QCHK(hipMemcpyAsync(d_alive, alive, n, hipMemcpyHostToDevice, st));
+        QCHK(launch_dedup((const uint64_t *)d_hash.p, d_alive, n, ds.base, ds.keys, ds.first, ds.slots, ds.small, ds.small + 1, d_dup, st));
+        QCHK(hipMemcpyAsync(dup, d_dup, n, hipMemcpyDeviceToHost, st));
+        unsigned long long nk = 0;
+        QCHK(hipMemcpyAsync(&nk, ds.small + 1, 8, hipMemcpyDeviceToHost, st));
+        QCHK(hipStreamSynchronize(st));
+        ds.n_keys = nk; ds.base += n;
+        return MF_OK;
+    };
+#undef QCHK
     static_assert(sizeof(QualSpan) == sizeof(QualRec), "host and device record layouts must match");
     QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
     P.dedup = dedup != 0; P.trunc = truncate_only != 0;
     int threads = (int)std::thread::hardware_concurrency() - 4; if (threads < 2) threads = 2; if (threads > 64) threads = 64;
     QualStats qs; std::string perr;
-    rc = run_qualfilter_pipeline(fq1, fq2, out1, out2, P, threads, env_u32("MF_BATCH_READS", 2000000), scan, qs, perr);
-    hipFree(d_text.p); hipFree(d_recs.p); hipFree(d_cnt.p); hipFree(d_hash.p);
+    rc = run_qualfilter_pipeline(fq1, fq2, out1, out2, P, threads, env_u32("MF_BATCH_READS", 2000000), scan, dedup_fn, qs, perr);
+    if (ctx) { hipFree(d_text.p); hipFree(d_recs.p); hipFree(d_cnt.p); hipFree(d_hash.p); hipFree(d_flags.p); hipFree(ds.keys); hipFree(ds.first); hipFree(ds.small); }
     if (rc != MF_OK) return fail(rc, "%s", perr.c_str());
     if (kept) *kept = qs.kept;
     if (total) *total = qs.total;

@@ -44,6 +44,14 @@ hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const
 struct QualRec { uint32_t s_off, s_len, q_off, q_len; };
 hipError_t launch_qualscan(const uint8_t *text, const QualRec *recs, uint32_t n, uint32_t quality, uint32_t *n_count, uint32_t *bad_count,
                            uint64_t *hashes /* nullptr: no dedup hashes */, hipStream_t st);
+// the quality filter's de-duplication set on the device (HashSet<u64> semantics, first occurrence by file index wins): keys and
+// first have `slots` (a power of two) entries -- keys zeroed, first all ones -- zero_idx is all ones, n_keys counts the entries.
+// dup[i] = 1 for a live record whose hash an earlier live record (of this or an earlier call; base = file index of record 0) carried
+hipError_t launch_dedup(const uint64_t *hashes, const uint8_t *alive, uint32_t n, uint64_t base, unsigned long long *keys,
+                        unsigned long long *first, uint64_t slots, unsigned long long *zero_idx, unsigned long long *n_keys, uint8_t *dup,
+                        hipStream_t st);
+hipError_t launch_dedup_rehash(const unsigned long long *old_keys, const unsigned long long *old_first, uint64_t old_slots,
+                               unsigned long long *keys, unsigned long long *first, uint64_t slots, hipStream_t st);
 // protein-space baiting (mf_protein.hip): peptide k-mer table builder and the six-frame filter kernel
 hipError_t launch_build_ptable(const uint8_t *aa, const uint8_t *runlen, uint64_t total, int kp, uint64_t *keys, uint64_t slots,
                                hipStream_t st);

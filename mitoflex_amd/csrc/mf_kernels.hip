@@ -1303,6 +1303,82 @@ seqhash_kernel(const uint8_t *__restrict__ text, const QualRec *__restrict__ rec
     hashes[r] = v0 ^ v1 ^ v2 ^ v3;
 }
 
+// De-duplication set of the quality filter on the device: HashSet<u64> semantics over the SipHash values (main.rs:244-250: a
+// record whose hash an EARLIER record that reached this point carried is dropped).  Open addressing, keys[] holds the hash
+// (0 = empty; the hash value 0 itself lives in zero_idx), first[] the smallest file index of a live record that carried it
+// (atomicMin): "first occurrence wins" without any order of execution.  Batches come in file order, so an entry left by an
+// earlier batch always wins over the current one.
+__device__ __forceinline__ uint64_t dedup_mix(uint64_t x) { x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 32; return x; }
+
+__global__ void __launch_bounds__(256)
+dedup_insert_kernel(const uint64_t *__restrict__ hashes, const uint8_t *__restrict__ alive, uint32_t n, uint64_t base,
+                    unsigned long long *__restrict__ keys, unsigned long long *__restrict__ first, uint64_t mask,
+                    unsigned long long *__restrict__ zero_idx, unsigned long long *__restrict__ n_keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !alive[i]) return;
+    const uint64_t h = hashes[i];
+    if (h == 0) { atomicMin(zero_idx, (unsigned long long)(base + i)); return; }
+    uint64_t slot = dedup_mix(h) & mask;
+    for (;;) {
+        unsigned long long k = keys[slot];
+        if (k == 0) { k = atomicCAS(&keys[slot], 0ull, (unsigned long long)h); if (k == 0) { atomicAdd(n_keys, 1ull); k = h; } }
+        if (k == h) { atomicMin(&first[slot], (unsigned long long)(base + i)); return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dedup_check_kernel(const uint64_t *__restrict__ hashes, const uint8_t *__restrict__ alive, uint32_t n, uint64_t base,
+                   const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ first, uint64_t mask,
+                   const unsigned long long *__restrict__ zero_idx, uint8_t *__restrict__ dup)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t d = 0;
+    if (alive[i]) {
+        const uint64_t h = hashes[i];
+        if (h == 0) d = *zero_idx != base + i;
+        else {
+            uint64_t slot = dedup_mix(h) & mask;
+            while (keys[slot] != h) slot = (slot + 1) & mask;            // (inserted by the launch before this one)
+            d = first[slot] != base + i;
+        }
+    }
+    dup[i] = d;
+}
+
+// moves every entry of a full table into one of twice the size
+__global__ void __launch_bounds__(256)
+dedup_rehash_kernel(const unsigned long long *__restrict__ old_keys, const unsigned long long *__restrict__ old_first, uint64_t old_slots,
+                    unsigned long long *__restrict__ keys, unsigned long long *__restrict__ first, uint64_t mask)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= old_slots) return;
+    const unsigned long long h = old_keys[i];
+    if (h == 0) return;
+    uint64_t slot = dedup_mix(h) & mask;
+    while (atomicCAS(&keys[slot], 0ull, h) != 0) slot = (slot + 1) & mask;      // (keys are distinct)
+    first[slot] = old_first[i];
+}
+
+hipError_t launch_dedup(const uint64_t *hashes, const uint8_t *alive, uint32_t n, uint64_t base, unsigned long long *keys,
+                        unsigned long long *first, uint64_t slots, unsigned long long *zero_idx, unsigned long long *n_keys, uint8_t *dup,
+                        hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, st, hashes, alive, n, base, keys, first, slots - 1, zero_idx, n_keys);
+    hipLaunchKernelGGL(dedup_check_kernel, dim3((n + 255) / 256), dim3(256), 0, st, hashes, alive, n, base, keys, first, slots - 1, zero_idx, dup);
+    return hipGetLastError();
+}
+
+hipError_t launch_dedup_rehash(const unsigned long long *old_keys, const unsigned long long *old_first, uint64_t old_slots,
+                               unsigned long long *keys, unsigned long long *first, uint64_t slots, hipStream_t st)
+{
+    hipLaunchKernelGGL(dedup_rehash_kernel, dim3((unsigned)((old_slots + 255) / 256)), dim3(256), 0, st, old_keys, old_first, old_slots, keys, first, slots - 1);
+    return hipGetLastError();
+}
+
 hipError_t launch_qualscan(const uint8_t *text, const QualRec *recs, uint32_t n, uint32_t quality, uint32_t *n_count, uint32_t *bad_count,
                            uint64_t *hashes, hipStream_t st)
 {

@@ -556,35 +556,11 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
 }
 
 // ================================================================ FASTQ quality filter (filter_v2)
-// Same readers; the decision stage is one thread because the reference's rules are sequential
-// (dedup keeps the first occurrence, the -t budget stops at the first read that overflows it:
-// filter/filter_bin/src/main.rs:244-259).  What is data parallel -- counting N and low-quality
-// bytes, hashing the sequences -- runs on the GPU over the raw text of each batch.
+// Same readers; the decision stage is one thread because the reference's -t budget is sequential (it stops at the first read
+// that overflows it: filter/filter_bin/src/main.rs:254-259).  What is data parallel -- counting N and low-quality bytes,
+// hashing the sequences, and the de-duplication set itself ("first occurrence wins" is a minimum over file indices, which needs
+// no order of execution) -- runs on the GPU over the raw text of each batch.
 namespace {
-
-struct U64Set {                                     // open-address set with HashSet<u64> semantics
-    // one array (0 = empty slot, the value 0 itself is kept in a flag): an insert is one cache miss,
-    // and prefetch() lets the caller start that miss a few records ahead
-    std::vector<uint64_t> slot; size_t n = 0, mask = 0; bool has_zero = false;
-    U64Set() { slot.assign(1 << 16, 0); mask = (1 << 16) - 1; }
-    static uint64_t mix(uint64_t x) { x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 32; return x; }
-    void grow()
-    {
-        std::vector<uint64_t> os; os.swap(slot);
-        slot.assign(os.size() * 2, 0); mask = slot.size() - 1; n = 0;
-        for (uint64_t v : os) if (v) insert(v);
-    }
-    void prefetch(uint64_t v) const { __builtin_prefetch(&slot[mix(v) & mask], 1, 1); }
-    bool insert(uint64_t v)                          // false when already present
-    {
-        if (v == 0) { const bool fresh = !has_zero; has_zero = true; return fresh; }
-        if (2 * (n + 1) > slot.size()) grow();
-        size_t i = mix(v) & mask;
-        while (slot[i]) { if (slot[i] == v) return false; i = (i + 1) & mask; }
-        slot[i] = v; n++;
-        return true;
-    }
-};
 
 bool utf8_ok(const char *p, size_t n)
 {
@@ -631,12 +607,13 @@ using QualPtr = std::shared_ptr<QualBatch>;
 } // namespace
 
 int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &P,
-                            int threads, uint64_t batch_reads, const QualScanFn &scan, QualStats &stats, std::string &err)
+                            int threads, uint64_t batch_reads, const QualScanFn &scan, const QualDedupFn &dedup, QualStats &stats,
+                            std::string &err)
 {
     const int nm = fq2 ? 2 : 1;
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
     const bool timing = getenv("MF_PIPE_TIMING") != nullptr;      // busy seconds of every stage on stderr (diagnostics)
-    std::atomic<uint64_t> t_read[2] = {{0}, {0}}, t_check{0}, t_scan{0}, t_decide{0}, t_write[2] = {{0}, {0}};
+    std::atomic<uint64_t> t_read[2] = {{0}, {0}}, t_check{0}, t_scan{0}, t_decide{0}, t_dedup{0}, t_wait_in{0}, t_wait_out{0}, t_write[2] = {{0}, {0}};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const uint64_t t_start = now_us();
     BatchReader rd[2];
@@ -671,15 +648,17 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
 
     // ---- decisions (sequential semantics), GPU counting per batch
     th.emplace_back([&] {
-        U64Set seen; uint64_t budget = 0, idx = 0; bool stop = false;
+        uint64_t budget = 0, idx = 0; bool stop = false;
         const uint64_t L = P.end - P.start;
-        std::vector<uint32_t> nc[2], bc[2]; std::vector<uint64_t> hs;      // per-batch scratch, capacity kept
+        std::vector<uint32_t> nc[2], bc[2]; std::vector<uint8_t> alive, dupf;      // per-batch scratch, capacity kept
         std::vector<QualSpan, DefaultInitAlloc<QualSpan>> sp;
         std::shared_ptr<MateBatch> cur[2]; uint64_t pos[2] = {0, 0};
         while (!stop) {
             bool ok = true;
+            const uint64_t tp0 = now_us();
             for (int m = 0; m < nm && ok; m++)
                 while (ok && (!cur[m] || pos[m] == cur[m]->recs.size())) { cur[m].reset(); pos[m] = 0; ok = q_read[m].pop(cur[m]); }
+            t_wait_in += now_us() - tp0;
             if (!ok) break;                                   // a reader has run out: the shorter file bounds the pair count
             auto qb = qual_pool->get();
             uint64_t n = cur[0]->recs.size() - pos[0];
@@ -733,10 +712,9 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                             sp[i] = QualSpan{(uint32_t)(recs[i].s - base), recs[i].sl, (uint32_t)(recs[i].q - base), recs[i].ql};
                     });
                     nc[m].resize(n_ok); bc[m].resize(n_ok);
-                    if (m == 0 && P.dedup) hs.resize(n_ok);
                     std::string e;
                     const int r = scan(base, (size_t)(endp - base), sp.data(), (uint32_t)n_ok, P.quality, nc[m].data(), bc[m].data(),
-                                       (m == 0 && P.dedup) ? hs.data() : nullptr, e);
+                                       m == 0 && P.dedup, e);
                     if (r != MF_OK) { set_err(r, e); ok = false; }
                 }
                 if (!ok) { abort_all(); break; }
@@ -744,28 +722,43 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
             t_scan += now_us() - ts0;
             const uint64_t td0 = now_us();
             qb->keep.assign(n ? n : 1, 0);
-            for (uint64_t i = 0; i < n_ok; i++) {
-                const FqRec &r1 = mrec[0][i];
-                if (P.dedup && !P.trunc && i + 16 < n_ok) seen.prefetch(hs[i + 16]);
-                if (!P.trunc) {
-                    bool drop = nc[0][i] > P.ns || (nm == 2 && nc[1][i] > P.ns);                       // main.rs:236, 302
-                    if (!drop) {
-                        // PE: both mates against a cutoff from seq1's length (main.rs:239-243); SE: from the quality string (:305)
-                        const float cf = (float)(nm == 2 ? r1.sl : r1.ql) * P.limit;
-                        const uint64_t cutoff = !(cf > 0.0f) ? 0 : (cf >= 18446744073709551616.0f ? ~0ull : (uint64_t)cf);
-                        drop = bc[0][i] >= cutoff || (nm == 2 && bc[1][i] >= cutoff);
+            // what does not depend on other records: too many N, too many low qualities (in parallel)
+            if (!P.trunc) {
+                alive.resize(n_ok ? n_ok : 1);
+                parallel_chunks(n_ok, threads, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t i = lo; i < hi; i++) {
+                        const FqRec &r1 = mrec[0][i];
+                        bool drop = nc[0][i] > P.ns || (nm == 2 && nc[1][i] > P.ns);                       // main.rs:236, 302
+                        if (!drop) {
+                            // PE: both mates against a cutoff from seq1's length (main.rs:239-243); SE: from the quality string (:305)
+                            const float cf = (float)(nm == 2 ? r1.sl : r1.ql) * P.limit;
+                            const uint64_t cutoff = !(cf > 0.0f) ? 0 : (cf >= 18446744073709551616.0f ? ~0ull : (uint64_t)cf);
+                            drop = bc[0][i] >= cutoff || (nm == 2 && bc[1][i] >= cutoff);
+                        }
+                        alive[i] = !drop;
                     }
-                    if (!drop && P.dedup) drop = !seen.insert(hs[i]);                                     // main.rs:244-250
-                    if (drop) continue;
+                });
+                if (P.dedup && n_ok) {                                                                     // main.rs:244-250
+                    dupf.resize(n_ok);
+                    std::string e;
+                    const uint64_t tdd = now_us();
+                    const int r = dedup(alive.data(), (uint32_t)n_ok, dupf.data(), e);
+                    t_dedup += now_us() - tdd;
+                    if (r != MF_OK) { set_err(r, e); abort_all(); break; }
                 }
-                if (P.trim) { budget += r1.sl; if (budget > P.trim) { stop = true; break; } }          // main.rs:254-259
+            }
+            for (uint64_t i = 0; i < n_ok; i++) {
+                if (!P.trunc && (!alive[i] || (P.dedup && dupf[i]))) continue;
+                if (P.trim) { budget += mrec[0][i].sl; if (budget > P.trim) { stop = true; break; } }    // main.rs:254-259
                 qb->keep[i] = 1; stats.kept++;
             }
             stats.total += n_ok;
             t_decide += now_us() - td0;
             qb->n = n_ok; qb->index = idx++;
             if (panicked) { stats.panicked = true; stop = true; }
+            const uint64_t tq0 = now_us();
             for (int m = 0; m < nm; m++) if (!q_write[m].push(qb)) { stop = true; break; }
+            t_wait_out += now_us() - tq0;
         }
         winding_down = true;
         for (auto &q : q_read) q.abort();
@@ -806,8 +799,8 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
 
     for (auto &t : th) t.join();
     if (timing)
-        fprintf(stderr, "[mf qualfilter] wall %.3f s | read %.3f %.3f | validate %.3f | scan (H2D, kernels, D2H) %.3f | decide %.3f | write %.3f %.3f\n",
-                (now_us() - t_start) / 1e6, t_read[0] / 1e6, t_read[1] / 1e6, t_check / 1e6, t_scan / 1e6, t_decide / 1e6, t_write[0] / 1e6, t_write[1] / 1e6);
+        fprintf(stderr, "[mf qualfilter] wall %.3f s | read %.3f %.3f | decision thread: waiting for input %.3f, validate %.3f, scan (H2D, kernels, D2H) %.3f, decide %.3f (of which dedup on the device %.3f), waiting for the writers %.3f | write %.3f %.3f\n",
+                (now_us() - t_start) / 1e6, t_read[0] / 1e6, t_read[1] / 1e6, t_wait_in / 1e6, t_check / 1e6, t_scan / 1e6, t_decide / 1e6, t_dedup / 1e6, t_wait_out / 1e6, t_write[0] / 1e6, t_write[1] / 1e6);
     return rc;
 }
 

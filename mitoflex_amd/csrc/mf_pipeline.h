@@ -26,12 +26,17 @@ struct QualParams {
     bool dedup = false, trunc = false;
 };
 struct QualSpan { uint32_t s_off, s_len, q_off, q_len; };     // same layout as the kernels' QualRec
-// counts (and, when hashes != nullptr, SipHash-1-3 of the sequences) of n records whose strings are offsets into text
+// counts of n records whose strings are offsets into text; with want_hashes the SipHash-1-3 values of the sequences are computed
+// too and KEPT BY THE CALLEE for the dedup call that follows for the same records
 using QualScanFn = std::function<int(const char *text, size_t len, const QualSpan *recs, uint32_t n, uint32_t quality,
-                                     uint32_t *n_count, uint32_t *bad_count, uint64_t *hashes, std::string &err)>;
+                                     uint32_t *n_count, uint32_t *bad_count, bool want_hashes, std::string &err)>;
+// de-duplication (main.rs:244-250) of the n records hashed by the last scan call, in file order over all calls: alive[i] = the record
+// reached the dedup test; dup[i] = 1 when an earlier live record (of this or an earlier call) carried the same hash value
+using QualDedupFn = std::function<int(const uint8_t *alive, uint32_t n, uint8_t *dup, std::string &err)>;
 struct QualStats { uint64_t kept = 0, total = 0; bool panicked = false; };
 // fq1 == nullptr: standard input; out2 == nullptr with fq2 set: standard output (reference: helper.rs:14-52)
 int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &p,
-                            int threads, uint64_t batch_reads, const QualScanFn &scan, QualStats &stats, std::string &err);
+                            int threads, uint64_t batch_reads, const QualScanFn &scan, const QualDedupFn &dedup, QualStats &stats,
+                            std::string &err);
 
 } // namespace mf

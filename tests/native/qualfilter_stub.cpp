@@ -9,6 +9,8 @@
 #include <string.h>
 #include <string>
 #include <thread>
+#include <unordered_set>
+#include <vector>
 
 static thread_local std::string t_err;
 
@@ -39,23 +41,30 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     if (!out1) { t_err = "out1 is NULL"; return MF_E_ARG; }
     if (start > end) { t_err = "start comes after end"; return MF_E_ARG; }
     if (quality == 0 || quality > 100) { t_err = "quality must be in 1..100"; return MF_E_ARG; }
-    mf::QualScanFn scan = [](const char *text, size_t, const mf::QualSpan *recs, uint32_t n, uint32_t q, uint32_t *n_count, uint32_t *bad_count,
-                             uint64_t *hashes, std::string &) -> int {
+    std::vector<uint64_t> last_hashes;                 // of the batch scanned last (the real library keeps them on the device)
+    std::unordered_set<uint64_t> seen;                 // the reference's HashSet<u64>, filled in file order
+    mf::QualScanFn scan = [&](const char *text, size_t, const mf::QualSpan *recs, uint32_t n, uint32_t q, uint32_t *n_count, uint32_t *bad_count,
+                              bool want_hashes, std::string &) -> int {
+        if (want_hashes) last_hashes.resize(n);
         for (uint32_t i = 0; i < n; i++) {
             const unsigned char *s = (const unsigned char *)text + recs[i].s_off, *qq = (const unsigned char *)text + recs[i].q_off;
             uint32_t nn = 0, nb = 0;
             for (uint32_t j = 0; j < recs[i].s_len; j++) nn += s[j] == 'N';
             for (uint32_t j = 0; j < recs[i].q_len; j++) nb += qq[j] <= q;
             n_count[i] = nn; bad_count[i] = nb;
-            if (hashes) { std::string m((const char *)s, recs[i].s_len); m.push_back((char)0xff); hashes[i] = siphash13((const unsigned char *)m.data(), m.size()); }
+            if (want_hashes) { std::string m((const char *)s, recs[i].s_len); m.push_back((char)0xff); last_hashes[i] = siphash13((const unsigned char *)m.data(), m.size()); }
         }
+        return MF_OK;
+    };
+    mf::QualDedupFn dedup_fn = [&](const uint8_t *alive, uint32_t n, uint8_t *dup, std::string &) -> int {
+        for (uint32_t i = 0; i < n; i++) dup[i] = alive[i] ? !seen.insert(last_hashes[i]).second : 0;      // main.rs:244-250, literally
         return MF_OK;
     };
     mf::QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
     P.dedup = dedup != 0; P.trunc = truncate_only != 0;
     mf::QualStats qs; std::string perr;
     const char *b = getenv("MF_BATCH_READS");
-    const int rc = mf::run_qualfilter_pipeline(fq1, fq2, out1, out2, P, 6, b ? strtoull(b, nullptr, 10) : 2000000, scan, qs, perr);
+    const int rc = mf::run_qualfilter_pipeline(fq1, fq2, out1, out2, P, 6, b ? strtoull(b, nullptr, 10) : 2000000, scan, dedup_fn, qs, perr);
     if (rc != MF_OK) { t_err = perr; return rc; }
     if (kept) *kept = qs.kept;
     if (total) *total = qs.total;

@@ -164,6 +164,7 @@ def _check_bulk(cli, tmp_path, case, monkeypatch):
     mk = _mk()
     monkeypatch.setenv("MF_BATCH_READS", "3001")           # several batches, dedup/trim state carried across
     monkeypatch.setenv("MF_PARSE_SEG", "40000")
+    monkeypatch.setenv("MF_DEDUP_LOG2_SLOTS", "6")         # the device's dedup set starts with 64 slots: it is doubled and rehashed again and again
     s1, s2, q1, q2 = mk.rand_pair(case["n"], case["seed"], L=case["L"])
     t1, t2 = mk.fq(s1, q1, "a"), mk.fq(s2, q2, "b")
     rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if "{in2}" in case["argv"] else None, case["argv"])
@@ -202,6 +203,7 @@ def _check_random(cli, tmp_path, monkeypatch):
             argv += ["--truncate_only"]
         monkeypatch.setenv("MF_BATCH_READS", str(rng.choice([1, 7, 64, 2000000])))
         monkeypatch.setenv("MF_PARSE_SEG", str(rng.choice([64, 1000, 1 << 25])))
+        monkeypatch.setenv("MF_DEDUP_LOG2_SLOTS", str(rng.choice([4, 24])))
         rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if pe else None, argv)
         b1, b2 = t1.encode("latin-1"), t2.encode("latin-1")
         erc, e1, e2 = ref.run(list(argv), lambda p: b1 if "in1" in p else b2)
