@@ -636,6 +636,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
     // (stride-8 geometries, k < 28: twice the samples, several times the records -- measured faster through the candidate bitmap)
+    // (round 3, after the stage-1 fields were fixed for 14-base samples: still the faster pass for stride 8 -- k = 21 0.299 vs 0.302-0.309 ms, k = 25 0.278-0.280 vs 0.281-0.283)
     if (screened && pass_kind() != 1 && !r->prefer_split && thr == 1 && !count_all && (S.stride == 16 || pass_kind() == 2)) {
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish

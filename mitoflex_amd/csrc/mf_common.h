@@ -61,6 +61,12 @@ MF_HD uint32_t bloom_hash(uint32_t smer) { return (smer & 0xFFFFFFu) * 0x9E3779u
 // false positives for 14-base samples, 0.056 % for 16-base ones.  (Rounds 1-2 took the fields from the bytes of (h:smer) >> 11:
 // the same 0.05 % for 16-base samples, but 0.27 % for 14-base ones -- byte 2 was smer[31:27], one live bit when s = 14 -- and one
 // more instruction per sample.)
+// stage-1 block index: idx_bits = log2w - 2 bits of h that end just below bit 2s, i.e. h[2s-1 : 2s-idx_bits] (for s = 16: the top
+// bits).  h mod 2^(2s) only depends on the s-mer's own 2s bits even when the value hashed carries the following bases in the
+// bits above them (the sum and the product only carry upwards), and the four fields sit below bit 24 <= 2s: so the screen
+// hashes a sample AS IT LIES IN THE WORD, without masking it to 2s bits first -- one instruction per sample less for s < 16.
+// (Simulated, 14-base samples: 0.065 % false positives against 0.052 % with the top bits.)  s >= 12 (screen_geom_for).
+MF_HD uint32_t stage1_index_lo(int s, uint32_t log2w) { const uint32_t ib = log2w - 2; return (uint32_t)(2 * s) >= ib ? (uint32_t)(2 * s) - ib : 0u; }
 MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return ((i < 3 ? smer >> (8 * i) : h >> 8)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
 constexpr int STAGE2_K = 4;

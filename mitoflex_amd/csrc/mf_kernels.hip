@@ -136,8 +136,7 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
     const uint64_t chunk = (uint64_t)blockDim.x * U;
     const uint64_t n_chunks = R.n_vec / chunk;          // n_vec is padded to a whole number of chunks
-    const uint32_t blk_shift = 32 - (S.bloom_log2w - 2);
-    const uint32_t smask = S.smask;
+    const uint32_t idx_lo = stage1_index_lo(S.s, S.bloom_log2w), idx_bits = S.bloom_log2w - 2;
     const uint64_t cstep = gridDim.x;
     ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
 
@@ -164,9 +163,10 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
             for (int q = 0; q < 4; q++) {
 #pragma unroll
                 for (int j = 0; j < SPW; j++) {
-                    const uint32_t sm = (SPW == 1) ? (MASKED ? wv[q] & smask : wv[q]) : (alignbit(wv[q + 1], wv[q], 16u * j) & smask);
+                    // the sample as it lies in the stream: for s < 16 the bases behind it ride along in the bits above 2s (stage1_index_lo)
+                    const uint32_t sm = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
                     const uint32_t h = bloom_hash(sm);
-                    const uint4 blk = s_tab4[h >> blk_shift];
+                    const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];        // one v_bfe_u32
                     const uint32_t t = lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);   // stage1_field
                     hitmask = alignbit(hitmask, t, 31);             // (hitmask << 1) | sign(t)
                 }
@@ -1090,10 +1090,10 @@ __global__ void materialize2_kernel(BaitView B, int k, const uint32_t *postab, u
     keys[2 * s] = kv.lo; keys[2 * s + 1] = kv.hi;
 }
 
-__device__ __forceinline__ void stage1_insert(uint32_t sm, uint32_t *bloom, uint32_t log2w)
+__device__ __forceinline__ void stage1_insert(uint32_t sm, int s, uint32_t *bloom, uint32_t log2w)
 {
     const uint32_t h = bloom_hash(sm);
-    uint32_t *blk = bloom + 4 * (size_t)(h >> (32 - (log2w - 2)));
+    uint32_t *blk = bloom + 4 * (size_t)((h >> stage1_index_lo(s, log2w)) & ((1u << (log2w - 2)) - 1));
 #pragma unroll
     for (int i = 0; i < 4; i++) atomicOr(&blk[i], 1u << stage1_bit(sm, h, i));
 }
@@ -1120,7 +1120,7 @@ __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t
     uint32_t fwd = alignbit(B.words[wi + 1], B.words[wi], sh);
     if (s < 16) fwd &= (1u << (2 * s)) - 1;
     const uint32_t rc = revcomp_s(fwd, s);
-    stage1_insert(fwd, bloom, log2w); stage1_insert(rc, bloom, log2w);
+    stage1_insert(fwd, s, bloom, log2w); stage1_insert(rc, s, bloom, log2w);
     stab_insert(fwd, stab, stab_mask, has_ones); stab_insert(rc, stab, stab_mask, has_ones);
     const uint32_t cn = fwd < rc ? fwd : rc;
     const uint32_t ha = stage2_hash_a(cn), hb = stage2_hash_b(cn);
