@@ -123,9 +123,9 @@ __device__ __forceinline__ uint32_t lshl_by_byte(uint32_t amt, uint32_t data)
 // (i = (u*4+q)*SPW+j) is bit NS-1-i of hitmask, NS = U*4*SPW.
 struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pad; };
 
-// SPW: samples per word (stride 16 -> 1, stride 8 -> 2).  MASKED: stride 16 with s < 16 (28 <= k <= 30): the sample is
-// the low 2s bits of the word.
-template <int SPW, int U, bool MASKED>
+// SPW: samples per word (stride 16 -> 1, stride 8 -> 2).  For s < 16 a sample is the low 2s bits of what is hashed; the bits
+// above them ride along (stage1_index_lo in mf_common.h).
+template <int SPW, int U>
 __global__ void __launch_bounds__(1024)
 screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
               uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -1429,7 +1429,7 @@ template <auto Kernel> static void raise_lds_limit_once(size_t max_bytes)
     done.fetch_or(bit, std::memory_order_release);
 }
 
-template <int SPW, bool MASKED>
+template <int SPW>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
@@ -1437,8 +1437,8 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, S.stride);
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
-    raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U, MASKED>>(128 * 1024 + 16);
-    MF_LAUNCH((screen_kernel<SPW, SCREEN_U, MASKED>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
+    raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U>>(128 * 1024 + 16);
+    MF_LAUNCH((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
               static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
 }
 
@@ -1458,9 +1458,8 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                          const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
-    if (S.stride == 16 && S.s == 16) launch_screen_spw<1, false>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
-    else if (S.stride == 16) launch_screen_spw<1, true>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
-    else launch_screen_spw<2, true>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
     return hipGetLastError();
 }
 

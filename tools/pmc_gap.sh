@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the time between screen_kernel<1, 2, false> and the bare read loop of its own shape goes: the same counters for both
+# Where the time between screen_kernel<1, 2> and the bare read loop of its own shape goes: the same counters for both
 # (rocprofv3 --pmc, one small group of counters per pass; serial passes so that every screen launch has the device to itself).
 #   tools/pmc_gap.sh  ->  gpurun_out/pmc_gap/summary.txt
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_gap; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
