@@ -327,7 +327,7 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
     uint32_t r4 = r4_in | z;                    // 4 * (index of the dword nd holds), low 32 bits: the ring address and, by difference, the dwords taken
     uint32_t n = 0, end = W_MORE;
     uint32_t la = lds_off(L.sym) + (lane == 0 ? 0 : (ROUND + 2 * lane) * 4);
-    const uint32_t step1 = lane == 0 ? 4 : 0, step2 = 2 * step1;
+    const uint32_t step1 = lane == 0 ? 4 : 0, lane4 = lane * 4;
     // refill below 30 valid bits (so that the shift of the incoming dword, bc + 2, stays below 32): 30 <= bc <= 61 afterwards
 #define GZ_REFILL() do { if (GZ_UNI(bc < 30u)) { lo |= nd << (bc + 2); hi |= nd >> (30 - bc); bc += 32; r4 += 4; nd = L.ring[(r4 >> 2) & (RING - 1)] | z; } } while (0)
 #define GZ_DROP(x) do { const uint32_t x_ = (x); lo = __builtin_amdgcn_alignbit(hi, lo, x_); hi >>= (x_ & 31u); bc -= x_; } while (0)
@@ -335,88 +335,126 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
     const uint32_t k_len = 0xA0000000u, k_sign = 0x80000000u, k_limit = STG - 260 - 2 * ROUND;
     static_assert(offsetof(Lds, lit) == 0 && offsetof(Lds, ring) == 4096 && offsetof(Lds, dist) == 6144, "offsets used by the assembly");
     while (n < ROUND - 1) {
-        uint32_t e, t, d, x, lenm3, reason;
+        uint32_t e, t, d, lenm3, reason;
         n = (uint32_t)__builtin_amdgcn_readfirstlane(n);
         // The walk proper.  Literal entries two lookups per pass; a length entry takes its extra bits, the distance code and its
         // extra bits and leaves one list entry; the refill (ring read of the NEXT dword issued when the current one is taken)
         // is part of the loop.  It leaves for what is rare: reason 0 = the list (or the staging buffer) is full; 2 = e is an
         // end of block, a long code or invalid, nothing of it dropped; 3 = d is a long or invalid distance code, the length
         // (less 3, in lenm3) already taken.
+        // Inside the loop everything that is serial is SCALAR: bit buffer (s[20:21], two bits up), bit count (s22), ring position
+        // (s26), the fields of a table entry, the list entry of a match.  A drop is one s_lshr_b64 (its shift operand takes the
+        // low six bits of the entry as they are) and a subtraction.  The two first-level tables are copied from LDS into 24 vector
+        // registers (1024 + 512 entries = 16 + 8 registers of 64 lanes) when the loop is entered, and a lookup is a register read:
+        // entry i sits in lane i & 63 of register i >> 6 -- the loop runs in GPR index mode (source 0 relative: s_set_gpr_idx_idx
+        // picks the register) and v_readlane picks the lane.  EXEC is lane 0 alone in the loop, so the few vector instructions
+        // left (entry to a vector register, list store, list address) are lane 0's; none of them has a vector register as source 0.
 #define GZ_A_REFILL \
-            "v_add_u32 %[t], 2, %[bc]\n\t" \
-            "v_lshl_or_b32 %[lo], %[nd], %[t], %[lo]\n\t" \
-            "v_sub_u32 %[t], 30, %[bc]\n\t" \
-            "v_lshrrev_b32 %[t], %[t], %[nd]\n\t" \
-            "v_or_b32 %[hi], %[hi], %[t]\n\t" \
-            "v_add_u32 %[bc], 32, %[bc]\n\t" \
-            "v_add_u32 %[r4], 4, %[r4]\n\t" \
-            "v_and_b32 %[t], 0x7fc, %[r4]\n\t" \
+            "s_waitcnt lgkmcnt(0)\n\t" \
+            "s_set_gpr_idx_idx s25\n\t" \
+            "v_readfirstlane_b32 s24, %[nd]\n\t" \
+            "s_add_u32 s28, s22, 2\n\t" \
+            "s_lshl_b64 s[30:31], s[24:25], s28\n\t" \
+            "s_or_b64 s[20:21], s[20:21], s[30:31]\n\t" \
+            "s_add_u32 s22, s22, 32\n\t" \
+            "s_add_u32 s26, s26, 4\n\t" \
+            "s_and_b32 s28, s26, 0x7fc\n\t" \
+            "v_mov_b32 %[t], s28\n\t" \
             "ds_read_b32 %[nd], %[t] offset:4096\n"
-#define GZ_A_DROP(r) \
-            "v_alignbit_b32 %[lo], %[hi], %[lo], %[" r "]\n\t" \
-            "v_lshrrev_b32 %[hi], %[" r "], %[hi]\n\t" \
-            "v_sub_u32_sdwa %[bc], %[bc], %[" r "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+#define GZ_A_DROP_CODE \
+            "s_lshr_b64 s[20:21], s[20:21], s27\n\t" \
+            "s_and_b32 s28, s27, 0xff\n\t" \
+            "s_sub_u32 s22, s22, s28\n\t"
+#define GZ_A_DROP_X \
+            "s_lshr_b64 s[20:21], s[20:21], s29\n\t" \
+            "s_sub_u32 s22, s22, s29\n\t"
+#define GZ_A_LOOKUP(regbits, first) \
+            "s_bfe_u32 s28, s20, " regbits "\n\t" \
+            "s_bfe_u32 s23, s20, 0x60002\n\t" \
+            "s_set_gpr_idx_idx s28\n\t" \
+            "v_readlane_b32 s27, " first ", s23\n\t" \
+            "s_cmp_lt_i32 s27, 0\n\t"
+        /* x extra bits (count in s29) from the bit buffer into s28 */
+#define GZ_A_EXTRA \
+            "s_lshr_b32 s28, s20, 2\n\t" \
+            "s_bfm_b32 s35, s29, 0\n\t" \
+            "s_and_b32 s28, s28, s35\n\t"
+#define GZ_A_LOAD_ROW(reg, off) "ds_read_b32 " reg ", %[lane4] offset:" off "\n\t"
         asm volatile(
-            "s_mov_b32 %[reason], 0\n"
+            GZ_A_LOAD_ROW("v104", "0") GZ_A_LOAD_ROW("v105", "256") GZ_A_LOAD_ROW("v106", "512") GZ_A_LOAD_ROW("v107", "768")
+            GZ_A_LOAD_ROW("v108", "1024") GZ_A_LOAD_ROW("v109", "1280") GZ_A_LOAD_ROW("v110", "1536") GZ_A_LOAD_ROW("v111", "1792")
+            GZ_A_LOAD_ROW("v112", "2048") GZ_A_LOAD_ROW("v113", "2304") GZ_A_LOAD_ROW("v114", "2560") GZ_A_LOAD_ROW("v115", "2816")
+            GZ_A_LOAD_ROW("v116", "3072") GZ_A_LOAD_ROW("v117", "3328") GZ_A_LOAD_ROW("v118", "3584") GZ_A_LOAD_ROW("v119", "3840")
+            GZ_A_LOAD_ROW("v120", "6144") GZ_A_LOAD_ROW("v121", "6400") GZ_A_LOAD_ROW("v122", "6656") GZ_A_LOAD_ROW("v123", "6912")
+            GZ_A_LOAD_ROW("v124", "7168") GZ_A_LOAD_ROW("v125", "7424") GZ_A_LOAD_ROW("v126", "7680") GZ_A_LOAD_ROW("v127", "7936")
+            "v_readfirstlane_b32 s20, %[lo]\n\t"
+            "v_readfirstlane_b32 s21, %[hi]\n\t"
+            "v_readfirstlane_b32 s22, %[bc]\n\t"
+            "v_readfirstlane_b32 s26, %[r4]\n\t"
+            "v_readfirstlane_b32 s34, %[mtot]\n\t"
+            "s_mov_b32 s25, 0\n\t"
+            "s_mov_b32 s27, 0\n\t"
+            "s_mov_b32 s38, 0\n\t"
+            "s_mov_b32 %[reason], 0\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 s[36:37], exec\n\t"
+            "s_mov_b64 exec, 1\n\t"
+            "s_set_gpr_idx_on s25, gpr_idx(SRC0)\n"
             ".Lgz_top_%=:\n\t"
-            "v_cmp_gt_u32 vcc, 30, %[bc]\n\t"
-            "s_cbranch_vccz .Lgz_pair_%=\n\t"
+            "s_cmp_lt_u32 s22, 30\n\t"
+            "s_cbranch_scc0 .Lgz_pair_%=\n\t"
             GZ_A_REFILL
             ".Lgz_pair_%=:\n\t"
-            "v_and_b32 %[t], 0xffc, %[lo]\n\t"
-            "ds_read_b32 %[e], %[t]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cmp_gt_i32 vcc, 0, %[e]\n\t"
-            "s_cbranch_vccnz .Lgz_nl1_%=\n\t"
+            GZ_A_LOOKUP("0x40008", "v104")
+            "s_cbranch_scc1 .Lgz_nl1_%=\n\t"
+            "v_mov_b32 %[e], s27\n\t"
             "ds_write_b32 %[la], %[e]\n\t"
-            GZ_A_DROP("e")
-            "v_and_b32 %[t], 0xffc, %[lo]\n\t"
-            "ds_read_b32 %[e], %[t]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cmp_gt_i32 vcc, 0, %[e]\n\t"
-            "s_cbranch_vccnz .Lgz_nl2_%=\n\t"
+            GZ_A_DROP_CODE
+            GZ_A_LOOKUP("0x40008", "v104")
+            "s_cbranch_scc1 .Lgz_nl2_%=\n\t"
+            "v_mov_b32 %[e], s27\n\t"
             "ds_write_b32 %[la], %[e] offset:4\n\t"
-            "v_add_u32 %[la], %[la], %[step2]\n\t"
-            GZ_A_DROP("e")
+            "v_add_u32 %[la], 8, %[la]\n\t"
+            GZ_A_DROP_CODE
             "s_add_u32 %[n], %[n], 2\n\t"
             "s_cmp_lt_u32 %[n], 63\n\t"
             "s_cbranch_scc1 .Lgz_top_%=\n\t"
             "s_branch .Lgz_done_%=\n"
             ".Lgz_nl2_%=:\n\t"
-            "v_add_u32 %[la], %[la], %[step1]\n\t"
+            "v_add_u32 %[la], 4, %[la]\n\t"
             "s_add_u32 %[n], %[n], 1\n"
             ".Lgz_nl1_%=:\n\t"
-            "v_cmp_gt_u32 vcc, %[klen], %[e]\n\t"
-            "s_cbranch_vccz .Lgz_other_%=\n\t"
-            GZ_A_DROP("e")
-            "v_bfe_u32 %[x], %[e], 24, 3\n\t"
-            "v_bfe_u32 %[t], %[lo], 2, %[x]\n\t"
-            "v_bfe_u32 %[len], %[e], 8, 8\n\t"
-            "v_add_u32 %[len], %[len], %[t]\n\t"
-            GZ_A_DROP("x")
-            "v_cmp_gt_u32 vcc, 30, %[bc]\n\t"
-            "s_cbranch_vccz .Lgz_dist_%=\n\t"
+            "s_cmp_lt_u32 s27, %[klen]\n\t"
+            "s_cbranch_scc0 .Lgz_other_%=\n\t"
+            GZ_A_DROP_CODE
+            "s_bfe_u32 s29, s27, 0x30018\n\t"
+            GZ_A_EXTRA
+            "s_bfe_u32 s38, s27, 0x80008\n\t"
+            "s_add_u32 s38, s38, s28\n\t"
+            GZ_A_DROP_X
+            "s_cmp_lt_u32 s22, 30\n\t"
+            "s_cbranch_scc0 .Lgz_dist_%=\n\t"
             GZ_A_REFILL
             ".Lgz_dist_%=:\n\t"
-            "v_and_b32 %[t], 0x7fc, %[lo]\n\t"
-            "ds_read_b32 %[d], %[t] offset:6144\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cmp_gt_i32 vcc, 0, %[d]\n\t"
-            "s_cbranch_vccnz .Lgz_dlong_%=\n\t"
-            GZ_A_DROP("d")
-            "v_bfe_u32 %[x], %[d], 24, 4\n\t"
-            "v_bfe_u32 %[t], %[lo], 2, %[x]\n\t"
-            "v_bfe_u32 %[d], %[d], 8, 15\n\t"
-            "v_add_u32 %[d], %[d], %[t]\n\t"
-            GZ_A_DROP("x")
-            "v_lshl_or_b32 %[t], %[d], 9, %[len]\n\t"
-            "v_or_b32 %[t], %[sign], %[t]\n\t"
+            GZ_A_LOOKUP("0x30008", "v120")
+            "s_cbranch_scc1 .Lgz_dlong_%=\n\t"
+            GZ_A_DROP_CODE
+            "s_bfe_u32 s29, s27, 0x40018\n\t"
+            GZ_A_EXTRA
+            "s_bfe_u32 s33, s27, 0xf0008\n\t"
+            "s_add_u32 s33, s33, s28\n\t"
+            GZ_A_DROP_X
+            "s_lshl_b32 s33, s33, 9\n\t"
+            "s_or_b32 s33, s33, s38\n\t"
+            "s_or_b32 s33, s33, %[sign]\n\t"
+            "v_mov_b32 %[t], s33\n\t"
             "ds_write_b32 %[la], %[t]\n\t"
-            "v_add_u32 %[la], %[la], %[step1]\n\t"
-            "v_add3_u32 %[mtot], %[mtot], %[len], 3\n\t"
+            "v_add_u32 %[la], 4, %[la]\n\t"
+            "s_add_u32 s34, s34, s38\n\t"
+            "s_add_u32 s34, s34, 3\n\t"
             "s_add_u32 %[n], %[n], 1\n\t"
-            "v_cmp_lt_u32 vcc, %[limit], %[mtot]\n\t"
-            "s_cbranch_vccnz .Lgz_done_%=\n\t"
+            "s_cmp_gt_u32 s34, %[limit]\n\t"
+            "s_cbranch_scc1 .Lgz_done_%=\n\t"
             "s_cmp_lt_u32 %[n], 63\n\t"
             "s_cbranch_scc1 .Lgz_top_%=\n\t"
             "s_branch .Lgz_done_%=\n"
@@ -425,13 +463,32 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
             "s_branch .Lgz_done_%=\n"
             ".Lgz_other_%=:\n\t"
             "s_mov_b32 %[reason], 2\n"
-            ".Lgz_done_%=:\n"
+            ".Lgz_done_%=:\n\t"
+            "s_set_gpr_idx_off\n\t"
+            "s_mov_b64 exec, s[36:37]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_readfirstlane_b32 s24, %[nd]\n\t"
+            "v_mov_b32 %[nd], s24\n\t"
+            "v_mov_b32 %[lo], s20\n\t"
+            "v_mov_b32 %[hi], s21\n\t"
+            "v_mov_b32 %[bc], s22\n\t"
+            "v_mov_b32 %[r4], s26\n\t"
+            "v_mov_b32 %[mtot], s34\n\t"
+            "v_mov_b32 %[e], s27\n\t"
+            "v_mov_b32 %[d], s27\n\t"
+            "v_mov_b32 %[len], s38\n"
             : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [nd] "+v"(nd), [r4] "+v"(r4), [la] "+v"(la), [mtot] "+v"(mtot), [n] "+s"(n),
-              [e] "=&v"(e), [t] "=&v"(t), [d] "=&v"(d), [x] "=&v"(x), [len] "=&v"(lenm3), [reason] "=&s"(reason)
-            : [step1] "v"(step1), [step2] "v"(step2), [klen] "s"(k_len), [sign] "s"(k_sign), [limit] "s"(k_limit)
-            : "vcc", "scc", "memory");
+              [e] "=&v"(e), [t] "=&v"(t), [d] "=&v"(d), [len] "=&v"(lenm3), [reason] "=&s"(reason)
+            : [lane4] "v"(lane4), [klen] "s"(k_len), [sign] "s"(k_sign), [limit] "s"(k_limit)
+            : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s33", "s34", "s35", "s36", "s37", "s38",
+              "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
+              "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+#undef GZ_A_LOAD_ROW
+#undef GZ_A_EXTRA
+#undef GZ_A_LOOKUP
+#undef GZ_A_DROP_CODE
+#undef GZ_A_DROP_X
 #undef GZ_A_REFILL
-#undef GZ_A_DROP
         if (reason == 0) break;
         if (reason == 2) {
             GZ_REFILL();                             // (a second lookup may leave as few as 20 bits; a long code and its extra bits need 20)
