@@ -28,6 +28,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
+#include <errno.h>
 #include <unistd.h>
 #include <vector>
 
@@ -113,24 +114,23 @@ template <class T> struct DevBuf {
 };
 
 struct Mapped {
-    const uint8_t *p = nullptr; size_t n = 0;
-    ~Mapped() { if (p) munmap(const_cast<uint8_t *>(p), n); }
+    const uint8_t *p = nullptr; size_t n = 0; int fd = -1;          // (the descriptor stays open: the uploader reads through it)
+    ~Mapped() { if (p) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) ::close(fd); }
     bool open(const char *path, bool &regular)
     {
         regular = false;
-        const int fd = ::open(path, O_RDONLY);
+        fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); return true; }
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return true;
         regular = true;
         n = (size_t)st.st_size;
         if (n) {
             void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { ::close(fd); n = 0; return false; }
+            if (m == MAP_FAILED) { n = 0; return false; }
             p = (const uint8_t *)m;
             madvise(m, n, MADV_SEQUENTIAL);
         }
-        ::close(fd);
         return true;
     }
 };
@@ -151,9 +151,9 @@ public:
         for (auto &s : stage_) if (s) (void)hipHostFree(s);
         if (st_) (void)hipStreamDestroy(st_);
     }
-    int start(const uint8_t *src, size_t n, uint8_t *dst, int device, std::string &err)
+    int start(const uint8_t *src, int fd, size_t n, uint8_t *dst, int device, std::string &err)
     {
-        src_ = src; n_ = n; dst_ = dst; device_ = device;
+        src_ = src; fd_ = fd; n_ = n; dst_ = dst; device_ = device;
         const size_t np = (n + PIECE - 1) / PIECE;
         ev_.assign(np, nullptr);
         for (auto &e : ev_) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -189,15 +189,25 @@ private:
     {
         if (hipSetDevice(device_) != hipSuccess) { fail_(); return; }
         const size_t np = ev_.size();
-        const int nthr = 4;
+        const int nthr = (int)std::min<uint64_t>(16, std::max<uint64_t>(1, env_u64("MF_UPLOAD_THREADS", 8)));
         for (size_t i = 0; i < np && !stop_; i++) {
             const int b = (int)(i & 1);
             if (i >= 2 && hipEventSynchronize(free_ev_[b]) != hipSuccess) { fail_(); return; }       // the copy that read this staging buffer is done
             const size_t off = i * PIECE, len = std::min(PIECE, n_ - off);
-            {   // page-cache -> pinned memory on a few threads (one memcpy stream does ~5 GB/s)
+            {   // page cache -> pinned memory on a few threads, with pread: reading the mapping instead takes a fault per 64 KiB and
+                // does 3 GB/s a thread, and with four of those the whole path ran at the 11 GB/s of this copy (a 4.9 GB .gz in 0.44 s
+                // whatever the decoder did); the mapping stays for what the host looks at (headers, trailers, gaps)
+                auto part = [&](int t) {
+                    size_t a = len * t / nthr; const size_t e = len * (t + 1) / nthr;
+                    while (a < e) {
+                        const ssize_t got = fd_ >= 0 ? pread(fd_, stage_[b] + a, e - a, (off_t)(off + a)) : -1;
+                        if (got <= 0) { if (got < 0 && errno == EINTR) continue; memcpy(stage_[b] + a, src_ + off + a, e - a); break; }     // (a file that cannot be read this way: through the mapping)
+                        a += (size_t)got;
+                    }
+                };
                 std::vector<std::thread> th;
-                for (int t = 1; t < nthr; t++) th.emplace_back([&, t] { const size_t a = len * t / nthr, e = len * (t + 1) / nthr; memcpy(stage_[b] + a, src_ + off + a, e - a); });
-                memcpy(stage_[b], src_ + off, len / nthr);
+                for (int t = 1; t < nthr; t++) th.emplace_back(part, t);
+                part(0);
                 for (auto &x : th) x.join();
             }
             if (hipMemcpyAsync(dst_ + off, stage_[b], len, hipMemcpyHostToDevice, st_) != hipSuccess || hipEventRecord(ev_[i], st_) != hipSuccess ||
@@ -208,7 +218,7 @@ private:
         (void)hipStreamSynchronize(st_);
     }
     void fail_() { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; } cv_.notify_all(); }
-    const uint8_t *src_ = nullptr; size_t n_ = 0; uint8_t *dst_ = nullptr; int device_ = 0;
+    const uint8_t *src_ = nullptr; int fd_ = -1; size_t n_ = 0; uint8_t *dst_ = nullptr; int device_ = 0;
     hipStream_t st_ = nullptr; uint8_t *stage_[2] = {nullptr, nullptr}; hipEvent_t free_ev_[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_;
     std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; bool failed_ = false; std::atomic<bool> stop_{false};
@@ -220,7 +230,7 @@ private:
 // link stream runs only there.  Where CU masks are not to be had, ordinary streams.  The sets are made once and handed from
 // call to call: destroying a CU-masked stream right after use was seen to hang inside the runtime (ROCm 7.2), and they cost a
 // few milliseconds to make.
-constexpr uint32_t GZ_NSTREAM = 7;
+constexpr uint32_t GZ_NSTREAM = 10;
 struct StreamSet { int device = -1; hipStream_t sd[GZ_NSTREAM] = {}, link = nullptr, rest = nullptr; };
 class StreamSets {
 public:
@@ -236,7 +246,12 @@ public:
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
         const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
         std::vector<uint32_t> m_dec((size_t)words, 0), m_link((size_t)words, 0);
-        for (int b = 0; b < n_cu; b++) (b >= n_cu - 8 ? m_link : m_dec)[b / 32] |= 1u << (b % 32);
+        // A decode wavefront holds 128 vector registers and 9.9 KB of LDS for tens of milliseconds, sixteen of them fill a CU to the
+        // last register: whatever else has to run meanwhile -- the link step, marker resolution, CRC, the consumer's line index and
+        // pack kernels, all short and all on some host thread's critical path -- needs CUs of its own.  Four per XCD by default.
+        int reserve = (int)env_u64("MF_GZDEV_RESERVED_CUS", 32);
+        reserve = std::max(8, std::min(n_cu / 2, reserve)) & ~7;
+        for (int b = 0; b < n_cu; b++) (b >= n_cu - reserve ? m_link : m_dec)[b / 32] |= 1u << (b % 32);
         const bool masks = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
         bool ok = true;
         for (auto &q : s->sd)
@@ -264,7 +279,7 @@ struct Arena {
 };
 
 // a range of an input's text that has become available, in order
-struct TextPiece { uint64_t T0 = 0, len = 0; bool last = false; };
+struct TextPiece { uint64_t T0 = 0, len = 0; bool last = false; uint64_t est_total = 0; };      // est_total: the file's whole text, as far as one can tell now
 
 // ---- one gzip file decoded on the device (runs on the mate's producer thread, on its own streams)
 class GzStream {
@@ -416,6 +431,10 @@ public:
         next_slab_ = k + 1;
         if (next_slab_ == n_slabs_ && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
         out.T0 = T0; out.len = h_chain_->total - T0; out.last = done_;
+        {   // the text so far over the compressed bytes it came from, times the file
+            const double in = (double)std::min<uint64_t>(size_, base_byte_ + (uint64_t)hi * chunk_);
+            out.est_total = done_ ? h_chain_->total : (uint64_t)((double)h_chain_->total * ((double)size_ / std::max(1.0, in)) * 1.03);
+        }
         return MF_OK;
     }
     uint64_t gap_bytes() const { return gap_bytes_; }
@@ -525,7 +544,7 @@ private:
     uint32_t cps_ = 0, n_chunks_ = 0, n_slabs_ = 0, next_slab_ = 0, launched_ = 0;
     DevBuf<GzChunk> d_chunks_; DevBuf<uint64_t> d_out_off_; DevBuf<GzChain> d_chain_; DevBuf<uint32_t> d_crc_;
     GzChain *h_chain_ = nullptr; std::vector<GzChunk> h_chunks_; std::vector<uint32_t> h_crc_;
-    static constexpr uint32_t NSYM = 9, NSTREAM = GZ_NSTREAM;      // decode kernels in flight: enough wavefronts to fill the chip (a slab is a few hundred chunks)
+    static constexpr uint32_t NSYM = 12, NSTREAM = GZ_NSTREAM;      // decode kernels in flight: enough wavefronts to fill the chip (a slab is a few hundred chunks)
     Sym sym_[NSYM]; StreamSet *streams_ = nullptr; hipStream_t sd_[NSTREAM] = {}, sp_ = nullptr, sr_ = nullptr; hipEvent_t ev_link_ = nullptr;     // sp_: the link stream (reserved CUs); sr_: resolve and CRC (the whole chip)
     bool in_member_ = false, done_ = false;
     uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
@@ -579,10 +598,12 @@ struct Mate {
 };
 
 // grow a device buffer, keeping what is in it (bytes)
-template <class T> int grow_keep(T *&p, size_t &cap_bytes, size_t used_bytes, size_t need_bytes, hipStream_t st, std::string &err)
+// room for need_bytes (must_bytes, when given, is what has to fit now: need_bytes is then a wish -- the estimate for the whole file --
+// that only counts when a new allocation has to be made anyway)
+template <class T> int grow_keep(T *&p, size_t &cap_bytes, size_t used_bytes, size_t need_bytes, hipStream_t st, std::string &err, size_t must_bytes = 0)
 {
-    if (need_bytes <= cap_bytes && p) return MF_OK;
-    const size_t cap = need_bytes + need_bytes / 2 + 4096;
+    if ((must_bytes ? must_bytes : need_bytes) <= cap_bytes && p) return MF_OK;
+    const size_t cap = must_bytes ? std::max(need_bytes + need_bytes / 16, must_bytes + must_bytes / 2) + 4096 : need_bytes + need_bytes / 2 + 4096;
     T *q = nullptr;
     DCHK(hipMalloc(&q, cap));
     if (p) { if (used_bytes) DCHK(hipMemcpyAsync(q, p, used_bytes, hipMemcpyDeviceToDevice, st)); DCHK(hipStreamSynchronize(st)); g_trash.add(p); }      // (hipMalloc'ed: an mf_reads owns these)
@@ -617,7 +638,7 @@ struct Ingest {
             for (uint64_t T0 = 0; !rc && T0 < M.map.n && !M.stop;) {
                 const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
                 if (!M.up.wait_for(st, T1) || hipStreamSynchronize(st) != hipSuccess) { rc = MF_E_HIP; err = "upload of " + M.path + " failed"; break; }
-                TextPiece t; t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n;
+                TextPiece t; t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n; t.est_total = M.map.n;
                 { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(t); }
                 M.cv.notify_all();
                 T0 = T1;
@@ -679,9 +700,14 @@ struct Ingest {
             const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
             // room in the file's read set: words (with the screen's padding), offsets, then pack behind what is there
             const uint64_t words_after = (M.bases + nb + 15) / 16;
-            int rc = grow_keep(R->d_words, R->cap_words, ((M.bases + 15) / 16) * 4, padded_words_for(words_after) * 4, sp, err);
+            // (the read set is sized for the whole file from what this piece says about it -- bases and records per byte of text --
+            // so that it is not moved to a larger allocation every few pieces: a hipMalloc and a copy of all there is so far each time)
+            const uint64_t text_done = P.T0 + P.len;
+            const double scale = text_done && P.est_total > text_done ? (double)P.est_total / (double)text_done : 1.0;
+            const uint64_t words_est = (uint64_t)((double)words_after * scale), rec_est = (uint64_t)((double)(M.rec_done + n_rec) * scale);
+            int rc = grow_keep(R->d_words, R->cap_words, ((M.bases + 15) / 16) * 4, padded_words_for(std::max(words_after, words_est)) * 4, sp, err, padded_words_for(words_after) * 4);
             if (rc) return rc;
-            rc = grow_keep(R->d_offsets, R->cap_offsets, (M.rec_done + 1) * 8, (M.rec_done + n_rec + 1) * 8, sp, err);
+            rc = grow_keep(R->d_offsets, R->cap_offsets, (M.rec_done + 1) * 8, (std::max(M.rec_done + n_rec, rec_est) + 1) * 8, sp, err, (M.rec_done + n_rec + 1) * 8);
             if (rc) return rc;
             DCHK(launch_add_base(R->d_offsets + M.rec_done, M.offsets_tmp.p, n_rec + 1, M.bases, sp));
             const uint64_t pb = pack_blocks(nb, M.bases);
@@ -867,7 +893,7 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
         DCHK(M.d_file.need(M.map.n + 256, false));
         DCHK(hipMemsetAsync(M.d_file.p + M.map.n, 0, 256, I.sp));
         DCHK(hipStreamSynchronize(I.sp));
-        rc = M.up.start(M.map.p, M.map.n, M.d_file.p, phys(device), err);
+        rc = M.up.start(M.map.p, M.map.fd, M.map.n, M.d_file.p, phys(device), err);
         if (rc) return rc;
         if (M.gz) {
             M.gzs.reset(new GzStream());

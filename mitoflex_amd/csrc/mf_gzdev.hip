@@ -37,18 +37,24 @@ constexpr uint32_t D_INVALID = 1u << 30;
 constexpr uint32_t PENDING = 0x4000;     // staging value: reference to another staging slot (bit 15 clear, bit 14 set)
 
 struct Canon { uint16_t first[16], cnt[16], off[16]; };
-struct Lds {                             // the walk's inline assembly relies on lit at LDS offset 0 and ring at LIT_SIZE * 4
-    uint32_t lit[LIT_SIZE];
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+// the first-level tables of the block being walked: entry i of a table is lane i & 63 of element i >> 6 (in the walk's assembly: v[104:119], v[120:127])
+struct TabRegs { u32x16 lit; u32x8 dist; };
+struct Lds {                             // the walk's inline assembly relies on ring at LDS offset 0
     uint32_t ring[RING];
-    uint32_t dist[DIST_SIZE];
-    uint32_t pre[PRE_SIZE];
-    uint32_t sym[ROUND + 2 * 64];    // the round's list; behind it two slots per lane for the stores of the lanes that are not the writer
-    uint16_t soff[ROUND];
-    uint16_t stg[STG];
+    // A block's first-level tables are built here by all lanes and then live in vector registers (TabRegs) while its codes are
+    // walked; the rounds' list and staging buffers take the same bytes afterwards: 9.9 KB a wavefront, sixteen wavefronts a CU.
+    union {
+        struct { uint32_t lit[LIT_SIZE]; uint32_t dist[DIST_SIZE]; uint32_t pre[PRE_SIZE]; uint8_t lens[328]; uint8_t plens[24]; };
+        struct {
+            uint32_t sym[ROUND + 2 * 64];    // the round's list; behind it two slots per lane for the stores of the lanes that are not the writer
+            uint16_t soff[ROUND];
+            uint16_t stg[STG];
+        };
+    };
     uint16_t sorted_lit[288], sorted_dist[32];
     Canon clit, cdist;
-    uint8_t lens[328];
-    uint8_t plens[24];
 };
 
 // LSB-first bit reader.  The input reaches the wavefront through a ring of RING dwords in LDS that all 64 lanes top up
@@ -316,9 +322,9 @@ enum WalkEnd : uint32_t { W_MORE = 0, W_EOB = 1, W_ERROR = 2 };
 // literal codes -- nearly all of FASTQ -- is a hand-written loop: two lookups per pass, 12 instructions per lookup.
 #define GZ_UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
 __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(size_t)p; }
-__device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint32_t &n_out)
+__device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint32_t &n_out, TabRegs &T)
 {
-    static_assert(LIT_SIZE * 4 == 4096 && RING * 4 == 2048, "the assembly below has these sizes in its masks and offsets");
+    static_assert(LIT_SIZE == 1024 && DIST_SIZE == 512 && RING * 4 == 2048, "the assembly below has these sizes in its masks and register counts");
     uint32_t z;
     asm volatile("v_mov_b32 %0, 0" : "=v"(z));
     uint32_t lo = (uint32_t)(rd.bb << 2) | z, hi = (uint32_t)(rd.bb >> 30) | z;
@@ -327,13 +333,13 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
     uint32_t r4 = r4_in | z;                    // 4 * (index of the dword nd holds), low 32 bits: the ring address and, by difference, the dwords taken
     uint32_t n = 0, end = W_MORE;
     uint32_t la = lds_off(L.sym) + (lane == 0 ? 0 : (ROUND + 2 * lane) * 4);
-    const uint32_t step1 = lane == 0 ? 4 : 0, lane4 = lane * 4;
+    const uint32_t step1 = lane == 0 ? 4 : 0;
     // refill below 30 valid bits (so that the shift of the incoming dword, bc + 2, stays below 32): 30 <= bc <= 61 afterwards
 #define GZ_REFILL() do { if (GZ_UNI(bc < 30u)) { lo |= nd << (bc + 2); hi |= nd >> (30 - bc); bc += 32; r4 += 4; nd = L.ring[(r4 >> 2) & (RING - 1)] | z; } } while (0)
 #define GZ_DROP(x) do { const uint32_t x_ = (x); lo = __builtin_amdgcn_alignbit(hi, lo, x_); hi >>= (x_ & 31u); bc -= x_; } while (0)
 #define GZ_PEEK(nb) __builtin_amdgcn_ubfe(lo, 2u, (nb))
     const uint32_t k_len = 0xA0000000u, k_sign = 0x80000000u, k_limit = STG - 260 - 2 * ROUND;
-    static_assert(offsetof(Lds, lit) == 0 && offsetof(Lds, ring) == 4096 && offsetof(Lds, dist) == 6144, "offsets used by the assembly");
+    static_assert(offsetof(Lds, ring) == 0, "offset used by the assembly");
     while (n < ROUND - 1) {
         uint32_t e, t, d, lenm3, reason;
         n = (uint32_t)__builtin_amdgcn_readfirstlane(n);
@@ -360,7 +366,7 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
             "s_add_u32 s26, s26, 4\n\t" \
             "s_and_b32 s28, s26, 0x7fc\n\t" \
             "v_mov_b32 %[t], s28\n\t" \
-            "ds_read_b32 %[nd], %[t] offset:4096\n"
+            "ds_read_b32 %[nd], %[t]\n"
 #define GZ_A_DROP_CODE \
             "s_lshr_b64 s[20:21], s[20:21], s27\n\t" \
             "s_and_b32 s28, s27, 0xff\n\t" \
@@ -379,14 +385,7 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
             "s_lshr_b32 s28, s20, 2\n\t" \
             "s_bfm_b32 s35, s29, 0\n\t" \
             "s_and_b32 s28, s28, s35\n\t"
-#define GZ_A_LOAD_ROW(reg, off) "ds_read_b32 " reg ", %[lane4] offset:" off "\n\t"
         asm volatile(
-            GZ_A_LOAD_ROW("v104", "0") GZ_A_LOAD_ROW("v105", "256") GZ_A_LOAD_ROW("v106", "512") GZ_A_LOAD_ROW("v107", "768")
-            GZ_A_LOAD_ROW("v108", "1024") GZ_A_LOAD_ROW("v109", "1280") GZ_A_LOAD_ROW("v110", "1536") GZ_A_LOAD_ROW("v111", "1792")
-            GZ_A_LOAD_ROW("v112", "2048") GZ_A_LOAD_ROW("v113", "2304") GZ_A_LOAD_ROW("v114", "2560") GZ_A_LOAD_ROW("v115", "2816")
-            GZ_A_LOAD_ROW("v116", "3072") GZ_A_LOAD_ROW("v117", "3328") GZ_A_LOAD_ROW("v118", "3584") GZ_A_LOAD_ROW("v119", "3840")
-            GZ_A_LOAD_ROW("v120", "6144") GZ_A_LOAD_ROW("v121", "6400") GZ_A_LOAD_ROW("v122", "6656") GZ_A_LOAD_ROW("v123", "6912")
-            GZ_A_LOAD_ROW("v124", "7168") GZ_A_LOAD_ROW("v125", "7424") GZ_A_LOAD_ROW("v126", "7680") GZ_A_LOAD_ROW("v127", "7936")
             "v_readfirstlane_b32 s20, %[lo]\n\t"
             "v_readfirstlane_b32 s21, %[hi]\n\t"
             "v_readfirstlane_b32 s22, %[bc]\n\t"
@@ -396,7 +395,6 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
             "s_mov_b32 s27, 0\n\t"
             "s_mov_b32 s38, 0\n\t"
             "s_mov_b32 %[reason], 0\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b64 s[36:37], exec\n\t"
             "s_mov_b64 exec, 1\n\t"
             "s_set_gpr_idx_on s25, gpr_idx(SRC0)\n"
@@ -478,12 +476,10 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
             "v_mov_b32 %[d], s27\n\t"
             "v_mov_b32 %[len], s38\n"
             : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [nd] "+v"(nd), [r4] "+v"(r4), [la] "+v"(la), [mtot] "+v"(mtot), [n] "+s"(n),
-              [e] "=&v"(e), [t] "=&v"(t), [d] "=&v"(d), [len] "=&v"(lenm3), [reason] "=&s"(reason)
-            : [lane4] "v"(lane4), [klen] "s"(k_len), [sign] "s"(k_sign), [limit] "s"(k_limit)
-            : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s33", "s34", "s35", "s36", "s37", "s38",
-              "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
-              "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
-#undef GZ_A_LOAD_ROW
+              [e] "=&v"(e), [t] "=&v"(t), [d] "=&v"(d), [len] "=&v"(lenm3), [reason] "=&s"(reason),
+              "+{v[104:119]}"(T.lit), "+{v[120:127]}"(T.dist)              // (read only: in and out so that they stay where they are between the rounds)
+            : [klen] "s"(k_len), [sign] "s"(k_sign), [limit] "s"(k_limit)
+            : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s33", "s34", "s35", "s36", "s37", "s38");
 #undef GZ_A_EXTRA
 #undef GZ_A_LOOKUP
 #undef GZ_A_DROP_CODE
@@ -510,7 +506,13 @@ __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint3
             const uint32_t xl = (e >> 24) & 7u;
             lenm3 = ((e >> 8) & 0xFFu) + GZ_PEEK(xl); GZ_DROP(xl);
             GZ_REFILL();
-            d = L.dist[(lo >> 2) & (DIST_SIZE - 1)];
+            {   // (the table is in registers: element idx >> 6, lane idx & 63)
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((lo >> 2) & (DIST_SIZE - 1));
+                uint32_t row = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) if ((idx >> 6) == (uint32_t)j) row = T.dist[j];          // (constant element indices: the tuple stays in registers)
+                d = (uint32_t)__builtin_amdgcn_readlane(row, idx & 63) | z;
+            }
         }
         if (GZ_UNI((int32_t)d < 0)) {
             if (GZ_UNI((d & D_INVALID) != 0)) { end = W_ERROR; break; }
@@ -613,6 +615,8 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
     rd.ring = L.ring; rd.rd_dw = 0; rd.ring_hi = 0; rd.nd = 0; rd.bb = 0; rd.bc = 0;
     // A speculative chunk tries the candidates of its range in order: one whose header parses strictly is decoded; if the data
     // behind it turns out not to decode (a false candidate) the search goes on behind it.
+    TabRegs T;
+    T.lit = (u32x16)(0u); T.dist = (u32x8)(0u);
     bool searching = c != exact_chunk;
     Search S; S.b0 = nominal - 64; S.mask = 0;
     uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
@@ -672,6 +676,13 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
             } else ok = read_code_lengths(L, rd, strict, lane, hlit, hdist);
             if (!ok) why = 4;
             else if (!build_tables(L, hlit, hdist, strict, lane)) why = 5;
+            if (!why) {                      // the tables move into registers; their LDS bytes become the rounds' list and staging buffers
+#pragma unroll
+                for (int j = 0; j < 16; j++) T.lit[j] = L.lit[j * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 8; j++) T.dist[j] = L.dist[j * 64 + lane];
+            }
+            __syncthreads();
         }
         if (!why) {
             searching = false;
@@ -680,7 +691,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
                 if (opos + STG > sym_cap) { status = GZ_OVERFLOW; break; }
                 rd.top_up(lane);
                 uint32_t n = 0;
-                end = walk(L, rd, lane, n);
+                end = walk(L, rd, lane, n, T);
                 if (end == W_ERROR) why = 6;
                 if (rd.bitpos() > size_bits) { end = W_ERROR; why = 7; }
                 __syncthreads();

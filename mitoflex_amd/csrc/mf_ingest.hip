@@ -43,7 +43,8 @@ template <class T> __device__ __forceinline__ T block_exclusive(T v, T *lds, T *
 }
 
 // ------------------------------------------------------------------------------------------------------------ scan
-constexpr uint32_t SCAN_BLOCK = 1024, SCAN_ITEMS = 4, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+// (256-thread workgroups: they find room beside whatever else is on a CU; a 1024-thread one waits for a quarter of a CU to come free)
+constexpr uint32_t SCAN_BLOCK = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const uint32_t *in, uint64_t n, uint64_t *partial)
 {
     __shared__ uint64_t lds[16];

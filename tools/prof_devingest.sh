@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT; T=/tmp/e2ep; mkdir -p $T gpurun_out
 READS=${1:-8000000}; L=${2:-1}
 python tools/make_fastq.py $T/s --pairs $READS --mates 1 --block 2000000 > /dev/null
-gzip -$L -c $T/s_1.fq > $T/s.fq.gz
+if [ "${L#p}" != "$L" ]; then python tools/pgzip.py $T/s_1.fq $T/s.fq.gz --level ${L#p}; else gzip -$L -c $T/s_1.fq > $T/s.fq.gz; fi      # (p6: one member written on many cores, seconds instead of minutes)
 cat > $T/run.py <<PY
 import sys, time
 sys.path.insert(0, "$GRAFT_REPO_ROOT")
