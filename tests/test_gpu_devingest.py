@@ -252,6 +252,20 @@ def test_highly_compressible_input_grows_the_symbol_buffers(mf, ol, bait_text, t
     assert (k, t) == (30000, 60000)
 
 
+@pytest.mark.parametrize("knobs", [dict(MF_GZDEV_RESERVED_CUS="8", MF_UPLOAD_THREADS="1"), dict(MF_GZDEV_RESERVED_CUS="64", MF_UPLOAD_THREADS="16"),
+                                   dict(MF_GZDEV_NO_CUMASK="1")], ids=["reserve8-upload1", "reserve64-upload16", "no-cu-masks"])
+def test_stream_and_upload_knobs(knobs):
+    """The CU masks of the decoder's streams and the uploader's thread count are read when a process makes its first stream set, so the
+    variants run in child processes: gzip levels x seams, several members, flush points -- same bytes as the oracle whatever the knobs say."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_devingest.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "test_gz_levels_and_seams or test_several_members or test_flush_points or test_plain_files"],
+                       capture_output=True, env=dict(os.environ, **knobs), cwd=root, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+
+
 @pytest.mark.parametrize("level", [1, 6])
 def test_configs4_at_full_size(mf, ol, bait_text, tmp_path_factory, level):
     """BASELINE.json configs[4] at its stated size: 33 333 334 single-end reads of 150 bases in ONE gzip member, filtered file to
