@@ -274,8 +274,9 @@ struct Arena {
     static constexpr size_t FRONT = 32768 + 256; // readable bytes in front of p: a damaged stream may point a full window back from its first byte
     uint8_t *p = nullptr; size_t cap = 0;       // cap bytes usable (+ 64 readable behind)
     uint8_t *raw = nullptr; size_t raw_bytes = 0; // the allocation, when the arena owns one
-    std::mutex mu;                               // held by the consumer while its kernels read the arena, by the producer while it moves it
-    ~Arena() { g_pool.put(raw, raw_bytes); }
+    std::mutex mu;                               // held by the consumer while it enqueues kernels that read the arena, by the producer while it moves it
+    hipEvent_t read_ev = nullptr; bool read_pending = false;      // behind the consumer's last kernels that read it: the producer waits for it before it moves the arena
+    ~Arena() { if (read_ev) (void)hipEventDestroy(read_ev); g_pool.put(raw, raw_bytes); }
 };
 
 // a range of an input's text that has become available, in order
@@ -453,7 +454,8 @@ private:
         DCHK(g_pool.get((void **)&raw, Arena::FRONT + cap + 64, &raw_bytes));
         DCHK(hipMemsetAsync(raw, 0, Arena::FRONT, sr_)); DCHK(hipStreamSynchronize(sr_));
         uint8_t *p = raw + Arena::FRONT;
-        std::lock_guard<std::mutex> lk(arena_->mu);       // (no kernel of the consumer is reading the old one)
+        std::lock_guard<std::mutex> lk(arena_->mu);
+        if (arena_->read_pending) { DCHK(hipEventSynchronize(arena_->read_ev)); arena_->read_pending = false; }      // (no kernel of the consumer is reading the old one)
         const uint64_t have = h_chain_ ? h_chain_->total : 0;
         if (arena_->raw) {
             if (have) { DCHK(hipMemcpyAsync(p, arena_->p, have, hipMemcpyDeviceToDevice, sr_)); DCHK(hipStreamSynchronize(sr_)); }
@@ -594,7 +596,10 @@ struct Mate {
     mf_reads *reads = nullptr;           // the read set of the whole file, appended to batch by batch
     Writer out;
     DevBuf<uint32_t> tile_cnt, seq_len, inv_cnt, out_len, minmax; DevBuf<uint64_t> tile_base, scan_tmp, inv_base, out_off, offsets_tmp; DevBuf<uint8_t> d_out;
-    ~Mate() { TRACE("~Mate"); stop = true; if (prod.joinable()) prod.join(); reads_release(reads); TRACE("~Mate body done"); }
+    // small results the host waits for (counts that size the next buffers), in pinned memory: a copy to pageable memory is a
+    // synchronisation of its own.  [0] newlines [1] last byte [2] used [3] bases [4] min/max length [5] invalid bases [6] output bytes
+    uint64_t *h_small = nullptr;
+    ~Mate() { TRACE("~Mate"); stop = true; if (prod.joinable()) prod.join(); reads_release(reads); if (h_small) (void)hipHostFree(h_small); TRACE("~Mate body done"); }
 };
 
 // grow a device buffer, keeping what is in it (bytes)
@@ -661,26 +666,28 @@ struct Ingest {
         const uint8_t *text = M.arena.p + B->start;
         const uint64_t n = M.carry + P.len;
         const uint64_t tiles = (n + INGEST_TILE - 1) / INGEST_TILE;
+        if (!M.h_small) { DCHK(hipHostMalloc((void **)&M.h_small, 64, hipHostMallocDefault)); memset(M.h_small, 0, 64); }
+        volatile uint64_t *hs = M.h_small;
         uint64_t n_lines = 0, used = 0;
+        hs[2] = 0;
         if (n) {
             DCHK(M.tile_cnt.need(tiles)); DCHK(M.tile_base.need(tiles + 1)); DCHK(M.scan_tmp.need(tiles / 4096 + 4));
             DCHK(launch_count_newlines(text, n, M.tile_cnt.p, sp));
             DCHK(launch_scan_u32(M.tile_cnt.p, tiles, M.tile_base.p, M.scan_tmp.p, sp));
-            uint64_t newlines = 0; uint8_t last_byte = 0;
-            DCHK(hipMemcpyAsync(&newlines, M.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipMemcpyAsync(&last_byte, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
+            hs[1] = 0;
+            DCHK(hipMemcpyAsync(M.h_small + 0, M.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(M.h_small + 1, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
+            const uint64_t newlines = hs[0]; const uint8_t last_byte = (uint8_t)hs[1];
             const bool open_line = P.last && last_byte != '\n';      // lines() yields an unterminated last line
             n_lines = newlines + (open_line ? 1 : 0);
             DCHK(B->line_start.need(n_lines + 2, false));
             DCHK(launch_line_starts(text, n, M.tile_base.p, B->line_start.p, sp));
             if (open_line) { const uint64_t v = n + 1; DCHK(hipMemcpyAsync(B->line_start.p + n_lines, &v, 8, hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
             B->n_rec = n_lines / 4;
-            DCHK(hipMemcpyAsync(&used, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipStreamSynchronize(sp));
-            if (used > n) used = n;                                   // (the virtual line end of an unterminated last line)
+            DCHK(hipMemcpyAsync(M.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));     // (read with the next synchronisation)
+            if (!B->n_rec) DCHK(hipStreamSynchronize(sp));
         }
-        M.carry = P.last ? 0 : n - used;                              // a partial record at the very end is dropped
         if (timing) t_index += now_s() - t0;
         const double t1 = now_s();
         const uint64_t n_rec = B->n_rec;
@@ -692,10 +699,10 @@ struct Ingest {
             { const uint32_t init[2] = {~0u, 0u}; DCHK(hipMemcpyAsync(M.minmax.p, init, 8, hipMemcpyHostToDevice, sp)); }
             DCHK(launch_seq_lens(text, B->line_start.p, n_rec, M.seq_len.p, M.minmax.p, sp));
             DCHK(launch_scan_u32(M.seq_len.p, n_rec, M.offsets_tmp.p, M.scan_tmp.p, sp));
-            uint64_t nb = 0; uint32_t mm[2] = {0, 0};
-            DCHK(hipMemcpyAsync(&nb, M.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipMemcpyAsync(mm, M.minmax.p, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(M.h_small + 3, M.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(M.h_small + 4, M.minmax.p, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
+            const uint64_t nb = hs[3]; const uint32_t mm[2] = {(uint32_t)hs[4], (uint32_t)(hs[4] >> 32)};
             M.min_len = std::min(M.min_len, mm[0]); M.max_len = std::max(M.max_len, mm[1]);
             const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
             // room in the file's read set: words (with the screen's padding), offsets, then pack behind what is there
@@ -716,17 +723,24 @@ struct Ingest {
                 DCHK(M.inv_cnt.need(pb)); DCHK(M.inv_base.need(pb + 1)); DCHK(M.scan_tmp.need(pb / 4096 + 4));
                 DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : M.offsets_tmp.p, uniform, n_rec, nb, M.bases, R->d_words, M.inv_cnt.p, nullptr, nullptr, sp));
                 DCHK(launch_scan_u32(M.inv_cnt.p, pb, M.inv_base.p, M.scan_tmp.p, sp));
-                DCHK(hipMemcpyAsync(&inv, M.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
+                DCHK(hipMemcpyAsync(M.h_small + 5, M.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
                 DCHK(hipStreamSynchronize(sp));
+                inv = hs[5];
                 if (inv) {
                     rc = grow_keep(R->d_npos, R->cap_npos, M.n_npos * 8, (M.n_npos + inv) * 8, sp, err);
                     if (rc) return rc;
                     DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : M.offsets_tmp.p, uniform, n_rec, nb, M.bases, R->d_words, M.inv_cnt.p, M.inv_base.p, R->d_npos + M.n_npos, sp));
                 }
             }
-            DCHK(hipStreamSynchronize(sp));
+            // (no synchronisation at the end: the next piece's kernels follow on the same stream, and the arena is not moved before
+            // the event below has passed)
             M.bases += nb; M.n_npos += inv;
         }
+        used = hs[2];                                                 // (arrived with one of the synchronisations above)
+        if (used > n) used = n;                                       // (the virtual line end of an unterminated last line)
+        M.carry = P.last ? 0 : n - used;                              // a partial record at the very end is dropped
+        if (!M.arena.read_ev) DCHK(hipEventCreateWithFlags(&M.arena.read_ev, hipEventDisableTiming));
+        DCHK(hipEventRecord(M.arena.read_ev, sp)); M.arena.read_pending = true;
         M.rec_done += n_rec;
         M.batches.push_back(std::move(B));
         if (timing) t_pack += now_s() - t1;
