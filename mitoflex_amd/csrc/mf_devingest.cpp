@@ -297,6 +297,7 @@ public:
         if (ev_link_) (void)hipEventDestroy(ev_link_);
         TRACE("streams destroyed");
         if (h_chain_) (void)hipHostFree(h_chain_);
+        if (h_crc_) (void)hipHostFree(h_crc_);
         TRACE("~GzStream done");
     }
     // data: the mapped file; d_file: its copy on the device (size + 64 readable, being filled by `up`)
@@ -346,9 +347,14 @@ public:
         return MF_OK;
     }
     // text of the next slab (possibly nothing) is in the arena when this returns
+    // Marker resolution and the CRC of slab k run while slab k + 1 is waited for and linked (they are the link step's only
+    // neighbours on the producer's critical path: 1.8 ms of 5.5 per slab), so the piece this returns is the one BEFORE the slab it
+    // has just linked -- nothing the first time, the last piece in a call of its own.
     int next(TextPiece &out, std::string &err)
     {
         hipStream_t sp = sp_;
+        out = TextPiece();
+        if (done_ || next_slab_ >= n_slabs_) return finish_pending(out, err);
         const uint32_t k = next_slab_;
         // decode runs ahead of the text: this slab (waiting for its bytes if need be) and as many of the following ones as there are
         // symbol buffers and uploaded bytes for
@@ -383,12 +389,13 @@ public:
         if (rc) return rc;
         const bool last_slab = k + 1 == n_slabs_;
         // link; the host steps in where the chain stops
-        for (;;) {
+        for (bool first = true;; first = false) {
             if (!done_ && in_member_) {
                 DCHK(launch_gz_chain(d_chain_.p, d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, arena_->p, 0, sp));
                 DCHK(hipMemcpyAsync(h_chain_, d_chain_.p, offsetof(GzChain, window), hipMemcpyDeviceToHost, sp));
-                DCHK(hipStreamSynchronize(sp));
             }
+            if (first) { rc = finish_pending(out, err); if (rc) return rc; }       // (the slab before: its resolve and CRC kernels ran beside this slab's decode wait and link)
+            if (!done_ && in_member_) DCHK(hipStreamSynchronize(sp));
             TRACE("chain: stop %u next %u cur_bit %llu total %llu linked %u", h_chain_->stop, h_chain_->next, (unsigned long long)h_chain_->cur_bit, (unsigned long long)h_chain_->total, h_chain_->linked);
             if (done_) break;
             uint64_t to_bit = 0;
@@ -425,17 +432,26 @@ public:
         }
         DCHK(hipEventRecord(ev_link_, sp)); DCHK(hipStreamWaitEvent(sr_, ev_link_, 0));
         DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, arena_->p, 0, max_sym, sr_));
-        // the rest of the member's CRC over this slab
-        if (h_chain_->total > crc_done_) { rc = crc_over(crc_done_, h_chain_->total, sr_, err); if (rc) return rc; }
-        DCHK(hipStreamSynchronize(sr_));
-        S.slab = ~0u;                                     // (its symbols are text now)
+        // the rest of the member's CRC over this slab: launched here, taken in by finish_pending
+        if (h_chain_->total > crc_done_) { rc = crc_launch(crc_done_, h_chain_->total, sr_, err); if (rc) return rc; }
         next_slab_ = k + 1;
         if (next_slab_ == n_slabs_ && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
-        out.T0 = T0; out.len = h_chain_->total - T0; out.last = done_;
+        pend_.T0 = T0; pend_.len = h_chain_->total - T0; pend_.last = done_;
         {   // the text so far over the compressed bytes it came from, times the file
             const double in = (double)std::min<uint64_t>(size_, base_byte_ + (uint64_t)hi * chunk_);
-            out.est_total = done_ ? h_chain_->total : (uint64_t)((double)h_chain_->total * ((double)size_ / std::max(1.0, in)) * 1.03);
+            pend_.est_total = done_ ? h_chain_->total : (uint64_t)((double)h_chain_->total * ((double)size_ / std::max(1.0, in)) * 1.03);
         }
+        pending_ = true; pend_sym_ = k % NSYM;
+        return MF_OK;
+    }
+    // the slab whose resolve and CRC kernels are in flight becomes text: its piece goes to `out`
+    int finish_pending(TextPiece &out, std::string &err)
+    {
+        if (!pending_) return MF_OK;
+        DCHK(hipStreamSynchronize(sr_));
+        crc_finish();
+        sym_[pend_sym_].slab = ~0u;                        // (its symbols are text now)
+        out = pend_; pending_ = false;
         return MF_OK;
     }
     uint64_t gap_bytes() const { return gap_bytes_; }
@@ -525,19 +541,26 @@ private:
         DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, offsetof(GzChain, window), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp));
         return MF_OK;
     }
-    // running CRC of the member over the text [from, to)
-    int crc_over(uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
+    // running CRC of the member over the text [from, to): the kernel and the copy of its piece CRCs (crc_launch), the combination on the host (crc_finish)
+    int crc_launch(uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
     {
+        if (crc_n_) { DCHK(hipStreamSynchronize(sp)); crc_finish(); }        // (an earlier launch on this stream that nobody has taken in)
         const uint64_t n = to - from;
         const size_t np = (size_t)((n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
         DCHK(d_crc_.need(np));
-        h_crc_.resize(np);
+        if (np > h_crc_cap_) { if (h_crc_) (void)hipHostFree(h_crc_); h_crc_ = nullptr; h_crc_cap_ = 0; DCHK(hipHostMalloc((void **)&h_crc_, (np + np / 2 + 64) * 4, hipHostMallocDefault)); h_crc_cap_ = np + np / 2 + 64; }
         TRACE("crc over %llu bytes", (unsigned long long)n);
         DCHK(launch_gz_crc(arena_->p + from, n, d_crc_.p, sp));
-        DCHK(hipMemcpyAsync(h_crc_.data(), d_crc_.p, np * 4, hipMemcpyDeviceToHost, sp));
+        DCHK(hipMemcpyAsync(h_crc_, d_crc_.p, np * 4, hipMemcpyDeviceToHost, sp));
+        crc_n_ = n; crc_done_ = to;
+        return MF_OK;
+    }
+    void crc_finish() { if (crc_n_) { crc_ = gz_crc_combine(crc_, gz_crc_finish(h_crc_, crc_n_), crc_n_); crc_n_ = 0; } }      // (the stream of crc_launch has been synchronised)
+    int crc_over(uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
+    {
+        const int rc = crc_launch(from, to, sp, err); if (rc) return rc;
         DCHK(hipStreamSynchronize(sp));
-        crc_ = gz_crc_combine(crc_, gz_crc_finish(h_crc_.data(), n), n);
-        crc_done_ = to;
+        crc_finish();
         return MF_OK;
     }
 
@@ -545,7 +568,8 @@ private:
     size_t chunk_ = 0, base_byte_ = 0, sym_cap_ = 0; uint64_t expand_ = 8;
     uint32_t cps_ = 0, n_chunks_ = 0, n_slabs_ = 0, next_slab_ = 0, launched_ = 0;
     DevBuf<GzChunk> d_chunks_; DevBuf<uint64_t> d_out_off_; DevBuf<GzChain> d_chain_; DevBuf<uint32_t> d_crc_;
-    GzChain *h_chain_ = nullptr; std::vector<GzChunk> h_chunks_; std::vector<uint32_t> h_crc_;
+    GzChain *h_chain_ = nullptr; std::vector<GzChunk> h_chunks_; uint32_t *h_crc_ = nullptr; size_t h_crc_cap_ = 0; uint64_t crc_n_ = 0;      // h_crc_: pinned
+    TextPiece pend_; bool pending_ = false; uint32_t pend_sym_ = 0;
     static constexpr uint32_t NSYM = 12, NSTREAM = GZ_NSTREAM;      // decode kernels in flight: enough wavefronts to fill the chip (a slab is a few hundred chunks)
     Sym sym_[NSYM]; StreamSet *streams_ = nullptr; hipStream_t sd_[NSTREAM] = {}, sp_ = nullptr, sr_ = nullptr; hipEvent_t ev_link_ = nullptr;     // sp_: the link stream (reserved CUs); sr_: resolve and CRC (the whole chip)
     bool in_member_ = false, done_ = false;
@@ -631,6 +655,7 @@ struct Ingest {
                 TextPiece t;
                 rc = M.gzs->next(t, err);
                 if (rc || M.stop) break;
+                if (!t.len && !t.last) continue;                       // (the first call: the decoder hands a slab over one call late)
                 { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(t); }
                 M.cv.notify_all();
                 if (t.last) break;
