@@ -1,19 +1,20 @@
 // DEFLATE decoding on gfx950 (see mf_gzdev.h for the scheme).  One wavefront per chunk of the compressed stream.
 //
 // Inside a wavefront the work is split by what is serial and what is not:
-//   * the Huffman walk -- table lookup, drop the code's bits, next lookup -- is one dependent chain; lane 0 walks up to 64
-//     codes ("a round") and leaves table entries / (length, distance) pairs in an LDS list.  First-level tables of 2^10
-//     (literal/length) and 2^9 (distance) entries live in LDS; an entry holds TWO literals where both codes fit into the
-//     index; codes longer than the index are decoded canonically (first code / count per length), so there are no
-//     sub-tables and the LDS footprint is fixed;
+//   * the Huffman walk -- table lookup, drop the code's bits, next lookup -- is one dependent chain: up to 63 codes ("a round")
+//     are walked and leave table entries / (length, distance) pairs in an LDS list.  It is hand-written assembly and scalar
+//     where it is serial (bit buffer, bit count, entry fields).  First-level tables of 2^10 (literal/length) and 2^9 (distance)
+//     entries are built in LDS and then held in 24 VECTOR REGISTERS for the block (a lookup is a v_readlane in GPR index mode);
+//     an entry holds TWO literals where both codes fit into the index; codes longer than the index are decoded canonically
+//     (first code / count per length), so there are no sub-tables and the footprint is fixed;
 //   * everything else is done by all 64 lanes: the search for a block header (one bit offset per lane), building the decode
 //     tables from the code lengths (ranks by ballot, table fill by symbol), and turning a round's list into output -- a
 //     prefix sum gives every list entry its place, then every OUTPUT POSITION of the round finds its entry (binary search in
 //     LDS) and fetches its symbol: a literal, a symbol written in an earlier round (global memory, all loads of the round in
 //     flight together), a marker, or -- for a match that reaches into the round itself -- a reference that is chased
 //     through the LDS staging buffer afterwards.  The round leaves as coalesced 16-bit stores.
-// The kernel is bound by the issue rate of the walk (about a dozen vector instructions per code on one lane); what hides it
-// is occupancy: ~10 KiB of LDS per wavefront, so fifteen chunks are in flight per CU.
+// The kernel is bound by one wavefront's dependent chain (about 290 cycles per code, the all-lane expansion a third on top)
+// times the wavefronts a CU holds: 9.9 KB of LDS and 128 VGPRs per wavefront, sixteen chunks in flight per CU.
 #include "mf_gzdev.h"
 #include <stddef.h>
 
@@ -313,13 +314,11 @@ __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *wo
 
 enum WalkEnd : uint32_t { W_MORE = 0, W_EOB = 1, W_ERROR = 2 };
 
-// Walk codes until the round is full, the block ends or something is wrong.  One dependent chain.  Every lane runs it with
-// the same values, but in VECTOR registers: a CU has one scalar unit for its four SIMDs, and a walk the compiler had moved
-// to it (the values are wave-uniform) ran all the CU's wavefronts through that one port.  `z` is a zero the compiler cannot
-// see through; branch conditions go through a ballot, which makes them scalar branches without exec-mask juggling.  Only
-// lane 0's stores reach the list -- the other lanes store to slots of their own.
-// The bit buffer is kept two bits up (lo & 0xFFC is the byte offset of a literal/length table entry) and the run of
-// literal codes -- nearly all of FASTQ -- is a hand-written loop: two lookups per pass, 12 instructions per lookup.
+// Walk codes until the round is full, the block ends or something is wrong.  One dependent chain.  Outside the assembly loop
+// (the rare paths: long codes, end of block, the refill in front of them) every lane runs it with the same values in VECTOR
+// registers -- `z` is a zero the compiler cannot see through; branch conditions go through a ballot, which makes them scalar
+// branches without exec-mask juggling; only lane 0's stores reach the list, the other lanes store to slots of their own.
+// The bit buffer is kept two bits up (bits 2.. of `lo` are the next bits of the stream).
 #define GZ_UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
 __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(size_t)p; }
 __device__ __forceinline__ uint32_t walk(Lds &L, BitRd &rd, uint32_t lane, uint32_t &n_out, TabRegs &T)
