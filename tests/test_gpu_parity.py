@@ -40,7 +40,7 @@ def test_table_byte_identical(mf, ol, bait_text, k):
     assert np.array_equal(ks.export_table(), t.keys)
 
 
-@pytest.mark.parametrize("k", [15, 21, 25, 27, 28, 30, 31, 32, 33, 41, 63])
+@pytest.mark.parametrize("k", [15, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 41, 63])
 @pytest.mark.parametrize("uniform", [False, True])
 def test_filter_matches_oracle(mf, ol, bait_text, k, uniform):
     seqs = make_reads(bait_text, 6000, seed=100 + k, uniform=uniform)
