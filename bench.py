@@ -233,7 +233,7 @@ def md5_of(path):
     return h.hexdigest()
 
 
-def prepare_inputs(a, tmp):
+def prepare_inputs(a, tmp, solo=True):
     """Every file the file-level measurements read, made by child processes BEFORE this process initialises the GPU (and not
     at all when this process is being profiled: the children would inherit the profiler).  -> {name: path or note}"""
     import shutil
@@ -248,7 +248,7 @@ def prepare_inputs(a, tmp):
             with open(os.path.join(tmp, "s_1.fq.gz"), "wb") as g:
                 subprocess.check_call(["gzip", "-1", "-c", os.path.join(tmp, "s_1.fq")], stdout=g, env=env)
             files["small"] = os.path.join(tmp, "s")
-        if a.e2e_full_reads > 0:
+        if a.e2e_full_reads > 0 and solo:                 # (configs[4] is a one-GPU configuration: the other ranks of a multi-rank run would only wait for the file)
             need = a.e2e_full_reads * 321 * 1.7
             if shutil.disk_usage(tmp).free < need:
                 files["full_note"] = "not enough scratch space for the configs[4] file"
@@ -259,7 +259,7 @@ def prepare_inputs(a, tmp):
                 run([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), os.path.join(tmp, "f_1.fq"), os.path.join(tmp, "f_1.fq.gz"), "--level", "6"])
                 files["full"] = os.path.join(tmp, "f")
                 files["full_prep_seconds"] = {"generate": round(t1 - t0, 1), "compress": round(time.time() - t1, 1)}
-        if not a.no_group_a:
+        if not a.no_group_a and solo:
             run([sys.executable, "-c", G20_GENERATOR, os.path.join(tmp, "g20.fa")])
             files["g20"] = os.path.join(tmp, "g20.fa")
     except Exception as e:
@@ -352,7 +352,7 @@ def main():
     tmpdir = tempfile.TemporaryDirectory(prefix="mf_bench_", dir="/tmp") if rank == 0 else None
     if rank == 0 and not solo:
         a.e2e_full_reads, a.no_group_a = 0, True     # with several ranks only the small paired set is made (file level over all devices)
-    files = prepare_inputs(a, tmpdir.name) if rank == 0 else {}
+    files = prepare_inputs(a, tmpdir.name, solo) if rank == 0 else {}
     live, valu = (None, None), (None, None)
     default_set = a.reads == READS_5GBP
     if solo and not a.no_live_traffic and default_set:
