@@ -739,34 +739,66 @@ __global__ __launch_bounds__(1024) void gz_chain_kernel(GzChain *chain, const Gz
     // the window is text too: a chunk's markers are looked up there by the resolve kernel
     for (uint32_t i = tid; i < wlen; i += 1024) text[(int64_t)(total - text_base) - (int64_t)wlen + i] = win[0][GZ_WINDOW - wlen + i];
     uint32_t a = 0;
-    for (; c < chunk_hi; c++) {
-        const GzChunk ch = chunks[c];
-        const bool ok = ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END;
-        if (!ok || ch.start_bit < cur) { if (tid == 0) out_off[c] = ~0ull; discarded++; continue; }
-        if (ch.start_bit > cur) { stop = GZ_STOP_GAP; break; }
-        if (tid == 0) out_off[c] = total;
-        const uint32_t n = ch.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW, keep = GZ_WINDOW - tail;
-        const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap + (n - tail);
-        uint8_t *tp = text + (int64_t)(total - text_base) + (n - tail);
-        const uint8_t *wa = win[a]; uint8_t *wb = win[a ^ 1];
-        for (uint32_t i = tid; i < keep; i += 1024) wb[i] = wa[i + tail];          // (a chunk shorter than the window: the rest slides)
-        for (uint32_t i = tid * 8; i < tail; i += 1024 * 8) {
-            uint16_t v[8];
-            const uint32_t m = tail - i < 8 ? tail - i : 8;
-            if (m == 8) __builtin_memcpy(v, sp + i, 16); else for (uint32_t k = 0; k < m; k++) v[k] = sp[i + k];
-            uint8_t b[8];
-            for (uint32_t k = 0; k < m; k++) b[k] = (v[k] & GZ_MARK) ? wa[v[k] & 0x7FFFu] : (uint8_t)v[k];
-            if (m == 8 && ((keep + i) & 7) == 0) {                          // eight bytes at a time to the new window and to the text
-                uint64_t q; __builtin_memcpy(&q, b, 8);
-                *reinterpret_cast<uint64_t *>(wb + keep + i) = q;
-                __builtin_memcpy(tp + i, &q, 8);
-            } else for (uint32_t k = 0; k < m; k++) { wb[keep + i + k] = b[k]; tp[i + k] = b[k]; }
+    // The descriptor of a chunk is fetched two chunks ahead and the tail of its symbols -- the last 32 Ki, four 16-byte loads a thread --
+    // one chunk ahead, so that a chunk's turn finds both in registers: what is serial per chunk is the look-up of its markers in
+    // the LDS window and a barrier, not three memory latencies.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const GzChunk none{0, 0, 0, GZ_NONE};
+    auto desc = [&](uint32_t i) -> GzChunk { return i < chunk_hi ? chunks[i] : none; };
+    auto usable = [](const GzChunk &d) { return d.status == GZ_AT_BOUNDARY || d.status == GZ_MEMBER_END; };
+    // thread's j-th piece of a chunk's tail: symbols [tid * 8 + j * 8192, +8) of the tail
+    auto fetch = [&](uint32_t i, const GzChunk &d, u32x4 (&raw)[4]) {
+        if (!usable(d)) return;
+        const uint32_t n = d.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW;
+        const uint16_t *sp = sym + (uint64_t)(i - chunk_lo) * sym_cap + (n - tail);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t k = tid * 8 + j * 8192;
+            if (k + 8 <= tail) __builtin_memcpy(&raw[j], sp + k, 16);
+            else if (k < tail) { uint16_t v[8] = {}; for (uint32_t q = 0; k + q < tail; q++) v[q] = sp[k + q]; __builtin_memcpy(&raw[j], v, 16); }      // (the last piece: never past the chunk's symbols)
         }
-        __syncthreads();
-        a ^= 1;
-        total += n; cur = ch.end_bit; linked++;
-        wlen = wlen + n < GZ_WINDOW ? wlen + n : GZ_WINDOW;
-        if (ch.status == GZ_MEMBER_END) { c++; stop = GZ_STOP_MEMBER_END; break; }
+    };
+    GzChunk ch = desc(c), nx = desc(c + 1);
+    u32x4 cur_raw[4] = {}, nxt_raw[4] = {};
+    fetch(c, ch, cur_raw);
+    for (; c < chunk_hi; c++) {
+        const GzChunk nx2 = desc(c + 2);
+        fetch(c + 1, nx, nxt_raw);
+        const bool ok = usable(ch);
+        bool take = false;
+        if (!ok || ch.start_bit < cur) { if (tid == 0) out_off[c] = ~0ull; discarded++; }
+        else if (ch.start_bit > cur) { stop = GZ_STOP_GAP; break; }
+        else take = true;
+        if (take) {
+            if (tid == 0) out_off[c] = total;
+            const uint32_t n = ch.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW, keep = GZ_WINDOW - tail;
+            uint8_t *tp = text + (int64_t)(total - text_base) + (n - tail);
+            const uint8_t *wa = win[a]; uint8_t *wb = win[a ^ 1];
+            for (uint32_t i = tid; i < keep; i += 1024) wb[i] = wa[i + tail];          // (a chunk shorter than the window: the rest slides)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = tid * 8 + j * 8192;
+                if (i >= tail) continue;
+                uint16_t v[8];
+                __builtin_memcpy(v, &cur_raw[j], 16);
+                const uint32_t m = tail - i < 8 ? tail - i : 8;
+                uint8_t bts[8];
+                for (uint32_t k = 0; k < 8; k++) bts[k] = k < m ? ((v[k] & GZ_MARK) ? wa[v[k] & 0x7FFFu] : (uint8_t)v[k]) : 0;
+                if (m == 8 && ((keep + i) & 7) == 0) {                          // eight bytes at a time to the new window and to the text
+                    uint64_t q; __builtin_memcpy(&q, bts, 8);
+                    *reinterpret_cast<uint64_t *>(wb + keep + i) = q;
+                    __builtin_memcpy(tp + i, &q, 8);
+                } else for (uint32_t k = 0; k < m; k++) { wb[keep + i + k] = bts[k]; tp[i + k] = bts[k]; }
+            }
+            __syncthreads();
+            a ^= 1;
+            total += n; cur = ch.end_bit; linked++;
+            wlen = wlen + n < GZ_WINDOW ? wlen + n : GZ_WINDOW;
+            if (ch.status == GZ_MEMBER_END) { c++; stop = GZ_STOP_MEMBER_END; break; }
+        }
+        ch = nx; nx = nx2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) cur_raw[j] = nxt_raw[j];
     }
     for (uint32_t i = tid * 16; i < GZ_WINDOW; i += 1024 * 16)
         *reinterpret_cast<uint4 *>(&chain->window[i]) = *reinterpret_cast<const uint4 *>(&win[a][i]);
