@@ -210,3 +210,38 @@ def test_crc_and_marker_resolution_match_their_definitions(built_lib, tmp_path, 
         env["MF_NO_SIMD"] = "1"
     for seed in (1, 2, 3):
         assert subprocess.check_output([out, str(seed)], env=env).decode().strip() == "ok"
+
+
+@pytest.fixture(scope="module")
+def gap_exe(built_lib, tmp_path_factory):
+    csrc = os.path.join(ROOT, "mitoflex_amd", "csrc")
+    out = str(tmp_path_factory.mktemp("inflate") / "gap_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tests", "native", "gap_check.cpp"),
+                           os.path.join(csrc, "build", "mf_inflate.o"), os.path.join(csrc, "build", "mf_pinflate.o"),
+                           "-lz", "-lpthread", "-o", out])
+    return out
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_inflate_gap_between_block_boundaries(gap_exe, tmp_path, level):
+    """mf::inflate_gap -- the host's part of the device decoder (where two chunks do not link, and behind the last chunk) -- from
+    one block boundary to another of a single-member file, with the 32 KiB in front as its window: the bytes zlib has for that
+    stretch, the stop at the wanted bit, the member's end.  Boundaries come from zlib's Z_BLOCK mode (tests/native/gap_check.cpp);
+    level 6 is written with sync flush points (empty stored blocks), level 0 is stored blocks only."""
+    rng = random.Random(40 + level)
+    text = fastq_like(rng, 30000)
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)
+    parts, pos = [], 0
+    while pos < len(text):
+        n = rng.randrange(50000, 400000)
+        parts.append(c.compress(text[pos:pos + n]))
+        pos += n
+        if level == 6:
+            parts.append(c.flush(zlib.Z_SYNC_FLUSH))
+    parts.append(c.flush())
+    p = tmp_path / "g.gz"
+    p.write_bytes(b"".join(parts))
+    for seed in (1, 2, 3):
+        r = subprocess.run([gap_exe, str(p), str(seed)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+        assert "0 wrong" in r.stdout
