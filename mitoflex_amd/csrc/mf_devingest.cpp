@@ -1,11 +1,13 @@
 // Device ingest path of mf_filter_fastq_files (see mf_devingest.h).
 //
-
-// A plain FASTQ file then IS the text; a .gz is decoded in slabs of a few thousand speculative chunks (mf_gzdev.h): decode of
-// slab k + 1 and k + 2 run on their own streams while slab k is linked, resolved, CRC-checked, indexed, packed, filtered and
-// its survivors copied out.  Text is cut into records where it lies (mf_ingest.h); what is behind the last complete record of
-// a slab (the carry) is the front of the next slab's text.  Pass bits go to a file-wide bitmap per mate, so that the pair rule
-// can be applied to slabs of the two mates that do not cover the same records; the mate that is behind in records is advanced.
+// An uploader thread reads the file into pinned staging and copies it up; one producer thread per mate turns it into text in a
+// contiguous arena -- a plain FASTQ file IS the text; a .gz is decoded in slabs of a few hundred speculative chunks (mf_gzdev.h):
+// the decode kernels of up to twelve slabs ahead run on their own streams while slab k is linked and slab k - 1 is resolved and
+// CRC-checked --; the calling thread is the consumer: it cuts the text into records where it lies (mf_ingest.h; what is behind
+// the last complete record of a piece, the carry, is the front of the next piece's text), packs them behind what the whole-file
+// read set already holds, runs ONE filter pass over the file when both mates are in, and copies the survivors out to a writer
+// thread per output file.  Pass bits are a file-wide bitmap per mate, so the pair rule does not care that the pieces of the two
+// mates do not cover the same records; the mate that is behind in records is advanced.
 #include "mf_devingest.h"
 #include "mf_api_internal.h"
 #include "mf_gzdev.h"

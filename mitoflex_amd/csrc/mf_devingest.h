@@ -2,8 +2,8 @@
 // the GPU as they are, and inflate, line indexing, 2-bit packing, the filter and the copy of the survivors all run there
 // (configs[4] of BASELINE.json; the reference's conventions: .gz by extension and 4-line records,
 // filter/filter_bin/src/helper.rs:14-31, main.rs:287-321).  The host maps the files, feeds the copy engine and writes the
-// survivors; it decodes deflate data only across the rare places the device decoder cannot link (a stored or fixed block at a
-// chunk seam, the last block of a member).
+// survivors; it decodes deflate data only across the rare places the device decoder cannot link (a block start no chunk found,
+// files of stored blocks only).
 #pragma once
 #include "../../include/mitofilter.h"
 #include <stdint.h>
