@@ -277,24 +277,36 @@ __device__ __forceinline__ bool build_tables(Lds &L, uint32_t hlit, uint32_t hdi
 // Candidates for a block start: the bit offsets in [pos, to_bit) that look like the header of a non-final dynamic block --
 // type bits, symbol counts, Kraft sum of the precode -- 64 offsets a step, one per lane.  Returns the next one (~0: none) and
 // keeps the rest of the current step in `mask`.
-struct Search { uint64_t b0, mask; };
+// The search looks at SEARCH_W windows of 64 bit offsets at a time (one offset per lane and window): the loads of all of them are in
+// flight together -- a step of the search is a memory round trip, and with one window a step that was what it cost.
+constexpr int SEARCH_W = 4;
+struct Search { uint64_t b0; uint64_t mask[SEARCH_W]; };      // mask[j]: candidates among the offsets b0 + 64 j + lane
 __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *words, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
 {
     for (;;) {
-        if (S.mask) {
-            const int idx = __ffsll((unsigned long long)S.mask) - 1;
-            S.mask &= S.mask - 1;
-            return S.b0 + (uint64_t)idx;
-        }
-        S.b0 += 64;
+#pragma unroll
+        for (int j = 0; j < SEARCH_W; j++)
+            if (S.mask[j]) {
+                const int idx = __ffsll((unsigned long long)S.mask[j]) - 1;
+                S.mask[j] &= S.mask[j] - 1;
+                return S.b0 + (uint64_t)(64 * j + idx);
+            }
+        S.b0 += 64 * SEARCH_W;
         if (S.b0 >= to_bit) return ~0ull;
-        const uint64_t bit = S.b0 + lane;
-        bool ok = bit < to_bit && bit + 128 <= size_bits;
-        if (ok) {
-            const uint64_t wi = bit >> 5; const uint32_t s = (uint32_t)bit & 31;
-            const uint32_t w0 = words[wi], w1 = words[wi + 1], w2 = words[wi + 2], w3 = words[wi + 3];
-            const uint32_t h0 = __funnelshift_r(w0, w1, s), h1 = __funnelshift_r(w1, w2, s), h2 = __funnelshift_r(w2, w3, s);
-            ok = (h0 & 7u) == 4u && ((h0 >> 3) & 31u) <= 29u && ((h0 >> 8) & 31u) <= 29u;      // BFINAL = 0, BTYPE = 10b
+        uint32_t w[SEARCH_W][4]; bool in[SEARCH_W];
+#pragma unroll
+        for (int j = 0; j < SEARCH_W; j++) {
+            const uint64_t bit = S.b0 + (uint64_t)(64 * j) + lane;
+            in[j] = bit < to_bit && bit + 128 <= size_bits;
+            const uint64_t wi = in[j] ? bit >> 5 : 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[j][q] = words[wi + q];
+        }
+#pragma unroll
+        for (int j = 0; j < SEARCH_W; j++) {
+            const uint32_t s = (uint32_t)(S.b0 + (uint64_t)(64 * j) + lane) & 31;
+            const uint32_t h0 = __funnelshift_r(w[j][0], w[j][1], s), h1 = __funnelshift_r(w[j][1], w[j][2], s), h2 = __funnelshift_r(w[j][2], w[j][3], s);
+            bool ok = in[j] && (h0 & 7u) == 4u && ((h0 >> 3) & 31u) <= 29u && ((h0 >> 8) & 31u) <= 29u;      // BFINAL = 0, BTYPE = 10b
             if (ok) {
                 const uint32_t hclen = ((h0 >> 13) & 15u) + 4;
                 const uint64_t a = h0 | ((uint64_t)h1 << 32), b = h1 | ((uint64_t)h2 << 32);
@@ -307,8 +319,8 @@ __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *wo
                 }
                 ok = k == 128u;
             }
+            S.mask[j] = __ballot(ok);
         }
-        S.mask = __ballot(ok);
     }
 }
 
@@ -617,7 +629,8 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
     TabRegs T;
     T.lit = (u32x16)(0u); T.dist = (u32x8)(0u);
     bool searching = c != exact_chunk;
-    Search S; S.b0 = nominal - 64; S.mask = 0;
+    Search S; S.b0 = nominal - 64 * SEARCH_W;
+    for (int j = 0; j < SEARCH_W; j++) S.mask[j] = 0;
     uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
     uint32_t status = GZ_NONE;
     if (!searching) rd.seek(start, lane);
