@@ -76,6 +76,7 @@ public:
         return e;
     }
     void put(void *p, size_t bytes) { if (!p) return; std::lock_guard<std::mutex> lk(mu_); free_.emplace(bytes, p); held_ += bytes; }
+    size_t held() { std::lock_guard<std::mutex> lk(mu_); return held_; }          // bytes waiting for the next call
     void trim(size_t keep)                          // (only when no kernel of this path is in flight)
     {
         std::vector<void *> drop;
@@ -919,13 +920,13 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
             if (M.map.n < 18 || d[0] != 0x1f || d[1] != 0x8b) return MF_DEVINGEST_DECLINED;      // (gzread hands such a file through; so does the host reader)
             if ((d[3] & 4) && M.map.n >= 18 && d[12] == 'B' && d[13] == 'C') return MF_DEVINGEST_DECLINED;   // BGZF: the host reader decodes its members side by side
         }
-        need += M.gz ? M.map.n * 8 + ((size_t)20 << 30) : M.map.n + M.map.n / 2;
+        need += M.gz ? M.map.n * 8 + ((size_t)32 << 30) : M.map.n + M.map.n / 2;      // (file, text arena, read set; twelve symbol buffers of 2.4 GB)
     }
     int rc = get_ctx(device, &I.ctx, 0);
     if (rc) { err = mf_thread_error(); return rc; }
     {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) return MF_DEVINGEST_DECLINED;       // too large to keep resident: the host pipeline streams it
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + g_pool.held() < need) return MF_DEVINGEST_DECLINED;       // too large to keep resident: the host pipeline streams it (what the pool holds from earlier calls counts as free)
     }
     const double t_begin = now_s();
     I.sp = I.ctx->stream;
