@@ -283,6 +283,7 @@ def e2e_files(mf, ks, files, a):
         out["pe_plain_reads_per_s"] = run(t + "_1.fq", t + "_2.fq", t + "_o1.fq", t + "_o2.fq", 2 * a.e2e_pairs)[0]
         out["se_gz_reads_per_s"] = run(t + "_1.fq.gz", None, t + "_og.fq", None, a.e2e_pairs)[0]
         out["pairs"] = a.e2e_pairs
+        out["note_small"] = "small inputs (the SE .gz has `pairs` reads): a call's fixed latencies dominate -- a 64 KiB chunk takes a wavefront ~12 ms to decode, whatever the file size; configs4_se_gz is the throughput figure"
     if "full" in files:
         # configs[4] at its stated size: one gzip member of single-end reads, device ingest (inflate, line index, 2-bit pack, filter
         # and survivor copy on the GPU).  Checked against the host pipeline on the plain text of the same reads, byte for byte.
