@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 2
+#define MF_ABI_VERSION 3
 
 enum {
     MF_OK = 0,
@@ -196,6 +196,19 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2,
                           const char *out1, const char *out2,
                           uint32_t threshold, int pair_mode, int n_devices,
                           uint64_t *kept, uint64_t *total);
+/* The same on a chosen list of devices (ABI 3): devices[0 .. n_devices) are device indices below
+ * mf_device_count(), each at most once.  A ".gz" FILE takes the device ingest path: its bytes are
+ * copied up as they are, the slabs of the stream are dealt to the listed devices round robin and
+ * inflate, line index, 2-bit pack, filter and the copy of the survivors run there, with a bounded
+ * amount of device memory whatever the file's size (the reference's readers stream too:
+ * filter/filter_bin/src/helper.rs:14-31).  Plain files, pipes and BGZF take the host pipeline,
+ * which wants the list to be a run of consecutive devices.  mf_filter_fastq_files(.., n, ..) is
+ * this call with devices 0 .. n - 1. */
+int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2,
+                             const char *out1, const char *out2,
+                             uint32_t threshold, int pair_mode,
+                             const int *devices, int n_devices,
+                             uint64_t *kept, uint64_t *total);
 
 /* ---- FASTQ quality filter: the reference's `filter/filter_v2` (filter/filter_bin/src/main.rs:14-329),
  * the stage that runs on the raw reads before this path (SURVEY.md 8f "next" #2).  Same rules, same

@@ -426,6 +426,7 @@ static int bait_main(int argc, char **argv)
 {
     std::string bait, fq1, fq2, out1, out2, pair = "either", libpath;
     int k = 0, devices = 1, gcode = 5; unsigned thr = 1; bool protein = false;
+    std::vector<int> device_list;              // --device-list 2,3: these devices instead of 0 .. N - 1
     for (int a = 2; a < argc; a++) {
         std::string o = argv[a];
         auto need = [&](const char *name) -> std::string {
@@ -442,13 +443,18 @@ static int bait_main(int argc, char **argv)
         else if (o == "-k" || o == "--kmer") k = atoi(need("-k").c_str());
         else if (o == "-t" || o == "--threshold") thr = (unsigned)strtoul(need("-t").c_str(), nullptr, 10);
         else if (o == "--devices") devices = atoi(need("--devices").c_str());
+        else if (o == "--device-list") {
+            const std::string v = need("--device-list");
+            for (size_t i = 0; i < v.size();) { size_t j = v.find(',', i); if (j == std::string::npos) j = v.size(); if (j > i) device_list.push_back(atoi(v.substr(i, j - i).c_str())); i = j + 1; }
+            if (device_list.empty()) { fprintf(stderr, "error: --device-list wants device numbers separated by commas\n"); return 1; }
+        }
         else if (o == "--protein") protein = true;                       // --bait is a protein FASTA (e.g. profile/MT_database/<clade>.fa)
         else if (o == "--code" || o == "--genetic-code") gcode = atoi(need("--code").c_str());
         else { fprintf(stderr, "error: unknown option '%s' for fastfilter bait\n", o.c_str()); return 1; }
     }
     if (bait.empty() || fq1.empty() || out1.empty() || (fq2.empty() != out2.empty()) || (pair != "either" && pair != "both")) {
         fputs("usage: fastfilter bait --bait BAIT.fa [-k 31] [-t 1] --fq1 R1.fq [--fq2 R2.fq] --out1 O1.fq [--out2 O2.fq]"
-              " [--pair either|both] [--devices N]\n"
+              " [--pair either|both] [--devices N | --device-list D0,D1,..]\n"
               "       fastfilter bait --protein --bait PROTEINS.fa [--code 5] [-k 9] ...   (six-frame peptide k-mers)\n", stderr);
         return 1;
     }
@@ -458,17 +464,22 @@ static int bait_main(int argc, char **argv)
     if (!h) { fprintf(stderr, "error: cannot load %s: %s (the bait filter has no CPU fallback)\n", libpath.c_str(), dlerror()); return 2; }
 #define SYM(name) auto p_##name = (decltype(&name))dlsym(h, #name); if (!p_##name) { fprintf(stderr, "error: %s lacks symbol %s\n", libpath.c_str(), #name); return 2; }
     SYM(mf_abi_version) SYM(mf_last_error) SYM(mf_kmerset_build_from_fasta) SYM(mf_kmerset_build_protein_from_fasta)
-    SYM(mf_filter_fastq_files) SYM(mf_kmerset_free)
+    SYM(mf_filter_fastq_files) SYM(mf_filter_fastq_files_on) SYM(mf_kmerset_free)
 #undef SYM
     if (p_mf_abi_version() != MF_ABI_VERSION) { fprintf(stderr, "error: ABI version mismatch\n"); return 2; }
     mf_kmerset *ks = nullptr;
-    const int brc = protein ? p_mf_kmerset_build_protein_from_fasta(bait.c_str(), k, gcode, 0, &ks)
-                            : p_mf_kmerset_build_from_fasta(bait.c_str(), k, 0, &ks);
+    const int dev0 = device_list.empty() ? 0 : device_list[0];
+    const int brc = protein ? p_mf_kmerset_build_protein_from_fasta(bait.c_str(), k, gcode, dev0, &ks)
+                            : p_mf_kmerset_build_from_fasta(bait.c_str(), k, dev0, &ks);
     if (brc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 3; }
     uint64_t kept = 0, total = 0;
-    int rc = p_mf_filter_fastq_files(ks, fq1.c_str(), fq2.empty() ? nullptr : fq2.c_str(), out1.c_str(),
+    int rc = device_list.empty()
+        ? p_mf_filter_fastq_files(ks, fq1.c_str(), fq2.empty() ? nullptr : fq2.c_str(), out1.c_str(),
+                                  out2.empty() ? nullptr : out2.c_str(), thr, pair == "both" ? MF_PAIR_BOTH : MF_PAIR_EITHER,
+                                  devices, &kept, &total)
+        : p_mf_filter_fastq_files_on(ks, fq1.c_str(), fq2.empty() ? nullptr : fq2.c_str(), out1.c_str(),
                                      out2.empty() ? nullptr : out2.c_str(), thr, pair == "both" ? MF_PAIR_BOTH : MF_PAIR_EITHER,
-                                     devices, &kept, &total);
+                                     device_list.data(), (int)device_list.size(), &kept, &total);
     if (rc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); p_mf_kmerset_free(ks); return 3; }
     p_mf_kmerset_free(ks);
     printf("%llu\n", (unsigned long long)kept);      // same stdout contract as the contig filter

@@ -848,8 +848,9 @@ int mf_filter_packed(const mf_kmerset *ks, int device, const uint32_t *words, co
 }
 
 // ------------------------------------------------------------- file level
-int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2,
-                          uint32_t threshold, int pair_mode, int n_devices, uint64_t *kept, uint64_t *total)
+// the file-level call on a list of (logical) devices
+static int filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2,
+                                 uint32_t threshold, int pair_mode, const int *devices, int n_devices, uint64_t *kept, uint64_t *total)
 {
     if (!ks || !fq1 || !out1) return fail(MF_E_ARG, "NULL argument");
     if ((fq2 == nullptr) != (out2 == nullptr)) return fail(MF_E_ARG, "fq2 and out2 must be given together");
@@ -857,24 +858,33 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     if (threshold < 1) return fail(MF_E_ARG, "threshold must be >= 1");
     const int have = mf_device_count();
     if (have <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible; libmitofilter_hip has no CPU fallback");
-    if (n_devices < 1) n_devices = 1;
-    if (n_devices > have) n_devices = have;
+    if (!devices || n_devices < 1) return fail(MF_E_ARG, "empty device list");
+    for (int i = 0; i < n_devices; i++) {
+        if (devices[i] < 0 || devices[i] >= have) return fail(MF_E_ARG, "device %d out of range (have %d)", devices[i], have);
+        for (int j = 0; j < i; j++) if (devices[j] == devices[i]) return fail(MF_E_ARG, "device %d listed twice", devices[i]);
+    }
 
-    // One device and a regular .gz file: the bytes go to the GPU as they are and inflate, line indexing, packing, filter and the
-    // copy of the survivors run there (mf_devingest.cpp) -- the host's inflate is what bounds the host pipeline on compressed
-    // input.  Plain files stay with the host pipeline by default (it packs them to a quarter of their size before the copy to
-    // the device, and at ~45 GB/s of text); MF_INGEST=device sends them the same way, MF_INGEST=host keeps everything on the
-    // host pipeline.  Pipes, BGZF files and several devices always take the host pipeline.
+    // A regular .gz file: the bytes go to the GPU(s) as they are and inflate, line indexing, packing, filter and the copy of the
+    // survivors run there (mf_devingest.cpp, streaming: device memory stays bounded whatever the file's size) -- the host's inflate is
+    // what bounds the host pipeline on compressed input.  Plain files stay with the host pipeline by default (it packs them to a
+    // quarter of their size before the copy to the device, and at ~45 GB/s of text); MF_INGEST=device sends them the same way,
+    // MF_INGEST=host keeps everything on the host pipeline.  Pipes and BGZF files always take the host pipeline.
     {
         const char *ing = getenv("MF_INGEST");
         const bool force = ing && strcmp(ing, "device") == 0, any_gz = has_gz_ext(fq1) || (fq2 && has_gz_ext(fq2));
-        if (n_devices == 1 && !(ing && strcmp(ing, "host") == 0) && (force || any_gz)) {
+        if (!(ing && strcmp(ing, "host") == 0) && (force || any_gz)) {
             std::string derr;
-            const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, 0, kept, total, derr);
+            const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, devices, n_devices, kept, total, derr);
             if (drc == MF_OK) return MF_OK;
             if (drc != MF_DEVINGEST_DECLINED) return fail(drc, "%s", derr.c_str());
+            if (getenv("MF_PIPE_TIMING")) fprintf(stderr, "[mf device ingest] declined%s%s: the host pipeline takes the input\n", derr.empty() ? "" : ": ", derr.c_str());
         }
     }
+    // The host pipeline deals its batches to logical devices 0 .. n - 1 of a contiguous range: it is given the list's first device
+    // as its base when the list is a run of consecutive devices, which is what the callers of this library pass.
+    for (int i = 1; i < n_devices; i++)
+        if (devices[i] != devices[0] + i) return fail(MF_E_ARG, "the host pipeline (plain files, pipes, BGZF) takes a run of consecutive devices; got %d after %d", devices[i], devices[i - 1]);
+    const int dev_base = devices[0];
     const int hw = (int)std::thread::hardware_concurrency();
     // pack threads: what is left after the readers, writers and device workers
     int pack_threads = hw - 4 - n_devices; if (pack_threads < 1) pack_threads = 1; if (pack_threads > 64) pack_threads = 64;
@@ -893,10 +903,10 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     const int lanes = (int)env_u32("MF_WORKERS_PER_DEVICE", 2) < 1 ? 1 : (int)env_u32("MF_WORKERS_PER_DEVICE", 2);
     const int n_workers = n_devices * lanes;
     std::vector<mf_reads *> arena((size_t)n_workers, nullptr);
-    BatchFilterFn fn = [ks, threshold, n_devices, &arena](int worker, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
+    BatchFilterFn fn = [ks, threshold, n_devices, dev_base, &arena](int worker, const PackedHost &P, uint64_t n, std::vector<uint32_t> &bits, std::string &err) -> int {
         bits.assign((n + 31) / 32 + 1, 0);
         if (n == 0) return MF_OK;
-        const int device = worker % n_devices, lane = worker / n_devices;
+        const int device = dev_base + worker % n_devices, lane = worker / n_devices;
         DevCtx *ctx; int rc = get_ctx(device, &ctx, lane);
         if (rc == MF_OK && !arena[worker]) {
             arena[worker] = new (std::nothrow) mf_reads();
@@ -921,6 +931,24 @@ int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, cons
     if (kept) *kept = ps.kept;
     if (total) *total = ps.total;
     return MF_OK;
+}
+
+int mf_filter_fastq_files(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2,
+                          uint32_t threshold, int pair_mode, int n_devices, uint64_t *kept, uint64_t *total)
+{
+    const int have = mf_device_count();
+    if (have <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible; libmitofilter_hip has no CPU fallback");
+    if (n_devices < 1) n_devices = 1;
+    if (n_devices > have) n_devices = have;
+    std::vector<int> devs((size_t)n_devices);
+    for (int i = 0; i < n_devices; i++) devs[(size_t)i] = i;
+    return filter_fastq_files_on(ks, fq1, fq2, out1, out2, threshold, pair_mode, devs.data(), n_devices, kept, total);
+}
+
+int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2,
+                             uint32_t threshold, int pair_mode, const int *devices, int n_devices, uint64_t *kept, uint64_t *total)
+{
+    return filter_fastq_files_on(ks, fq1, fq2, out1, out2, threshold, pair_mode, devices, n_devices, kept, total);
 }
 
 // ------------------------------------------------------------- quality filter

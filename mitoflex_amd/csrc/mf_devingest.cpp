@@ -1,13 +1,22 @@
-// Device ingest path of mf_filter_fastq_files (see mf_devingest.h).
+// Device ingest path of mf_filter_fastq_files (see mf_devingest.h).  Streaming: what a file holds in device memory at any time is
+// bounded, whatever its size.
 //
-// An uploader thread reads the file into pinned staging and copies it up; one producer thread per mate turns it into text in a
-// contiguous arena -- a plain FASTQ file IS the text; a .gz is decoded in slabs of a few hundred speculative chunks (mf_gzdev.h):
-// the decode kernels of up to twelve slabs ahead run on their own streams while slab k is linked and slab k - 1 is resolved and
-// CRC-checked --; the calling thread is the consumer: it cuts the text into records where it lies (mf_ingest.h; what is behind
-// the last complete record of a piece, the carry, is the front of the next piece's text), packs them behind what the whole-file
-// read set already holds, runs ONE filter pass over the file when both mates are in, and copies the survivors out to a writer
-// thread per output file.  Pass bits are a file-wide bitmap per mate, so the pair rule does not care that the pieces of the two
-// mates do not cover the same records; the mate that is behind in records is advanced.
+// Per mate file one PRODUCER thread turns the file into pieces of text in device buffers, in order:
+//   * a .gz is decoded in slabs of a few hundred speculative chunks (mf_gzdev.h).  Its compressed bytes pass through a RING per
+//     device (a power of two of bytes; byte b of the file lives at ring[b % R]) that an uploader thread fills a piece at a time and
+//     that is recycled as slabs are linked; the decode kernels of up to twelve slabs run ahead on their own streams while slab
+//     k is linked and slab k - 1 is resolved and CRC-checked; symbol room per chunk follows the expansion the file has shown so
+//     far; every slab's text goes to a buffer of its own (the 32 KiB window and the carry in front of it);
+//   * a plain FASTQ file IS the text: it is read straight into such buffers.
+//   With n devices the slabs are dealt to them round robin: the link step of slab k needs the state the link step of slab k - 1
+//   left (bit position, text length, the last 32 KiB: 33 KB through the host), nothing else crosses devices.
+// The calling thread is the CONSUMER.  Per piece, on the device that holds it: cut the text into records where it lies
+// (mf_ingest.h; what is behind the last complete record of a piece, the carry, is copied to the front of the next piece's
+// buffer), 2-bit pack them into the device's refillable read set, ONE filter pass over the piece's reads; the pass bits come
+// back to the host (a bit per read), where the pair rule is applied across the two mates' file-wide bitmaps -- the pieces of the
+// two mates do not cover the same records, the mate that is behind in records is advanced --; a piece whose records the other
+// mate has covered gets its keep mask, its survivors are gathered on the device and copied out to a writer thread per output
+// file, and its buffers go back to the pool.  A producer blocks when its mate holds MF_INGEST_TEXT_BUFS text buffers.
 #include "mf_devingest.h"
 #include "mf_api_internal.h"
 #include "mf_gzdev.h"
@@ -37,19 +46,20 @@
 namespace mf {
 namespace {
 
-#define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + " failed: " + hipGetErrorString(e_); return MF_E_HIP; } } while (0)
+#define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + " failed: " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP; } } while (0)
 
 uint64_t env_u64(const char *name, uint64_t dflt) { const char *v = getenv(name); return v && *v ? strtoull(v, nullptr, 10) : dflt; }
 static const bool g_trace = getenv("MF_DEVINGEST_TRACE") != nullptr;
-#define TRACE(...) do { if (g_trace) { fprintf(stderr, "[devingest %.3f] ", now_s() - (double)(long)now_s() + ((long)now_s() % 1000)); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
-double now_s();
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define TRACE(...) do { if (g_trace) { const double t_ = now_s(); fprintf(stderr, "[devingest %.3f] ", t_ - (double)((long)t_ / 1000 * 1000)); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
+size_t pow2_ceil(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
-// Device memory of this path comes from a pool that outlives the call.  Two reasons.  hipFree waits for the whole device to go
-// idle -- with decode kernels in flight on other streams that is tens of milliseconds a call -- so nothing is freed while a
-// file is being processed: outgrown buffers go back to the pool.  And allocating (and later releasing) the tens of gigabytes a
-// large file takes costs more than a second, which a caller that filters file after file (the bim loop) would pay every
-// time: a call's buffers are kept for the next one, up to MF_DEVPOOL_GB (default 96; MF_KEEP_BUFFERS=0: nothing is kept).
+// Device memory of this path comes from a pool per device that outlives the call.  Two reasons.  hipFree waits for the whole
+// device to go idle -- with decode kernels in flight on other streams that is tens of milliseconds a call -- so nothing is freed
+// while a file is being processed: buffers go back to the pool and are handed out again (a slab's symbol and text buffers have
+// the size of the slab before).  And allocating (and later releasing) gigabytes costs a large fraction of a second, which a caller
+// that filters file after file (the bim loop) would pay every time: a call's buffers are kept for the next one, up to
+// MF_DEVPOOL_GB (default 16; MF_KEEP_BUFFERS=0: nothing is kept).  get() wants the caller's current device to be `dev`.
 class DevPool {
 public:
     static size_t round_up(size_t bytes)
@@ -58,59 +68,86 @@ public:
         while (unit * 16 < bytes && unit < ((size_t)256 << 20)) unit <<= 1;         // 1 MiB steps for small blocks, up to 256 MiB steps
         return (bytes + unit - 1) / unit * unit;
     }
-    hipError_t get(void **p, size_t bytes, size_t *got)
+    hipError_t get(int dev, void **p, size_t bytes, size_t *got)
     {
         const size_t want = round_up(bytes ? bytes : 1);
         {
             std::lock_guard<std::mutex> lk(mu_);
-            auto it = free_.lower_bound(want);
-            if (it != free_.end() && it->first <= want + want / 2 + ((size_t)64 << 20)) { *p = it->second; *got = it->first; held_ -= it->first; free_.erase(it); return hipSuccess; }
+            PerDev &D = dev_[dev];
+            auto it = D.free_.lower_bound(want);
+            if (it != D.free_.end() && it->first <= want + want / 2 + ((size_t)64 << 20)) {
+                *p = it->second; *got = it->first; D.held -= it->first; D.free_.erase(it);
+                account(dev, (long long)*got);
+                return hipSuccess;
+            }
         }
         hipError_t e = hipMalloc(p, want);
-        if (e != hipSuccess) {                      // make room: release what the pool holds and try once more
+        if (e != hipSuccess) {                      // make room: release what the pool holds for this device and try once more
             (void)hipGetLastError();
-            trim(0);
+            trim_dev(dev, 0);
             e = hipMalloc(p, want);
+            if (e != hipSuccess) (void)hipGetLastError();
         }
         *got = want;
+        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu_); account(dev, (long long)want); }
         return e;
     }
-    void put(void *p, size_t bytes) { if (!p) return; std::lock_guard<std::mutex> lk(mu_); free_.emplace(bytes, p); held_ += bytes; }
-    size_t held() { std::lock_guard<std::mutex> lk(mu_); return held_; }          // bytes waiting for the next call
-    void trim(size_t keep)                          // (only when no kernel of this path is in flight)
+    void put(int dev, void *p, size_t bytes)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        PerDev &D = dev_[dev];
+        D.free_.emplace(bytes, p); D.held += bytes;
+        account(dev, -(long long)bytes);
+    }
+    size_t held(int dev) { std::lock_guard<std::mutex> lk(mu_); return dev_[dev].held; }          // bytes waiting for the next call
+    // high-water mark of the bytes in use (handed out and not yet returned) on any one device since reset_peak()
+    size_t peak() { std::lock_guard<std::mutex> lk(mu_); size_t m = 0; for (auto &kv : dev_) m = std::max(m, kv.second.peak); return m; }
+    void reset_peak() { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) kv.second.peak = kv.second.used; }
+    void trim(size_t keep_per_dev)                  // (only when no kernel of this path is in flight)
+    {
+        std::vector<int> devs;
+        { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) devs.push_back(kv.first); }
+        for (int d : devs) trim_dev(d, keep_per_dev);
+    }
+private:
+    struct PerDev { std::multimap<size_t, void *> free_; size_t held = 0, used = 0, peak = 0; };
+    void account(int dev, long long delta) { PerDev &D = dev_[dev]; D.used = (size_t)((long long)D.used + delta); if (D.used > D.peak) D.peak = D.used; }     // (mu_ held)
+    void trim_dev(int dev, size_t keep)
     {
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            while (held_ > keep && !free_.empty()) { auto it = free_.begin(); drop.push_back(it->second); held_ -= it->first; free_.erase(it); }
+            PerDev &D = dev_[dev];
+            while (D.held > keep && !D.free_.empty()) { auto it = D.free_.begin(); drop.push_back(it->second); D.held -= it->first; D.free_.erase(it); }
         }
+        if (drop.empty()) return;
+        int cur = -1; (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
         for (void *q : drop) (void)hipFree(q);
+        if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
     }
-private:
-    std::mutex mu_; std::multimap<size_t, void *> free_; size_t held_ = 0;
+    std::mutex mu_; std::map<int, PerDev> dev_;
 };
 DevPool g_pool;
-// (buffers that an mf_reads owns are hipMalloc'ed; outgrown ones are parked here and freed when the call is over)
-struct Trash {
-    std::mutex mu; std::vector<void *> v;
-    void add(void *p) { if (p) { std::lock_guard<std::mutex> lk(mu); v.push_back(p); } }
-    void empty() { std::lock_guard<std::mutex> lk(mu); for (void *p : v) (void)hipFree(p); v.clear(); }
-};
-Trash g_trash;
 
+// a device buffer from the pool; `dev` is the PHYSICAL device
 template <class T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;                      // cap in elements
-    size_t bytes_ = 0;
+    size_t bytes_ = 0; int dev_ = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { g_pool.put(p, bytes_); }
-    hipError_t need(size_t n, bool slack = true)          // contents are NOT kept
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), bytes_(o.bytes_), dev_(o.dev_) { o.p = nullptr; o.cap = 0; o.bytes_ = 0; }
+    ~DevBuf() { g_pool.put(dev_, p, bytes_); }
+    void release() { g_pool.put(dev_, p, bytes_); p = nullptr; cap = 0; bytes_ = 0; }
+    hipError_t need(int dev, size_t n, bool slack = true)          // contents are NOT kept
     {
-        if (n <= cap && p) return hipSuccess;
-        g_pool.put(p, bytes_); p = nullptr; cap = 0; bytes_ = 0;
+        if (n <= cap && p && dev == dev_) return hipSuccess;
+        release();
+        dev_ = dev;
         const size_t want = slack ? n + n / 2 + 1024 : (n ? n : 1);
         void *q = nullptr; size_t got = 0;
-        hipError_t e = g_pool.get(&q, want * sizeof(T), &got);
+        hipError_t e = g_pool.get(dev, &q, want * sizeof(T), &got);
         if (e == hipSuccess) { p = (T *)q; bytes_ = got; cap = got / sizeof(T); }
         return e;
     }
@@ -119,13 +156,17 @@ template <class T> struct DevBuf {
 struct Mapped {
     const uint8_t *p = nullptr; size_t n = 0; int fd = -1;          // (the descriptor stays open: the uploader reads through it)
     ~Mapped() { if (p) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) ::close(fd); }
+    // regular = false: not a file this path takes (a pipe, a device ...) -- it has NOT been opened (opening a FIFO blocks until a
+    // writer appears, and closing it again may break that writer's pipe before the host pipeline opens it)
     bool open(const char *path, bool &regular)
     {
         regular = false;
+        struct stat st;
+        if (stat(path, &st) != 0) return false;
+        if (!S_ISREG(st.st_mode)) return true;
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
-        struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return true;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); fd = -1; return true; }
         regular = true;
         n = (size_t)st.st_size;
         if (n) {
@@ -138,106 +179,51 @@ struct Mapped {
     }
 };
 
-// ---- the file's bytes -> device memory, in order, on a copy stream of its own.  Consumers make their stream wait for the
-// event of the piece that completes the range they read.
-class Uploader {
-public:
-    static constexpr size_t PIECE = (size_t)32 << 20;
-    ~Uploader()
+// ---- page cache -> pinned memory on a few threads, with pread: reading a mapping instead takes a fault per 64 KiB and does
+// 3 GB/s a thread (with four of those the whole path once ran at the 11 GB/s of that copy, whatever the decoder did); the
+// mapping stays for what the host looks at (headers, trailers, gaps)
+struct Stager {
+    uint8_t *buf[2] = {nullptr, nullptr}; size_t piece = 0; int fd = -1; int nthr = 8;
+    ~Stager() { for (auto &b : buf) if (b) (void)hipHostFree(b); }
+    hipError_t init(size_t piece_bytes, int fd_)
     {
-        TRACE("~Uploader");
-        stop_ = true;
-        if (th_.joinable()) th_.join();
-        TRACE("uploader joined");
-        for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
-        for (auto &e : free_ev_) if (e) (void)hipEventDestroy(e);
-        for (auto &s : stage_) if (s) (void)hipHostFree(s);
-        if (st_) (void)hipStreamDestroy(st_);
+        piece = piece_bytes; fd = fd_;
+        nthr = (int)std::min<uint64_t>(16, std::max<uint64_t>(1, env_u64("MF_UPLOAD_THREADS", 8)));
+        for (auto &b : buf) { hipError_t e = hipHostMalloc((void **)&b, piece + 256, hipHostMallocPortable); if (e != hipSuccess) return e; }
+        return hipSuccess;
     }
-    int start(const uint8_t *src, int fd, size_t n, uint8_t *dst, int device, std::string &err)
+    bool read(int b, size_t off, size_t len)          // false: the file could not be read (truncated under us, an I/O error)
     {
-        src_ = src; fd_ = fd; n_ = n; dst_ = dst; device_ = device;
-        const size_t np = (n + PIECE - 1) / PIECE;
-        ev_.assign(np, nullptr);
-        for (auto &e : ev_) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        DCHK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            DCHK(hipHostMalloc((void **)&stage_[i], PIECE, hipHostMallocDefault));
-            DCHK(hipEventCreateWithFlags(&free_ev_[i], hipEventDisableTiming));
-        }
-        th_ = std::thread([this] { run(); });
-        return MF_OK;
-    }
-    // the copy of bytes [0, upto) has been issued (so wait_for would not block the host)
-    bool issued(size_t upto)
-    {
-        if (n_ == 0 || upto == 0) return true;
-        if (upto > n_) upto = n_;
-        std::lock_guard<std::mutex> lk(mu_);
-        return failed_ || enqueued_ > (upto - 1) / PIECE;
-    }
-    // make `st` wait until bytes [0, upto) are on the device (upto is clamped to the file).  false: the uploader failed
-    bool wait_for(hipStream_t st, size_t upto)
-    {
-        if (n_ == 0 || upto == 0) return true;
-        if (upto > n_) upto = n_;
-        const size_t j = (upto - 1) / PIECE;
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return enqueued_ > j || failed_; });
-        if (failed_) return false;
-        return hipStreamWaitEvent(st, ev_[j], 0) == hipSuccess;
-    }
-private:
-    void run()
-    {
-        if (hipSetDevice(device_) != hipSuccess) { fail_(); return; }
-        const size_t np = ev_.size();
-        const int nthr = (int)std::min<uint64_t>(16, std::max<uint64_t>(1, env_u64("MF_UPLOAD_THREADS", 8)));
-        for (size_t i = 0; i < np && !stop_; i++) {
-            const int b = (int)(i & 1);
-            if (i >= 2 && hipEventSynchronize(free_ev_[b]) != hipSuccess) { fail_(); return; }       // the copy that read this staging buffer is done
-            const size_t off = i * PIECE, len = std::min(PIECE, n_ - off);
-            {   // page cache -> pinned memory on a few threads, with pread: reading the mapping instead takes a fault per 64 KiB and
-                // does 3 GB/s a thread, and with four of those the whole path ran at the 11 GB/s of this copy (a 4.9 GB .gz in 0.44 s
-                // whatever the decoder did); the mapping stays for what the host looks at (headers, trailers, gaps)
-                auto part = [&](int t) {
-                    size_t a = len * t / nthr; const size_t e = len * (t + 1) / nthr;
-                    while (a < e) {
-                        const ssize_t got = fd_ >= 0 ? pread(fd_, stage_[b] + a, e - a, (off_t)(off + a)) : -1;
-                        if (got <= 0) { if (got < 0 && errno == EINTR) continue; memcpy(stage_[b] + a, src_ + off + a, e - a); break; }     // (a file that cannot be read this way: through the mapping)
-                        a += (size_t)got;
-                    }
-                };
-                std::vector<std::thread> th;
-                for (int t = 1; t < nthr; t++) th.emplace_back(part, t);
-                part(0);
-                for (auto &x : th) x.join();
+        std::atomic<bool> ok{true};
+        const int nt = len < ((size_t)1 << 20) ? 1 : nthr;
+        auto part = [&](int t) {
+            size_t a = len * t / nt; const size_t e = len * (t + 1) / nt;
+            while (a < e) {
+                const ssize_t got = pread(fd, buf[b] + a, e - a, (off_t)(off + a));
+                if (got < 0 && errno == EINTR) continue;
+                if (got <= 0) { ok = false; return; }
+                a += (size_t)got;
             }
-            if (hipMemcpyAsync(dst_ + off, stage_[b], len, hipMemcpyHostToDevice, st_) != hipSuccess || hipEventRecord(ev_[i], st_) != hipSuccess ||
-                hipEventRecord(free_ev_[b], st_) != hipSuccess) { fail_(); return; }
-            { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; }
-            cv_.notify_all();
-        }
-        (void)hipStreamSynchronize(st_);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(part, t);
+        part(0);
+        for (auto &x : th) x.join();
+        return ok;
     }
-    void fail_() { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; } cv_.notify_all(); }
-    const uint8_t *src_ = nullptr; int fd_ = -1; size_t n_ = 0; uint8_t *dst_ = nullptr; int device_ = 0;
-    hipStream_t st_ = nullptr; uint8_t *stage_[2] = {nullptr, nullptr}; hipEvent_t free_ev_[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev_;
-    std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; bool failed_ = false; std::atomic<bool> stop_{false};
 };
 
 // ---- the decoder's streams.  The link step is the decoder's one serial path, and its workgroup wants 64 KiB of LDS -- on a chip
 // whose LDS the decode wavefronts of the slabs ahead have filled it would wait tens of milliseconds for a CU to drain.  So a few
-// CUs (one per XCD: mask bit b is a CU of XCD b mod 8) are kept free of decode work: the decode streams are masked off them, the
+// CUs (mask bit b is a CU of XCD b mod 8) are kept free of decode work: the decode streams are masked off them, the
 // link stream runs only there.  Where CU masks are not to be had, ordinary streams.  The sets are made once and handed from
 // call to call: destroying a CU-masked stream right after use was seen to hang inside the runtime (ROCm 7.2), and they cost a
 // few milliseconds to make.
 constexpr uint32_t GZ_NSTREAM = 10;
-struct StreamSet { int device = -1; hipStream_t sd[GZ_NSTREAM] = {}, link = nullptr, rest = nullptr; };
+struct StreamSet { int device = -1; hipStream_t sd[GZ_NSTREAM] = {}, link = nullptr, rest = nullptr, copy = nullptr; };
 class StreamSets {
 public:
-    StreamSet *take(int device, std::string &err)
+    StreamSet *take(int device, std::string &err)              // (the caller's current device is `device`)
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -249,9 +235,8 @@ public:
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
         const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
         std::vector<uint32_t> m_dec((size_t)words, 0), m_link((size_t)words, 0);
-        // A decode wavefront holds 128 vector registers and 9.9 KB of LDS for tens of milliseconds, sixteen of them fill a CU to the
-        // last register: whatever else has to run meanwhile -- the link step, marker resolution, CRC, the consumer's line index and
-        // pack kernels, all short and all on some host thread's critical path -- needs CUs of its own.  Four per XCD by default.
+        // Whatever else has to run while decode wavefronts fill the chip -- the link step, marker resolution, CRC, the consumer's
+        // line index and pack kernels, all short and all on some host thread's critical path -- needs CUs of its own.  Four per XCD.
         int reserve = (int)env_u64("MF_GZDEV_RESERVED_CUS", 32);
         reserve = std::max(8, std::min(n_cu / 2, reserve)) & ~7;
         for (int b = 0; b < n_cu; b++) (b >= n_cu - reserve ? m_link : m_dec)[b / 32] |= 1u << (b % 32);
@@ -261,6 +246,7 @@ public:
             if (!masks || hipExtStreamCreateWithCUMask(&q, (uint32_t)words, m_dec.data()) != hipSuccess) { (void)hipGetLastError(); ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess; }
         if (!masks || hipExtStreamCreateWithCUMask(&s->link, (uint32_t)words, m_link.data()) != hipSuccess) { (void)hipGetLastError(); ok = ok && hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess; }
         ok = ok && hipStreamCreateWithFlags(&s->rest, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking) == hipSuccess;
         if (!ok) { err = "hipStreamCreate failed"; return nullptr; }           // (what was made stays behind: never destroyed, see above)
         return s.release();
     }
@@ -270,155 +256,345 @@ private:
 };
 StreamSets g_streams;
 
-// ---- the text of one input file on the device: ONE contiguous arena per mate, so that a record that spans two slabs, or the
-// 32 KiB deflate window in front of a chunk, is simply the bytes in front.  A plain file's arena is the uploaded file; a .gz's
-// grows (rarely) as the text does.  The producer thread writes behind `ready`, the consumer reads in front of it.
-struct Arena {
-    static constexpr size_t FRONT = 32768 + 256; // readable bytes in front of p: a damaged stream may point a full window back from its first byte
-    uint8_t *p = nullptr; size_t cap = 0;       // cap bytes usable (+ 64 readable behind)
-    uint8_t *raw = nullptr; size_t raw_bytes = 0; // the allocation, when the arena owns one
-    std::mutex mu;                               // held by the consumer while it enqueues kernels that read the arena, by the producer while it moves it
-    hipEvent_t read_ev = nullptr; bool read_pending = false;      // behind the consumer's last kernels that read it: the producer waits for it before it moves the arena
-    ~Arena() { if (read_ev) (void)hipEventDestroy(read_ev); g_pool.put(raw, raw_bytes); }
+// ---- how many text buffers a mate may hold at a time (the producer waits for one to come back)
+struct Slots {
+    std::mutex mu; std::condition_variable cv; int free_ = 0; std::atomic<bool> *stop = nullptr;
+    bool take() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return free_ > 0 || (stop && *stop); }); if (free_ <= 0) return false; free_--; return true; }
+    void give() { { std::lock_guard<std::mutex> lk(mu); free_++; } cv.notify_all(); }
+    void wake() { cv.notify_all(); }
+};
+
+// ---- the text of one piece of an input file on one device.  In front of the text: `pad` readable bytes -- the 32 KiB deflate
+// window of the piece's first chunk (written by the link step), and room for the carry: the head of the record that the piece
+// before left unfinished is copied there, so that a record is always contiguous.
+constexpr size_t TEXT_FRONT = 32768 + 256;     // a damaged stream may point a full window back from its first byte
+struct TextBuf {
+    int dev = 0, ldev = 0;                      // physical / logical device
+    uint8_t *raw = nullptr; size_t raw_bytes = 0;
+    uint8_t *p = nullptr; size_t pad = 0, cap = 0;      // p = raw + pad; cap text bytes fit behind p (and 64 more are readable)
+    Slots *slots = nullptr;
+    ~TextBuf() { g_pool.put(dev, raw, raw_bytes); if (slots) slots->give(); }
+    static hipError_t make(std::unique_ptr<TextBuf> &out, int dev, int ldev, size_t pad, size_t text_bytes, Slots *slots)
+    {
+        std::unique_ptr<TextBuf> b(new TextBuf());
+        b->dev = dev; b->ldev = ldev;
+        pad = (pad + 255) & ~(size_t)255;
+        hipError_t e = g_pool.get(dev, (void **)&b->raw, pad + text_bytes + 64, &b->raw_bytes);
+        if (e != hipSuccess) { b->raw = nullptr; b->raw_bytes = 0; if (slots) slots->give(); return e; }
+        b->slots = slots;
+        b->pad = pad; b->p = b->raw + pad; b->cap = b->raw_bytes - pad - 64;
+        out = std::move(b);
+        return hipSuccess;
+    }
 };
 
 // a range of an input's text that has become available, in order
-struct TextPiece { uint64_t T0 = 0, len = 0; bool last = false; uint64_t est_total = 0; };      // est_total: the file's whole text, as far as one can tell now
+struct TextPiece { std::unique_ptr<TextBuf> buf; uint64_t T0 = 0, len = 0; bool last = false; };
 
-// ---- one gzip file decoded on the device (runs on the mate's producer thread, on its own streams)
+// ---- a .gz file's bytes -> the rings of the devices that decode it, in order, a piece at a time.  The slab layout says which
+// devices want which bytes; the producer moves the low-water mark (everything in front of it has been linked) and the uploader
+// keeps within a ring's length of it.  Decode streams wait for the event of the piece that completes the range they read.
+class GzUploader {
+public:
+    struct Lane { int dev = 0; uint8_t *ring = nullptr; hipStream_t st = nullptr; };
+    ~GzUploader()
+    {
+        stop_ = true; cv_.notify_all();
+        if (th_.joinable()) th_.join();
+        for (size_t l = 0; l < lanes_.size(); l++) {
+            (void)hipSetDevice(lanes_[l].dev);
+            for (auto &e : ev_[l]) if (e) (void)hipEventDestroy(e);
+            for (int b = 0; b < 2; b++) if (free_ev_[l][b]) (void)hipEventDestroy(free_ev_[l][b]);
+        }
+    }
+    // piece_lanes[i]: bit l set = lane l wants piece i
+    int start(int fd, size_t n, size_t ring_bytes, size_t piece, std::vector<Lane> lanes, std::vector<uint64_t> piece_lanes, std::string &err)
+    {
+        n_ = n; ring_ = ring_bytes; piece_ = piece; lanes_ = std::move(lanes); want_ = std::move(piece_lanes);
+        DCHK(stage_.init(piece_, fd));
+        ev_.assign(lanes_.size(), std::vector<hipEvent_t>(want_.size(), nullptr));
+        free_ev_.assign(lanes_.size(), std::array<hipEvent_t, 2>{nullptr, nullptr});
+        stage_used_[0] = stage_used_[1] = 0;
+        low_ = 0;
+        th_ = std::thread([this] { run(); });
+        return MF_OK;
+    }
+    void set_low_water(uint64_t byte) { { std::lock_guard<std::mutex> lk(mu_); if (byte > low_) low_ = byte; } cv_.notify_all(); }
+    // the copy of bytes [0, upto) has been issued (so wait_for would not block the host)
+    bool issued(size_t upto)
+    {
+        if (n_ == 0 || upto == 0) return true;
+        if (upto > n_) upto = n_;
+        std::lock_guard<std::mutex> lk(mu_);
+        return failed_ || enqueued_ > (upto - 1) / piece_;
+    }
+    // make `st` (a stream of lane l's device) wait until the bytes [.., upto) that lane l wants are in its ring.  false: the uploader failed
+    bool wait_for(size_t l, hipStream_t st, size_t upto)
+    {
+        if (n_ == 0 || upto == 0) return true;
+        if (upto > n_) upto = n_;
+        size_t j = (upto - 1) / piece_;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return enqueued_ > j || failed_; });
+        if (failed_) return false;
+        while (!((want_[j] >> l) & 1)) { if (!j) return true; j--; }       // (the copy stream is in order: the last piece of this lane at or in front of j)
+        return hipStreamWaitEvent(st, ev_[l][j], 0) == hipSuccess;
+    }
+private:
+    void run()
+    {
+        const size_t np = want_.size();
+        for (size_t i = 0; i < np && !stop_; i++) {
+            const size_t off = i * piece_, len = std::min(piece_, n_ - off);
+            if (!want_[i]) { { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; } cv_.notify_all(); continue; }
+            {   // not more than a ring's length ahead of what has been linked
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || off + len + 256 <= low_ + ring_; });
+                if (stop_) return;
+            }
+            const int b = (int)(i & 1);
+            for (size_t l = 0; l < lanes_.size(); l++)          // the copies that read this staging buffer are done
+                if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(); return; } }
+            stage_used_[b] = 0;
+            if (!stage_.read(b, off, len)) { fail_(); return; }
+            size_t total = len;
+            if (off + len == n_) { memset(stage_.buf[b] + len, 0, 256); total += 256; }          // readable and zero behind the last byte
+            for (size_t l = 0; l < lanes_.size(); l++) {
+                if (!((want_[i] >> l) & 1)) continue;
+                const Lane &L = lanes_[l];
+                if (hipSetDevice(L.dev) != hipSuccess) { fail_(); return; }
+                if (!ev_[l][i] && hipEventCreateWithFlags(&ev_[l][i], hipEventDisableTiming) != hipSuccess) { fail_(); return; }
+                if (!free_ev_[l][b] && hipEventCreateWithFlags(&free_ev_[l][b], hipEventDisableTiming) != hipSuccess) { fail_(); return; }
+                // (a piece never straddles the end of the ring -- the ring is a multiple of the piece --, the zeros behind the file may)
+                const size_t r0 = off & (ring_ - 1), first = std::min(total, ring_ - r0);
+                if (hipMemcpyAsync(L.ring + r0, stage_.buf[b], first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(); return; }
+                if (first < total && hipMemcpyAsync(L.ring, stage_.buf[b] + first, total - first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(); return; }
+                if (hipEventRecord(ev_[l][i], L.st) != hipSuccess || hipEventRecord(free_ev_[l][b], L.st) != hipSuccess) { fail_(); return; }
+                stage_used_[b] |= (uint64_t)1 << l;
+            }
+            { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; }
+            cv_.notify_all();
+        }
+        for (auto &L : lanes_) { if (hipSetDevice(L.dev) == hipSuccess) (void)hipStreamSynchronize(L.st); }
+    }
+    void fail_() { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; } cv_.notify_all(); }
+    size_t n_ = 0, ring_ = 0, piece_ = 0;
+    std::vector<Lane> lanes_; std::vector<uint64_t> want_;
+    Stager stage_; uint64_t stage_used_[2] = {0, 0};
+    std::vector<std::vector<hipEvent_t>> ev_; std::vector<std::array<hipEvent_t, 2>> free_ev_;
+    std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; uint64_t low_ = 0; bool failed_ = false; std::atomic<bool> stop_{false};
+};
+
+// ---- one gzip file decoded on the device(s) (runs on the mate's producer thread, on its own streams)
 class GzStream {
 public:
     ~GzStream()
     {
         TRACE("~GzStream");
-        for (auto &s : sym_) { if (s.ev) (void)hipEventDestroy(s.ev); }
-        if (streams_) {                           // nothing of this decoder may be in flight when its buffers go back to the pool
-            for (auto &s : sd_) if (s) (void)hipStreamSynchronize(s);
-            (void)hipStreamSynchronize(sp_); (void)hipStreamSynchronize(sr_);
-            g_streams.give(streams_);
+        up_.reset();                                  // (the uploader's copies go to the rings below)
+        for (auto &L : lanes_) {                      // nothing of this decoder may be in flight when its buffers go back to the pool
+            if (!L.streams) continue;
+            (void)hipSetDevice(L.dev);
+            for (auto &s : L.streams->sd) if (s) (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(L.streams->link); (void)hipStreamSynchronize(L.streams->rest); (void)hipStreamSynchronize(L.streams->copy);
+            if (L.ev_link) (void)hipEventDestroy(L.ev_link);
         }
-        if (ev_link_) (void)hipEventDestroy(ev_link_);
-        TRACE("streams destroyed");
+        for (auto &S : slabs_) if (S->ev) { (void)hipSetDevice(lanes_[S->lane].dev); (void)hipEventDestroy(S->ev); }
+        if (pend_slab_ && pend_slab_->ev) { (void)hipSetDevice(lanes_[pend_slab_->lane].dev); (void)hipEventDestroy(pend_slab_->ev); }
+        slabs_.clear(); pend_slab_.reset(); pend_.buf.reset(); cur_buf_.reset();
+        for (auto &L : lanes_) {
+            L.ring.release(); L.d_chunks.release(); L.d_out_off.release(); L.d_chain.release(); L.d_crc.release();
+            if (L.h_crc) { (void)hipSetDevice(L.dev); (void)hipHostFree(L.h_crc); }
+            g_streams.give(L.streams);
+        }
         if (h_chain_) (void)hipHostFree(h_chain_);
-        if (h_crc_) (void)hipHostFree(h_crc_);
         TRACE("~GzStream done");
     }
-    // data: the mapped file; d_file: its copy on the device (size + 64 readable, being filled by `up`)
-    int open(const uint8_t *data, size_t size, uint8_t *d_file, Uploader *up, Arena *arena, const std::string &path, std::string &err)
+    // data: the mapped file (what the host looks at: headers, trailers, gaps); devices: the logical devices that decode it
+    // nslab: slabs whose decode kernels may be in flight per device (enough wavefronts to fill the chip: twelve for one file, seven each for two mates)
+    int open(const uint8_t *data, size_t size, int fd, const std::vector<int> &devices, const std::string &path, Slots *slots, size_t carry_room,
+             uint32_t nslab, std::atomic<bool> *stop, std::string &err)
     {
-        data_ = data; size_ = size; d_file_ = d_file; up_ = up; arena_ = arena; path_ = path;
+        const uint32_t NSLAB = std::max<uint32_t>(1, (uint32_t)env_u64("MF_GZDEV_SLABS_IN_FLIGHT", nslab));
+        data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
+        const uint32_t nl = (uint32_t)devices.size();
         // chunks: large enough that the serial link step (a fixed cost per chunk) stays small, small enough that a file keeps the chip busy
         size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)256 << 10) & ~(size_t)4095;
         chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", dflt);
         if (chunk_ < 1024) chunk_ = 1024;
         cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", std::max<uint64_t>(256, ((uint64_t)128 << 20) / chunk_));
         if (cps_ < 1) cps_ = 1;
-        expand_ = env_u64("MF_GZDEV_EXPAND", 8);
+        // symbols of room per compressed byte: a first guess (FASTQ compresses three- to fivefold; the rule adds a chunk's worth, so
+        // 3.5 covers 4.5 : 1), then what the file has shown plus a quarter; a slab that overflows is decoded again with four times the room
+        expand_ = getenv("MF_GZDEV_EXPAND") ? (double)env_u64("MF_GZDEV_EXPAND", 4) : 3.5;
+        expand_fixed_ = getenv("MF_GZDEV_EXPAND") != nullptr;
+        text_piece_max_ = env_u64("MF_GZDEV_TEXT_PIECE", (uint64_t)1 << 30);
         size_t pos = 0;
         if (!member_header(pos, err)) return MF_E_FORMAT;
         base_byte_ = pos;
         n_chunks_ = (uint32_t)((size_ - base_byte_ + chunk_ - 1) / chunk_);
         if (n_chunks_ == 0) n_chunks_ = 1;
         if (cps_ > n_chunks_) cps_ = n_chunks_;
-        n_slabs_ = (n_chunks_ + cps_ - 1) / cps_;
-        sym_cap_ = chunk_ * expand_ + 262144;
-        DCHK(d_chunks_.need(n_chunks_, false)); DCHK(d_out_off_.need(n_chunks_, false)); DCHK(d_chain_.need(1, false));
+        // the ring: room for the slabs in flight, the bytes a slab's last chunk reads behind its range, and the uploader's pieces
+        margin_ = (size_t)env_u64("MF_GZDEV_MARGIN", (size_t)8 << 20);
+        const size_t slab_bytes = (size_t)cps_ * chunk_;
+        size_t ring = pow2_ceil(std::max<size_t>(size_ + 512, 4096));
         {
-            int dev = 0;
-            DCHK(hipGetDevice(&dev));
-            streams_ = g_streams.take(dev, err);
-            if (!streams_) return MF_E_HIP;
-            for (uint32_t i = 0; i < NSTREAM; i++) sd_[i] = streams_->sd[i];
-            sp_ = streams_->link; sr_ = streams_->rest;
-            DCHK(hipEventCreateWithFlags(&ev_link_, hipEventDisableTiming));
+            uint64_t want = env_u64("MF_GZDEV_RING_BYTES", 0);
+            if (!want) want = (uint64_t)NSLAB * nl * slab_bytes + margin_ + ((size_t)96 << 20);
+            want = pow2_ceil(std::max<uint64_t>(want, 4096));
+            if (want < ring) ring = (size_t)want;
         }
-        // (never the null stream: the CU-masked streams are blocking ones, a copy on the null stream would wait for every decode
-        // kernel in flight -- of the other mate's file too)
-        DCHK(hipMemsetAsync(d_chunks_.p, 0, n_chunks_ * sizeof(GzChunk), sr_));
-        DCHK(hipMemsetAsync(d_out_off_.p, 0xFF, n_chunks_ * sizeof(uint64_t), sr_));
-        DCHK(hipHostMalloc((void **)&h_chain_, sizeof(GzChain), hipHostMallocDefault));
+        piece_ = std::min<size_t>((size_t)32 << 20, std::max<size_t>(ring / 8, 512));
+        for (;;) {          // slabs in flight: what the ring holds beside the margin and three pieces of the uploader
+            const size_t fixed = margin_ + 3 * piece_ + 512;
+            if (ring > fixed + slab_bytes) { max_inflight_ = (uint32_t)std::min<size_t>((size_t)NSLAB * nl, (ring - fixed) / slab_bytes); break; }
+            ring <<= 1;
+        }
+        ring_ = ring;
+        // the slabs: short ones first (the consumer gets text, and the decoder its estimate of the expansion, early), dealt round robin
+        {
+            uint32_t lo = 0, n = std::max<uint32_t>(std::min<uint32_t>(cps_, 16), cps_ / 8), s = 0;
+            while (lo < n_chunks_) {
+                const uint32_t hi = std::min(n_chunks_, lo + n);
+                plan_.push_back(SlabPlan{lo, hi, s % nl});
+                lo = hi; s++;
+                n = std::min(cps_, n * 2);
+            }
+        }
+        h_chunks_.resize(n_chunks_);
+        DCHK(hipHostMalloc((void **)&h_chain_, sizeof(GzChain), hipHostMallocPortable));
         memset(h_chain_, 0, sizeof(GzChain));
         h_chain_->cur_bit = (uint64_t)base_byte_ * 8;
-        DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sr_));
-        DCHK(hipStreamSynchronize(sr_));
-        for (auto &s : sym_) { DCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)); s.slab = ~0u; }
-        h_chunks_.resize(n_chunks_);
-        // the arena: a first guess at the size of the text (FASTQ compresses three- to fivefold); it is moved when it proves too small
-        const int rc = grow_arena(std::max<size_t>(size_ * 4, (size_t)64 << 20), err);
+        lanes_.resize(nl);
+        std::vector<GzUploader::Lane> ul(nl);
+        for (uint32_t l = 0; l < nl; l++) {
+            Lane &L = lanes_[l];
+            L.ldev = devices[l]; L.dev = phys(devices[l]);
+            DCHK(hipSetDevice(L.dev));
+            L.streams = g_streams.take(L.dev, err);
+            if (!L.streams) return MF_E_HIP;
+            DCHK(hipEventCreateWithFlags(&L.ev_link, hipEventDisableTiming));
+            DCHK(L.ring.need(L.dev, ring_ + 4096, false));
+            DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_out_off.need(L.dev, n_chunks_, false)); DCHK(L.d_chain.need(L.dev, 1, false));
+            // (never the null stream: the CU-masked streams are blocking ones, a copy on the null stream would wait for every decode
+            // kernel in flight -- of the other mate's file too)
+            hipStream_t sr = L.streams->rest;
+            DCHK(hipMemsetAsync(L.d_chunks.p, 0, n_chunks_ * sizeof(GzChunk), sr));
+            DCHK(hipMemsetAsync(L.d_out_off.p, 0xFF, n_chunks_ * sizeof(uint64_t), sr));
+            DCHK(hipMemcpyAsync(L.d_chain.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sr));
+            DCHK(hipStreamSynchronize(sr));
+            ul[l].dev = L.dev; ul[l].ring = L.ring.p; ul[l].st = L.streams->copy;
+        }
+        chain_lane_ = 0; chain_dirty_ = false;
+        // which lanes want which pieces of the file
+        const size_t np = (size_ + piece_ - 1) / piece_;
+        std::vector<uint64_t> want(np, 0);
+        for (const SlabPlan &P : plan_) {
+            const size_t a = P.lo ? base_byte_ + (size_t)P.lo * chunk_ : 0, b = std::min(size_, base_byte_ + (size_t)P.hi * chunk_ + margin_);
+            for (size_t i = a / piece_; i <= (b - 1) / piece_ && i < np; i++) want[i] |= (uint64_t)1 << P.lane;
+        }
+        up_.reset(new GzUploader());
+        const int rc = up_->start(fd, size_, ring_, piece_, ul, want, err);
         if (rc) return rc;
         in_member_ = true;
+        TRACE("gz open: %u chunks of %zu B, %zu slabs (<= %u chunks), ring %zu MiB, pieces of %zu KiB, %u slabs in flight, %u lanes", n_chunks_, chunk_, plan_.size(), cps_,
+              ring_ >> 20, piece_ >> 10, max_inflight_, nl);
         return MF_OK;
     }
-    // text of the next slab (possibly nothing) is in the arena when this returns
-    // Marker resolution and the CRC of slab k run while slab k + 1 is waited for and linked (they are the link step's only
-    // neighbours on the producer's critical path: 1.8 ms of 5.5 per slab), so the piece this returns is the one BEFORE the slab it
-    // has just linked -- nothing the first time, the last piece in a call of its own.
+    // The next piece of text (possibly nothing: out.buf is null).  Marker resolution and the CRC of piece k run while piece k + 1 is
+    // waited for and linked (they are the link step's only neighbours on the producer's critical path), so the piece this returns
+    // is the one BEFORE the piece it has just linked -- nothing the first time, the last piece in a call of its own.
     int next(TextPiece &out, std::string &err)
     {
-        hipStream_t sp = sp_;
         out = TextPiece();
-        if (done_ || next_slab_ >= n_slabs_) return finish_pending(out, err);
-        const uint32_t k = next_slab_;
-        // decode runs ahead of the text: this slab (waiting for its bytes if need be) and as many of the following ones as there are
-        // symbol buffers and uploaded bytes for
-        for (uint32_t j = k; j < k + NSYM && j < n_slabs_; j++) { const int rc = launch_decode(j, j == k, err); if (rc) return rc; }
-        const uint32_t lo = k * cps_, hi = std::min(n_chunks_, lo + cps_);
-        Sym &S = sym_[k % NSYM];
-        TRACE("slab %u: chunks %u..%u, waiting for decode", k, lo, hi);
-        DCHK(hipStreamWaitEvent(sp, S.ev, 0));
-        DCHK(hipMemcpyAsync(h_chunks_.data() + lo, d_chunks_.p + lo, (hi - lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sp));
-        DCHK(hipStreamSynchronize(sp));
-        uint64_t sum = 0; uint32_t max_sym = 0;
-        for (;;) {
-            bool overflow = false;
-            sum = 0; max_sym = 0;
-            for (uint32_t c = lo; c < hi; c++) {
-                const GzChunk &ch = h_chunks_[c];
-                if (ch.status == GZ_OVERFLOW) overflow = true;
-                if (ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END) { sum += ch.n_sym; max_sym = std::max(max_sym, ch.n_sym); }
-            }
-            TRACE("slab %u decoded: %llu symbols, overflow %d", k, (unsigned long long)sum, (int)overflow);
-            if (!overflow) break;
-            // text that expands more than the symbol buffers allow for (a run of identical reads, say): this slab again, with four times the room
-            if (S.cap > chunk_ * 2048) { err = "gzip data in " + path_ + " expands more than a thousandfold: not decoded on the device"; return MF_E_FORMAT; }
-            S.cap *= 4;
-            DCHK(S.p.need((size_t)(hi - lo) * S.cap, false));
-            DCHK(launch_gz_decode(d_file_, size_, base_byte_, chunk_, lo, hi - lo, 0, (uint64_t)base_byte_ * 8, S.p.p, S.cap, d_chunks_.p, sd_[0]));
-            DCHK(hipMemcpyAsync(h_chunks_.data() + lo, d_chunks_.p + lo, (hi - lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd_[0]));
-            DCHK(hipStreamSynchronize(sd_[0]));
-        }
-        const uint64_t T0 = h_chain_->total;
-        int rc = grow_arena(T0 + sum + ((size_t)1 << 20), err);
+        if (done_ || (slabs_.empty() && next_plan_ >= plan_.size())) return finish_pending(out, err);
+        // decode runs ahead of the text: the front slab (waiting for its bytes if need be) and as many of the following ones as the
+        // ring has room and uploaded bytes for
+        int rc = launch_ahead(err);
         if (rc) return rc;
-        const bool last_slab = k + 1 == n_slabs_;
+        Slab &S = *slabs_.front();
+        Lane &L = lanes_[S.lane];
+        DCHK(hipSetDevice(L.dev));
+        hipStream_t sp = L.streams->link, sr = L.streams->rest;
+        if (!S.read_back) {
+            TRACE("slab %u..%u on lane %u: waiting for decode", S.lo, S.hi, S.lane);
+            DCHK(hipStreamWaitEvent(sp, S.ev, 0));
+            DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sp));
+            DCHK(hipStreamSynchronize(sp));
+            for (;;) {
+                bool overflow = false;
+                for (uint32_t c = S.lo; c < S.hi; c++) if (h_chunks_[c].status == GZ_OVERFLOW) overflow = true;
+                if (!overflow) break;
+                // text that expands more than the symbol buffers allow for (a run of identical reads, say): this slab again, with four
+                // times the room -- the first half of it only, when that would be a very large buffer
+                if (S.cap > chunk_ * 2048) { err = "gzip data in " + path_ + " expands more than a thousandfold: not decoded on the device"; return MF_E_FORMAT; }
+                const size_t budget = (size_t)env_u64("MF_GZDEV_RETRY_BYTES", (size_t)4 << 30);
+                while (S.hi - S.lo > 1 && (size_t)(S.hi - S.lo) * S.cap * 4 * 2 > budget) {
+                    const uint32_t mid = S.lo + (S.hi - S.lo) / 2;
+                    std::unique_ptr<Slab> B(new Slab());
+                    B->lo = mid; B->hi = S.hi; B->lane = S.lane; B->cap = 0;      // (decoded when it is the front slab: its bytes are in the ring)
+                    S.hi = mid;
+                    slabs_.insert(slabs_.begin() + 1, std::move(B));
+                    n_splits_++;
+                }
+                S.cap *= 4;
+                TRACE("slab %u..%u overflowed: again with %zu symbols per chunk", S.lo, S.hi, S.cap);
+                DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
+                hipStream_t sd = L.streams->sd[0];
+                DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, sd));
+                DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd));
+                DCHK(hipStreamSynchronize(sd));
+            }
+            uint32_t mx = 0;
+            for (uint32_t c = S.lo; c < S.hi; c++) { const GzChunk &ch = h_chunks_[c]; if (ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END) mx = std::max(mx, ch.n_sym); }
+            max_sym_seen_ = std::max(max_sym_seen_, mx);
+            S.read_back = true; S.cur = S.lo;
+        }
+        // the chunks of this piece: as many of the slab's as make a text buffer of reasonable size
+        const uint32_t a = S.cur; uint32_t b = a; uint64_t sum = 0; uint32_t max_sym = 0;
+        while (b < S.hi) {
+            const GzChunk &ch = h_chunks_[b];
+            const uint64_t n = (ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END) ? ch.n_sym : 0;
+            if (b > a && sum + n > text_piece_max_) break;
+            sum += n; max_sym = std::max<uint32_t>(max_sym, (uint32_t)n); b++;
+        }
+        const bool last_piece = b == n_chunks_;
+        const uint64_t T0 = h_chain_->total;
+        TRACE("piece: chunks %u..%u, %llu symbols, text from %llu", a, b, (unsigned long long)sum, (unsigned long long)T0);
+        rc = new_text(L, T0, sum + ((size_t)1 << 20), err);
+        if (rc) return rc;
         // link; the host steps in where the chain stops
+        const uint16_t *sym_a = S.sym.p;             // (the chain and resolve kernels index the slab's symbols from its first chunk)
         for (bool first = true;; first = false) {
             if (!done_ && in_member_) {
-                DCHK(launch_gz_chain(d_chain_.p, d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, arena_->p, 0, sp));
-                DCHK(hipMemcpyAsync(h_chain_, d_chain_.p, offsetof(GzChain, window), hipMemcpyDeviceToHost, sp));
+                rc = chain_to(S.lane, sp, err); if (rc) return rc;
+                DCHK(launch_gz_chain(L.d_chain.p, L.d_chunks.p, S.lo, b, sym_a, S.cap, L.d_out_off.p, cur_buf_->p, T0, sp));
+                DCHK(hipMemcpyAsync(h_chain_, L.d_chain.p, lanes_.size() > 1 ? sizeof(GzChain) : offsetof(GzChain, window), hipMemcpyDeviceToHost, sp));
             }
-            if (first) { rc = finish_pending(out, err); if (rc) return rc; }       // (the slab before: its resolve and CRC kernels ran beside this slab's decode wait and link)
+            if (first) { rc = finish_pending(out, err); if (rc) return rc; DCHK(hipSetDevice(L.dev)); }       // (the piece before: its resolve and CRC kernels ran beside this one's decode wait and link)
             if (!done_ && in_member_) DCHK(hipStreamSynchronize(sp));
             TRACE("chain: stop %u next %u cur_bit %llu total %llu linked %u", h_chain_->stop, h_chain_->next, (unsigned long long)h_chain_->cur_bit, (unsigned long long)h_chain_->total, h_chain_->linked);
             if (done_) break;
             uint64_t to_bit = 0;
-            if (h_chain_->stop == GZ_STOP_MEMBER_END) { rc = member_end(max_sym, sp, err); if (rc) return rc; if (done_) break; }
+            // (behind a member's end the link step goes on with the rest of the piece's chunks, from the next member's first block)
+            if (h_chain_->stop == GZ_STOP_MEMBER_END) { rc = member_end(S, a, b, max_sym, T0, err); if (rc) return rc; if (done_) break; continue; }
             if (h_chain_->stop == GZ_STOP_GAP) to_bit = h_chunks_[h_chain_->next].start_bit;
             else if (h_chain_->stop == GZ_STOP_NONE) {
-                if (!last_slab) break;
+                if (!last_piece) break;
                 to_bit = (uint64_t)size_ * 8;             // behind the last chunk: the host decodes to the end of the member
             }
             // ---- decode across the gap on the host, with the window the chain left
-            DCHK(hipMemcpyAsync(h_chain_->window, d_chain_.p->window, GZ_WINDOW, hipMemcpyDeviceToHost, sp)); DCHK(hipStreamSynchronize(sp));
+            if (lanes_.size() == 1) { DCHK(hipMemcpyAsync(h_chain_->window, L.d_chain.p->window, GZ_WINDOW, hipMemcpyDeviceToHost, sp)); DCHK(hipStreamSynchronize(sp)); }
             std::vector<uint8_t> bytes; uint64_t end_bit = 0; bool mend = false; std::string why;
             if (!inflate_gap(data_, size_, h_chain_->cur_bit, to_bit, h_chain_->window, h_chain_->wlen, bytes, end_bit, mend, why)) {
                 err = "gzip read error in " + path_ + ": " + why; return MF_E_FORMAT;
             }
             gap_bytes_ += bytes.size(); n_gaps_++;
             TRACE("gap: %zu bytes, ends at bit %llu (wanted %llu), member end %d", bytes.size(), (unsigned long long)end_bit, (unsigned long long)to_bit, (int)mend);
-            rc = grow_arena(h_chain_->total + bytes.size() + sum + ((size_t)1 << 20), err);
+            rc = grow_text(L, T0, h_chain_->total + bytes.size() + sum + ((size_t)1 << 20), err);
             if (rc) return rc;
-            if (!bytes.empty()) { DCHK(hipMemcpyAsync(arena_->p + h_chain_->total, bytes.data(), bytes.size(), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
+            if (!bytes.empty()) { DCHK(hipMemcpyAsync(cur_buf_->p + (h_chain_->total - T0), bytes.data(), bytes.size(), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
             // the window behind the gap
             if (bytes.size() >= GZ_WINDOW) { memcpy(h_chain_->window, bytes.data() + bytes.size() - GZ_WINDOW, GZ_WINDOW); h_chain_->wlen = GZ_WINDOW; }
             else {
@@ -428,76 +604,125 @@ public:
                 h_chain_->wlen = (uint32_t)(keep + bytes.size());
             }
             h_chain_->cur_bit = end_bit; h_chain_->total += bytes.size();
-            if (h_chain_->stop == GZ_STOP_NONE && last_slab && !mend && bytes.empty()) { err = "gzip read error in " + path_ + ": truncated deflate stream"; return MF_E_FORMAT; }
+            if (h_chain_->stop == GZ_STOP_NONE && last_piece && !mend && bytes.empty()) { err = "gzip read error in " + path_ + ": truncated deflate stream"; return MF_E_FORMAT; }
             h_chain_->stop = mend ? GZ_STOP_MEMBER_END : GZ_STOP_NONE;
-            DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp));
-            if (mend) { rc = member_end(max_sym, sp, err); if (rc) return rc; if (done_) break; }
+            chain_dirty_ = true;
+            if (mend) { rc = member_end(S, a, b, max_sym, T0, err); if (rc) return rc; if (done_) break; }
         }
-        DCHK(hipEventRecord(ev_link_, sp)); DCHK(hipStreamWaitEvent(sr_, ev_link_, 0));
-        DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, S.p.p, S.cap, d_out_off_.p, arena_->p, 0, max_sym, sr_));
-        // the rest of the member's CRC over this slab: launched here, taken in by finish_pending
-        if (h_chain_->total > crc_done_) { rc = crc_launch(crc_done_, h_chain_->total, sr_, err); if (rc) return rc; }
-        next_slab_ = k + 1;
-        if (next_slab_ == n_slabs_ && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
-        pend_.T0 = T0; pend_.len = h_chain_->total - T0; pend_.last = done_;
-        {   // the text so far over the compressed bytes it came from, times the file
-            const double in = (double)std::min<uint64_t>(size_, base_byte_ + (uint64_t)hi * chunk_);
-            pend_.est_total = done_ ? h_chain_->total : (uint64_t)((double)h_chain_->total * ((double)size_ / std::max(1.0, in)) * 1.03);
+        DCHK(hipEventRecord(L.ev_link, sp)); DCHK(hipStreamWaitEvent(sr, L.ev_link, 0));
+        DCHK(launch_gz_resolve(L.d_chunks.p, a, b, sym_a + (size_t)(a - S.lo) * S.cap, S.cap, L.d_out_off.p, cur_buf_->p, T0, max_sym, sr));
+        // the rest of the member's CRC over this piece: launched here, taken in by finish_pending
+        if (h_chain_->total > crc_done_) { rc = crc_launch(L, crc_done_, h_chain_->total, T0, sr, err); if (rc) return rc; }
+        S.cur = b;
+        const bool slab_done = S.cur == S.hi || done_;
+        if (last_piece && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
+        pend_.buf = std::move(cur_buf_); pend_.T0 = T0; pend_.len = h_chain_->total - T0; pend_.last = done_;
+        pending_ = true; pend_lane_ = S.lane;
+        if (slab_done) {
+            pend_slab_ = std::move(slabs_.front()); slabs_.pop_front();      // (its symbols are being resolved: kept until finish_pending)
+            // what is in front of the next slab has been linked: the ring may take new bytes there
+            const uint32_t lo_next = !slabs_.empty() ? slabs_.front()->lo : (next_plan_ < plan_.size() ? plan_[next_plan_].lo : n_chunks_);
+            up_->set_low_water(base_byte_ + (uint64_t)lo_next * chunk_);
         }
-        pending_ = true; pend_sym_ = k % NSYM;
         return MF_OK;
     }
-    // the slab whose resolve and CRC kernels are in flight becomes text: its piece goes to `out`
+    // the piece whose resolve and CRC kernels are in flight becomes text: it goes to `out`
     int finish_pending(TextPiece &out, std::string &err)
     {
         if (!pending_) return MF_OK;
-        DCHK(hipStreamSynchronize(sr_));
-        crc_finish();
-        sym_[pend_sym_].slab = ~0u;                        // (its symbols are text now)
-        out = pend_; pending_ = false;
+        Lane &L = lanes_[pend_lane_];
+        DCHK(hipSetDevice(L.dev));
+        DCHK(hipStreamSynchronize(L.streams->rest));
+        crc_finish(L);
+        if (pend_slab_) { if (pend_slab_->ev) (void)hipEventDestroy(pend_slab_->ev); pend_slab_.reset(); }      // (its symbols are text now)
+        out = std::move(pend_); pend_ = TextPiece(); pending_ = false;
         return MF_OK;
     }
+    bool finished() const { return !pending_ && (done_ || (slabs_.empty() && next_plan_ >= plan_.size())); }
     uint64_t gap_bytes() const { return gap_bytes_; }
     uint64_t gaps() const { return n_gaps_; }
     uint64_t chunks_linked() const { return h_chain_ ? h_chain_->linked : 0; }
     uint32_t chunks() const { return n_chunks_; }
     size_t chunk_bytes() const { return chunk_; }
+    size_t ring_bytes() const { return ring_; }
+    uint32_t splits() const { return n_splits_; }
 private:
-    struct Sym { DevBuf<uint16_t> p; size_t cap = 0; hipEvent_t ev = nullptr; uint32_t slab = ~0u; };     // cap: symbols of room per chunk
-    // the arena holds at least `need` bytes (what is in it moves along)
-    int grow_arena(size_t need, std::string &err)
+    struct Lane {
+        int dev = 0, ldev = 0; StreamSet *streams = nullptr; hipEvent_t ev_link = nullptr;
+        DevBuf<uint8_t> ring; DevBuf<GzChunk> d_chunks; DevBuf<uint64_t> d_out_off; DevBuf<GzChain> d_chain; DevBuf<uint32_t> d_crc;
+        uint32_t *h_crc = nullptr; size_t h_crc_cap = 0; uint64_t crc_n = 0;      // h_crc: pinned
+    };
+    struct SlabPlan { uint32_t lo, hi, lane; };
+    struct Slab {
+        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; size_t cap = 0, limit = 0; hipEvent_t ev = nullptr;     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
+        bool launched = false, read_back = false;
+    };
+    size_t sym_cap_now() const
     {
-        if (need <= arena_->cap) return MF_OK;
-        const size_t cap = std::max(need + need / 2, (size_t)64 << 20);
-        uint8_t *raw = nullptr; size_t raw_bytes = 0;
-        DCHK(g_pool.get((void **)&raw, Arena::FRONT + cap + 64, &raw_bytes));
-        DCHK(hipMemsetAsync(raw, 0, Arena::FRONT, sr_)); DCHK(hipStreamSynchronize(sr_));
-        uint8_t *p = raw + Arena::FRONT;
-        std::lock_guard<std::mutex> lk(arena_->mu);
-        if (arena_->read_pending) { DCHK(hipEventSynchronize(arena_->read_ev)); arena_->read_pending = false; }      // (no kernel of the consumer is reading the old one)
-        const uint64_t have = h_chain_ ? h_chain_->total : 0;
-        if (arena_->raw) {
-            if (have) { DCHK(hipMemcpyAsync(p, arena_->p, have, hipMemcpyDeviceToDevice, sr_)); DCHK(hipStreamSynchronize(sr_)); }
-            g_pool.put(arena_->raw, arena_->raw_bytes);       // (link, resolve and CRC of this stream are between slabs here; the consumer is held off by the lock)
+        if (expand_fixed_ || !max_sym_seen_) return (size_t)((double)chunk_ * expand_) + 262144;
+        // what the largest chunk so far needed, and a quarter; a chunk reads one block past its range (and up to a chunk's worth of
+        // stored blocks), which the maximum has seen as well
+        return (size_t)max_sym_seen_ + max_sym_seen_ / 4 + 65536;
+    }
+    int launch_ahead(std::string &err)
+    {
+        // slabs that were split off an overflowing one wait at the front without a launch
+        while (slabs_.size() < max_inflight_ && next_plan_ < plan_.size()) {
+            std::unique_ptr<Slab> S(new Slab());
+            const SlabPlan &P = plan_[next_plan_++];
+            S->lo = P.lo; S->hi = P.hi; S->lane = P.lane;
+            slabs_.push_back(std::move(S));
         }
-        arena_->raw = raw; arena_->raw_bytes = raw_bytes; arena_->p = p; arena_->cap = raw_bytes - Arena::FRONT - 64;
+        for (size_t i = 0; i < slabs_.size(); i++) {
+            Slab &S = *slabs_[i];
+            if (S.launched) continue;
+            Lane &L = lanes_[S.lane];
+            // the chunks read past their own range up to the end of a block, and the reader's ring a little further
+            const size_t upto = std::min(size_, base_byte_ + (size_t)S.hi * chunk_ + margin_);
+            if (i > 0 && !up_->issued(upto)) break;
+            DCHK(hipSetDevice(L.dev));
+            if (!S.cap) S.cap = sym_cap_now();
+            DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
+            if (!S.ev) DCHK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+            hipStream_t st = L.streams->sd[launch_seq_++ % GZ_NSTREAM];
+            if (!up_->wait_for(S.lane, st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_IO; }
+            S.limit = upto;
+            DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, st));
+            DCHK(hipEventRecord(S.ev, st));
+            S.launched = true;
+        }
         return MF_OK;
     }
-    int launch_decode(uint32_t j, bool must, std::string &err)
+    // the chain state is on lane l's device (it travels through the host between lanes, and after the host has changed it)
+    int chain_to(uint32_t l, hipStream_t sp, std::string &err)
     {
-        Sym &S = sym_[j % NSYM];
-        if (j != launched_ || S.slab != ~0u) return MF_OK;     // launched already -- or its buffer still holds an earlier slab: launched when that one has become text
-        const uint32_t lo = j * cps_, hi = std::min(n_chunks_, lo + cps_);
-        hipStream_t st = sd_[j % NSTREAM];
-        // the chunks read past their own range up to the end of a block, and the reader's ring a little further
-        const size_t upto = base_byte_ + (size_t)hi * chunk_ + ((size_t)8 << 20);
-        if (!must && !up_->issued(upto)) return MF_OK;
-        S.cap = sym_cap_;
-        DCHK(S.p.need((size_t)(hi - lo) * S.cap, false));
-        if (!up_->wait_for(st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_HIP; }
-        DCHK(launch_gz_decode(d_file_, size_, base_byte_, chunk_, lo, hi - lo, 0, (uint64_t)base_byte_ * 8, S.p.p, S.cap, d_chunks_.p, st));
-        DCHK(hipEventRecord(S.ev, st));
-        S.slab = j; launched_ = j + 1;
+        if (l == chain_lane_ && !chain_dirty_) return MF_OK;
+        DCHK(hipMemcpyAsync(lanes_[l].d_chain.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sp));
+        DCHK(hipStreamSynchronize(sp));
+        chain_lane_ = l; chain_dirty_ = false;
+        return MF_OK;
+    }
+    // a fresh buffer for the piece that begins at text offset T0
+    int new_text(Lane &L, uint64_t T0, size_t text_bytes, std::string &err)
+    {
+        (void)T0;
+        if (!slots_->take()) { err = "stopped"; return MF_E_IO; }
+        DCHK(TextBuf::make(cur_buf_, L.dev, L.ldev, pad_, text_bytes, slots_));
+        // (a damaged stream may point a full window back from the first byte of the text: zeros there, ahead of the link step on its stream)
+        DCHK(hipMemsetAsync(cur_buf_->p - TEXT_FRONT, 0, TEXT_FRONT, L.streams->link));
+        return MF_OK;
+    }
+    // ... holds at least `need_abs - T0` bytes (what is in it moves along)
+    int grow_text(Lane &L, uint64_t T0, uint64_t need_abs, std::string &err)
+    {
+        if (need_abs - T0 <= cur_buf_->cap) return MF_OK;
+        std::unique_ptr<TextBuf> nb;
+        DCHK(TextBuf::make(nb, L.dev, L.ldev, pad_, (size_t)((need_abs - T0) + (need_abs - T0) / 2), nullptr));
+        const uint64_t have = h_chain_->total - T0;
+        hipStream_t sr = L.streams->rest;
+        DCHK(hipMemcpyAsync(nb->raw, cur_buf_->raw, cur_buf_->pad + have, hipMemcpyDeviceToDevice, sr)); DCHK(hipStreamSynchronize(sr));
+        nb->slots = cur_buf_->slots; cur_buf_->slots = nullptr;          // (the slot moves to the new buffer)
+        cur_buf_ = std::move(nb);
         return MF_OK;
     }
     // gzip header at byte pos -> pos = first byte of deflate data
@@ -520,19 +745,19 @@ private:
         return false;
     }
     // the chain stands behind the final block of a member: check the trailer, look for another member
-    int member_end(uint32_t max_sym, hipStream_t sp, std::string &err)
+    int member_end(Slab &S, uint32_t a, uint32_t b, uint32_t max_sym, uint64_t T0, std::string &err)
     {
+        Lane &L = lanes_[S.lane];
+        hipStream_t sp = L.streams->link, sr = L.streams->rest;
         const size_t pos = (size_t)((h_chain_->cur_bit + 7) >> 3);
         if (pos + 8 > size_) { err = "gzip read error in " + path_ + ": truncated gzip trailer"; return MF_E_FORMAT; }
         uint32_t want_crc, want_len; memcpy(&want_crc, data_ + pos, 4); memcpy(&want_len, data_ + pos + 4, 4);
-        // CRC of the member's text up to here (the resolve kernel has not run yet for this slab: do it for what is accepted)
-        {
-            const uint32_t k = next_slab_, lo = k * cps_, hi = std::min(n_chunks_, lo + cps_);
-            DCHK(hipEventRecord(ev_link_, sp)); DCHK(hipStreamWaitEvent(sr_, ev_link_, 0));
-            DCHK(launch_gz_resolve(d_chunks_.p, lo, hi, sym_[k % NSYM].p.p, sym_[k % NSYM].cap, d_out_off_.p, arena_->p, 0, max_sym, sr_));
-        }
-        if (h_chain_->total > crc_done_) { const int rc = crc_over(crc_done_, h_chain_->total, sr_, err); if (rc) return rc; }
-        DCHK(hipStreamSynchronize(sr_));
+        // CRC of the member's text up to here (the resolve kernel has not run yet for this piece: do it for what is accepted)
+        DCHK(hipEventRecord(L.ev_link, sp)); DCHK(hipStreamWaitEvent(sr, L.ev_link, 0));
+        DCHK(launch_gz_resolve(L.d_chunks.p, a, b, S.sym.p + (size_t)(a - S.lo) * S.cap, S.cap, L.d_out_off.p, cur_buf_->p, T0, max_sym, sr));
+        if (h_chain_->total > crc_done_) { const int rc = crc_launch(L, crc_done_, h_chain_->total, T0, sr, err); if (rc) return rc; }
+        DCHK(hipStreamSynchronize(sr));
+        crc_finish(L);
         TRACE("member end: crc %08x want %08x", crc_, want_crc);
         if (crc_ != want_crc) { err = "gzip read error in " + path_ + ": incorrect data check"; return MF_E_FORMAT; }
         if ((uint32_t)(h_chain_->total - member_T0_) != want_len) { err = "gzip read error in " + path_ + ": incorrect length check"; return MF_E_FORMAT; }
@@ -541,40 +766,36 @@ private:
         if (p >= size_ || size_ - p < 2 || data_[p] != 0x1f || data_[p + 1] != 0x8b) { done_ = true; in_member_ = false; return MF_OK; }   // trailing bytes that are no member: ignored
         if (!member_header(p, err)) return MF_E_FORMAT;
         h_chain_->cur_bit = (uint64_t)p * 8; h_chain_->wlen = 0; h_chain_->stop = GZ_STOP_NONE;
-        DCHK(hipMemcpyAsync(d_chain_.p, h_chain_, offsetof(GzChain, window), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp));
-        return MF_OK;
+        chain_dirty_ = true;
+        return chain_to(S.lane, sp, err);
     }
-    // running CRC of the member over the text [from, to): the kernel and the copy of its piece CRCs (crc_launch), the combination on the host (crc_finish)
-    int crc_launch(uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
+    // running CRC of the member over the text [from, to) of the current piece: the kernel and the copy of its piece CRCs (crc_launch),
+    // the combination on the host (crc_finish)
+    int crc_launch(Lane &L, uint64_t from, uint64_t to, uint64_t T0, hipStream_t st, std::string &err)
     {
-        if (crc_n_) { DCHK(hipStreamSynchronize(sp)); crc_finish(); }        // (an earlier launch on this stream that nobody has taken in)
+        if (L.crc_n) { DCHK(hipStreamSynchronize(st)); crc_finish(L); }        // (an earlier launch on this stream that nobody has taken in)
         const uint64_t n = to - from;
         const size_t np = (size_t)((n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
-        DCHK(d_crc_.need(np));
-        if (np > h_crc_cap_) { if (h_crc_) (void)hipHostFree(h_crc_); h_crc_ = nullptr; h_crc_cap_ = 0; DCHK(hipHostMalloc((void **)&h_crc_, (np + np / 2 + 64) * 4, hipHostMallocDefault)); h_crc_cap_ = np + np / 2 + 64; }
-        TRACE("crc over %llu bytes", (unsigned long long)n);
-        DCHK(launch_gz_crc(arena_->p + from, n, d_crc_.p, sp));
-        DCHK(hipMemcpyAsync(h_crc_, d_crc_.p, np * 4, hipMemcpyDeviceToHost, sp));
-        crc_n_ = n; crc_done_ = to;
+        DCHK(L.d_crc.need(L.dev, np));
+        if (np > L.h_crc_cap) { if (L.h_crc) (void)hipHostFree(L.h_crc); L.h_crc = nullptr; L.h_crc_cap = 0; DCHK(hipHostMalloc((void **)&L.h_crc, (np + np / 2 + 64) * 4, hipHostMallocDefault)); L.h_crc_cap = np + np / 2 + 64; }
+        DCHK(launch_gz_crc(cur_buf_->p + (from - T0), n, L.d_crc.p, st));
+        DCHK(hipMemcpyAsync(L.h_crc, L.d_crc.p, np * 4, hipMemcpyDeviceToHost, st));
+        L.crc_n = n; crc_done_ = to;
         return MF_OK;
     }
-    void crc_finish() { if (crc_n_) { crc_ = gz_crc_combine(crc_, gz_crc_finish(h_crc_, crc_n_), crc_n_); crc_n_ = 0; } }      // (the stream of crc_launch has been synchronised)
-    int crc_over(uint64_t from, uint64_t to, hipStream_t sp, std::string &err)
-    {
-        const int rc = crc_launch(from, to, sp, err); if (rc) return rc;
-        DCHK(hipStreamSynchronize(sp));
-        crc_finish();
-        return MF_OK;
-    }
+    void crc_finish(Lane &L) { if (L.crc_n) { crc_ = gz_crc_combine(crc_, gz_crc_finish(L.h_crc, L.crc_n), L.crc_n); L.crc_n = 0; } }      // (the stream of crc_launch has been synchronised)
 
-    const uint8_t *data_ = nullptr; size_t size_ = 0; uint8_t *d_file_ = nullptr; Uploader *up_ = nullptr; Arena *arena_ = nullptr; std::string path_;
-    size_t chunk_ = 0, base_byte_ = 0, sym_cap_ = 0; uint64_t expand_ = 8;
-    uint32_t cps_ = 0, n_chunks_ = 0, n_slabs_ = 0, next_slab_ = 0, launched_ = 0;
-    DevBuf<GzChunk> d_chunks_; DevBuf<uint64_t> d_out_off_; DevBuf<GzChain> d_chain_; DevBuf<uint32_t> d_crc_;
-    GzChain *h_chain_ = nullptr; std::vector<GzChunk> h_chunks_; uint32_t *h_crc_ = nullptr; size_t h_crc_cap_ = 0; uint64_t crc_n_ = 0;      // h_crc_: pinned
-    TextPiece pend_; bool pending_ = false; uint32_t pend_sym_ = 0;
-    static constexpr uint32_t NSYM = 12, NSTREAM = GZ_NSTREAM;      // decode kernels in flight: enough wavefronts to fill the chip (a slab is a few hundred chunks)
-    Sym sym_[NSYM]; StreamSet *streams_ = nullptr; hipStream_t sd_[NSTREAM] = {}, sp_ = nullptr, sr_ = nullptr; hipEvent_t ev_link_ = nullptr;     // sp_: the link stream (reserved CUs); sr_: resolve and CRC (the whole chip)
+    const uint8_t *data_ = nullptr; size_t size_ = 0; std::string path_; Slots *slots_ = nullptr; size_t pad_ = TEXT_FRONT; std::atomic<bool> *stop_ = nullptr;
+    size_t chunk_ = 0, base_byte_ = 0, margin_ = 0, ring_ = 0, piece_ = 0; double expand_ = 6; bool expand_fixed_ = false; uint32_t max_sym_seen_ = 0;
+    uint64_t text_piece_max_ = 0;
+    uint32_t cps_ = 0, n_chunks_ = 0, max_inflight_ = 1, launch_seq_ = 0, n_splits_ = 0;
+    std::vector<Lane> lanes_; std::vector<SlabPlan> plan_; size_t next_plan_ = 0;
+    std::deque<std::unique_ptr<Slab>> slabs_;          // launched or waiting, in stream order; front = being linked
+    std::unique_ptr<GzUploader> up_;
+    GzChain *h_chain_ = nullptr; uint32_t chain_lane_ = 0; bool chain_dirty_ = false;      // h_chain_: pinned; the master copy between link steps
+    std::vector<GzChunk> h_chunks_;
+    std::unique_ptr<TextBuf> cur_buf_;
+    TextPiece pend_; bool pending_ = false; uint32_t pend_lane_ = 0; std::unique_ptr<Slab> pend_slab_;
     bool in_member_ = false, done_ = false;
     uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
 };
@@ -603,236 +824,338 @@ private:
     std::thread th_; std::mutex mu_; std::condition_variable cv_; std::deque<std::vector<char>> q_;
 };
 
-// records of one piece of text, cut where they lie
+// bits [r0, r0 + n) of a bitmap -> out (bit 0 = bit r0); out has (n + 31) / 32 words
+void extract_bits(const std::vector<uint32_t> &v, uint64_t r0, uint64_t n, uint32_t *out)
+{
+    const uint64_t nw = (n + 31) / 32, w0 = r0 >> 5; const uint32_t sh = (uint32_t)(r0 & 31);
+    for (uint64_t j = 0; j < nw; j++) {
+        const uint32_t a = w0 + j < v.size() ? v[w0 + j] : 0, b = w0 + j + 1 < v.size() ? v[w0 + j + 1] : 0;
+        out[j] = sh ? (a >> sh) | (b << (32 - sh)) : a;
+    }
+    if (n & 31) out[nw - 1] &= (1u << (n & 31)) - 1;
+}
+// the other way: n bits of src (bit 0 first) become bits [r0, r0 + n) of v
+void append_bits(std::vector<uint32_t> &v, uint64_t r0, uint64_t n, const uint32_t *src)
+{
+    if (!n) return;
+    v.resize((size_t)((r0 + n + 31) / 32 + 1), 0);
+    const uint64_t nw = (n + 31) / 32, w0 = r0 >> 5; const uint32_t sh = (uint32_t)(r0 & 31);
+    for (uint64_t j = 0; j < nw; j++) {
+        uint32_t x = src[j];
+        if (j == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1;
+        v[w0 + j] |= x << sh;
+        if (sh) v[w0 + j + 1] |= x >> (32 - sh);
+    }
+}
+
+// records of one piece of text, cut where they lie; waits (with its text) until the other mate's pass bits cover it
 struct Batch {
-    uint64_t start = 0;                  // arena offset of the first record's header (the piece's T0 less the carry)
-    DevBuf<uint64_t> line_start;         // offsets from `start`
+    std::unique_ptr<TextBuf> buf;
+    const uint8_t *text = nullptr;       // the first record's header (the piece's text less the carry in front of it)
+    DevBuf<uint64_t> line_start;         // offsets from `text`
     uint64_t n_rec = 0, rec_base = 0;
+    int ldev = 0;
+};
+
+// what the consumer keeps per (mate, device): scratch buffers and the refillable read set
+struct DevScratch {
+    int ldev = 0, dev = 0; DevCtx *ctx = nullptr;
+    mf_reads *reads = nullptr;
+    DevBuf<uint32_t> tile_cnt, seq_len, inv_cnt, out_len, minmax, mask; DevBuf<uint64_t> tile_base, scan_tmp, inv_base, out_off, offsets_tmp; DevBuf<uint8_t> d_out;
+    // small results the host waits for (counts that size the next buffers), in pinned memory: a copy to pageable memory is a
+    // synchronisation of its own.  [0] newlines [1] last byte [2] used [3] bases [4] min/max length [5] invalid bases [6] output bytes;
+    // [7], [8]: values on their way TO the device (the virtual end of an unterminated last line, the start value of min/max)
+    uint64_t *h_small = nullptr;
+    uint32_t *h_bits = nullptr; size_t h_bits_cap = 0;       // pinned: the pass bits of a piece on their way to the host, the keep mask on its way back
+    ~DevScratch() { reads_release(reads); (void)hipSetDevice(dev); if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); }
 };
 
 struct Mate {
     std::string path; Mapped map; bool gz = false;
-    DevBuf<uint8_t> d_file; Uploader up; Arena arena; std::unique_ptr<GzStream> gzs;
-    // producer: text pieces in order (a plain file: one piece per uploaded slab)
+    std::unique_ptr<GzStream> gzs; Slots slots;
+    // producer: text pieces in order
     std::thread prod; std::mutex mu; std::condition_variable cv; std::deque<TextPiece> ready; int prod_rc = MF_OK; std::string prod_err; bool prod_done = false;
     std::atomic<bool> stop{false};
     // consumer
-    uint64_t carry = 0, rec_done = 0, bases = 0, n_npos = 0; bool eof = false;
-    uint32_t min_len = ~0u, max_len = 0;
-    std::vector<std::unique_ptr<Batch>> batches;
-    mf_reads *reads = nullptr;           // the read set of the whole file, appended to batch by batch
+    uint64_t rec_done = 0; bool eof = false;
+    uint8_t *h_carry = nullptr; size_t h_carry_cap = 0, carry = 0;      // pinned: the head of the record the last piece left unfinished
+    std::deque<std::unique_ptr<Batch>> batches;          // filtered, not yet written
+    std::vector<uint32_t> bits;                          // pass bits of the whole file so far, one per record
+    std::map<int, std::unique_ptr<DevScratch>> scratch;
     Writer out;
-    DevBuf<uint32_t> tile_cnt, seq_len, inv_cnt, out_len, minmax; DevBuf<uint64_t> tile_base, scan_tmp, inv_base, out_off, offsets_tmp; DevBuf<uint8_t> d_out;
-    // small results the host waits for (counts that size the next buffers), in pinned memory: a copy to pageable memory is a
-    // synchronisation of its own.  [0] newlines [1] last byte [2] used [3] bases [4] min/max length [5] invalid bases [6] output bytes
-    uint64_t *h_small = nullptr;
-    ~Mate() { TRACE("~Mate"); stop = true; if (prod.joinable()) prod.join(); reads_release(reads); if (h_small) (void)hipHostFree(h_small); TRACE("~Mate body done"); }
+    ~Mate()
+    {
+        TRACE("~Mate");
+        stop = true; slots.wake();
+        batches.clear(); ready.clear();                   // (text buffers give their slots back: a producer waiting for one wakes up)
+        if (prod.joinable()) prod.join();
+        ready.clear();
+        gzs.reset();
+        scratch.clear();
+        if (h_carry) (void)hipHostFree(h_carry);
+    }
 };
 
-// grow a device buffer, keeping what is in it (bytes)
-// room for need_bytes (must_bytes, when given, is what has to fit now: need_bytes is then a wish -- the estimate for the whole file --
-// that only counts when a new allocation has to be made anyway)
-template <class T> int grow_keep(T *&p, size_t &cap_bytes, size_t used_bytes, size_t need_bytes, hipStream_t st, std::string &err, size_t must_bytes = 0)
-{
-    if ((must_bytes ? must_bytes : need_bytes) <= cap_bytes && p) return MF_OK;
-    const size_t cap = must_bytes ? std::max(need_bytes + need_bytes / 16, must_bytes + must_bytes / 2) + 4096 : need_bytes + need_bytes / 2 + 4096;
-    T *q = nullptr;
-    DCHK(hipMalloc(&q, cap));
-    if (p) { if (used_bytes) DCHK(hipMemcpyAsync(q, p, used_bytes, hipMemcpyDeviceToDevice, st)); DCHK(hipStreamSynchronize(st)); g_trash.add(p); }      // (hipMalloc'ed: an mf_reads owns these)
-    p = q; cap_bytes = cap;
-    return MF_OK;
-}
-
 struct Ingest {
-    mf_kmerset *ks; uint32_t threshold; bool pair_both; int device; DevCtx *ctx; hipStream_t sp;
+    mf_kmerset *ks; uint32_t threshold; bool pair_both; std::vector<int> devices;
     Mate m[2]; int nm = 1;
-    uint64_t kept = 0, total = 0;
+    uint64_t kept = 0, total = 0, emitted[2] = {0, 0};
+    bool wrote_any = false;
+    size_t mem_used_max = 0;           // device memory in use (everything on the device, this path's buffers and the rest), the largest seen after a piece
+    size_t carry_room = (size_t)1 << 20;
     bool timing = false; double t_wait = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;
+
+    std::mutex mu_all; std::condition_variable cv_all;          // any producer has something new
+    void publish(Mate &M, TextPiece &&t) { { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(std::move(t)); } M.cv.notify_all(); cv_all.notify_all(); }
 
     void producer(Mate &M)
     {
-        (void)hipSetDevice(phys(device));
         std::string err; int rc = MF_OK;
         if (M.gz) {
             for (;;) {
                 TextPiece t;
                 rc = M.gzs->next(t, err);
                 if (rc || M.stop) break;
-                if (!t.len && !t.last) continue;                       // (the first call: the decoder hands a slab over one call late)
-                { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(t); }
-                M.cv.notify_all();
-                if (t.last) break;
+                if (!t.buf) { if (M.gzs->finished()) break; continue; }   // (the first call: the decoder hands a piece over one call late)
+                const bool last = t.last;
+                publish(M, std::move(t));
+                if (last) break;
             }
-        } else {
-            // a plain file is its own text: pieces become available as they are uploaded
-            const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)256 << 20), 64);
-            hipStream_t st = nullptr; hipEvent_t ev = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = MF_E_HIP; err = "hipStreamCreate failed"; }
-            for (uint64_t T0 = 0; !rc && T0 < M.map.n && !M.stop;) {
-                const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
-                if (!M.up.wait_for(st, T1) || hipStreamSynchronize(st) != hipSuccess) { rc = MF_E_HIP; err = "upload of " + M.path + " failed"; break; }
-                TextPiece t; t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n; t.est_total = M.map.n;
-                { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(t); }
-                M.cv.notify_all();
-                T0 = T1;
-            }
-            if (ev) (void)hipEventDestroy(ev);
-            if (st) (void)hipStreamDestroy(st);
-        }
+        } else rc = plain_producer(M, err);
+        if (M.stop && rc) { rc = MF_OK; err.clear(); }                 // (told to stop: not a failure of its own)
         TRACE("producer done rc %d", rc);
         { std::lock_guard<std::mutex> lk(M.mu); M.prod_rc = rc; M.prod_err = err; M.prod_done = true; }
-        M.cv.notify_all();
+        M.cv.notify_all(); cv_all.notify_all();
     }
 
-    // lines -> records -> appended to the mate's packed read set
-    int ingest(Mate &M, const TextPiece &P, std::string &err)
+    // a plain file is its own text: slabs of it are read straight into text buffers, dealt to the devices round robin
+    int plain_producer(Mate &M, std::string &err)
+    {
+        const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)256 << 20), 64);
+        const size_t piece = (size_t)std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>(slab, 4096));
+        Stager stg;
+        DCHK(hipSetDevice(phys(devices[0])));
+        DCHK(stg.init(piece, M.map.fd));
+        struct PerDev { hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+        std::vector<PerDev> pd(devices.size());
+        struct Cleanup { std::vector<PerDev> &pd; const std::vector<int> &devs; ~Cleanup() { for (size_t i = 0; i < pd.size(); i++) { (void)hipSetDevice(phys(devs[i])); for (auto &e : pd[i].ev) if (e) (void)hipEventDestroy(e); if (pd[i].st) { (void)hipStreamSynchronize(pd[i].st); (void)hipStreamDestroy(pd[i].st); } } } } cleanup{pd, devices};
+        uint64_t n_piece = 0; int used_by[2] = {-1, -1};
+        uint64_t s = 0;
+        for (uint64_t T0 = 0; T0 < M.map.n && !M.stop; s++) {
+            const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
+            const size_t li = (size_t)(s % devices.size());
+            const int ldev = devices[li], dev = phys(ldev);
+            DCHK(hipSetDevice(dev));
+            PerDev &P = pd[li];
+            if (!P.st) { DCHK(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking)); for (auto &e : P.ev) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+            if (!M.slots.take()) break;
+            TextPiece t;
+            DCHK(TextBuf::make(t.buf, dev, ldev, TEXT_FRONT + carry_room, (size_t)(T1 - T0), &M.slots));
+            for (uint64_t off = T0; off < T1; off += piece, n_piece++) {
+                const int b = (int)(n_piece & 1);
+                if (used_by[b] >= 0) { const size_t lj = (size_t)used_by[b]; DCHK(hipSetDevice(phys(devices[lj]))); DCHK(hipEventSynchronize(pd[lj].ev[b])); DCHK(hipSetDevice(dev)); }
+                const size_t len = (size_t)std::min<uint64_t>(piece, T1 - off);
+                if (!stg.read(b, (size_t)off, len)) { err = "read error on " + M.path; return MF_E_IO; }
+                DCHK(hipMemcpyAsync(t.buf->p + (off - T0), stg.buf[b], len, hipMemcpyHostToDevice, P.st));
+                DCHK(hipEventRecord(P.ev[b], P.st));
+                used_by[b] = (int)li;
+            }
+            DCHK(hipStreamSynchronize(P.st));
+            t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n;
+            publish(M, std::move(t));
+            T0 = T1;
+        }
+        return MF_OK;
+    }
+
+    DevScratch *scratch_for(Mate &M, int ldev, std::string &err)
+    {
+        auto it = M.scratch.find(ldev);
+        if (it != M.scratch.end()) { if (hipSetDevice(it->second->dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; } return it->second.get(); }
+        std::unique_ptr<DevScratch> S(new DevScratch());
+        S->ldev = ldev; S->dev = phys(ldev);
+        if (get_ctx(ldev, &S->ctx, 0)) { err = mf_thread_error(); return nullptr; }
+        if (hipHostMalloc((void **)&S->h_small, 128, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return nullptr; }
+        memset(S->h_small, 0, 128);
+        DevScratch *p = S.get();
+        M.scratch[ldev] = std::move(S);
+        return p;
+    }
+
+    // lines -> records -> the device's read set -> one filter pass; the pass bits join the mate's file-wide bitmap on the host
+    int ingest(Mate &M, TextPiece &P, std::string &err)
     {
         const double t0 = now_s();
-        std::lock_guard<std::mutex> alk(M.arena.mu);                 // the arena stays where it is while these kernels read it
+        DevScratch *Sp = scratch_for(M, P.buf->ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        // the carry in front of the piece's text.  It fits the room in front of the buffer -- or the piece moves to a buffer that
+        // holds both (records longer than the room: tests, mostly)
+        if (M.carry > P.buf->pad) {
+            std::unique_ptr<TextBuf> nb;
+            DCHK(TextBuf::make(nb, dev, P.buf->ldev, TEXT_FRONT + M.carry, (size_t)P.len, nullptr));
+            DCHK(hipMemcpyAsync(nb->p, P.buf->p, P.len, hipMemcpyDeviceToDevice, sp));
+            DCHK(hipStreamSynchronize(sp));
+            nb->slots = P.buf->slots; P.buf->slots = nullptr;
+            P.buf = std::move(nb);
+        }
+        if (M.carry) DCHK(hipMemcpyAsync(P.buf->p - M.carry, M.h_carry, M.carry, hipMemcpyHostToDevice, sp));
         std::unique_ptr<Batch> B(new Batch());
-        B->start = P.T0 - M.carry; B->rec_base = M.rec_done;
-        const uint8_t *text = M.arena.p + B->start;
+        B->ldev = S.ldev; B->rec_base = M.rec_done;
+        B->text = P.buf->p - M.carry;
+        const uint8_t *text = B->text;
         const uint64_t n = M.carry + P.len;
         const uint64_t tiles = (n + INGEST_TILE - 1) / INGEST_TILE;
-        if (!M.h_small) { DCHK(hipHostMalloc((void **)&M.h_small, 64, hipHostMallocDefault)); memset(M.h_small, 0, 64); }
-        volatile uint64_t *hs = M.h_small;
+        volatile uint64_t *hs = S.h_small;
         uint64_t n_lines = 0, used = 0;
         hs[2] = 0;
         if (n) {
-            DCHK(M.tile_cnt.need(tiles)); DCHK(M.tile_base.need(tiles + 1)); DCHK(M.scan_tmp.need(tiles / 4096 + 4));
-            DCHK(launch_count_newlines(text, n, M.tile_cnt.p, sp));
-            DCHK(launch_scan_u32(M.tile_cnt.p, tiles, M.tile_base.p, M.scan_tmp.p, sp));
+            DCHK(S.tile_cnt.need(dev, tiles)); DCHK(S.tile_base.need(dev, tiles + 1)); DCHK(S.scan_tmp.need(dev, tiles / 4096 + 4));
+            DCHK(launch_count_newlines(text, n, S.tile_cnt.p, sp));
+            DCHK(launch_scan_u32(S.tile_cnt.p, tiles, S.tile_base.p, S.scan_tmp.p, sp));
             hs[1] = 0;
-            DCHK(hipMemcpyAsync(M.h_small + 0, M.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipMemcpyAsync(M.h_small + 1, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(S.h_small + 0, S.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(S.h_small + 1, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
             const uint64_t newlines = hs[0]; const uint8_t last_byte = (uint8_t)hs[1];
             const bool open_line = P.last && last_byte != '\n';      // lines() yields an unterminated last line
             n_lines = newlines + (open_line ? 1 : 0);
-            DCHK(B->line_start.need(n_lines + 2, false));
-            DCHK(launch_line_starts(text, n, M.tile_base.p, B->line_start.p, sp));
-            if (open_line) { const uint64_t v = n + 1; DCHK(hipMemcpyAsync(B->line_start.p + n_lines, &v, 8, hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
+            DCHK(B->line_start.need(dev, n_lines + 2, false));
+            DCHK(launch_line_starts(text, n, S.tile_base.p, B->line_start.p, sp));
+            if (open_line) { S.h_small[7] = n + 1; DCHK(hipMemcpyAsync(B->line_start.p + n_lines, S.h_small + 7, 8, hipMemcpyHostToDevice, sp)); }
             B->n_rec = n_lines / 4;
-            DCHK(hipMemcpyAsync(M.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));     // (read with the next synchronisation)
+            DCHK(hipMemcpyAsync(S.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));     // (read with the next synchronisation)
             if (!B->n_rec) DCHK(hipStreamSynchronize(sp));
         }
         if (timing) t_index += now_s() - t0;
         const double t1 = now_s();
         const uint64_t n_rec = B->n_rec;
+        std::vector<uint32_t> bits;
         if (n_rec) {
-            if (!M.reads) { M.reads = new (std::nothrow) mf_reads(); if (!M.reads) { err = "out of memory"; return MF_E_NOMEM; } M.reads->device = device; M.reads->lane = 0; }
-            mf_reads *R = M.reads;
-            // sequence lengths, the batch's own offsets
-            DCHK(M.seq_len.need(n_rec)); DCHK(M.minmax.need(2)); DCHK(M.offsets_tmp.need(n_rec + 1)); DCHK(M.scan_tmp.need(n_rec / 4096 + 4));
-            { const uint32_t init[2] = {~0u, 0u}; DCHK(hipMemcpyAsync(M.minmax.p, init, 8, hipMemcpyHostToDevice, sp)); }
-            DCHK(launch_seq_lens(text, B->line_start.p, n_rec, M.seq_len.p, M.minmax.p, sp));
-            DCHK(launch_scan_u32(M.seq_len.p, n_rec, M.offsets_tmp.p, M.scan_tmp.p, sp));
-            DCHK(hipMemcpyAsync(M.h_small + 3, M.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipMemcpyAsync(M.h_small + 4, M.minmax.p, 8, hipMemcpyDeviceToHost, sp));
+            if (!S.reads) { S.reads = new (std::nothrow) mf_reads(); if (!S.reads) { err = "out of memory"; return MF_E_NOMEM; } S.reads->device = S.ldev; S.reads->lane = 0; }
+            mf_reads *R = S.reads;
+            // sequence lengths, the piece's own base offsets
+            DCHK(S.seq_len.need(dev, n_rec)); DCHK(S.minmax.need(dev, 2)); DCHK(S.offsets_tmp.need(dev, n_rec + 1)); DCHK(S.scan_tmp.need(dev, n_rec / 4096 + 4));
+            S.h_small[8] = (uint64_t)0xFFFFFFFFull;                   // {~0u, 0u}
+            DCHK(hipMemcpyAsync(S.minmax.p, S.h_small + 8, 8, hipMemcpyHostToDevice, sp));
+            DCHK(launch_seq_lens(text, B->line_start.p, n_rec, S.seq_len.p, S.minmax.p, sp));
+            DCHK(launch_scan_u32(S.seq_len.p, n_rec, S.offsets_tmp.p, S.scan_tmp.p, sp));
+            DCHK(hipMemcpyAsync(S.h_small + 3, S.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
             const uint64_t nb = hs[3]; const uint32_t mm[2] = {(uint32_t)hs[4], (uint32_t)(hs[4] >> 32)};
-            M.min_len = std::min(M.min_len, mm[0]); M.max_len = std::max(M.max_len, mm[1]);
             const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
-            // room in the file's read set: words (with the screen's padding), offsets, then pack behind what is there
-            const uint64_t words_after = (M.bases + nb + 15) / 16;
-            // (the read set is sized for the whole file from what this piece says about it -- bases and records per byte of text --
-            // so that it is not moved to a larger allocation every few pieces: a hipMalloc and a copy of all there is so far each time)
-            const uint64_t text_done = P.T0 + P.len;
-            const double scale = text_done && P.est_total > text_done ? (double)P.est_total / (double)text_done : 1.0;
-            const uint64_t words_est = (uint64_t)((double)words_after * scale), rec_est = (uint64_t)((double)(M.rec_done + n_rec) * scale);
-            int rc = grow_keep(R->d_words, R->cap_words, ((M.bases + 15) / 16) * 4, padded_words_for(std::max(words_after, words_est)) * 4, sp, err, padded_words_for(words_after) * 4);
-            if (rc) return rc;
-            rc = grow_keep(R->d_offsets, R->cap_offsets, (M.rec_done + 1) * 8, (std::max(M.rec_done + n_rec, rec_est) + 1) * 8, sp, err, (M.rec_done + n_rec + 1) * 8);
-            if (rc) return rc;
-            DCHK(launch_add_base(R->d_offsets + M.rec_done, M.offsets_tmp.p, n_rec + 1, M.bases, sp));
-            const uint64_t pb = pack_blocks(nb, M.bases);
+            const uint64_t n_words = (nb + 15) / 16;
+            // invalid bases are rare (N calls): room for one in 64 bases, more when a piece proves to need it
+            const uint64_t pb = pack_blocks(nb, 0);
+            uint64_t npos_cap = std::max<uint64_t>(nb / 64 + 1024, S.reads->cap_npos / 8);
+            int rc = reads_reserve(R, true, n_words, n_rec, uniform, npos_cap, S.ctx);
+            if (rc) { err = mf_thread_error(); return rc; }
+            if (!uniform) DCHK(hipMemcpyAsync(R->d_offsets, S.offsets_tmp.p, (n_rec + 1) * 8, hipMemcpyDeviceToDevice, sp));
             uint64_t inv = 0;
             if (pb) {
-                DCHK(M.inv_cnt.need(pb)); DCHK(M.inv_base.need(pb + 1)); DCHK(M.scan_tmp.need(pb / 4096 + 4));
-                DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : M.offsets_tmp.p, uniform, n_rec, nb, M.bases, R->d_words, M.inv_cnt.p, nullptr, nullptr, sp));
-                DCHK(launch_scan_u32(M.inv_cnt.p, pb, M.inv_base.p, M.scan_tmp.p, sp));
-                DCHK(hipMemcpyAsync(M.h_small + 5, M.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
+                DCHK(S.inv_cnt.need(dev, pb)); DCHK(S.inv_base.need(dev, pb + 1)); DCHK(S.scan_tmp.need(dev, pb / 4096 + 4));
+                DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, nullptr, nullptr, sp));
+                DCHK(launch_scan_u32(S.inv_cnt.p, pb, S.inv_base.p, S.scan_tmp.p, sp));
+                DCHK(hipMemcpyAsync(S.h_small + 5, S.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
                 DCHK(hipStreamSynchronize(sp));
                 inv = hs[5];
                 if (inv) {
-                    rc = grow_keep(R->d_npos, R->cap_npos, M.n_npos * 8, (M.n_npos + inv) * 8, sp, err);
-                    if (rc) return rc;
-                    DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : M.offsets_tmp.p, uniform, n_rec, nb, M.bases, R->d_words, M.inv_cnt.p, M.inv_base.p, R->d_npos + M.n_npos, sp));
+                    if (inv > npos_cap) { rc = reads_reserve(R, true, n_words, n_rec, uniform, inv, S.ctx); if (rc) { err = mf_thread_error(); return rc; } }     // (words and offsets stay where they are: only the list grows)
+                    DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, S.inv_base.p, R->d_npos, sp));
                 }
             }
-            // (no synchronisation at the end: the next piece's kernels follow on the same stream, and the arena is not moved before
-            // the event below has passed)
-            M.bases += nb; M.n_npos += inv;
-        }
+            if (timing) t_pack += now_s() - t1;
+            const double t2 = now_s();
+            rc = reads_finish(R, true, n_words, n_rec, nb, uniform, inv, S.ctx);
+            if (rc) { err = mf_thread_error(); return rc; }
+            const size_t bw = (size_t)((n_rec + 31) / 32);
+            if (bw + 2 > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (bw + bw / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = bw + bw / 2 + 1024; }
+            rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, S.h_bits, nullptr, 1, nullptr);
+            if (rc) { err = mf_thread_error(); return rc; }
+            append_bits(M.bits, M.rec_done, n_rec, S.h_bits);
+            if (timing) { t_filter += now_s() - t2; size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) == hipSuccess) mem_used_max = std::max(mem_used_max, t - f); }
+        } else if (timing) t_pack += now_s() - t1;
         used = hs[2];                                                 // (arrived with one of the synchronisations above)
         if (used > n) used = n;                                       // (the virtual line end of an unterminated last line)
-        M.carry = P.last ? 0 : n - used;                              // a partial record at the very end is dropped
-        if (!M.arena.read_ev) DCHK(hipEventCreateWithFlags(&M.arena.read_ev, hipEventDisableTiming));
-        DCHK(hipEventRecord(M.arena.read_ev, sp)); M.arena.read_pending = true;
+        const size_t carry = P.last ? 0 : (size_t)(n - used);         // a partial record at the very end is dropped
+        if (carry) {
+            if (carry > M.h_carry_cap) {
+                uint8_t *q = nullptr;
+                DCHK(hipHostMalloc((void **)&q, carry + carry / 2 + 4096, hipHostMallocPortable));
+                if (M.h_carry) (void)hipHostFree(M.h_carry);
+                M.h_carry = q; M.h_carry_cap = carry + carry / 2 + 4096;
+            }
+            DCHK(hipMemcpyAsync(M.h_carry, text + used, carry, hipMemcpyDeviceToHost, sp));
+            DCHK(hipStreamSynchronize(sp));
+        }
+        M.carry = carry;
         M.rec_done += n_rec;
-        M.batches.push_back(std::move(B));
-        if (timing) t_pack += now_s() - t1;
-        return MF_OK;
-    }
-
-    // the whole file's read set through the filter: pass bits stay on the device (R->d_bits[R->cur])
-    int filter(Mate &M, std::string &err)
-    {
-        if (!M.rec_done) return MF_OK;
-        mf_reads *R = M.reads;
-        const uint64_t n_words = (M.bases + 15) / 16, padded = padded_words_for(n_words);
-        int rc = grow_keep(R->d_words, R->cap_words, n_words * 4, padded * 4, sp, err);
-        if (rc) return rc;
-        DCHK(hipMemsetAsync(R->d_words + n_words, 0, (padded - n_words) * 4, sp));
-        if (!R->d_npos) { rc = grow_keep(R->d_npos, R->cap_npos, 0, 8, sp, err); if (rc) return rc; }
-        const uint32_t uniform = (M.min_len == M.max_len && M.min_len > 0) ? M.min_len : 0;
-        rc = reads_finish(R, false, n_words, M.rec_done, M.bases, uniform, M.n_npos, ctx);
-        if (rc) { err = mf_thread_error(); return rc; }
-        rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, nullptr, nullptr, 1, nullptr);
-        if (rc) { err = mf_thread_error(); return rc; }
+        B->buf = std::move(P.buf);
+        if (n_rec) M.batches.push_back(std::move(B));                 // (a piece without a complete record has nothing to write: its buffer goes back now)
         return MF_OK;
     }
 
     // survivors of the first n_emit records of batch B -> the mate's writer
-    int emit(Mate &M, Batch &B, uint64_t n_emit, const uint32_t *bits_other, std::string &err)
+    int emit(Mate &M, int mi, Batch &B, uint64_t n_emit, std::string &err)
     {
         if (n_emit > B.n_rec) n_emit = B.n_rec;
         if (!n_emit) return MF_OK;
-        const uint8_t *text = M.arena.p + B.start;
-        DCHK(M.out_len.need(n_emit)); DCHK(M.out_off.need(n_emit + 1)); DCHK(M.scan_tmp.need(n_emit / 4096 + 4));
-        DCHK(launch_out_lens(text, B.line_start.p, n_emit, B.rec_base, M.reads->d_bits[M.reads->cur], bits_other, pair_both ? 1 : 0, M.out_len.p, sp));
-        DCHK(launch_scan_u32(M.out_len.p, n_emit, M.out_off.p, M.scan_tmp.p, sp));
-        uint64_t bytes = 0;
-        DCHK(hipMemcpyAsync(&bytes, M.out_off.p + n_emit, 8, hipMemcpyDeviceToHost, sp));
+        DevScratch *Sp = scratch_for(M, B.ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        // the pair rule, on the host: this mate's bits and the other's over the batch's records
+        const size_t bw = (size_t)((n_emit + 31) / 32);
+        if (bw + 2 > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (bw + bw / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = bw + bw / 2 + 1024; }
+        extract_bits(M.bits, B.rec_base, n_emit, S.h_bits);
+        uint64_t keep_n = 0;
+        if (nm == 2) {
+            std::vector<uint32_t> other(bw);
+            extract_bits(m[1 - mi].bits, B.rec_base, n_emit, other.data());
+            for (size_t j = 0; j < bw; j++) S.h_bits[j] = pair_both ? (S.h_bits[j] & other[j]) : (S.h_bits[j] | other[j]);
+        }
+        for (size_t j = 0; j < bw; j++) keep_n += (uint64_t)__builtin_popcount(S.h_bits[j]);
+        if (mi == 0) kept += keep_n;
+        emitted[mi] += n_emit;
+        if (!keep_n) return MF_OK;
+        DCHK(S.mask.need(dev, bw + 1)); DCHK(S.out_len.need(dev, n_emit)); DCHK(S.out_off.need(dev, n_emit + 1)); DCHK(S.scan_tmp.need(dev, n_emit / 4096 + 4));
+        DCHK(hipMemcpyAsync(S.mask.p, S.h_bits, bw * 4, hipMemcpyHostToDevice, sp));
+        DCHK(launch_out_lens(B.text, B.line_start.p, n_emit, 0, S.mask.p, nullptr, 0, S.out_len.p, sp));
+        DCHK(launch_scan_u32(S.out_len.p, n_emit, S.out_off.p, S.scan_tmp.p, sp));
+        DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n_emit, 8, hipMemcpyDeviceToHost, sp));
         DCHK(hipStreamSynchronize(sp));
+        const uint64_t bytes = ((volatile uint64_t *)S.h_small)[6];
         if (bytes) {
-            DCHK(M.d_out.need(bytes));
-            DCHK(launch_gather(text, B.line_start.p, n_emit, M.out_len.p, M.out_off.p, M.d_out.p, sp));
+            DCHK(S.d_out.need(dev, bytes));
+            DCHK(launch_gather(B.text, B.line_start.p, n_emit, S.out_len.p, S.out_off.p, S.d_out.p, sp));
             std::vector<char> host(bytes);
-            DCHK(hipMemcpyAsync(host.data(), M.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(host.data(), S.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
+            wrote_any = true;
             M.out.push(std::move(host));
         }
         return MF_OK;
     }
 
-    // number of survivors among pairs [0, n): population count over the combined bitmaps (read back in pieces)
-    int count_kept(uint64_t n, std::string &err)
+    // write what can be written: the batches whose records the other mate's pass bits cover (all of them once `fin`)
+    int drain(bool fin, std::string &err)
     {
-        kept = 0;
-        const uint64_t nw = (n + 31) / 32;
-        std::vector<uint32_t> a((size_t)std::min<uint64_t>(nw, (uint64_t)1 << 22)), b(a.size());
-        for (uint64_t w0 = 0; w0 < nw; w0 += a.size()) {
-            const uint64_t k = std::min<uint64_t>(a.size(), nw - w0);
-            DCHK(hipMemcpy(a.data(), m[0].reads->d_bits[m[0].reads->cur] + w0, k * 4, hipMemcpyDeviceToHost));
-            if (nm == 2) DCHK(hipMemcpy(b.data(), m[1].reads->d_bits[m[1].reads->cur] + w0, k * 4, hipMemcpyDeviceToHost));
-            for (uint64_t i = 0; i < k; i++) {
-                uint32_t v = nm == 2 ? (pair_both ? (a[i] & b[i]) : (a[i] | b[i])) : a[i];
-                const uint64_t first = (w0 + i) * 32;
-                if (first + 32 > n) v &= n > first ? ((1u << (n - first)) - 1) : 0u;
-                kept += (uint64_t)__builtin_popcount(v);
+        const double te = now_s();
+        for (int i = 0; i < nm; i++) {
+            Mate &M = m[i];
+            const uint64_t covered = fin ? total : (nm == 2 ? std::min(m[0].rec_done, m[1].rec_done) : M.rec_done);
+            while (!M.batches.empty()) {
+                Batch &B = *M.batches.front();
+                if (!fin && B.rec_base + B.n_rec > covered) break;
+                if (B.rec_base < covered) { const int rc = emit(M, i, B, covered - B.rec_base, err); if (rc) return rc; }       // (pairs end with the shorter file)
+                M.batches.pop_front();
             }
         }
+        if (timing) t_emit += now_s() - te;
         return MF_OK;
     }
 
@@ -852,7 +1175,7 @@ struct Ingest {
                     Mate &M = m[(pick + step) % nm];
                     if (M.eof) continue;
                     std::unique_lock<std::mutex> lk(M.mu);
-                    if (!M.ready.empty()) { P = M.ready.front(); M.ready.pop_front(); got = true; pick = (pick + step) % nm; }
+                    if (!M.ready.empty()) { P = std::move(M.ready.front()); M.ready.pop_front(); got = true; pick = (pick + step) % nm; }
                     else if (M.prod_done) {
                         if (M.prod_rc) { err = M.prod_err; return M.prod_rc; }
                         M.eof = true;                                  // (an input without text: an empty file cannot get here, but a .gz of nothing can)
@@ -861,54 +1184,41 @@ struct Ingest {
                 if (got) break;
                 bool any = false; for (int i = 0; i < nm; i++) any = any || !m[i].eof;
                 if (!any) break;
-                std::unique_lock<std::mutex> lk(m[pick].mu);
-                m[pick].cv.wait_for(lk, std::chrono::milliseconds(1));
+                std::unique_lock<std::mutex> lk(mu_all);
+                cv_all.wait_for(lk, std::chrono::microseconds(500));
             }
             if (timing) t_wait += now_s() - tw;
             if (!got) continue;
             Mate &M = m[pick];
-            const int rc = ingest(M, P, err);
+            const bool last = P.last;
+            int rc = ingest(M, P, err);
             if (rc) return rc;
-            if (P.last) M.eof = true;
+            if (last) M.eof = true;
+            rc = drain(false, err);
+            if (rc) return rc;
         }
         for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (M.prod.joinable()) M.prod.join(); if (M.prod_rc) { err = M.prod_err; return M.prod_rc; } }
-        // ---- filter, then write the survivors batch by batch
-        const double tf = now_s();
         total = nm == 2 ? std::min(m[0].rec_done, m[1].rec_done) : m[0].rec_done;
-        for (int i = 0; i < nm; i++) { const int rc = filter(m[i], err); if (rc) return rc; }
-        if (timing) t_filter += now_s() - tf;
-        const double te = now_s();
-        if (total) {
-            for (int i = 0; i < nm; i++) {
-                Mate &M = m[i];
-                const uint32_t *other = nm == 2 ? m[1 - i].reads->d_bits[m[1 - i].reads->cur] : nullptr;
-                for (auto &B : M.batches) {
-                    if (B->rec_base >= total) break;                  // pairs end with the shorter file
-                    const int rc = emit(M, *B, total - B->rec_base, other, err);
-                    if (rc) return rc;
-                }
-            }
-            const int rc = count_kept(total, err);
-            if (rc) return rc;
-        }
-        if (timing) t_emit += now_s() - te;
-        return MF_OK;
+        return drain(true, err);
     }
 };
+
+bool alloc_failure(int rc) { return rc == MF_E_NOMEM; }
 
 } // namespace
 
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
-                      bool pair_both, int device, uint64_t *kept, uint64_t *total, std::string &err)
+                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err)
 {
-    struct EndOfCall { ~EndOfCall() { g_trash.empty(); const char *kb = getenv("MF_KEEP_BUFFERS"); g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 96) << 30); } } end_of_call;     // (declared first: runs after everything of this call is gone)
+    struct EndOfCall { ~EndOfCall() { const char *kb = getenv("MF_KEEP_BUFFERS"); g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 16) << 30); } } end_of_call;     // (declared first: runs after everything of this call is gone)
     Ingest I;
-    I.ks = ks; I.threshold = threshold; I.pair_both = pair_both; I.device = device; I.nm = fq2 ? 2 : 1;
+    I.ks = ks; I.threshold = threshold; I.pair_both = pair_both; I.nm = fq2 ? 2 : 1;
+    for (int i = 0; i < n_devices; i++) I.devices.push_back(devices[i]);
+    if (I.devices.empty() || I.devices.size() > 64) { err = "bad device list"; return MF_E_ARG; }
     I.timing = getenv("MF_PIPE_TIMING") != nullptr;
+    I.carry_room = (size_t)env_u64("MF_INGEST_CARRY_ROOM", (size_t)1 << 20);
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
-    // ---- is this an input for the device path?  Everything of a file stays resident until its survivors are written: the
-    // compressed bytes, the text, the line index, the packed reads.
-    size_t need = (size_t)4 << 30;
+    // ---- is this an input for the device path?
     for (int i = 0; i < I.nm; i++) {
         Mate &M = I.m[i];
         M.path = in_path[i]; M.gz = has_gz_ext(in_path[i]);
@@ -920,46 +1230,41 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
             if (M.map.n < 18 || d[0] != 0x1f || d[1] != 0x8b) return MF_DEVINGEST_DECLINED;      // (gzread hands such a file through; so does the host reader)
             if ((d[3] & 4) && M.map.n >= 18 && d[12] == 'B' && d[13] == 'C') return MF_DEVINGEST_DECLINED;   // BGZF: the host reader decodes its members side by side
         }
-        need += M.gz ? M.map.n * 8 + ((size_t)32 << 30) : M.map.n + M.map.n / 2;      // (file, text arena, read set; twelve symbol buffers of 2.4 GB)
     }
-    int rc = get_ctx(device, &I.ctx, 0);
-    if (rc) { err = mf_thread_error(); return rc; }
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + g_pool.held() < need) return MF_DEVINGEST_DECLINED;       // too large to keep resident: the host pipeline streams it (what the pool holds from earlier calls counts as free)
-    }
+    for (int d : I.devices) { DevCtx *c = nullptr; const int rc = get_ctx(d, &c, 0); if (rc) { err = mf_thread_error(); return rc; } }
     const double t_begin = now_s();
-    I.sp = I.ctx->stream;
-    for (int i = 0; i < I.nm; i++) {
+    g_pool.reset_peak();
+    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", 4)) + (int)I.devices.size() - 1;
+    int rc = MF_OK;
+    for (int i = 0; i < I.nm && !rc; i++) {
         Mate &M = I.m[i];
-        DCHK(M.d_file.need(M.map.n + 256, false));
-        DCHK(hipMemsetAsync(M.d_file.p + M.map.n, 0, 256, I.sp));
-        DCHK(hipStreamSynchronize(I.sp));
-        rc = M.up.start(M.map.p, M.map.fd, M.map.n, M.d_file.p, phys(device), err);
-        if (rc) return rc;
+        M.slots.free_ = text_bufs; M.slots.stop = &M.stop;
         if (M.gz) {
             M.gzs.reset(new GzStream());
-            rc = M.gzs->open(M.map.p, M.map.n, M.d_file.p, &M.up, &M.arena, M.path, err);
-            if (rc) return rc;
-        } else { M.arena.p = M.d_file.p; M.arena.cap = M.map.n; }
+            rc = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, &M.stop, err);
+        }
     }
+    if (alloc_failure(rc)) { TRACE("declined: %s", err.c_str()); return MF_DEVINGEST_DECLINED; }      // (nothing has been touched: the host pipeline streams the file)
+    if (rc) return rc;
     for (int i = 0; i < I.nm; i++) if (!I.m[i].out.open(out_path[i])) { err = std::string("Cannot open file ") + out_path[i]; return MF_E_IO; }
     const double t_setup = now_s() - t_begin;
     rc = I.run(err);
     TRACE("run returned %d", rc);
-    for (int i = 0; i < I.nm; i++) I.m[i].stop = true;
+    for (int i = 0; i < I.nm; i++) { I.m[i].stop = true; I.m[i].slots.wake(); }
     bool wrote = true;
     for (int i = 0; i < I.nm; i++) wrote = I.m[i].out.close() && wrote;
+    // out of device memory before a byte of the survivors was written: the host pipeline takes the file (it truncates the outputs again)
+    if (alloc_failure(rc) && !I.wrote_any) { TRACE("declined after a failed allocation: %s", err.c_str()); return MF_DEVINGEST_DECLINED; }
     if (rc) return rc;
     if (!wrote) { err = std::string("write error on ") + out_path[0]; return MF_E_IO; }
     if (kept) *kept = I.kept;
     if (total) *total = I.total;
     if (I.timing) {
-        fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f",
-                now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit);
+        fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
+                now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
         for (int i = 0; i < I.nm; i++)
-            if (I.m[i].gzs) fprintf(stderr, " | mate %d: %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there", i + 1, (unsigned long long)I.m[i].gzs->chunks_linked(),
-                                    I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes());
+            if (I.m[i].gzs) fprintf(stderr, " | mate %d: %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, (unsigned long long)I.m[i].gzs->chunks_linked(),
+                                    I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes(), I.m[i].gzs->ring_bytes() >> 20, I.m[i].gzs->splits());
         fprintf(stderr, "\n");
     }
     return MF_OK;

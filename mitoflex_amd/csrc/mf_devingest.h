@@ -13,8 +13,9 @@ namespace mf {
 
 constexpr int MF_DEVINGEST_DECLINED = 1;      // not an input this path takes (a pipe, BGZF, an empty file ...): use the host pipeline
 
-// fq2 / out2 null: single end.  Returns MF_OK, MF_DEVINGEST_DECLINED (nothing has been written) or an MF_E_* code with err set.
+// fq2 / out2 null: single end.  devices: the (logical) devices the slabs of the input are dealt to, round robin.
+// Returns MF_OK, MF_DEVINGEST_DECLINED (no survivor has been written: the caller takes the host pipeline) or an MF_E_* code with err set.
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
-                      bool pair_both, int device, uint64_t *kept, uint64_t *total, std::string &err);
+                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err);
 
 } // namespace mf

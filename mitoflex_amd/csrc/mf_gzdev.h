@@ -37,11 +37,14 @@ struct GzChunk {
 };
 
 // Decode chunks [chunk_lo, chunk_lo + n_chunks) of the deflate data in d_data[0 .. size) (readable, zero padded, up to size + 64).
+// ring_bytes != 0: d_data is a ring of that many bytes (a power of two, >= 4096) and byte b of the file lives at d_data[b % ring_bytes];
+// limit_bytes: the bytes of the file in front of it are on the device -- a chunk whose decoding would read past it stops as
+// GZ_FAILED (n_sym = 8), nothing of it is accepted and the host bridges the stretch.
 // Chunk c covers the bits [(base_byte + c * chunk_bytes) * 8, (base_byte + (c + 1) * chunk_bytes) * 8).  exact_chunk /
 // exact_bit: that chunk starts at exactly that bit, a known block boundary (the first block of a member, or where a gap
 // fill ended); pass exact_chunk = ~0u for none.  Symbols of chunk c go to d_sym + (c - chunk_lo) * sym_cap.
-hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes, uint32_t chunk_lo,
-                            uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
+hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t size, uint64_t limit_bytes, uint64_t base_byte, uint64_t chunk_bytes,
+                            uint32_t chunk_lo, uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
                             GzChunk *d_chunks, hipStream_t st);
 
 // ---- linking the chunks (one workgroup, in stream order) and turning symbols into text

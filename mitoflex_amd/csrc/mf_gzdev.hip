@@ -62,7 +62,9 @@ struct Lds {                             // the walk's inline assembly relies on
 // together (one 16-byte load per lane, 1 KiB a time); the walk itself only ever reads LDS.  Every value in here is
 // wave-uniform: all lanes execute the reader with the same state, so its branches are scalar branches.
 struct BitRd {
-    const uint4 *base; uint32_t vmax;        // vectors 0 .. vmax of the input are readable
+    const uint4 *base; uint64_t vmax;        // vectors 0 .. vmax of the input are readable
+    uint64_t vmask;                          // the input lives in a ring of vmask + 1 vectors (all ones: no ring)
+    uint64_t origin_v;                       // rd_dw and ring_hi count from this vector of the input (a chunk reads a few MiB; the file may have more than 2^32 dwords)
     uint32_t *ring;                          // LDS; holds the dwords [ring_hi - RING, ring_hi)
     uint32_t rd_dw, ring_hi;                 // rd_dw: next dword to enter the bit buffer
     uint32_t nd;                             // ring[rd_dw], read ahead
@@ -77,11 +79,11 @@ struct BitRd {
     __device__ __forceinline__ void refill() { if (bc <= 30) { bb |= (uint64_t)next_dword() << bc; bc += 32; } }   // afterwards 31 <= bc <= 62
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1); }           // n <= 31
     __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
-    __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)rd_dw * 32 - bc; }
+    __device__ __forceinline__ uint64_t bitpos() const { return origin_v * 128 + (uint64_t)rd_dw * 32 - bc; }
     __device__ __forceinline__ void load_half(uint32_t lane)      // 256 more dwords behind ring_hi
     {
-        const uint32_t v = ring_hi / 4 + lane;
-        const uint4 x = base[v < vmax ? v : vmax];
+        const uint64_t v = origin_v + ring_hi / 4 + lane;
+        const uint4 x = base[(v < vmax ? v : vmax) & vmask];
         *reinterpret_cast<uint4 *>(&ring[(ring_hi + 4 * lane) & (RING - 1)]) = x;
         ring_hi += RING / 2;
     }
@@ -92,7 +94,7 @@ struct BitRd {
     }
     __device__ __forceinline__ void seek(uint64_t bit, uint32_t lane)
     {
-        const uint32_t d = (uint32_t)(bit >> 5);
+        const uint32_t d = (uint32_t)((bit - origin_v * 128) >> 5);
         if (!(d + RING / 2 <= ring_hi && d + RING >= ring_hi)) {
             __syncthreads();
             ring_hi = d & ~3u;
@@ -281,7 +283,7 @@ __device__ __forceinline__ bool build_tables(Lds &L, uint32_t hlit, uint32_t hdi
 // flight together -- a step of the search is a memory round trip, and with one window a step that was what it cost.
 constexpr int SEARCH_W = 4;
 struct Search { uint64_t b0; uint64_t mask[SEARCH_W]; };      // mask[j]: candidates among the offsets b0 + 64 j + lane
-__device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *words, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
+__device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *words, uint64_t wmask, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
 {
     for (;;) {
 #pragma unroll
@@ -300,7 +302,7 @@ __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *wo
             in[j] = bit < to_bit && bit + 128 <= size_bits;
             const uint64_t wi = in[j] ? bit >> 5 : 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) w[j][q] = words[wi + q];
+            for (int q = 0; q < 4; q++) w[j][q] = words[(wi + q) & wmask];
         }
 #pragma unroll
         for (int j = 0; j < SEARCH_W; j++) {
@@ -610,19 +612,21 @@ __device__ __forceinline__ uint32_t expand(Lds &L, uint32_t n, uint16_t *out, ui
     return tot;
 }
 
-__global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes,
-                                                       uint32_t chunk_lo, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *sym,
+__global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint64_t ring_mask, uint64_t size, uint64_t limit_bytes, uint64_t base_byte,
+                                                       uint64_t chunk_bytes, uint32_t chunk_lo, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *sym,
                                                        uint64_t sym_cap, GzChunk *chunks)
 {
     __shared__ Lds L;
     const uint32_t lane = threadIdx.x;
     const uint32_t c = chunk_lo + blockIdx.x;
     uint16_t *out = sym + (uint64_t)blockIdx.x * sym_cap;
-    const uint64_t size_bits = size * 8;
+    const uint64_t size_bits = size * 8, limit_bits = limit_bytes * 8;      // limit: what of the stream is on the device (the rest of the ring holds other bytes)
     const uint64_t nominal = (base_byte + (uint64_t)c * chunk_bytes) * 8, stop_bit = nominal + chunk_bytes * 8;
     const uint64_t search_end = stop_bit < size_bits ? stop_bit : size_bits;
     GzChunk res; res.start_bit = 0; res.end_bit = 0; res.n_sym = 0; res.status = GZ_NONE;
-    BitRd rd; rd.base = reinterpret_cast<const uint4 *>(data); rd.vmax = (uint32_t)((size + 48) / 16);      // readable (and zero) up to size + 64
+    BitRd rd; rd.base = reinterpret_cast<const uint4 *>(data); rd.vmax = (size + 48) / 16;      // readable (and zero) up to size + 64
+    rd.vmask = ring_mask >> 4;
+    rd.origin_v = (c == exact_chunk && exact_bit < nominal ? exact_bit : nominal) >> 7;
     rd.ring = L.ring; rd.rd_dw = 0; rd.ring_hi = 0; rd.nd = 0; rd.bb = 0; rd.bc = 0;
     // A speculative chunk tries the candidates of its range in order: one whose header parses strictly is decoded; if the data
     // behind it turns out not to decode (a false candidate) the search goes on behind it.
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
         bool strict = false;
         why = 0;
         if (searching) {
-            start = next_candidate(S, reinterpret_cast<const uint32_t *>(data), search_end, size_bits, lane);
+            start = next_candidate(S, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, search_end, size_bits, lane);
             if (start == ~0ull) { status = GZ_NONE; break; }
             rd.seek(start + 3, lane);
             strict = true; opos = 0; blk_pos = start; blk_opos = 0;
@@ -669,9 +673,10 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
                 const uint32_t nlen = rd.peek(16); rd.drop(16);
                 const uint64_t byte = rd.bitpos() >> 3;
                 if ((len ^ nlen) != 0xFFFFu || byte + len > size) why = 3;
+                else if (byte + len > limit_bytes) why = 8;
                 else {
                     if (opos + len > sym_cap) { status = GZ_OVERFLOW; break; }
-                    for (uint32_t i = lane; i < len; i += 64) out[opos + i] = data[byte + i];
+                    for (uint32_t i = lane; i < len; i += 64) out[opos + i] = data[(byte + i) & ring_mask];
                     opos += len;
                     rd.seek((byte + len) * 8, lane);
                     if (final) { status = GZ_MEMBER_END; break; }
@@ -706,6 +711,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
                 end = walk(L, rd, lane, n, T);
                 if (end == W_ERROR) why = 6;
                 if (rd.bitpos() > size_bits) { end = W_ERROR; why = 7; }
+                else if (rd.bitpos() > limit_bits) { end = W_ERROR; why = 8; }          // ran into bytes that are not on the device yet: the host bridges this stretch
                 __syncthreads();
                 if (end == W_ERROR) break;
                 opos += expand(L, n, out, opos, lane);
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
         if (why) {
             // not deflate data.  From a speculative start that only says the candidate was false: the search goes on behind it
             // (S still holds the rest of the candidates of its step)
-            if (c != exact_chunk) { searching = true; continue; }
+            if (c != exact_chunk && why != 8) { searching = true; continue; }
             status = GZ_FAILED; break;
         }
         if (final) { status = GZ_MEMBER_END; break; }
@@ -907,13 +913,15 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *text, uint64
 
 } // namespace
 
-hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t size, uint64_t base_byte, uint64_t chunk_bytes, uint32_t chunk_lo,
-                            uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
+hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t size, uint64_t limit_bytes, uint64_t base_byte, uint64_t chunk_bytes,
+                            uint32_t chunk_lo, uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
                             GzChunk *d_chunks, hipStream_t st)
 {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, size, base_byte, chunk_bytes, chunk_lo, exact_chunk,
-                       exact_bit, d_sym, sym_cap, d_chunks);
+    if (ring_bytes && ((ring_bytes & (ring_bytes - 1)) || ring_bytes < 4096)) return hipErrorInvalidValue;
+    const uint64_t ring_mask = ring_bytes ? ring_bytes - 1 : ~0ull;
+    hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, ring_mask, size, limit_bytes < size ? limit_bytes : size, base_byte, chunk_bytes,
+                       chunk_lo, exact_chunk, exact_bit, d_sym, sym_cap, d_chunks);
     return hipGetLastError();
 }
 

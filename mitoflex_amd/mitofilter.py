@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -29,7 +29,7 @@ EXPORTS = (
     "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_resident_passes", "mf_filter_packed",
-    "mf_filter_fastq_files", "mf_qualfilter_files",
+    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_qualfilter_files",
 )
 
 
@@ -99,10 +99,12 @@ def load(path: Optional[str] = None):
     L.mf_filter_packed.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, vp]
     L.mf_filter_fastq_files.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
                                         C.c_int, u64p, u64p]
+    L.mf_filter_fastq_files_on.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
+                                           C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                       C.c_uint32, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
                                       C.POINTER(C.c_int)]
-    if L.mf_abi_version() != 2:
+    if L.mf_abi_version() != 3:
         raise MitoFilterError("libmitofilter_hip ABI version mismatch")
     _lib = L
     return L
@@ -289,11 +291,17 @@ def filter_packed(ks: KmerSet, words, offsets, npos, threshold: int = 1, device:
 
 
 def filter_fastq_files(ks: KmerSet, fq1: str, fq2: Optional[str], out1: str, out2: Optional[str],
-                       threshold: int = 1, pair_mode: int = PAIR_EITHER, n_devices: int = 1) -> Tuple[int, int]:
-    """-> (kept, total) reads (SE) or pairs (PE)."""
+                       threshold: int = 1, pair_mode: int = PAIR_EITHER, n_devices: int = 1,
+                       devices: Optional[Sequence[int]] = None) -> Tuple[int, int]:
+    """-> (kept, total) reads (SE) or pairs (PE).  devices: an explicit list of device indices (instead of 0 .. n_devices - 1)."""
     kept, total = C.c_uint64(), C.c_uint64()
-    _chk(load().mf_filter_fastq_files(ks._h, _enc(fq1), _enc(fq2), _enc(out1), _enc(out2), threshold, pair_mode,
-                                      n_devices, C.byref(kept), C.byref(total)))
+    if devices is not None:
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _chk(load().mf_filter_fastq_files_on(ks._h, _enc(fq1), _enc(fq2), _enc(out1), _enc(out2), threshold, pair_mode,
+                                             arr, len(devices), C.byref(kept), C.byref(total)))
+    else:
+        _chk(load().mf_filter_fastq_files(ks._h, _enc(fq1), _enc(fq2), _enc(out1), _enc(out2), threshold, pair_mode,
+                                          n_devices, C.byref(kept), C.byref(total)))
     return kept.value, total.value
 
 

@@ -15,6 +15,7 @@ import pytest
 from tests.util_data import make_reads, write_fastq
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(autouse=True)
@@ -252,6 +253,123 @@ def test_highly_compressible_input_grows_the_symbol_buffers(mf, ol, bait_text, t
     assert (k, t) == (30000, 60000)
 
 
+# ---- round 4: the path streams -- a ring for the compressed bytes, a text buffer per piece, a bounded number of both
+
+STREAMING = {"MF_GZDEV_CHUNK_BYTES": "4096", "MF_GZDEV_SLAB_CHUNKS": "3", "MF_GZDEV_RING_BYTES": "65536", "MF_GZDEV_MARGIN": "8192",
+             "MF_INGEST_TEXT_BUFS": "2", "MF_GZDEV_TEXT_PIECE": "20000", "MF_INGEST_SLAB_BYTES": "50001"}
+
+
+@pytest.mark.parametrize("level", [1, 6])
+@pytest.mark.parametrize("carry_room", ["0", "1048576"])
+def test_ring_wraps_and_buffers_recycle(mf, ol, bait_text, tmp_path, monkeypatch, capfd, level, carry_room):
+    """A 64 KiB ring under files of several hundred kilobytes (it wraps many times), two text buffers per mate, pieces of at most
+    20 kB of text, and -- with no carry room -- every piece moved to a buffer that holds the carry too: same bytes as the oracle."""
+    for k, v in STREAMING.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("MF_INGEST_CARRY_ROOM", carry_room)
+    monkeypatch.setenv("MF_PIPE_TIMING", "1")
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s1 = make_reads(bait_text, 6000, seed=81)
+    s2 = make_reads(bait_text, 5900, seed=82)
+    fq1, fq2 = str(tmp_path / "a_1.fq.gz"), str(tmp_path / "a_2.fq.gz")
+    open(fq1, "wb").write(gz_bytes(fastq_text(s1, "a", tail=b"@partial\nACGT\n"), level))
+    open(fq2, "wb").write(gz_bytes(fastq_text(s2, "b", crlf=True, last_newline=False), level))
+    assert os.path.getsize(fq1) > 4 * 65536
+    capfd.readouterr()
+    k, t = run_both(mf, ol, bait, ks, fq1, fq2, tmp_path, 1, mf.PAIR_EITHER)
+    assert t == 5900 and 0 < k < t
+    err = capfd.readouterr().err
+    assert "ring 0 MiB" in err and "declined" not in err, err           # (65536 bytes print as 0 MiB: the knob was honoured)
+    run_both(mf, ol, bait, ks, fq1, None, tmp_path, 1)
+    # plain text through the same buffers
+    p1 = str(tmp_path / "p_1.fq")
+    open(p1, "wb").write(fastq_text(s1, "a", crlf=True))
+    run_both(mf, ol, bait, ks, p1, fq2, tmp_path, 1, mf.PAIR_BOTH)
+
+
+def test_long_blocks_past_the_margin_are_bridged(mf, ol, bait_text, tmp_path, monkeypatch, capfd):
+    """A chunk may only read what has been copied up: the bytes of its slab and a margin behind it.  With a margin of 1 KiB
+    nearly every slab's last chunk runs into it (a deflate block of level 9 is tens of kilobytes long) -- those chunks stop,
+    nothing of them is accepted, and the host decodes across the stretch."""
+    for k, v in STREAMING.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("MF_GZDEV_MARGIN", "1024")
+    monkeypatch.setenv("MF_PIPE_TIMING", "1")
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s = make_reads(bait_text, 5000, seed=83)
+    fq = str(tmp_path / "m.fq.gz")
+    open(fq, "wb").write(gz_bytes(fastq_text(s, "m"), 9))
+    capfd.readouterr()
+    k, t = run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    assert t == 5000
+    import re
+    m = re.search(r"(\d+) gaps bridged on the host, (\d+) bytes decoded there", capfd.readouterr().err)
+    assert m and int(m.group(1)) >= 1 and int(m.group(2)) > 200000          # (most of the text: hardly a chunk gets to the end of its block)
+
+
+def _gzip_tools():
+    import shutil
+    tools = [("gzip", lvl) for lvl in (1, 6, 9) if shutil.which("gzip")]
+    tools += [(t, 6) for t in ("pigz", "bgzip") if shutil.which(t)]
+    return tools
+
+
+@pytest.mark.parametrize("tool,level", _gzip_tools())
+def test_files_written_by_real_compressors(mf, ol, bait_text, tmp_path, tool, level):
+    """gzip -1 / -6 / -9 (and pigz, bgzip where the box has them) write the input themselves -- not zlib.compressobj, not this
+    repository's tools/pgzip.py.  (bgzip writes BGZF, which this library decodes on the host: the call must still be right.)"""
+    import subprocess
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    s1, s2 = make_reads(bait_text, 150000, seed=91), make_reads(bait_text, 150000, seed=92)
+    fq1, fq2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    open(fq1, "wb").write(fastq_text(s1, "a"))
+    open(fq2, "wb").write(fastq_text(s2, "b"))
+    for f in (fq1, fq2):
+        with open(f + ".gz", "wb") as o:
+            subprocess.check_call([tool, "-%d" % level, "-c", f] if tool != "bgzip" else [tool, "-c", f], stdout=o)
+    k, t = run_both(mf, ol, bait, ks, fq1 + ".gz", fq2 + ".gz", tmp_path)
+    assert t == 150000 and 0 < k < t
+
+
+@pytest.mark.parametrize("n_dev", [2, 4])
+def test_slabs_dealt_to_several_devices(ol, bait_text, tmp_path, n_dev):
+    """`fastfilter bait --devices N` on .gz input takes the device path: the slabs of either stream are dealt to the N devices
+    round robin, the link state travels through the host, every piece is cut, packed, filtered and gathered on the device that
+    holds it.  MF_FAKE_DEVICES maps N logical devices (own contexts, streams, rings, bait tables, read sets) onto the one GPU of
+    the box; a child process, because the variable is read when the library is loaded."""
+    import subprocess
+    s1 = make_reads(bait_text, 9000, seed=15)
+    s2 = make_reads(bait_text, 9100, seed=16)
+    fq1, fq2 = str(tmp_path / "a_1.fq.gz"), str(tmp_path / "a_2.fq.gz")
+    open(fq1, "wb").write(gz_bytes(fastq_text(s1, "a", tail=b"@partial\nACGT\n"), 6))
+    open(fq2, "wb").write(gz_bytes(fastq_text(s2, "b", crlf=True, last_newline=False), 1, members=3))
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+    ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
+    g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
+    cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
+    env = dict(os.environ, MF_FAKE_DEVICES=str(n_dev), MF_PIPE_TIMING="1", MF_GZDEV_CHUNK_BYTES="8192", MF_GZDEV_SLAB_CHUNKS="5",
+               MF_GZDEV_TEXT_PIECE="200000")
+    env.pop("MF_INGEST", None)
+    for args in (["--devices", str(n_dev)], ["--device-list", ",".join(str(d) for d in reversed(range(1, n_dev)))]):
+        p = subprocess.run([cli, "bait", "--bait", bait, "-k", "31", "--fq1", fq1, "--fq2", fq2, "--out1", g1, "--out2", g2] + args,
+                           capture_output=True, env=env, timeout=300)
+        err = p.stderr.decode()
+        assert p.returncode == 0, err[:3000]
+        n_used = n_dev if args[0] == "--devices" else n_dev - 1
+        assert "[mf device ingest] wall" in err and ("%d device(s)" % n_used) in err and "declined" not in err, err[:3000]
+        assert int(p.stdout.decode().split()[0]) == ok and ot == 9000
+        assert open(g1, "rb").read() == open(o1, "rb").read()
+        assert open(g2, "rb").read() == open(o2, "rb").read()
+
+
 @pytest.mark.parametrize("knobs", [dict(MF_GZDEV_RESERVED_CUS="8", MF_UPLOAD_THREADS="1"), dict(MF_GZDEV_RESERVED_CUS="64", MF_UPLOAD_THREADS="16"),
                                    dict(MF_GZDEV_NO_CUMASK="1")], ids=["reserve8-upload1", "reserve64-upload16", "no-cu-masks"])
 def test_stream_and_upload_knobs(knobs):
@@ -267,7 +385,7 @@ def test_stream_and_upload_knobs(knobs):
 
 
 @pytest.mark.parametrize("level", [1, 6])
-def test_configs4_at_full_size(mf, ol, bait_text, tmp_path_factory, level):
+def test_configs4_at_full_size(mf, ol, bait_text, tmp_path_factory, monkeypatch, capfd, level):
     """BASELINE.json configs[4] at its stated size: 33 333 334 single-end reads of 150 bases in ONE gzip member, filtered file to
     file on one GPU.  The file is generated on the box (tools/make_fastq.py, 2 M-read blocks) and compressed by tools/pgzip.py
     (one member, 8 MiB slices).  Checked: the totals; the survivors of the first million reads byte for byte against the oracle
@@ -303,11 +421,19 @@ def test_configs4_at_full_size(mf, ol, bait_text, tmp_path_factory, level):
     ks = mf.KmerSet.from_fasta(bait, 31)
     out = str(d / "dev.fq")
     best = 1e9
+    monkeypatch.setenv("MF_PIPE_TIMING", "1")
+    capfd.readouterr()
     for _ in range(2):
         t0 = time.perf_counter()
         kept, total = mf.filter_fastq_files(ks, gz, None, out, None)
         best = min(best, time.perf_counter() - t0)
     assert (kept, total) == (int(want_kept), int(want_total)) and total == n
+    # the path streams: a 5 GB file (10.7 GB of text) goes through with a bounded amount of device memory
+    import re
+    err = capfd.readouterr().err
+    used = [float(x) for x in re.findall(r"device memory in use at most ([0-9.]+) GB", err)]
+    assert len(used) == 2 and max(used) < 40.0 and "declined" not in err, err[-2000:]
+    print("configs[4] level %d: device memory in use at most %.1f GB" % (level, max(used)))
     got = open(out, "rb").read()
     assert hashlib.md5(got).hexdigest() == want_md5
     win = open(str(d / "win.out"), "rb").read()

@@ -66,7 +66,7 @@ int main(int argc, char **argv)
     for (int r = 0; r < reps; r++) {
         CK(hipMemset(d_chunks, 0, n_chunks * sizeof(mf::GzChunk)));
         CK(hipEventRecord(e0, 0));
-        CK(mf::launch_gz_decode(d_data, size, base_byte, chunk, 0, n_chunks, 0, (uint64_t)base_byte * 8, d_sym, cap, d_chunks, 0));
+        CK(mf::launch_gz_decode(d_data, 0, size, size, base_byte, chunk, 0, n_chunks, 0, (uint64_t)base_byte * 8, d_sym, cap, d_chunks, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
