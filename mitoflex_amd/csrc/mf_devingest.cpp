@@ -289,7 +289,7 @@ struct TextBuf {
 };
 
 // a range of an input's text that has become available, in order
-struct TextPiece { std::unique_ptr<TextBuf> buf; uint64_t T0 = 0, len = 0; bool last = false; };
+struct TextPiece { std::unique_ptr<TextBuf> buf; uint64_t T0 = 0, len = 0; bool last = false; double grow = 1.0; };      // grow: how much larger than this one the file's pieces become (the first slabs of a .gz are short)
 
 // ---- a .gz file's bytes -> the rings of the devices that decode it, in order, a piece at a time.  The slab layout says which
 // devices want which bytes; the producer moves the low-water mark (everything in front of it has been linked) and the uploader
@@ -542,7 +542,7 @@ public:
                 TRACE("slab %u..%u overflowed: again with %zu symbols per chunk", S.lo, S.hi, S.cap);
                 DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
                 hipStream_t sd = L.streams->sd[0];
-                DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, sd));
+                DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, sd));
                 DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd));
                 DCHK(hipStreamSynchronize(sd));
             }
@@ -617,6 +617,7 @@ public:
         const bool slab_done = S.cur == S.hi || done_;
         if (last_piece && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
         pend_.buf = std::move(cur_buf_); pend_.T0 = T0; pend_.len = h_chain_->total - T0; pend_.last = done_;
+        pend_.grow = b > a ? std::max(1.0, (double)cps_ / (double)(b - a)) : 1.0;
         pending_ = true; pend_lane_ = S.lane;
         if (slab_done) {
             pend_slab_ = std::move(slabs_.front()); slabs_.pop_front();      // (its symbols are being resolved: kept until finish_pending)
@@ -654,7 +655,7 @@ private:
     };
     struct SlabPlan { uint32_t lo, hi, lane; };
     struct Slab {
-        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; size_t cap = 0, limit = 0; hipEvent_t ev = nullptr;     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
+        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; DevBuf<uint32_t> lst; size_t cap = 0, limit = 0; hipEvent_t ev = nullptr;     // lst: the lane-parallel kernel's code lists     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
         bool launched = false, read_back = false;
     };
     size_t sym_cap_now() const
@@ -683,11 +684,12 @@ private:
             DCHK(hipSetDevice(L.dev));
             if (!S.cap) S.cap = sym_cap_now();
             DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
+            if (!gz_decode_serial()) DCHK(S.lst.need(L.dev, gz_decode_scratch_bytes(S.hi - S.lo) / 4, false));
             if (!S.ev) DCHK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
             hipStream_t st = L.streams->sd[launch_seq_++ % GZ_NSTREAM];
             if (!up_->wait_for(S.lane, st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_IO; }
             S.limit = upto;
-            DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, st));
+            DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, st));
             DCHK(hipEventRecord(S.ev, st));
             S.launched = true;
         }
@@ -1034,6 +1036,7 @@ struct Ingest {
         const uint64_t n_rec = B->n_rec;
         std::vector<uint32_t> bits;
         if (n_rec) {
+            const bool first_set = !S.reads;
             if (!S.reads) { S.reads = new (std::nothrow) mf_reads(); if (!S.reads) { err = "out of memory"; return MF_E_NOMEM; } S.reads->device = S.ldev; S.reads->lane = 0; }
             mf_reads *R = S.reads;
             // sequence lengths, the piece's own base offsets
@@ -1051,7 +1054,19 @@ struct Ingest {
             // invalid bases are rare (N calls): room for one in 64 bases, more when a piece proves to need it
             const uint64_t pb = pack_blocks(nb, 0);
             uint64_t npos_cap = std::max<uint64_t>(nb / 64 + 1024, S.reads->cap_npos / 8);
-            int rc = reads_reserve(R, true, n_words, n_rec, uniform, npos_cap, S.ctx);
+            int rc = MF_OK;
+            if (first_set && P.grow > 1.0) {
+                // The read set is refilled piece after piece, and growing it means hipFree -- which waits for every kernel on the
+                // device, the decoder's included.  The first slabs of a .gz are short ones: give the set the size of a full slab's now.
+                const double g = std::min(P.grow, 64.0) * 1.2;
+                const uint64_t nw = (uint64_t)((double)n_words * g), nr = (uint64_t)((double)n_rec * g);
+                rc = reads_reserve(R, true, nw, nr, 0, (uint64_t)((double)npos_cap * g), S.ctx);
+                if (!rc) rc = reads_finish(R, true, nw, nr, nw * 16, 0, 0, S.ctx);        // (no invalid positions: nothing of the empty set is read)
+                if (rc) { err = mf_thread_error(); return rc; }
+                const size_t bw = (size_t)(nr / 32 + 1024);
+                if (bw > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, bw * 4, hipHostMallocDefault)); S.h_bits_cap = bw; }
+            }
+            rc = reads_reserve(R, true, n_words, n_rec, uniform, npos_cap, S.ctx);
             if (rc) { err = mf_thread_error(); return rc; }
             if (!uniform) DCHK(hipMemcpyAsync(R->d_offsets, S.offsets_tmp.p, (n_rec + 1) * 8, hipMemcpyDeviceToDevice, sp));
             uint64_t inv = 0;

@@ -43,9 +43,13 @@ struct GzChunk {
 // Chunk c covers the bits [(base_byte + c * chunk_bytes) * 8, (base_byte + (c + 1) * chunk_bytes) * 8).  exact_chunk /
 // exact_bit: that chunk starts at exactly that bit, a known block boundary (the first block of a member, or where a gap
 // fill ended); pass exact_chunk = ~0u for none.  Symbols of chunk c go to d_sym + (c - chunk_lo) * sym_cap.
+// d_scratch: gz_decode_scratch_bytes(n_chunks) bytes for the lane-parallel kernel's code lists (nullptr, or MF_GZDEV_KERNEL=serial:
+// the one-lane walk of round 3 runs instead).
 hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t size, uint64_t limit_bytes, uint64_t base_byte, uint64_t chunk_bytes,
                             uint32_t chunk_lo, uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
-                            GzChunk *d_chunks, hipStream_t st);
+                            GzChunk *d_chunks, uint32_t *d_scratch, hipStream_t st);
+size_t gz_decode_scratch_bytes(uint32_t n_chunks);
+bool gz_decode_serial();
 
 // ---- linking the chunks (one workgroup, in stream order) and turning symbols into text
 enum GzStop : uint32_t {

@@ -16,28 +16,21 @@
 // The kernel is bound by one wavefront's dependent chain (about 290 cycles per code, the all-lane expansion a third on top)
 // times the wavefronts a CU holds: 9.9 KB of LDS and 128 VGPRs per wavefront, sixteen chunks in flight per CU.
 #include "mf_gzdev.h"
+#include "mf_gzlane.h"
 #include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace mf {
 namespace {
 
-constexpr int LIT_BITS = 10, DIST_BITS = 9, PRE_BITS = 7;
-constexpr uint32_t LIT_SIZE = 1u << LIT_BITS, DIST_SIZE = 1u << DIST_BITS, PRE_SIZE = 1u << PRE_BITS;
+using namespace gzl;                     // table sizes, entry formats, Canon, the lane's walk (mf_gzlane.h)
 constexpr uint32_t ROUND = 64;           // list entries per round
 constexpr uint32_t STG = 1024;           // output symbols per round (staging buffer)
 constexpr uint32_t RING = 512;           // dwords of input held in LDS
 
-// literal/length entry: bits 0-7 bits to drop; bit 31 set = not a literal (one signed compare in the walk).
-//   literal:  bits 8-15 first byte, 16-23 second byte, bit 24 = two literals
-//   other:    bits 29-30 kind; a length: bits 24-26 extra bits, bits 8-15 base - 3
-constexpr uint32_t E_OTHER = 1u << 31, E_DOUBLE = 1u << 24;
-constexpr uint32_t K_MASK = 3u << 29, K_LENGTH = 0u << 29, K_EOB = 1u << 29, K_LONG = 2u << 29, K_INVALID = 3u << 29;
-// distance entry: bits 0-7 bits to drop; bit 31 set = long code (bit 30 clear) or invalid (bit 30 set); bits 24-27 extra bits, 8-22 base - 1
-constexpr uint32_t D_INVALID = 1u << 30;
-// list entry of a match: bit 31 | (length - 3) | (distance - 1) << 9; of literals: the table entry itself
 constexpr uint32_t PENDING = 0x4000;     // staging value: reference to another staging slot (bit 15 clear, bit 14 set)
 
-struct Canon { uint16_t first[16], cnt[16], off[16]; };
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // the first-level tables of the block being walked: entry i of a table is lane i & 63 of element i >> 6 (in the walk's assembly: v[104:119], v[120:127])
@@ -108,27 +101,6 @@ struct BitRd {
         refill();
     }
 };
-
-__device__ __forceinline__ uint32_t lit_entry(uint32_t s)
-{
-    if (s < 256) return s << 8;
-    if (s == 256) return E_OTHER | K_EOB;
-    if (s < 286) {
-        const uint32_t k = s - 257;
-        uint32_t extra = 0, base = 3 + k;
-        if (k == 28) base = 258;
-        else if (k >= 8) { extra = (k >> 2) - 1; base = 3 + ((4 + (k & 3)) << extra); }
-        return E_OTHER | K_LENGTH | (extra << 24) | ((base - 3) << 8);      // the base is stored less 3 (what the list entry holds)
-    }
-    return E_OTHER | K_INVALID;
-}
-__device__ __forceinline__ uint32_t dist_entry(uint32_t d)
-{
-    if (d >= 30) return E_OTHER | D_INVALID;
-    uint32_t extra = 0, base = 1 + d;
-    if (d >= 4) { extra = (d >> 1) - 1; base = 1 + ((2 + (d & 1)) << extra); }
-    return (extra << 24) | ((base - 1) << 8);                                     // the base is stored less 1
-}
 
 // Canonical Huffman decode table from code lengths, by the whole wavefront.  KIND 0: precode, 1: literal/length, 2: distance.
 // Returns the Kraft sum in units of 2^-15 (32768 = complete; more = over-subscribed, nothing is built); *n_codes = codes in use.
@@ -201,7 +173,7 @@ __device__ __forceinline__ void pair_literals(uint32_t *lit, uint32_t lane)
             if (l1 < (uint32_t)LIT_BITS) {
                 const uint32_t e2 = lit[i >> l1];
                 if (!(e2 & E_OTHER) && l1 + (e2 & 255) <= (uint32_t)LIT_BITS)
-                    ne[j] = (l1 + (e2 & 255)) | E_DOUBLE | (e1 & 0xFF00u) | ((e2 & 0xFF00u) << 8);
+                    ne[j] = (l1 + (e2 & 255)) | E_DOUBLE | (l1 << 25) | (e1 & 0xFF00u) | ((e2 & 0xFF00u) << 8);
             }
         }
     }
@@ -215,7 +187,8 @@ __device__ const uint8_t PRE_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 
 // Dynamic block header behind the three type bits: the code lengths of both alphabets into L.lens (uniform code; only the
 // LDS stores are left to lane 0).  strict: only what a compressor emits (a complete precode).
-__device__ __forceinline__ bool read_code_lengths(Lds &L, BitRd &rd, bool strict, uint32_t lane, uint32_t &hlit, uint32_t &hdist)
+template <class LDS>
+__device__ __forceinline__ bool read_code_lengths(LDS &L, BitRd &rd, bool strict, uint32_t lane, uint32_t &hlit, uint32_t &hdist)
 {
     rd.top_up(lane);
     rd.refill();
@@ -265,7 +238,8 @@ __device__ __forceinline__ bool read_code_lengths(Lds &L, BitRd &rd, bool strict
 }
 
 // both decode tables from L.lens[0 .. hlit + hdist)
-__device__ __forceinline__ bool build_tables(Lds &L, uint32_t hlit, uint32_t hdist, bool strict, uint32_t lane)
+template <class LDS>
+__device__ __forceinline__ bool build_tables(LDS &L, uint32_t hlit, uint32_t hdist, bool strict, uint32_t lane)
 {
     uint32_t kraft = build_table<LIT_BITS, 1>(L.lens, hlit, L.lit, L.sorted_lit, L.clit, lane, nullptr);
     if (kraft > 32768 || (strict && kraft != 32768)) return false;
@@ -739,6 +713,302 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
     }
 }
 
+// ------------------------------------------------------------------------------------------ the lane-parallel decoder
+// gz_decode_kernel above walks a block's codes on ONE lane (290 cycles a code, and a CU's instruction issue is what its sixteen
+// wavefronts share: the chip full, it streams 18-24 GB/s of text).  This kernel keeps everything around the walk -- one wavefront
+// per chunk, the search for a block start, the header and table construction by all lanes, 16-bit symbols with markers -- and
+// replaces the walk and the expansion:
+//   * THE WALK IS DONE BY ALL 64 LANES AT ONCE.  A step covers 64 spans of SPAN bits of the block; lane i walks the codes that
+//     start in span i (mf_gzlane.h), from where lane i - 1 stopped.  That it has to guess at first (the span's border); a Huffman
+//     stream decoded from a wrong offset falls into step with the true one within a few dozen codes, so nearly every lane ENDS at
+//     the right bit all the same.  Lanes whose start was wrong walk again from their predecessor's end, until no start moves
+//     (measured on FASTQ at gzip -1 / -6 / -9: one re-walk, rarely two; tools/gzlane_model.cpp).  Lane 0 starts at the true
+//     position, so by induction every lane of the chain holds true codes.  Each lane leaves its codes as list entries in its own
+//     stretch of a scratch list in global memory (16-byte stores of four entries).
+//   * THE EXPANSION takes the lists lane by lane, RN entries a round (twice the old round, from a list that is already there: its
+//     loads are issued ahead), every output position of the round finding its entry by binary search in LDS, as before.
+// The tables stay in LDS (the lanes index them on their own); ring, precode and code-length arrays share their bytes with the
+// round's list and staging buffer.
+constexpr uint32_t SPAN = 2048;          // bits of the block per lane and step
+constexpr uint32_t LCAP = 1024;          // list entries a lane may leave per step (a code has at least one bit, a double literal entry two)
+constexpr uint32_t RN = 128;             // list entries per round of the expansion
+constexpr uint32_t STG2 = 2048;          // output symbols per round (staging buffer)
+constexpr uint32_t MAX_REWALK = 6;       // re-walk rounds per step; what is not chained by then waits for the next step
+struct Lds2 {
+    uint32_t lit[LIT_SIZE]; uint32_t dist[DIST_SIZE];
+    union {
+        struct { uint32_t ring[RING]; uint32_t pre[PRE_SIZE]; uint8_t lens[328]; uint8_t plens[24]; };      // between blocks: the header reader's
+        struct { uint32_t sym[RN]; uint16_t soff[RN]; uint16_t stg[STG2]; };                                 // inside a block: the expansion's
+    };
+    uint16_t sorted_lit[288], sorted_dist[32];
+    Canon clit, cdist;
+};
+
+// dword w of the stream, counted from the chunk's origin; every lane reads its own
+struct LaneIn {
+    const uint32_t *words; uint64_t origin_dw, wmask, max_dw;
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { uint64_t i = origin_dw + w; i = i < max_dw ? i : max_dw; return words[i & wmask]; }
+};
+// a lane's list entries: four at a time, one 16-byte store
+struct LaneOut {
+    uint32_t *base; uint32_t n, e0, e1, e2;
+    __device__ __forceinline__ void put(uint32_t e)
+    {
+        const uint32_t k = n & 3u;
+        if (k == 3u) { uint4 v; v.x = e0; v.y = e1; v.z = e2; v.w = e; *reinterpret_cast<uint4 *>(base + (n - 3u)) = v; }
+        else if (k == 0u) e0 = e; else if (k == 1u) e1 = e; else e2 = e;
+        n++;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        const uint32_t k = n & 3u, b = n - k;
+        if (k > 0u) base[b] = e0;
+        if (k > 1u) base[b + 1] = e1;
+        if (k > 2u) base[b + 2] = e2;
+    }
+};
+
+// One round of the expansion: up to RN list entries at lst[0 .. n) -> symbols at out[opos ..].  Takes as many entries as fit the
+// staging buffer (at least one); returns their number in `taken` and the number of symbols written.
+__device__ __forceinline__ uint32_t expand2(Lds2 &L, const uint32_t *lst, uint32_t n, uint16_t *out, uint64_t opos, uint32_t lane, uint32_t &taken)
+{
+    constexpr uint32_t K = RN / 64;
+    uint32_t s[K], cnt[K], off[K];
+#pragma unroll
+    for (uint32_t t = 0; t < K; t++) { const uint32_t j = t * 64 + lane; s[t] = j < n ? lst[j] : 0u; }
+    uint32_t run = 0, n_ok = 0;
+    uint64_t any_match = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < K; t++) {
+        const uint32_t j = t * 64 + lane;
+        cnt[t] = j < n ? ((s[t] >> 31) ? (s[t] & 0x1FFu) + 3 : 1 + ((s[t] >> 24) & 1u)) : 0;
+        uint32_t inc = cnt[t];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += u; }
+        inc += run;
+        off[t] = inc - cnt[t];
+        run = __shfl(inc, 63);
+        // entries whose symbols fit the staging buffer (a prefix of the list: the sums are monotone)
+        const uint64_t okm = __ballot(j < n && inc <= STG2);
+        n_ok += (uint32_t)__popcll(okm);
+        any_match |= __ballot(j < n && inc <= STG2 && (s[t] >> 31));
+    }
+    taken = n_ok;
+    // symbols of the entries taken
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < K; t++) { const uint32_t j = t * 64 + lane; const uint32_t e = j < n_ok ? off[t] + cnt[t] : 0; uint32_t m = e; for (int d = 32; d; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d)); tot = max(tot, m); }
+    if (any_match == 0) {                        // literals only: every entry stores its one or two symbols itself
+#pragma unroll
+        for (uint32_t t = 0; t < K; t++) {
+            const uint32_t j = t * 64 + lane;
+            if (j < n_ok) { out[opos + off[t]] = (uint16_t)((s[t] >> 8) & 0xFFu); if (cnt[t] == 2) out[opos + off[t] + 1] = (uint16_t)((s[t] >> 16) & 0xFFu); }
+        }
+        return tot;
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < K; t++) { const uint32_t j = t * 64 + lane; L.sym[j] = s[t]; L.soff[j] = (uint16_t)(j < n_ok ? off[t] : 0xFFFFu); }
+    __syncthreads();
+    bool pending = false;
+    for (uint32_t p = lane; p < tot; p += 64) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = RN / 2; step; step >>= 1) { const uint32_t j = lo + step; if (j < n_ok && L.soff[j] <= p) lo = j; }
+        const uint32_t e = L.sym[lo], o = L.soff[lo];
+        uint32_t v;
+        if (!(e >> 31)) v = (p == o ? (e >> 8) : (e >> 16)) & 0xFFu;
+        else {
+            const uint32_t len = (e & 0x1FFu) + 3, D = ((e >> 9) & 0x7FFFu) + 1, t = p - o;
+            const uint32_t r = D < len ? t % D : t;
+            const int32_t srel = (int32_t)o - (int32_t)D + (int32_t)r;
+            if (srel >= 0) { v = PENDING | (uint32_t)srel; pending = true; }
+            else {
+                const int64_t g = (int64_t)opos + srel;
+                v = g >= 0 ? out[g] : (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g));
+            }
+        }
+        L.stg[p] = (uint16_t)v;
+    }
+    __syncthreads();
+    while (__any(pending)) {                     // references into the round itself: they point strictly backwards
+        pending = false;
+        for (uint32_t p = lane; p < tot; p += 64) {
+            const uint32_t v = L.stg[p];
+            if ((v & 0xC000u) == PENDING) {
+                const uint32_t w = L.stg[v & 0x3FFFu];
+                if ((w & 0xC000u) == PENDING) pending = true; else L.stg[p] = (uint16_t)w;
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t p = lane; p < tot; p += 64) out[opos + p] = L.stg[p];
+    __syncthreads();
+    return tot;
+}
+
+enum BlockEnd : uint32_t { B_EOB = 0, B_ERROR = 1, B_OVERFLOW = 2, B_PAST_SIZE = 3, B_PAST_LIMIT = 4 };
+
+// The codes of one block (tables built in L), from bit `from` (absolute) on, by all lanes.  On B_EOB `from` is the bit behind the
+// end-of-block code and opos the symbols written.
+__device__ __forceinline__ uint32_t decode_block(Lds2 &L, const LaneIn &in, uint64_t origin_bits, uint64_t &from, uint64_t size_bits, uint64_t limit_bits,
+                                                  uint16_t *out, uint64_t &opos, uint64_t sym_cap, uint32_t *lst, uint32_t lane)
+{
+    uint32_t b_rel = (uint32_t)(from - origin_bits);
+    for (;;) {
+        uint32_t start = b_rel + lane * SPAN;
+        const uint32_t stop = b_rel + (lane + 1) * SPAN;
+        LaneOut lo; lo.base = lst + lane * LCAP; lo.n = 0; lo.e0 = lo.e1 = lo.e2 = 0;
+        Span sp; sp.end = start; sp.n_code = 0; sp.n_sym = 0; sp.flags = 0;
+        bool need = true;                       // this lane has to walk (again): its start has moved
+        for (uint32_t it = 0;; it++) {
+            if (need) {
+                lo.n = 0;
+                sp = walk_span(L.lit, L.dist, L.clit, L.cdist, L.sorted_lit, L.sorted_dist, in, start, stop, LCAP, lo);
+                lo.flush();
+            }
+            const uint32_t prev_end = __shfl_up(sp.end, 1), prev_flags = __shfl_up(sp.flags, 1);
+            need = lane > 0 && !(prev_flags & (SP_EOB | SP_ERR)) && prev_end != start;
+            if (!__any(need) || it == MAX_REWALK) break;       // (a lane that still needs a walk keeps its old start and list: it is not part of the chain below)
+            if (need) start = prev_end;
+        }
+        // the chain: lanes 0 .. V - 1 each start where the lane before stopped
+        const uint32_t prev_end = __shfl_up(sp.end, 1), prev_flags = __shfl_up(sp.flags, 1);
+        const bool good = lane == 0 || (!(prev_flags & (SP_EOB | SP_ERR)) && prev_end == start);
+        const uint64_t bad = ~__ballot(good);
+        const uint32_t V = bad ? (uint32_t)__ffsll((unsigned long long)bad) - 1 : 64;
+        if (__any(lane < V && (sp.flags & SP_ERR))) return B_ERROR;
+        const uint32_t end_rel = (uint32_t)__shfl(sp.end, (int)V - 1), end_flags = (uint32_t)__shfl(sp.flags, (int)V - 1);
+        if (origin_bits + end_rel > size_bits) return B_PAST_SIZE;
+        if (origin_bits + end_rel > limit_bits) return B_PAST_LIMIT;
+        uint32_t tot = lane < V ? sp.n_sym : 0;
+        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d);
+        if (opos + tot > sym_cap) return B_OVERFLOW;
+        __threadfence_block();                   // the lists are read by other lanes than the ones that wrote them
+        __syncthreads();
+        for (uint32_t i = 0; i < V; i++) {
+            const uint32_t ni = (uint32_t)__shfl(sp.n_code, (int)i);
+            const uint32_t *li = lst + i * LCAP;
+            for (uint32_t k0 = 0; k0 < ni;) {
+                uint32_t taken = 0;
+                opos += expand2(L, li + k0, ni - k0 < RN ? ni - k0 : RN, out, opos, lane, taken);
+                k0 += taken;
+            }
+        }
+        b_rel = end_rel;
+        if (end_flags & SP_EOB) { from = origin_bits + end_rel; return B_EOB; }
+    }
+}
+
+__global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uint64_t ring_mask, uint64_t size, uint64_t limit_bytes, uint64_t base_byte,
+                                                        uint64_t chunk_bytes, uint32_t chunk_lo, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *sym,
+                                                        uint64_t sym_cap, GzChunk *chunks, uint32_t *lists)
+{
+    __shared__ Lds2 L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = chunk_lo + blockIdx.x;
+    uint16_t *out = sym + (uint64_t)blockIdx.x * sym_cap;
+    uint32_t *lst = lists + (uint64_t)blockIdx.x * (64 * LCAP);
+    const uint64_t size_bits = size * 8, limit_bits = limit_bytes * 8;
+    const uint64_t nominal = (base_byte + (uint64_t)c * chunk_bytes) * 8, stop_bit = nominal + chunk_bytes * 8;
+    const uint64_t search_end = stop_bit < size_bits ? stop_bit : size_bits;
+    GzChunk res; res.start_bit = 0; res.end_bit = 0; res.n_sym = 0; res.status = GZ_NONE;
+    BitRd rd; rd.base = reinterpret_cast<const uint4 *>(data); rd.vmax = (size + 48) / 16;      // readable (and zero) up to size + 64
+    rd.vmask = ring_mask >> 4;
+    rd.origin_v = (c == exact_chunk && exact_bit < nominal ? exact_bit : nominal) >> 7;
+    rd.ring = L.ring; rd.rd_dw = 0; rd.ring_hi = 0; rd.nd = 0; rd.bb = 0; rd.bc = 0;
+    LaneIn in; in.words = reinterpret_cast<const uint32_t *>(data); in.origin_dw = rd.origin_v * 4; in.wmask = ring_mask >> 2; in.max_dw = rd.vmax * 4 + 3;
+    const uint64_t origin_bits = rd.origin_v * 128;
+    bool searching = c != exact_chunk;
+    Search S; S.b0 = nominal - 64 * SEARCH_W;
+    for (int j = 0; j < SEARCH_W; j++) S.mask[j] = 0;
+    uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
+    uint32_t status = GZ_NONE;
+    if (!searching) rd.seek(start, lane);
+    else if (nominal >= size_bits) { if (lane == 0) chunks[c] = res; return; }
+    uint64_t behind_from = ~0ull;                   // the first block boundary behind the chunk's own range
+    uint32_t why = 0;                               // what stopped a decode that failed (reported in n_sym of a GZ_FAILED chunk)
+    for (;;) {
+        uint32_t final = 0, type = 2;
+        bool strict = false;
+        why = 0;
+        if (searching) {
+            start = next_candidate(S, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, search_end, size_bits, lane);
+            if (start == ~0ull) { status = GZ_NONE; break; }
+            rd.seek(start + 3, lane);
+            strict = true; opos = 0; blk_pos = start; blk_opos = 0;
+        } else {
+            blk_pos = rd.bitpos(); blk_opos = opos;
+            // (the rules of gz_decode_kernel: behind its range a chunk stops in front of a non-final dynamic block; stored and fixed
+            // blocks and the member's final block are decoded here too, for at most one chunk's worth of input behind the range)
+            const bool behind = blk_pos >= stop_bit;
+            if (behind && behind_from == ~0ull) behind_from = blk_pos;
+            if (behind && (blk_pos + 3 > size_bits || blk_pos - behind_from >= chunk_bytes * 8)) { status = GZ_AT_BOUNDARY; break; }
+            if (blk_pos + 3 > size_bits) why = 1;
+            else {
+                rd.top_up(lane);
+                rd.refill(); final = rd.peek(1); type = rd.peek(3) >> 1;
+                if (behind && !final && type == 2) { status = GZ_AT_BOUNDARY; break; }
+                rd.drop(3);
+                if (type == 3) why = 2;
+            }
+            if (!why && type == 0) {               // stored block: byte aligned LEN, ~LEN, then the bytes
+                rd.drop(rd.bc & 7); rd.refill();
+                const uint32_t len = rd.peek(16); rd.drop(16); rd.refill();
+                const uint32_t nlen = rd.peek(16); rd.drop(16);
+                const uint64_t byte = rd.bitpos() >> 3;
+                if ((len ^ nlen) != 0xFFFFu || byte + len > size) why = 3;
+                else if (byte + len > limit_bytes) why = 8;
+                else {
+                    if (opos + len > sym_cap) { status = GZ_OVERFLOW; break; }
+                    for (uint32_t i = lane; i < len; i += 64) out[opos + i] = data[(byte + i) & ring_mask];
+                    opos += len;
+                    rd.seek((byte + len) * 8, lane);
+                    if (final) { status = GZ_MEMBER_END; break; }
+                    continue;
+                }
+            }
+        }
+        if (!why) {
+            uint32_t hlit = 288, hdist = 32;
+            bool ok = true;
+            if (type == 1) {
+                for (uint32_t i = lane; i < 320; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : (i < 288 ? 8 : 5)));
+                __syncthreads();
+            } else ok = read_code_lengths(L, rd, strict, lane, hlit, hdist);
+            if (!ok) why = 4;
+            else if (!build_tables(L, hlit, hdist, strict, lane)) why = 5;
+            __syncthreads();
+        }
+        if (!why) {
+            searching = false;
+            uint64_t at = rd.bitpos();
+            const uint32_t e = decode_block(L, in, origin_bits, at, size_bits, limit_bits, out, opos, sym_cap, lst, lane);
+            __syncthreads();
+            rd.ring_hi = 0; rd.rd_dw = 0;            // (the ring's bytes were the expansion's in between: whoever seeks next loads it again)
+            if (e == B_OVERFLOW) { status = GZ_OVERFLOW; break; }
+            if (e == B_ERROR) why = 6; else if (e == B_PAST_SIZE) why = 7; else if (e == B_PAST_LIMIT) why = 8;
+            if (!why) rd.seek(at, lane);
+        }
+        if (why) {
+            // not deflate data.  From a speculative start that only says the candidate was false: the search goes on behind it
+            // (S still holds the rest of the candidates of its step)
+            if (c != exact_chunk && why != 8) { searching = true; continue; }
+            status = GZ_FAILED; break;
+        }
+        if (final) { status = GZ_MEMBER_END; break; }
+    }
+    if (lane == 0) {
+        res.start_bit = start;
+        if (status == GZ_OVERFLOW) { res.end_bit = blk_pos; res.n_sym = (uint32_t)blk_opos; }
+        else if (status == GZ_AT_BOUNDARY) { res.end_bit = blk_pos; res.n_sym = (uint32_t)opos; }
+        else { res.end_bit = rd.bitpos(); res.n_sym = (uint32_t)opos; }
+        if (status == GZ_NONE) res.n_sym = 0;
+        if (status == GZ_FAILED) res.n_sym = why;
+        res.status = status;
+        chunks[c] = res;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------- chain
 // One workgroup walks the chunks in stream order.  The last 32 KiB of accepted text live in LDS (two buffers: the tail of a
 // chunk is resolved against the window in front of the chunk while the window behind it is being written).  The 64 KiB are why
@@ -913,15 +1183,27 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *text, uint64
 
 } // namespace
 
+// scratch for the lane-parallel decoder: 64 lanes x LCAP list entries per chunk of a launch
+size_t gz_decode_scratch_bytes(uint32_t n_chunks) { return (size_t)n_chunks * 64 * LCAP * sizeof(uint32_t); }
+bool gz_decode_serial()       // MF_GZDEV_KERNEL=serial: the one-lane walk of round 3 (A/B runs); default: the lane-parallel kernel
+{
+    static const bool serial = [] { const char *v = getenv("MF_GZDEV_KERNEL"); return v && strcmp(v, "serial") == 0; }();
+    return serial;
+}
+
 hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t size, uint64_t limit_bytes, uint64_t base_byte, uint64_t chunk_bytes,
                             uint32_t chunk_lo, uint32_t n_chunks, uint32_t exact_chunk, uint64_t exact_bit, uint16_t *d_sym, uint64_t sym_cap,
-                            GzChunk *d_chunks, hipStream_t st)
+                            GzChunk *d_chunks, uint32_t *d_scratch, hipStream_t st)
 {
     if (!n_chunks) return hipSuccess;
     if (ring_bytes && ((ring_bytes & (ring_bytes - 1)) || ring_bytes < 4096)) return hipErrorInvalidValue;
     const uint64_t ring_mask = ring_bytes ? ring_bytes - 1 : ~0ull;
-    hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, ring_mask, size, limit_bytes < size ? limit_bytes : size, base_byte, chunk_bytes,
-                       chunk_lo, exact_chunk, exact_bit, d_sym, sym_cap, d_chunks);
+    if (gz_decode_serial() || !d_scratch)
+        hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, ring_mask, size, limit_bytes < size ? limit_bytes : size, base_byte, chunk_bytes,
+                           chunk_lo, exact_chunk, exact_bit, d_sym, sym_cap, d_chunks);
+    else
+        hipLaunchKernelGGL(gz_decode2_kernel, dim3(n_chunks), dim3(64), 0, st, d_data, ring_mask, size, limit_bytes < size ? limit_bytes : size, base_byte, chunk_bytes,
+                           chunk_lo, exact_chunk, exact_bit, d_sym, sym_cap, d_chunks, d_scratch);
     return hipGetLastError();
 }
 

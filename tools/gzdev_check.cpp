@@ -61,12 +61,14 @@ int main(int argc, char **argv)
     CK(hipMalloc(&d_data, size + 64)); CK(hipMemcpy(d_data, gz.data(), size + 64, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_sym, (size_t)n_chunks * cap * 2));
     CK(hipMalloc(&d_chunks, n_chunks * sizeof(mf::GzChunk)));
+    uint32_t *d_scratch = nullptr;          // the lane-parallel kernel's code lists (MF_GZDEV_KERNEL=serial: the one-lane walk)
+    if (!mf::gz_decode_serial()) CK(hipMalloc(&d_scratch, mf::gz_decode_scratch_bytes(n_chunks)));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     for (int r = 0; r < reps; r++) {
         CK(hipMemset(d_chunks, 0, n_chunks * sizeof(mf::GzChunk)));
         CK(hipEventRecord(e0, 0));
-        CK(mf::launch_gz_decode(d_data, 0, size, size, base_byte, chunk, 0, n_chunks, 0, (uint64_t)base_byte * 8, d_sym, cap, d_chunks, 0));
+        CK(mf::launch_gz_decode(d_data, 0, size, size, base_byte, chunk, 0, n_chunks, 0, (uint64_t)base_byte * 8, d_sym, cap, d_chunks, d_scratch, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
