@@ -210,6 +210,26 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2,
                              const int *devices, int n_devices,
                              uint64_t *kept, uint64_t *total);
 
+/* What the calling thread's last successful mf_filter_fastq_files / _on call did (ABI 3).  path: which
+ * of the library's two ingest paths took the input. */
+enum { MF_INGEST_PATH_HOST = 0, MF_INGEST_PATH_DEVICE = 1 };
+typedef struct {
+    int32_t  path, n_devices, consumers, reserved;
+    uint64_t input_bytes;          /* bytes of the input files as they lie (compressed, if .gz) -- device path only */
+    uint64_t text_bytes;           /* bytes of FASTQ text they hold -- device path only */
+    uint64_t records;              /* FASTQ records cut from it, both mates */
+    double   seconds;              /* wall time of the call */
+    double   decode_busy_seconds;  /* time with at least one inflate kernel running, summed over devices and mates (0: no .gz) */
+    uint64_t pool_bytes_peak;      /* this call's device buffers at most, on any one device */
+    uint64_t device_bytes_peak;    /* everything in use on a device at most (hipMemGetInfo after each piece) */
+    uint64_t chunks, chunks_linked, gaps, gap_bytes;   /* speculative chunks; those the link step took; stretches (bytes of text) the host bridged */
+} mf_ingest_stats_t;
+int mf_last_ingest_stats(mf_ingest_stats_t *out);
+
+/* Host-to-device copy rate of this box in GB/s (pinned memory, `bytes` per copy, best of `reps`): the
+ * roof of the device ingest path, whose input goes up over PCIe as it lies on disk. */
+int mf_h2d_bandwidth(int device, size_t bytes, int reps, double *gb_per_s);
+
 /* ---- FASTQ quality filter: the reference's `filter/filter_v2` (filter/filter_bin/src/main.rs:14-329),
  * the stage that runs on the raw reads before this path (SURVEY.md 8f "next" #2).  Same rules, same
  * output bytes: cut [start, end), drop reads with more than `ns` 'N' or with at least

@@ -12,6 +12,7 @@
 #include "mf_devingest.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -848,6 +849,10 @@ int mf_filter_packed(const mf_kmerset *ks, int device, const uint32_t *words, co
 }
 
 // ------------------------------------------------------------- file level
+// what the calling thread's last file-level call did (mf_last_ingest_stats)
+static thread_local mf_ingest_stats_t t_ingest_stats;
+static thread_local bool t_ingest_stats_valid = false;
+
 // the file-level call on a list of (logical) devices
 static int filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2,
                                  uint32_t threshold, int pair_mode, const int *devices, int n_devices, uint64_t *kept, uint64_t *total)
@@ -873,9 +878,19 @@ static int filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq
         const char *ing = getenv("MF_INGEST");
         const bool force = ing && strcmp(ing, "device") == 0, any_gz = has_gz_ext(fq1) || (fq2 && has_gz_ext(fq2));
         if (!(ing && strcmp(ing, "host") == 0) && (force || any_gz)) {
-            std::string derr;
-            const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, devices, n_devices, kept, total, derr);
-            if (drc == MF_OK) return MF_OK;
+            std::string derr; IngestStats is;
+            const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, devices, n_devices, kept, total, derr, &is);
+            if (drc == MF_OK) {
+                mf_ingest_stats_t &o = t_ingest_stats;
+                memset(&o, 0, sizeof o);
+                o.path = MF_INGEST_PATH_DEVICE; o.n_devices = is.n_devices; o.consumers = is.consumers;
+                o.input_bytes = is.input_bytes; o.text_bytes = is.text_bytes; o.records = is.records;
+                o.seconds = is.seconds; o.decode_busy_seconds = is.decode_busy_seconds;
+                o.pool_bytes_peak = is.pool_bytes_peak; o.device_bytes_peak = is.device_bytes_peak;
+                o.chunks = is.chunks; o.chunks_linked = is.chunks_linked; o.gaps = is.gaps; o.gap_bytes = is.gap_bytes;
+                t_ingest_stats_valid = true;
+                return MF_OK;
+            }
             if (drc != MF_DEVINGEST_DECLINED) return fail(drc, "%s", derr.c_str());
             if (getenv("MF_PIPE_TIMING")) fprintf(stderr, "[mf device ingest] declined%s%s: the host pipeline takes the input\n", derr.empty() ? "" : ": ", derr.c_str());
         }
@@ -920,7 +935,15 @@ static int filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq
         return rc;
     };
     PipelineStats ps; std::string perr;
+    const auto t_pipe0 = std::chrono::steady_clock::now();
     const int rc = run_fastq_pipeline(fq1, fq2, out1, out2, pair_mode == MF_PAIR_BOTH, n_workers, pack_threads, batch_reads, fn, ps, perr);
+    {
+        mf_ingest_stats_t &o = t_ingest_stats;
+        memset(&o, 0, sizeof o);
+        o.path = MF_INGEST_PATH_HOST; o.n_devices = n_devices; o.records = ps.total * (fq2 ? 2 : 1);
+        o.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pipe0).count();
+        t_ingest_stats_valid = rc == MF_OK;
+    }
     {
         const auto t0 = std::chrono::steady_clock::now();
         for (mf_reads *a : arena) reads_release(a);
@@ -949,6 +972,39 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
                              uint32_t threshold, int pair_mode, const int *devices, int n_devices, uint64_t *kept, uint64_t *total)
 {
     return filter_fastq_files_on(ks, fq1, fq2, out1, out2, threshold, pair_mode, devices, n_devices, kept, total);
+}
+
+int mf_last_ingest_stats(mf_ingest_stats_t *out)
+{
+    if (!out) return fail(MF_E_ARG, "NULL argument");
+    if (!t_ingest_stats_valid) return fail(MF_E_ARG, "no file-level call has succeeded on this thread");
+    *out = t_ingest_stats;
+    return MF_OK;
+}
+
+// host-to-device copy rate of this box: `bytes` from pinned memory to device memory, the best of `reps` (the roof of the device ingest
+// path, which sends the input file's bytes up as they are)
+int mf_h2d_bandwidth(int device, size_t bytes, int reps, double *gb_per_s)
+{
+    if (!gb_per_s || !bytes || reps < 1) return fail(MF_E_ARG, "bad argument");
+    DevCtx *ctx; int rc = get_ctx(device, &ctx); if (rc) return rc;
+    void *h = nullptr, *d = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Free { void *&h, *&d; hipEvent_t &e0, &e1; ~Free() { if (h) (void)hipHostFree(h); if (d) (void)hipFree(d); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); } } fr{h, d, e0, e1};
+    HIPCHK(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    memset(h, 0x5A, bytes);
+    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    double best = 0;
+    for (int i = 0; i <= reps; i++) {                     // (the first copy is a warm-up)
+        HIPCHK(hipEventRecord(e0, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (i && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    *gb_per_s = best;
+    return MF_OK;
 }
 
 // ------------------------------------------------------------- quality filter

@@ -347,16 +347,20 @@ private:
         for (size_t i = 0; i < np && !stop_; i++) {
             const size_t off = i * piece_, len = std::min(piece_, n_ - off);
             if (!want_[i]) { { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; } cv_.notify_all(); continue; }
+            const double t_a = now_s();
             {   // not more than a ring's length ahead of what has been linked
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || off + len + 256 <= low_ + ring_; });
                 if (stop_) return;
             }
+            const double t_b = now_s();
             const int b = (int)(i & 1);
             for (size_t l = 0; l < lanes_.size(); l++)          // the copies that read this staging buffer are done
                 if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(); return; } }
             stage_used_[b] = 0;
+            const double t_c = now_s();
             if (!stage_.read(b, off, len)) { fail_(); return; }
+            t_ring_ += t_b - t_a; t_copy_wait_ += t_c - t_b; t_read_ += now_s() - t_c;
             size_t total = len;
             if (off + len == n_) { memset(stage_.buf[b] + len, 0, 256); total += 256; }          // readable and zero behind the last byte
             for (size_t l = 0; l < lanes_.size(); l++) {
@@ -378,6 +382,9 @@ private:
         for (auto &L : lanes_) { if (hipSetDevice(L.dev) == hipSuccess) (void)hipStreamSynchronize(L.st); }
     }
     void fail_() { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; } cv_.notify_all(); }
+public:
+    double t_ring_ = 0, t_copy_wait_ = 0, t_read_ = 0;          // the uploader thread's time: waiting for room in the ring, for the copy out of a staging buffer, reading the file
+private:
     size_t n_ = 0, ring_ = 0, piece_ = 0;
     std::vector<Lane> lanes_; std::vector<uint64_t> want_;
     Stager stage_; uint64_t stage_used_[2] = {0, 0};
@@ -398,9 +405,10 @@ public:
             for (auto &s : L.streams->sd) if (s) (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(L.streams->link); (void)hipStreamSynchronize(L.streams->rest); (void)hipStreamSynchronize(L.streams->copy);
             if (L.ev_link) (void)hipEventDestroy(L.ev_link);
+            if (L.ev_base) (void)hipEventDestroy(L.ev_base);
         }
-        for (auto &S : slabs_) if (S->ev) { (void)hipSetDevice(lanes_[S->lane].dev); (void)hipEventDestroy(S->ev); }
-        if (pend_slab_ && pend_slab_->ev) { (void)hipSetDevice(lanes_[pend_slab_->lane].dev); (void)hipEventDestroy(pend_slab_->ev); }
+        for (auto &S : slabs_) { (void)hipSetDevice(lanes_[S->lane].dev); if (S->ev) (void)hipEventDestroy(S->ev); if (S->ev0) (void)hipEventDestroy(S->ev0); }
+        if (pend_slab_) { (void)hipSetDevice(lanes_[pend_slab_->lane].dev); if (pend_slab_->ev) (void)hipEventDestroy(pend_slab_->ev); if (pend_slab_->ev0) (void)hipEventDestroy(pend_slab_->ev0); }
         slabs_.clear(); pend_slab_.reset(); pend_.buf.reset(); cur_buf_.reset();
         for (auto &L : lanes_) {
             L.ring.release(); L.d_chunks.release(); L.d_out_off.release(); L.d_chain.release(); L.d_crc.release();
@@ -419,7 +427,9 @@ public:
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
         // chunks: large enough that the serial link step (a fixed cost per chunk) stays small, small enough that a file keeps the chip busy
-        size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)256 << 10) & ~(size_t)4095;
+        // (the link step costs ~7 us a chunk whatever its size, one chunk after the other: 512 KiB chunks for files of gigabytes -- the
+        // decode kernel runs at the same rate on them, tools/gzdev_check)
+        size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)512 << 10) & ~(size_t)4095;
         chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", dflt);
         if (chunk_ < 1024) chunk_ = 1024;
         cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", std::max<uint64_t>(256, ((uint64_t)128 << 20) / chunk_));
@@ -475,6 +485,7 @@ public:
             L.streams = g_streams.take(L.dev, err);
             if (!L.streams) return MF_E_HIP;
             DCHK(hipEventCreateWithFlags(&L.ev_link, hipEventDisableTiming));
+            DCHK(hipEventCreate(&L.ev_base)); DCHK(hipEventRecord(L.ev_base, L.streams->rest));
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
             DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_out_off.need(L.dev, n_chunks_, false)); DCHK(L.d_chain.need(L.dev, 1, false));
             // (never the null stream: the CU-masked streams are blocking ones, a copy on the null stream would wait for every decode
@@ -519,9 +530,11 @@ public:
         hipStream_t sp = L.streams->link, sr = L.streams->rest;
         if (!S.read_back) {
             TRACE("slab %u..%u on lane %u: waiting for decode", S.lo, S.hi, S.lane);
+            const double tw0 = now_s();
             DCHK(hipStreamWaitEvent(sp, S.ev, 0));
             DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
+            t_wait_decode_ += now_s() - tw0;
             for (;;) {
                 bool overflow = false;
                 for (uint32_t c = S.lo; c < S.hi; c++) if (h_chunks_[c].status == GZ_OVERFLOW) overflow = true;
@@ -549,6 +562,11 @@ public:
             uint32_t mx = 0;
             for (uint32_t c = S.lo; c < S.hi; c++) { const GzChunk &ch = h_chunks_[c]; if (ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END) mx = std::max(mx, ch.n_sym); }
             max_sym_seen_ = std::max(max_sym_seen_, mx);
+            {   // when its decode kernel ran, on the lane's clock (for the busy time of the decoder)
+                float a_ms = 0, b_ms = 0;
+                if (L.ev_base && hipEventElapsedTime(&a_ms, L.ev_base, S.ev0) == hipSuccess && hipEventElapsedTime(&b_ms, L.ev_base, S.ev) == hipSuccess) L.spans.emplace_back((double)a_ms, (double)b_ms);
+                else (void)hipGetLastError();
+            }
             S.read_back = true; S.cur = S.lo;
         }
         // the chunks of this piece: as many of the slab's as make a text buffer of reasonable size
@@ -561,6 +579,7 @@ public:
         }
         const bool last_piece = b == n_chunks_;
         const uint64_t T0 = h_chain_->total;
+        const double tl0 = now_s();
         TRACE("piece: chunks %u..%u, %llu symbols, text from %llu", a, b, (unsigned long long)sum, (unsigned long long)T0);
         rc = new_text(L, T0, sum + ((size_t)1 << 20), err);
         if (rc) return rc;
@@ -609,6 +628,7 @@ public:
             chain_dirty_ = true;
             if (mend) { rc = member_end(S, a, b, max_sym, T0, err); if (rc) return rc; if (done_) break; }
         }
+        t_link_ += now_s() - tl0;
         DCHK(hipEventRecord(L.ev_link, sp)); DCHK(hipStreamWaitEvent(sr, L.ev_link, 0));
         DCHK(launch_gz_resolve(L.d_chunks.p, a, b, sym_a + (size_t)(a - S.lo) * S.cap, S.cap, L.d_out_off.p, cur_buf_->p, T0, max_sym, sr));
         // the rest of the member's CRC over this piece: launched here, taken in by finish_pending
@@ -635,11 +655,28 @@ public:
         DCHK(hipSetDevice(L.dev));
         DCHK(hipStreamSynchronize(L.streams->rest));
         crc_finish(L);
-        if (pend_slab_) { if (pend_slab_->ev) (void)hipEventDestroy(pend_slab_->ev); pend_slab_.reset(); }      // (its symbols are text now)
+        if (pend_slab_) { if (pend_slab_->ev) (void)hipEventDestroy(pend_slab_->ev); if (pend_slab_->ev0) (void)hipEventDestroy(pend_slab_->ev0); pend_slab_.reset(); }      // (its symbols are text now)
         out = std::move(pend_); pend_ = TextPiece(); pending_ = false;
         return MF_OK;
     }
     bool finished() const { return !pending_ && (done_ || (slabs_.empty() && next_plan_ >= plan_.size())); }
+    uint64_t text_bytes() const { return h_chain_ ? h_chain_->total : 0; }
+    // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer and for the piece before to be resolved); the uploader's
+    void producer_times(double &wait_decode, double &link, double &up_ring, double &up_copy, double &up_read) const
+    { wait_decode = t_wait_decode_; link = t_link_; up_ring = up_ ? up_->t_ring_ : 0; up_copy = up_ ? up_->t_copy_wait_ : 0; up_read = up_ ? up_->t_read_ : 0; }
+    // seconds during which at least one decode kernel of this stream was running on a device, summed over the devices
+    double decode_busy_seconds() const
+    {
+        double sum = 0;
+        for (const Lane &L : lanes_) {
+            std::vector<std::pair<double, double>> v = L.spans;
+            std::sort(v.begin(), v.end());
+            double a = 0, b = -1;
+            for (auto &x : v) { if (x.first > b) { if (b > a) sum += b - a; a = x.first; b = x.second; } else if (x.second > b) b = x.second; }
+            if (b > a) sum += b - a;
+        }
+        return sum / 1e3;
+    }
     uint64_t gap_bytes() const { return gap_bytes_; }
     uint64_t gaps() const { return n_gaps_; }
     uint64_t chunks_linked() const { return h_chain_ ? h_chain_->linked : 0; }
@@ -649,13 +686,13 @@ public:
     uint32_t splits() const { return n_splits_; }
 private:
     struct Lane {
-        int dev = 0, ldev = 0; StreamSet *streams = nullptr; hipEvent_t ev_link = nullptr;
+        int dev = 0, ldev = 0; StreamSet *streams = nullptr; hipEvent_t ev_link = nullptr, ev_base = nullptr; std::vector<std::pair<double, double>> spans;
         DevBuf<uint8_t> ring; DevBuf<GzChunk> d_chunks; DevBuf<uint64_t> d_out_off; DevBuf<GzChain> d_chain; DevBuf<uint32_t> d_crc;
         uint32_t *h_crc = nullptr; size_t h_crc_cap = 0; uint64_t crc_n = 0;      // h_crc: pinned
     };
     struct SlabPlan { uint32_t lo, hi, lane; };
     struct Slab {
-        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; DevBuf<uint32_t> lst; size_t cap = 0, limit = 0; hipEvent_t ev = nullptr;     // lst: the lane-parallel kernel's code lists     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
+        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; DevBuf<uint32_t> lst; size_t cap = 0, limit = 0; hipEvent_t ev = nullptr, ev0 = nullptr;     // lst: the lane-parallel kernel's code lists; ev0 / ev: in front of and behind the slab's decode kernel     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
         bool launched = false, read_back = false;
     };
     size_t sym_cap_now() const
@@ -685,10 +722,12 @@ private:
             if (!S.cap) S.cap = sym_cap_now();
             DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
             if (!gz_decode_serial()) DCHK(S.lst.need(L.dev, gz_decode_scratch_bytes(S.hi - S.lo) / 4, false));
-            if (!S.ev) DCHK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+            if (!S.ev) DCHK(hipEventCreate(&S.ev));
+            if (!S.ev0) DCHK(hipEventCreate(&S.ev0));
             hipStream_t st = L.streams->sd[launch_seq_++ % GZ_NSTREAM];
             if (!up_->wait_for(S.lane, st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_IO; }
             S.limit = upto;
+            DCHK(hipEventRecord(S.ev0, st));
             DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, st));
             DCHK(hipEventRecord(S.ev, st));
             S.launched = true;
@@ -800,6 +839,7 @@ private:
     TextPiece pend_; bool pending_ = false; uint32_t pend_lane_ = 0; std::unique_ptr<Slab> pend_slab_;
     bool in_member_ = false, done_ = false;
     uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
+    double t_wait_decode_ = 0, t_link_ = 0;
 };
 
 // ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
@@ -840,7 +880,7 @@ void extract_bits(const std::vector<uint32_t> &v, uint64_t r0, uint64_t n, uint3
 void append_bits(std::vector<uint32_t> &v, uint64_t r0, uint64_t n, const uint32_t *src)
 {
     if (!n) return;
-    v.resize((size_t)((r0 + n + 31) / 32 + 1), 0);
+    { const size_t need = (size_t)((r0 + n + 31) / 32 + 1); if (v.size() < need) v.resize(need, 0); }      // (pieces finish out of order: never shrink)
     const uint64_t nw = (n + 31) / 32, w0 = r0 >> 5; const uint32_t sh = (uint32_t)(r0 & 31);
     for (uint64_t j = 0; j < nw; j++) {
         uint32_t x = src[j];
@@ -855,13 +895,14 @@ struct Batch {
     std::unique_ptr<TextBuf> buf;
     const uint8_t *text = nullptr;       // the first record's header (the piece's text less the carry in front of it)
     DevBuf<uint64_t> line_start;         // offsets from `text`
-    uint64_t n_rec = 0, rec_base = 0;
+    uint64_t n_rec = 0, rec_base = 0, n_text = 0, n_lines = 0;
     int ldev = 0;
+    bool filtered = false;               // its pass bits are in the mate's bitmap
 };
 
-// what the consumer keeps per (mate, device): scratch buffers and the refillable read set
+// what a consumer thread keeps per device: scratch buffers and the refillable read set (its own context of the device: own streams)
 struct DevScratch {
-    int ldev = 0, dev = 0; DevCtx *ctx = nullptr;
+    int ldev = 0, dev = 0, lane = 0; DevCtx *ctx = nullptr;
     mf_reads *reads = nullptr;
     DevBuf<uint32_t> tile_cnt, seq_len, inv_cnt, out_len, minmax, mask; DevBuf<uint64_t> tile_base, scan_tmp, inv_base, out_off, offsets_tmp; DevBuf<uint8_t> d_out;
     // small results the host waits for (counts that size the next buffers), in pinned memory: a copy to pageable memory is a
@@ -869,7 +910,8 @@ struct DevScratch {
     // [7], [8]: values on their way TO the device (the virtual end of an unterminated last line, the start value of min/max)
     uint64_t *h_small = nullptr;
     uint32_t *h_bits = nullptr; size_t h_bits_cap = 0;       // pinned: the pass bits of a piece on their way to the host, the keep mask on its way back
-    ~DevScratch() { reads_release(reads); (void)hipSetDevice(dev); if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); }
+    uint8_t *h_out = nullptr; size_t h_out_cap = 0;          // pinned: survivors on their way to the writer
+    ~DevScratch() { reads_release(reads); (void)hipSetDevice(dev); if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); if (h_out) (void)hipHostFree(h_out); }
 };
 
 struct Mate {
@@ -878,12 +920,15 @@ struct Mate {
     // producer: text pieces in order
     std::thread prod; std::mutex mu; std::condition_variable cv; std::deque<TextPiece> ready; int prod_rc = MF_OK; std::string prod_err; bool prod_done = false;
     std::atomic<bool> stop{false};
-    // consumer
-    uint64_t rec_done = 0; bool eof = false;
+    // consumers (under Ingest::mu): pieces are taken in order; their line index is cut in that order too (the carry links them),
+    // packing and filtering of several pieces run side by side
+    uint64_t taken = 0, a_turn = 0;      // pieces handed to a consumer; the piece whose line index may be cut now
+    bool eof = false;                    // the last piece has been taken
+    uint64_t rec_indexed = 0;            // records of the pieces indexed so far (the next piece's first record)
+    uint64_t rec_filtered = 0;           // ... of the leading pieces whose pass bits are in `bits`
     uint8_t *h_carry = nullptr; size_t h_carry_cap = 0, carry = 0;      // pinned: the head of the record the last piece left unfinished
-    std::deque<std::unique_ptr<Batch>> batches;          // filtered, not yet written
+    std::deque<std::unique_ptr<Batch>> batches;          // indexed, in order; leave when written
     std::vector<uint32_t> bits;                          // pass bits of the whole file so far, one per record
-    std::map<int, std::unique_ptr<DevScratch>> scratch;
     Writer out;
     ~Mate()
     {
@@ -893,7 +938,6 @@ struct Mate {
         if (prod.joinable()) prod.join();
         ready.clear();
         gzs.reset();
-        scratch.clear();
         if (h_carry) (void)hipHostFree(h_carry);
     }
 };
@@ -901,11 +945,17 @@ struct Mate {
 struct Ingest {
     mf_kmerset *ks; uint32_t threshold; bool pair_both; std::vector<int> devices;
     Mate m[2]; int nm = 1;
-    uint64_t kept = 0, total = 0, emitted[2] = {0, 0};
+    uint64_t kept = 0, total = 0;
     bool wrote_any = false;
     size_t mem_used_max = 0;           // device memory in use (everything on the device, this path's buffers and the rest), the largest seen after a piece
     size_t carry_room = (size_t)1 << 20;
-    bool timing = false; double t_wait = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;
+    bool timing = false; double t_wait = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;      // summed over the consumer threads
+    // consumers
+    struct Worker { int id = 0; std::map<int, std::unique_ptr<DevScratch>> scratch; std::thread th; };
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::mutex mu; std::condition_variable cv;          // the state the consumers share (turns, record counts, batches, bitmaps, timing sums)
+    std::mutex emit_mu;                                 // one consumer at a time writes survivors (batches leave in order)
+    bool failed = false; int fail_rc = MF_OK; std::string fail_err;
 
     std::mutex mu_all; std::condition_variable cv_all;          // any producer has something new
     void publish(Mate &M, TextPiece &&t) { { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(std::move(t)); } M.cv.notify_all(); cv_all.notify_all(); }
@@ -970,25 +1020,26 @@ struct Ingest {
         return MF_OK;
     }
 
-    DevScratch *scratch_for(Mate &M, int ldev, std::string &err)
+    DevScratch *scratch_for(Worker &W, int ldev, std::string &err)
     {
-        auto it = M.scratch.find(ldev);
-        if (it != M.scratch.end()) { if (hipSetDevice(it->second->dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; } return it->second.get(); }
+        auto it = W.scratch.find(ldev);
+        if (it != W.scratch.end()) { if (hipSetDevice(it->second->dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; } return it->second.get(); }
         std::unique_ptr<DevScratch> S(new DevScratch());
-        S->ldev = ldev; S->dev = phys(ldev);
-        if (get_ctx(ldev, &S->ctx, 0)) { err = mf_thread_error(); return nullptr; }
+        S->ldev = ldev; S->dev = phys(ldev); S->lane = W.id;
+        if (get_ctx(ldev, &S->ctx, W.id)) { err = mf_thread_error(); return nullptr; }
         if (hipHostMalloc((void **)&S->h_small, 128, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return nullptr; }
         memset(S->h_small, 0, 128);
         DevScratch *p = S.get();
-        M.scratch[ldev] = std::move(S);
+        W.scratch[ldev] = std::move(S);
         return p;
     }
 
-    // lines -> records -> the device's read set -> one filter pass; the pass bits join the mate's file-wide bitmap on the host
-    int ingest(Mate &M, TextPiece &P, std::string &err)
+    // ---- step A of a piece (one piece of a mate at a time, in order): the carry goes in front of its text, lines are counted and
+    // indexed, the records counted; what is behind the last complete record is the next piece's carry.
+    int index_piece(Worker &W, Mate &M, TextPiece &P, std::unique_ptr<Batch> &Bout, std::string &err)
     {
         const double t0 = now_s();
-        DevScratch *Sp = scratch_for(M, P.buf->ldev, err);
+        DevScratch *Sp = scratch_for(W, P.buf->ldev, err);
         if (!Sp) return MF_E_HIP;
         DevScratch &S = *Sp;
         const int dev = S.dev;
@@ -1005,10 +1056,11 @@ struct Ingest {
         }
         if (M.carry) DCHK(hipMemcpyAsync(P.buf->p - M.carry, M.h_carry, M.carry, hipMemcpyHostToDevice, sp));
         std::unique_ptr<Batch> B(new Batch());
-        B->ldev = S.ldev; B->rec_base = M.rec_done;
+        B->ldev = S.ldev;
         B->text = P.buf->p - M.carry;
         const uint8_t *text = B->text;
         const uint64_t n = M.carry + P.len;
+        B->n_text = n;
         const uint64_t tiles = (n + INGEST_TILE - 1) / INGEST_TILE;
         volatile uint64_t *hs = S.h_small;
         uint64_t n_lines = 0, used = 0;
@@ -1027,73 +1079,11 @@ struct Ingest {
             DCHK(B->line_start.need(dev, n_lines + 2, false));
             DCHK(launch_line_starts(text, n, S.tile_base.p, B->line_start.p, sp));
             if (open_line) { S.h_small[7] = n + 1; DCHK(hipMemcpyAsync(B->line_start.p + n_lines, S.h_small + 7, 8, hipMemcpyHostToDevice, sp)); }
-            B->n_rec = n_lines / 4;
-            DCHK(hipMemcpyAsync(S.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));     // (read with the next synchronisation)
-            if (!B->n_rec) DCHK(hipStreamSynchronize(sp));
-        }
-        if (timing) t_index += now_s() - t0;
-        const double t1 = now_s();
-        const uint64_t n_rec = B->n_rec;
-        std::vector<uint32_t> bits;
-        if (n_rec) {
-            const bool first_set = !S.reads;
-            if (!S.reads) { S.reads = new (std::nothrow) mf_reads(); if (!S.reads) { err = "out of memory"; return MF_E_NOMEM; } S.reads->device = S.ldev; S.reads->lane = 0; }
-            mf_reads *R = S.reads;
-            // sequence lengths, the piece's own base offsets
-            DCHK(S.seq_len.need(dev, n_rec)); DCHK(S.minmax.need(dev, 2)); DCHK(S.offsets_tmp.need(dev, n_rec + 1)); DCHK(S.scan_tmp.need(dev, n_rec / 4096 + 4));
-            S.h_small[8] = (uint64_t)0xFFFFFFFFull;                   // {~0u, 0u}
-            DCHK(hipMemcpyAsync(S.minmax.p, S.h_small + 8, 8, hipMemcpyHostToDevice, sp));
-            DCHK(launch_seq_lens(text, B->line_start.p, n_rec, S.seq_len.p, S.minmax.p, sp));
-            DCHK(launch_scan_u32(S.seq_len.p, n_rec, S.offsets_tmp.p, S.scan_tmp.p, sp));
-            DCHK(hipMemcpyAsync(S.h_small + 3, S.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 8, hipMemcpyDeviceToHost, sp));
+            B->n_rec = n_lines / 4; B->n_lines = n_lines;
+            DCHK(hipMemcpyAsync(S.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
-            const uint64_t nb = hs[3]; const uint32_t mm[2] = {(uint32_t)hs[4], (uint32_t)(hs[4] >> 32)};
-            const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
-            const uint64_t n_words = (nb + 15) / 16;
-            // invalid bases are rare (N calls): room for one in 64 bases, more when a piece proves to need it
-            const uint64_t pb = pack_blocks(nb, 0);
-            uint64_t npos_cap = std::max<uint64_t>(nb / 64 + 1024, S.reads->cap_npos / 8);
-            int rc = MF_OK;
-            if (first_set && P.grow > 1.0) {
-                // The read set is refilled piece after piece, and growing it means hipFree -- which waits for every kernel on the
-                // device, the decoder's included.  The first slabs of a .gz are short ones: give the set the size of a full slab's now.
-                const double g = std::min(P.grow, 64.0) * 1.2;
-                const uint64_t nw = (uint64_t)((double)n_words * g), nr = (uint64_t)((double)n_rec * g);
-                rc = reads_reserve(R, true, nw, nr, 0, (uint64_t)((double)npos_cap * g), S.ctx);
-                if (!rc) rc = reads_finish(R, true, nw, nr, nw * 16, 0, 0, S.ctx);        // (no invalid positions: nothing of the empty set is read)
-                if (rc) { err = mf_thread_error(); return rc; }
-                const size_t bw = (size_t)(nr / 32 + 1024);
-                if (bw > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, bw * 4, hipHostMallocDefault)); S.h_bits_cap = bw; }
-            }
-            rc = reads_reserve(R, true, n_words, n_rec, uniform, npos_cap, S.ctx);
-            if (rc) { err = mf_thread_error(); return rc; }
-            if (!uniform) DCHK(hipMemcpyAsync(R->d_offsets, S.offsets_tmp.p, (n_rec + 1) * 8, hipMemcpyDeviceToDevice, sp));
-            uint64_t inv = 0;
-            if (pb) {
-                DCHK(S.inv_cnt.need(dev, pb)); DCHK(S.inv_base.need(dev, pb + 1)); DCHK(S.scan_tmp.need(dev, pb / 4096 + 4));
-                DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, nullptr, nullptr, sp));
-                DCHK(launch_scan_u32(S.inv_cnt.p, pb, S.inv_base.p, S.scan_tmp.p, sp));
-                DCHK(hipMemcpyAsync(S.h_small + 5, S.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
-                DCHK(hipStreamSynchronize(sp));
-                inv = hs[5];
-                if (inv) {
-                    if (inv > npos_cap) { rc = reads_reserve(R, true, n_words, n_rec, uniform, inv, S.ctx); if (rc) { err = mf_thread_error(); return rc; } }     // (words and offsets stay where they are: only the list grows)
-                    DCHK(launch_pack(text, B->line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, S.inv_base.p, R->d_npos, sp));
-                }
-            }
-            if (timing) t_pack += now_s() - t1;
-            const double t2 = now_s();
-            rc = reads_finish(R, true, n_words, n_rec, nb, uniform, inv, S.ctx);
-            if (rc) { err = mf_thread_error(); return rc; }
-            const size_t bw = (size_t)((n_rec + 31) / 32);
-            if (bw + 2 > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (bw + bw / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = bw + bw / 2 + 1024; }
-            rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, S.h_bits, nullptr, 1, nullptr);
-            if (rc) { err = mf_thread_error(); return rc; }
-            append_bits(M.bits, M.rec_done, n_rec, S.h_bits);
-            if (timing) { t_filter += now_s() - t2; size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) == hipSuccess) mem_used_max = std::max(mem_used_max, t - f); }
-        } else if (timing) t_pack += now_s() - t1;
-        used = hs[2];                                                 // (arrived with one of the synchronisations above)
+        }
+        used = hs[2];
         if (used > n) used = n;                                       // (the virtual line end of an unterminated last line)
         const size_t carry = P.last ? 0 : (size_t)(n - used);         // a partial record at the very end is dropped
         if (carry) {
@@ -1107,18 +1097,93 @@ struct Ingest {
             DCHK(hipStreamSynchronize(sp));
         }
         M.carry = carry;
-        M.rec_done += n_rec;
         B->buf = std::move(P.buf);
-        if (n_rec) M.batches.push_back(std::move(B));                 // (a piece without a complete record has nothing to write: its buffer goes back now)
+        Bout = std::move(B);
+        if (timing) { std::lock_guard<std::mutex> lk(mu); t_index += now_s() - t0; }
         return MF_OK;
     }
 
-    // survivors of the first n_emit records of batch B -> the mate's writer
-    int emit(Mate &M, int mi, Batch &B, uint64_t n_emit, std::string &err)
+    // ---- step B (several pieces side by side, each on its consumer's own streams): records -> the consumer's read set -> one
+    // filter pass; the pass bits come back in S.h_bits
+    int filter_piece(Worker &W, Batch &Bt, double grow, std::string &err)
+    {
+        const double t1 = now_s();
+        DevScratch *Sp = scratch_for(W, Bt.ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        volatile uint64_t *hs = S.h_small;
+        const uint8_t *text = Bt.text;
+        const uint64_t n_rec = Bt.n_rec;
+        const bool first_set = !S.reads;
+        if (!S.reads) { S.reads = new (std::nothrow) mf_reads(); if (!S.reads) { err = "out of memory"; return MF_E_NOMEM; } S.reads->device = S.ldev; S.reads->lane = S.lane; }
+        mf_reads *R = S.reads;
+        // sequence lengths, the piece's own base offsets
+        DCHK(S.seq_len.need(dev, n_rec)); DCHK(S.minmax.need(dev, 2)); DCHK(S.offsets_tmp.need(dev, n_rec + 1)); DCHK(S.scan_tmp.need(dev, n_rec / 4096 + 4));
+        S.h_small[8] = (uint64_t)0xFFFFFFFFull;                   // {~0u, 0u}
+        DCHK(hipMemcpyAsync(S.minmax.p, S.h_small + 8, 8, hipMemcpyHostToDevice, sp));
+        DCHK(launch_seq_lens(text, Bt.line_start.p, n_rec, S.seq_len.p, S.minmax.p, sp));
+        DCHK(launch_scan_u32(S.seq_len.p, n_rec, S.offsets_tmp.p, S.scan_tmp.p, sp));
+        DCHK(hipMemcpyAsync(S.h_small + 3, S.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
+        DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 8, hipMemcpyDeviceToHost, sp));
+        DCHK(hipStreamSynchronize(sp));
+        const uint64_t nb = hs[3]; const uint32_t mm[2] = {(uint32_t)hs[4], (uint32_t)(hs[4] >> 32)};
+        const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
+        const uint64_t n_words = (nb + 15) / 16;
+        // invalid bases are rare (N calls): room for one in 64 bases, more when a piece proves to need it
+        const uint64_t pb = pack_blocks(nb, 0);
+        uint64_t npos_cap = std::max<uint64_t>(nb / 64 + 1024, S.reads->cap_npos / 8);
+        int rc = MF_OK;
+        if (first_set && grow > 1.0) {
+            // The read set is refilled piece after piece, and growing it means hipFree -- which waits for every kernel on the
+            // device, the decoder's included.  The first slabs of a .gz are short ones: give the set the size of a full slab's now.
+            const double g = std::min(grow, 64.0) * 1.2;
+            const uint64_t nw = (uint64_t)((double)n_words * g), nr = (uint64_t)((double)n_rec * g);
+            rc = reads_reserve(R, true, nw, nr, 0, (uint64_t)((double)npos_cap * g), S.ctx);
+            if (!rc) rc = reads_finish(R, true, nw, nr, nw * 16, 0, 0, S.ctx);        // (no invalid positions: nothing of the empty set is read)
+            if (rc) { err = mf_thread_error(); return rc; }
+            const size_t bw = (size_t)(nr / 32 + 1024);
+            if (bw > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, bw * 4, hipHostMallocDefault)); S.h_bits_cap = bw; }
+        }
+        rc = reads_reserve(R, true, n_words, n_rec, uniform, npos_cap, S.ctx);
+        if (rc) { err = mf_thread_error(); return rc; }
+        if (!uniform) DCHK(hipMemcpyAsync(R->d_offsets, S.offsets_tmp.p, (n_rec + 1) * 8, hipMemcpyDeviceToDevice, sp));
+        uint64_t inv = 0;
+        if (pb) {
+            DCHK(S.inv_cnt.need(dev, pb)); DCHK(S.inv_base.need(dev, pb + 1)); DCHK(S.scan_tmp.need(dev, pb / 4096 + 4));
+            DCHK(launch_pack(text, Bt.line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, nullptr, nullptr, sp));
+            DCHK(launch_scan_u32(S.inv_cnt.p, pb, S.inv_base.p, S.scan_tmp.p, sp));
+            DCHK(hipMemcpyAsync(S.h_small + 5, S.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipStreamSynchronize(sp));
+            inv = hs[5];
+            if (inv) {
+                if (inv > npos_cap) { rc = reads_reserve(R, true, n_words, n_rec, uniform, inv, S.ctx); if (rc) { err = mf_thread_error(); return rc; } }     // (words and offsets stay where they are: only the list grows)
+                DCHK(launch_pack(text, Bt.line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, S.inv_base.p, R->d_npos, sp));
+            }
+        }
+        const double t2 = now_s();
+        rc = reads_finish(R, true, n_words, n_rec, nb, uniform, inv, S.ctx);
+        if (rc) { err = mf_thread_error(); return rc; }
+        const size_t bw = (size_t)((n_rec + 31) / 32);
+        if (bw + 2 > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (bw + bw / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = bw + bw / 2 + 1024; }
+        rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, S.h_bits, nullptr, 1, nullptr);
+        if (rc) { err = mf_thread_error(); return rc; }
+        {
+            size_t f = 0, t = 0; const bool got = hipMemGetInfo(&f, &t) == hipSuccess;
+            std::lock_guard<std::mutex> lk(mu);
+            t_pack += t2 - t1; t_filter += now_s() - t2;
+            if (got) mem_used_max = std::max(mem_used_max, t - f);
+        }
+        return MF_OK;
+    }
+
+    // survivors of the first n_emit records of batch B -> the mate's writer (emit_mu held)
+    int emit(Worker &W, Mate &M, int mi, Batch &B, uint64_t n_emit, std::string &err)
     {
         if (n_emit > B.n_rec) n_emit = B.n_rec;
         if (!n_emit) return MF_OK;
-        DevScratch *Sp = scratch_for(M, B.ldev, err);
+        DevScratch *Sp = scratch_for(W, B.ldev, err);
         if (!Sp) return MF_E_HIP;
         DevScratch &S = *Sp;
         const int dev = S.dev;
@@ -1126,95 +1191,166 @@ struct Ingest {
         // the pair rule, on the host: this mate's bits and the other's over the batch's records
         const size_t bw = (size_t)((n_emit + 31) / 32);
         if (bw + 2 > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (bw + bw / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = bw + bw / 2 + 1024; }
-        extract_bits(M.bits, B.rec_base, n_emit, S.h_bits);
         uint64_t keep_n = 0;
-        if (nm == 2) {
-            std::vector<uint32_t> other(bw);
-            extract_bits(m[1 - mi].bits, B.rec_base, n_emit, other.data());
-            for (size_t j = 0; j < bw; j++) S.h_bits[j] = pair_both ? (S.h_bits[j] & other[j]) : (S.h_bits[j] | other[j]);
+        {
+            std::lock_guard<std::mutex> lk(mu);                      // (the bitmaps grow under other consumers' hands)
+            extract_bits(M.bits, B.rec_base, n_emit, S.h_bits);
+            if (nm == 2) {
+                std::vector<uint32_t> other(bw);
+                extract_bits(m[1 - mi].bits, B.rec_base, n_emit, other.data());
+                for (size_t j = 0; j < bw; j++) S.h_bits[j] = pair_both ? (S.h_bits[j] & other[j]) : (S.h_bits[j] | other[j]);
+            }
         }
         for (size_t j = 0; j < bw; j++) keep_n += (uint64_t)__builtin_popcount(S.h_bits[j]);
         if (mi == 0) kept += keep_n;
-        emitted[mi] += n_emit;
         if (!keep_n) return MF_OK;
-        DCHK(S.mask.need(dev, bw + 1)); DCHK(S.out_len.need(dev, n_emit)); DCHK(S.out_off.need(dev, n_emit + 1)); DCHK(S.scan_tmp.need(dev, n_emit / 4096 + 4));
-        DCHK(hipMemcpyAsync(S.mask.p, S.h_bits, bw * 4, hipMemcpyHostToDevice, sp));
-        DCHK(launch_out_lens(B.text, B.line_start.p, n_emit, 0, S.mask.p, nullptr, 0, S.out_len.p, sp));
-        DCHK(launch_scan_u32(S.out_len.p, n_emit, S.out_off.p, S.scan_tmp.p, sp));
-        DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n_emit, 8, hipMemcpyDeviceToHost, sp));
+        // the survivors are few: their record numbers go up as a list (in place of the mask they were read from), and the kernels
+        // that measure and copy them run over the list
+        {
+            std::vector<uint32_t> idx; idx.reserve((size_t)keep_n);
+            for (size_t j = 0; j < bw; j++) for (uint32_t wv = S.h_bits[j]; wv; wv &= wv - 1) idx.push_back((uint32_t)(j * 32 + (uint32_t)__builtin_ctz(wv)));
+            if (keep_n > S.h_bits_cap) { (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (keep_n + keep_n / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = keep_n + keep_n / 2 + 1024; }
+            memcpy(S.h_bits, idx.data(), keep_n * 4);
+        }
+        DCHK(S.mask.need(dev, keep_n)); DCHK(S.out_len.need(dev, keep_n)); DCHK(S.out_off.need(dev, keep_n + 1)); DCHK(S.scan_tmp.need(dev, keep_n / 4096 + 4));
+        DCHK(hipMemcpyAsync(S.mask.p, S.h_bits, keep_n * 4, hipMemcpyHostToDevice, sp));
+        DCHK(launch_sel_lens(B.text, B.line_start.p, S.mask.p, keep_n, S.out_len.p, sp));
+        DCHK(launch_scan_u32(S.out_len.p, keep_n, S.out_off.p, S.scan_tmp.p, sp));
+        DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + keep_n, 8, hipMemcpyDeviceToHost, sp));
         DCHK(hipStreamSynchronize(sp));
         const uint64_t bytes = ((volatile uint64_t *)S.h_small)[6];
         if (bytes) {
             DCHK(S.d_out.need(dev, bytes));
-            DCHK(launch_gather(B.text, B.line_start.p, n_emit, S.out_len.p, S.out_off.p, S.d_out.p, sp));
-            std::vector<char> host(bytes);
-            DCHK(hipMemcpyAsync(host.data(), S.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
+            DCHK(launch_sel_gather(B.text, B.line_start.p, S.mask.p, keep_n, S.out_off.p, S.d_out.p, sp));
+            if (bytes > S.h_out_cap) { if (S.h_out) (void)hipHostFree(S.h_out); S.h_out = nullptr; S.h_out_cap = 0; DCHK(hipHostMalloc((void **)&S.h_out, bytes + bytes / 2 + 65536, hipHostMallocDefault)); S.h_out_cap = bytes + bytes / 2 + 65536; }
+            DCHK(hipMemcpyAsync(S.h_out, S.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
             wrote_any = true;
-            M.out.push(std::move(host));
+            M.out.push(std::vector<char>(S.h_out, S.h_out + bytes));
         }
         return MF_OK;
     }
 
-    // write what can be written: the batches whose records the other mate's pass bits cover (all of them once `fin`)
-    int drain(bool fin, std::string &err)
+    // write what can be written: the leading batches of either mate that are filtered and whose records the other mate's pass bits
+    // cover (all that are left, cut at `total`, once `fin`).  One consumer at a time.
+    int drain(Worker &W, bool fin, std::string &err)
     {
+        std::lock_guard<std::mutex> elk(emit_mu);
         const double te = now_s();
         for (int i = 0; i < nm; i++) {
             Mate &M = m[i];
-            const uint64_t covered = fin ? total : (nm == 2 ? std::min(m[0].rec_done, m[1].rec_done) : M.rec_done);
-            while (!M.batches.empty()) {
-                Batch &B = *M.batches.front();
-                if (!fin && B.rec_base + B.n_rec > covered) break;
-                if (B.rec_base < covered) { const int rc = emit(M, i, B, covered - B.rec_base, err); if (rc) return rc; }       // (pairs end with the shorter file)
-                M.batches.pop_front();
+            for (;;) {
+                std::unique_ptr<Batch> B; uint64_t covered = 0;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (M.batches.empty() || !M.batches.front()->filtered) break;
+                    covered = fin ? total : (nm == 2 ? std::min(m[0].rec_filtered, m[1].rec_filtered) : M.rec_filtered);
+                    if (!fin && M.batches.front()->rec_base + M.batches.front()->n_rec > covered) break;
+                    B = std::move(M.batches.front()); M.batches.pop_front();
+                }
+                if (B->rec_base < covered) { const int rc = emit(W, M, i, *B, covered - B->rec_base, err); if (rc) return rc; }       // (pairs end with the shorter file)
             }
         }
-        if (timing) t_emit += now_s() - te;
+        if (timing) { std::lock_guard<std::mutex> lk(mu); t_emit += now_s() - te; }
         return MF_OK;
+    }
+
+    // the next piece for a consumer: of the mate that is behind in records, if it has one ready (a mate whose text is not there yet
+    // does not hold up the other).  false: nothing more will come (or the run has failed)
+    bool take_piece(int &mi, TextPiece &P, uint64_t &seq, std::string &err, int &rc)
+    {
+        const double tw = now_s();
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (failed) return false;
+                int order[2] = {0, 1};
+                if (nm == 2 && m[1].rec_indexed < m[0].rec_indexed) { order[0] = 1; order[1] = 0; }
+                bool any_open = false;
+                for (int k = 0; k < nm; k++) {
+                    Mate &M = m[order[k]];
+                    if (M.eof) continue;
+                    std::unique_lock<std::mutex> plk(M.mu);
+                    if (!M.ready.empty()) {
+                        P = std::move(M.ready.front()); M.ready.pop_front();
+                        mi = order[k]; seq = M.taken++;
+                        if (P.last) M.eof = true;
+                        if (timing) t_wait += now_s() - tw;
+                        return true;
+                    }
+                    if (M.prod_done) {
+                        if (M.prod_rc) { rc = M.prod_rc; err = M.prod_err; return false; }
+                        M.eof = true;                              // (an input without text: an empty file cannot get here, but a .gz of nothing can)
+                    } else any_open = true;
+                }
+                if (!any_open) { if (timing) t_wait += now_s() - tw; return false; }
+            }
+            std::unique_lock<std::mutex> lk(mu_all);
+            cv_all.wait_for(lk, std::chrono::microseconds(300));
+        }
+    }
+
+    void fail_with(int rc, const std::string &err)
+    {
+        { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; fail_rc = rc; fail_err = err; } }
+        cv.notify_all(); cv_all.notify_all();
+    }
+
+    void consume(Worker &W)
+    {
+        std::string err;
+        for (;;) {
+            int mi = 0, rc = MF_OK; TextPiece P; uint64_t seq = 0;
+            if (!take_piece(mi, P, seq, err, rc)) { if (rc) fail_with(rc, err); return; }
+            Mate &M = m[mi];
+            {   // the line index of a mate's pieces is cut in order
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || M.a_turn == seq; });
+                if (failed) return;
+            }
+            const double grow = P.grow;
+            std::unique_ptr<Batch> B;
+            rc = index_piece(W, M, P, B, err);
+            Batch *Bp = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!rc) {
+                    B->rec_base = M.rec_indexed; M.rec_indexed += B->n_rec;
+                    if (B->n_rec) { Bp = B.get(); M.batches.push_back(std::move(B)); }       // (a piece without a complete record has nothing to write: its buffer goes back now)
+                }
+                M.a_turn = seq + 1;
+            }
+            cv.notify_all();
+            if (rc) { fail_with(rc, err); return; }
+            B.reset();
+            if (Bp) {
+                rc = filter_piece(W, *Bp, grow, err);
+                if (rc) { fail_with(rc, err); return; }
+                DevScratch &S = *W.scratch[Bp->ldev];
+                std::lock_guard<std::mutex> lk(mu);
+                append_bits(M.bits, Bp->rec_base, Bp->n_rec, S.h_bits);
+                Bp->filtered = true;
+                // records of the leading filtered pieces (a piece without records is not in the list and holds nobody up)
+                uint64_t upto = M.rec_filtered;
+                for (auto &q : M.batches) { if (q->rec_base < upto) continue; if (q->rec_base != upto || !q->filtered) break; upto = q->rec_base + q->n_rec; }
+                M.rec_filtered = upto;
+            }
+            rc = drain(W, false, err);
+            if (rc) { fail_with(rc, err); return; }
+        }
     }
 
     int run(std::string &err)
     {
         for (int i = 0; i < nm; i++) m[i].prod = std::thread([this, i] { producer(m[i]); });
-        // ---- ingest the text as it becomes available, the mate that is behind first
-        for (;;) {
-            int pick = -1;
-            for (int i = 0; i < nm; i++) if (!m[i].eof && (pick < 0 || m[i].rec_done < m[pick].rec_done)) pick = i;
-            if (pick < 0) break;
-            // (a mate whose text is not there yet does not hold up the other)
-            bool got = false; TextPiece P;
-            const double tw = now_s();
-            for (;;) {
-                for (int step = 0; step < nm && !got; step++) {
-                    Mate &M = m[(pick + step) % nm];
-                    if (M.eof) continue;
-                    std::unique_lock<std::mutex> lk(M.mu);
-                    if (!M.ready.empty()) { P = std::move(M.ready.front()); M.ready.pop_front(); got = true; pick = (pick + step) % nm; }
-                    else if (M.prod_done) {
-                        if (M.prod_rc) { err = M.prod_err; return M.prod_rc; }
-                        M.eof = true;                                  // (an input without text: an empty file cannot get here, but a .gz of nothing can)
-                    }
-                }
-                if (got) break;
-                bool any = false; for (int i = 0; i < nm; i++) any = any || !m[i].eof;
-                if (!any) break;
-                std::unique_lock<std::mutex> lk(mu_all);
-                cv_all.wait_for(lk, std::chrono::microseconds(500));
-            }
-            if (timing) t_wait += now_s() - tw;
-            if (!got) continue;
-            Mate &M = m[pick];
-            const bool last = P.last;
-            int rc = ingest(M, P, err);
-            if (rc) return rc;
-            if (last) M.eof = true;
-            rc = drain(false, err);
-            if (rc) return rc;
-        }
+        const int nw = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, env_u64("MF_INGEST_CONSUMERS", 3)));
+        for (int w = 0; w < nw; w++) { workers.emplace_back(new Worker()); workers.back()->id = w; }
+        for (auto &W : workers) { Worker *wp = W.get(); wp->th = std::thread([this, wp] { consume(*wp); }); }
+        for (auto &W : workers) W->th.join();
+        if (failed) { err = fail_err; return fail_rc; }
         for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (M.prod.joinable()) M.prod.join(); if (M.prod_rc) { err = M.prod_err; return M.prod_rc; } }
-        total = nm == 2 ? std::min(m[0].rec_done, m[1].rec_done) : m[0].rec_done;
-        return drain(true, err);
+        total = nm == 2 ? std::min(m[0].rec_indexed, m[1].rec_indexed) : m[0].rec_indexed;
+        return drain(*workers[0], true, err);
     }
 };
 
@@ -1223,7 +1359,7 @@ bool alloc_failure(int rc) { return rc == MF_E_NOMEM; }
 } // namespace
 
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
-                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err)
+                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats)
 {
     struct EndOfCall { ~EndOfCall() { const char *kb = getenv("MF_KEEP_BUFFERS"); g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 16) << 30); } } end_of_call;     // (declared first: runs after everything of this call is gone)
     Ingest I;
@@ -1249,7 +1385,7 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     for (int d : I.devices) { DevCtx *c = nullptr; const int rc = get_ctx(d, &c, 0); if (rc) { err = mf_thread_error(); return rc; } }
     const double t_begin = now_s();
     g_pool.reset_peak();
-    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", 4)) + (int)I.devices.size() - 1;
+    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", 6)) + (int)I.devices.size() - 1;        // (three consumers each hold one, the decoder one, the rest wait for the other mate or for a consumer)
     int rc = MF_OK;
     for (int i = 0; i < I.nm && !rc; i++) {
         Mate &M = I.m[i];
@@ -1274,11 +1410,26 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     if (!wrote) { err = std::string("write error on ") + out_path[0]; return MF_E_IO; }
     if (kept) *kept = I.kept;
     if (total) *total = I.total;
+    if (stats) {
+        *stats = IngestStats();
+        stats->seconds = now_s() - t_begin; stats->n_devices = (int)I.devices.size(); stats->consumers = (int)I.workers.size();
+        stats->pool_bytes_peak = g_pool.peak(); stats->device_bytes_peak = I.mem_used_max;
+        for (int i = 0; i < I.nm; i++) {
+            Mate &M = I.m[i];
+            stats->input_bytes += M.map.n; stats->records += M.rec_indexed;
+            if (M.gzs) {
+                stats->text_bytes += M.gzs->text_bytes(); stats->decode_busy_seconds += M.gzs->decode_busy_seconds();
+                stats->chunks += M.gzs->chunks(); stats->chunks_linked += M.gzs->chunks_linked(); stats->gaps += M.gzs->gaps(); stats->gap_bytes += M.gzs->gap_bytes();
+            } else stats->text_bytes += M.map.n;
+        }
+    }
     if (I.timing) {
         fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
                 now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
         for (int i = 0; i < I.nm; i++)
-            if (I.m[i].gzs) fprintf(stderr, " | mate %d: %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, (unsigned long long)I.m[i].gzs->chunks_linked(),
+            if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, a, b, c, d, e); }
+        for (int i = 0; i < I.nm; i++)
+            if (I.m[i].gzs) fprintf(stderr, " | mate %d: inflate kernels busy %.3f s (%.1f GB/s of text), %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, I.m[i].gzs->decode_busy_seconds(), I.m[i].gzs->decode_busy_seconds() > 0 ? (double)I.m[i].gzs->text_bytes() / I.m[i].gzs->decode_busy_seconds() / 1e9 : 0.0, (unsigned long long)I.m[i].gzs->chunks_linked(),
                                     I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes(), I.m[i].gzs->ring_bytes() >> 20, I.m[i].gzs->splits());
         fprintf(stderr, "\n");
     }

@@ -13,9 +13,18 @@ namespace mf {
 
 constexpr int MF_DEVINGEST_DECLINED = 1;      // not an input this path takes (a pipe, BGZF, an empty file ...): use the host pipeline
 
+// what a call of the device path did (mf_last_ingest_stats of the C ABI)
+struct IngestStats {
+    uint64_t input_bytes = 0, text_bytes = 0, records = 0;     // bytes of the input files as they lie; text they hold; FASTQ records cut from it (both mates)
+    double seconds = 0, decode_busy_seconds = 0;               // wall time of the call; time during which at least one inflate kernel was running (0: no .gz input)
+    uint64_t pool_bytes_peak = 0, device_bytes_peak = 0;       // this call's buffers / everything in use on the device, at most, on any one device
+    uint64_t chunks = 0, chunks_linked = 0, gaps = 0, gap_bytes = 0;
+    int n_devices = 0, consumers = 0;
+};
+
 // fq2 / out2 null: single end.  devices: the (logical) devices the slabs of the input are dealt to, round robin.
 // Returns MF_OK, MF_DEVINGEST_DECLINED (no survivor has been written: the caller takes the host pipeline) or an MF_E_* code with err set.
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
-                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err);
+                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats = nullptr);
 
 } // namespace mf

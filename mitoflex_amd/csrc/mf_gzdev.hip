@@ -256,20 +256,23 @@ __device__ __forceinline__ bool build_tables(LDS &L, uint32_t hlit, uint32_t hdi
 // The search looks at SEARCH_W windows of 64 bit offsets at a time (one offset per lane and window): the loads of all of them are in
 // flight together -- a step of the search is a memory round trip, and with one window a step that was what it cost.
 constexpr int SEARCH_W = 4;
-struct Search { uint64_t b0; uint64_t mask[SEARCH_W]; };      // mask[j]: candidates among the offsets b0 + 64 j + lane
+// m0: candidates among the offsets b0 + lane of the current window; m1 .. m7: the windows behind it, `left` of them still to come.
+// (Named members and a shift from one to the next, not an array picked by index: the masks are wave-uniform and stay in scalar registers.)
+struct Search { uint64_t b0; uint64_t m0, m1, m2, m3, m4, m5, m6, m7; uint32_t left; };
+__device__ __forceinline__ void search_init(Search &S, uint64_t first_bit) { S.b0 = first_bit - 64; S.m0 = S.m1 = S.m2 = S.m3 = S.m4 = S.m5 = S.m6 = S.m7 = 0; S.left = 0; }
 __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *words, uint64_t wmask, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
 {
+    static_assert(SEARCH_W >= 1 && SEARCH_W <= 8, "the members of Search");
     for (;;) {
-#pragma unroll
-        for (int j = 0; j < SEARCH_W; j++)
-            if (S.mask[j]) {
-                const int idx = __ffsll((unsigned long long)S.mask[j]) - 1;
-                S.mask[j] &= S.mask[j] - 1;
-                return S.b0 + (uint64_t)(64 * j + idx);
-            }
-        S.b0 += 64 * SEARCH_W;
+        if (S.m0) {
+            const int idx = __ffsll((unsigned long long)S.m0) - 1;
+            S.m0 &= S.m0 - 1;
+            return S.b0 + (uint64_t)idx;
+        }
+        if (S.left) { S.m0 = S.m1; S.m1 = S.m2; S.m2 = S.m3; S.m3 = S.m4; S.m4 = S.m5; S.m5 = S.m6; S.m6 = S.m7; S.m7 = 0; S.b0 += 64; S.left--; continue; }
+        S.b0 += 64;
         if (S.b0 >= to_bit) return ~0ull;
-        uint32_t w[SEARCH_W][4]; bool in[SEARCH_W];
+        uint32_t w[SEARCH_W][4]; bool in[SEARCH_W]; uint64_t k8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < SEARCH_W; j++) {
             const uint64_t bit = S.b0 + (uint64_t)(64 * j) + lane;
@@ -295,8 +298,10 @@ __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *wo
                 }
                 ok = k == 128u;
             }
-            S.mask[j] = __ballot(ok);
+            k8[j] = __ballot(ok);
         }
+        S.m0 = k8[0]; S.m1 = k8[1]; S.m2 = k8[2]; S.m3 = k8[3]; S.m4 = k8[4]; S.m5 = k8[5]; S.m6 = k8[6]; S.m7 = k8[7];
+        S.left = SEARCH_W - 1;
     }
 }
 
@@ -607,8 +612,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
     TabRegs T;
     T.lit = (u32x16)(0u); T.dist = (u32x8)(0u);
     bool searching = c != exact_chunk;
-    Search S; S.b0 = nominal - 64 * SEARCH_W;
-    for (int j = 0; j < SEARCH_W; j++) S.mask[j] = 0;
+    Search S; search_init(S, nominal);
     uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
     uint32_t status = GZ_NONE;
     if (!searching) rd.seek(start, lane);
@@ -729,26 +733,58 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
 //     loads are issued ahead), every output position of the round finding its entry by binary search in LDS, as before.
 // The tables stay in LDS (the lanes index them on their own); ring, precode and code-length arrays share their bytes with the
 // round's list and staging buffer.
-constexpr uint32_t SPAN = 2048;          // bits of the block per lane and step
-constexpr uint32_t LCAP = 1024;          // list entries a lane may leave per step (a code has at least one bit, a double literal entry two)
-constexpr uint32_t RN = 128;             // list entries per round of the expansion
+constexpr uint32_t SPAN = 1024;          // bits of the block per lane and step
+constexpr uint32_t LCAP = 512;           // list entries a lane may leave per step (more codes than that in 1024 bits: the lane stops early, the next step goes on from there)
+constexpr uint32_t RN = 256;             // list entries per round of the expansion
 constexpr uint32_t STG2 = 2048;          // output symbols per round (staging buffer)
 constexpr uint32_t MAX_REWALK = 6;       // re-walk rounds per step; what is not chained by then waits for the next step
+// dwords of the stream a lane may touch in a step: its span, a code that starts in the span's last bit (48 bits), the bit buffer's
+// 64 bits and one dword read ahead.  Odd, so that the lanes' rows start in different LDS banks.
+constexpr uint32_t SPAN_DW = SPAN / 32, STAGE_DW = SPAN_DW + 5;
+static_assert(SPAN % 32 == 0 && STAGE_DW % 2 == 1 && RN <= 256 && RN % 64 == 0 && STG2 % 256 == 0 && STG2 <= 0x4000, "layout of the rounds");
 struct Lds2 {
     uint32_t lit[LIT_SIZE]; uint32_t dist[DIST_SIZE];
     union {
         struct { uint32_t ring[RING]; uint32_t pre[PRE_SIZE]; uint8_t lens[328]; uint8_t plens[24]; };      // between blocks: the header reader's
-        struct { uint32_t sym[RN]; uint16_t soff[RN]; uint16_t stg[STG2]; };                                 // inside a block: the expansion's
+        uint32_t stage[64 * STAGE_DW];                                                                       // a step's walks: the stream, a row per lane
+        struct { uint32_t sym[RN]; uint16_t soff[RN]; uint16_t stg[STG2]; uint8_t own[STG2]; };              // a step's expansion
     };
     uint16_t sorted_lit[288], sorted_dist[32];
     Canon clit, cdist;
 };
 
-// dword w of the stream, counted from the chunk's origin; every lane reads its own
+// dword w of the stream, counted from the chunk's origin (global memory, through the ring)
 struct LaneIn {
     const uint32_t *words; uint64_t origin_dw, wmask, max_dw;
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { uint64_t i = origin_dw + w; i = i < max_dw ? i : max_dw; return words[i & wmask]; }
 };
+// ... from the lane's row of the step's staged input (LDS): the walk never waits for global memory
+struct LaneInLds {
+    const uint32_t *row; uint32_t w_first;
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { uint32_t k = w - w_first; k = k < STAGE_DW ? k : STAGE_DW - 1; return row[k]; }
+};
+// The stream from bit b_rel on, 64 spans and what a lane reads past its span, into LDS: row i = dwords (b_rel >> 5) + SPAN_DW i .. + STAGE_DW - 1.
+// Loaded coalesced, all loads in flight together (one memory latency per step instead of one per few codes).
+__device__ __forceinline__ void stage_input(Lds2 &L, const LaneIn &in, uint32_t b_rel, uint32_t lane)
+{
+    const uint32_t w0 = b_rel >> 5;
+    constexpr uint32_t TOTAL = 64 * SPAN_DW + (STAGE_DW - SPAN_DW), ROUNDS = (TOTAL + 63) / 64, BATCH = 7;      // (seven loads in flight a thread, five batches)
+#pragma unroll 1
+    for (uint32_t i0 = 0; i0 < ROUNDS; i0 += BATCH) {
+        uint32_t v[BATCH];
+#pragma unroll
+        for (uint32_t i = 0; i < BATCH; i++) { const uint32_t g = lane + 64 * (i0 + i); v[i] = g < TOTAL ? in(w0 + g) : 0u; }
+#pragma unroll
+        for (uint32_t i = 0; i < BATCH; i++) {
+            const uint32_t g = lane + 64 * (i0 + i), row = g / SPAN_DW, col = g % SPAN_DW;
+            if (g < TOTAL) {
+                if (row < 64) L.stage[row * STAGE_DW + col] = v[i];
+                if (col < STAGE_DW - SPAN_DW && row >= 1) L.stage[(row - 1) * STAGE_DW + SPAN_DW + col] = v[i];      // (the head of a span is the tail of the row before)
+            }
+        }
+    }
+    __syncthreads();
+}
 // a lane's list entries: four at a time, one 16-byte store
 struct LaneOut {
     uint32_t *base; uint32_t n, e0, e1, e2;
@@ -768,66 +804,167 @@ struct LaneOut {
     }
 };
 
-// One round of the expansion: up to RN list entries at lst[0 .. n) -> symbols at out[opos ..].  Takes as many entries as fit the
-// staging buffer (at least one); returns their number in `taken` and the number of symbols written.
-__device__ __forceinline__ uint32_t expand2(Lds2 &L, const uint32_t *lst, uint32_t n, uint16_t *out, uint64_t opos, uint32_t lane, uint32_t &taken)
+// The lane's walk of mf_gzlane.h (same codes, same list entries, same end: tools/gzdev_check holds it to zlib) written for the staged
+// rows: there is no bit buffer to keep filled -- the 32 bits at the lane's position are two LDS dwords and one v_alignbit, taken
+// afresh for every code (and once more for a match's distance), so the state of the walk is the position alone and everything
+// is 32-bit arithmetic.  A length code and its extra bits are at most 20 bits, a distance code and its extra bits at most 28.
+__device__ __forceinline__ uint32_t bits_at(const uint32_t *row, uint32_t w_first, uint32_t pos)
+{
+    const uint32_t k = (pos >> 5) - w_first;
+    return __builtin_amdgcn_alignbit(row[k + 1], row[k], pos & 31u);
+}
+__device__ __forceinline__ Span walk_rows(const Lds2 &L, const uint32_t *row, uint32_t w_first, uint32_t start, uint32_t stop, uint32_t max_codes, LaneOut &out)
+{
+    Span r; r.end = start; r.n_code = 0; r.n_sym = 0; r.flags = 0;
+    uint32_t pos = start;
+    for (;;) {
+        if (pos >= stop) { r.end = pos; break; }
+        if (r.n_code >= max_codes) { r.end = pos; r.flags |= SP_FULL; break; }
+        const uint32_t win = bits_at(row, w_first, pos);
+        uint32_t e = L.lit[win & (LIT_SIZE - 1)];
+        if ((int32_t)e >= 0) {                  // one or two literals
+            uint32_t l = e & 255u;
+            if ((e & E_DOUBLE) && pos + ((e >> 25) & 15u) >= stop) { l = (e >> 25) & 15u; e &= 0xFF00u; }      // (a span ends at the first code boundary at or behind `stop`: mf_gzlane.h)
+            pos += l;
+            r.n_sym += 1 + ((e >> 24) & 1u);
+            out.put(e);
+            r.n_code++;
+            continue;
+        }
+        uint32_t used;                          // bits of `win` taken so far
+        if ((e & K_MASK) == K_LONG) {           // longer than the table's index: canonical decode
+            const uint32_t rev = __brev(win);
+            uint32_t s = 0xFFFFu, len = 0;
+            for (uint32_t l = LIT_BITS + 1; l <= 15; l++) {
+                const uint32_t idx = (rev >> (32 - l)) - L.clit.first[l];
+                if (idx < L.clit.cnt[l]) { len = l; s = L.sorted_lit[L.clit.off[l] + idx]; break; }
+            }
+            if (s == 0xFFFFu) { r.end = pos; r.flags |= SP_ERR; break; }
+            e = lit_entry(s);
+            if ((int32_t)e >= 0) { pos += len; r.n_sym++; out.put(e); r.n_code++; continue; }
+            used = len;
+        } else used = e & 255u;
+        const uint32_t kind = e & K_MASK;
+        if (kind == K_EOB) { r.end = pos + used; r.flags |= SP_EOB; break; }
+        if (kind != K_LENGTH) { r.end = pos; r.flags |= SP_ERR; break; }
+        const uint32_t xl = (e >> 24) & 7u;
+        const uint32_t lenm3 = ((e >> 8) & 0xFFu) + __builtin_amdgcn_ubfe(win, used, xl);
+        const uint32_t pos_d = pos + used + xl;
+        const uint32_t win2 = bits_at(row, w_first, pos_d);
+        uint32_t d = L.dist[win2 & (DIST_SIZE - 1)], used2;
+        if ((int32_t)d < 0) {
+            if (d & D_INVALID) { r.end = pos; r.flags |= SP_ERR; break; }
+            const uint32_t rev = __brev(win2);
+            uint32_t s = 0xFFFFu, dl = 0;
+            for (uint32_t l = DIST_BITS + 1; l <= 15; l++) {
+                const uint32_t idx = (rev >> (32 - l)) - L.cdist.first[l];
+                if (idx < L.cdist.cnt[l]) { dl = l; s = L.sorted_dist[L.cdist.off[l] + idx]; break; }
+            }
+            if (s == 0xFFFFu) { r.end = pos; r.flags |= SP_ERR; break; }
+            d = dist_entry(s);
+            if ((int32_t)d < 0) { r.end = pos; r.flags |= SP_ERR; break; }
+            used2 = dl;
+        } else used2 = d & 255u;
+        const uint32_t xd = (d >> 24) & 15u;
+        const uint32_t distm1 = ((d >> 8) & 0x7FFFu) + __builtin_amdgcn_ubfe(win2, used2, xd);
+        pos = pos_d + used2 + xd;
+        r.n_sym += lenm3 + 3;
+        out.put(0x80000000u | lenm3 | (distm1 << 9));
+        r.n_code++;
+    }
+    return r;
+}
+
+// One round of the expansion: up to RN entries of the step's list at cl[0 .. n) -> symbols at out[opos ..].  Takes as many entries
+// as fit the staging buffer (at least one); returns their number in `taken` and the number of symbols written.
+// Every output position of the round needs the entry it belongs to.  The entries mark where they start (one byte per position),
+// a thread takes a run of consecutive positions and the running maximum of the marks -- within the thread, then across the
+// wavefront -- is each position's entry: two LDS round trips, where a binary search per position took eight, one after the other.
+__device__ __forceinline__ uint32_t expand3(Lds2 &L, const uint32_t *cl, uint32_t n, uint16_t *out, uint64_t opos, uint32_t lane, uint32_t &taken)
 {
     constexpr uint32_t K = RN / 64;
-    uint32_t s[K], cnt[K], off[K];
+    uint32_t s[K], cnt[K], end[K];
+    uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t t = 0; t < K; t++) { const uint32_t j = t * 64 + lane; s[t] = j < n ? lst[j] : 0u; }
-    uint32_t run = 0, n_ok = 0;
-    uint64_t any_match = 0;
+    for (uint32_t q = 0; q < K; q++) { const uint32_t j = lane * K + q; s[q] = j < n ? cl[j] : 0u; }
 #pragma unroll
-    for (uint32_t t = 0; t < K; t++) {
-        const uint32_t j = t * 64 + lane;
-        cnt[t] = j < n ? ((s[t] >> 31) ? (s[t] & 0x1FFu) + 3 : 1 + ((s[t] >> 24) & 1u)) : 0;
-        uint32_t inc = cnt[t];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += u; }
-        inc += run;
-        off[t] = inc - cnt[t];
-        run = __shfl(inc, 63);
-        // entries whose symbols fit the staging buffer (a prefix of the list: the sums are monotone)
-        const uint64_t okm = __ballot(j < n && inc <= STG2);
-        n_ok += (uint32_t)__popcll(okm);
-        any_match |= __ballot(j < n && inc <= STG2 && (s[t] >> 31));
+    for (uint32_t q = 0; q < K; q++) {
+        const uint32_t j = lane * K + q;
+        cnt[q] = j < n ? ((s[q] >> 31) ? (s[q] & 0x1FFu) + 3 : 1 + ((s[q] >> 24) & 1u)) : 0;
+        sum += cnt[q]; end[q] = sum;
     }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += u; }
+    const uint32_t base = inc - sum;
+    uint32_t okc = 0, my_end = 0; bool my_match = false;
+#pragma unroll
+    for (uint32_t q = 0; q < K; q++) {
+        end[q] += base;
+        const bool ok = lane * K + q < n && end[q] <= STG2;          // (a prefix of the list: the ends grow)
+        if (ok) { okc++; my_end = end[q]; my_match = my_match || (s[q] >> 31); }
+    }
+    uint32_t n_ok = okc, tot = my_end;
+    for (int d = 32; d; d >>= 1) { n_ok += __shfl_xor(n_ok, d); tot = max(tot, (uint32_t)__shfl_xor(tot, d)); }
     taken = n_ok;
-    // symbols of the entries taken
-    uint32_t tot = 0;
+    if (!__any(my_match)) {                      // literals only: every entry stores its one or two symbols itself
 #pragma unroll
-    for (uint32_t t = 0; t < K; t++) { const uint32_t j = t * 64 + lane; const uint32_t e = j < n_ok ? off[t] + cnt[t] : 0; uint32_t m = e; for (int d = 32; d; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d)); tot = max(tot, m); }
-    if (any_match == 0) {                        // literals only: every entry stores its one or two symbols itself
-#pragma unroll
-        for (uint32_t t = 0; t < K; t++) {
-            const uint32_t j = t * 64 + lane;
-            if (j < n_ok) { out[opos + off[t]] = (uint16_t)((s[t] >> 8) & 0xFFu); if (cnt[t] == 2) out[opos + off[t] + 1] = (uint16_t)((s[t] >> 16) & 0xFFu); }
+        for (uint32_t q = 0; q < K; q++) {
+            const uint32_t j = lane * K + q, o = end[q] - cnt[q];
+            if (j < n_ok) { out[opos + o] = (uint16_t)((s[q] >> 8) & 0xFFu); if (cnt[q] == 2) out[opos + o + 1] = (uint16_t)((s[q] >> 16) & 0xFFu); }
         }
         return tot;
     }
+    const uint32_t C = (((tot + 63) >> 6) + 3) & ~3u;      // positions per thread: a multiple of four (the marks are read a dword at a time), at most STG2 / 64
+    uint32_t *own32 = reinterpret_cast<uint32_t *>(L.own);
 #pragma unroll
-    for (uint32_t t = 0; t < K; t++) { const uint32_t j = t * 64 + lane; L.sym[j] = s[t]; L.soff[j] = (uint16_t)(j < n_ok ? off[t] : 0xFFFFu); }
+    for (uint32_t q = 0; q < K; q++) { const uint32_t j = lane * K + q; if (j < n_ok) { L.sym[j] = s[q]; L.soff[j] = (uint16_t)(end[q] - cnt[q]); } }
+    for (uint32_t i = 0; i < C / 4; i++) own32[lane * (C / 4) + i] = 0u;
     __syncthreads();
-    bool pending = false;
-    for (uint32_t p = lane; p < tot; p += 64) {
-        uint32_t lo = 0;
 #pragma unroll
-        for (uint32_t step = RN / 2; step; step >>= 1) { const uint32_t j = lo + step; if (j < n_ok && L.soff[j] <= p) lo = j; }
-        const uint32_t e = L.sym[lo], o = L.soff[lo];
-        uint32_t v;
-        if (!(e >> 31)) v = (p == o ? (e >> 8) : (e >> 16)) & 0xFFu;
-        else {
-            const uint32_t len = (e & 0x1FFu) + 3, D = ((e >> 9) & 0x7FFFu) + 1, t = p - o;
-            const uint32_t r = D < len ? t % D : t;
-            const int32_t srel = (int32_t)o - (int32_t)D + (int32_t)r;
-            if (srel >= 0) { v = PENDING | (uint32_t)srel; pending = true; }
-            else {
-                const int64_t g = (int64_t)opos + srel;
-                v = g >= 0 ? out[g] : (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g));
+    for (uint32_t q = 0; q < K; q++) { const uint32_t j = lane * K + q; if (j < n_ok && j > 0) L.own[end[q] - cnt[q]] = (uint8_t)j; }      // (entry 0 starts at position 0: the maximum starts there)
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < C / 4; i++) {
+        const uint32_t o4 = own32[lane * (C / 4) + i];
+        m = max(m, max(max(o4 & 0xFFu, (o4 >> 8) & 0xFFu), max((o4 >> 16) & 0xFFu, o4 >> 24)));
+    }
+    uint32_t carry = m;                          // -> the largest mark in front of this thread's positions
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(carry, d); if (lane >= (uint32_t)d) carry = max(carry, u); }
+    carry = __shfl_up(carry, 1);
+    if (lane == 0) carry = 0;
+    bool pending = false;
+    uint32_t run = carry;
+#pragma unroll 1
+    for (uint32_t i = 0; i < C / 4; i++) {
+        {
+            const uint32_t o4 = own32[lane * (C / 4) + i];      // (read again rather than kept: eight registers a thread for a 50-cycle read)
+            uint32_t vv[4];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) {
+                const uint32_t p = lane * C + 4 * i + b;
+                run = max(run, (o4 >> (8 * b)) & 0xFFu);
+                uint32_t v = 0;
+                if (p < tot) {
+                    const uint32_t e = L.sym[run], o = L.soff[run];
+                    if (!(e >> 31)) v = (p == o ? (e >> 8) : (e >> 16)) & 0xFFu;
+                    else {
+                        const uint32_t len = (e & 0x1FFu) + 3, D = ((e >> 9) & 0x7FFFu) + 1, t = p - o;
+                        const uint32_t r = D < len ? t % D : t;
+                        const int32_t srel = (int32_t)o - (int32_t)D + (int32_t)r;
+                        if (srel >= 0) { v = PENDING | (uint32_t)srel; pending = true; }
+                        else {
+                            const int64_t g = (int64_t)opos + srel;
+                            v = g >= 0 ? out[g] : (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g));
+                        }
+                    }
+                }
+                vv[b] = v;
             }
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) { const uint32_t p = lane * C + 4 * i + b; if (p < tot) L.stg[p] = (uint16_t)vv[b]; }
         }
-        L.stg[p] = (uint16_t)v;
     }
     __syncthreads();
     while (__any(pending)) {                     // references into the round itself: they point strictly backwards
@@ -836,7 +973,8 @@ __device__ __forceinline__ uint32_t expand2(Lds2 &L, const uint32_t *lst, uint32
             const uint32_t v = L.stg[p];
             if ((v & 0xC000u) == PENDING) {
                 const uint32_t w = L.stg[v & 0x3FFFu];
-                if ((w & 0xC000u) == PENDING) pending = true; else L.stg[p] = (uint16_t)w;
+                L.stg[p] = (uint16_t)w;          // the symbol -- or the reference it holds itself: the chain to follow halves with every pass
+                if ((w & 0xC000u) == PENDING) pending = true;
             }
         }
         __syncthreads();
@@ -848,22 +986,43 @@ __device__ __forceinline__ uint32_t expand2(Lds2 &L, const uint32_t *lst, uint32
 
 enum BlockEnd : uint32_t { B_EOB = 0, B_ERROR = 1, B_OVERFLOW = 2, B_PAST_SIZE = 3, B_PAST_LIMIT = 4 };
 
+// cycle counts per phase of a chunk (tools/gzdev_check built with -DGZ_PROFILE reads them from the head of the chunk's list scratch)
+#ifdef GZ_PROFILE
+struct Prof { unsigned long long t[8]; };      // 0 search + header reads, 1 table construction, 2 walks, 3 expansion, 4 steps, 5 walk rounds, 6 expansion rounds, 7 blocks
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(i) do { prof.t[i] += __builtin_readcyclecounter() - prof_t0_; } while (0)
+#define PROF_CNT(i, n) do { prof.t[i] += (n); } while (0)
+#else
+struct Prof {};
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(i) do {} while (0)
+#define PROF_CNT(i, n) do {} while (0)
+#endif
+
 // The codes of one block (tables built in L), from bit `from` (absolute) on, by all lanes.  On B_EOB `from` is the bit behind the
-// end-of-block code and opos the symbols written.
+// end-of-block code and opos the symbols written.  lst: the chunk's scratch -- a list of LCAP entries per lane, and behind the 64
+// of them room for a step's list in one piece.
 __device__ __forceinline__ uint32_t decode_block(Lds2 &L, const LaneIn &in, uint64_t origin_bits, uint64_t &from, uint64_t size_bits, uint64_t limit_bits,
-                                                  uint16_t *out, uint64_t &opos, uint64_t sym_cap, uint32_t *lst, uint32_t lane)
+                                                  uint16_t *out, uint64_t &opos, uint64_t sym_cap, uint32_t *lst, uint32_t lane, Prof &prof)
 {
     uint32_t b_rel = (uint32_t)(from - origin_bits);
+    uint32_t *cl = lst + 64 * LCAP;
     for (;;) {
         uint32_t start = b_rel + lane * SPAN;
         const uint32_t stop = b_rel + (lane + 1) * SPAN;
         LaneOut lo; lo.base = lst + lane * LCAP; lo.n = 0; lo.e0 = lo.e1 = lo.e2 = 0;
         Span sp; sp.end = start; sp.n_code = 0; sp.n_sym = 0; sp.flags = 0;
         bool need = true;                       // this lane has to walk (again): its start has moved
+        PROF_CNT(4, 1);
+        { PROF_T0();
+        __syncthreads();
+        stage_input(L, in, b_rel, lane);
+        const uint32_t *row = &L.stage[lane * STAGE_DW]; const uint32_t w_first = (b_rel >> 5) + lane * SPAN_DW;
         for (uint32_t it = 0;; it++) {
+            PROF_CNT(5, 1);
             if (need) {
                 lo.n = 0;
-                sp = walk_span(L.lit, L.dist, L.clit, L.cdist, L.sorted_lit, L.sorted_dist, in, start, stop, LCAP, lo);
+                sp = walk_rows(L, row, w_first, start, stop, LCAP, lo);
                 lo.flush();
             }
             const uint32_t prev_end = __shfl_up(sp.end, 1), prev_flags = __shfl_up(sp.flags, 1);
@@ -871,6 +1030,7 @@ __device__ __forceinline__ uint32_t decode_block(Lds2 &L, const LaneIn &in, uint
             if (!__any(need) || it == MAX_REWALK) break;       // (a lane that still needs a walk keeps its old start and list: it is not part of the chain below)
             if (need) start = prev_end;
         }
+        PROF_ADD(2); }
         // the chain: lanes 0 .. V - 1 each start where the lane before stopped
         const uint32_t prev_end = __shfl_up(sp.end, 1), prev_flags = __shfl_up(sp.flags, 1);
         const bool good = lane == 0 || (!(prev_flags & (SP_EOB | SP_ERR)) && prev_end == start);
@@ -883,17 +1043,31 @@ __device__ __forceinline__ uint32_t decode_block(Lds2 &L, const LaneIn &in, uint
         uint32_t tot = lane < V ? sp.n_sym : 0;
         for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d);
         if (opos + tot > sym_cap) return B_OVERFLOW;
-        __threadfence_block();                   // the lists are read by other lanes than the ones that wrote them
-        __syncthreads();
-        for (uint32_t i = 0; i < V; i++) {
-            const uint32_t ni = (uint32_t)__shfl(sp.n_code, (int)i);
-            const uint32_t *li = lst + i * LCAP;
-            for (uint32_t k0 = 0; k0 < ni;) {
-                uint32_t taken = 0;
-                opos += expand2(L, li + k0, ni - k0 < RN ? ni - k0 : RN, out, opos, lane, taken);
-                k0 += taken;
+        { PROF_T0();
+        // the lists of the chain's lanes, one behind the other (every lane moves its own: eight entries in flight)
+        const uint32_t n_mine = lane < V ? sp.n_code : 0;
+        uint32_t cinc = n_mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(cinc, d); if (lane >= (uint32_t)d) cinc += u; }
+        const uint32_t n_list = (uint32_t)__shfl(cinc, 63);
+        {
+            const uint32_t *src = lst + lane * LCAP; uint32_t *dst = cl + (cinc - n_mine);
+            for (uint32_t k = 0; k < n_mine; k += 8) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(src + k), b = *reinterpret_cast<const uint4 *>(src + k + 4);      // (inside the lane's LCAP entries: LCAP is a multiple of eight)
+                const uint32_t e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) if (k + q < n_mine) dst[k + q] = e[q];
             }
         }
+        __threadfence_block();                   // the list is read by other lanes than the ones that wrote it
+        __syncthreads();
+        for (uint32_t e0 = 0; e0 < n_list;) {
+            uint32_t taken = 0;
+            opos += expand3(L, cl + e0, n_list - e0 < RN ? n_list - e0 : RN, out, opos, lane, taken);
+            e0 += taken;
+            PROF_CNT(6, 1);
+        }
+        PROF_ADD(3); }
         b_rel = end_rel;
         if (end_flags & SP_EOB) { from = origin_bits + end_rel; return B_EOB; }
     }
@@ -907,7 +1081,7 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
     const uint32_t lane = threadIdx.x;
     const uint32_t c = chunk_lo + blockIdx.x;
     uint16_t *out = sym + (uint64_t)blockIdx.x * sym_cap;
-    uint32_t *lst = lists + (uint64_t)blockIdx.x * (64 * LCAP);
+    uint32_t *lst = lists + (uint64_t)blockIdx.x * (2 * 64 * LCAP);
     const uint64_t size_bits = size * 8, limit_bits = limit_bytes * 8;
     const uint64_t nominal = (base_byte + (uint64_t)c * chunk_bytes) * 8, stop_bit = nominal + chunk_bytes * 8;
     const uint64_t search_end = stop_bit < size_bits ? stop_bit : size_bits;
@@ -919,18 +1093,23 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
     LaneIn in; in.words = reinterpret_cast<const uint32_t *>(data); in.origin_dw = rd.origin_v * 4; in.wmask = ring_mask >> 2; in.max_dw = rd.vmax * 4 + 3;
     const uint64_t origin_bits = rd.origin_v * 128;
     bool searching = c != exact_chunk;
-    Search S; S.b0 = nominal - 64 * SEARCH_W;
-    for (int j = 0; j < SEARCH_W; j++) S.mask[j] = 0;
+    Search S; search_init(S, nominal);
     uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
     uint32_t status = GZ_NONE;
     if (!searching) rd.seek(start, lane);
     else if (nominal >= size_bits) { if (lane == 0) chunks[c] = res; return; }
     uint64_t behind_from = ~0ull;                   // the first block boundary behind the chunk's own range
     uint32_t why = 0;                               // what stopped a decode that failed (reported in n_sym of a GZ_FAILED chunk)
+    Prof prof;
+#ifdef GZ_PROFILE
+    for (int i = 0; i < 8; i++) prof.t[i] = 0;
+    const unsigned long long prof_begin = __builtin_readcyclecounter();
+#endif
     for (;;) {
         uint32_t final = 0, type = 2;
         bool strict = false;
         why = 0;
+        PROF_T0();
         if (searching) {
             start = next_candidate(S, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, search_end, size_bits, lane);
             if (start == ~0ull) { status = GZ_NONE; break; }
@@ -975,14 +1154,16 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
                 for (uint32_t i = lane; i < 320; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : (i < 288 ? 8 : 5)));
                 __syncthreads();
             } else ok = read_code_lengths(L, rd, strict, lane, hlit, hdist);
+            PROF_ADD(0);
             if (!ok) why = 4;
-            else if (!build_tables(L, hlit, hdist, strict, lane)) why = 5;
+            else { PROF_T0(); if (!build_tables(L, hlit, hdist, strict, lane)) why = 5; PROF_ADD(1); }
             __syncthreads();
-        }
+        } else PROF_ADD(0);
         if (!why) {
             searching = false;
+            PROF_CNT(7, 1);
             uint64_t at = rd.bitpos();
-            const uint32_t e = decode_block(L, in, origin_bits, at, size_bits, limit_bits, out, opos, sym_cap, lst, lane);
+            const uint32_t e = decode_block(L, in, origin_bits, at, size_bits, limit_bits, out, opos, sym_cap, lst, lane, prof);
             __syncthreads();
             rd.ring_hi = 0; rd.rd_dw = 0;            // (the ring's bytes were the expansion's in between: whoever seeks next loads it again)
             if (e == B_OVERFLOW) { status = GZ_OVERFLOW; break; }
@@ -1006,6 +1187,11 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
         if (status == GZ_FAILED) res.n_sym = why;
         res.status = status;
         chunks[c] = res;
+#ifdef GZ_PROFILE
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(lst);
+        for (int i = 0; i < 8; i++) pp[i] = prof.t[i];
+        pp[8] = __builtin_readcyclecounter() - prof_begin;
+#endif
     }
 }
 
@@ -1184,7 +1370,7 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *text, uint64
 } // namespace
 
 // scratch for the lane-parallel decoder: 64 lanes x LCAP list entries per chunk of a launch
-size_t gz_decode_scratch_bytes(uint32_t n_chunks) { return (size_t)n_chunks * 64 * LCAP * sizeof(uint32_t); }
+size_t gz_decode_scratch_bytes(uint32_t n_chunks) { return (size_t)n_chunks * 2 * 64 * LCAP * sizeof(uint32_t); }
 bool gz_decode_serial()       // MF_GZDEV_KERNEL=serial: the one-lane walk of round 3 (A/B runs); default: the lane-parallel kernel
 {
     static const bool serial = [] { const char *v = getenv("MF_GZDEV_KERNEL"); return v && strcmp(v, "serial") == 0; }();

@@ -38,6 +38,9 @@ hipError_t launch_store_bits(const uint32_t *batch_bits, uint64_t n_rec, uint32_
 // line ends when kept (bits_a[r] | bits_b[r], or & when both; bits_b may be nullptr), else 0
 hipError_t launch_out_lens(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t rec_base, const uint32_t *bits_a,
                            const uint32_t *bits_b, int both, uint32_t *out_len, hipStream_t st);
+// the same two steps over a list of records: out_len[i] = output bytes of record sel[i]; the records go to out[out_off[i] ..]
+hipError_t launch_sel_lens(const uint8_t *text, const uint64_t *line_start, const uint32_t *sel, uint64_t n_sel, uint32_t *out_len, hipStream_t st);
+hipError_t launch_sel_gather(const uint8_t *text, const uint64_t *line_start, const uint32_t *sel, uint64_t n_sel, const uint64_t *out_off, uint8_t *out, hipStream_t st);
 // copies the kept records to out[out_off[r] ..] (out_off = exclusive scan of out_len)
 hipError_t launch_gather(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, const uint32_t *out_len, const uint64_t *out_off,
                          uint8_t *out, hipStream_t st);

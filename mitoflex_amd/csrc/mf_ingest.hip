@@ -259,6 +259,29 @@ __global__ __launch_bounds__(256) void out_lens_kernel(const uint8_t *text, cons
     if (keep) { const RecSpan x = rec_span(text, line_start, r); n = x.hl + x.sl + x.ql + 5; }      // header LF seq LF '+' LF qual LF
     out_len[r] = n;
 }
+// the same for a short list of records (sel: their indices, ascending): what survives a bait filter is a fraction of a per cent of
+// the records, and kernels over the list cost nothing beside kernels over every record
+__global__ __launch_bounds__(256) void sel_lens_kernel(const uint8_t *text, const uint64_t *line_start, const uint32_t *sel, uint64_t n_sel, uint32_t *out_len)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_sel) return;
+    const RecSpan x = rec_span(text, line_start, sel[i]);
+    out_len[i] = x.hl + x.sl + x.ql + 5;
+}
+__global__ __launch_bounds__(256) void sel_gather_kernel(const uint8_t *text, const uint64_t *line_start, const uint32_t *sel, uint64_t n_sel, const uint64_t *out_off, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // one wavefront per record
+    if (i >= n_sel) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const RecSpan x = rec_span(text, line_start, sel[i]);
+    uint8_t *o = out + out_off[i];
+    for (uint32_t k = lane; k < x.hl; k += 64) o[k] = text[x.h + k];
+    o += x.hl;
+    for (uint32_t k = lane; k < x.sl; k += 64) o[1 + k] = text[x.s + k];
+    if (lane == 0) { o[0] = '\n'; o[1 + x.sl] = '\n'; o[2 + x.sl] = '+'; o[3 + x.sl] = '\n'; o[4 + x.sl + x.ql] = '\n'; }
+    o += x.sl + 4;
+    for (uint32_t k = lane; k < x.ql; k += 64) o[k] = text[x.q + k];
+}
 __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, const uint32_t *out_len,
                                                      const uint64_t *out_off, uint8_t *out)
 {
@@ -346,6 +369,20 @@ hipError_t launch_out_lens(const uint8_t *text, const uint64_t *line_start, uint
 {
     if (!n_rec) return hipSuccess;
     hipLaunchKernelGGL(out_lens_kernel, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, text, line_start, n_rec, rec_base, bits_a, bits_b, both, out_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_sel_lens(const uint8_t *text, const uint64_t *line_start, const uint32_t *sel, uint64_t n_sel, uint32_t *out_len, hipStream_t st)
+{
+    if (!n_sel) return hipSuccess;
+    hipLaunchKernelGGL(sel_lens_kernel, dim3((uint32_t)((n_sel + 255) / 256)), dim3(256), 0, st, text, line_start, sel, n_sel, out_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_sel_gather(const uint8_t *text, const uint64_t *line_start, const uint32_t *sel, uint64_t n_sel, const uint64_t *out_off, uint8_t *out, hipStream_t st)
+{
+    if (!n_sel) return hipSuccess;
+    hipLaunchKernelGGL(sel_gather_kernel, dim3((uint32_t)((n_sel + 3) / 4)), dim3(256), 0, st, text, line_start, sel, n_sel, out_off, out);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ EXPORTS = (
     "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_resident_passes", "mf_filter_packed",
-    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_qualfilter_files",
+    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_last_ingest_stats", "mf_h2d_bandwidth", "mf_qualfilter_files",
 )
 
 
@@ -56,6 +56,17 @@ class FilterStats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class IngestStats(C.Structure):
+    _fields_ = [("path", C.c_int32), ("n_devices", C.c_int32), ("consumers", C.c_int32), ("reserved", C.c_int32),
+                ("input_bytes", C.c_uint64), ("text_bytes", C.c_uint64), ("records", C.c_uint64),
+                ("seconds", C.c_double), ("decode_busy_seconds", C.c_double),
+                ("pool_bytes_peak", C.c_uint64), ("device_bytes_peak", C.c_uint64),
+                ("chunks", C.c_uint64), ("chunks_linked", C.c_uint64), ("gaps", C.c_uint64), ("gap_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
 _lib = None
@@ -101,6 +112,8 @@ def load(path: Optional[str] = None):
                                         C.c_int, u64p, u64p]
     L.mf_filter_fastq_files_on.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
                                            C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mf_last_ingest_stats.argtypes = [C.POINTER(IngestStats)]
+    L.mf_h2d_bandwidth.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                       C.c_uint32, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
                                       C.POINTER(C.c_int)]
@@ -303,6 +316,20 @@ def filter_fastq_files(ks: KmerSet, fq1: str, fq2: Optional[str], out1: str, out
         _chk(load().mf_filter_fastq_files(ks._h, _enc(fq1), _enc(fq2), _enc(out1), _enc(out2), threshold, pair_mode,
                                           n_devices, C.byref(kept), C.byref(total)))
     return kept.value, total.value
+
+
+def last_ingest_stats() -> dict:
+    """What this thread's last filter_fastq_files call did: which ingest path, bytes, seconds, device memory, decoder counters."""
+    st = IngestStats()
+    _chk(load().mf_last_ingest_stats(C.byref(st)))
+    return st.as_dict()
+
+
+def h2d_bandwidth(device: int = 0, nbytes: int = 1 << 30, reps: int = 3) -> float:
+    """GB/s of a pinned host-to-device copy on this box (the roof of the device ingest path)."""
+    v = C.c_double()
+    _chk(load().mf_h2d_bandwidth(device, nbytes, reps, C.byref(v)))
+    return v.value
 
 
 def qualfilter_files(fq1: Optional[str], fq2: Optional[str], out1: str, out2: Optional[str], start: int = 0, end: int = 0,

@@ -75,6 +75,16 @@ int main(int argc, char **argv)
         if (ms < best) best = ms;
         printf("  decode kernel: %.3f ms\n", ms);
     }
+#ifdef GZ_PROFILE
+    if (d_scratch) {          // cycle counts per phase, summed over the chunks (the kernel leaves them at the head of every chunk's list scratch)
+        const size_t per = mf::gz_decode_scratch_bytes(1);
+        unsigned long long tot[9] = {0}, v[9];
+        for (uint32_t c = 0; c < n_chunks; c++) { CK(hipMemcpy(v, (const char *)d_scratch + (size_t)c * per, sizeof v, hipMemcpyDeviceToHost)); for (int i = 0; i < 9; i++) tot[i] += v[i]; }
+        printf("  cycles per chunk (s_memtime, 100 MHz): search + header %.0f | tables %.0f | walks %.0f | expansion %.0f | whole %.0f ;  per chunk: %.1f blocks, %.1f steps, %.1f walk rounds, %.1f expansion rounds\n",
+               (double)tot[0] / n_chunks, (double)tot[1] / n_chunks, (double)tot[2] / n_chunks, (double)tot[3] / n_chunks, (double)tot[8] / n_chunks,
+               (double)tot[7] / n_chunks, (double)tot[4] / n_chunks, (double)tot[5] / n_chunks, (double)tot[6] / n_chunks);
+    }
+#endif
     std::vector<mf::GzChunk> ch(n_chunks);
     CK(hipMemcpy(ch.data(), d_chunks, n_chunks * sizeof(mf::GzChunk), hipMemcpyDeviceToHost));
     std::vector<uint16_t> sym(cap);
