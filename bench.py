@@ -19,10 +19,13 @@ host cores and checks every GPU pass bit against it.
 Ranks are independent (each filters its own shard, no collective); the launcher's RANK / WORLD_SIZE are all this
 script needs, so torch is never imported: the barrier and the max over ranks go through a directory in /dev/shm.
 
-Beside the headline, at N = 1 (`extra`): files in / files out -- a bounded PE / SE run and configs[4] at its stated size
-(33 333 334 single-end reads, one gzip member, device ingest: inflate, line index, pack, filter on the GPU) -- and the
-Group-A row of BASELINE.md (the contig filter CLI on the 1 M-record generator file of SURVEY.md 8c).  Every input file is made
-BEFORE this process touches the GPU, by child processes that do not inherit a profiler's environment.
+Beside the headline, at N = 1 (`extra`): files in / files out -- a bounded PE / SE run, configs[4] at its stated size
+(33 333 334 single-end reads, one gzip member, device ingest: inflate, line index, pack, filter on the GPU; priced against the
+box's host-to-device copy rate, its roof) and an eighth of it compressed by the compressors people use (gzip, pigz, bgzip where the
+box has them) --, configs[2]'s other k (21 and 41) on the same resident reads (`extra.k_sweep`), and the Group-A row of
+BASELINE.md (the contig filter CLI on the 1 M-record generator file of SURVEY.md 8c).  At N > 1 every rank also filters a
+.gz shard of its own, file to file, on its own GPU (`extra.per_gpu_file_reads_per_s`).  Every input file is made BEFORE this
+process touches the GPU, by child processes that do not inherit a profiler's environment.
 """
 import argparse
 import json
@@ -58,6 +61,10 @@ def parse():
     ap.add_argument("--e2e-full-reads", type=int, default=READS_5GBP,
                     help="reads of the single-end .gz file of configs[4] that is filtered file to file (default: its stated size, 5 Gbp; 0 = skip)")
     ap.add_argument("--no-group-a", action="store_true", help="skip the Group-A row (contig filter CLI on the 1 M-record generator file)")
+    ap.add_argument("--real-gz-reads", type=int, default=READS_5GBP // 8,
+                    help="reads of the single-end file that gzip / pigz / bgzip compress themselves (default: an eighth of configs[4]; 0 = skip)")
+    ap.add_argument("--k-sweep", default="21,41", help="other k of configs[2] timed on the same resident reads, a few steps each ('' = none)")
+    ap.add_argument("--rank-file-reads", type=int, default=500_000, help="N > 1: reads of the .gz shard every rank filters file to file on its own GPU (0 = skip)")
     return ap.parse_args()
 
 
@@ -248,6 +255,15 @@ def prepare_inputs(a, tmp, solo=True):
             with open(os.path.join(tmp, "s_1.fq.gz"), "wb") as g:
                 subprocess.check_call(["gzip", "-1", "-c", os.path.join(tmp, "s_1.fq")], stdout=g, env=env)
             files["small"] = os.path.join(tmp, "s")
+        real = []
+        if a.real_gz_reads > 0 and solo and shutil.which("gzip"):
+            # the same kind of reads, compressed by the tools themselves (single-threaded gzip takes its minute: started now, waited for below)
+            run([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(tmp, "r"), "--pairs", str(a.real_gz_reads), "--mates", "1", "--block", "2000000"])
+            src = os.path.join(tmp, "r_1.fq")
+            for name, cmd in (("gzip-6", ["gzip", "-6", "-c", src]), ("pigz-6", ["pigz", "-6", "-c", src]), ("bgzip", ["bgzip", "-c", src])):
+                if shutil.which(cmd[0]):
+                    out = os.path.join(tmp, "r_1.%s.fq.gz" % name)
+                    real.append((name, out, subprocess.Popen(cmd, stdout=open(out, "wb"), env=env)))
         if a.e2e_full_reads > 0 and solo:                 # (configs[4] is a one-GPU configuration: the other ranks of a multi-rank run would only wait for the file)
             need = a.e2e_full_reads * 321 * 1.7
             if shutil.disk_usage(tmp).free < need:
@@ -262,6 +278,9 @@ def prepare_inputs(a, tmp, solo=True):
         if not a.no_group_a and solo:
             run([sys.executable, "-c", G20_GENERATOR, os.path.join(tmp, "g20.fa")])
             files["g20"] = os.path.join(tmp, "g20.fa")
+        for name, out, proc in real:
+            if proc.wait() == 0:
+                files.setdefault("real", {"plain": os.path.join(tmp, "r_1.fq"), "bait": os.path.join(tmp, "r.bait.fa"), "gz": {}})["gz"][name] = out
     except Exception as e:
         files["error"] = str(e)[:200]
     return files
@@ -283,7 +302,7 @@ def e2e_files(mf, ks, files, a):
         out["pe_plain_reads_per_s"] = run(t + "_1.fq", t + "_2.fq", t + "_o1.fq", t + "_o2.fq", 2 * a.e2e_pairs)[0]
         out["se_gz_reads_per_s"] = run(t + "_1.fq.gz", None, t + "_og.fq", None, a.e2e_pairs)[0]
         out["pairs"] = a.e2e_pairs
-        out["note_small"] = "small inputs (the SE .gz has `pairs` reads): a call's fixed latencies dominate -- a 64 KiB chunk takes a wavefront ~12 ms to decode, whatever the file size; configs4_se_gz is the throughput figure"
+        out["note_small"] = "small inputs (the SE .gz has `pairs` reads): a call's fixed latencies dominate; configs4_se_gz is the throughput figure"
     if "full" in files:
         # configs[4] at its stated size: one gzip member of single-end reads, device ingest (inflate, line index, 2-bit pack, filter
         # and survivor copy on the GPU).  Checked against the host pipeline on the plain text of the same reads, byte for byte.
@@ -298,10 +317,24 @@ def e2e_files(mf, ks, files, a):
         else:
             os.environ["MF_INGEST"] = prev
         rate, secs, res = run(t + "_1.fq.gz", None, t + "_od.fq", None, n)
+        ist = mf.last_ingest_stats()                 # (of the last of the three calls)
         md5 = md5_of(t + "_od.fq")
+        gz_bytes = os.path.getsize(t + "_1.fq.gz")
+        try:
+            h2d = mf.h2d_bandwidth(0, 1 << 30, 3)
+        except Exception:
+            h2d = None
         out["configs4_se_gz"] = {
+            # the leg's roof: its input crosses PCIe once, as it lies on disk -- compressed bytes over the time of the whole call, against a
+            # pinned host-to-device copy of 1 GiB measured on this box in this process
+            "roofline": {"bound": "pcie_h2d", "achieved": gz_bytes / secs / 1e9, "peak": h2d, "unit": "GB/s", "frac": (gz_bytes / secs / 1e9 / h2d) if h2d else None,
+                         "note": "compressed input bytes / seconds of the whole call (file in the page cache -> survivors written)"},
+            "inflate_kernels": {"busy_seconds": ist["decode_busy_seconds"], "text_GB_per_s": (ist["text_bytes"] / ist["decode_busy_seconds"] / 1e9) if ist["decode_busy_seconds"] > 0 else None,
+                                "note": "time with at least one gz_decode kernel running (HIP events around every launch), while upload, link step and the consumers' kernels share the device"},
+            "ingest_path": "device" if ist["path"] == 1 else "host", "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9, "call_buffers_peak_GB": ist["pool_bytes_peak"] / 1e9,
+            "chunks": ist["chunks"], "chunks_linked": ist["chunks_linked"], "gaps_bridged_on_host": ist["gaps"],
             "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), "kept": int(res[0]), "total": int(res[1]),
-            "gz_bytes": os.path.getsize(t + "_1.fq.gz"), "text_bytes": os.path.getsize(t + "_1.fq"),
+            "gz_bytes": gz_bytes, "text_bytes": os.path.getsize(t + "_1.fq"),
             "input": "synthetic single-end FASTQ (tools/make_fastq.py), ONE gzip member written by tools/pgzip.py at level 6 (8 MiB slices)",
             "ingest": "device: compressed bytes uploaded as they are; inflate, line index, 2-bit pack, filter, survivor copy on the GPU",
             "output_md5": md5, "output_equals_host_pipeline_on_plain_text": bool(md5 == md5_of(t + "_oh.fq") and tuple(res) == tuple(host_res)),
@@ -309,7 +342,38 @@ def e2e_files(mf, ks, files, a):
             "prep_seconds": files.get("full_prep_seconds")}
     elif "full_note" in files:
         out["configs4_se_gz"] = {"skipped": files["full_note"]}
+    if "real" in files:
+        # an eighth of configs[4], compressed by gzip / pigz / bgzip themselves (not by this repository's tools/pgzip.py): the same
+        # call, checked against the host pipeline on the plain text of the same reads
+        r = files["real"]
+        n = a.real_gz_reads
+        rks = mf.KmerSet.from_fasta(r["bait"], a.k)
+        prev = os.environ.get("MF_INGEST")
+        os.environ["MF_INGEST"] = "host"
+        _, _, host_res = run2(mf, rks, r["plain"], r["plain"] + ".host.out", 1)
+        if prev is None:
+            del os.environ["MF_INGEST"]
+        else:
+            os.environ["MF_INGEST"] = prev
+        host_md5 = md5_of(r["plain"] + ".host.out")
+        legs = {}
+        for name, path in sorted(r["gz"].items()):
+            secs, _, res = run2(mf, rks, path, path + ".out", 3)
+            ist = mf.last_ingest_stats()
+            legs[name] = {"reads_per_s": n / secs, "seconds": round(secs, 4), "gz_bytes": os.path.getsize(path), "ingest_path": "device" if ist["path"] == 1 else "host (BGZF members are decoded side by side on the host)",
+                          "output_equals_host_pipeline_on_plain_text": bool(md5_of(path + ".out") == host_md5 and tuple(res) == tuple(host_res))}
+        out["real_compressors"] = {"reads": n, "files": legs}
     return out
+
+
+def run2(mf, ks, f1, o1, reps):
+    """best seconds of `reps` single-end file-to-file calls, rate placeholder, (kept, total)"""
+    best, res = 1e9, None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = mf.filter_fastq_files(ks, f1, None, o1, None)
+        best = min(best, time.perf_counter() - t0)
+    return best, None, res
 
 
 def group_a(files):
@@ -354,6 +418,19 @@ def main():
     if rank == 0 and not solo:
         a.e2e_full_reads, a.no_group_a = 0, True     # with several ranks only the small paired set is made (file level over all devices)
     files = prepare_inputs(a, tmpdir.name, solo) if rank == 0 else {}
+    # N > 1: a .gz shard of its own for every rank (file level on its own GPU, beside the resident rate), made by child processes now
+    rank_tmp, rank_gz = None, None
+    if world > 1 and a.rank_file_reads > 0 and not being_profiled():
+        try:
+            rank_tmp = tempfile.TemporaryDirectory(prefix="mf_bench_r%d_" % rank, dir="/tmp")
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(rank_tmp.name, "k"), "--pairs", str(a.rank_file_reads),
+                                   "--mates", "1", "--seed", str(777 + rank)], env=child_env(), stdout=subprocess.DEVNULL)
+            with open(os.path.join(rank_tmp.name, "k_1.fq.gz"), "wb") as g:
+                subprocess.check_call(["gzip", "-1", "-c", os.path.join(rank_tmp.name, "k_1.fq")], stdout=g, env=child_env())
+            rank_gz = os.path.join(rank_tmp.name, "k_1.fq.gz")
+        except Exception:
+            rank_gz = None
+        os.environ.setdefault("MF_DEVPOOL_GB", "4")       # (ranks of one node: what a process keeps between calls stays small)
     live, valu = (None, None), (None, None)
     default_set = a.reads == READS_5GBP
     if solo and not a.no_live_traffic and default_set:
@@ -366,7 +443,7 @@ def main():
         os.environ["MF_HOST_THREADS"] = str(max(1, (os.cpu_count() or 1) // local_world))
     from mitoflex_amd import mitofilter as mf
     mf.load()
-    from tests.util_data import make_bait
+    from mitoflex_amd.utility.synth_bait import make_bait
     bait = make_bait()
     n_dev = mf.device_count()
     if local_world > max(1, n_dev) and os.environ.get("MF_BENCH_SHARE_GPU") != "1":
@@ -431,15 +508,11 @@ def main():
     if solo:
         one = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, 1)    # a single step: nothing to overlap with
         extra["ms_single_pass_latency"] = round(one.ms_total, 4)
-        # the same kernel with the device to itself (MF_PASS=serial: one stream, no overlap between steps), every dispatch sampled
-        prev = os.environ.get("MF_PASS")
-        os.environ["MF_PASS"] = "serial"; os.environ["MF_EVENT_STRIDE"] = "1"
+        # the same kernel with the device to itself (option pass=serial: one stream, no overlap between steps), every dispatch sampled
+        mf.set_option("pass", "serial"); os.environ["MF_EVENT_STRIDE"] = "1"
         alone = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_SCREENED, min(a.steps, 20))
         os.environ["MF_EVENT_STRIDE"] = "8"
-        if prev is None:
-            del os.environ["MF_PASS"]
-        else:
-            os.environ["MF_PASS"] = prev
+        mf.set_option("pass", os.environ.get("MF_PASS", "default") if os.environ.get("MF_ENV_KNOBS") == "1" else "default")
         if alone.ms_screen > 0:
             alone_frac = alg_bytes / (alone.ms_screen / 1e3) / 1e9 / HBM_PEAK_GBPS
             extra["screen_kernel_alone"] = {"ms": round(alone.ms_screen, 4), "frac_of_hbm_peak": round(alone_frac, 4),
@@ -450,6 +523,33 @@ def main():
         ex = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_EXHAUSTIVE, 1)
         extra["exhaustive_reads_per_s"] = a.reads / (ex.ms_total / 1e3)
         extra["exhaustive_passed"] = int(ex.n_pass)
+
+    if solo and a.k_sweep:
+        # configs[2]: the other k on the same resident reads (a few steps each: set built on the device, warm-up, timed loop, sampled loop)
+        sweep = {}
+        for kk in [int(x) for x in a.k_sweep.split(",") if x.strip()]:
+            if kk == a.k:
+                continue
+            try:
+                ks2 = mf.KmerSet.from_text(bait, kk, dev)
+                n_st = min(a.steps, 20)
+                os.environ["MF_EVENT_STRIDE"] = "1000000000"
+                mf.filter_resident(ks2, reads, THRESHOLD, mf.MODE_SCREENED, 10)
+                mf.device_synchronize(dev)
+                c0 = time.perf_counter()
+                s2 = mf.filter_resident(ks2, reads, THRESHOLD, mf.MODE_SCREENED, n_st)
+                mf.device_synchronize(dev)
+                dt = time.perf_counter() - c0
+                os.environ["MF_EVENT_STRIDE"] = "1"
+                sp2 = mf.filter_resident(ks2, reads, THRESHOLD, mf.MODE_SCREENED, n_st)
+                os.environ["MF_EVENT_STRIDE"] = "8"
+                sweep[str(kk)] = {"reads_per_s": a.reads * n_st / dt, "ms_per_step": dt / n_st * 1e3, "steps": n_st, "passed": int(s2.n_pass),
+                                  "ms_screen_kernel": round(sp2.ms_screen, 4), "whole_pass_frac_of_hbm_peak": round(alg_bytes / (dt / n_st) / 1e9 / HBM_PEAK_GBPS, 4),
+                                  "bound": "valu (stride-8 screen)" if kk < 28 else "hbm"}
+                ks2.close()
+            except Exception as e:
+                sweep[str(kk)] = {"error": str(e)[:160]}
+        extra["k_sweep"] = sweep
 
     cpu = None
     if want_cpu:
@@ -507,6 +607,29 @@ def main():
         elif rank == 0:
             extra["file_level_all_devices"] = {"skipped": "fewer visible devices than ranks" if n_dev < world else "no input files"}
         rdv.barrier(timeout=1800.0)
+        # every rank's own .gz shard, file to file, through the device ingest path on its own GPU (one process per GPU: the form in which
+        # .gz input scales over a node -- `--devices N` in one process deals one stream's slabs to N devices instead)
+        mine_rate, path = 0.0, -1
+        if rank_gz:
+            try:
+                reads.close()
+                best = 1e9
+                for _ in range(3):
+                    c0 = time.perf_counter()
+                    mf.filter_fastq_files(ks, rank_gz, None, rank_gz + ".out", None, devices=[dev])
+                    best = min(best, time.perf_counter() - c0)
+                mine_rate = a.rank_file_reads / best
+                path = mf.last_ingest_stats()["path"]
+            except Exception:
+                mine_rate = 0.0
+        rates = rdv.gather(mine_rate, timeout=1800.0)
+        paths = rdv.gather(float(path), timeout=1800.0)
+        if rank == 0:
+            extra["per_gpu_file_reads_per_s"] = rates
+            extra["file_level_one_process_per_gpu"] = {"reads_per_rank": a.rank_file_reads, "aggregate_reads_per_s": sum(rates), "device_ingest_on_every_rank": all(p == 1.0 for p in paths),
+                                                       "note": "each rank: its own gzip -1 shard -> mf_filter_fastq_files_on(devices=[its GPU]); small shards, a call's fixed latencies dominate; MF_DEVPOOL_GB=4 per rank"}
+    if rank_tmp is not None:
+        rank_tmp.cleanup()
     if tmpdir is not None:
         tmpdir.cleanup()
 

@@ -210,6 +210,13 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2,
                              const int *devices, int n_devices,
                              uint64_t *kept, uint64_t *total);
 
+/* Options that select which kernels a filter pass runs (process-wide; every variant gives the same bits and is parity-tested):
+ *   pass=default|split|serial   adapt=0|1   finish_streams=0|1|2   screen_streams=1|2   split_pipe=0|1   exact_co=0|1
+ * The library does NOT take these from the environment in a production process: the MF_PASS, MF_ADAPT, MF_FINISH_STREAMS,
+ * MF_SCREEN_STREAMS, MF_SPLIT_PIPE and MF_EXACT_CO variables only count when MF_ENV_KNOBS=1 is set beside them (tests, bench.py,
+ * profiling scripts).  ABI 3. */
+int mf_set_option(const char *name, const char *value);
+
 /* What the calling thread's last successful mf_filter_fastq_files / _on call did (ABI 3).  path: which
  * of the library's two ingest paths took the input. */
 enum { MF_INGEST_PATH_HOST = 0, MF_INGEST_PATH_DEVICE = 1 };

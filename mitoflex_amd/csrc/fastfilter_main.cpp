@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 // ------------------------------------------------------------ error exits
@@ -427,6 +428,7 @@ static int bait_main(int argc, char **argv)
     std::string bait, fq1, fq2, out1, out2, pair = "either", libpath;
     int k = 0, devices = 1, gcode = 5; unsigned thr = 1; bool protein = false;
     std::vector<int> device_list;              // --device-list 2,3: these devices instead of 0 .. N - 1
+    std::vector<std::pair<std::string, std::string>> options;      // --option pass=serial: how a filter pass is run (mf_set_option)
     for (int a = 2; a < argc; a++) {
         std::string o = argv[a];
         auto need = [&](const char *name) -> std::string {
@@ -448,13 +450,18 @@ static int bait_main(int argc, char **argv)
             for (size_t i = 0; i < v.size();) { size_t j = v.find(',', i); if (j == std::string::npos) j = v.size(); if (j > i) device_list.push_back(atoi(v.substr(i, j - i).c_str())); i = j + 1; }
             if (device_list.empty()) { fprintf(stderr, "error: --device-list wants device numbers separated by commas\n"); return 1; }
         }
+        else if (o == "--option") {
+            const std::string v = need("--option"); const size_t eq = v.find('=');
+            if (eq == std::string::npos || eq == 0) { fprintf(stderr, "error: --option wants name=value\n"); return 1; }
+            options.emplace_back(v.substr(0, eq), v.substr(eq + 1));
+        }
         else if (o == "--protein") protein = true;                       // --bait is a protein FASTA (e.g. profile/MT_database/<clade>.fa)
         else if (o == "--code" || o == "--genetic-code") gcode = atoi(need("--code").c_str());
         else { fprintf(stderr, "error: unknown option '%s' for fastfilter bait\n", o.c_str()); return 1; }
     }
     if (bait.empty() || fq1.empty() || out1.empty() || (fq2.empty() != out2.empty()) || (pair != "either" && pair != "both")) {
         fputs("usage: fastfilter bait --bait BAIT.fa [-k 31] [-t 1] --fq1 R1.fq [--fq2 R2.fq] --out1 O1.fq [--out2 O2.fq]"
-              " [--pair either|both] [--devices N | --device-list D0,D1,..]\n"
+              " [--pair either|both] [--devices N | --device-list D0,D1,..] [--option name=value ..]\n"
               "       fastfilter bait --protein --bait PROTEINS.fa [--code 5] [-k 9] ...   (six-frame peptide k-mers)\n", stderr);
         return 1;
     }
@@ -464,9 +471,10 @@ static int bait_main(int argc, char **argv)
     if (!h) { fprintf(stderr, "error: cannot load %s: %s (the bait filter has no CPU fallback)\n", libpath.c_str(), dlerror()); return 2; }
 #define SYM(name) auto p_##name = (decltype(&name))dlsym(h, #name); if (!p_##name) { fprintf(stderr, "error: %s lacks symbol %s\n", libpath.c_str(), #name); return 2; }
     SYM(mf_abi_version) SYM(mf_last_error) SYM(mf_kmerset_build_from_fasta) SYM(mf_kmerset_build_protein_from_fasta)
-    SYM(mf_filter_fastq_files) SYM(mf_filter_fastq_files_on) SYM(mf_kmerset_free)
+    SYM(mf_filter_fastq_files) SYM(mf_filter_fastq_files_on) SYM(mf_kmerset_free) SYM(mf_set_option)
 #undef SYM
     if (p_mf_abi_version() != MF_ABI_VERSION) { fprintf(stderr, "error: ABI version mismatch\n"); return 2; }
+    for (auto &kv : options) if (p_mf_set_option(kv.first.c_str(), kv.second.c_str()) != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 1; }
     mf_kmerset *ks = nullptr;
     const int dev0 = device_list.empty() ? 0 : device_list[0];
     const int brc = protein ? p_mf_kmerset_build_protein_from_fasta(bait.c_str(), k, gcode, dev0, &ks)

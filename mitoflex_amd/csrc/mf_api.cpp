@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -413,11 +414,46 @@ int mf_kmerset_free(mf_kmerset *ks)
 // How a screened pass is run.  Default: screen_kernel, then finish_kernel when the threshold is 1 and no hit counts are wanted
 // (mark_kernel + exact_kernel otherwise).  MF_PASS=split: always screen, mark, exact.  MF_PASS=serial: screen + finish
 // without overlapping consecutive passes (for comparison).
-static int pass_kind()          // (looked up on every pass: bench.py times the serial form next to the default one in one process)
+// The switches that select WHICH KERNELS a pass runs live in one options block.  A production process never reads them from the
+// environment: they are set through mf_set_option (the CLI's --option name=value), or -- for the test suite, bench.py and the profiling
+// scripts -- taken from the MF_* variables when MF_ENV_KNOBS=1 says so.  Every variant is parity-tested (tests/test_gpu_parity.py).
+struct PassOptions {
+    std::atomic<int> pass{0};             // 0 default (screen + finish, pipelined) | 1 split | 2 serial            "pass"            MF_PASS
+    std::atomic<int> adapt{1};            // switch the pass kind from the previous call's tallies                   "adapt"           MF_ADAPT
+    std::atomic<int> finish_streams{0};   // 0 by tallies | 1 | 2                                                    "finish_streams"  MF_FINISH_STREAMS
+    std::atomic<int> screen_streams{2};   // consecutive screens on one stream or on two in turn                     "screen_streams"  MF_SCREEN_STREAMS
+    std::atomic<int> split_pipe{1};       // the candidate-bitmap pass pipelined                                     "split_pipe"      MF_SPLIT_PIPE
+    std::atomic<int> exact_co{0};         // the co-resident exact kernel behind every screen (tests)                "exact_co"        MF_EXACT_CO
+};
+static PassOptions g_opt;
+static int set_option(const char *name, const char *value)
 {
-    const char *v = getenv("MF_PASS");
-    return v && strcmp(v, "split") == 0 ? 1 : (v && strcmp(v, "serial") == 0 ? 2 : 0);
+    const std::string n = name ? name : "", v = value ? value : "";
+    if (n == "pass") { if (v == "" || v == "default") g_opt.pass = 0; else if (v == "split") g_opt.pass = 1; else if (v == "serial") g_opt.pass = 2; else return -1; return 0; }
+    char *end = nullptr; const long x = strtol(v.c_str(), &end, 10);
+    if (v.empty() || *end) return -1;
+    if (n == "adapt") g_opt.adapt = x != 0;
+    else if (n == "finish_streams") { if (x < 0 || x > 2) return -1; g_opt.finish_streams = (int)x; }
+    else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
+    else if (n == "split_pipe") g_opt.split_pipe = x != 0;
+    else if (n == "exact_co") g_opt.exact_co = x != 0;
+    else return -1;
+    return 0;
 }
+static void options_from_env_once()
+{
+    static const bool done = [] {
+        const char *k = getenv("MF_ENV_KNOBS");
+        if (k && k[0] == '1') {
+            static const char *const pairs[][2] = {{"pass", "MF_PASS"}, {"adapt", "MF_ADAPT"}, {"finish_streams", "MF_FINISH_STREAMS"}, {"screen_streams", "MF_SCREEN_STREAMS"},
+                                                   {"split_pipe", "MF_SPLIT_PIPE"}, {"exact_co", "MF_EXACT_CO"}};
+            for (auto &p : pairs) { const char *v = getenv(p[1]); if (v && *v && set_option(p[0], v) != 0) fprintf(stderr, "libmitofilter_hip: %s=%s is not a value of option '%s' (ignored)\n", p[1], v, p[0]); }
+        }
+        return true;
+    }();
+    (void)done;
+}
+static int pass_kind() { options_from_env_once(); return g_opt.pass; }          // (looked up on every pass: bench.py times the serial form next to the default one in one process)
 
 void reads_release(mf_reads *r)
 {
@@ -653,12 +689,12 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // before the next screen is and one stream carries them all; when they are what a pass waits for (bait-rich input: 2 % bait
         // reads and more, seen in the last call's tallies) those of consecutive passes go to two streams and run side by side --
         // 2 %: 0.303 -> 0.280 ms per pass, 10 %: 0.666 -> 0.596; at 0.5 % the same costs 2 % (0.208 -> 0.213).  MF_FINISH_STREAMS=1 / 2 forces.
-        static const uint32_t fin_streams = env_u32("MF_FINISH_STREAMS", 0);
+        const uint32_t fin_streams = (uint32_t)g_opt.finish_streams;
         const bool fin2 = fin_streams == 2 || (fin_streams == 0 && r->finish_two);
         hipStream_t sf = two ? ((fin2 && (q & 1)) ? ctx->stream4 : ctx->stream2) : st;
         // consecutive screens go to two streams in turn: nothing orders them against each other (different buffer sets), so the
         // workgroups of the next screen take over the CUs as the last ones of this screen drain (MF_SCREEN_STREAMS=1: one stream)
-        static const bool alt = env_u32("MF_SCREEN_STREAMS", 2) == 2;
+        const bool alt = g_opt.screen_streams == 2;
         hipStream_t ss = (two && alt && (q & 1)) ? ctx->stream3 : st;
         if (two) HIPCHK(hipStreamWaitEvent(ss, r->ev_finish[q], 0));           // the finish kernels of NSETS passes ago read this set
         // cross-stream order without marker packets in the screen's stream: the events ride on the dispatches themselves
@@ -678,8 +714,8 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
     }
     // split / exhaustive: no per-pass memsets -- the exact kernel clears the candidate words it consumes, writes every
     // result word and zeroes unused tally slots
-    static const bool split_pipe = env_u32("MF_SPLIT_PIPE", 1) != 0;
-    static const bool exact_co = env_u32("MF_EXACT_CO", 0) != 0;           // (tests: the co-resident exact kernel behind every screen)
+    const bool split_pipe = g_opt.split_pipe != 0;
+    const bool exact_co = g_opt.exact_co != 0;           // (tests: the co-resident exact kernel behind every screen)
     if (screened && !count_all && overlap && split_pipe && pass_kind() != 2 && !r->split_serial) {
         // The three-kernel pass, pipelined like the one above: pass i works on buffer set i mod 2 (records, candidate
         // bitmap, result bitmap, tallies); its mark and exact kernels go to the second stream and run beside the screen of
@@ -692,7 +728,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
             HIPCHK(dev_reserve(r->d_rec_counts[q], c1, r->cap_rec_counts, false));
         }
         if (!r->d_cand[q]) { size_t c = 0; HIPCHK(dev_reserve(r->d_cand[q], c, r->cap_bitmap, false)); r->cand_clean[q] = false; }
-        static const bool alt = env_u32("MF_SCREEN_STREAMS", 2) == 2;
+        const bool alt = g_opt.screen_streams == 2;
         hipStream_t ss = (alt && (q & 1)) ? ctx->stream3 : st, sf = ctx->stream2;
         HIPCHK(hipStreamWaitEvent(ss, r->ev_finish[q], 0));                    // the exact kernel of NSETS passes ago worked on this set
         if (!r->cand_clean[q]) { HIPCHK(hipMemsetAsync(r->d_cand[q], 0, r->bitmap_bytes, ss)); r->cand_clean[q] = true; }
@@ -781,7 +817,7 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
             for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) n += q[2 * i];
             pass_per_step[s] = n;
         }
-    static const bool adapt = env_u32("MF_ADAPT", 1) != 0;          // (MF_ADAPT=0: measurements of the sample pass on bait-rich input)
+    const bool adapt = g_opt.adapt != 0;          // (adapt = 0: measurements of the sample pass on bait-rich input)
     if (adapt && !T->view.prot && mode == MF_MODE_SCREENED && T->view.s > 0 && r->v.n_reads >= 100000) {
         // work items per read: ~0.025 at 0.5 % bait reads, 0.4 at 10 %, 0.8 at 20 %.  (Since a run start is left to the first lane that
         // holds one, the two kinds of pass are within 5 % of each other from 2 % to 100 % bait reads; the switch stays for inputs
@@ -972,6 +1008,13 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
                              uint32_t threshold, int pair_mode, const int *devices, int n_devices, uint64_t *kept, uint64_t *total)
 {
     return filter_fastq_files_on(ks, fq1, fq2, out1, out2, threshold, pair_mode, devices, n_devices, kept, total);
+}
+
+int mf_set_option(const char *name, const char *value)
+{
+    options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1)", name ? name : "(null)", value ? value : "(null)");
+    return MF_OK;
 }
 
 int mf_last_ingest_stats(mf_ingest_stats_t *out)

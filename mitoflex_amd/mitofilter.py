@@ -29,7 +29,7 @@ EXPORTS = (
     "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_resident_passes", "mf_filter_packed",
-    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_last_ingest_stats", "mf_h2d_bandwidth", "mf_qualfilter_files",
+    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_last_ingest_stats", "mf_h2d_bandwidth", "mf_set_option", "mf_qualfilter_files",
 )
 
 
@@ -112,6 +112,7 @@ def load(path: Optional[str] = None):
                                         C.c_int, u64p, u64p]
     L.mf_filter_fastq_files_on.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
                                            C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mf_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.mf_last_ingest_stats.argtypes = [C.POINTER(IngestStats)]
     L.mf_h2d_bandwidth.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -316,6 +317,12 @@ def filter_fastq_files(ks: KmerSet, fq1: str, fq2: Optional[str], out1: str, out
         _chk(load().mf_filter_fastq_files(ks._h, _enc(fq1), _enc(fq2), _enc(out1), _enc(out2), threshold, pair_mode,
                                           n_devices, C.byref(kept), C.byref(total)))
     return kept.value, total.value
+
+
+def set_option(name: str, value) -> None:
+    """Process-wide switch of how a filter pass is run (pass=default|split|serial, adapt, finish_streams, screen_streams, split_pipe,
+    exact_co): the library does not read these from the environment unless MF_ENV_KNOBS=1."""
+    _chk(load().mf_set_option(_enc(name), _enc(str(value))))
 
 
 def last_ingest_stats() -> dict:

@@ -384,8 +384,8 @@ def test_bench_ranks_under_torchrun(tmp_path, world):
     reads = 2000000 if world == 2 else 600000
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-                        "--prewarm-ms", "5", "--reads", str(reads), "--no-exhaustive", "--cpu-sample", "0", "--e2e-pairs", "0"],
-                       capture_output=True, timeout=300, cwd=str(tmp_path), env=dict(os.environ, MF_BENCH_SHARE_GPU="1"))
+                        "--prewarm-ms", "5", "--reads", str(reads), "--no-exhaustive", "--cpu-sample", "0", "--e2e-pairs", "0", "--rank-file-reads", "60000"],
+                       capture_output=True, timeout=600, cwd=str(tmp_path), env=dict(os.environ, MF_BENCH_SHARE_GPU="1"))
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -398,6 +398,10 @@ def test_bench_ranks_under_torchrun(tmp_path, world):
     assert len(per) == len(ms) == world and all(x > 0 for x in per)
     assert abs(max(ms) - d["ms_per_step"]) < 1e-3 and sum(per) >= d["value"] * (1 - 1e-9)
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["whole_pass_frac"] > 0
+    # every rank filtered a .gz shard of its own, file to file, through the device ingest path on "its" GPU
+    rates, fl = d["extra"]["per_gpu_file_reads_per_s"], d["extra"]["file_level_one_process_per_gpu"]
+    assert len(rates) == world and all(x > 0 for x in rates) and fl["device_ingest_on_every_rank"] and fl["reads_per_rank"] == 60000
+    assert abs(fl["aggregate_reads_per_s"] - sum(rates)) < 1e-6 * sum(rates)
 
 
 def test_bench_refuses_more_ranks_than_gpus(tmp_path):
@@ -451,8 +455,39 @@ def test_other_pass_kinds_match_oracle(kind):
     extra = {"split": dict(MF_PASS="split"), "serial": dict(MF_PASS="serial"), "split-co": dict(MF_PASS="split", MF_EXACT_CO="1"),
              "split-one-stream": dict(MF_PASS="split", MF_SPLIT_PIPE="0"), "one-screen-stream": dict(MF_SCREEN_STREAMS="1"),
              "two-finish-streams": dict(MF_FINISH_STREAMS="2")}[kind]
-    env = dict(os.environ, **extra)
+    env = dict(os.environ, MF_ENV_KNOBS="1", **extra)          # (without MF_ENV_KNOBS=1 the library ignores these variables: test_options_are_not_read_from_a_stray_environment)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_kmer_golden.py"),
                         "-m", "gpu", "-q", "-x", "-k", "test_filter_matches_oracle or test_edge_cases or test_gpu_matches_golden or test_synth_uniform or test_multi_pass_calls"],
                        capture_output=True, env=env, cwd=ROOT, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
+
+
+def test_options_are_not_read_from_a_stray_environment(mf, ol, bait_text):
+    """MF_PASS & co select kernels; a production process must not pick them up from a stray variable: without MF_ENV_KNOBS=1 they are
+    ignored (the three-kernel pass leaves mark-kernel time in the stats, the default pass does not), mf_set_option is the way in, and
+    either way the bits are the oracle's."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from mitoflex_amd import mitofilter as mf\n"
+        "from tests.util_data import make_bait\n"
+        "bait = make_bait(); ks = mf.KmerSet.from_text(bait, 31, 0)\n"
+        "r = mf.Reads.synth(300000, 150, seed=5, bait_text=bait, mito_ppm=5000, sub_ppm=10000, n_read_ppm=10000, n_base_ppm=1000, device=0)\n"
+        "os.environ['MF_EVENT_STRIDE'] = '1'\n"
+        "a = mf.filter_resident(ks, r, 1, mf.MODE_SCREENED, 2)\n"
+        "mf.set_option('pass', 'split'); b = mf.filter_resident(ks, r, 1, mf.MODE_SCREENED, 2); mf.set_option('pass', 'default')\n"
+        "c = mf.filter_resident(ks, r, 1, mf.MODE_SCREENED, 2)\n"
+        "print(a.ms_mark > 0, b.ms_mark > 0, c.ms_mark > 0, a.n_pass == b.n_pass == c.n_pass)\n"
+        "try:\n    mf.set_option('pass', 'nonsense'); print('accepted')\nexcept mf.MitoFilterError:\n    print('rejected')\n"
+    ) % ROOT
+    for knobs, want in ((None, "False True False True"), ("1", "True True False True")):
+        env = dict(os.environ, MF_PASS="split")
+        env.pop("MF_ENV_KNOBS", None)
+        if knobs:
+            env["MF_ENV_KNOBS"] = knobs
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        out = p.stdout.decode().split("\n")
+        assert out[0] == want and out[1] == "rejected", (knobs, out)

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mitoflex_amd import mitofilter as mf
-from tests.util_data import make_bait
+from mitoflex_amd.utility.synth_bait import make_bait
 bait = make_bait()
 ks = mf.KmerSet.from_text(bait, 31)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 33_333_334

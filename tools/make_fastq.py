@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util_data import bait_records, make_bait  # noqa: E402
+from mitoflex_amd.utility.synth_bait import bait_records, make_bait  # noqa: E402
 
 
 def write_mate(path, n, L, seed, mate, bait_seq, mito_frac, sub_rate, qual="uniform", first=0, append=False):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # counters of the finish kernels on bait-rich input (10 % bait reads, serial passes: every kernel alone on the device)
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_finish; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp MF_PASS=serial
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_finish; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp MF_ENV_KNOBS=1 MF_PASS=serial
 PPM=${1:-100000}
 pass() { name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/bait_fraction_sweep.py 33333334 $PPM > /dev/null 2> $OUT/$name.err

@@ -21,7 +21,7 @@ for k, d in agg.items():
 PY
 }
 pass() { name=$1; shift
-  MF_PASS=serial timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/s_$name -- python3 $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --e2e-full-reads 0 --no-group-a --no-live-traffic > /dev/null 2> $OUT/s_$name.err
+  MF_ENV_KNOBS=1 MF_PASS=serial timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/s_$name -- python3 $R/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --e2e-full-reads 0 --no-group-a --no-live-traffic > /dev/null 2> $OUT/s_$name.err
   f=$(find $OUT/s_$name -name "*counter_collection.csv" | head -1); [ -n "$f" ] && sum "$f" screen
   READBW_SHAPE_ONLY=1 timeout 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/r_$name -- /tmp/readbw > /dev/null 2> $OUT/r_$name.err
   f=$(find $OUT/r_$name -name "*counter_collection.csv" | head -1); [ -n "$f" ] && sum "$f" readloop

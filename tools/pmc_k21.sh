@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters of the candidate-bitmap pass at k = 21 (one stream, so that every kernel has the device to itself)
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_k21; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp MF_SPLIT_PIPE=0
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_k21; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp MF_ENV_KNOBS=1 MF_SPLIT_PIPE=0
 pmc() { name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --k 21 --steps 3 --warmup 1 --prewarm-ms 0 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --no-live-traffic > /dev/null 2> $OUT/$name.err
   python3 - $(find $OUT/$name -name "*counter_collection.csv" | head -1) <<'PY'

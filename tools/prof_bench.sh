@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03; mkdir -p $OUT; cd /tmp; export TMPDIR
 Q="--cpu-sample 0 --no-exhaustive --e2e-pairs 0 --e2e-full-reads 0 --no-group-a --no-live-traffic"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 $Q > $OUT/bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv; rm -rf $OUT/trace
-MF_PASS=serial timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 $Q > /dev/null 2>&1
+MF_ENV_KNOBS=1 MF_PASS=serial timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 $Q > /dev/null 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_serial.csv; rm -rf $OUT/trace
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc -- python3 $R/bench.py --steps 3 --warmup 1 $Q > /dev/null 2>&1

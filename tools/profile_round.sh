@@ -7,15 +7,15 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_gpu.t
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err; cat $OUT/bench_driver_cmd.json
 for k in 21 41; do timeout 300 python bench.py --k $k --steps 20 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic > $OUT/bench_k$k.json 2>> $OUT/bench.err; done
-MF_PASS=split timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_split_pass.json 2>> $OUT/bench.err
-MF_SCREEN_STREAMS=1 timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_one_screen_stream.json 2>> $OUT/bench.err
-MF_SPLIT_PIPE=0 timeout 300 python bench.py --k 21 --steps 20 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_k21_one_stream.json 2>> $OUT/bench.err
-MF_PASS=serial timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_serial_pass.json 2>> $OUT/bench.err
+MF_ENV_KNOBS=1 MF_PASS=split timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_split_pass.json 2>> $OUT/bench.err
+MF_ENV_KNOBS=1 MF_SCREEN_STREAMS=1 timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_one_screen_stream.json 2>> $OUT/bench.err
+MF_ENV_KNOBS=1 MF_SPLIT_PIPE=0 timeout 300 python bench.py --k 21 --steps 20 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_k21_one_stream.json 2>> $OUT/bench.err
+MF_ENV_KNOBS=1 MF_PASS=serial timeout 300 python bench.py --steps 30 --cpu-sample 0 --e2e-pairs 0 --no-live-traffic --no-exhaustive > $OUT/bench_serial_pass.json 2>> $OUT/bench.err
 timeout 300 python tools/bait_fraction_sweep.py > $OUT/bait_fraction.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --no-live-traffic > $OUT/trace_bench.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null; cat $OUT/kernel_stats.csv
-MF_PASS=serial timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --no-live-traffic > $OUT/trace_serial_bench.json 2> $OUT/trace_serial.err
+MF_ENV_KNOBS=1 MF_PASS=serial timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --no-live-traffic > $OUT/trace_serial_bench.json 2> $OUT/trace_serial.err
 cp $(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_serial.csv 2>/dev/null; head -4 $OUT/kernel_stats_serial.csv
 pmc() { name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exhaustive --e2e-pairs 0 --no-live-traffic > /dev/null 2> $OUT/pmc_$name.err

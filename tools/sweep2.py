@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mitoflex_amd import mitofilter as mf
-from tests.util_data import make_bait
+from mitoflex_amd.utility.synth_bait import make_bait
 bait = make_bait()
 k = int(os.environ.get("SWEEP_K", "31"))
 ks = mf.KmerSet.from_text(bait, k)
