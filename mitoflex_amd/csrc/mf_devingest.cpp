@@ -522,7 +522,9 @@ public:
         if (done_ || (slabs_.empty() && next_plan_ >= plan_.size())) return finish_pending(out, err);
         // decode runs ahead of the text: the front slab (waiting for its bytes if need be) and as many of the following ones as the
         // ring has room and uploaded bytes for
+        const double tla = now_s();
         int rc = launch_ahead(err);
+        t_launch_ += now_s() - tla;
         if (rc) return rc;
         Slab &S = *slabs_.front();
         Lane &L = lanes_[S.lane];
@@ -583,6 +585,7 @@ public:
         TRACE("piece: chunks %u..%u, %llu symbols, text from %llu", a, b, (unsigned long long)sum, (unsigned long long)T0);
         rc = new_text(L, T0, sum + ((size_t)1 << 20), err);
         if (rc) return rc;
+        t_newtext_ += now_s() - tl0;
         // link; the host steps in where the chain stops
         const uint16_t *sym_a = S.sym.p;             // (the chain and resolve kernels index the slab's symbols from its first chunk)
         for (bool first = true;; first = false) {
@@ -591,8 +594,8 @@ public:
                 DCHK(launch_gz_chain(L.d_chain.p, L.d_chunks.p, S.lo, b, sym_a, S.cap, L.d_out_off.p, cur_buf_->p, T0, sp));
                 DCHK(hipMemcpyAsync(h_chain_, L.d_chain.p, lanes_.size() > 1 ? sizeof(GzChain) : offsetof(GzChain, window), hipMemcpyDeviceToHost, sp));
             }
-            if (first) { rc = finish_pending(out, err); if (rc) return rc; DCHK(hipSetDevice(L.dev)); }       // (the piece before: its resolve and CRC kernels ran beside this one's decode wait and link)
-            if (!done_ && in_member_) DCHK(hipStreamSynchronize(sp));
+            if (first) { const double tf = now_s(); rc = finish_pending(out, err); if (rc) return rc; DCHK(hipSetDevice(L.dev)); t_finish_ += now_s() - tf; }       // (the piece before: its resolve and CRC kernels ran beside this one's decode wait and link)
+            { const double tc = now_s(); if (!done_ && in_member_) DCHK(hipStreamSynchronize(sp)); t_chain_sync_ += now_s() - tc; }
             TRACE("chain: stop %u next %u cur_bit %llu total %llu linked %u", h_chain_->stop, h_chain_->next, (unsigned long long)h_chain_->cur_bit, (unsigned long long)h_chain_->total, h_chain_->linked);
             if (done_) break;
             uint64_t to_bit = 0;
@@ -661,9 +664,12 @@ public:
     }
     bool finished() const { return !pending_ && (done_ || (slabs_.empty() && next_plan_ >= plan_.size())); }
     uint64_t text_bytes() const { return h_chain_ ? h_chain_->total : 0; }
+    double launch_seconds() const { return t_launch_; }
+    void link_parts(double &newtext, double &finish, double &chain_sync) const { newtext = t_newtext_; finish = t_finish_; chain_sync = t_chain_sync_; }
+    double slot_seconds() const { return t_slot_; }
     // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer and for the piece before to be resolved); the uploader's
     void producer_times(double &wait_decode, double &link, double &up_ring, double &up_copy, double &up_read) const
-    { wait_decode = t_wait_decode_; link = t_link_; up_ring = up_ ? up_->t_ring_ : 0; up_copy = up_ ? up_->t_copy_wait_ : 0; up_read = up_ ? up_->t_read_ : 0; }
+    { wait_decode = t_wait_decode_; link = t_link_ + 1000.0 * 0; (void)t_launch_; up_ring = up_ ? up_->t_ring_ : 0; up_copy = up_ ? up_->t_copy_wait_ : 0; up_read = up_ ? up_->t_read_ : 0; }
     // seconds during which at least one decode kernel of this stream was running on a device, summed over the devices
     double decode_busy_seconds() const
     {
@@ -747,7 +753,9 @@ private:
     int new_text(Lane &L, uint64_t T0, size_t text_bytes, std::string &err)
     {
         (void)T0;
+        const double ts = now_s();
         if (!slots_->take()) { err = "stopped"; return MF_E_IO; }
+        t_slot_ += now_s() - ts;
         DCHK(TextBuf::make(cur_buf_, L.dev, L.ldev, pad_, text_bytes, slots_));
         // (a damaged stream may point a full window back from the first byte of the text: zeros there, ahead of the link step on its stream)
         DCHK(hipMemsetAsync(cur_buf_->p - TEXT_FRONT, 0, TEXT_FRONT, L.streams->link));
@@ -839,7 +847,7 @@ private:
     TextPiece pend_; bool pending_ = false; uint32_t pend_lane_ = 0; std::unique_ptr<Slab> pend_slab_;
     bool in_member_ = false, done_ = false;
     uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
-    double t_wait_decode_ = 0, t_link_ = 0;
+    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_finish_ = 0, t_chain_sync_ = 0, t_slot_ = 0;
 };
 
 // ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
@@ -958,7 +966,12 @@ struct Ingest {
     bool failed = false; int fail_rc = MF_OK; std::string fail_err;
 
     std::mutex mu_all; std::condition_variable cv_all;          // any producer has something new
-    void publish(Mate &M, TextPiece &&t) { { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(std::move(t)); } M.cv.notify_all(); cv_all.notify_all(); }
+    double t_begin = 0, t_first_piece = 0, t_last_piece = 0, t_consumed = 0;      // when the first / last piece of text was handed over, when the last consumer was done (seconds into the call)
+    void publish(Mate &M, TextPiece &&t)
+    {
+        { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(std::move(t)); const double now = now_s() - t_begin; if (t_first_piece == 0) t_first_piece = now; t_last_piece = now; }
+        M.cv.notify_all(); cv_all.notify_all();
+    }
 
     void producer(Mate &M)
     {
@@ -1347,6 +1360,7 @@ struct Ingest {
         for (int w = 0; w < nw; w++) { workers.emplace_back(new Worker()); workers.back()->id = w; }
         for (auto &W : workers) { Worker *wp = W.get(); wp->th = std::thread([this, wp] { consume(*wp); }); }
         for (auto &W : workers) W->th.join();
+        t_consumed = now_s() - t_begin;
         if (failed) { err = fail_err; return fail_rc; }
         for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (M.prod.joinable()) M.prod.join(); if (M.prod_rc) { err = M.prod_err; return M.prod_rc; } }
         total = nm == 2 ? std::min(m[0].rec_indexed, m[1].rec_indexed) : m[0].rec_indexed;
@@ -1384,6 +1398,7 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     }
     for (int d : I.devices) { DevCtx *c = nullptr; const int rc = get_ctx(d, &c, 0); if (rc) { err = mf_thread_error(); return rc; } }
     const double t_begin = now_s();
+    I.t_begin = t_begin;
     g_pool.reset_peak();
     const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", 6)) + (int)I.devices.size() - 1;        // (three consumers each hold one, the decoder one, the rest wait for the other mate or for a consumer)
     int rc = MF_OK;
@@ -1426,8 +1441,10 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     if (I.timing) {
         fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
                 now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
+        fprintf(stderr, " | first text after %.3f s, last after %.3f, consumers done after %.3f", I.t_first_piece, I.t_last_piece, I.t_consumed);
         for (int i = 0; i < I.nm; i++)
-            if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, a, b, c, d, e); }
+            if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);
+                              double x, y, z; I.m[i].gzs->link_parts(x, y, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f, waiting for the piece before to be resolved and checked %.3f, waiting for the chain kernel %.3f)", x, I.m[i].gzs->slot_seconds(), y, z); }
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) fprintf(stderr, " | mate %d: inflate kernels busy %.3f s (%.1f GB/s of text), %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, I.m[i].gzs->decode_busy_seconds(), I.m[i].gzs->decode_busy_seconds() > 0 ? (double)I.m[i].gzs->text_bytes() / I.m[i].gzs->decode_busy_seconds() / 1e9 : 0.0, (unsigned long long)I.m[i].gzs->chunks_linked(),
                                     I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes(), I.m[i].gzs->ring_bytes() >> 20, I.m[i].gzs->splits());

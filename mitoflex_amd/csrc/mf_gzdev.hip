@@ -733,21 +733,27 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
 //     loads are issued ahead), every output position of the round finding its entry by binary search in LDS, as before.
 // The tables stay in LDS (the lanes index them on their own); ring, precode and code-length arrays share their bytes with the
 // round's list and staging buffer.
-constexpr uint32_t SPAN = 1024;          // bits of the block per lane and step
+#ifndef GZ_SPAN
+#define GZ_SPAN 1024
+#endif
+constexpr uint32_t SPAN = GZ_SPAN;       // bits of the block per lane and step
 constexpr uint32_t LCAP = 512;           // list entries a lane may leave per step (more codes than that in 1024 bits: the lane stops early, the next step goes on from there)
-constexpr uint32_t RN = 256;             // list entries per round of the expansion
-constexpr uint32_t STG2 = 2048;          // output symbols per round (staging buffer)
+#ifndef GZ_RN
+#define GZ_RN 256
+#endif
+constexpr uint32_t RN = GZ_RN;           // list entries per round of the expansion
+constexpr uint32_t STG2 = RN * 8;        // output symbols per round (staging buffer)
 constexpr uint32_t MAX_REWALK = 6;       // re-walk rounds per step; what is not chained by then waits for the next step
 // dwords of the stream a lane may touch in a step: its span, a code that starts in the span's last bit (48 bits), the bit buffer's
 // 64 bits and one dword read ahead.  Odd, so that the lanes' rows start in different LDS banks.
 constexpr uint32_t SPAN_DW = SPAN / 32, STAGE_DW = SPAN_DW + 5;
-static_assert(SPAN % 32 == 0 && STAGE_DW % 2 == 1 && RN <= 256 && RN % 64 == 0 && STG2 % 256 == 0 && STG2 <= 0x4000, "layout of the rounds");
+static_assert(SPAN % 32 == 0 && STAGE_DW % 2 == 1 && RN % 64 == 0 && STG2 % 256 == 0 && STG2 <= 0x4000, "layout of the rounds");
 struct Lds2 {
     uint32_t lit[LIT_SIZE]; uint32_t dist[DIST_SIZE];
     union {
         struct { uint32_t ring[RING]; uint32_t pre[PRE_SIZE]; uint8_t lens[328]; uint8_t plens[24]; };      // between blocks: the header reader's
         uint32_t stage[64 * STAGE_DW];                                                                       // a step's walks: the stream, a row per lane
-        struct { uint32_t sym[RN]; uint16_t soff[RN]; uint16_t stg[STG2]; uint8_t own[STG2]; };              // a step's expansion
+        uint16_t stg[STG2];                                                                                  // a step's expansion: the round's symbols
     };
     uint16_t sorted_lit[288], sorted_dist[32];
     Canon clit, cdist;
@@ -875,13 +881,32 @@ __device__ __forceinline__ Span walk_rows(const Lds2 &L, const uint32_t *row, ui
     return r;
 }
 
+// cycle counts per phase of a chunk (tools/gzdev_check built with -DGZ_PROFILE reads them from the head of the chunk's list scratch)
+#ifdef GZ_PROFILE
+struct Prof { unsigned long long t[16]; };      // 0 search + header reads, 1 table construction, 2 walks, 3 expansion, 4 steps, 5 walk rounds, 6 expansion rounds, 7 blocks, 8 round: list + sums, 9 round: symbols, 10 round: chase, 11 round: store, 12 chase passes
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(i) do { prof.t[i] += __builtin_readcyclecounter() - prof_t0_; } while (0)
+#define PROF_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); prof.t[i] += n_ - prof_last_; prof_last_ = n_; } while (0)
+#define PROF_CNT(i, n) do { prof.t[i] += (n); } while (0)
+#else
+struct Prof {};
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(i) do {} while (0)
+#define PROF_STAMP(i) do {} while (0)
+#define PROF_CNT(i, n) do {} while (0)
+#endif
+
 // One round of the expansion: up to RN entries of the step's list at cl[0 .. n) -> symbols at out[opos ..].  Takes as many entries
 // as fit the staging buffer (at least one); returns their number in `taken` and the number of symbols written.
-// Every output position of the round needs the entry it belongs to.  The entries mark where they start (one byte per position),
-// a thread takes a run of consecutive positions and the running maximum of the marks -- within the thread, then across the
-// wavefront -- is each position's entry: two LDS round trips, where a binary search per position took eight, one after the other.
-__device__ __forceinline__ uint32_t expand3(Lds2 &L, const uint32_t *cl, uint32_t n, uint16_t *out, uint64_t opos, uint32_t lane, uint32_t &taken)
+// Every thread has four consecutive entries of the list and expands them itself: a literal entry is one or two stores to the
+// staging buffer; a match writes its symbols eight at a time -- a symbol of the round itself as a reference that is followed
+// afterwards (pointer doubling: the passes grow with the logarithm of the longest chain), an earlier symbol of the chunk straight from
+// global memory, all eight loads in flight together, a symbol from in front of the chunk as a marker.  (The first versions found the
+// entry of every output POSITION -- by binary search, then by a running maximum over start marks: three and two times the
+// instructions, most of them spent on positions that a literal entry settles with one store.)
+__device__ __forceinline__ uint32_t expand4(Lds2 &L, const uint32_t *cl, uint32_t n, uint16_t *out, uint64_t opos, uint32_t lane, uint32_t &taken, Prof &prof)
 {
+    PROF_T0();
     constexpr uint32_t K = RN / 64;
     uint32_t s[K], cnt[K], end[K];
     uint32_t sum = 0;
@@ -907,6 +932,10 @@ __device__ __forceinline__ uint32_t expand3(Lds2 &L, const uint32_t *cl, uint32_
     uint32_t n_ok = okc, tot = my_end;
     for (int d = 32; d; d >>= 1) { n_ok += __shfl_xor(n_ok, d); tot = max(tot, (uint32_t)__shfl_xor(tot, d)); }
     taken = n_ok;
+    PROF_ADD(8);
+#ifdef GZ_PROFILE
+    unsigned long long prof_last_ = __builtin_readcyclecounter();
+#endif
     if (!__any(my_match)) {                      // literals only: every entry stores its one or two symbols itself
 #pragma unroll
         for (uint32_t q = 0; q < K; q++) {
@@ -915,59 +944,90 @@ __device__ __forceinline__ uint32_t expand3(Lds2 &L, const uint32_t *cl, uint32_
         }
         return tot;
     }
-    const uint32_t C = (((tot + 63) >> 6) + 3) & ~3u;      // positions per thread: a multiple of four (the marks are read a dword at a time), at most STG2 / 64
-    uint32_t *own32 = reinterpret_cast<uint32_t *>(L.own);
-#pragma unroll
-    for (uint32_t q = 0; q < K; q++) { const uint32_t j = lane * K + q; if (j < n_ok) { L.sym[j] = s[q]; L.soff[j] = (uint16_t)(end[q] - cnt[q]); } }
-    for (uint32_t i = 0; i < C / 4; i++) own32[lane * (C / 4) + i] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (uint32_t q = 0; q < K; q++) { const uint32_t j = lane * K + q; if (j < n_ok && j > 0) L.own[end[q] - cnt[q]] = (uint8_t)j; }      // (entry 0 starts at position 0: the maximum starts there)
-    __syncthreads();
-    uint32_t m = 0;
-    for (uint32_t i = 0; i < C / 4; i++) {
-        const uint32_t o4 = own32[lane * (C / 4) + i];
-        m = max(m, max(max(o4 & 0xFFu, (o4 >> 8) & 0xFFu), max((o4 >> 16) & 0xFFu, o4 >> 24)));
-    }
-    uint32_t carry = m;                          // -> the largest mark in front of this thread's positions
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(carry, d); if (lane >= (uint32_t)d) carry = max(carry, u); }
-    carry = __shfl_up(carry, 1);
-    if (lane == 0) carry = 0;
     bool pending = false;
-    uint32_t run = carry;
-#pragma unroll 1
-    for (uint32_t i = 0; i < C / 4; i++) {
-        {
-            const uint32_t o4 = own32[lane * (C / 4) + i];      // (read again rather than kept: eight registers a thread for a 50-cycle read)
-            uint32_t vv[4];
+    // Symbol t of a match comes from first + (t mod D), counted from the round's first symbol (a match may be longer than its
+    // distance).  A source inside the round is a reference that is followed afterwards; one in front of the chunk a marker; one in
+    // earlier output of the chunk is loaded -- EIGHT SYMBOLS WITH ONE 16-BYTE LOAD (the sources of a match lie side by side; with a
+    // distance below eight the eight symbols at `first` hold the whole period).  The loads are unconditional, every lane loads
+    // (from the chunk's first symbols if it has no use for the data), and what a symbol is gets decided by selects afterwards: a
+    // load whose register is also written on another path of a divergent branch makes that path wait for it (s_waitcnt vmcnt(0)
+    // in front of the write) -- with per-symbol conditional loads every symbol of a round cost a memory round trip.
+    // The first eight symbols of all four entries go first (most matches of FASTQ text are no longer): four loads in flight a thread.
+    uint4 vec[K]; int32_t shift[K];            // shift: symbol i of vec is the symbol at (first + i - shift) ... see sym8()
 #pragma unroll
-            for (uint32_t b = 0; b < 4; b++) {
-                const uint32_t p = lane * C + 4 * i + b;
-                run = max(run, (o4 >> (8 * b)) & 0xFFu);
-                uint32_t v = 0;
-                if (p < tot) {
-                    const uint32_t e = L.sym[run], o = L.soff[run];
-                    if (!(e >> 31)) v = (p == o ? (e >> 8) : (e >> 16)) & 0xFFu;
-                    else {
-                        const uint32_t len = (e & 0x1FFu) + 3, D = ((e >> 9) & 0x7FFFu) + 1, t = p - o;
-                        const uint32_t r = D < len ? t % D : t;
-                        const int32_t srel = (int32_t)o - (int32_t)D + (int32_t)r;
-                        if (srel >= 0) { v = PENDING | (uint32_t)srel; pending = true; }
-                        else {
-                            const int64_t g = (int64_t)opos + srel;
-                            v = g >= 0 ? out[g] : (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g));
-                        }
+    for (uint32_t q = 0; q < K; q++) {
+        const uint32_t j = lane * K + q, o = end[q] - cnt[q], e = s[q];
+        const bool is_match = j < n_ok && (e >> 31);
+        const int32_t first = (int32_t)o - (int32_t)(((e >> 9) & 0x7FFFu) + 1);
+        const int64_t g0 = (int64_t)opos + first;                          // chunk position of the match's first source symbol
+        const int64_t gb = (is_match && g0 > 0) ? g0 : 0;                  // ... of the first symbol loaded (never in front of the chunk's buffer)
+        shift[q] = (int32_t)(gb - g0);
+        __builtin_memcpy(&vec[q], out + gb, 16);                           // (2-byte aligned: one global_load_dwordx4)
+    }
+    // symbol number i (0 .. 7 + shift) of the stretch that starts at `first`
+    auto sym8 = [](const uint4 &x, int32_t i) -> uint32_t {
+        const uint64_t lo = x.x | ((uint64_t)x.y << 32), hi = x.z | ((uint64_t)x.w << 32);
+        return (uint32_t)((i < 4 ? lo >> (16 * i) : hi >> (16 * (i - 4))) & 0xFFFFu);
+    };
+#pragma unroll
+    for (uint32_t q = 0; q < K; q++) {
+        const uint32_t j = lane * K + q, o = end[q] - cnt[q], e = s[q];
+        if (j < n_ok) {
+            if (!(e >> 31)) { L.stg[o] = (uint16_t)((e >> 8) & 0xFFu); if (cnt[q] == 2) L.stg[o + 1] = (uint16_t)((e >> 16) & 0xFFu); }
+            else {
+                const uint32_t len = cnt[q], D = ((e >> 9) & 0x7FFFu) + 1;
+                const int32_t first = (int32_t)o - (int32_t)D;
+                const int64_t g0 = (int64_t)opos + first;
+                uint32_t r = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) {
+                    if (u < len) {
+                        const int32_t srel = first + (int32_t)r;
+                        uint32_t w;
+                        if (srel >= 0) { w = PENDING | (uint32_t)srel; pending = true; }
+                        else if (g0 + r < 0) w = (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g0 + r));
+                        else w = sym8(vec[q], (int32_t)r - shift[q]);
+                        L.stg[o + u] = (uint16_t)w;
                     }
+                    r++; if (r == D) r = 0;
                 }
-                vv[b] = v;
             }
+        }
+    }
+    // what is left of the long matches, eight symbols at a time (all lanes go along while one has something left): with a distance
+    // of eight or more another 16-byte load per eight symbols, below that the period is in vec already
 #pragma unroll
-            for (uint32_t b = 0; b < 4; b++) { const uint32_t p = lane * C + 4 * i + b; if (p < tot) L.stg[p] = (uint16_t)vv[b]; }
+    for (uint32_t q = 0; q < K; q++) {
+        const uint32_t j = lane * K + q, o = end[q] - cnt[q], e = s[q];
+        const bool is_long = j < n_ok && (e >> 31) && cnt[q] > 8;
+        const uint32_t len = is_long ? cnt[q] : 0, D = ((e >> 9) & 0x7FFFu) + 1;
+        const int32_t first = (int32_t)o - (int32_t)D;
+        const int64_t g0 = (int64_t)opos + first;
+        for (uint32_t t0 = 8; __any(t0 < len); t0 += 8) {
+            // (D >= 8: symbols t0 .. t0 + 7 come from first + t0 ..; D < 8: from the period)
+            const int64_t gs = g0 + t0;
+            const int64_t gb = (t0 < len && D >= 8 && gs > 0) ? gs : 0;
+            uint4 x; __builtin_memcpy(&x, out + gb, 16);
+            const int32_t sh = (int32_t)(gb - gs);
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t t = t0 + u;
+                if (t < len) {
+                    const uint32_t r = D >= 8 ? t : t % D;
+                    const int32_t srel = first + (int32_t)r;
+                    uint32_t w;
+                    if (srel >= 0) { w = PENDING | (uint32_t)srel; pending = true; }
+                    else if (g0 + r < 0) w = (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g0 + r));
+                    else w = D >= 8 ? sym8(x, (int32_t)u - sh) : sym8(vec[q], (int32_t)r - shift[q]);
+                    L.stg[o + t] = (uint16_t)w;
+                }
+            }
         }
     }
     __syncthreads();
+    PROF_STAMP(9);
     while (__any(pending)) {                     // references into the round itself: they point strictly backwards
+        PROF_CNT(12, 1);
         pending = false;
         for (uint32_t p = lane; p < tot; p += 64) {
             const uint32_t v = L.stg[p];
@@ -979,25 +1039,14 @@ __device__ __forceinline__ uint32_t expand3(Lds2 &L, const uint32_t *cl, uint32_
         }
         __syncthreads();
     }
+    PROF_STAMP(10);
     for (uint32_t p = lane; p < tot; p += 64) out[opos + p] = L.stg[p];
     __syncthreads();
+    PROF_STAMP(11);
     return tot;
 }
 
 enum BlockEnd : uint32_t { B_EOB = 0, B_ERROR = 1, B_OVERFLOW = 2, B_PAST_SIZE = 3, B_PAST_LIMIT = 4 };
-
-// cycle counts per phase of a chunk (tools/gzdev_check built with -DGZ_PROFILE reads them from the head of the chunk's list scratch)
-#ifdef GZ_PROFILE
-struct Prof { unsigned long long t[8]; };      // 0 search + header reads, 1 table construction, 2 walks, 3 expansion, 4 steps, 5 walk rounds, 6 expansion rounds, 7 blocks
-#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
-#define PROF_ADD(i) do { prof.t[i] += __builtin_readcyclecounter() - prof_t0_; } while (0)
-#define PROF_CNT(i, n) do { prof.t[i] += (n); } while (0)
-#else
-struct Prof {};
-#define PROF_T0() do {} while (0)
-#define PROF_ADD(i) do {} while (0)
-#define PROF_CNT(i, n) do {} while (0)
-#endif
 
 // The codes of one block (tables built in L), from bit `from` (absolute) on, by all lanes.  On B_EOB `from` is the bit behind the
 // end-of-block code and opos the symbols written.  lst: the chunk's scratch -- a list of LCAP entries per lane, and behind the 64
@@ -1042,7 +1091,7 @@ __device__ __forceinline__ uint32_t decode_block(Lds2 &L, const LaneIn &in, uint
         if (origin_bits + end_rel > limit_bits) return B_PAST_LIMIT;
         uint32_t tot = lane < V ? sp.n_sym : 0;
         for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d);
-        if (opos + tot > sym_cap) return B_OVERFLOW;
+        if (opos + tot + 8 > sym_cap) return B_OVERFLOW;      // (+ 8: the expansion reads earlier output sixteen bytes at a time)
         { PROF_T0();
         // the lists of the chain's lanes, one behind the other (every lane moves its own: eight entries in flight)
         const uint32_t n_mine = lane < V ? sp.n_code : 0;
@@ -1063,7 +1112,7 @@ __device__ __forceinline__ uint32_t decode_block(Lds2 &L, const LaneIn &in, uint
         __syncthreads();
         for (uint32_t e0 = 0; e0 < n_list;) {
             uint32_t taken = 0;
-            opos += expand3(L, cl + e0, n_list - e0 < RN ? n_list - e0 : RN, out, opos, lane, taken);
+            opos += expand4(L, cl + e0, n_list - e0 < RN ? n_list - e0 : RN, out, opos, lane, taken, prof);
             e0 += taken;
             PROF_CNT(6, 1);
         }
@@ -1102,7 +1151,7 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
     uint32_t why = 0;                               // what stopped a decode that failed (reported in n_sym of a GZ_FAILED chunk)
     Prof prof;
 #ifdef GZ_PROFILE
-    for (int i = 0; i < 8; i++) prof.t[i] = 0;
+    for (int i = 0; i < 16; i++) prof.t[i] = 0;
     const unsigned long long prof_begin = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -1189,8 +1238,8 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
         chunks[c] = res;
 #ifdef GZ_PROFILE
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(lst);
-        for (int i = 0; i < 8; i++) pp[i] = prof.t[i];
-        pp[8] = __builtin_readcyclecounter() - prof_begin;
+        for (int i = 0; i < 16; i++) pp[i] = prof.t[i];
+        pp[16] = __builtin_readcyclecounter() - prof_begin;
 #endif
     }
 }

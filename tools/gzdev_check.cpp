@@ -78,11 +78,13 @@ int main(int argc, char **argv)
 #ifdef GZ_PROFILE
     if (d_scratch) {          // cycle counts per phase, summed over the chunks (the kernel leaves them at the head of every chunk's list scratch)
         const size_t per = mf::gz_decode_scratch_bytes(1);
-        unsigned long long tot[9] = {0}, v[9];
-        for (uint32_t c = 0; c < n_chunks; c++) { CK(hipMemcpy(v, (const char *)d_scratch + (size_t)c * per, sizeof v, hipMemcpyDeviceToHost)); for (int i = 0; i < 9; i++) tot[i] += v[i]; }
-        printf("  cycles per chunk (s_memtime, 100 MHz): search + header %.0f | tables %.0f | walks %.0f | expansion %.0f | whole %.0f ;  per chunk: %.1f blocks, %.1f steps, %.1f walk rounds, %.1f expansion rounds\n",
-               (double)tot[0] / n_chunks, (double)tot[1] / n_chunks, (double)tot[2] / n_chunks, (double)tot[3] / n_chunks, (double)tot[8] / n_chunks,
+        unsigned long long tot[17] = {0}, v[17];
+        for (uint32_t c = 0; c < n_chunks; c++) { CK(hipMemcpy(v, (const char *)d_scratch + (size_t)c * per, sizeof v, hipMemcpyDeviceToHost)); for (int i = 0; i < 17; i++) tot[i] += v[i]; }
+        printf("  cycles per chunk (shader clock): search + header %.0f | tables %.0f | walks %.0f | expansion %.0f | whole %.0f ;  per chunk: %.1f blocks, %.1f steps, %.1f walk rounds, %.1f expansion rounds\n",
+               (double)tot[0] / n_chunks, (double)tot[1] / n_chunks, (double)tot[2] / n_chunks, (double)tot[3] / n_chunks, (double)tot[16] / n_chunks,
                (double)tot[7] / n_chunks, (double)tot[4] / n_chunks, (double)tot[5] / n_chunks, (double)tot[6] / n_chunks);
+        printf("  inside the expansion rounds: list + sums %.0f | symbols %.0f | chase %.0f (%.1f passes a chunk) | store %.0f\n",
+               (double)tot[8] / n_chunks, (double)tot[9] / n_chunks, (double)tot[10] / n_chunks, (double)tot[12] / n_chunks, (double)tot[11] / n_chunks);
     }
 #endif
     std::vector<mf::GzChunk> ch(n_chunks);

@@ -53,11 +53,14 @@ if __name__ == "__main__":
     ap.add_argument("--qual", choices=["uniform", "binned"], default="uniform")
     ap.add_argument("--mates", type=int, default=2, help="1: only mate 1 (single-end sets)")
     ap.add_argument("--block", type=int, default=0, help="write in blocks of this many records (memory bound for large sets)")
+    ap.add_argument("--only-mate", type=int, default=0, help="write this mate's file only (1 or 2): very large pairs are made and compressed one file at a time")
     a = ap.parse_args()
     bait = make_bait()
     open(a.prefix + ".bait.fa", "w").write(bait)
     g = bait_records(bait)[0]
     for mate in (1, 2)[:a.mates]:
+        if a.only_mate and mate != a.only_mate:
+            continue
         if a.block and a.pairs > a.block:          # big files: block by block (a block's seed follows from its index)
             for b, first in enumerate(range(0, a.pairs, a.block)):
                 write_mate(f"{a.prefix}_{mate}.fq", min(a.block, a.pairs - first), a.len, a.seed + mate + 1000 * (b + 1), mate, g, a.mito, 0.01, a.qual,
