@@ -747,13 +747,13 @@ constexpr uint32_t MAX_REWALK = 6;       // re-walk rounds per step; what is not
 // dwords of the stream a lane may touch in a step: its span, a code that starts in the span's last bit (48 bits), the bit buffer's
 // 64 bits and one dword read ahead.  Odd, so that the lanes' rows start in different LDS banks.
 constexpr uint32_t SPAN_DW = SPAN / 32, STAGE_DW = SPAN_DW + 5;
-static_assert(SPAN % 32 == 0 && STAGE_DW % 2 == 1 && RN % 64 == 0 && STG2 % 256 == 0 && STG2 <= 0x4000, "layout of the rounds");
+static_assert(SPAN % 32 == 0 && STAGE_DW % 2 == 1 && RN % 64 == 0 && STG2 % 512 == 0 && STG2 <= 0x10000, "layout of the rounds");
 struct Lds2 {
     uint32_t lit[LIT_SIZE]; uint32_t dist[DIST_SIZE];
     union {
         struct { uint32_t ring[RING]; uint32_t pre[PRE_SIZE]; uint8_t lens[328]; uint8_t plens[24]; };      // between blocks: the header reader's
         uint32_t stage[64 * STAGE_DW];                                                                       // a step's walks: the stream, a row per lane
-        uint16_t stg[STG2];                                                                                  // a step's expansion: the round's symbols
+        uint32_t stg[STG2];                                                                                  // a step's expansion: the round's symbols, one 32-bit cell each
     };
     uint16_t sorted_lit[288], sorted_dist[32];
     Canon clit, cdist;
@@ -883,7 +883,7 @@ __device__ __forceinline__ Span walk_rows(const Lds2 &L, const uint32_t *row, ui
 
 // cycle counts per phase of a chunk (tools/gzdev_check built with -DGZ_PROFILE reads them from the head of the chunk's list scratch)
 #ifdef GZ_PROFILE
-struct Prof { unsigned long long t[16]; };      // 0 search + header reads, 1 table construction, 2 walks, 3 expansion, 4 steps, 5 walk rounds, 6 expansion rounds, 7 blocks, 8 round: list + sums, 9 round: symbols, 10 round: chase, 11 round: store, 12 chase passes
+struct Prof { unsigned long long t[16]; };      // 0 search + header reads, 1 table construction, 2 walks, 3 expansion, 4 steps, 5 walk rounds, 6 expansion rounds, 7 blocks, 8 round: list + sums, 9 round: cells, 13 round: loads of earlier output, 10 round: chase, 11 round: store, 12 chase passes
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
 #define PROF_ADD(i) do { prof.t[i] += __builtin_readcyclecounter() - prof_t0_; } while (0)
 #define PROF_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); prof.t[i] += n_ - prof_last_; prof_last_ = n_; } while (0)
@@ -944,103 +944,85 @@ __device__ __forceinline__ uint32_t expand4(Lds2 &L, const uint32_t *cl, uint32_
         }
         return tot;
     }
+    // The round's symbols are made in a staging buffer of 32-bit cells: a final symbol (kind 0: a literal byte or a marker), a
+    // reference to an earlier cell of the round (kind 1), or a reference to earlier output of the chunk (kind 2: how far in front of the
+    // round's first symbol, less one).  Symbol t of a match is the symbol D in front of it -- position first + t of the round, with
+    // first = (the match's own first position) - D; for a match longer than its distance that is a symbol of the match itself: no modulo
+    // anywhere -- so filling the cells is arithmetic and LDS stores only.  The loads from earlier output come afterwards, by POSITION:
+    // consecutive lanes take consecutive cells, so the symbols one match copies are neighbours in one or two cache lines, eight loads a
+    // lane are in flight together, and every lane loads unconditionally (the chunk's first symbol if its cell needs nothing) with the
+    // cases told apart by selects -- a load whose register is also written on another path of a divergent branch makes that path wait
+    // for it (s_waitcnt vmcnt(0) in front of the write), which is how the first versions came to pay a memory round trip per symbol.
+    constexpr uint32_t C_REF = 1u << 16, C_FAR = 2u << 16;
     bool pending = false;
-    // Symbol t of a match comes from first + (t mod D), counted from the round's first symbol (a match may be longer than its
-    // distance).  A source inside the round is a reference that is followed afterwards; one in front of the chunk a marker; one in
-    // earlier output of the chunk is loaded -- EIGHT SYMBOLS WITH ONE 16-BYTE LOAD (the sources of a match lie side by side; with a
-    // distance below eight the eight symbols at `first` hold the whole period).  The loads are unconditional, every lane loads
-    // (from the chunk's first symbols if it has no use for the data), and what a symbol is gets decided by selects afterwards: a
-    // load whose register is also written on another path of a divergent branch makes that path wait for it (s_waitcnt vmcnt(0)
-    // in front of the write) -- with per-symbol conditional loads every symbol of a round cost a memory round trip.
-    // The first eight symbols of all four entries go first (most matches of FASTQ text are no longer): four loads in flight a thread.
-    uint4 vec[K]; int32_t shift[K];            // shift: symbol i of vec is the symbol at (first + i - shift) ... see sym8()
-#pragma unroll
-    for (uint32_t q = 0; q < K; q++) {
-        const uint32_t j = lane * K + q, o = end[q] - cnt[q], e = s[q];
-        const bool is_match = j < n_ok && (e >> 31);
-        const int32_t first = (int32_t)o - (int32_t)(((e >> 9) & 0x7FFFu) + 1);
-        const int64_t g0 = (int64_t)opos + first;                          // chunk position of the match's first source symbol
-        const int64_t gb = (is_match && g0 > 0) ? g0 : 0;                  // ... of the first symbol loaded (never in front of the chunk's buffer)
-        shift[q] = (int32_t)(gb - g0);
-        __builtin_memcpy(&vec[q], out + gb, 16);                           // (2-byte aligned: one global_load_dwordx4)
-    }
-    // symbol number i (0 .. 7 + shift) of the stretch that starts at `first`
-    auto sym8 = [](const uint4 &x, int32_t i) -> uint32_t {
-        const uint64_t lo = x.x | ((uint64_t)x.y << 32), hi = x.z | ((uint64_t)x.w << 32);
-        return (uint32_t)((i < 4 ? lo >> (16 * i) : hi >> (16 * (i - 4))) & 0xFFFFu);
-    };
 #pragma unroll
     for (uint32_t q = 0; q < K; q++) {
         const uint32_t j = lane * K + q, o = end[q] - cnt[q], e = s[q];
         if (j < n_ok) {
-            if (!(e >> 31)) { L.stg[o] = (uint16_t)((e >> 8) & 0xFFu); if (cnt[q] == 2) L.stg[o + 1] = (uint16_t)((e >> 16) & 0xFFu); }
+            if (!(e >> 31)) { L.stg[o] = (e >> 8) & 0xFFu; if (cnt[q] == 2) L.stg[o + 1] = (e >> 16) & 0xFFu; }
             else {
-                const uint32_t len = cnt[q], D = ((e >> 9) & 0x7FFFu) + 1;
-                const int32_t first = (int32_t)o - (int32_t)D;
-                const int64_t g0 = (int64_t)opos + first;
-                uint32_t r = 0;
+                const uint32_t len = cnt[q];
+                const int32_t first = (int32_t)o - (int32_t)(((e >> 9) & 0x7FFFu) + 1);
+                pending = pending || first + (int32_t)len > 0;
 #pragma unroll
                 for (uint32_t u = 0; u < 8; u++) {
-                    if (u < len) {
-                        const int32_t srel = first + (int32_t)r;
-                        uint32_t w;
-                        if (srel >= 0) { w = PENDING | (uint32_t)srel; pending = true; }
-                        else if (g0 + r < 0) w = (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g0 + r));
-                        else w = sym8(vec[q], (int32_t)r - shift[q]);
-                        L.stg[o + u] = (uint16_t)w;
-                    }
-                    r++; if (r == D) r = 0;
+                    const int32_t srel = first + (int32_t)u;
+                    if (u < len) L.stg[o + u] = srel >= 0 ? (C_REF | (uint32_t)srel) : (C_FAR | (uint32_t)(-srel - 1));
                 }
             }
         }
     }
-    // what is left of the long matches, eight symbols at a time (all lanes go along while one has something left): with a distance
-    // of eight or more another 16-byte load per eight symbols, below that the period is in vec already
+    // what is left of the long matches (all lanes go along while one has something left)
 #pragma unroll
     for (uint32_t q = 0; q < K; q++) {
         const uint32_t j = lane * K + q, o = end[q] - cnt[q], e = s[q];
-        const bool is_long = j < n_ok && (e >> 31) && cnt[q] > 8;
-        const uint32_t len = is_long ? cnt[q] : 0, D = ((e >> 9) & 0x7FFFu) + 1;
-        const int32_t first = (int32_t)o - (int32_t)D;
-        const int64_t g0 = (int64_t)opos + first;
+        const uint32_t len = (j < n_ok && (e >> 31) && cnt[q] > 8) ? cnt[q] : 0;
+        const int32_t first = (int32_t)o - (int32_t)(((e >> 9) & 0x7FFFu) + 1);
         for (uint32_t t0 = 8; __any(t0 < len); t0 += 8) {
-            // (D >= 8: symbols t0 .. t0 + 7 come from first + t0 ..; D < 8: from the period)
-            const int64_t gs = g0 + t0;
-            const int64_t gb = (t0 < len && D >= 8 && gs > 0) ? gs : 0;
-            uint4 x; __builtin_memcpy(&x, out + gb, 16);
-            const int32_t sh = (int32_t)(gb - gs);
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++) {
                 const uint32_t t = t0 + u;
-                if (t < len) {
-                    const uint32_t r = D >= 8 ? t : t % D;
-                    const int32_t srel = first + (int32_t)r;
-                    uint32_t w;
-                    if (srel >= 0) { w = PENDING | (uint32_t)srel; pending = true; }
-                    else if (g0 + r < 0) w = (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g0 + r));
-                    else w = D >= 8 ? sym8(x, (int32_t)u - sh) : sym8(vec[q], (int32_t)r - shift[q]);
-                    L.stg[o + t] = (uint16_t)w;
-                }
+                const int32_t srel = first + (int32_t)t;
+                if (t < len) L.stg[o + t] = srel >= 0 ? (C_REF | (uint32_t)srel) : (C_FAR | (uint32_t)(-srel - 1));
             }
         }
     }
     __syncthreads();
     PROF_STAMP(9);
+    // earlier output of the chunk, by position, eight cells a lane at a time
+    for (uint32_t p0 = 0; p0 < tot; p0 += 512) {
+        uint32_t c[8], ld[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t p = p0 + 64 * i + lane;
+            c[i] = p < tot ? L.stg[p] : 0u;
+            const int64_t g = (int64_t)opos - 1 - (int64_t)(c[i] & 0xFFFFu);
+            ld[i] = out[((c[i] >> 16) == 2u && g >= 0) ? g : 0];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t p = p0 + 64 * i + lane;
+            const int64_t g = (int64_t)opos - 1 - (int64_t)(c[i] & 0xFFFFu);
+            if (p < tot && (c[i] >> 16) == 2u) L.stg[p] = g >= 0 ? ld[i] : (uint32_t)(GZ_MARK | (uint32_t)((int64_t)GZ_WINDOW + g));
+        }
+    }
+    __syncthreads();
+    PROF_STAMP(13);
     while (__any(pending)) {                     // references into the round itself: they point strictly backwards
         PROF_CNT(12, 1);
         pending = false;
         for (uint32_t p = lane; p < tot; p += 64) {
             const uint32_t v = L.stg[p];
-            if ((v & 0xC000u) == PENDING) {
-                const uint32_t w = L.stg[v & 0x3FFFu];
-                L.stg[p] = (uint16_t)w;          // the symbol -- or the reference it holds itself: the chain to follow halves with every pass
-                if ((w & 0xC000u) == PENDING) pending = true;
+            if (v >> 16) {
+                const uint32_t w = L.stg[v & 0xFFFFu];
+                L.stg[p] = w;                    // the symbol -- or the reference it holds itself: the chain to follow halves with every pass
+                if (w >> 16) pending = true;
             }
         }
         __syncthreads();
     }
     PROF_STAMP(10);
-    for (uint32_t p = lane; p < tot; p += 64) out[opos + p] = L.stg[p];
+    for (uint32_t p = lane; p < tot; p += 64) out[opos + p] = (uint16_t)L.stg[p];
     __syncthreads();
     PROF_STAMP(11);
     return tot;

@@ -83,8 +83,8 @@ int main(int argc, char **argv)
         printf("  cycles per chunk (shader clock): search + header %.0f | tables %.0f | walks %.0f | expansion %.0f | whole %.0f ;  per chunk: %.1f blocks, %.1f steps, %.1f walk rounds, %.1f expansion rounds\n",
                (double)tot[0] / n_chunks, (double)tot[1] / n_chunks, (double)tot[2] / n_chunks, (double)tot[3] / n_chunks, (double)tot[16] / n_chunks,
                (double)tot[7] / n_chunks, (double)tot[4] / n_chunks, (double)tot[5] / n_chunks, (double)tot[6] / n_chunks);
-        printf("  inside the expansion rounds: list + sums %.0f | symbols %.0f | chase %.0f (%.1f passes a chunk) | store %.0f\n",
-               (double)tot[8] / n_chunks, (double)tot[9] / n_chunks, (double)tot[10] / n_chunks, (double)tot[12] / n_chunks, (double)tot[11] / n_chunks);
+        printf("  inside the expansion rounds: list + sums %.0f | cells %.0f | loads of earlier output %.0f | chase %.0f (%.1f passes a chunk) | store %.0f\n",
+               (double)tot[8] / n_chunks, (double)tot[9] / n_chunks, (double)tot[13] / n_chunks, (double)tot[10] / n_chunks, (double)tot[12] / n_chunks, (double)tot[11] / n_chunks);
     }
 #endif
     std::vector<mf::GzChunk> ch(n_chunks);
