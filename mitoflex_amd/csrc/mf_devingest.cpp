@@ -182,14 +182,40 @@ struct Mapped {
 // ---- page cache -> pinned memory on a few threads, with pread: reading a mapping instead takes a fault per 64 KiB and does
 // 3 GB/s a thread (with four of those the whole path once ran at the 11 GB/s of that copy, whatever the decoder did); the
 // mapping stays for what the host looks at (headers, trailers, gaps)
+// pinned staging buffers are kept from call to call (allocating and releasing two 32 MiB pinned buffers costs several milliseconds,
+// which is most of what a call on a small file spends outside its pipeline); MF_KEEP_BUFFERS=0 releases them with the call
+class PinnedCache {
+public:
+    hipError_t get(uint8_t **p, size_t bytes)
+    {
+        { std::lock_guard<std::mutex> lk(mu_); auto it = free_.lower_bound(bytes); if (it != free_.end() && it->first <= bytes * 2 + 4096) { *p = it->second; size_[*p] = it->first; free_.erase(it); return hipSuccess; } }
+        void *q = nullptr;
+        hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocPortable);
+        if (e == hipSuccess) { *p = (uint8_t *)q; std::lock_guard<std::mutex> lk(mu_); size_[*p] = bytes; }
+        return e;
+    }
+    void put(uint8_t *p)
+    {
+        if (!p) return;
+        const char *kb = getenv("MF_KEEP_BUFFERS");
+        std::unique_lock<std::mutex> lk(mu_);
+        const size_t n = size_[p];
+        if ((kb && kb[0] == '0') || free_.size() >= 8) { size_.erase(p); lk.unlock(); (void)hipHostFree(p); return; }
+        free_.emplace(n, p);
+    }
+private:
+    std::mutex mu_; std::multimap<size_t, uint8_t *> free_; std::map<uint8_t *, size_t> size_;
+};
+PinnedCache g_pinned;
+
 struct Stager {
     uint8_t *buf[2] = {nullptr, nullptr}; size_t piece = 0; int fd = -1; int nthr = 8;
-    ~Stager() { for (auto &b : buf) if (b) (void)hipHostFree(b); }
+    ~Stager() { for (auto &b : buf) g_pinned.put(b); }
     hipError_t init(size_t piece_bytes, int fd_)
     {
         piece = piece_bytes; fd = fd_;
         nthr = (int)std::min<uint64_t>(16, std::max<uint64_t>(1, env_u64("MF_UPLOAD_THREADS", 8)));
-        for (auto &b : buf) { hipError_t e = hipHostMalloc((void **)&b, piece + 256, hipHostMallocPortable); if (e != hipSuccess) return e; }
+        for (auto &b : buf) { hipError_t e = g_pinned.get(&b, piece + 256); if (e != hipSuccess) return e; }
         return hipSuccess;
     }
     bool read(int b, size_t off, size_t len)          // false: the file could not be read (truncated under us, an I/O error)
@@ -427,9 +453,9 @@ public:
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
         // chunks: large enough that the serial link step (a fixed cost per chunk) stays small, small enough that a file keeps the chip busy
-        // (the link step costs ~7 us a chunk whatever its size, one chunk after the other: 512 KiB chunks for files of gigabytes -- the
-        // decode kernel runs at the same rate on them, tools/gzdev_check)
-        size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)512 << 10) & ~(size_t)4095;
+        // (512 KiB chunks halve the link step's share -- 4.5 us a chunk, one after the other -- and lose as much again in the first slab's decode
+        // and in waiting for decode kernels: measured level or slightly behind, profiles/r04)
+        size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)256 << 10) & ~(size_t)4095;
         chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", dflt);
         if (chunk_ < 1024) chunk_ = 1024;
         cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", std::max<uint64_t>(256, ((uint64_t)128 << 20) / chunk_));
@@ -922,6 +948,32 @@ struct DevScratch {
     ~DevScratch() { reads_release(reads); (void)hipSetDevice(dev); if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); if (h_out) (void)hipHostFree(h_out); }
 };
 
+// A consumer's scratch -- small pinned buffers, device buffers, the refillable read set with everything the filter hangs on it -- is kept
+// from call to call per (device, consumer): making it anew costs a call a few milliseconds at the start and a hipFree per buffer of the
+// read set (each waits for the device to go idle) at the end.  MF_KEEP_BUFFERS=0 releases it with the call.
+class ScratchCache {
+public:
+    std::unique_ptr<DevScratch> take(int ldev, int lane)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = kept_.find(std::make_pair(ldev, lane));
+        if (it == kept_.end()) return nullptr;
+        std::unique_ptr<DevScratch> p = std::move(it->second);
+        kept_.erase(it);
+        return p;
+    }
+    void give(std::unique_ptr<DevScratch> p)
+    {
+        const char *kb = getenv("MF_KEEP_BUFFERS");
+        if (!p || (kb && kb[0] == '0')) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        kept_[std::make_pair(p->ldev, p->lane)] = std::move(p);
+    }
+private:
+    std::mutex mu_; std::map<std::pair<int, int>, std::unique_ptr<DevScratch>> kept_;
+};
+ScratchCache &g_scratch = *new ScratchCache();          // (never destroyed: its entries would call into HIP while the process is being torn down)
+
 struct Mate {
     std::string path; Mapped map; bool gz = false;
     std::unique_ptr<GzStream> gzs; Slots slots;
@@ -959,7 +1011,10 @@ struct Ingest {
     size_t carry_room = (size_t)1 << 20;
     bool timing = false; double t_wait = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;      // summed over the consumer threads
     // consumers
-    struct Worker { int id = 0; std::map<int, std::unique_ptr<DevScratch>> scratch; std::thread th; };
+    struct Worker {
+        int id = 0; std::map<int, std::unique_ptr<DevScratch>> scratch; std::thread th;
+        ~Worker() { for (auto &kv : scratch) g_scratch.give(std::move(kv.second)); }
+    };
     std::vector<std::unique_ptr<Worker>> workers;
     std::mutex mu; std::condition_variable cv;          // the state the consumers share (turns, record counts, batches, bitmaps, timing sums)
     std::mutex emit_mu;                                 // one consumer at a time writes survivors (batches leave in order)
@@ -1037,6 +1092,12 @@ struct Ingest {
     {
         auto it = W.scratch.find(ldev);
         if (it != W.scratch.end()) { if (hipSetDevice(it->second->dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; } return it->second.get(); }
+        if (std::unique_ptr<DevScratch> kept = g_scratch.take(ldev, W.id)) {          // (a consumer's buffers and read set of an earlier call)
+            if (hipSetDevice(kept->dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
+            DevScratch *p = kept.get();
+            W.scratch[ldev] = std::move(kept);
+            return p;
+        }
         std::unique_ptr<DevScratch> S(new DevScratch());
         S->ldev = ldev; S->dev = phys(ldev); S->lane = W.id;
         if (get_ctx(ldev, &S->ctx, W.id)) { err = mf_thread_error(); return nullptr; }
@@ -1375,7 +1436,17 @@ bool alloc_failure(int rc) { return rc == MF_E_NOMEM; }
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
                       bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats)
 {
-    struct EndOfCall { ~EndOfCall() { const char *kb = getenv("MF_KEEP_BUFFERS"); g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 16) << 30); } } end_of_call;     // (declared first: runs after everything of this call is gone)
+    // (declared first: runs after everything of this call is gone.  What a process keeps between calls: up to MF_DEVPOOL_GB per device, default 24 --
+    // a call on a file of gigabytes holds 17-24 GB, and a process that filters file after file should not give them back and ask for them again)
+    struct EndOfCall {
+        bool timing = false; double t0 = 0;
+        ~EndOfCall()
+        {
+            const char *kb = getenv("MF_KEEP_BUFFERS");
+            g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 24) << 30);
+            if (timing) fprintf(stderr, "[mf device ingest] streams, threads and buffers of the call put away in %.3f s\n", now_s() - t0);
+        }
+    } end_of_call;
     Ingest I;
     I.ks = ks; I.threshold = threshold; I.pair_both = pair_both; I.nm = fq2 ? 2 : 1;
     for (int i = 0; i < n_devices; i++) I.devices.push_back(devices[i]);
@@ -1449,6 +1520,7 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
             if (I.m[i].gzs) fprintf(stderr, " | mate %d: inflate kernels busy %.3f s (%.1f GB/s of text), %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, I.m[i].gzs->decode_busy_seconds(), I.m[i].gzs->decode_busy_seconds() > 0 ? (double)I.m[i].gzs->text_bytes() / I.m[i].gzs->decode_busy_seconds() / 1e9 : 0.0, (unsigned long long)I.m[i].gzs->chunks_linked(),
                                     I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes(), I.m[i].gzs->ring_bytes() >> 20, I.m[i].gzs->splits());
         fprintf(stderr, "\n");
+        end_of_call.timing = true; end_of_call.t0 = now_s();
     }
     return MF_OK;
 }

@@ -305,6 +305,111 @@ __device__ __forceinline__ uint64_t next_candidate(Search &S, const uint32_t *wo
     }
 }
 
+// ---- candidates are vetted 64 at a time, one per lane
+// What the window test above lets through is still mostly noise: about one bit offset in five hundred, a thousand in a chunk that holds
+// no block start at all -- and sending each through the wavefront's header reader (seek, precode table, code lengths until a Kraft sum
+// runs over) cost ~20 k cycles apiece: 8 M cycles a chunk, more than half of what a 64 KiB chunk of a small file takes, 23 M in the
+// chunks that find nothing.  So the next 64 candidates are collected first and every LANE reads the header of its own: the 19 precode
+// lengths into one register, the code lengths decoded with the canonical rule bit by bit (no table), running Kraft sums of both
+// alphabets -- the rules of read_code_lengths / build_tables for a strict header, nothing built.  The first lane that comes through
+// gives the wavefront its start (the header is then read again by all lanes, which builds the tables); the others stay in the batch
+// in case the data behind it does not decode.
+__device__ __forceinline__ bool vet_header(const uint32_t *words, uint64_t wmask, uint64_t max_dw, uint64_t c, uint64_t size_bits)
+{
+    uint64_t w = c >> 5;
+    auto ld = [&](uint64_t i) -> uint32_t { i = i < max_dw ? i : max_dw; return words[i & wmask]; };
+    const uint32_t sh = (uint32_t)c & 31u;
+    uint64_t bb = ((uint64_t)ld(w) | ((uint64_t)ld(w + 1) << 32)) >> sh; uint32_t bc = 64 - sh;
+    w += 2;
+    uint32_t used = 0;
+    auto need = [&](uint32_t n) { if (bc < n) { bb |= (uint64_t)ld(w) << bc; bc += 32; w++; } };        // n <= 32
+    auto take = [&](uint32_t n) -> uint32_t { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); bb >>= n; bc -= n; used += n; return v; };
+    need(17);
+    (void)take(3);
+    const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    // precode: length of symbol s in bits 3 s .. 3 s + 2 of pl
+    uint64_t pl = 0;
+    constexpr uint64_t ORDER_LO = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+    constexpr uint64_t ORDER_HI = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+#pragma unroll
+    for (uint32_t i = 0; i < 19; i++) {
+        if (i < hclen) {
+            need(3);
+            const uint32_t sym = (uint32_t)((i < 12 ? ORDER_LO >> (5 * i) : ORDER_HI >> (5 * (i - 12))) & 31u);
+            pl |= (uint64_t)take(3) << (3 * sym);
+        }
+    }
+    // codes per length (5 bits each, length l in bits 5 (l - 1) ..) and the symbols sorted by (length, symbol), 5 bits each
+    uint64_t cn = 0, sl_lo = 0, sl_hi = 0; uint32_t k = 0, kraft = 0;
+    for (uint32_t l = 1; l <= 7; l++) {
+        uint32_t c_l = 0;
+#pragma unroll
+        for (uint32_t sy = 0; sy < 19; sy++)
+            if (((uint32_t)(pl >> (3 * sy)) & 7u) == l) {
+                if (k < 12) sl_lo |= (uint64_t)sy << (5 * k); else sl_hi |= (uint64_t)sy << (5 * (k - 12));
+                k++; c_l++;
+            }
+        cn |= (uint64_t)c_l << (5 * (l - 1));
+        kraft += c_l << (7 - l);
+    }
+    if (kraft != 128u) return false;
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0, kl = 0, kd = 0, nd = 0; bool has_eob = false;
+    while (i < total) {
+        need(16);
+        // one precode symbol, bit by bit (codes are packed most significant bit first)
+        uint32_t code = 0, first = 0, index = 0, sym = 0xFFu;
+        for (uint32_t l = 1; l <= 7; l++) {
+            code |= (uint32_t)bb & 1u; bb >>= 1; bc--; used++;
+            const uint32_t cnt = (uint32_t)(cn >> (5 * (l - 1))) & 31u;
+            if (code - first < cnt) { const uint32_t at = index + (code - first); sym = (uint32_t)((at < 12 ? sl_lo >> (5 * at) : sl_hi >> (5 * (at - 12))) & 31u); break; }
+            index += cnt; first = (first + cnt) << 1; code <<= 1;
+        }
+        if (sym == 0xFFu) return false;
+        uint32_t rep = 1, val = sym;
+        if (sym >= 16) {
+            val = 0;
+            if (sym == 16) { if (i == 0) return false; val = prev; rep = 3 + take(2); }
+            else if (sym == 17) rep = 3 + take(3);
+            else rep = 11 + take(7);
+            if (i + rep > total) return false;
+        }
+        if (val) {
+            const uint32_t in_lit = i >= hlit ? 0 : (i + rep <= hlit ? rep : hlit - i);
+            kl += in_lit * (32768u >> val); kd += (rep - in_lit) * (32768u >> val); nd += rep - in_lit;
+            if (kl > 32768u || kd > 32768u) return false;
+            if (i <= 256 && 256 < i + rep) has_eob = true;
+        }
+        i += rep; prev = val;
+    }
+    if (kl != 32768u || !has_eob) return false;
+    if (nd > 1 && kd != 32768u) return false;
+    return c + used <= size_bits;
+}
+// the next candidate that passes vet_header (~0: none in [.., to_bit)); V: the batch in hand
+struct Vetted { uint64_t cand; uint64_t vmask; bool dry; };      // cand: this lane's candidate of the batch; vmask: lanes whose candidate came through and has not been handed out
+__device__ __forceinline__ uint64_t next_vetted(Search &S, Vetted &V, const uint32_t *words, uint64_t wmask, uint64_t max_dw, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
+{
+    for (;;) {
+        if (V.vmask) {
+            const int idx = __ffsll((unsigned long long)V.vmask) - 1;
+            V.vmask &= V.vmask - 1;
+            return __shfl(V.cand, idx);
+        }
+        if (V.dry) return ~0ull;
+        uint32_t n = 0; uint64_t mine = ~0ull;
+        while (n < 64) {
+            const uint64_t c = next_candidate(S, words, wmask, to_bit, size_bits, lane);
+            if (c == ~0ull) { V.dry = true; break; }
+            if (lane == n) mine = c;
+            n++;
+        }
+        const bool ok = lane < n && vet_header(words, wmask, max_dw, mine, size_bits);
+        V.cand = mine; V.vmask = __ballot(ok);
+    }
+}
+
 enum WalkEnd : uint32_t { W_MORE = 0, W_EOB = 1, W_ERROR = 2 };
 
 // Walk codes until the round is full, the block ends or something is wrong.  One dependent chain.  Outside the assembly loop
@@ -1125,6 +1230,7 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
     const uint64_t origin_bits = rd.origin_v * 128;
     bool searching = c != exact_chunk;
     Search S; search_init(S, nominal);
+    Vetted V; V.cand = ~0ull; V.vmask = 0; V.dry = false;
     uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
     uint32_t status = GZ_NONE;
     if (!searching) rd.seek(start, lane);
@@ -1142,7 +1248,7 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
         why = 0;
         PROF_T0();
         if (searching) {
-            start = next_candidate(S, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, search_end, size_bits, lane);
+            start = next_vetted(S, V, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, in.max_dw, search_end, size_bits, lane);
             if (start == ~0ull) { status = GZ_NONE; break; }
             rd.seek(start + 3, lane);
             strict = true; opos = 0; blk_pos = start; blk_opos = 0;

@@ -79,7 +79,13 @@ int main(int argc, char **argv)
     if (d_scratch) {          // cycle counts per phase, summed over the chunks (the kernel leaves them at the head of every chunk's list scratch)
         const size_t per = mf::gz_decode_scratch_bytes(1);
         unsigned long long tot[17] = {0}, v[17];
-        for (uint32_t c = 0; c < n_chunks; c++) { CK(hipMemcpy(v, (const char *)d_scratch + (size_t)c * per, sizeof v, hipMemcpyDeviceToHost)); for (int i = 0; i < 17; i++) tot[i] += v[i]; }
+        unsigned long long slow[17] = {0};
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            CK(hipMemcpy(v, (const char *)d_scratch + (size_t)c * per, sizeof v, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 17; i++) tot[i] += v[i];
+            if (v[16] > slow[16]) memcpy(slow, v, sizeof slow);
+        }
+        printf("  the slowest chunk: search + header %llu | tables %llu | walks %llu | expansion %llu | whole %llu ; %llu blocks, %llu steps\n", slow[0], slow[1], slow[2], slow[3], slow[16], slow[7], slow[4]);
         printf("  cycles per chunk (shader clock): search + header %.0f | tables %.0f | walks %.0f | expansion %.0f | whole %.0f ;  per chunk: %.1f blocks, %.1f steps, %.1f walk rounds, %.1f expansion rounds\n",
                (double)tot[0] / n_chunks, (double)tot[1] / n_chunks, (double)tot[2] / n_chunks, (double)tot[3] / n_chunks, (double)tot[16] / n_chunks,
                (double)tot[7] / n_chunks, (double)tot[4] / n_chunks, (double)tot[5] / n_chunks, (double)tot[6] / n_chunks);
