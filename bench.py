@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--no-group-a", action="store_true", help="skip the Group-A row (contig filter CLI on the 1 M-record generator file)")
     ap.add_argument("--real-gz-reads", type=int, default=READS_5GBP // 8,
                     help="reads of the single-end file that gzip / pigz / bgzip compress themselves (default: an eighth of configs[4]; 0 = skip)")
-    ap.add_argument("--k-sweep", default="21,41", help="other k of configs[2] timed on the same resident reads, a few steps each ('' = none)")
+    ap.add_argument("--k-sweep", default="21,41", help="other k of configs[2] timed on the same resident reads, a few steps each ('none' = none)")
     ap.add_argument("--rank-file-reads", type=int, default=500_000, help="N > 1: reads of the .gz shard every rank filters file to file on its own GPU (0 = skip)")
     return ap.parse_args()
 
@@ -524,10 +524,10 @@ def main():
         extra["exhaustive_reads_per_s"] = a.reads / (ex.ms_total / 1e3)
         extra["exhaustive_passed"] = int(ex.n_pass)
 
-    if solo and a.k_sweep:
+    if solo and a.k_sweep and a.k_sweep != "none":
         # configs[2]: the other k on the same resident reads (a few steps each: set built on the device, warm-up, timed loop, sampled loop)
         sweep = {}
-        for kk in [int(x) for x in a.k_sweep.split(",") if x.strip()]:
+        for kk in [int(x) for x in a.k_sweep.replace('"', "").split(",") if x.strip().isdigit()]:
             if kk == a.k:
                 continue
             try:

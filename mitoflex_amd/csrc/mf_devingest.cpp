@@ -277,6 +277,24 @@ public:
         return s.release();
     }
     void give(StreamSet *s) { if (s) { std::lock_guard<std::mutex> lk(mu_); free_.push_back(s); } }
+    // Under rocprofv3 a process that still owns CU-masked streams when it exits dies in the profiler's finaliser (SIGSEGV below
+    // __cxa_finalize, after the profile has been written; without a profiler the exit is clean).  So when a profiler is loaded
+    // the idle sets are destroyed here, at exit, after a device synchronisation -- not otherwise: destroying such a stream was seen to
+    // hang now and then (above), and an exit that hangs is worse than one a profiler complains about.
+    ~StreamSets()
+    {
+        const char *pre = getenv("LD_PRELOAD");
+        const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
+        if (!profiled) return;
+        for (StreamSet *s : free_) {
+            if (hipSetDevice(s->device) != hipSuccess) continue;
+            (void)hipDeviceSynchronize();
+            for (auto &q : s->sd) if (q) (void)hipStreamDestroy(q);
+            if (s->link) (void)hipStreamDestroy(s->link);
+            if (s->rest) (void)hipStreamDestroy(s->rest);
+            if (s->copy) (void)hipStreamDestroy(s->copy);
+        }
+    }
 private:
     std::mutex mu_; std::vector<StreamSet *> free_;
 };
