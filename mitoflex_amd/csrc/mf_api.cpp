@@ -1059,6 +1059,35 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     if (!out1) return fail(MF_E_ARG, "out1 is NULL");
     if (start > end) return fail(MF_E_ARG, "start comes after end");
     if (quality == 0 || quality > 100) return fail(MF_E_ARG, "quality must be in 1..100");
+    QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
+    P.dedup = dedup != 0; P.trunc = truncate_only != 0;
+    // Regular files -- .gz or plain -- take the device ingest path (mf_devingest.cpp): the bytes go up as they lie, and inflate, line index,
+    // counting, hashing, the de-duplication set, the decisions and the formatting of the kept records run there; what comes back is the
+    // output's text.  Standard input, pipes, BGZF, empty files and .gz outputs keep the host pipeline below, and MF_QUAL_INGEST=host keeps
+    // everything there (=device is the default; both write the same bytes: tests/test_filter_v2.py runs the reference's vectors through both).
+    {
+        const char *ing = getenv("MF_QUAL_INGEST");
+        if (!(ing && strcmp(ing, "host") == 0) && fq1) {
+            if (mf_device_count() <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible; libmitofilter_hip has no CPU fallback");
+            std::string derr; IngestStats is; bool pan = false;
+            const int drc = run_device_qualfilter(fq1, fq2, out1, out2, P, device, kept, total, &pan, derr, &is);
+            if (drc == MF_OK) {
+                mf_ingest_stats_t &o = t_ingest_stats;
+                memset(&o, 0, sizeof o);
+                o.path = MF_INGEST_PATH_DEVICE; o.n_devices = is.n_devices; o.consumers = is.consumers;
+                o.input_bytes = is.input_bytes; o.text_bytes = is.text_bytes; o.records = is.records;
+                o.seconds = is.seconds; o.decode_busy_seconds = is.decode_busy_seconds;
+                o.pool_bytes_peak = is.pool_bytes_peak; o.device_bytes_peak = is.device_bytes_peak;
+                o.chunks = is.chunks; o.chunks_linked = is.chunks_linked; o.gaps = is.gaps; o.gap_bytes = is.gap_bytes;
+                t_ingest_stats_valid = true;
+                if (panicked) *panicked = pan ? 1 : 0;
+                return MF_OK;
+            }
+            if (drc != MF_DEVINGEST_DECLINED) return fail(drc, "%s", derr.c_str());
+            if (getenv("MF_PIPE_TIMING")) fprintf(stderr, "[mf device ingest] quality filter declined%s%s: the host pipeline takes the input\n", derr.empty() ? "" : ": ", derr.c_str());
+        }
+    }
+    t_ingest_stats_valid = false;
     // The device is set up by the first batch that needs it (the decision thread), while the readers are already parsing: HIP's
     // start-up is a third of a second, as long as the whole pipeline takes for a few million records.  Without a gfx950 device the
     // call fails there with MF_E_NO_DEVICE (no CPU fallback) -- the output files have been created by then.
@@ -1134,8 +1163,6 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     };
 #undef QCHK
     static_assert(sizeof(QualSpan) == sizeof(QualRec), "host and device record layouts must match");
-    QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
-    P.dedup = dedup != 0; P.trunc = truncate_only != 0;
     int threads = (int)std::thread::hardware_concurrency() - 4; if (threads < 2) threads = 2; if (threads > 64) threads = 64;
     QualStats qs; std::string perr;
     rc = run_qualfilter_pipeline(fq1, fq2, out1, out2, P, threads, env_u32("MF_BATCH_READS", 2000000), scan, dedup_fn, qs, perr);

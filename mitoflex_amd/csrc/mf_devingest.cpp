@@ -23,6 +23,7 @@
 #include "mf_host.h"
 #include "mf_ingest.h"
 #include "mf_pinflate.h"
+#include "mf_pipeline.h"
 
 #include <algorithm>
 #include <atomic>
@@ -306,6 +307,7 @@ struct Slots {
     bool take() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return free_ > 0 || (stop && *stop); }); if (free_ <= 0) return false; free_--; return true; }
     void give() { { std::lock_guard<std::mutex> lk(mu); free_++; } cv.notify_all(); }
     void wake() { cv.notify_all(); }
+    bool none_free() { std::lock_guard<std::mutex> lk(mu); return free_ <= 0; }
 };
 
 // ---- the text of one piece of an input file on one device.  In front of the text: `pad` readable bytes -- the 32 KiB deflate
@@ -950,7 +952,12 @@ struct Batch {
     uint64_t n_rec = 0, rec_base = 0, n_text = 0, n_lines = 0;
     int ldev = 0;
     bool filtered = false;               // its pass bits are in the mate's bitmap
+    // the quality filter's job (QualState below): what one pass over the records found, kept with the batch until its turn to be decided
+    DevBuf<uint32_t> q_bad, q_sl, q_ql, q_olen; DevBuf<uint8_t> q_fl; DevBuf<uint64_t> q_hash;
+    uint64_t q_done = 0;                                  // (Ingest::mu) records of it that have been decided
 };
+// records [r0, r0 + n) of a batch, decided: their text goes to bytes [out_at, out_at + bytes) of the mate's output file
+struct QPart { uint64_t r0 = 0, n = 0, out_at = 0, bytes = 0; };
 
 // what a consumer thread keeps per device: scratch buffers and the refillable read set (its own context of the device: own streams)
 struct DevScratch {
@@ -963,7 +970,25 @@ struct DevScratch {
     uint64_t *h_small = nullptr;
     uint32_t *h_bits = nullptr; size_t h_bits_cap = 0;       // pinned: the pass bits of a piece on their way to the host, the keep mask on its way back
     uint8_t *h_out = nullptr; size_t h_out_cap = 0;          // pinned: survivors on their way to the writer
-    ~DevScratch() { reads_release(reads); (void)hipSetDevice(dev); if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); if (h_out) (void)hipHostFree(h_out); }
+    // the quality filter's job: the other mate's scan results and keep flags on their way up, keep flags on their way down (pinned), per-record scratch
+    uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
+    DevBuf<uint32_t> q_bad2; DevBuf<uint8_t> q_fl2, q_alive, q_dup, q_keep;
+    hipEvent_t ev_out[2] = {nullptr, nullptr};
+    hipError_t stage(size_t bytes)
+    {
+        if (bytes <= h_stage_cap) return hipSuccess;
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr; h_stage_cap = 0;
+        hipError_t e = hipHostMalloc((void **)&h_stage, bytes + bytes / 2 + 65536, hipHostMallocDefault);
+        if (e == hipSuccess) h_stage_cap = bytes + bytes / 2 + 65536;
+        return e;
+    }
+    ~DevScratch()
+    {
+        reads_release(reads); (void)hipSetDevice(dev);
+        if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); if (h_out) (void)hipHostFree(h_out); if (h_stage) (void)hipHostFree(h_stage);
+        for (auto &e : ev_out) if (e) (void)hipEventDestroy(e);
+    }
 };
 
 // A consumer's scratch -- small pinned buffers, device buffers, the refillable read set with everything the filter hangs on it -- is kept
@@ -992,6 +1017,92 @@ private:
 };
 ScratchCache &g_scratch = *new ScratchCache();          // (never destroyed: its entries would call into HIP while the process is being torn down)
 
+// ---- the quality filter's job on this path (the reference's filter_v2: filter/filter_bin/src/main.rs:188-323)
+// one value per record of a file, written and read a piece at a time by several threads: segments of 2^20 records that never move
+template <class T> class SegArray {
+public:
+    SegArray() : tab_(new std::atomic<T *>[NSEG]) { for (size_t i = 0; i < NSEG; i++) tab_[i] = nullptr; }
+    ~SegArray() { for (size_t i = 0; i < NSEG; i++) delete[] tab_[i].load(); }
+    bool put(uint64_t r0, uint64_t n, const T *src)
+    {
+        if (!n) return true;
+        if ((r0 + n - 1) / SEG >= NSEG) return false;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (uint64_t g = r0 / SEG; g <= (r0 + n - 1) / SEG; g++) if (!tab_[g].load()) { T *q = new (std::nothrow) T[SEG]; if (!q) return false; tab_[g] = q; }
+        }
+        for (uint64_t i = 0; i < n;) { const uint64_t g = (r0 + i) / SEG, o = (r0 + i) % SEG, c = std::min<uint64_t>(n - i, SEG - o); memcpy(tab_[g].load() + o, src + i, c * sizeof(T)); i += c; }
+        return true;
+    }
+    void get(uint64_t r0, uint64_t n, T *dst) const          // (of records that have been put)
+    {
+        for (uint64_t i = 0; i < n;) { const uint64_t g = (r0 + i) / SEG, o = (r0 + i) % SEG, c = std::min<uint64_t>(n - i, SEG - o); memcpy(dst + i, tab_[g].load() + o, c * sizeof(T)); i += c; }
+    }
+private:
+    static constexpr uint64_t SEG = (uint64_t)1 << 20; static constexpr size_t NSEG = (size_t)1 << 16;
+    std::unique_ptr<std::atomic<T *>[]> tab_; std::mutex mu_;
+};
+
+// An output file of the quality filter.  Nearly every record is written, so the pieces' text is as large as the input's: a regular
+// file takes the pieces at their offsets from whichever consumer has one ready (pwrite); anything else -- standard output, a pipe,
+// a .gz (compressed by OutFile as the reference's GzEncoder would) -- takes them in order.
+class QSink {
+public:
+    bool open(const char *path)
+    {
+        if (path && !has_gz_ext(path)) {
+            fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            if (fd_ < 0) return false;
+            struct stat sb;
+            if (fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) { direct_ = true; return true; }
+            ::close(fd_); fd_ = -1;
+        }
+        return of_.open(path);
+    }
+    bool write_at(uint64_t off, const uint8_t *p, size_t n)
+    {
+        if (direct_) {
+            while (n) {
+                const ssize_t w = pwrite(fd_, p, n, (off_t)off);
+                if (w < 0) { if (errno == EINTR) continue; ok_ = false; return false; }
+                p += w; n -= (size_t)w; off += (uint64_t)w;
+            }
+            return true;
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return next_ == off || !ok_ || abort_; });
+        if (!ok_ || abort_) return false;
+        if (n && !of_.write((const char *)p, n)) ok_ = false;
+        next_ = off + n;
+        lk.unlock(); cv_.notify_all();
+        return ok_;
+    }
+    void abort() { { std::lock_guard<std::mutex> lk(mu_); abort_ = true; } cv_.notify_all(); }
+    bool close()
+    {
+        if (direct_) { const bool c = fd_ < 0 || ::close(fd_) == 0; fd_ = -1; return c && ok_; }
+        return of_.close() && ok_;
+    }
+    ~QSink() { if (fd_ >= 0) ::close(fd_); }
+private:
+    int fd_ = -1; bool direct_ = false; OutFile of_;
+    std::mutex mu_; std::condition_variable cv_; uint64_t next_ = 0; bool ok_ = true, abort_ = false;
+};
+
+struct QualState {
+    QualParams P; bool pe = false; uint64_t cap = ~0ull;          // cap: the longest a cut string gets (end - start), ~0: no end
+    SegArray<uint32_t> bad2; SegArray<uint8_t> fl2, keep;         // mate 2's scan results, mate 1's decisions: per record of the file, on the host
+    uint64_t panic_rec[2] = {~0ull, ~0ull};                       // (Ingest::mu) the first record at which the reference would panic, per mate, among the scanned pieces
+    // decisions are taken a piece of mate 1 at a time, in order (Ingest::emit_mu):
+    uint64_t budget = 0, kept = 0, out_pos[2] = {0, 0};
+    uint64_t decided = 0; bool decided_final = false, panicked = false;      // (Ingest::mu) records [0, decided) have their keep flags; final: no more will be decided
+    int in_flight = 0;                                            // (Ingest::mu) pieces being gathered and written
+    // the de-duplication set (keys, smallest file index per key; mf_kernels.hip): on the device for the whole file
+    DevBuf<unsigned long long> dd_keys, dd_first, dd_small; uint64_t dd_slots = 0, dd_n = 0;
+    QSink sink[2];
+    double t_scan = 0, t_decide = 0, t_gather = 0, t_write = 0;   // (Ingest::mu) summed over the consumers
+};
+
 struct Mate {
     std::string path; Mapped map; bool gz = false;
     std::unique_ptr<GzStream> gzs; Slots slots;
@@ -1005,7 +1116,7 @@ struct Mate {
     uint64_t rec_indexed = 0;            // records of the pieces indexed so far (the next piece's first record)
     uint64_t rec_filtered = 0;           // ... of the leading pieces whose pass bits are in `bits`
     uint8_t *h_carry = nullptr; size_t h_carry_cap = 0, carry = 0;      // pinned: the head of the record the last piece left unfinished
-    std::deque<std::unique_ptr<Batch>> batches;          // indexed, in order; leave when written
+    std::deque<std::shared_ptr<Batch>> batches;          // indexed, in order; leave when written
     std::vector<uint32_t> bits;                          // pass bits of the whole file so far, one per record
     Writer out;
     ~Mate()
@@ -1021,7 +1132,8 @@ struct Mate {
 };
 
 struct Ingest {
-    mf_kmerset *ks; uint32_t threshold; bool pair_both; std::vector<int> devices;
+    mf_kmerset *ks = nullptr; uint32_t threshold = 1; bool pair_both = false; std::vector<int> devices;
+    QualState *qual = nullptr;          // set: the job is the quality filter (one device), not the bait filter
     Mate m[2]; int nm = 1;
     uint64_t kept = 0, total = 0;
     bool wrote_any = false;
@@ -1128,7 +1240,7 @@ struct Ingest {
 
     // ---- step A of a piece (one piece of a mate at a time, in order): the carry goes in front of its text, lines are counted and
     // indexed, the records counted; what is behind the last complete record is the next piece's carry.
-    int index_piece(Worker &W, Mate &M, TextPiece &P, std::unique_ptr<Batch> &Bout, std::string &err)
+    int index_piece(Worker &W, Mate &M, TextPiece &P, std::shared_ptr<Batch> &Bout, std::string &err)
     {
         const double t0 = now_s();
         DevScratch *Sp = scratch_for(W, P.buf->ldev, err);
@@ -1147,7 +1259,7 @@ struct Ingest {
             P.buf = std::move(nb);
         }
         if (M.carry) DCHK(hipMemcpyAsync(P.buf->p - M.carry, M.h_carry, M.carry, hipMemcpyHostToDevice, sp));
-        std::unique_ptr<Batch> B(new Batch());
+        std::shared_ptr<Batch> B(new Batch());
         B->ldev = S.ldev;
         B->text = P.buf->p - M.carry;
         const uint8_t *text = B->text;
@@ -1332,7 +1444,7 @@ struct Ingest {
         for (int i = 0; i < nm; i++) {
             Mate &M = m[i];
             for (;;) {
-                std::unique_ptr<Batch> B; uint64_t covered = 0;
+                std::shared_ptr<Batch> B; uint64_t covered = 0;
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     if (M.batches.empty() || !M.batches.front()->filtered) break;
@@ -1349,10 +1461,11 @@ struct Ingest {
 
     // the next piece for a consumer: of the mate that is behind in records, if it has one ready (a mate whose text is not there yet
     // does not hold up the other).  false: nothing more will come (or the run has failed)
-    bool take_piece(int &mi, TextPiece &P, uint64_t &seq, std::string &err, int &rc)
+    // again (quality filter): set when nothing is ready yet but more may come -- the caller has other work to look after
+    bool take_piece(int &mi, TextPiece &P, uint64_t &seq, std::string &err, int &rc, bool *again = nullptr)
     {
         const double tw = now_s();
-        for (;;) {
+        for (int round = 0;; round++) {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (failed) return false;
@@ -1362,6 +1475,10 @@ struct Ingest {
                 for (int k = 0; k < nm; k++) {
                     Mate &M = m[order[k]];
                     if (M.eof) continue;
+                    if (qual && qual->decided_final && M.rec_indexed >= qual->decided) {      // nothing behind the last decided record is wanted
+                        M.eof = true; M.stop = true; M.slots.wake();
+                        continue;
+                    }
                     std::unique_lock<std::mutex> plk(M.mu);
                     if (!M.ready.empty()) {
                         P = std::move(M.ready.front()); M.ready.pop_front();
@@ -1376,9 +1493,367 @@ struct Ingest {
                     } else any_open = true;
                 }
                 if (!any_open) { if (timing) t_wait += now_s() - tw; return false; }
+                if (again && round) { *again = true; if (timing) t_wait += now_s() - tw; return false; }
             }
             std::unique_lock<std::mutex> lk(mu_all);
             cv_all.wait_for(lk, std::chrono::microseconds(300));
+        }
+    }
+
+
+    // ================================================================ the quality filter's job
+    // A piece goes through: line index (in turn per mate, as above) -> SCAN (side by side: one pass over the records' bytes) ->
+    // DECIDE (one piece at a time, mate 1's in file order: the tests, the de-duplication set, the -t budget; mate 2's pieces
+    // pick up the keep flags of their records) -> GATHER + WRITE (side by side again: the pieces' places in the output files are
+    // known from the decisions).  The two mates' pieces do not cover the same records, so what one mate's step needs of the other
+    // travels through per-record arrays on the host (mate 2's counts, mate 1's keep flags).
+
+    void update_scanned(Mate &M)          // (mu held) records of the leading scanned pieces
+    {
+        uint64_t upto = M.rec_filtered;
+        for (auto &q : M.batches) { if (q->rec_base < upto) continue; if (q->rec_base != upto || !q->filtered) break; upto = q->rec_base + q->n_rec; }
+        M.rec_filtered = upto;
+    }
+    bool scans_done(const Mate &M) const { return M.eof && M.a_turn == M.taken && M.rec_filtered == M.rec_indexed; }      // (mu held) every piece that will ever come is scanned
+
+    int q_scan(Worker &W, int mi, Batch &B, std::string &err)
+    {
+        const double t0 = now_s();
+        QualState &Q = *qual;
+        DevScratch *Sp = scratch_for(W, B.ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        volatile uint64_t *hs = S.h_small;
+        const uint64_t n = B.n_rec;
+        if (n >= 0xFFFFFFF0ull) { err = "a piece of text with 2^32 records"; return MF_E_ARG; }
+        DCHK(B.q_bad.need(dev, n, false)); DCHK(B.q_sl.need(dev, n, false)); DCHK(B.q_ql.need(dev, n, false)); DCHK(B.q_olen.need(dev, n, false)); DCHK(B.q_fl.need(dev, n, false));
+        DCHK(S.minmax.need(dev, 2));
+        S.h_small[8] = ~0ull;
+        DCHK(hipMemcpyAsync(S.minmax.p, S.h_small + 8, 8, hipMemcpyHostToDevice, sp));
+        DCHK(launch_qual_scan(B.text, B.line_start.p, n, Q.P.start, Q.cap, Q.P.quality, Q.P.ns, B.q_bad.p, B.q_fl.p, B.q_sl.p, B.q_ql.p, B.q_olen.p, S.minmax.p, sp));
+        if (mi == 0 && Q.P.dedup && !Q.P.trunc) { DCHK(B.q_hash.need(dev, n, false)); DCHK(launch_qual_hash(B.text, B.line_start.p, n, Q.P.start, B.q_sl.p, B.q_hash.p, sp)); }
+        DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 4, hipMemcpyDeviceToHost, sp));
+        uint32_t *h_bad = nullptr; uint8_t *h_fl = nullptr;
+        if (mi == 1) {
+            DCHK(S.stage(n * 5 + 16));
+            h_bad = (uint32_t *)S.h_stage; h_fl = S.h_stage + n * 4;
+            DCHK(hipMemcpyAsync(h_bad, B.q_bad.p, n * 4, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(h_fl, B.q_fl.p, n, hipMemcpyDeviceToHost, sp));
+        }
+        DCHK(hipStreamSynchronize(sp));
+        const uint32_t first_flag = (uint32_t)hs[4];
+        if (mi == 1 && (!Q.bad2.put(B.rec_base, n, h_bad) || !Q.fl2.put(B.rec_base, n, h_fl))) { err = "out of memory"; return MF_E_NOMEM; }
+        uint64_t panic_at = ~0ull;
+        if (first_flag != ~0u) {
+            // rare: a byte that is not ASCII in a line the reference unwraps, or a string shorter than the cut's start.  The flagged
+            // records are looked at on the host, in order, until one makes the reference panic (a header in UTF-8 does not).
+            std::vector<uint8_t> fl(n), text(B.n_text + 1); std::vector<uint64_t> ls(4 * n + 1);
+            DCHK(hipMemcpy(fl.data(), B.q_fl.p, n, hipMemcpyDeviceToHost));
+            DCHK(hipMemcpy(ls.data(), B.line_start.p, (4 * n + 1) * 8, hipMemcpyDeviceToHost));
+            DCHK(hipMemcpy(text.data(), B.text, B.n_text, hipMemcpyDeviceToHost));
+            auto line = [&](uint64_t k, const char *&p, size_t &len) {
+                const uint64_t a = ls[k], b = std::min<uint64_t>(ls[k + 1], B.n_text + 1);
+                len = (size_t)(b - a - 1); p = (const char *)text.data() + a;
+                if (len && p[len - 1] == '\r') len--;
+            };
+            for (uint64_t r = first_flag; r < n && panic_at == ~0ull; r++) {
+                if (!(fl[r] & (QF_HIGH | QF_SHORT | QF_LONG))) continue;
+                if (fl[r] & QF_LONG) { err = "a FASTQ record of 4 GiB or more"; return MF_E_ARG; }
+                if (fl[r] & QF_SHORT) { panic_at = r; break; }
+                for (int k : {0, 1, 3}) { const char *p; size_t len; line(4 * r + k, p, len); if (!utf8_valid(p, len)) { panic_at = r; break; } }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            Mate &M = m[mi];
+            if (panic_at != ~0ull) Q.panic_rec[mi] = std::min(Q.panic_rec[mi], B.rec_base + panic_at);
+            B.filtered = true;
+            update_scanned(M);
+            Q.t_scan += now_s() - t0;
+            size_t f = 0, t = 0;
+            if (hipMemGetInfo(&f, &t) == hipSuccess) mem_used_max = std::max(mem_used_max, t - f);
+        }
+        return MF_OK;
+    }
+
+    int q_dedup_room(DevScratch &S, uint64_t n, std::string &err)          // the set holds at most half its slots after n more keys
+    {
+        QualState &Q = *qual;
+        const int dev = S.dev; hipStream_t sp = S.ctx->stream;
+        if (!Q.dd_slots) {
+            uint64_t lg = env_u64("MF_DEDUP_LOG2_SLOTS", 24);
+            lg = std::min<uint64_t>(std::max<uint64_t>(lg, 4), 34);
+            Q.dd_slots = (uint64_t)1 << lg;
+            DCHK(Q.dd_keys.need(dev, Q.dd_slots, false)); DCHK(Q.dd_first.need(dev, Q.dd_slots, false));
+            DCHK(hipMemsetAsync(Q.dd_keys.p, 0, Q.dd_slots * 8, sp)); DCHK(hipMemsetAsync(Q.dd_first.p, 0xFF, Q.dd_slots * 8, sp));
+        }
+        while (2 * (Q.dd_n + n) > Q.dd_slots) {
+            DevBuf<unsigned long long> k2, f2;
+            DCHK(k2.need(dev, Q.dd_slots * 2, false)); DCHK(f2.need(dev, Q.dd_slots * 2, false));
+            DCHK(hipMemsetAsync(k2.p, 0, Q.dd_slots * 16, sp)); DCHK(hipMemsetAsync(f2.p, 0xFF, Q.dd_slots * 16, sp));
+            DCHK(launch_dedup_rehash(Q.dd_keys.p, Q.dd_first.p, Q.dd_slots, k2.p, f2.p, Q.dd_slots * 2, sp));
+            DCHK(hipStreamSynchronize(sp));
+            std::swap(Q.dd_keys.p, k2.p); std::swap(Q.dd_keys.cap, k2.cap); std::swap(Q.dd_keys.bytes_, k2.bytes_);
+            std::swap(Q.dd_first.p, f2.p); std::swap(Q.dd_first.cap, f2.cap); std::swap(Q.dd_first.bytes_, f2.bytes_);
+            Q.dd_slots *= 2;
+        }
+        return MF_OK;
+    }
+
+    // records [r0, r0 + n) of mate 1's piece B (emit_mu held): the tests, the de-duplication, the budget; where their output goes.
+    // *stopped: the -t budget ran out among them (part.n: the records in front of the one that overflowed it)
+    int q_decide(Worker &W, Batch &B, uint64_t r0, uint64_t n, QPart &part, bool *stopped, std::string &err)
+    {
+        const uint64_t g0 = B.rec_base + r0;          // file index of the first
+        const double t0 = now_s();
+        QualState &Q = *qual;
+        DevScratch *Sp = scratch_for(W, B.ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        volatile uint64_t *hs = S.h_small;
+        uint64_t bytes = 0, kept_here = 0;
+        if (n) {
+            DCHK(S.q_alive.need(dev, n)); DCHK(S.q_keep.need(dev, n)); DCHK(S.out_len.need(dev, n)); DCHK(S.out_off.need(dev, n + 1)); DCHK(S.scan_tmp.need(dev, n / 4096 + 4));
+            DCHK(S.stage(n * 5 + 16));
+            if (Q.pe) {
+                DCHK(S.q_bad2.need(dev, n)); DCHK(S.q_fl2.need(dev, n));
+                Q.bad2.get(g0, n, (uint32_t *)S.h_stage); Q.fl2.get(g0, n, S.h_stage + n * 4);
+                DCHK(hipMemcpyAsync(S.q_bad2.p, S.h_stage, n * 4, hipMemcpyHostToDevice, sp));
+                DCHK(hipMemcpyAsync(S.q_fl2.p, S.h_stage + n * 4, n, hipMemcpyHostToDevice, sp));
+            }
+            DCHK(launch_qual_decide(n, Q.pe, Q.P.trunc, Q.P.limit, B.q_bad.p + r0, B.q_fl.p + r0, B.q_sl.p + r0, B.q_ql.p + r0, S.q_bad2.p, S.q_fl2.p, S.q_alive.p, sp));
+            const bool dd = Q.P.dedup && !Q.P.trunc;
+            if (!Q.dd_small.p) {          // [0] file index of the hash value 0, [1] keys in the set, [2] kept records of a piece
+                DCHK(Q.dd_small.need(dev, 4, false));
+                DCHK(hipMemsetAsync(Q.dd_small.p, 0xFF, 8, sp)); DCHK(hipMemsetAsync(Q.dd_small.p + 1, 0, 24, sp));
+            }
+            if (dd) { const int rc = q_dedup_room(S, n, err); if (rc) return rc; }
+            if (dd) {
+                DCHK(S.q_dup.need(dev, n));
+                DCHK(launch_dedup(B.q_hash.p + r0, S.q_alive.p, (uint32_t)n, g0, Q.dd_keys.p, Q.dd_first.p, Q.dd_slots, Q.dd_small.p, Q.dd_small.p + 1, S.q_dup.p, sp));
+            }
+            DCHK(hipMemsetAsync(Q.dd_small.p + 2, 0, 8, sp));
+            DCHK(launch_qual_keep(n, S.q_alive.p, dd ? S.q_dup.p : nullptr, B.q_olen.p + r0, S.q_keep.p, S.out_len.p, Q.dd_small.p + 2, sp));
+            uint8_t *h_keep = S.h_stage;
+            if (Q.P.trim) {
+                // the budget is sequential (main.rs:254-259, 311-316): the first kept record that overflows it ends the run
+                uint32_t *h_sl = (uint32_t *)(S.h_stage + ((n + 15) & ~(uint64_t)15));          // (n * 5 + 16 bytes are there)
+                DCHK(hipMemcpyAsync(h_keep, S.q_keep.p, n, hipMemcpyDeviceToHost, sp));
+                DCHK(hipMemcpyAsync(h_sl, B.q_sl.p + r0, n * 4, hipMemcpyDeviceToHost, sp));
+                DCHK(hipStreamSynchronize(sp));
+                uint64_t i = 0;
+                for (; i < n; i++) {
+                    if (!h_keep[i]) continue;
+                    Q.budget += h_sl[i];
+                    if (Q.budget > Q.P.trim) { *stopped = true; break; }
+                    kept_here++;
+                }
+                n = i;
+            }
+            if (n) {
+                DCHK(launch_scan_u32(S.out_len.p, n, S.out_off.p, S.scan_tmp.p, sp));
+                DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n, 8, hipMemcpyDeviceToHost, sp));
+                DCHK(hipMemcpyAsync(S.h_small + 3, Q.dd_small.p + 1, 16, hipMemcpyDeviceToHost, sp));       // keys of the set, kept of the piece
+                if (Q.pe && !Q.P.trim) DCHK(hipMemcpyAsync(h_keep, S.q_keep.p, n, hipMemcpyDeviceToHost, sp));
+                DCHK(hipStreamSynchronize(sp));
+                bytes = hs[6]; if (dd) Q.dd_n = hs[3];
+                if (!Q.P.trim) kept_here = hs[4];
+                if (Q.pe && !Q.keep.put(g0, n, h_keep)) { err = "out of memory"; return MF_E_NOMEM; }
+            }
+        }
+        part.r0 = r0; part.n = n; part.bytes = bytes; part.out_at = Q.out_pos[0]; Q.out_pos[0] += bytes;
+        Q.kept += kept_here;
+        { std::lock_guard<std::mutex> lk(mu); Q.t_decide += now_s() - t0; }
+        return MF_OK;
+    }
+
+    // mate 2's piece B, its first n records (emit_mu held): the keep flags mate 1's decisions left for them
+    int q_keep2(Worker &W, Batch &B, uint64_t n, QPart &part, std::string &err)
+    {
+        const double t0 = now_s();
+        QualState &Q = *qual;
+        DevScratch *Sp = scratch_for(W, B.ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        uint64_t bytes = 0;
+        if (n) {
+            DCHK(S.q_keep.need(dev, n)); DCHK(S.out_len.need(dev, n)); DCHK(S.out_off.need(dev, n + 1)); DCHK(S.scan_tmp.need(dev, n / 4096 + 4));
+            DCHK(S.stage(n + 16));
+            Q.keep.get(B.rec_base, n, S.h_stage);
+            DCHK(hipMemcpyAsync(S.q_keep.p, S.h_stage, n, hipMemcpyHostToDevice, sp));
+            DCHK(launch_qual_keep(n, S.q_keep.p, nullptr, B.q_olen.p, nullptr, S.out_len.p, nullptr, sp));
+            DCHK(launch_scan_u32(S.out_len.p, n, S.out_off.p, S.scan_tmp.p, sp));
+            DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipStreamSynchronize(sp));
+            bytes = ((volatile uint64_t *)S.h_small)[6];
+        }
+        part.r0 = 0; part.n = n; part.bytes = bytes; part.out_at = Q.out_pos[1]; Q.out_pos[1] += bytes;
+        { std::lock_guard<std::mutex> lk(mu); Q.t_decide += now_s() - t0; }
+        return MF_OK;
+    }
+
+    // the kept records of a decided piece -> its place in the output file (any number of pieces at a time; S.out_len / S.out_off are
+    // still those of the piece: the consumer that decided it is the one that writes it, and does nothing in between)
+    int q_emit(Worker &W, int mi, Batch &B, const QPart &part, std::string &err)
+    {
+        QualState &Q = *qual;
+        if (!part.bytes) return MF_OK;
+        const double t0 = now_s();
+        DevScratch *Sp = scratch_for(W, B.ldev, err);
+        if (!Sp) return MF_E_HIP;
+        DevScratch &S = *Sp;
+        const int dev = S.dev;
+        hipStream_t sp = S.ctx->stream;
+        const uint64_t bytes = part.bytes;
+        DCHK(S.d_out.need(dev, bytes));
+        DCHK(launch_qual_gather(B.text, B.line_start.p + 4 * part.r0, part.n, Q.P.start, B.q_sl.p + part.r0, B.q_ql.p + part.r0, S.out_len.p, S.out_off.p, S.d_out.p, sp));
+        const size_t chunk = (size_t)std::max<uint64_t>(env_u64("MF_QUAL_OUT_CHUNK", (uint64_t)16 << 20), 4096);
+        if (S.h_out_cap < 2 * chunk) { if (S.h_out) (void)hipHostFree(S.h_out); S.h_out = nullptr; S.h_out_cap = 0; DCHK(hipHostMalloc((void **)&S.h_out, 2 * chunk, hipHostMallocDefault)); S.h_out_cap = 2 * chunk; }
+        for (auto &e : S.ev_out) if (!e) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const uint64_t nc = (bytes + chunk - 1) / chunk;
+        auto issue = [&](uint64_t k) -> hipError_t {
+            const uint64_t off = k * chunk, len = std::min<uint64_t>(chunk, bytes - off);
+            hipError_t e = hipMemcpyAsync(S.h_out + (k & 1) * chunk, S.d_out.p + off, len, hipMemcpyDeviceToHost, sp);
+            return e != hipSuccess ? e : hipEventRecord(S.ev_out[k & 1], sp);
+        };
+        double tw = 0;
+        DCHK(issue(0));
+        for (uint64_t k = 0; k < nc; k++) {
+            DCHK(hipEventSynchronize(S.ev_out[k & 1]));
+            if (k + 1 < nc) DCHK(issue(k + 1));              // (into the buffer the chunk before the last was written from)
+            const uint64_t off = k * chunk, len = std::min<uint64_t>(chunk, bytes - off);
+            const double w0 = now_s();
+            if (!Q.sink[mi].write_at(part.out_at + off, S.h_out + (k & 1) * chunk, (size_t)len)) { err = std::string("write error on ") + out_name(mi); return MF_E_IO; }
+            tw += now_s() - w0;
+        }
+        wrote_any = true;
+        { std::lock_guard<std::mutex> lk(mu); Q.t_gather += now_s() - t0 - tw; Q.t_write += tw; }
+        return MF_OK;
+    }
+    std::string out_path_[2];
+    const char *out_name(int mi) const { return out_path_[mi].empty() ? "<stdout>" : out_path_[mi].c_str(); }
+
+    // decide and write what can be decided and written.  true: did something
+    bool q_progress(Worker &W, std::string &err, int &rc)
+    {
+        QualState &Q = *qual;
+        bool did = false;
+        for (;;) {
+            std::shared_ptr<Batch> B; int mi = -1; uint64_t r0 = 0, n = 0; bool final = false, by_panic = false, stopped = false, whole = false;
+            QPart part;
+            {
+                std::unique_lock<std::mutex> elk(emit_mu, std::try_to_lock);          // (somebody else is deciding: there is other work)
+                if (!elk.owns_lock()) break;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (failed) break;
+                    Mate &A = m[0];
+                    while (Q.decided_final && !A.batches.empty() && A.batches.front()->filtered) { A.batches.pop_front(); did = true; }      // (nothing of them is wanted)
+                    if (!Q.decided_final && !A.batches.empty() && A.batches.front()->filtered) {
+                        Batch &F = *A.batches.front();
+                        const uint64_t end = F.rec_base + F.n_rec, cur = F.rec_base + F.q_done;
+                        uint64_t limit = std::min(end, Q.panic_rec[0]), upto = limit;          // limit: what of the piece will ever be decided
+                        bool ready = true;
+                        if (Q.pe) {
+                            const bool other_done = scans_done(m[1]);
+                            limit = std::min(limit, Q.panic_rec[1]);
+                            if (other_done) limit = std::min(limit, m[1].rec_indexed);          // (pairs end with the shorter file)
+                            upto = other_done ? limit : std::min(limit, m[1].rec_filtered);     // ... and what can be now: the records mate 2's scanned pieces cover
+                            // A part of the piece is decided only when waiting for the rest cannot end: the other mate holds all its text buffers
+                            // (its pieces wait for THESE decisions before they are written and their buffers come back)
+                            ready = upto == limit || (upto > cur && m[1].slots.none_free());
+                        }
+                        if (ready) {
+                            whole = upto == limit;
+                            final = whole && limit < end;
+                            by_panic = final && std::min(Q.panic_rec[0], Q.panic_rec[1]) == limit;
+                            r0 = F.q_done; n = upto > cur ? upto - cur : 0;
+                            B = A.batches.front(); mi = 0;
+                            if (whole) A.batches.pop_front();
+                        }
+                    }
+                    if (mi < 0 && !Q.decided_final && A.eof && A.a_turn == A.taken && A.batches.empty()) { Q.decided_final = true; did = true; }      // mate 1 has been decided to its end
+                    if (mi < 0 && Q.pe && !m[1].batches.empty() && m[1].batches.front()->filtered) {
+                        Batch &F = *m[1].batches.front();
+                        const uint64_t end = F.rec_base + F.n_rec;
+                        if (Q.decided >= end || Q.decided_final) {
+                            const uint64_t upto = std::min(end, Q.decided);
+                            n = upto > F.rec_base ? upto - F.rec_base : 0;
+                            B = m[1].batches.front(); m[1].batches.pop_front(); mi = 1;
+                        }
+                    }
+                    if (mi >= 0) Q.in_flight++;
+                }
+                if (mi < 0) break;
+                rc = mi == 0 ? q_decide(W, *B, r0, n, part, &stopped, err) : q_keep2(W, *B, n, part, err);
+                if (!rc && mi == 0) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    B->q_done = r0 + part.n;
+                    Q.decided = B->rec_base + B->q_done;
+                    if (stopped && !whole) m[0].batches.pop_front();                            // (B is the front: nobody else decides)
+                    if (final || stopped) { Q.decided_final = true; if (by_panic && !stopped) Q.panicked = true; }
+                }
+            }
+            cv.notify_all(); cv_all.notify_all();
+            if (!rc) rc = q_emit(W, mi, *B, part, err);
+            B.reset();                                     // (the last part written: the text buffer goes back, a producer may be waiting for one)
+            { std::lock_guard<std::mutex> lk(mu); Q.in_flight--; }
+            cv.notify_all(); cv_all.notify_all();
+            did = true;
+            if (rc) return true;
+        }
+        return did;
+    }
+
+    bool q_all_done()          // (takes mu)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (failed) return true;
+        for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (!M.eof || M.a_turn != M.taken || !M.batches.empty()) return false; }
+        return qual->in_flight == 0;
+    }
+
+    void consume_q(Worker &W)
+    {
+        std::string err;
+        for (;;) {
+            int rc = MF_OK;
+            bool did = q_progress(W, err, rc);
+            if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; }
+            int mi = 0; TextPiece P; uint64_t seq = 0; bool again = false;
+            if (take_piece(mi, P, seq, err, rc, &again)) {
+                Mate &M = m[mi];
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed || M.a_turn == seq; });
+                    if (failed) return;
+                }
+                std::shared_ptr<Batch> B;
+                rc = index_piece(W, M, P, B, err);
+                Batch *Bp = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!rc) {
+                        B->rec_base = M.rec_indexed; M.rec_indexed += B->n_rec;
+                        if (B->n_rec) { Bp = B.get(); M.batches.push_back(std::move(B)); }
+                    }
+                    M.a_turn = seq + 1;
+                }
+                cv.notify_all();
+                if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; }
+                B.reset();
+                if (Bp) { rc = q_scan(W, mi, *Bp, err); if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; } }
+                continue;
+            }
+            if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; }
+            if (q_all_done()) return;
+            if (!did && !again) { std::unique_lock<std::mutex> lk(mu_all); cv_all.wait_for(lk, std::chrono::microseconds(200)); }
         }
     }
 
@@ -1401,7 +1876,7 @@ struct Ingest {
                 if (failed) return;
             }
             const double grow = P.grow;
-            std::unique_ptr<Batch> B;
+            std::shared_ptr<Batch> B;
             rc = index_piece(W, M, P, B, err);
             Batch *Bp = nullptr;
             {
@@ -1435,12 +1910,18 @@ struct Ingest {
     int run(std::string &err)
     {
         for (int i = 0; i < nm; i++) m[i].prod = std::thread([this, i] { producer(m[i]); });
-        const int nw = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, env_u64("MF_INGEST_CONSUMERS", 3)));
+        const int nw = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, env_u64("MF_INGEST_CONSUMERS", qual ? 6 : 3)));          // (the quality filter's consumers spend their time writing)
         for (int w = 0; w < nw; w++) { workers.emplace_back(new Worker()); workers.back()->id = w; }
-        for (auto &W : workers) { Worker *wp = W.get(); wp->th = std::thread([this, wp] { consume(*wp); }); }
+        for (auto &W : workers) { Worker *wp = W.get(); wp->th = std::thread([this, wp] { if (qual) consume_q(*wp); else consume(*wp); }); }
         for (auto &W : workers) W->th.join();
         t_consumed = now_s() - t_begin;
         if (failed) { err = fail_err; return fail_rc; }
+        if (qual) {          // (a producer that was told to stop early -- the budget spent, a panic, the shorter mate's end -- has not failed)
+            for (int i = 0; i < nm; i++) { m[i].stop = true; m[i].slots.wake(); }
+            for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (M.prod.joinable()) M.prod.join(); }
+            total = qual->decided; kept = qual->kept;
+            return MF_OK;
+        }
         for (int i = 0; i < nm; i++) { Mate &M = m[i]; if (M.prod.joinable()) M.prod.join(); if (M.prod_rc) { err = M.prod_err; return M.prod_rc; } }
         total = nm == 2 ? std::min(m[0].rec_indexed, m[1].rec_indexed) : m[0].rec_indexed;
         return drain(*workers[0], true, err);
@@ -1451,8 +1932,8 @@ bool alloc_failure(int rc) { return rc == MF_E_NOMEM; }
 
 } // namespace
 
-int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
-                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats)
+// what the two jobs of this path share: is it an input for the path, set-up, the run, what the caller learns about it
+static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *out1, const char *out2, std::string &err, IngestStats *stats)
 {
     // (declared first: runs after everything of this call is gone.  What a process keeps between calls: up to MF_DEVPOOL_GB per device, default 24 --
     // a call on a file of gigabytes holds 17-24 GB, and a process that filters file after file should not give them back and ask for them again)
@@ -1465,16 +1946,16 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
             if (timing) fprintf(stderr, "[mf device ingest] streams, threads and buffers of the call put away in %.3f s\n", now_s() - t0);
         }
     } end_of_call;
-    Ingest I;
-    I.ks = ks; I.threshold = threshold; I.pair_both = pair_both; I.nm = fq2 ? 2 : 1;
-    for (int i = 0; i < n_devices; i++) I.devices.push_back(devices[i]);
+    I.nm = fq2 ? 2 : 1;
     if (I.devices.empty() || I.devices.size() > 64) { err = "bad device list"; return MF_E_ARG; }
     I.timing = getenv("MF_PIPE_TIMING") != nullptr;
     I.carry_room = (size_t)env_u64("MF_INGEST_CARRY_ROOM", (size_t)1 << 20);
     const char *in_path[2] = {fq1, fq2}, *out_path[2] = {out1, out2};
+    for (int i = 0; i < I.nm; i++) I.out_path_[i] = out_path[i] ? out_path[i] : "";
     // ---- is this an input for the device path?
     for (int i = 0; i < I.nm; i++) {
         Mate &M = I.m[i];
+        if (!in_path[i]) return MF_DEVINGEST_DECLINED;          // (standard input)
         M.path = in_path[i]; M.gz = has_gz_ext(in_path[i]);
         bool regular = false;
         if (!M.map.open(in_path[i], regular)) { err = std::string("Cannot open file ") + in_path[i]; return MF_E_IO; }
@@ -1489,7 +1970,9 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     const double t_begin = now_s();
     I.t_begin = t_begin;
     g_pool.reset_peak();
-    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", 6)) + (int)I.devices.size() - 1;        // (three consumers each hold one, the decoder one, the rest wait for the other mate or for a consumer)
+    // text buffers a mate may hold: the consumers each hold one, the decoder one, the rest wait for the other mate or for a consumer (the quality
+    // filter's pieces wait longer: their text is written out)
+    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", I.qual ? 8 : 6)) + (int)I.devices.size() - 1;
     int rc = MF_OK;
     for (int i = 0; i < I.nm && !rc; i++) {
         Mate &M = I.m[i];
@@ -1501,19 +1984,18 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
     }
     if (alloc_failure(rc)) { TRACE("declined: %s", err.c_str()); return MF_DEVINGEST_DECLINED; }      // (nothing has been touched: the host pipeline streams the file)
     if (rc) return rc;
-    for (int i = 0; i < I.nm; i++) if (!I.m[i].out.open(out_path[i])) { err = std::string("Cannot open file ") + out_path[i]; return MF_E_IO; }
+    for (int i = 0; i < I.nm; i++)
+        if (!(I.qual ? I.qual->sink[i].open(out_path[i]) : I.m[i].out.open(out_path[i]))) { err = std::string("Cannot open file ") + (out_path[i] ? out_path[i] : "<stdout>"); return MF_E_IO; }
     const double t_setup = now_s() - t_begin;
     rc = I.run(err);
     TRACE("run returned %d", rc);
     for (int i = 0; i < I.nm; i++) { I.m[i].stop = true; I.m[i].slots.wake(); }
     bool wrote = true;
-    for (int i = 0; i < I.nm; i++) wrote = I.m[i].out.close() && wrote;
+    for (int i = 0; i < I.nm; i++) wrote = (I.qual ? I.qual->sink[i].close() : I.m[i].out.close()) && wrote;
     // out of device memory before a byte of the survivors was written: the host pipeline takes the file (it truncates the outputs again)
     if (alloc_failure(rc) && !I.wrote_any) { TRACE("declined after a failed allocation: %s", err.c_str()); return MF_DEVINGEST_DECLINED; }
     if (rc) return rc;
-    if (!wrote) { err = std::string("write error on ") + out_path[0]; return MF_E_IO; }
-    if (kept) *kept = I.kept;
-    if (total) *total = I.total;
+    if (!wrote) { err = std::string("write error on ") + (out_path[0] ? out_path[0] : "<stdout>"); return MF_E_IO; }
     if (stats) {
         *stats = IngestStats();
         stats->seconds = now_s() - t_begin; stats->n_devices = (int)I.devices.size(); stats->consumers = (int)I.workers.size();
@@ -1528,8 +2010,13 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
         }
     }
     if (I.timing) {
-        fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
-                now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
+        if (I.qual)
+            fprintf(stderr, "[mf device ingest] quality filter: wall %.3f s | set-up %.3f | consumers (summed over %zu): waiting for text %.3f, line index %.3f, scan %.3f, decisions %.3f, gather + copy down %.3f, writing %.3f | %llu + %llu bytes written | buffers of this call at most %.2f GB, device memory in use at most %.2f GB",
+                    now_s() - t_begin, t_setup, I.workers.size(), I.t_wait, I.t_index, I.qual->t_scan, I.qual->t_decide, I.qual->t_gather, I.qual->t_write,
+                    (unsigned long long)I.qual->out_pos[0], (unsigned long long)I.qual->out_pos[1], (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9);
+        else
+            fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
+                    now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
         fprintf(stderr, " | first text after %.3f s, last after %.3f, consumers done after %.3f", I.t_first_piece, I.t_last_piece, I.t_consumed);
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);
@@ -1540,6 +2027,37 @@ int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const ch
         fprintf(stderr, "\n");
         end_of_call.timing = true; end_of_call.t0 = now_s();
     }
+    return MF_OK;
+}
+
+int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
+                      bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats)
+{
+    Ingest I;
+    I.ks = ks; I.threshold = threshold; I.pair_both = pair_both;
+    for (int i = 0; i < n_devices; i++) I.devices.push_back(devices[i]);
+    const int rc = run_ingest(I, fq1, fq2, out1, out2, err, stats);
+    if (rc) return rc;
+    if (kept) *kept = I.kept;
+    if (total) *total = I.total;
+    return MF_OK;
+}
+
+int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &P, int device, uint64_t *kept,
+                          uint64_t *total, bool *panicked, std::string &err, IngestStats *stats)
+{
+    if (out1 && has_gz_ext(out1) && env_u64("MF_QUAL_DEVICE_GZ_OUT", 0) == 0) return MF_DEVINGEST_DECLINED;      // compressing the output is the host pipeline's (many threads)
+    if (out2 && has_gz_ext(out2) && env_u64("MF_QUAL_DEVICE_GZ_OUT", 0) == 0) return MF_DEVINGEST_DECLINED;
+    QualState Q;                      // (before the Ingest: its batches hold buffers the state does not own, but the set's go back to the pool last)
+    Q.P = P; Q.pe = fq2 != nullptr; Q.cap = P.end ? P.end - P.start : ~0ull;
+    Ingest I;
+    I.qual = &Q;
+    I.devices.push_back(device);
+    const int rc = run_ingest(I, fq1, fq2, out1, out2, err, stats);
+    if (rc) return rc;
+    if (kept) *kept = I.kept;
+    if (total) *total = I.total;
+    if (panicked) *panicked = Q.panicked;
     return MF_OK;
 }
 

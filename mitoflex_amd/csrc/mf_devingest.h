@@ -27,4 +27,12 @@ struct IngestStats {
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
                       bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats = nullptr);
 
+// The same path with the reference's FASTQ quality filter (filter_v2: filter/filter_bin/src/main.rs:188-323) as its job instead of the
+// bait filter: counting, hashing, the de-duplication set, the decisions and the formatting of the kept records run on `device` over
+// the text where the decoder left it; the host checks the rare line that is not ASCII, spends the -t budget and writes.  Declines
+// (MF_DEVINGEST_DECLINED, nothing touched) standard input, pipes, BGZF, empty files and .gz outputs.
+struct QualParams;
+int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &P, int device, uint64_t *kept,
+                          uint64_t *total, bool *panicked, std::string &err, IngestStats *stats = nullptr);
+
 } // namespace mf

@@ -45,4 +45,28 @@ hipError_t launch_sel_gather(const uint8_t *text, const uint64_t *line_start, co
 hipError_t launch_gather(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, const uint32_t *out_len, const uint64_t *out_off,
                          uint8_t *out, hipStream_t st);
 
+// ---- the FASTQ quality filter (the reference's filter_v2, filter/filter_bin/src/main.rs:188-323) over records of text on the device
+// per-record flags of launch_qual_scan
+constexpr uint32_t QF_HIGH = 1;       // a byte >= 0x80 in the header, sequence or quality line: the host checks those lines for UTF-8 (the reference unwraps them)
+constexpr uint32_t QF_SHORT = 2;      // the sequence or the quality string is shorter than the cut's start: the reference panics
+constexpr uint32_t QF_NFAIL = 4;      // more than `ns` 'N' in the cut sequence
+constexpr uint32_t QF_LONG = 8;       // a record of 4 GiB or more: not handled here
+// One pass over the records' bytes.  start / cap: the cut [start, start + cap) of sequence and quality string (cap = ~0: to the end).
+// bad[r] = bytes <= quality of the cut quality string; cut_sl / cut_ql = lengths of the cut strings; olen[r] = bytes of the record as
+// it is written (header LF sequence LF '+' LF quality LF); *first_flag (preset to ~0) = the first record with QF_HIGH, QF_SHORT or QF_LONG.
+// text must be readable 16 bytes past the last record.
+hipError_t launch_qual_scan(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, uint64_t cap, uint32_t quality, uint64_t ns,
+                            uint32_t *bad, uint8_t *flags, uint32_t *cut_sl, uint32_t *cut_ql, uint32_t *olen, uint32_t *first_flag, hipStream_t st);
+// SipHash-1-3 of the cut sequences followed by 0xff (Rust's `str::hash` into DefaultHasher); reads whole dwords around the sequence
+hipError_t launch_qual_hash(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, const uint32_t *cut_sl, uint64_t *hashes, hipStream_t st);
+// alive[i] = 0 when record i fails the N or the quality test (of either mate with pe; *2 = the other mate's scan results); all 1 with trunc
+hipError_t launch_qual_decide(uint64_t n, bool pe, bool trunc, float limit, const uint32_t *bad1, const uint8_t *fl1, const uint32_t *sl1, const uint32_t *ql1,
+                              const uint32_t *bad2, const uint8_t *fl2, uint8_t *alive, hipStream_t st);
+// keep[i] = alive[i] && !dup[i] (dup, keep may be null); out_len[i] = keep ? olen[i] : 0; *kept += number kept (may be null)
+hipError_t launch_qual_keep(uint64_t n, const uint8_t *alive, const uint8_t *dup, const uint32_t *olen, uint8_t *keep, uint32_t *out_len, unsigned long long *kept,
+                            hipStream_t st);
+// the kept records (out_len != 0) as the reference writes them, at out[out_off[r] ..]
+hipError_t launch_qual_gather(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, const uint32_t *cut_sl, const uint32_t *cut_ql,
+                              const uint32_t *out_len, const uint64_t *out_off, uint8_t *out, hipStream_t st);
+
 } // namespace mf

@@ -298,6 +298,168 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *text, const 
     for (uint32_t i = lane; i < x.ql; i += 64) o[i] = text[x.q + i];
 }
 
+
+// ------------------------------------------------------------------------------------------------------------ quality filter
+// The reference's FASTQ quality filter (filter/filter_bin/src/main.rs:188-323) over text that is already on the device: what it
+// asks of a record -- the cut [start, end) of sequence and quality string (:222-233, :291-299), the 'N's of the cut sequence
+// (:236, :302), the quality bytes at or below the threshold (:239-243, :305-309), whether a line that it unwraps holds a byte that
+// is not ASCII (:214-216, :287-289: such a line may not be UTF-8, the host looks) or is shorter than the cut's start (`drain` panics) --
+// comes from ONE pass over the record's bytes, eight lanes a record, sixteen bytes a lane and step.
+
+// 0x80 in byte k of the dword at relative offset p for which lo <= p + k < hi
+__device__ __forceinline__ uint32_t win80(uint32_t p, uint32_t lo, uint32_t hi)
+{
+    if (p + 4 <= lo || p >= hi) return 0;
+    uint32_t m = 0x80808080u;
+    if (p < lo) m &= 0xFFFFFFFFu << (8 * (lo - p));
+    if (p + 4 > hi) m &= 0xFFFFFFFFu >> (8 * (p + 4 - hi));
+    return m;
+}
+constexpr uint32_t QS_GROUP = 8;          // lanes per record
+
+__global__ __launch_bounds__(256) void qual_scan_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, uint64_t cap,
+                                                        uint32_t quality, uint64_t ns, uint32_t *bad, uint8_t *flags, uint32_t *cut_sl, uint32_t *cut_ql,
+                                                        uint32_t *olen, uint32_t *first_flag)
+{
+    const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / QS_GROUP;
+    const uint32_t l = threadIdx.x % QS_GROUP;
+    uint32_t nn = 0, nb = 0, hi = 0, fl = 0, hl = 0, csl = 0, cql = 0;
+    if (r < n_rec) {
+        const uint64_t l0 = line_start[4 * r], l1 = line_start[4 * r + 1], l2 = line_start[4 * r + 2], l3 = line_start[4 * r + 3], l4 = line_start[4 * r + 4];
+        if (l4 - l0 >= 0xFFFFFF00ull) fl |= QF_LONG;
+        else {
+            hl = line_len(text, l0, l1);
+            const uint32_t sl = line_len(text, l1, l2), ql = line_len(text, l3, l4);
+            uint32_t cs = (uint32_t)(l1 - l0), cq = (uint32_t)(l3 - l0);            // where the cut strings begin, counted from the record's first byte
+            if (start > sl || start > ql) fl |= QF_SHORT;
+            else {
+                cs += (uint32_t)start; cq += (uint32_t)start;
+                csl = sl - (uint32_t)start; cql = ql - (uint32_t)start;
+                if (cap < csl) csl = (uint32_t)cap;
+                if (cap < cql) cql = (uint32_t)cap;
+            }
+            const uint32_t total = (uint32_t)(l4 - l0), plus_lo = (uint32_t)(l2 - l0), plus_hi = (uint32_t)(l3 - l0);
+            const uint32_t q1 = (quality + 1) * 0x01010101u;
+            const uint8_t *base = text + l0;
+            for (uint32_t b = l * 16; b < total; b += QS_GROUP * 16) {
+                const uint4 v = load16(base + b);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t p = b + 4 * j, x = w[j];
+                    hi |= x & (win80(p, 0, plus_lo) | win80(p, plus_hi, total));            // (the '+' line is never unwrapped)
+                    nn += __popc(eq_flags(x, 0x4E4E4E4Eu) & win80(p, cs, cs + csl));
+                    const uint32_t d = (x | 0x80808080u) - q1;                              // per byte, no borrow: top bit clear <=> low seven bits <= quality
+                    nb += __popc(~d & ~x & win80(p, cq, cq + cql));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = QS_GROUP / 2; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, QS_GROUP); nb += __shfl_xor(nb, o, QS_GROUP); hi |= __shfl_xor(hi, o, QS_GROUP); }
+    if (r < n_rec && l == 0) {
+        if (hi) fl |= QF_HIGH;
+        if ((uint64_t)nn > ns) fl |= QF_NFAIL;
+        bad[r] = nb; flags[r] = (uint8_t)fl; cut_sl[r] = csl; cut_ql[r] = cql; olen[r] = hl + csl + cql + 5;
+        if (fl & (QF_HIGH | QF_SHORT | QF_LONG)) atomicMin(first_flag, (uint32_t)r);
+    }
+}
+
+// SipHash-1-3, keys (0, 0), of the cut sequence followed by 0xff: `seq1.hash()` of the reference's de-duplication
+// (main.rs:244-250, 325-329; std's DefaultHasher).  One lane per record, the message read as aligned dwords.
+__device__ __forceinline__ void sip_round(uint64_t &v0, uint64_t &v1, uint64_t &v2, uint64_t &v3)
+{
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+    v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+}
+__global__ __launch_bounds__(256) void qual_hash_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, const uint32_t *cut_sl,
+                                                        uint64_t *hashes)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint32_t s_len = cut_sl[r];
+    const uint8_t *p = text + line_start[4 * r + 1] + (s_len ? start : 0);           // (a record the cut panics on has no cut sequence)
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3) * 8;
+    auto alignbit = [](uint32_t hi, uint32_t lo, uint32_t s) -> uint32_t { return s ? (lo >> s) | (hi << (32 - s)) : lo; };
+    uint64_t v0 = 0x736F6D6570736575ULL, v1 = 0x646F72616E646F6DULL, v2 = 0x6C7967656E657261ULL, v3 = 0x7465646279746573ULL;
+    uint32_t d0 = w[0];
+    uint64_t i = 0;
+    auto block = [&](uint64_t at) -> uint64_t {             // eight message bytes from byte `at` (a multiple of 8)
+        const uint32_t *q = w + (at >> 2);
+        const uint32_t d1 = q[1], d2 = q[2];
+        const uint64_t m = ((uint64_t)alignbit(d2, d1, sh) << 32) | alignbit(d1, d0, sh);
+        d0 = d2;
+        return m;
+    };
+    for (; i + 8 <= (uint64_t)s_len; i += 8) { const uint64_t m = block(i); v3 ^= m; sip_round(v0, v1, v2, v3); v0 ^= m; }
+    const uint32_t t = (uint32_t)(s_len - i);               // the t < 8 bytes that are left, then 0xff (str's Hash); t == 7: the 0xff completes a block
+    uint64_t tailv = block(i);
+    tailv = t == 0 ? 0 : (tailv & (~0ULL >> (64 - 8 * t)));
+    tailv |= 0xFFULL << (8 * t);
+    if (t == 7) { v3 ^= tailv; sip_round(v0, v1, v2, v3); v0 ^= tailv; tailv = 0; }
+    const uint64_t b = ((((uint64_t)s_len + 1) & 0xFF) << 56) | tailv;
+    v3 ^= b; sip_round(v0, v1, v2, v3); v0 ^= b;
+    v2 ^= 0xFF;
+    sip_round(v0, v1, v2, v3); sip_round(v0, v1, v2, v3); sip_round(v0, v1, v2, v3);
+    hashes[r] = v0 ^ v1 ^ v2 ^ v3;
+}
+
+// the tests that need no other record (main.rs:236-243, 302-309): alive[i] = the record reaches the de-duplication / is kept
+__global__ __launch_bounds__(256) void qual_decide_kernel(uint64_t n, int pe, int trunc, float limit, const uint32_t *bad1, const uint8_t *fl1, const uint32_t *sl1,
+                                                          const uint32_t *ql1, const uint32_t *bad2, const uint8_t *fl2, uint8_t *alive)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool drop = false;
+    if (!trunc) {
+        drop = (fl1[i] & QF_NFAIL) || (pe && (fl2[i] & QF_NFAIL));
+        if (!drop) {
+            // PE: both mates against a cutoff from seq1's length; SE: from the quality string's.  f32 product, `as usize` (saturating, NaN -> 0)
+            const float cf = (float)(pe ? sl1[i] : ql1[i]) * limit;
+            const uint64_t cutoff = !(cf > 0.0f) ? 0 : (cf >= 18446744073709551616.0f ? ~0ull : (uint64_t)cf);
+            drop = (uint64_t)bad1[i] >= cutoff || (pe && (uint64_t)bad2[i] >= cutoff);
+        }
+    }
+    alive[i] = drop ? 0 : 1;
+}
+// keep = alive and not a duplicate; out_len = output bytes of a kept record; *kept += the kept ones
+__global__ __launch_bounds__(256) void qual_keep_kernel(uint64_t n, const uint8_t *alive, const uint8_t *dup, const uint32_t *olen, uint8_t *keep, uint32_t *out_len,
+                                                        unsigned long long *kept)
+{
+    __shared__ uint32_t lds[4];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t k = 0;
+    if (i < n) {
+        k = alive[i] && !(dup && dup[i]);
+        if (keep) keep[i] = (uint8_t)k;
+        out_len[i] = k ? olen[i] : 0;
+    }
+    const uint32_t s = block_sum(k, lds);
+    if (threadIdx.x == 0 && s && kept) atomicAdd(kept, (unsigned long long)s);
+}
+// header LF cut-sequence LF '+' LF cut-quality LF of the kept records (main.rs:261-268, 317-321), one wavefront a record
+__global__ __launch_bounds__(256) void qual_gather_kernel(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, const uint32_t *cut_sl,
+                                                          const uint32_t *cut_ql, const uint32_t *out_len, const uint64_t *out_off, uint8_t *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rec || out_len[r] == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t l0 = line_start[4 * r], l1 = line_start[4 * r + 1], l3 = line_start[4 * r + 3];
+    const uint32_t hl = line_len(text, l0, l1), sl = cut_sl[r], ql = cut_ql[r];
+    const uint8_t *h = text + l0, *s = text + l1 + start, *q = text + l3 + start;
+    uint8_t *o = out + out_off[r];
+    for (uint32_t i = lane; i < hl; i += 64) o[i] = h[i];
+    o += hl;
+    for (uint32_t i = lane; i < sl; i += 64) o[1 + i] = s[i];
+    if (lane == 0) { o[0] = '\n'; o[1 + sl] = '\n'; o[2 + sl] = '+'; o[3 + sl] = '\n'; o[4 + sl + ql] = '\n'; }
+    o += sl + 4;
+    for (uint32_t i = lane; i < ql; i += 64) o[i] = q[i];
+}
+
 } // namespace
 
 uint64_t pack_blocks(uint64_t total_bases, uint64_t base)
@@ -391,6 +553,42 @@ hipError_t launch_gather(const uint8_t *text, const uint64_t *line_start, uint64
 {
     if (!n_rec) return hipSuccess;
     hipLaunchKernelGGL(gather_kernel, dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st, text, line_start, n_rec, out_len, out_off, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_qual_scan(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, uint64_t cap, uint32_t quality, uint64_t ns,
+                            uint32_t *bad, uint8_t *flags, uint32_t *cut_sl, uint32_t *cut_ql, uint32_t *olen, uint32_t *first_flag, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    hipLaunchKernelGGL(qual_scan_kernel, dim3((uint32_t)((n_rec * QS_GROUP + 255) / 256)), dim3(256), 0, st, text, line_start, n_rec, start, cap, quality, ns, bad, flags,
+                       cut_sl, cut_ql, olen, first_flag);
+    return hipGetLastError();
+}
+hipError_t launch_qual_hash(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, const uint32_t *cut_sl, uint64_t *hashes, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    hipLaunchKernelGGL(qual_hash_kernel, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, text, line_start, n_rec, start, cut_sl, hashes);
+    return hipGetLastError();
+}
+hipError_t launch_qual_decide(uint64_t n, bool pe, bool trunc, float limit, const uint32_t *bad1, const uint8_t *fl1, const uint32_t *sl1, const uint32_t *ql1,
+                              const uint32_t *bad2, const uint8_t *fl2, uint8_t *alive, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(qual_decide_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, pe ? 1 : 0, trunc ? 1 : 0, limit, bad1, fl1, sl1, ql1, bad2, fl2, alive);
+    return hipGetLastError();
+}
+hipError_t launch_qual_keep(uint64_t n, const uint8_t *alive, const uint8_t *dup, const uint32_t *olen, uint8_t *keep, uint32_t *out_len, unsigned long long *kept,
+                            hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(qual_keep_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, alive, dup, olen, keep, out_len, kept);
+    return hipGetLastError();
+}
+hipError_t launch_qual_gather(const uint8_t *text, const uint64_t *line_start, uint64_t n_rec, uint64_t start, const uint32_t *cut_sl, const uint32_t *cut_ql,
+                              const uint32_t *out_len, const uint64_t *out_off, uint8_t *out, hipStream_t st)
+{
+    if (!n_rec) return hipSuccess;
+    hipLaunchKernelGGL(qual_gather_kernel, dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st, text, line_start, n_rec, start, cut_sl, cut_ql, out_len, out_off, out);
     return hipGetLastError();
 }
 

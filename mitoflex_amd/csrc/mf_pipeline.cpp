@@ -560,9 +560,7 @@ int run_fastq_pipeline(const char *fq1, const char *fq2, const char *out1, const
 // that overflows it: filter/filter_bin/src/main.rs:254-259).  What is data parallel -- counting N and low-quality bytes,
 // hashing the sequences, and the de-duplication set itself ("first occurrence wins" is a minimum over file indices, which needs
 // no order of execution) -- runs on the GPU over the raw text of each batch.
-namespace {
-
-bool utf8_ok(const char *p, size_t n)
+bool utf8_valid(const char *p, size_t n)
 {
     const unsigned char *s = (const unsigned char *)p; size_t i = 0;
     while (i < n) {
@@ -581,6 +579,8 @@ bool utf8_ok(const char *p, size_t n)
     }
     return true;
 }
+
+namespace {
 
 struct QualBatch {
     uint64_t index = 0, n = 0;
@@ -678,7 +678,7 @@ int run_qualfilter_pipeline(const char *fq1, const char *fq2, const char *out1, 
                         const FqRec &r = mrec[m][i];
                         // header, sequence and quality are unwrapped (main.rs:214-216, 287-289) and panic on invalid UTF-8; the
                         // '+' line is bound to `_` and never unwrapped: lines() yields an Err for it and carries on
-                        bad = !utf8_ok(r.h, r.hl) || !utf8_ok(r.s, r.sl) || !utf8_ok(r.q, r.ql);
+                        bad = !utf8_valid(r.h, r.hl) || !utf8_valid(r.s, r.sl) || !utf8_valid(r.q, r.ql);
                     }
                     if (!bad && P.start) {
                         for (int m = 0; m < nm; m++) bad = bad || P.start > mrec[m][i].sl;      // seq1, seq2 first

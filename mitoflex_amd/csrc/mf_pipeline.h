@@ -25,6 +25,7 @@ struct QualParams {
     uint32_t quality = 55; float limit = 0.2f;
     bool dedup = false, trunc = false;
 };
+bool utf8_valid(const char *p, size_t n);          // what Rust's `lines()` accepts (the reference unwraps header, sequence and quality line: main.rs:214-216, 287-289)
 struct QualSpan { uint32_t s_off, s_len, q_off, q_len; };     // same layout as the kernels' QualRec
 // counts of n records whose strings are offsets into text; with want_hashes the SipHash-1-3 values of the sequences are computed
 // too and KEPT BY THE CALLEE for the dedup call that follows for the same records

@@ -78,7 +78,7 @@ def _run_cli(cli, tmp, t1, t2, argv):
     args = [a.format(**paths) for a in argv]
     use_stdin = "-1" not in argv and not any(a.startswith("--fastq1") for a in argv) and t1 is not None
     p = subprocess.run([cli] + args, input=((t1 if isinstance(t1, bytes) else t1.encode("latin-1")) if use_stdin else None),
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     outs = []
     for k in ("out1", "out2"):
         ob = None
@@ -148,26 +148,72 @@ def test_cli_host_logic_random_against_oracle(cli_host_only, tmp_path, monkeypat
     _check_random(cli_host_only[0], tmp_path, monkeypatch)
 
 
+# The drop-in has two ways to the same bytes: regular files go to the GPU as they lie (inflate, line index, counting, hashing, the
+# de-duplication set, decisions and the formatting of the kept records on the device: mf_devingest.cpp -- the default), everything else
+# (standard input, pipes, BGZF, .gz outputs) and MF_QUAL_INGEST=host take the host pipeline with GPU counting.  Both are held to the ELF's vectors.
+# "device-seams": chunks of 4 KiB of compressed input, three to a slab, text pieces of a few hundred bytes to 20 kB, two text buffers
+# a mate -- records, mates' pieces and decisions meet at every possible kind of border.
+INGEST = {"device": {}, "host": {"MF_QUAL_INGEST": "host"},
+          "device-seams": {"MF_GZDEV_CHUNK_BYTES": "4096", "MF_GZDEV_SLAB_CHUNKS": "3", "MF_GZDEV_TEXT_PIECE": "20000", "MF_INGEST_SLAB_BYTES": "333",
+                           "MF_INGEST_TEXT_BUFS": "2", "MF_QUAL_OUT_CHUNK": "4096", "MF_INGEST_CONSUMERS": "3"}}
+
+
+def _set_ingest(monkeypatch, ingest):
+    monkeypatch.setenv("MF_PIPE_TIMING", "1")
+    for k, v in INGEST[ingest].items():
+        monkeypatch.setenv(k, v)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("ingest", ["device", "host", "device-seams"])
 @pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
-def test_cli_matches_elf(cli, tmp_path, case):
+def test_cli_matches_elf(cli, tmp_path, case, ingest, monkeypatch):
+    _set_ingest(monkeypatch, ingest)
     _check_case(cli, tmp_path, case)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ingest", ["device", "host", "device-seams"])
 @pytest.mark.parametrize("case", GOLD["bulk"], ids=lambda b: b["name"])
-def test_cli_bulk_md5(cli, tmp_path, case, monkeypatch):
+def test_cli_bulk_md5(cli, tmp_path, case, ingest, monkeypatch):
+    _set_ingest(monkeypatch, ingest)
+    if ingest == "device-seams":
+        monkeypatch.setenv("MF_INGEST_SLAB_BYTES", "7001")
     _check_bulk(cli, tmp_path, case, monkeypatch)
+    if ingest == "device-seams":
+        monkeypatch.setenv("MF_INGEST_SLAB_BYTES", "50001")
+        _check_bulk(cli, tmp_path, case, monkeypatch, gz=True)
 
 
-def _check_bulk(cli, tmp_path, case, monkeypatch):
+@pytest.mark.gpu
+def test_device_path_is_the_one_that_ran(cli, tmp_path):
+    """A .gz pair through the CLI: the timing line of the device path's quality filter must appear (and not the host pipeline's)."""
+    mk = _mk()
+    s1, s2, q1, q2 = mk.rand_pair(2000, 5, L=100)
+    for name, t in (("a_1.fq.gz", mk.fq(s1, q1, "a")), ("a_2.fq.gz", mk.fq(s2, q2, "b"))):
+        with gzip.open(str(tmp_path / name), "wb") as f:
+            f.write(t.encode("latin-1"))
+    env = dict(os.environ, MF_PIPE_TIMING="1")
+    env.pop("MF_QUAL_INGEST", None)
+    p = subprocess.run([cli, "-1", str(tmp_path / "a_1.fq.gz"), "-2", str(tmp_path / "a_2.fq.gz"), "-3", str(tmp_path / "o_1.fq"), "-4", str(tmp_path / "o_2.fq"), "-d"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    assert b"[mf device ingest] quality filter: wall" in p.stderr and b"[mf qualfilter]" not in p.stderr, p.stderr
+    from oracle import filter_v2_ref as ref
+    t1, t2 = mk.fq(s1, q1, "a").encode("latin-1"), mk.fq(s2, q2, "b").encode("latin-1")
+    erc, e1, e2 = ref.run(["-1", "a_1", "-2", "a_2", "-3", "o1", "-4", "o2", "-d"], lambda pth: t1 if "a_1" in pth else t2)
+    assert erc == 0 and open(str(tmp_path / "o_1.fq"), "rb").read() == e1 and open(str(tmp_path / "o_2.fq"), "rb").read() == e2
+
+
+def _check_bulk(cli, tmp_path, case, monkeypatch, gz=False):
     mk = _mk()
     monkeypatch.setenv("MF_BATCH_READS", "3001")           # several batches, dedup/trim state carried across
     monkeypatch.setenv("MF_PARSE_SEG", "40000")
     monkeypatch.setenv("MF_DEDUP_LOG2_SLOTS", "6")         # the device's dedup set starts with 64 slots: it is doubled and rehashed again and again
     s1, s2, q1, q2 = mk.rand_pair(case["n"], case["seed"], L=case["L"])
     t1, t2 = mk.fq(s1, q1, "a"), mk.fq(s2, q2, "b")
-    rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if "{in2}" in case["argv"] else None, case["argv"])
+    argv = [a.replace("{in1}", "{in1gz}").replace("{in2}", "{in2gz}") for a in case["argv"]] if gz else case["argv"]
+    rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if "{in2}" in case["argv"] else None, argv)
     assert rc == case["rc"]
     assert hashlib.md5(outs[0]).hexdigest() == case["out1_md5"] and outs[0].count(b"\n") == case["out1_lines"]
     if case["out2_md5"]:
@@ -175,15 +221,20 @@ def _check_bulk(cli, tmp_path, case, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_cli_random_against_oracle(cli, tmp_path, monkeypatch):
-    _check_random(cli, tmp_path, monkeypatch)
+@pytest.mark.parametrize("ingest", ["device", "host", "device-seams"])
+def test_cli_random_against_oracle(cli, tmp_path, ingest, monkeypatch):
+    _set_ingest(monkeypatch, ingest)
+    _check_random(cli, tmp_path, monkeypatch, seams=ingest == "device-seams")
 
 
-def _check_random(cli, tmp_path, monkeypatch):
+def _check_random(cli, tmp_path, monkeypatch, seams=False):
     from oracle import filter_v2_ref as ref
     mk = _mk()
     rng = random.Random(11)
     for it in range(40):
+        if seams:
+            monkeypatch.setenv("MF_INGEST_SLAB_BYTES", str(rng.choice([97, 333, 5000, 1 << 20])))
+            monkeypatch.setenv("MF_INGEST_CONSUMERS", str(rng.choice([1, 2, 5])))
         n = rng.randint(0, 300)
         s1, s2, q1, q2 = mk.rand_pair(n, 1000 + it, L=rng.choice([12, 40, 90]), lowq=rng.choice([0.02, 0.2]), dup=rng.choice([0, 0.4]))
         t1, t2 = mk.fq(s1, q1, "a", eol=rng.choice(["\n", "\r\n"])), mk.fq(s2, q2, "b")
@@ -204,7 +255,8 @@ def _check_random(cli, tmp_path, monkeypatch):
         monkeypatch.setenv("MF_BATCH_READS", str(rng.choice([1, 7, 64, 2000000])))
         monkeypatch.setenv("MF_PARSE_SEG", str(rng.choice([64, 1000, 1 << 25])))
         monkeypatch.setenv("MF_DEDUP_LOG2_SLOTS", str(rng.choice([4, 24])))
-        rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if pe else None, argv)
+        run_argv = [a.replace("{in1}", "{in1gz}").replace("{in2}", "{in2gz}") for a in argv] if seams and it % 2 else argv
+        rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2 if pe else None, run_argv)
         b1, b2 = t1.encode("latin-1"), t2.encode("latin-1")
         erc, e1, e2 = ref.run(list(argv), lambda p: b1 if "in1" in p else b2)
         assert rc == erc, (it, argv)
