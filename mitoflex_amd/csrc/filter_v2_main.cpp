@@ -7,6 +7,7 @@
 #include "../../include/mitofilter.h"
 
 #include <dlfcn.h>
+#include <time.h>
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
@@ -147,15 +148,23 @@ int main(int argc, char **argv)
 
     const char *libenv = getenv("MITOFILTER_LIB");
     const std::string libpath = libenv ? libenv : exe_dir() + "/../libmitofilter_hip.so";
+    const bool timing = getenv("MF_PIPE_TIMING") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+    const double t_load = now();
     void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "error: cannot load %s: %s (filter_v2 has no CPU fallback)\n", libpath.c_str(), dlerror()); return 2; }
     auto p_run = (decltype(&mf_qualfilter_files))dlsym(h, "mf_qualfilter_files");
     auto p_err = (decltype(&mf_last_error))dlsym(h, "mf_last_error");
     if (!p_run || !p_err) { fprintf(stderr, "error: %s lacks mf_qualfilter_files\n", libpath.c_str()); return 2; }
     uint64_t kept = 0, total = 0; int panicked = 0;
+    const double t_call = now();
     const int rc = p_run(fq1, fq2, opt['3'].c_str(), out2, start, end, ns, (uint32_t)q64, limit, opt.count('d') ? 1 : 0, trim,
                          opt.count('T') ? 1 : 0, 0, &kept, &total, &panicked);
+    if (timing) fprintf(stderr, "[filter_v2] loading the library %.3f s, the call %.3f s\n", t_call - t_load, now() - t_call);
     if (rc != MF_OK) { fprintf(stderr, "error: %s\n", p_err()); return 3; }
     if (panicked) rust_panic("called `Result::unwrap()` on an `Err` value / drain out of range");
-    return 0;
+    // (the outputs are written and closed; what is left is the GPU runtime's teardown -- queues, code objects, a tenth of a second -- which a
+    // process that is about to be gone has no use for)
+    fflush(stdout); fflush(stderr);
+    _exit(0);
 }

@@ -82,7 +82,9 @@ public:
                 return hipSuccess;
             }
         }
+        const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         hipError_t e = hipMalloc(p, want);
+        { std::lock_guard<std::mutex> lk(mu_); t_malloc_ += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; n_malloc_++; }
         if (e != hipSuccess) {                      // make room: release what the pool holds for this device and try once more
             (void)hipGetLastError();
             trim_dev(dev, 0);
@@ -104,7 +106,8 @@ public:
     size_t held(int dev) { std::lock_guard<std::mutex> lk(mu_); return dev_[dev].held; }          // bytes waiting for the next call
     // high-water mark of the bytes in use (handed out and not yet returned) on any one device since reset_peak()
     size_t peak() { std::lock_guard<std::mutex> lk(mu_); size_t m = 0; for (auto &kv : dev_) m = std::max(m, kv.second.peak); return m; }
-    void reset_peak() { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) kv.second.peak = kv.second.used; }
+    void reset_peak() { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) kv.second.peak = kv.second.used; t_malloc_ = 0; n_malloc_ = 0; }
+    void malloc_time(double &t, uint64_t &n) { std::lock_guard<std::mutex> lk(mu_); t = t_malloc_; n = n_malloc_; }          // seconds inside hipMalloc (summed over the threads) and calls since reset_peak()
     void trim(size_t keep_per_dev)                  // (only when no kernel of this path is in flight)
     {
         std::vector<int> devs;
@@ -128,7 +131,7 @@ private:
         for (void *q : drop) (void)hipFree(q);
         if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
     }
-    std::mutex mu_; std::map<int, PerDev> dev_;
+    std::mutex mu_; std::map<int, PerDev> dev_; double t_malloc_ = 0; uint64_t n_malloc_ = 0;
 };
 DevPool g_pool;
 
@@ -247,57 +250,96 @@ struct Stager {
 // call to call: destroying a CU-masked stream right after use was seen to hang inside the runtime (ROCm 7.2), and they cost a
 // few milliseconds to make.
 constexpr uint32_t GZ_NSTREAM = 10;
-struct StreamSet { int device = -1; hipStream_t sd[GZ_NSTREAM] = {}, link = nullptr, rest = nullptr, copy = nullptr; };
+// The DECODE streams are the CU-masked ones.  Such a stream is a hardware queue of its own and takes 10-15 ms to make (the runtime
+// makes them one after the other, whoever asks), so there is one set of them per device for the whole process, shared by the mates
+// of a call: the first is made when the device is first used, the rest by a thread of the set's while the first slabs are already
+// decoding (n: streams made so far).  Never destroyed (below) -- except under a profiler.
+struct DecodeStreams {
+    int device = -1; hipStream_t sd[GZ_NSTREAM] = {}; std::atomic<uint32_t> n{0};
+    std::thread maker; std::atomic<bool> stop{false};
+    uint32_t words = 0; std::vector<uint32_t> mask; bool masked = false;
+    bool make(hipStream_t *q) const
+    {
+        if (masked && hipExtStreamCreateWithCUMask(q, words, mask.data()) == hipSuccess) return true;
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+    }
+    hipStream_t pick(uint32_t seq) const { return sd[seq % std::max<uint32_t>(1, n.load())]; }
+};
+// what a mate's decoder has of its own: the stream of the link step (chain, marker resolution, CRC), one for the rest (small copies,
+// set-up), one for the uploads.  Plain streams: their kernels find the CUs the decode streams are masked off.
+struct StreamSet { int device = -1; DecodeStreams *dec = nullptr; hipStream_t link = nullptr, rest = nullptr, copy = nullptr; };
 class StreamSets {
 public:
     StreamSet *take(int device, std::string &err)              // (the caller's current device is `device`)
     {
+        DecodeStreams *dec = decode_streams(device, err);
+        if (!dec) return nullptr;
         {
             std::lock_guard<std::mutex> lk(mu_);
             for (size_t i = 0; i < free_.size(); i++) if (free_[i]->device == device) { StreamSet *s = free_[i]; free_.erase(free_.begin() + (long)i); return s; }
         }
         std::unique_ptr<StreamSet> s(new StreamSet());
-        s->device = device;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
-        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
-        std::vector<uint32_t> m_dec((size_t)words, 0), m_link((size_t)words, 0);
-        // Whatever else has to run while decode wavefronts fill the chip -- the link step, marker resolution, CRC, the consumer's
-        // line index and pack kernels, all short and all on some host thread's critical path -- needs CUs of its own.  Four per XCD.
-        int reserve = (int)env_u64("MF_GZDEV_RESERVED_CUS", 32);
-        reserve = std::max(8, std::min(n_cu / 2, reserve)) & ~7;
-        for (int b = 0; b < n_cu; b++) (b >= n_cu - reserve ? m_link : m_dec)[b / 32] |= 1u << (b % 32);
-        const bool masks = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
-        bool ok = true;
-        for (auto &q : s->sd)
-            if (!masks || hipExtStreamCreateWithCUMask(&q, (uint32_t)words, m_dec.data()) != hipSuccess) { (void)hipGetLastError(); ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess; }
-        if (!masks || hipExtStreamCreateWithCUMask(&s->link, (uint32_t)words, m_link.data()) != hipSuccess) { (void)hipGetLastError(); ok = ok && hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess; }
+        s->device = device; s->dec = dec;
+        bool ok = hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&s->rest, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking) == hipSuccess;
-        if (!ok) { err = "hipStreamCreate failed"; return nullptr; }           // (what was made stays behind: never destroyed, see above)
+        if (!ok) { err = "hipStreamCreate failed"; return nullptr; }
         return s.release();
     }
     void give(StreamSet *s) { if (s) { std::lock_guard<std::mutex> lk(mu_); free_.push_back(s); } }
     // Under rocprofv3 a process that still owns CU-masked streams when it exits dies in the profiler's finaliser (SIGSEGV below
     // __cxa_finalize, after the profile has been written; without a profiler the exit is clean).  So when a profiler is loaded
-    // the idle sets are destroyed here, at exit, after a device synchronisation -- not otherwise: destroying such a stream was seen to
-    // hang now and then (above), and an exit that hangs is worse than one a profiler complains about.
+    // the streams are destroyed here, at exit, after a device synchronisation -- not otherwise: destroying such a stream was seen to
+    // hang now and then, and an exit that hangs is worse than one a profiler complains about.
     ~StreamSets()
     {
+        for (auto &kv : dec_) { kv.second->stop = true; if (kv.second->maker.joinable()) kv.second->maker.join(); }
         const char *pre = getenv("LD_PRELOAD");
         const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
         if (!profiled) return;
+        for (auto &kv : dec_) {
+            if (hipSetDevice(kv.first) != hipSuccess) continue;
+            (void)hipDeviceSynchronize();
+            for (auto &q : kv.second->sd) if (q) (void)hipStreamDestroy(q);
+        }
         for (StreamSet *s : free_) {
             if (hipSetDevice(s->device) != hipSuccess) continue;
-            (void)hipDeviceSynchronize();
-            for (auto &q : s->sd) if (q) (void)hipStreamDestroy(q);
             if (s->link) (void)hipStreamDestroy(s->link);
             if (s->rest) (void)hipStreamDestroy(s->rest);
             if (s->copy) (void)hipStreamDestroy(s->copy);
         }
     }
 private:
-    std::mutex mu_; std::vector<StreamSet *> free_;
+    DecodeStreams *decode_streams(int device, std::string &err)
+    {
+        std::lock_guard<std::mutex> lk(mu_dec_);
+        auto it = dec_.find(device);
+        if (it != dec_.end()) return it->second;
+        std::unique_ptr<DecodeStreams> d(new DecodeStreams());
+        d->device = device;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
+        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+        // Whatever else has to run while decode wavefronts fill the chip -- the link step, marker resolution, CRC, the consumers'
+        // kernels, all short and all on some host thread's critical path -- needs CUs of its own.  Four per XCD (mask bit b is a CU of XCD b mod 8).
+        int reserve = (int)env_u64("MF_GZDEV_RESERVED_CUS", 32);
+        reserve = std::max(8, std::min(n_cu / 2, reserve)) & ~7;
+        d->mask.assign((size_t)words, 0);
+        for (int b = 0; b < n_cu - reserve; b++) d->mask[b / 32] |= 1u << (b % 32);
+        d->words = (uint32_t)words;
+        d->masked = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
+        if (!d->make(&d->sd[0])) { err = "hipStreamCreate failed"; return nullptr; }
+        d->n = 1;
+        DecodeStreams *dp = d.release();
+        dp->maker = std::thread([dp] {
+            if (hipSetDevice(dp->device) != hipSuccess) return;
+            for (uint32_t i = 1; i < GZ_NSTREAM && !dp->stop; i++) { if (!dp->make(&dp->sd[i])) return; dp->n = i + 1; }       // (fewer streams: slabs share them)
+        });
+        dec_[device] = dp;
+        return dp;
+    }
+    std::mutex mu_, mu_dec_; std::vector<StreamSet *> free_; std::map<int, DecodeStreams *> dec_;
 };
 StreamSets g_streams;
 
@@ -448,7 +490,7 @@ public:
         for (auto &L : lanes_) {                      // nothing of this decoder may be in flight when its buffers go back to the pool
             if (!L.streams) continue;
             (void)hipSetDevice(L.dev);
-            for (auto &s : L.streams->sd) if (s) (void)hipStreamSynchronize(s);
+            for (auto &s : L.streams->dec->sd) if (s) (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(L.streams->link); (void)hipStreamSynchronize(L.streams->rest); (void)hipStreamSynchronize(L.streams->copy);
             if (L.ev_link) (void)hipEventDestroy(L.ev_link);
             if (L.ev_base) (void)hipEventDestroy(L.ev_base);
@@ -519,6 +561,7 @@ public:
             }
         }
         h_chunks_.resize(n_chunks_);
+        const double ts0 = now_s();
         DCHK(hipHostMalloc((void **)&h_chain_, sizeof(GzChain), hipHostMallocPortable));
         memset(h_chain_, 0, sizeof(GzChain));
         h_chain_->cur_bit = (uint64_t)base_byte_ * 8;
@@ -528,8 +571,10 @@ public:
             Lane &L = lanes_[l];
             L.ldev = devices[l]; L.dev = phys(devices[l]);
             DCHK(hipSetDevice(L.dev));
+            const double tl0 = now_s();
             L.streams = g_streams.take(L.dev, err);
             if (!L.streams) return MF_E_HIP;
+            t_open_streams_ += now_s() - tl0;
             DCHK(hipEventCreateWithFlags(&L.ev_link, hipEventDisableTiming));
             DCHK(hipEventCreate(&L.ev_base)); DCHK(hipEventRecord(L.ev_base, L.streams->rest));
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
@@ -551,9 +596,11 @@ public:
             const size_t a = P.lo ? base_byte_ + (size_t)P.lo * chunk_ : 0, b = std::min(size_, base_byte_ + (size_t)P.hi * chunk_ + margin_);
             for (size_t i = a / piece_; i <= (b - 1) / piece_ && i < np; i++) want[i] |= (uint64_t)1 << P.lane;
         }
+        const double tu0 = now_s();
         up_.reset(new GzUploader());
         const int rc = up_->start(fd, size_, ring_, piece_, ul, want, err);
         if (rc) return rc;
+        t_open_upload_ = now_s() - tu0; t_open_ = now_s() - ts0;
         in_member_ = true;
         TRACE("gz open: %u chunks of %zu B, %zu slabs (<= %u chunks), ring %zu MiB, pieces of %zu KiB, %u slabs in flight, %u lanes", n_chunks_, chunk_, plan_.size(), cps_,
               ring_ >> 20, piece_ >> 10, max_inflight_, nl);
@@ -602,7 +649,7 @@ public:
                 S.cap *= 4;
                 TRACE("slab %u..%u overflowed: again with %zu symbols per chunk", S.lo, S.hi, S.cap);
                 DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
-                hipStream_t sd = L.streams->sd[0];
+                hipStream_t sd = L.streams->dec->sd[0];
                 DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, sd));
                 DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd));
                 DCHK(hipStreamSynchronize(sd));
@@ -711,6 +758,7 @@ public:
     bool finished() const { return !pending_ && (done_ || (slabs_.empty() && next_plan_ >= plan_.size())); }
     uint64_t text_bytes() const { return h_chain_ ? h_chain_->total : 0; }
     double launch_seconds() const { return t_launch_; }
+    void open_parts(double &all, double &streams, double &uploader) const { all = t_open_; streams = t_open_streams_; uploader = t_open_upload_; }
     void link_parts(double &newtext, double &finish, double &chain_sync) const { newtext = t_newtext_; finish = t_finish_; chain_sync = t_chain_sync_; }
     double slot_seconds() const { return t_slot_; }
     // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer and for the piece before to be resolved); the uploader's
@@ -776,7 +824,7 @@ private:
             if (!gz_decode_serial()) DCHK(S.lst.need(L.dev, gz_decode_scratch_bytes(S.hi - S.lo) / 4, false));
             if (!S.ev) DCHK(hipEventCreate(&S.ev));
             if (!S.ev0) DCHK(hipEventCreate(&S.ev0));
-            hipStream_t st = L.streams->sd[launch_seq_++ % GZ_NSTREAM];
+            hipStream_t st = L.streams->dec->pick(launch_seq_++);
             if (!up_->wait_for(S.lane, st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_IO; }
             S.limit = upto;
             DCHK(hipEventRecord(S.ev0, st));
@@ -891,6 +939,7 @@ private:
     std::vector<GzChunk> h_chunks_;
     std::unique_ptr<TextBuf> cur_buf_;
     TextPiece pend_; bool pending_ = false; uint32_t pend_lane_ = 0; std::unique_ptr<Slab> pend_slab_;
+    double t_open_ = 0, t_open_streams_ = 0, t_open_upload_ = 0;
     bool in_member_ = false, done_ = false;
     uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
     double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_finish_ = 0, t_chain_sync_ = 0, t_slot_ = 0;
@@ -973,7 +1022,6 @@ struct DevScratch {
     // the quality filter's job: the other mate's scan results and keep flags on their way up, keep flags on their way down (pinned), per-record scratch
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
     DevBuf<uint32_t> q_bad2; DevBuf<uint8_t> q_fl2, q_alive, q_dup, q_keep;
-    hipEvent_t ev_out[2] = {nullptr, nullptr};
     hipError_t stage(size_t bytes)
     {
         if (bytes <= h_stage_cap) return hipSuccess;
@@ -987,7 +1035,6 @@ struct DevScratch {
     {
         reads_release(reads); (void)hipSetDevice(dev);
         if (h_small) (void)hipHostFree(h_small); if (h_bits) (void)hipHostFree(h_bits); if (h_out) (void)hipHostFree(h_out); if (h_stage) (void)hipHostFree(h_stage);
-        for (auto &e : ev_out) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -1043,50 +1090,118 @@ private:
     std::unique_ptr<std::atomic<T *>[]> tab_; std::mutex mu_;
 };
 
-// An output file of the quality filter.  Nearly every record is written, so the pieces' text is as large as the input's: a regular
-// file takes the pieces at their offsets from whichever consumer has one ready (pwrite); anything else -- standard output, a pipe,
-// a .gz (compressed by OutFile as the reference's GzEncoder would) -- takes them in order.
+// pinned buffers that the text of the kept records passes through on its way from the device to an output file: a consumer takes one,
+// copies a chunk of a piece's output down into it and hands it to the file's writer, which gives it back
+class OutChunks {
+public:
+    // (made one after the other by a thread of its own while the call is being set up and the first pieces are on their way: pinning memory
+    // takes its time -- more of it while streams and device buffers are being made -- and the first chunk is wanted long before the last)
+    void init(size_t chunk, int n)
+    {
+        chunk_ = chunk;
+        maker_ = std::thread([this, n] {
+            for (int i = 0; i < n; i++) {
+                { std::lock_guard<std::mutex> lk(mu_); if (abort_) break; }
+                void *q = nullptr;
+                const hipError_t e = hipHostMalloc(&q, chunk_, hipHostMallocPortable);
+                { std::lock_guard<std::mutex> lk(mu_); if (e != hipSuccess) { if (all_.empty()) err_ = e; done_ = true; } else { all_.push_back((uint8_t *)q); free_.push_back((uint8_t *)q); } }
+                cv_.notify_all();
+                if (e != hipSuccess) return;
+            }
+            { std::lock_guard<std::mutex> lk(mu_); done_ = true; }
+            cv_.notify_all();
+        });
+    }
+    size_t chunk() const { return chunk_; }
+    uint8_t *take(hipError_t *e)          // nullptr: not one chunk could be allocated (*e), or the run is being abandoned
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return abort_ || !free_.empty() || (done_ && all_.empty()); });
+        *e = err_;
+        if (abort_ || free_.empty()) return nullptr;
+        uint8_t *p = free_.back(); free_.pop_back();
+        return p;
+    }
+    void give(uint8_t *p) { { std::lock_guard<std::mutex> lk(mu_); free_.push_back(p); } cv_.notify_one(); }
+    void abort() { { std::lock_guard<std::mutex> lk(mu_); abort_ = true; } cv_.notify_all(); }
+    ~OutChunks() { abort(); if (maker_.joinable()) maker_.join(); for (uint8_t *p : all_) (void)hipHostFree(p); }
+private:
+    std::mutex mu_; std::condition_variable cv_; std::vector<uint8_t *> free_, all_; size_t chunk_ = 0;
+    std::thread maker_; bool done_ = false, abort_ = false; hipError_t err_ = hipSuccess;
+};
+
+// An output file of the quality filter.  Nearly every record is written, so what goes out is as large as the text that came in, and
+// writing it is what the job waits for: a thread per file does nothing else (a second one would queue behind the first on the
+// inode's lock).  The consumers hand it chunks with their places in the file; a regular file takes them as they come (pwrite),
+// anything else -- standard output, a pipe, a .gz (compressed by OutFile as the reference's GzEncoder would) -- in order.
 class QSink {
 public:
-    bool open(const char *path)
+    bool open(const char *path, OutChunks *pool)
     {
+        pool_ = pool;
+        bool ok = false;
         if (path && !has_gz_ext(path)) {
             fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
             if (fd_ < 0) return false;
             struct stat sb;
-            if (fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) { direct_ = true; return true; }
-            ::close(fd_); fd_ = -1;
+            if (fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) { direct_ = true; ok = true; }
+            else { ::close(fd_); fd_ = -1; }
         }
-        return of_.open(path);
+        if (!ok) ok = of_.open(path);
+        if (ok) th_ = std::thread([this] { run(); });
+        return ok;
     }
-    bool write_at(uint64_t off, const uint8_t *p, size_t n)
+    void push(uint64_t off, uint8_t *p, size_t n)          // p: a chunk of the pool, given back when written
     {
-        if (direct_) {
-            while (n) {
-                const ssize_t w = pwrite(fd_, p, n, (off_t)off);
-                if (w < 0) { if (errno == EINTR) continue; ok_ = false; return false; }
-                p += w; n -= (size_t)w; off += (uint64_t)w;
-            }
-            return true;
-        }
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return next_ == off || !ok_ || abort_; });
-        if (!ok_ || abort_) return false;
-        if (n && !of_.write((const char *)p, n)) ok_ = false;
-        next_ = off + n;
-        lk.unlock(); cv_.notify_all();
-        return ok_;
+        { std::lock_guard<std::mutex> lk(mu_); q_.emplace(off, Item{p, n}); }
+        cv_.notify_one();
     }
+    bool ok() { std::lock_guard<std::mutex> lk(mu_); return ok_; }
     void abort() { { std::lock_guard<std::mutex> lk(mu_); abort_ = true; } cv_.notify_all(); }
-    bool close()
+    double busy() const { return busy_; }
+    bool close()          // everything pushed is written (in order: up to the first gap) unless aborted
     {
+        if (th_.joinable()) { { std::lock_guard<std::mutex> lk(mu_); fin_ = true; } cv_.notify_all(); th_.join(); }
         if (direct_) { const bool c = fd_ < 0 || ::close(fd_) == 0; fd_ = -1; return c && ok_; }
         return of_.close() && ok_;
     }
-    ~QSink() { if (fd_ >= 0) ::close(fd_); }
+    ~QSink() { if (th_.joinable()) { abort(); { std::lock_guard<std::mutex> lk(mu_); fin_ = true; } cv_.notify_all(); th_.join(); } if (fd_ >= 0) ::close(fd_); }
 private:
-    int fd_ = -1; bool direct_ = false; OutFile of_;
-    std::mutex mu_; std::condition_variable cv_; uint64_t next_ = 0; bool ok_ = true, abort_ = false;
+    struct Item { uint8_t *p; size_t n; };
+    void run()
+    {
+        for (;;) {
+            uint64_t off = 0; Item it{nullptr, 0}; bool drop = false;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return abort_ || fin_ || (!q_.empty() && (direct_ || q_.begin()->first == next_)); });
+                if (q_.empty()) { if (fin_ || abort_) return; continue; }
+                if (!direct_ && !abort_ && q_.begin()->first != next_) { if (fin_) abort_ = true; else continue; }      // (closed with a gap: a failed run)
+                off = q_.begin()->first; it = q_.begin()->second; q_.erase(q_.begin());
+                drop = abort_ || !ok_;
+            }
+            if (!drop) {
+                const double t0 = now_s();
+                bool w = true;
+                if (direct_) {
+                    const uint8_t *p = it.p; size_t n = it.n; uint64_t o = off;
+                    while (n) {
+                        const ssize_t k = pwrite(fd_, p, n, (off_t)o);
+                        if (k < 0) { if (errno == EINTR) continue; w = false; break; }
+                        p += k; n -= (size_t)k; o += (uint64_t)k;
+                    }
+                } else w = of_.write((const char *)it.p, it.n);
+                busy_ += now_s() - t0;
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!w) ok_ = false;
+                next_ = off + it.n;
+            }
+            pool_->give(it.p);
+        }
+    }
+    int fd_ = -1; bool direct_ = false; OutFile of_; OutChunks *pool_ = nullptr;
+    std::thread th_; std::mutex mu_; std::condition_variable cv_; std::map<uint64_t, Item> q_;
+    uint64_t next_ = 0; bool ok_ = true, abort_ = false, fin_ = false; double busy_ = 0;
 };
 
 struct QualState {
@@ -1099,8 +1214,8 @@ struct QualState {
     int in_flight = 0;                                            // (Ingest::mu) pieces being gathered and written
     // the de-duplication set (keys, smallest file index per key; mf_kernels.hip): on the device for the whole file
     DevBuf<unsigned long long> dd_keys, dd_first, dd_small; uint64_t dd_slots = 0, dd_n = 0;
-    QSink sink[2];
-    double t_scan = 0, t_decide = 0, t_gather = 0, t_write = 0;   // (Ingest::mu) summed over the consumers
+    OutChunks chunks; QSink sink[2];                              // (the pool first: the sinks' threads give their last chunks back to it)
+    double t_scan = 0, t_decide = 0, t_gather = 0, t_chunk = 0;   // (Ingest::mu) summed over the consumers; t_chunk: waiting for a free chunk = for the writers
 };
 
 struct Mate {
@@ -1698,42 +1813,42 @@ struct Ingest {
         return MF_OK;
     }
 
-    // the kept records of a decided piece -> its place in the output file (any number of pieces at a time; S.out_len / S.out_off are
-    // still those of the piece: the consumer that decided it is the one that writes it, and does nothing in between)
-    int q_emit(Worker &W, int mi, Batch &B, const QPart &part, std::string &err)
+    // the kept records of a decided part -> its place in the output file (any number of parts at a time; S.out_len / S.out_off are
+    // still those of the part: the consumer that decided it is the one that gathers it, and does nothing in between).  The text is
+    // done with once the records are gathered: the last part's consumer lets go of the piece (B) there, and its buffer goes back
+    // to the producer while the output is on its way down and out.
+    int q_emit(Worker &W, int mi, std::shared_ptr<Batch> &B, const QPart &part, std::string &err)
     {
         QualState &Q = *qual;
-        if (!part.bytes) return MF_OK;
+        if (!part.bytes) { B.reset(); return MF_OK; }
         const double t0 = now_s();
-        DevScratch *Sp = scratch_for(W, B.ldev, err);
+        DevScratch *Sp = scratch_for(W, B->ldev, err);
         if (!Sp) return MF_E_HIP;
         DevScratch &S = *Sp;
         const int dev = S.dev;
         hipStream_t sp = S.ctx->stream;
         const uint64_t bytes = part.bytes;
         DCHK(S.d_out.need(dev, bytes));
-        DCHK(launch_qual_gather(B.text, B.line_start.p + 4 * part.r0, part.n, Q.P.start, B.q_sl.p + part.r0, B.q_ql.p + part.r0, S.out_len.p, S.out_off.p, S.d_out.p, sp));
-        const size_t chunk = (size_t)std::max<uint64_t>(env_u64("MF_QUAL_OUT_CHUNK", (uint64_t)16 << 20), 4096);
-        if (S.h_out_cap < 2 * chunk) { if (S.h_out) (void)hipHostFree(S.h_out); S.h_out = nullptr; S.h_out_cap = 0; DCHK(hipHostMalloc((void **)&S.h_out, 2 * chunk, hipHostMallocDefault)); S.h_out_cap = 2 * chunk; }
-        for (auto &e : S.ev_out) if (!e) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        const uint64_t nc = (bytes + chunk - 1) / chunk;
-        auto issue = [&](uint64_t k) -> hipError_t {
-            const uint64_t off = k * chunk, len = std::min<uint64_t>(chunk, bytes - off);
-            hipError_t e = hipMemcpyAsync(S.h_out + (k & 1) * chunk, S.d_out.p + off, len, hipMemcpyDeviceToHost, sp);
-            return e != hipSuccess ? e : hipEventRecord(S.ev_out[k & 1], sp);
-        };
+        DCHK(launch_qual_gather(B->text, B->line_start.p + 4 * part.r0, part.n, Q.P.start, B->q_sl.p + part.r0, B->q_ql.p + part.r0, S.out_len.p, S.out_off.p, S.d_out.p, sp));
+        DCHK(hipStreamSynchronize(sp));
+        B.reset();
+        const size_t chunk = Q.chunks.chunk();
         double tw = 0;
-        DCHK(issue(0));
-        for (uint64_t k = 0; k < nc; k++) {
-            DCHK(hipEventSynchronize(S.ev_out[k & 1]));
-            if (k + 1 < nc) DCHK(issue(k + 1));              // (into the buffer the chunk before the last was written from)
-            const uint64_t off = k * chunk, len = std::min<uint64_t>(chunk, bytes - off);
+        for (uint64_t off = 0; off < bytes; off += chunk) {
+            const uint64_t len = std::min<uint64_t>(chunk, bytes - off);
             const double w0 = now_s();
-            if (!Q.sink[mi].write_at(part.out_at + off, S.h_out + (k & 1) * chunk, (size_t)len)) { err = std::string("write error on ") + out_name(mi); return MF_E_IO; }
+            hipError_t e = hipSuccess;
+            uint8_t *p = Q.chunks.take(&e);
             tw += now_s() - w0;
+            if (!p) { if (e != hipSuccess) { err = std::string("hipHostMalloc failed: ") + hipGetErrorString(e); return MF_E_NOMEM; } err = "abandoned"; return MF_E_IO; }
+            hipError_t c = hipMemcpyAsync(p, S.d_out.p + off, len, hipMemcpyDeviceToHost, sp);
+            if (c == hipSuccess) c = hipStreamSynchronize(sp);
+            if (c != hipSuccess) { Q.chunks.give(p); err = std::string("copy of the output failed: ") + hipGetErrorString(c); return MF_E_HIP; }
+            Q.sink[mi].push(part.out_at + off, p, (size_t)len);
+            if (!Q.sink[mi].ok()) { err = std::string("write error on ") + out_name(mi); return MF_E_IO; }
         }
         wrote_any = true;
-        { std::lock_guard<std::mutex> lk(mu); Q.t_gather += now_s() - t0 - tw; Q.t_write += tw; }
+        { std::lock_guard<std::mutex> lk(mu); Q.t_gather += now_s() - t0 - tw; Q.t_chunk += tw; }
         return MF_OK;
     }
     std::string out_path_[2];
@@ -1801,8 +1916,8 @@ struct Ingest {
                 }
             }
             cv.notify_all(); cv_all.notify_all();
-            if (!rc) rc = q_emit(W, mi, *B, part, err);
-            B.reset();                                     // (the last part written: the text buffer goes back, a producer may be waiting for one)
+            if (!rc) rc = q_emit(W, mi, B, part, err);     // (lets go of B as soon as the records are gathered: the text buffer goes back, a producer may be waiting for one)
+            B.reset();
             { std::lock_guard<std::mutex> lk(mu); Q.in_flight--; }
             cv.notify_all(); cv_all.notify_all();
             did = true;
@@ -1811,6 +1926,7 @@ struct Ingest {
         return did;
     }
 
+    void q_abandon() { qual->chunks.abort(); for (auto &sk : qual->sink) sk.abort(); }
     bool q_all_done()          // (takes mu)
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -1825,7 +1941,7 @@ struct Ingest {
         for (;;) {
             int rc = MF_OK;
             bool did = q_progress(W, err, rc);
-            if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; }
+            if (rc) { fail_with(rc, err); q_abandon(); return; }
             int mi = 0; TextPiece P; uint64_t seq = 0; bool again = false;
             if (take_piece(mi, P, seq, err, rc, &again)) {
                 Mate &M = m[mi];
@@ -1846,12 +1962,12 @@ struct Ingest {
                     M.a_turn = seq + 1;
                 }
                 cv.notify_all();
-                if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; }
+                if (rc) { fail_with(rc, err); q_abandon(); return; }
                 B.reset();
-                if (Bp) { rc = q_scan(W, mi, *Bp, err); if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; } }
+                if (Bp) { rc = q_scan(W, mi, *Bp, err); if (rc) { fail_with(rc, err); q_abandon(); return; } }
                 continue;
             }
-            if (rc) { fail_with(rc, err); for (auto &sk : qual->sink) sk.abort(); return; }
+            if (rc) { fail_with(rc, err); q_abandon(); return; }
             if (q_all_done()) return;
             if (!did && !again) { std::unique_lock<std::mutex> lk(mu_all); cv_all.wait_for(lk, std::chrono::microseconds(200)); }
         }
@@ -1974,18 +2090,23 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     // filter's pieces wait longer: their text is written out)
     const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", I.qual ? 8 : 6)) + (int)I.devices.size() - 1;
     int rc = MF_OK;
-    for (int i = 0; i < I.nm && !rc; i++) {
-        Mate &M = I.m[i];
-        M.slots.free_ = text_bufs; M.slots.stop = &M.stop;
-        if (M.gz) {
+    {   // (the two mates' decoders side by side: most of it is making streams and pinning staging buffers)
+        int rcs[2] = {MF_OK, MF_OK}; std::string errs[2]; std::thread th[2];
+        for (int i = 0; i < I.nm; i++) {
+            Mate &M = I.m[i];
+            M.slots.free_ = text_bufs; M.slots.stop = &M.stop;
+            if (!M.gz) continue;
             M.gzs.reset(new GzStream());
-            rc = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, &M.stop, err);
+            auto open = [&I, &M, &rcs, &errs, i] { rcs[i] = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, &M.stop, errs[i]); };
+            if (i == 0 && I.nm == 2 && I.m[1].gz == false) open(); else if (i == 0 && I.nm == 2) th[0] = std::thread(open); else open();
         }
+        for (auto &t : th) if (t.joinable()) t.join();
+        for (int i = 0; i < I.nm && !rc; i++) if (rcs[i]) { rc = rcs[i]; err = errs[i]; }
     }
     if (alloc_failure(rc)) { TRACE("declined: %s", err.c_str()); return MF_DEVINGEST_DECLINED; }      // (nothing has been touched: the host pipeline streams the file)
     if (rc) return rc;
     for (int i = 0; i < I.nm; i++)
-        if (!(I.qual ? I.qual->sink[i].open(out_path[i]) : I.m[i].out.open(out_path[i]))) { err = std::string("Cannot open file ") + (out_path[i] ? out_path[i] : "<stdout>"); return MF_E_IO; }
+        if (!(I.qual ? I.qual->sink[i].open(out_path[i], &I.qual->chunks) : I.m[i].out.open(out_path[i]))) { err = std::string("Cannot open file ") + (out_path[i] ? out_path[i] : "<stdout>"); return MF_E_IO; }
     const double t_setup = now_s() - t_begin;
     rc = I.run(err);
     TRACE("run returned %d", rc);
@@ -2011,15 +2132,17 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     }
     if (I.timing) {
         if (I.qual)
-            fprintf(stderr, "[mf device ingest] quality filter: wall %.3f s | set-up %.3f | consumers (summed over %zu): waiting for text %.3f, line index %.3f, scan %.3f, decisions %.3f, gather + copy down %.3f, writing %.3f | %llu + %llu bytes written | buffers of this call at most %.2f GB, device memory in use at most %.2f GB",
-                    now_s() - t_begin, t_setup, I.workers.size(), I.t_wait, I.t_index, I.qual->t_scan, I.qual->t_decide, I.qual->t_gather, I.qual->t_write,
+            fprintf(stderr, "[mf device ingest] quality filter: wall %.3f s | set-up %.3f | consumers (summed over %zu): waiting for text %.3f, line index %.3f, scan %.3f, decisions %.3f, gather + copy down %.3f, waiting for the writers %.3f; writers busy %.3f %.3f | %llu + %llu bytes written | buffers of this call at most %.2f GB, device memory in use at most %.2f GB",
+                    now_s() - t_begin, t_setup, I.workers.size(), I.t_wait, I.t_index, I.qual->t_scan, I.qual->t_decide, I.qual->t_gather, I.qual->t_chunk, I.qual->sink[0].busy(), I.qual->sink[1].busy(),
                     (unsigned long long)I.qual->out_pos[0], (unsigned long long)I.qual->out_pos[1], (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9);
         else
             fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
                     now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
+        { double tm; uint64_t nm; g_pool.malloc_time(tm, nm); fprintf(stderr, " | %llu new device allocations took %.3f s (summed over the threads that asked)", (unsigned long long)nm, tm); }
         fprintf(stderr, " | first text after %.3f s, last after %.3f, consumers done after %.3f", I.t_first_piece, I.t_last_piece, I.t_consumed);
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);
+                              { double oa, os, ou; I.m[i].gzs->open_parts(oa, os, ou); fprintf(stderr, "; set-up %.3f (streams %.3f, uploader's buffers and thread %.3f)", oa, os, ou); }
                               double x, y, z; I.m[i].gzs->link_parts(x, y, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f, waiting for the piece before to be resolved and checked %.3f, waiting for the chain kernel %.3f)", x, I.m[i].gzs->slot_seconds(), y, z); }
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) fprintf(stderr, " | mate %d: inflate kernels busy %.3f s (%.1f GB/s of text), %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, I.m[i].gzs->decode_busy_seconds(), I.m[i].gzs->decode_busy_seconds() > 0 ? (double)I.m[i].gzs->text_bytes() / I.m[i].gzs->decode_busy_seconds() / 1e9 : 0.0, (unsigned long long)I.m[i].gzs->chunks_linked(),
@@ -2050,6 +2173,7 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
     if (out2 && has_gz_ext(out2) && env_u64("MF_QUAL_DEVICE_GZ_OUT", 0) == 0) return MF_DEVINGEST_DECLINED;
     QualState Q;                      // (before the Ingest: its batches hold buffers the state does not own, but the set's go back to the pool last)
     Q.P = P; Q.pe = fq2 != nullptr; Q.cap = P.end ? P.end - P.start : ~0ull;
+    Q.chunks.init((size_t)std::max<uint64_t>(env_u64("MF_QUAL_OUT_CHUNK", (uint64_t)4 << 20), 4096), (int)std::max<uint64_t>(2, env_u64("MF_QUAL_OUT_CHUNKS", 24)));
     Ingest I;
     I.qual = &Q;
     I.devices.push_back(device);
