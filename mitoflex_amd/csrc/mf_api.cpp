@@ -1061,13 +1061,17 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     if (quality == 0 || quality > 100) return fail(MF_E_ARG, "quality must be in 1..100");
     QualParams P; P.start = start; P.end = end; P.ns = ns; P.trim = trim; P.quality = quality; P.limit = limit;
     P.dedup = dedup != 0; P.trunc = truncate_only != 0;
-    // Regular files -- .gz or plain -- take the device ingest path (mf_devingest.cpp): the bytes go up as they lie, and inflate, line index,
-    // counting, hashing, the de-duplication set, the decisions and the formatting of the kept records run there; what comes back is the
-    // output's text.  Standard input, pipes, BGZF, empty files and .gz outputs keep the host pipeline below, and MF_QUAL_INGEST=host keeps
-    // everything there (=device is the default; both write the same bytes: tests/test_filter_v2.py runs the reference's vectors through both).
+    // Regular .gz files take the device ingest path (mf_devingest.cpp): the bytes go up as they lie, and inflate, line index, counting,
+    // hashing, the de-duplication set, the decisions and the formatting of the kept records run there; what comes back is the output's
+    // text.  Plain files stay with the host pipeline below by default, as in mf_filter_fastq_files (their text would cross PCIe twice, up as
+    // input and down as output, where the host pipeline sends it up once and writes from its own memory: level on the box, the host
+    // ahead on a few million pairs); MF_QUAL_INGEST=device sends them the same way, =host keeps everything on the host.  Standard input,
+    // pipes, BGZF, empty files and .gz outputs always take the host pipeline.  Both write the same bytes: tests/test_filter_v2.py runs
+    // the reference's vectors through both.
     {
         const char *ing = getenv("MF_QUAL_INGEST");
-        if (!(ing && strcmp(ing, "host") == 0) && fq1) {
+        const bool force = ing && strcmp(ing, "device") == 0, any_gz = (fq1 && has_gz_ext(fq1)) || (fq2 && has_gz_ext(fq2));
+        if (!(ing && strcmp(ing, "host") == 0) && fq1 && (force || any_gz)) {
             if (mf_device_count() <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible; libmitofilter_hip has no CPU fallback");
             std::string derr; IngestStats is; bool pan = false;
             const int drc = run_device_qualfilter(fq1, fq2, out1, out2, P, device, kept, total, &pan, derr, &is);

@@ -511,7 +511,7 @@ public:
     int open(const uint8_t *data, size_t size, int fd, const std::vector<int> &devices, const std::string &path, Slots *slots, size_t carry_room,
              uint32_t nslab, std::atomic<bool> *stop, std::string &err)
     {
-        const uint32_t NSLAB = std::max<uint32_t>(1, (uint32_t)env_u64("MF_GZDEV_SLABS_IN_FLIGHT", nslab));
+        uint32_t NSLAB = std::max<uint32_t>(1, (uint32_t)env_u64("MF_GZDEV_SLABS_IN_FLIGHT", nslab));
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
         // chunks: large enough that the serial link step (a fixed cost per chunk) stays small, small enough that a file keeps the chip busy
@@ -522,6 +522,9 @@ public:
         if (chunk_ < 1024) chunk_ = 1024;
         cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", std::max<uint64_t>(256, ((uint64_t)128 << 20) / chunk_));
         if (cps_ < 1) cps_ = 1;
+        // slabs in flight are counted in slabs of 512 chunks (the 256 KiB chunks of a large file): what fills the chip is chunks, and a file
+        // of a gigabyte, with its smaller chunks and more of them to a slab, would hold twice the symbol room for nothing
+        if (!getenv("MF_GZDEV_SLABS_IN_FLIGHT") && cps_ > 512) NSLAB = std::max<uint32_t>(2, (uint32_t)(((uint64_t)NSLAB * 512 + cps_ - 1) / cps_));
         // symbols of room per compressed byte: a first guess (FASTQ compresses three- to fivefold; the rule adds a chunk's worth, so
         // 3.5 covers 4.5 : 1), then what the file has shown plus a quarter; a slab that overflows is decoded again with four times the room
         expand_ = getenv("MF_GZDEV_EXPAND") ? (double)env_u64("MF_GZDEV_EXPAND", 4) : 3.5;

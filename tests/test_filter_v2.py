@@ -149,12 +149,13 @@ def test_cli_host_logic_random_against_oracle(cli_host_only, tmp_path, monkeypat
 
 
 # The drop-in has two ways to the same bytes: regular files go to the GPU as they lie (inflate, line index, counting, hashing, the
-# de-duplication set, decisions and the formatting of the kept records on the device: mf_devingest.cpp -- the default), everything else
-# (standard input, pipes, BGZF, .gz outputs) and MF_QUAL_INGEST=host take the host pipeline with GPU counting.  Both are held to the ELF's vectors.
+# de-duplication set, decisions and the formatting of the kept records on the device: mf_devingest.cpp -- the default for .gz input,
+# MF_QUAL_INGEST=device for plain files too), everything else (standard input, pipes, BGZF, .gz outputs) and MF_QUAL_INGEST=host take
+# the host pipeline with GPU counting.  Both are held to the ELF's vectors.
 # "device-seams": chunks of 4 KiB of compressed input, three to a slab, text pieces of a few hundred bytes to 20 kB, two text buffers
 # a mate -- records, mates' pieces and decisions meet at every possible kind of border.
-INGEST = {"device": {}, "host": {"MF_QUAL_INGEST": "host"},
-          "device-seams": {"MF_GZDEV_CHUNK_BYTES": "4096", "MF_GZDEV_SLAB_CHUNKS": "3", "MF_GZDEV_TEXT_PIECE": "20000", "MF_INGEST_SLAB_BYTES": "333",
+INGEST = {"device": {"MF_QUAL_INGEST": "device"}, "host": {"MF_QUAL_INGEST": "host"},
+          "device-seams": {"MF_QUAL_INGEST": "device", "MF_GZDEV_CHUNK_BYTES": "4096", "MF_GZDEV_SLAB_CHUNKS": "3", "MF_GZDEV_TEXT_PIECE": "20000", "MF_INGEST_SLAB_BYTES": "333",
                            "MF_INGEST_TEXT_BUFS": "2", "MF_QUAL_OUT_CHUNK": "4096", "MF_INGEST_CONSUMERS": "3"}}
 
 

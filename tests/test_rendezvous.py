@@ -68,3 +68,20 @@ def test_bench_line_shapes():
             assert r["bound"] == "valu" and "hbm" in r and r["hbm"]["unit"] == "GB/s", name
         else:
             assert r["bound"] == "hbm" and r["unit"] == "GB/s", name
+
+
+def test_bench_line_shapes_round4():
+    """Round 4's additions to the default line as committed under profiles/r04/: the file-level leg against its own roof, files written by
+    real compressors, the k sweep, the quality filter through the device ingest path."""
+    import json
+    f = os.path.join(ROOT, "profiles", "r04", "bench_shape_default.json")
+    if not os.path.exists(f):
+        pytest.skip("profiles/r04/bench_shape_default.json not committed yet")
+    x = json.load(open(f))["extra"]
+    c4 = x["e2e_files"]["configs4_se_gz"]
+    assert c4["roofline"]["bound"] == "pcie_h2d" and 0 < c4["roofline"]["frac"] < 1 and c4["output_equals_host_pipeline_on_plain_text"] and c4["ingest_path"] == "device"
+    assert all(v["output_equals_host_pipeline_on_plain_text"] for v in x["e2e_files"]["real_compressors"]["files"].values())
+    assert {"21", "41"} <= set(x["k_sweep"])
+    q = x["filter_v2"]
+    assert q["cli_outputs_equal"] and q["library_outputs_equal"] and q["library_call"]["device"]["ingest_path"] == "device"
+    assert {"device", "host"} <= set(q["cli_process_start_to_exit"])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # filter_v2 end to end on the GPU box: plain and .gz inputs, device ingest path against the host pipeline (MF_QUAL_INGEST=host);
-# process start to exit, outputs not pre-existing.  usage: tools/e2e_filter_v2_dev.sh [pairs] [consumers]
+# process start to exit, outputs not pre-existing.  usage: [QUICK=1] [BIG=n] tools/e2e_filter_v2_dev.sh [pairs]
 cd $GRAFT_REPO_ROOT; T=/tmp/fv2; mkdir -p $T
 PAIRS=${1:-8000000}
 python tools/make_fastq.py $T/s --pairs $PAIRS --block 2000000
@@ -19,6 +19,7 @@ def md5(p):
     return h.hexdigest()
 sums={}
 def t(tag, args, reads, env=None, reps=3, check=None):
+    global quick
     if quick and env and env.get("MF_QUAL_INGEST") == "host": return
     best=1e9
     e=dict(os.environ); e.update(env or {})
@@ -37,12 +38,29 @@ for sfx in ("", ".gz"):
     pe=["-1",T+"/s_1.fq"+sfx,"-2",T+"/s_2.fq"+sfx,"-3",T+"/o_1.fq","-4",T+"/o_2.fq"]
     se=["-1",T+"/s_1.fq"+sfx,"-3",T+"/o_se.fq","-q","60","-l","0.3"]
     kind="plain" if not sfx else ".gz"
-    t(f"PE default {kind} device", pe, 2*pairs, check="pe")
+    D={"MF_QUAL_INGEST":"device"}
+    t(f"PE default {kind} device", pe, 2*pairs, D, check="pe")
     t(f"PE default {kind} host", pe, 2*pairs, H, reps=2, check="pe")
-    t(f"PE dedup {kind} device", pe+["-d"], 2*pairs, check="ped")
+    t(f"PE dedup {kind} device", pe+["-d"], 2*pairs, D, check="ped")
     t(f"PE dedup {kind} host", pe+["-d"], 2*pairs, H, reps=2, check="ped")
-    t(f"SE q60 l0.3 {kind} device", se, pairs, check="se")
+    t(f"SE q60 l0.3 {kind} device", se, pairs, D, check="se")
     t(f"SE q60 l0.3 {kind} host", se, pairs, H, reps=2, check="se")
+big = int(os.environ.get("BIG", "0"))
+if big > 1:
+    # the same files BIG times over, as gzip members one behind the other: a longer input without the minutes it takes to make one
+    for m in ("1", "2"):
+        with open(f"{T}/b_{m}.fq.gz", "wb") as o:
+            for _ in range(big):
+                with open(f"{T}/s_{m}.fq.gz", "rb") as i:
+                    while True:
+                        blk = i.read(1 << 24)
+                        if not blk: break
+                        o.write(blk)
+    bpe = ["-1", T+"/b_1.fq.gz", "-2", T+"/b_2.fq.gz", "-3", T+"/o_1.fq", "-4", T+"/o_2.fq"]
+    t(f"PE default .gz x{big} device", bpe, 2*pairs*big, reps=2, check="big")
+    quick_saved, quick = quick, False
+    t(f"PE default .gz x{big} host", bpe, 2*pairs*big, H, reps=1, check="big")
+    quick = quick_saved
 for c in (() if quick else (3, 10)):
     t(f"PE dedup .gz device, {c} consumers", ["-1",T+"/s_1.fq.gz","-2",T+"/s_2.fq.gz","-3",T+"/o_1.fq","-4",T+"/o_2.fq","-d"], 2*pairs, {"MF_INGEST_CONSUMERS":str(c)})
 PY
