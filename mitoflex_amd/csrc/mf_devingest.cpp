@@ -257,7 +257,7 @@ constexpr uint32_t GZ_NSTREAM = 10;
 struct DecodeStreams {
     int device = -1; hipStream_t sd[GZ_NSTREAM] = {}; std::atomic<uint32_t> n{0};
     std::thread maker; std::atomic<bool> stop{false};
-    uint32_t words = 0; std::vector<uint32_t> mask; bool masked = false;
+    uint32_t words = 0; int n_cu = 0; std::vector<uint32_t> mask; bool masked = false;
     bool make(hipStream_t *q) const
     {
         if (masked && hipExtStreamCreateWithCUMask(q, words, mask.data()) == hipSuccess) return true;
@@ -266,8 +266,9 @@ struct DecodeStreams {
     }
     hipStream_t pick(uint32_t seq) const { return sd[seq % std::max<uint32_t>(1, n.load())]; }
 };
-// what a mate's decoder has of its own: the stream of the link step (chain, marker resolution, CRC), one for the rest (small copies,
-// set-up), one for the uploads.  Plain streams: their kernels find the CUs the decode streams are masked off.
+// what a mate's decoder has of its own: the stream of the link step (chain, marker resolution, CRC) -- masked to the CUs the decode
+// streams are masked off (MF_GZDEV_LINK_MASK=0: a plain stream, whose workgroups go wherever there is room) --, one for the rest (small
+// copies, set-up), one for the uploads.
 struct StreamSet { int device = -1; DecodeStreams *dec = nullptr; hipStream_t link = nullptr, rest = nullptr, copy = nullptr; };
 class StreamSets {
 public:
@@ -281,7 +282,17 @@ public:
         }
         std::unique_ptr<StreamSet> s(new StreamSet());
         s->device = device; s->dec = dec;
-        bool ok = hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess;
+        bool ok = true;
+        {
+            const char *lm = getenv("MF_GZDEV_LINK_MASK");
+            std::vector<uint32_t> m_link(dec->mask.size());
+            for (size_t i = 0; i < m_link.size(); i++) m_link[i] = ~dec->mask[i];
+            if (dec->n_cu % 32) m_link.back() &= (1u << (dec->n_cu % 32)) - 1;
+            if (!dec->masked || (lm && lm[0] == '0') || hipExtStreamCreateWithCUMask(&s->link, dec->words, m_link.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess;
+            }
+        }
         ok = ok && hipStreamCreateWithFlags(&s->rest, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking) == hipSuccess;
         if (!ok) { err = "hipStreamCreate failed"; return nullptr; }
@@ -327,7 +338,7 @@ private:
         reserve = std::max(8, std::min(n_cu / 2, reserve)) & ~7;
         d->mask.assign((size_t)words, 0);
         for (int b = 0; b < n_cu - reserve; b++) d->mask[b / 32] |= 1u << (b % 32);
-        d->words = (uint32_t)words;
+        d->words = (uint32_t)words; d->n_cu = n_cu;
         d->masked = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
         if (!d->make(&d->sd[0])) { err = "hipStreamCreate failed"; return nullptr; }
         d->n = 1;
