@@ -83,6 +83,11 @@ public:
             }
         }
         const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        // (test hook: MF_DEVPOOL_FAIL_AT=n makes the n-th new allocation of the process fail as if the device were full -- the call must then
+        // hand the input to the host pipeline, tests/test_gpu_devingest.py::test_a_failed_allocation_hands_the_call_to_the_host_pipeline)
+        static const uint64_t fail_at = env_u64("MF_DEVPOOL_FAIL_AT", 0);
+        static std::atomic<uint64_t> n_new{0};
+        if (fail_at && ++n_new >= fail_at) { *p = nullptr; *got = 0; return hipErrorOutOfMemory; }
         hipError_t e = hipMalloc(p, want);
         { std::lock_guard<std::mutex> lk(mu_); t_malloc_ += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; n_malloc_++; }
         if (e != hipSuccess) {                      // make room: release what the pool holds for this device and try once more

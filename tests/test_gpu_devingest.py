@@ -443,3 +443,31 @@ def test_configs4_at_full_size(mf, ol, bait_text, tmp_path_factory, monkeypatch,
     if level == 6:
         for f in os.listdir(str(d)):
             os.unlink(os.path.join(str(d), f))
+
+
+@pytest.mark.parametrize("fail_at", [1, 4, 12, 30])
+def test_a_failed_allocation_hands_the_call_to_the_host_pipeline(ol, bait_text, tmp_path, fail_at):
+    """Out of device memory before a survivor has been written (here: the n-th new allocation of the process is made to fail,
+    MF_DEVPOOL_FAIL_AT) is not an error of the call: the host pipeline takes the input, and the output is the oracle's.  A child
+    process: the hook counts the allocations of a process."""
+    import subprocess
+    s1 = make_reads(bait_text, 6000, seed=25)
+    s2 = make_reads(bait_text, 6000, seed=26)
+    fq1, fq2 = str(tmp_path / "a_1.fq.gz"), str(tmp_path / "a_2.fq.gz")
+    open(fq1, "wb").write(gz_bytes(fastq_text(s1, "a"), 6))
+    open(fq2, "wb").write(gz_bytes(fastq_text(s2, "b"), 6))
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+    ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
+    g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
+    cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
+    env = dict(os.environ, MF_PIPE_TIMING="1", MF_DEVPOOL_FAIL_AT=str(fail_at), MF_GZDEV_CHUNK_BYTES="16384", MF_GZDEV_SLAB_CHUNKS="8")
+    env.pop("MF_INGEST", None)
+    p = subprocess.run([cli, "bait", "--bait", bait, "-k", "31", "--fq1", fq1, "--fq2", fq2, "--out1", g1, "--out2", g2], capture_output=True, env=env, timeout=300)
+    err = p.stderr.decode()
+    assert p.returncode == 0, err[:3000]
+    assert "declined" in err, err[:3000]
+    assert int(p.stdout.decode().split()[0]) == ok and ot == 6000
+    assert open(g1, "rb").read() == open(o1, "rb").read()
+    assert open(g2, "rb").read() == open(o2, "rb").read()
