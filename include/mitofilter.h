@@ -244,7 +244,10 @@ int mf_h2d_bandwidth(int device, size_t bytes, int reps, double *gb_per_s);
  * kept; SipHash-1-3 like Rust's DefaultHasher), stop once `trim` bases have been kept,
  * `truncate_only` skips the tests.  fq1 NULL = standard input; out2 NULL with fq2 set = standard
  * output.  Counting and hashing run on the GPU over the raw FASTQ text; the order-dependent rules
- * are applied on the host.  *panicked is set when the reference would have aborted mid-file (cut
+ * are applied on the host.  Regular .gz input files take the device ingest path (inflate, line index,
+ * counting, hashing, the de-duplication set, the decisions and the formatting of the kept records on
+ * the GPU; mf_last_ingest_stats tells), everything else the host pipeline; MF_QUAL_INGEST=device|host
+ * forces either for what both can take.  Same bytes either way.  *panicked is set when the reference would have aborted mid-file (cut
  * start beyond a string, invalid UTF-8): output up to that record is written, as the reference's
  * BufWriter flushes on unwind, and the CLI then exits 101. */
 int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, const char *out2,

@@ -10,13 +10,20 @@
 //   * a plain FASTQ file IS the text: it is read straight into such buffers.
 //   With n devices the slabs are dealt to them round robin: the link step of slab k needs the state the link step of slab k - 1
 //   left (bit position, text length, the last 32 KiB: 33 KB through the host), nothing else crosses devices.
-// The calling thread is the CONSUMER.  Per piece, on the device that holds it: cut the text into records where it lies
-// (mf_ingest.h; what is behind the last complete record of a piece, the carry, is copied to the front of the next piece's
-// buffer), 2-bit pack them into the device's refillable read set, ONE filter pass over the piece's reads; the pass bits come
-// back to the host (a bit per read), where the pair rule is applied across the two mates' file-wide bitmaps -- the pieces of the
-// two mates do not cover the same records, the mate that is behind in records is advanced --; a piece whose records the other
-// mate has covered gets its keep mask, its survivors are gathered on the device and copied out to a writer thread per output
-// file, and its buffers go back to the pool.  A producer blocks when its mate holds MF_INGEST_TEXT_BUFS text buffers.
+// A few CONSUMER threads take the pieces.  Per piece, on the device that holds it: cut the text into records where it lies
+// (mf_ingest.h; one piece of a mate at a time, in order: what is behind the last complete record of a piece, the carry, goes to the
+// front of the next piece's buffer), then -- several pieces side by side, each consumer on its own streams -- the piece's job:
+//   * the bait filter (mf_filter_fastq_files): 2-bit pack into the consumer's refillable read set, ONE filter pass over the piece's
+//     reads; the pass bits come back to the host (a bit per read), where the pair rule is applied across the two mates' file-wide
+//     bitmaps -- the pieces of the two mates do not cover the same records, the mate that is behind in records is advanced --; a piece
+//     whose records the other mate has covered gets its list of kept records, its survivors are gathered on the device and copied out
+//     to a writer thread per output file;
+//   * the quality filter (mf_qualfilter_files, the reference's filter_v2): one pass over the records' bytes (counts, flags, cut
+//     lengths, SipHash), decisions a piece of mate 1 at a time in file order (the other mate's counts through per-record arrays on the
+//     host, the de-duplication set on the device, the -t budget on the host), the kept records formatted on the device and sent down
+//     through pinned chunks to a writer thread per output file -- nearly every record is kept, so this job writes as much as it reads.
+// A piece's buffers go back to the pool when its part of the output is on its way.  A producer blocks when its mate holds
+// MF_INGEST_TEXT_BUFS text buffers.
 #include "mf_devingest.h"
 #include "mf_api_internal.h"
 #include "mf_gzdev.h"
@@ -24,6 +31,7 @@
 #include "mf_ingest.h"
 #include "mf_pinflate.h"
 #include "mf_pipeline.h"
+#include "mf_qualsink.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1084,145 +1092,6 @@ private:
 ScratchCache &g_scratch = *new ScratchCache();          // (never destroyed: its entries would call into HIP while the process is being torn down)
 
 // ---- the quality filter's job on this path (the reference's filter_v2: filter/filter_bin/src/main.rs:188-323)
-// one value per record of a file, written and read a piece at a time by several threads: segments of 2^20 records that never move
-template <class T> class SegArray {
-public:
-    SegArray() : tab_(new std::atomic<T *>[NSEG]) { for (size_t i = 0; i < NSEG; i++) tab_[i] = nullptr; }
-    ~SegArray() { for (size_t i = 0; i < NSEG; i++) delete[] tab_[i].load(); }
-    bool put(uint64_t r0, uint64_t n, const T *src)
-    {
-        if (!n) return true;
-        if ((r0 + n - 1) / SEG >= NSEG) return false;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            for (uint64_t g = r0 / SEG; g <= (r0 + n - 1) / SEG; g++) if (!tab_[g].load()) { T *q = new (std::nothrow) T[SEG]; if (!q) return false; tab_[g] = q; }
-        }
-        for (uint64_t i = 0; i < n;) { const uint64_t g = (r0 + i) / SEG, o = (r0 + i) % SEG, c = std::min<uint64_t>(n - i, SEG - o); memcpy(tab_[g].load() + o, src + i, c * sizeof(T)); i += c; }
-        return true;
-    }
-    void get(uint64_t r0, uint64_t n, T *dst) const          // (of records that have been put)
-    {
-        for (uint64_t i = 0; i < n;) { const uint64_t g = (r0 + i) / SEG, o = (r0 + i) % SEG, c = std::min<uint64_t>(n - i, SEG - o); memcpy(dst + i, tab_[g].load() + o, c * sizeof(T)); i += c; }
-    }
-private:
-    static constexpr uint64_t SEG = (uint64_t)1 << 20; static constexpr size_t NSEG = (size_t)1 << 16;
-    std::unique_ptr<std::atomic<T *>[]> tab_; std::mutex mu_;
-};
-
-// pinned buffers that the text of the kept records passes through on its way from the device to an output file: a consumer takes one,
-// copies a chunk of a piece's output down into it and hands it to the file's writer, which gives it back
-class OutChunks {
-public:
-    // (made one after the other by a thread of its own while the call is being set up and the first pieces are on their way: pinning memory
-    // takes its time -- more of it while streams and device buffers are being made -- and the first chunk is wanted long before the last)
-    void init(size_t chunk, int n)
-    {
-        chunk_ = chunk;
-        maker_ = std::thread([this, n] {
-            for (int i = 0; i < n; i++) {
-                { std::lock_guard<std::mutex> lk(mu_); if (abort_) break; }
-                void *q = nullptr;
-                const hipError_t e = hipHostMalloc(&q, chunk_, hipHostMallocPortable);
-                { std::lock_guard<std::mutex> lk(mu_); if (e != hipSuccess) { if (all_.empty()) err_ = e; done_ = true; } else { all_.push_back((uint8_t *)q); free_.push_back((uint8_t *)q); } }
-                cv_.notify_all();
-                if (e != hipSuccess) return;
-            }
-            { std::lock_guard<std::mutex> lk(mu_); done_ = true; }
-            cv_.notify_all();
-        });
-    }
-    size_t chunk() const { return chunk_; }
-    uint8_t *take(hipError_t *e)          // nullptr: not one chunk could be allocated (*e), or the run is being abandoned
-    {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return abort_ || !free_.empty() || (done_ && all_.empty()); });
-        *e = err_;
-        if (abort_ || free_.empty()) return nullptr;
-        uint8_t *p = free_.back(); free_.pop_back();
-        return p;
-    }
-    void give(uint8_t *p) { { std::lock_guard<std::mutex> lk(mu_); free_.push_back(p); } cv_.notify_one(); }
-    void abort() { { std::lock_guard<std::mutex> lk(mu_); abort_ = true; } cv_.notify_all(); }
-    ~OutChunks() { abort(); if (maker_.joinable()) maker_.join(); for (uint8_t *p : all_) (void)hipHostFree(p); }
-private:
-    std::mutex mu_; std::condition_variable cv_; std::vector<uint8_t *> free_, all_; size_t chunk_ = 0;
-    std::thread maker_; bool done_ = false, abort_ = false; hipError_t err_ = hipSuccess;
-};
-
-// An output file of the quality filter.  Nearly every record is written, so what goes out is as large as the text that came in, and
-// writing it is what the job waits for: a thread per file does nothing else (a second one would queue behind the first on the
-// inode's lock).  The consumers hand it chunks with their places in the file; a regular file takes them as they come (pwrite),
-// anything else -- standard output, a pipe, a .gz (compressed by OutFile as the reference's GzEncoder would) -- in order.
-class QSink {
-public:
-    bool open(const char *path, OutChunks *pool)
-    {
-        pool_ = pool;
-        bool ok = false;
-        if (path && !has_gz_ext(path)) {
-            fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-            if (fd_ < 0) return false;
-            struct stat sb;
-            if (fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) { direct_ = true; ok = true; }
-            else { ::close(fd_); fd_ = -1; }
-        }
-        if (!ok) ok = of_.open(path);
-        if (ok) th_ = std::thread([this] { run(); });
-        return ok;
-    }
-    void push(uint64_t off, uint8_t *p, size_t n)          // p: a chunk of the pool, given back when written
-    {
-        { std::lock_guard<std::mutex> lk(mu_); q_.emplace(off, Item{p, n}); }
-        cv_.notify_one();
-    }
-    bool ok() { std::lock_guard<std::mutex> lk(mu_); return ok_; }
-    void abort() { { std::lock_guard<std::mutex> lk(mu_); abort_ = true; } cv_.notify_all(); }
-    double busy() const { return busy_; }
-    bool close()          // everything pushed is written (in order: up to the first gap) unless aborted
-    {
-        if (th_.joinable()) { { std::lock_guard<std::mutex> lk(mu_); fin_ = true; } cv_.notify_all(); th_.join(); }
-        if (direct_) { const bool c = fd_ < 0 || ::close(fd_) == 0; fd_ = -1; return c && ok_; }
-        return of_.close() && ok_;
-    }
-    ~QSink() { if (th_.joinable()) { abort(); { std::lock_guard<std::mutex> lk(mu_); fin_ = true; } cv_.notify_all(); th_.join(); } if (fd_ >= 0) ::close(fd_); }
-private:
-    struct Item { uint8_t *p; size_t n; };
-    void run()
-    {
-        for (;;) {
-            uint64_t off = 0; Item it{nullptr, 0}; bool drop = false;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return abort_ || fin_ || (!q_.empty() && (direct_ || q_.begin()->first == next_)); });
-                if (q_.empty()) { if (fin_ || abort_) return; continue; }
-                if (!direct_ && !abort_ && q_.begin()->first != next_) { if (fin_) abort_ = true; else continue; }      // (closed with a gap: a failed run)
-                off = q_.begin()->first; it = q_.begin()->second; q_.erase(q_.begin());
-                drop = abort_ || !ok_;
-            }
-            if (!drop) {
-                const double t0 = now_s();
-                bool w = true;
-                if (direct_) {
-                    const uint8_t *p = it.p; size_t n = it.n; uint64_t o = off;
-                    while (n) {
-                        const ssize_t k = pwrite(fd_, p, n, (off_t)o);
-                        if (k < 0) { if (errno == EINTR) continue; w = false; break; }
-                        p += k; n -= (size_t)k; o += (uint64_t)k;
-                    }
-                } else w = of_.write((const char *)it.p, it.n);
-                busy_ += now_s() - t0;
-                std::lock_guard<std::mutex> lk(mu_);
-                if (!w) ok_ = false;
-                next_ = off + it.n;
-            }
-            pool_->give(it.p);
-        }
-    }
-    int fd_ = -1; bool direct_ = false; OutFile of_; OutChunks *pool_ = nullptr;
-    std::thread th_; std::mutex mu_; std::condition_variable cv_; std::map<uint64_t, Item> q_;
-    uint64_t next_ = 0; bool ok_ = true, abort_ = false, fin_ = false; double busy_ = 0;
-};
-
 struct QualState {
     QualParams P; bool pe = false; uint64_t cap = ~0ull;          // cap: the longest a cut string gets (end - start), ~0: no end
     SegArray<uint32_t> bad2; SegArray<uint8_t> fl2, keep;         // mate 2's scan results, mate 1's decisions: per record of the file, on the host
@@ -1853,13 +1722,14 @@ struct Ingest {
         B.reset();
         const size_t chunk = Q.chunks.chunk();
         double tw = 0;
+        { const double w0 = now_s(); if (!Q.sink[mi].wait_turn(part.out_at)) { err = "abandoned"; return MF_E_IO; } tw += now_s() - w0; }      // (standard output, a pipe, a .gz: the parts' chunks are taken in file order)
         for (uint64_t off = 0; off < bytes; off += chunk) {
             const uint64_t len = std::min<uint64_t>(chunk, bytes - off);
             const double w0 = now_s();
-            hipError_t e = hipSuccess;
-            uint8_t *p = Q.chunks.take(&e);
+            bool no_mem = false;
+            uint8_t *p = Q.chunks.take(&no_mem);
             tw += now_s() - w0;
-            if (!p) { if (e != hipSuccess) { err = std::string("hipHostMalloc failed: ") + hipGetErrorString(e); return MF_E_NOMEM; } err = "abandoned"; return MF_E_IO; }
+            if (!p) { if (no_mem) { err = "hipHostMalloc failed: no pinned memory for the output's chunks"; return MF_E_NOMEM; } err = "abandoned"; return MF_E_IO; }
             hipError_t c = hipMemcpyAsync(p, S.d_out.p + off, len, hipMemcpyDeviceToHost, sp);
             if (c == hipSuccess) c = hipStreamSynchronize(sp);
             if (c != hipSuccess) { Q.chunks.give(p); err = std::string("copy of the output failed: ") + hipGetErrorString(c); return MF_E_HIP; }
@@ -2192,7 +2062,8 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
     if (out2 && has_gz_ext(out2) && env_u64("MF_QUAL_DEVICE_GZ_OUT", 0) == 0) return MF_DEVINGEST_DECLINED;
     QualState Q;                      // (before the Ingest: its batches hold buffers the state does not own, but the set's go back to the pool last)
     Q.P = P; Q.pe = fq2 != nullptr; Q.cap = P.end ? P.end - P.start : ~0ull;
-    Q.chunks.init((size_t)std::max<uint64_t>(env_u64("MF_QUAL_OUT_CHUNK", (uint64_t)4 << 20), 4096), (int)std::max<uint64_t>(2, env_u64("MF_QUAL_OUT_CHUNKS", 24)));
+    Q.chunks.init((size_t)std::max<uint64_t>(env_u64("MF_QUAL_OUT_CHUNK", (uint64_t)4 << 20), 4096), (int)std::max<uint64_t>(2, env_u64("MF_QUAL_OUT_CHUNKS", 24)),
+                  [](size_t n) -> void * { void *q = nullptr; return hipHostMalloc(&q, n, hipHostMallocPortable) == hipSuccess ? q : nullptr; }, [](void *q) { (void)hipHostFree(q); });
     Ingest I;
     I.qual = &Q;
     I.devices.push_back(device);

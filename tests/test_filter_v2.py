@@ -187,6 +187,27 @@ def test_cli_bulk_md5(cli, tmp_path, case, ingest, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ingest", ["device", "device-seams"])
+def test_cli_bulk_second_output_to_stdout(cli, tmp_path, ingest, monkeypatch):
+    """Without -4 the second mate's records go to standard output (helper.rs:46-49): a sink that takes its chunks in order -- from
+    consumers that finish their pieces in any order, through a pool of two chunks."""
+    _set_ingest(monkeypatch, ingest)
+    monkeypatch.setenv("MF_QUAL_OUT_CHUNKS", "2")
+    monkeypatch.setenv("MF_QUAL_OUT_CHUNK", "4096" if ingest == "device-seams" else "65536")
+    if ingest == "device-seams":
+        monkeypatch.setenv("MF_INGEST_SLAB_BYTES", "7001")
+    case = [c for c in GOLD["bulk"] if c["name"] == "bulk_pe_dedup_q"][0]
+    mk = _mk()
+    s1, s2, q1, q2 = mk.rand_pair(case["n"], case["seed"], L=case["L"])
+    t1, t2 = mk.fq(s1, q1, "a"), mk.fq(s2, q2, "b")
+    argv = [a for a in case["argv"] if a not in ("-4", "{out2}")]
+    rc, so, outs = _run_cli(cli, str(tmp_path), t1, t2, argv)
+    assert rc == case["rc"]
+    assert hashlib.md5(outs[0]).hexdigest() == case["out1_md5"]
+    assert hashlib.md5(so).hexdigest() == case["out2_md5"]
+
+
+@pytest.mark.gpu
 def test_device_path_is_the_one_that_ran(cli, tmp_path):
     """A .gz pair through the CLI: the timing line of the device path's quality filter must appear (and not the host pipeline's)."""
     mk = _mk()
