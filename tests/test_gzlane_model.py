@@ -1,0 +1,46 @@
+"""The lane-parallel block decode of the device DEFLATE decoder without a GPU: tools/gzlane_model.cpp runs the SAME per-lane walk the
+kernel runs (mitoflex_amd/csrc/mf_gzlane.h, compiled for the host: table entry formats, the pairing of literals, the rule for where a
+span ends) over 64 emulated lanes with the kernel's protocol -- guessed starts, re-walks until every lane starts where its predecessor
+ended, the confirmed prefix -- and compares the expansion with zlib's output byte for byte.  Streams of every kind a compressor writes:
+levels 1 / 6 / 9, fixed Huffman codes, Huffman only (no matches), RLE (distance 1 only), binned qualities, long reads."""
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gzlane") / "gzlane_model")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "gzlane_model.cpp"), "-lz", "-o", exe])
+    return exe
+
+
+def fastq(n, L, quals, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        ln = L if isinstance(L, int) else rng.randint(*L)
+        out.append("@r.%d lane:%d\n%s\n+\n%s\n" % (i, i % 8, "".join(rng.choice("ACGT") for _ in range(ln)), "".join(rng.choice(quals) for _ in range(ln))))
+    return "".join(out).encode()
+
+
+STREAMS = {"level1": (1, zlib.Z_DEFAULT_STRATEGY), "level6": (6, zlib.Z_DEFAULT_STRATEGY), "level9": (9, zlib.Z_DEFAULT_STRATEGY),
+           "fixed": (6, zlib.Z_FIXED), "huffman_only": (6, zlib.Z_HUFFMAN_ONLY), "rle": (6, zlib.Z_RLE), "filtered": (6, zlib.Z_FILTERED)}
+
+
+@pytest.mark.parametrize("kind", sorted(STREAMS))
+@pytest.mark.parametrize("text", ["short_reads", "binned_long_reads"])
+def test_lane_walk_equals_zlib(model, tmp_path, kind, text):
+    t = fastq(6000, 100, "#,:FI58<AEJ", 3) if text == "short_reads" else fastq(300, (2000, 9000), "F:,#", 4)
+    level, strategy = STREAMS[kind]
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
+    path = str(tmp_path / "t.gz")
+    open(path, "wb").write(c.compress(t) + c.flush())
+    for span_bits in ("1024", "2048", "256"):
+        p = subprocess.run([model, path, span_bits], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout.decode().strip().endswith("PASS"), (kind, text, span_bits, p.stdout[-600:], p.stderr[-600:])
