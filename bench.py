@@ -278,6 +278,7 @@ def prepare_inputs(a, tmp, solo=True):
                 files["full"] = os.path.join(tmp, "f")
                 files["full_prep_seconds"] = {"generate": round(t1 - t0, 1), "compress": round(time.time() - t1, 1)}
         if a.fv2_pairs > 0 and solo:
+          try:          # (a leg of its own: whatever goes wrong here costs the line this leg, not the file-level legs below)
             # the quality filter's drop-in CLI, process start to exit, on a .gz pair: device ingest path (the default) and host pipeline
             run([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(tmp, "q"), "--pairs", str(a.fv2_pairs), "--block", "2000000"])
             for m in ("1", "2"):
@@ -293,10 +294,12 @@ def prepare_inputs(a, tmp, solo=True):
                             os.unlink(q + tag + o)
                     t0 = time.perf_counter()
                     subprocess.check_call([exe, "-1", q + "_1.fq.gz", "-2", q + "_2.fq.gz", "-3", q + tag + "_c1.fq", "-4", q + tag + "_c2.fq", "-d"], env=dict(env, **extra_env),
-                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
                     best = min(best, time.perf_counter() - t0)
                 cli[tag] = best
             files["fv2"] = {"prefix": q, "cli_seconds": cli}
+          except Exception as e:
+            files["fv2_error"] = str(e)[:200]
         if not a.no_group_a and solo:
             run([sys.executable, "-c", G20_GENERATOR, os.path.join(tmp, "g20.fa")])
             files["g20"] = os.path.join(tmp, "g20.fa")
@@ -651,6 +654,8 @@ def main():
                     extra["filter_v2"] = filter_v2_leg(mf, files, a)
                 except Exception as e:
                     extra["filter_v2"] = {"error": str(e)[:200]}
+            elif "fv2_error" in files:
+                extra["filter_v2"] = {"error": files["fv2_error"]}
             if "g20" in files:
                 try:
                     extra["group_a"] = group_a(files)
