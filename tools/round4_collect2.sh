@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 collection, second part: the whole GPU suite, filter_v2 end to end (device ingest against host pipeline, same box), the bench line with its filter_v2 leg
+# round-4 collection, second part (after tools/round4_collect.sh): the whole GPU suite, filter_v2 end to end (device ingest against host pipeline, same box), the bench line with its filter_v2 leg
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r04; mkdir -p $O
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/pytest_gpu_tail.txt
 BIG=4 ./tools/e2e_filter_v2_dev.sh 2>&1 | cut -c1-1100 > $O/f_filter_v2_e2e.log
