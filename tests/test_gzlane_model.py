@@ -1,7 +1,8 @@
 """The lane-parallel block decode of the device DEFLATE decoder without a GPU: tools/gzlane_model.cpp runs the SAME per-lane walk the
 kernel runs (mitoflex_amd/csrc/mf_gzlane.h, compiled for the host: table entry formats, the pairing of literals, the rule for where a
 span ends) over 64 emulated lanes with the kernel's protocol -- guessed starts, re-walks until every lane starts where its predecessor
-ended, the confirmed prefix -- and compares the expansion with zlib's output byte for byte.  Streams of every kind a compressor writes:
+ended, the confirmed prefix -- expands the step's joined list the way the kernel's rounds do (a cell per output position: final symbol,
+reference into the round, reference to earlier output; pointer doubling) and compares with zlib's output byte for byte.  Streams of every kind a compressor writes:
 levels 1 / 6 / 9, fixed Huffman codes, Huffman only (no matches), RLE (distance 1 only), binned qualities, long reads."""
 import os
 import random
@@ -34,13 +35,18 @@ STREAMS = {"level1": (1, zlib.Z_DEFAULT_STRATEGY), "level6": (6, zlib.Z_DEFAULT_
 
 
 @pytest.mark.parametrize("kind", sorted(STREAMS))
-@pytest.mark.parametrize("text", ["short_reads", "binned_long_reads"])
+@pytest.mark.parametrize("text", ["short_reads", "binned_long_reads", "runs_of_identical_reads"])
 def test_lane_walk_equals_zlib(model, tmp_path, kind, text):
-    t = fastq(6000, 100, "#,:FI58<AEJ", 3) if text == "short_reads" else fastq(300, (2000, 9000), "F:,#", 4)
+    if text == "short_reads":
+        t = fastq(6000, 100, "#,:FI58<AEJ", 3)
+    elif text == "binned_long_reads":
+        t = fastq(300, (2000, 9000), "F:,#", 4)
+    else:          # matches longer than their distance, period after period: symbol t of a match is position first + t, no modulo
+        t = b"".join(fastq(1, 150, "F", 50 + i) * 400 + b"A" * 3000 + b"\n" for i in range(12))
     level, strategy = STREAMS[kind]
     c = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
     path = str(tmp_path / "t.gz")
     open(path, "wb").write(c.compress(t) + c.flush())
-    for span_bits in ("1024", "2048", "256"):
-        p = subprocess.run([model, path, span_bits], capture_output=True, timeout=300)
-        assert p.returncode == 0 and p.stdout.decode().strip().endswith("PASS"), (kind, text, span_bits, p.stdout[-600:], p.stderr[-600:])
+    for span_bits, cells in (("1024", "1"), ("1024", "0"), ("2048", "1"), ("256", "1")):          # cells = 1: the kernel's expansion rounds restated, 0: a plain LZ77 copy
+        p = subprocess.run([model, path, span_bits, "6", cells], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout.decode().strip().endswith("PASS"), (kind, text, span_bits, cells, p.stdout[-600:], p.stderr[-600:])

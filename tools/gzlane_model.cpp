@@ -1,9 +1,13 @@
 // CPU model of the lane-parallel block decoder of mitoflex_amd/csrc/mf_gzdev.hip: the SAME per-lane walk (mf_gzlane.h) run over 64
 // emulated lanes with the kernel's protocol -- nominal starts, re-walks until every lane starts where its predecessor ended, the
-// confirmed prefix, lists per lane -- and a plain LZ77 expansion, compared with zlib byte for byte.  Test infrastructure: it
-// validates the scheme (and prints how many walks a step takes) where there is no GPU.
-//   g++ -O2 -std=c++17 tools/gzlane_model.cpp -lz -o /tmp/gzlane_model && /tmp/gzlane_model file.gz [span_bits=2048] [max_iter=6]
+// confirmed prefix, lists per lane -- and the expansion of the step's joined list, compared with zlib byte for byte: either a plain LZ77
+// copy (cells = 0) or the kernel's rounds (cells = 1, expand4 of mf_gzdev.hip restated: 256 entries and at most 2 048 symbols a round,
+// a 32-bit cell per output position -- a final symbol, a reference to a cell of the round, a reference to earlier output --, symbol t of
+// a match at position first + t whatever the period, the references into the round followed by pointer doubling).  Test infrastructure:
+// it validates the scheme (and prints how many walks a step takes) where there is no GPU.
+//   g++ -O2 -std=c++17 tools/gzlane_model.cpp -lz -o /tmp/gzlane_model && /tmp/gzlane_model file.gz [span_bits=2048] [max_iter=6] [cells=0]
 #include "../mitoflex_amd/csrc/mf_gzlane.h"
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -74,6 +78,8 @@ int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: %s file.gz [span_bits] [max_iter]\n", argv[0]); return 2; }
     const uint32_t S = argc > 2 ? (uint32_t)atoi(argv[2]) : 2048, MAXIT = argc > 3 ? (uint32_t)atoi(argv[3]) : 6, LCAP = 1024;
+    const bool cells = argc > 4 && atoi(argv[4]) != 0;
+    uint64_t n_rounds = 0, n_passes = 0;
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END); const size_t size = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
@@ -105,7 +111,7 @@ int main(int argc, char **argv)
     static const uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     std::vector<uint8_t> out; out.reserve(ref.size());
     Bits br{gz.data(), size, (uint64_t)p * 8};
-    In in{gz.data(), size};
+    In in{gz.data(), size}; (void)in;
     Tables *T = new Tables();
     uint64_t n_steps = 0, n_walks = 0, n_blocks = 0, lanes_used = 0, iter_hist[16] = {0}, codes = 0, unconverged = 0;
     for (;;) {
@@ -163,7 +169,50 @@ int main(int argc, char **argv)
                 while (V < 64 && !(sp[V - 1].flags & (SP_EOB | SP_ERR)) && s[V] == sp[V - 1].end) V++;
                 if (it == MAXIT) unconverged++;
                 lanes_used += (uint64_t)V;
-                for (int i = 0; i < V; i++) {
+                if (cells) {
+                    // the kernel's way: the confirmed lanes' lists joined, taken RN entries a round
+                    constexpr uint32_t RN = 256, STG2 = RN * 8, C_REF = 1u << 16, C_FAR = 2u << 16;
+                    std::vector<uint32_t> cl; uint64_t want = 0;
+                    for (int i = 0; i < V; i++) {
+                        if (sp[i].flags & SP_ERR) { fprintf(stderr, "decode error in a confirmed lane (step %llu lane %d)\n", (unsigned long long)n_steps, i); return 1; }
+                        cl.insert(cl.end(), lst[i].begin(), lst[i].end()); want += sp[i].n_sym; codes += lst[i].size();
+                    }
+                    const size_t before = out.size();
+                    for (size_t e0 = 0; e0 < cl.size();) {
+                        const size_t n = std::min<size_t>(RN, cl.size() - e0);
+                        // the entries that fit the round's cells (a prefix; at least one: no entry stands for more than 258 symbols)
+                        uint32_t stg[STG2]; uint32_t tot = 0; size_t taken = 0;
+                        const size_t opos = out.size();
+                        for (; taken < n; taken++) {
+                            const uint32_t e = cl[e0 + taken], cnt = (e >> 31) ? (e & 0x1FFu) + 3 : 1 + ((e >> 24) & 1u);
+                            if (tot + cnt > STG2) break;
+                            const uint32_t o = tot;
+                            if (!(e >> 31)) { stg[o] = (e >> 8) & 0xFFu; if (cnt == 2) stg[o + 1] = (e >> 16) & 0xFFu; }
+                            else {
+                                const int32_t first = (int32_t)o - (int32_t)(((e >> 9) & 0x7FFFu) + 1);
+                                for (uint32_t t = 0; t < cnt; t++) { const int32_t srel = first + (int32_t)t; stg[o + t] = srel >= 0 ? (C_REF | (uint32_t)srel) : (C_FAR | (uint32_t)(-srel - 1)); }
+                            }
+                            tot += cnt;
+                        }
+                        if (!taken) { fprintf(stderr, "a round without an entry\n"); return 1; }
+                        for (uint32_t p = 0; p < tot; p++)          // earlier output, by position
+                            if ((stg[p] >> 16) == 2u) {
+                                const int64_t g = (int64_t)opos - 1 - (int64_t)(stg[p] & 0xFFFFu);
+                                if (g < 0) { fprintf(stderr, "distance too far\n"); return 1; }
+                                stg[p] = out[(size_t)g];
+                            }
+                        for (bool pending = true; pending;) {          // references into the round: strictly backwards, halved by every pass
+                            pending = false; n_passes++;
+                            uint32_t nx[STG2];
+                            for (uint32_t p = 0; p < tot; p++) { const uint32_t v = stg[p]; nx[p] = v; if (v >> 16) { nx[p] = stg[v & 0xFFFFu]; if (nx[p] >> 16) pending = true; } }
+                            memcpy(stg, nx, tot * 4);              // (all lanes of a pass read the cells as the pass found them -- or as a neighbour has already left them: either way the chain shrinks)
+                        }
+                        for (uint32_t p = 0; p < tot; p++) out.push_back((uint8_t)stg[p]);
+                        e0 += taken; n_rounds++;
+                    }
+                    if (out.size() - before != want) { fprintf(stderr, "symbol count mismatch\n"); return 1; }
+                }
+                else for (int i = 0; i < V; i++) {
                     if (sp[i].flags & SP_ERR) { fprintf(stderr, "decode error in a confirmed lane (step %llu lane %d)\n", (unsigned long long)n_steps, i); return 1; }
                     if (lst[i].size() != sp[i].n_code) { fprintf(stderr, "list size mismatch\n"); return 1; }
                     size_t before = out.size();
@@ -185,6 +234,7 @@ int main(int argc, char **argv)
     printf("%s: %zu -> %zu bytes, %llu blocks, %llu steps of 64 x %u bits, %.2f walks per lane and step, %.1f of 64 lanes confirmed per step, %llu codes, %llu steps not converged in %u rounds\n",
            argv[1], size, ref.size(), (unsigned long long)n_blocks, (unsigned long long)n_steps, S, (double)n_walks / (64.0 * n_steps), (double)lanes_used / n_steps,
            (unsigned long long)codes, (unsigned long long)unconverged, MAXIT);
+    if (cells) printf("expansion: %llu rounds, %.2f pointer-doubling passes a round\n", (unsigned long long)n_rounds, n_rounds ? (double)n_passes / n_rounds : 0.0);
     printf("re-walk rounds per step:"); for (int i = 0; i < 16; i++) if (iter_hist[i]) printf(" %d:%llu", i, (unsigned long long)iter_hist[i]); printf("\n");
     printf(ok ? "PASS\n" : "FAIL\n");
     return ok ? 0 : 1;
