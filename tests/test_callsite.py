@@ -129,7 +129,7 @@ def test_build_lib_fifo_cleans_up_when_buildlib_fails(tmp_path, monkeypatch):
                     "echo $$ > $(dirname $x)/filter.pid\ncat $a > $x; echo 1\n")     # blocks opening the pipe: nobody reads it
     stub.chmod(0o755)
     bad_core = tmp_path / "megahit_core"
-    bad_core.write_text("#!/bin/bash\nsleep 0.5\nexit 3\n")       # (the filter is up and blocked on its pipe by then)
+    bad_core.write_text("#!/bin/bash\nfor i in $(seq 200); do [ -s %s/t/filter.pid ] && break; sleep 0.05; done\nsleep 0.2\nexit 3\n" % tmp_path)       # (dies once the filter is up and blocked on its pipe)
     bad_core.chmod(0o755)
     (tmp_path / "a_1.fq").write_text("@r\nACGT\n+\nIIII\n")
     monkeypatch.setattr(w.MEGAHIT, "FAST_FILTER", property(lambda self: str(stub)))
