@@ -53,13 +53,40 @@ def test_wrapper_command_strings(c, tmp_path, monkeypatch):
     from mitoflex_amd.filter import filter as w
     from mitoflex_amd.utility import helper
     calls = []
-    monkeypatch.setattr(helper, "direct_call", lambda cmd: calls.append(cmd) or "")
     d = str(tmp_path)
+    for f in ("a.fq", "b.fq"):
+        open(os.path.join(d, f), "w").write("@r\nACGT\n+\nIIII\n")
+
+    def fake(cmd):
+        calls.append(cmd)
+        open(os.path.join(d, "o1.fq"), "w").close()          # (the call site sizes its first output afterwards)
+        return ""
+    monkeypatch.setattr(helper, "direct_call", fake)
     if c["kind"] == "se":
         w.filter_se(fqiabs=f"{d}/a.fq", fqoabs=f"{d}/o1.fq", **c["kwargs"])
     else:
         w.filter_pe(fq1=f"{d}/a.fq", fq2=f"{d}/b.fq", o1=f"{d}/o1.fq", o2=f"{d}/o2.fq", **c["kwargs"])
     assert calls[0].replace(d, "{dir}").replace(os.path.dirname(os.path.abspath(w.__file__)), "{bin}") == c["command"]
+
+
+def test_wrapper_errors_are_the_call_sites(tmp_path, monkeypatch):
+    """What the reference's call site does when things go wrong (filter/filter.py:39, 51, 62, 84): a missing input is the
+    FileNotFoundError of its `path.getsize`, a failing command ends the process with its message."""
+    from mitoflex_amd.filter import filter as w
+    from mitoflex_amd.utility import helper
+    d = str(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        w.filter_se(fqiabs=f"{d}/nothing.fq", fqoabs=f"{d}/o1.fq")
+    open(f"{d}/a.fq", "w").write("@r\nACGT\n+\nIIII\n")
+    with pytest.raises(FileNotFoundError):
+        w.filter_pe(fq1=f"{d}/a.fq", fq2=f"{d}/nothing.fq", o1=f"{d}/o1.fq", o2=f"{d}/o2.fq")
+
+    def boom(cmd):
+        raise RuntimeError("exit status 101")
+    monkeypatch.setattr(helper, "direct_call", boom)
+    with pytest.raises(SystemExit) as e:
+        w.filter_se(fqiabs=f"{d}/a.fq", fqoabs=f"{d}/o1.fq")
+    assert str(e.value) == "Error occured when running filter!"
 
 
 # ------------------------------------------------------------------------------------------- GPU
