@@ -355,7 +355,10 @@ def e2e_files(mf, ks, files, a):
             "roofline": {"bound": "pcie_h2d", "achieved": gz_bytes / secs / 1e9, "peak": h2d, "unit": "GB/s", "frac": (gz_bytes / secs / 1e9 / h2d) if h2d else None,
                          "note": "compressed input bytes / seconds of the whole call (file in the page cache -> survivors written)"},
             "inflate_kernels": {"busy_seconds": ist["decode_busy_seconds"], "text_GB_per_s": (ist["text_bytes"] / ist["decode_busy_seconds"] / 1e9) if ist["decode_busy_seconds"] > 0 else None,
-                                "note": "time with at least one gz_decode kernel running (HIP events around every launch), while upload, link step and the consumers' kernels share the device"},
+                                "note": "time with at least one gz_decode kernel running (HIP events around every launch), while upload, link step and the consumers' kernels share the device",
+                                "bound": "instruction issue and latency of divergent lane code, not memory: 6.6 wave-instructions per byte of text (VALU 3.5, scalar 2.7, LDS 0.26), wavefronts on "
+                                         "s_waitcnt 56 % of their cycles, ~2.7 B of HBM traffic per byte of text (profiles/r04/c_gzdev_pmc.txt); alone with the chip full the kernel does "
+                                         "73.9 GB/s of text (profiles/r04/h_gzdev_check_kernel_stats.csv) = 2.6e11 VALU wave-instructions/s of the chip's 6.1e11"},
             "ingest_path": "device" if ist["path"] == 1 else "host", "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9, "call_buffers_peak_GB": ist["pool_bytes_peak"] / 1e9,
             "chunks": ist["chunks"], "chunks_linked": ist["chunks_linked"], "gaps_bridged_on_host": ist["gaps"],
             "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), "kept": int(res[0]), "total": int(res[1]),
