@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 3
+#define MF_ABI_VERSION 4
 
 enum {
     MF_OK = 0,
@@ -232,6 +232,12 @@ typedef struct {
     uint64_t chunks, chunks_linked, gaps, gap_bytes;   /* speculative chunks; those the link step took; stretches (bytes of text) the host bridged */
 } mf_ingest_stats_t;
 int mf_last_ingest_stats(mf_ingest_stats_t *out);
+
+/* The device ingest path keeps device buffers, pinned staging buffers and the consumers' read sets of a call for the process's next
+ * call (allocating them anew costs a call a tenth of a second and more).  mf_release_cached() gives all of it back to the runtime;
+ * *bytes (may be NULL) receives the device bytes released.  Call it between calls, not during one.  The library calls the same code by
+ * itself whenever one of its own allocations finds a device full.  ABI 4. */
+int mf_release_cached(uint64_t *bytes);
 
 /* Host-to-device copy rate of this box in GB/s (pinned memory, `bytes` per copy, best of `reps`): the
  * roof of the device ingest path, whose input goes up over PCIe as it lies on disk. */

@@ -114,7 +114,7 @@ struct mf_kmerset {
 // device temporaries of one build: released on every exit path
 struct DevScratch {
     std::vector<void *> bufs;
-    template <class T> hipError_t alloc(T *&p, size_t bytes) { hipError_t e = hipMalloc(&p, bytes); if (e == hipSuccess) bufs.push_back(p); return e; }
+    template <class T> hipError_t alloc(T *&p, size_t bytes) { hipError_t e = dev_malloc(&p, bytes); if (e == hipSuccess) bufs.push_back(p); return e; }
     ~DevScratch() { for (void *p : bufs) hipFree(p); }
 };
 // tables under construction: released unless the build commits them
@@ -158,13 +158,13 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
         HIPCHK(tmp.alloc(d_aa, P.aa.size())); HIPCHK(tmp.alloc(d_run, P.runlen.size()));
         HIPCHK(hipMemcpyAsync(d_aa, P.aa.data(), P.aa.size(), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_run, P.runlen.data(), P.runlen.size(), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMalloc(&T.keys, ks->slots * sizeof(uint64_t)));
+        HIPCHK(dev_malloc(&T.keys, ks->slots * sizeof(uint64_t)));
         HIPCHK(hipMemsetAsync(T.keys, 0xFF, ks->slots * sizeof(uint64_t), st));
         HIPCHK(launch_build_ptable(d_aa, d_run, P.total, ks->k, T.keys, ks->slots, st));
-        HIPCHK(hipMalloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
+        HIPCHK(dev_malloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
         HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
         HIPCHK(launch_build_pbits(T.keys, ks->slots, T.kbloom, ks->kb_log2w, st));
-        HIPCHK(hipMalloc(&T.plut, sizeof ks->codon_lut));
+        HIPCHK(dev_malloc(&T.plut, sizeof ks->codon_lut));
         HIPCHK(hipMemcpyAsync(T.plut, ks->codon_lut, sizeof ks->codon_lut, hipMemcpyHostToDevice, st));
         HIPCHK(tmp.alloc(d_cnt, 16)); HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
         HIPCHK(launch_count_keys(T.keys, ks->slots, 1, nullptr, 0, d_cnt, st));
@@ -189,7 +189,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     HIPCHK(hipMemcpyAsync(d_words, B.words.data(), B.words.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_run, B.runlen.data(), B.runlen.size(), hipMemcpyHostToDevice, st));
     const size_t key_bytes = ks->slots * ks->kw * sizeof(uint64_t);
-    HIPCHK(hipMalloc(&T.keys, key_bytes));
+    HIPCHK(dev_malloc(&T.keys, key_bytes));
     HIPCHK(hipMemsetAsync(T.keys, 0xFF, key_bytes, st));
     if (ks->kw == 2) {
         if (B.total > 0xFFFFFFF0ull) return fail(MF_E_ARG, "bait longer than 2^32 bases is not supported for k > 32");
@@ -201,17 +201,17 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     BaitView bv{d_words, B.total, d_run};
     HIPCHK(launch_build_table(bv, ks->k, ks->kw, T.keys, ks->slots, d_pos, st));
     if (ks->geom.s) {
-        HIPCHK(hipMalloc(&T.bloom, ks->screen_words() * 4));
+        HIPCHK(dev_malloc(&T.bloom, ks->screen_words() * 4));
         HIPCHK(hipMemsetAsync(T.bloom, 0, ks->screen_words() * 4, st));
-        HIPCHK(hipMalloc(&T.stab, (size_t)ks->stab_slots * 4));
+        HIPCHK(dev_malloc(&T.stab, (size_t)ks->stab_slots * 4));
         HIPCHK(hipMemsetAsync(T.stab, 0xFF, (size_t)ks->stab_slots * 4, st));
         HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag, st));
     }
-    HIPCHK(hipMalloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
+    HIPCHK(dev_malloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
     HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
     HIPCHK(launch_build_kbloom(T.keys, ks->slots, ks->kw, T.kbloom, ks->kb_log2w, st));
     if (ks->kb_log2w > KB_CO_LOG2W) {        // the folded table of the co-resident exact kernel (pipelined passes)
-        HIPCHK(hipMalloc(&T.kbloom_co, sizeof(uint32_t) << KB_CO_LOG2W));
+        HIPCHK(dev_malloc(&T.kbloom_co, sizeof(uint32_t) << KB_CO_LOG2W));
         HIPCHK(hipMemsetAsync(T.kbloom_co, 0, sizeof(uint32_t) << KB_CO_LOG2W, st));
         HIPCHK(launch_build_kbloom(T.keys, ks->slots, ks->kw, T.kbloom_co, KB_CO_LOG2W, st));
     }
@@ -1025,6 +1025,13 @@ int mf_last_ingest_stats(mf_ingest_stats_t *out)
     return MF_OK;
 }
 
+int mf_release_cached(uint64_t *bytes)
+{
+    const size_t n = mf::release_cached_device_memory(true);
+    if (bytes) *bytes = n;
+    return MF_OK;
+}
+
 // host-to-device copy rate of this box: `bytes` from pinned memory to device memory, the best of `reps` (the roof of the device ingest
 // path, which sends the input file's bytes up as they are)
 int mf_h2d_bandwidth(int device, size_t bytes, int reps, double *gb_per_s)
@@ -1035,7 +1042,7 @@ int mf_h2d_bandwidth(int device, size_t bytes, int reps, double *gb_per_s)
     struct Free { void *&h, *&d; hipEvent_t &e0, &e1; ~Free() { if (h) (void)hipHostFree(h); if (d) (void)hipFree(d); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); } } fr{h, d, e0, e1};
     HIPCHK(hipHostMalloc(&h, bytes, hipHostMallocDefault));
     memset(h, 0x5A, bytes);
-    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(dev_malloc(&d, bytes));
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     double best = 0;
     for (int i = 0; i <= reps; i++) {                     // (the first copy is a warm-up)
@@ -1108,7 +1115,7 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
         if (bytes <= s.cap) return hipSuccess;
         if (s.p) hipFree(s.p);
         s.p = nullptr; s.cap = 0;
-        hipError_t e = hipMalloc(&s.p, bytes + bytes / 4 + 4096);
+        hipError_t e = dev_malloc(&s.p, bytes + bytes / 4 + 4096);
         if (e == hipSuccess) s.cap = bytes + bytes / 4 + 4096;
         return e;
     };
@@ -1132,7 +1139,7 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
     // and doubled (rehashed by a kernel) before a batch that could fill it beyond a half.
     struct DedupSet { unsigned long long *keys = nullptr, *first = nullptr, *small = nullptr; uint64_t slots = 0, n_keys = 0, base = 0; } ds;     // small: [0] zero_idx, [1] n_keys
     auto ds_alloc = [&](uint64_t slots, unsigned long long **keys, unsigned long long **first, std::string &err) -> int {
-        QCHK(hipMalloc((void **)keys, slots * 8)); QCHK(hipMalloc((void **)first, slots * 8));
+        QCHK(dev_malloc((void **)keys, slots * 8)); QCHK(dev_malloc((void **)first, slots * 8));
         QCHK(hipMemsetAsync(*keys, 0, slots * 8, st)); QCHK(hipMemsetAsync(*first, 0xFF, slots * 8, st));
         return MF_OK;
     };
@@ -1143,7 +1150,7 @@ int mf_qualfilter_files(const char *fq1, const char *fq2, const char *out1, cons
             if (lg < 4) lg = 4; if (lg > 34) lg = 34;
             ds.slots = (uint64_t)1 << lg;
             const int rc2 = ds_alloc(ds.slots, &ds.keys, &ds.first, err); if (rc2) return rc2;
-            QCHK(hipMalloc((void **)&ds.small, 16));
+            QCHK(dev_malloc((void **)&ds.small, 16));
             QCHK(hipMemsetAsync(ds.small, 0xFF, 8, st)); QCHK(hipMemsetAsync(ds.small + 1, 0, 8, st));
         }
         while (2 * (ds.n_keys + n) > ds.slots) {          // (every record of the batch may be a new key)

@@ -15,13 +15,30 @@ const std::string &mf_thread_error();
 int phys(int device);                                   // logical -> physical device (MF_FAKE_DEVICES)
 int get_ctx(int device, DevCtx **out, int lane = 0);
 
+// The device ingest path keeps device buffers of earlier calls in a pool per device (mf_devingest.cpp).  Memory that sits there idle must
+// never make another allocation of this library fail: release_cached_device_memory() gives the current device's idle pool buffers (and, with
+// all = true, every cache of every device: pool, consumers' scratch and read sets, pinned staging) back to the runtime; dev_malloc() is
+// hipMalloc that calls it and tries once more when the device is full.  Returns the bytes released.
+namespace mf { size_t release_cached_device_memory(bool all); }
+inline hipError_t dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        if (mf::release_cached_device_memory(false)) e = hipMalloc(p, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    return e;
+}
+template <class T> inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc(reinterpret_cast<void **>(p), bytes); }
+
 // grow a device buffer to at least `bytes` (with some slack when it is being re-used)
 template <class T> inline hipError_t dev_reserve(T *&p, size_t &cap, size_t bytes, bool slack)
 {
     if (bytes <= cap && p) return hipSuccess;
     if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
     const size_t want = slack ? bytes + bytes / 4 + 4096 : (bytes ? bytes : 16);
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = dev_malloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
 }

@@ -68,7 +68,9 @@ size_t pow2_ceil(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 // while a file is being processed: buffers go back to the pool and are handed out again (a slab's symbol and text buffers have
 // the size of the slab before).  And allocating (and later releasing) gigabytes costs a large fraction of a second, which a caller
 // that filters file after file (the bim loop) would pay every time: a call's buffers are kept for the next one, up to
-// MF_DEVPOOL_GB (default 16; MF_KEEP_BUFFERS=0: nothing is kept).  get() wants the caller's current device to be `dev`.
+// MF_DEVPOOL_GB (see run_ingest for the default; MF_KEEP_BUFFERS=0: nothing is kept).  Memory that idles here is given back whenever another
+// allocation of the library finds the device full (release_cached_device_memory, mf_api_internal.h) and by mf_release_cached() of the C ABI.
+// get() wants the caller's current device to be `dev`.
 class DevPool {
 public:
     static size_t round_up(size_t bytes)
@@ -117,6 +119,8 @@ public:
         account(dev, -(long long)bytes);
     }
     size_t held(int dev) { std::lock_guard<std::mutex> lk(mu_); return dev_[dev].held; }          // bytes waiting for the next call
+    size_t release(int dev) { const size_t h = held(dev); trim_dev(dev, 0); return h; }          // the idle buffers of one device back to the runtime; returns their bytes
+    size_t release_all() { size_t h = 0; std::vector<int> devs; { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) { devs.push_back(kv.first); h += kv.second.held; } } for (int d : devs) trim_dev(d, 0); return h; }
     // high-water mark of the bytes in use (handed out and not yet returned) on any one device since reset_peak()
     size_t peak() { std::lock_guard<std::mutex> lk(mu_); size_t m = 0; for (auto &kv : dev_) m = std::max(m, kv.second.peak); return m; }
     void reset_peak() { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) kv.second.peak = kv.second.used; t_malloc_ = 0; n_malloc_ = 0; }
@@ -220,6 +224,7 @@ public:
         if ((kb && kb[0] == '0') || free_.size() >= 8) { size_.erase(p); lk.unlock(); (void)hipHostFree(p); return; }
         free_.emplace(n, p);
     }
+    void clear() { std::vector<uint8_t *> v; { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : free_) { v.push_back(kv.second); size_.erase(kv.second); } free_.clear(); } for (uint8_t *q : v) (void)hipHostFree(q); }
 private:
     std::mutex mu_; std::multimap<size_t, uint8_t *> free_; std::map<uint8_t *, size_t> size_;
 };
@@ -514,7 +519,7 @@ public:
         for (auto &L : lanes_) {                      // nothing of this decoder may be in flight when its buffers go back to the pool
             if (!L.streams) continue;
             (void)hipSetDevice(L.dev);
-            for (auto &s : L.streams->dec->sd) if (s) (void)hipStreamSynchronize(s);
+            for (uint32_t i = 0, n = L.streams->dec->n.load(); i < n; i++) (void)hipStreamSynchronize(L.streams->dec->sd[i]);      // (the maker thread may still be writing the handles behind n)
             (void)hipStreamSynchronize(L.streams->link); (void)hipStreamSynchronize(L.streams->rest); (void)hipStreamSynchronize(L.streams->copy);
             if (L.ev_link) (void)hipEventDestroy(L.ev_link);
             if (L.ev_base) (void)hipEventDestroy(L.ev_base);
@@ -1086,6 +1091,7 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         kept_[std::make_pair(p->ldev, p->lane)] = std::move(p);
     }
+    void clear() { std::map<std::pair<int, int>, std::unique_ptr<DevScratch>> gone; { std::lock_guard<std::mutex> lk(mu_); gone.swap(kept_); } }      // (their device buffers go back to the pool: clear the pool after this)
 private:
     std::mutex mu_; std::map<std::pair<int, int>, std::unique_ptr<DevScratch>> kept_;
 };
@@ -1139,7 +1145,7 @@ struct Ingest {
     QualState *qual = nullptr;          // set: the job is the quality filter (one device), not the bait filter
     Mate m[2]; int nm = 1;
     uint64_t kept = 0, total = 0;
-    bool wrote_any = false;
+    std::atomic<bool> wrote_any{false};          // a byte of the output has been handed to a writer: the call can no longer be given to the host pipeline
     size_t mem_used_max = 0;           // device memory in use (everything on the device, this path's buffers and the rest), the largest seen after a piece
     size_t carry_room = (size_t)1 << 20;
     bool timing = false; double t_wait = 0, t_index = 0, t_pack = 0, t_filter = 0, t_emit = 0;      // summed over the consumer threads
@@ -1553,9 +1559,11 @@ struct Ingest {
             // rare: a byte that is not ASCII in a line the reference unwraps, or a string shorter than the cut's start.  The flagged
             // records are looked at on the host, in order, until one makes the reference panic (a header in UTF-8 does not).
             std::vector<uint8_t> fl(n), text(B.n_text + 1); std::vector<uint64_t> ls(4 * n + 1);
-            DCHK(hipMemcpy(fl.data(), B.q_fl.p, n, hipMemcpyDeviceToHost));
-            DCHK(hipMemcpy(ls.data(), B.line_start.p, (4 * n + 1) * 8, hipMemcpyDeviceToHost));
-            DCHK(hipMemcpy(text.data(), B.text, B.n_text, hipMemcpyDeviceToHost));
+            // (on the consumer's own stream: a copy on the null stream would wait for every decode kernel in flight on the blocking CU-masked streams)
+            DCHK(hipMemcpyAsync(fl.data(), B.q_fl.p, n, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(ls.data(), B.line_start.p, (4 * n + 1) * 8, hipMemcpyDeviceToHost, sp));
+            DCHK(hipMemcpyAsync(text.data(), B.text, B.n_text, hipMemcpyDeviceToHost, sp));
+            DCHK(hipStreamSynchronize(sp));
             auto line = [&](uint64_t k, const char *&p, size_t &len) {
                 const uint64_t a = ls[k], b = std::min<uint64_t>(ls[k + 1], B.n_text + 1);
                 len = (size_t)(b - a - 1); p = (const char *)text.data() + a;
@@ -1733,10 +1741,10 @@ struct Ingest {
             hipError_t c = hipMemcpyAsync(p, S.d_out.p + off, len, hipMemcpyDeviceToHost, sp);
             if (c == hipSuccess) c = hipStreamSynchronize(sp);
             if (c != hipSuccess) { Q.chunks.give(p); err = std::string("copy of the output failed: ") + hipGetErrorString(c); return MF_E_HIP; }
+            wrote_any = true;                   // (before the first byte reaches the sink: a later failure must not hand the call to the host pipeline, which would write them again)
             Q.sink[mi].push(part.out_at + off, p, (size_t)len);
             if (!Q.sink[mi].ok()) { err = std::string("write error on ") + out_name(mi); return MF_E_IO; }
         }
-        wrote_any = true;
         { std::lock_guard<std::mutex> lk(mu); Q.t_gather += now_s() - t0 - tw; Q.t_chunk += tw; }
         return MF_OK;
     }
@@ -2073,6 +2081,14 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
     if (total) *total = I.total;
     if (panicked) *panicked = Q.panicked;
     return MF_OK;
+}
+
+size_t release_cached_device_memory(bool all)
+{
+    if (all) { g_scratch.clear(); g_pinned.clear(); return g_pool.release_all(); }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return g_pool.release(dev);
 }
 
 } // namespace mf

@@ -29,7 +29,7 @@ EXPORTS = (
     "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
     "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_resident_passes", "mf_filter_packed",
-    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_last_ingest_stats", "mf_h2d_bandwidth", "mf_set_option", "mf_qualfilter_files",
+    "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_last_ingest_stats", "mf_h2d_bandwidth", "mf_set_option", "mf_qualfilter_files", "mf_release_cached",
 )
 
 
@@ -115,10 +115,11 @@ def load(path: Optional[str] = None):
     L.mf_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.mf_last_ingest_stats.argtypes = [C.POINTER(IngestStats)]
     L.mf_h2d_bandwidth.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    L.mf_release_cached.argtypes = [u64p]
     L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                       C.c_uint32, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
                                       C.POINTER(C.c_int)]
-    if L.mf_abi_version() != 3:
+    if L.mf_abi_version() != 4:
         raise MitoFilterError("libmitofilter_hip ABI version mismatch")
     _lib = L
     return L
@@ -330,6 +331,14 @@ def last_ingest_stats() -> dict:
     st = IngestStats()
     _chk(load().mf_last_ingest_stats(C.byref(st)))
     return st.as_dict()
+
+
+def release_cached() -> int:
+    """Give the device buffers, pinned staging and read sets the file-level calls keep between calls back to the runtime; returns
+    the device bytes released (the library does the same by itself when one of its allocations finds a device full)."""
+    v = C.c_uint64()
+    _chk(load().mf_release_cached(C.byref(v)))
+    return v.value
 
 
 def h2d_bandwidth(device: int = 0, nbytes: int = 1 << 30, reps: int = 3) -> float:

@@ -2,7 +2,7 @@
 is no collective -- so all bench.py needs from the launcher is RANK / WORLD_SIZE plus a barrier and a max over ranks,
 which go through a directory in /dev/shm (no torch, no process group).  Covered here on CPU with two and four
 processes; the GPU suite runs bench.py itself under torch.distributed.run with two ranks on one device
-(tests/test_gpu_parity.py::test_bench_two_ranks_under_torchrun)."""
+(tests/test_gpu_parity.py::test_bench_ranks_under_torchrun, two and eight ranks)."""
 import multiprocessing as mp
 import os
 import sys

@@ -1,0 +1,82 @@
+// What a process pays before its first useful kernel on this box: HIP start-up, code-object load, allocation, pinned memory, streams.
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -x hip tools/coldstart_probe.cpp -ldl -o tools/coldstart_probe     (make -C mitoflex_amd/csrc tools)
+//   tools/coldstart_probe [path/to/libmitofilter_hip.so]
+// Every line is "seconds since main() | what | seconds it took".  The reference's boundary on this path is a process per call
+// (/root/reference/utility/helper.py:78-86), so these are costs of EVERY call through the CLIs.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double T0;
+#define STEP(what, ...) do { const double a_ = now_s(); __VA_ARGS__; const double b_ = now_s(); printf("%8.4f | %-58s | %8.4f\n", b_ - T0, what, b_ - a_); fflush(stdout); } while (0)
+
+__global__ void touch_kernel(unsigned *p) { if (p) p[threadIdx.x] = threadIdx.x; }
+
+int main(int argc, char **argv)
+{
+    T0 = now_s();
+    int n = 0;
+    STEP("hipGetDeviceCount (runtime initialisation)", (void)hipGetDeviceCount(&n));
+    STEP("hipSetDevice(0) + hipFree(0) (context)", { (void)hipSetDevice(0); (void)hipFree(nullptr); });
+    unsigned *d = nullptr;
+    STEP("hipMalloc 4 KiB (first allocation)", (void)hipMalloc(&d, 4096));
+    STEP("first kernel of this binary (code object load + launch + sync)", { hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, 0, d); (void)hipDeviceSynchronize(); });
+    STEP("second kernel (launch + sync)", { hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, 0, d); (void)hipDeviceSynchronize(); });
+    for (size_t mb : {64, 256, 1024, 4096, 16384}) {
+        void *p = nullptr; char w[96];
+        snprintf(w, sizeof w, "hipMalloc %zu MiB", mb);
+        STEP(w, (void)hipMalloc(&p, mb << 20));
+        snprintf(w, sizeof w, "hipMemsetAsync over it + sync (first touch)");
+        STEP(w, { (void)hipMemsetAsync(p, 0, mb << 20, 0); (void)hipDeviceSynchronize(); });
+        snprintf(w, sizeof w, "hipFree %zu MiB", mb);
+        STEP(w, (void)hipFree(p));
+    }
+    {   // many small allocations against one arena
+        std::vector<void *> v(200);
+        STEP("200 x hipMalloc 8 MiB", for (auto &p : v) (void)hipMalloc(&p, 8 << 20));
+        STEP("200 x hipFree", for (auto &p : v) (void)hipFree(p));
+    }
+    for (size_t mb : {1, 32, 256}) {
+        void *p = nullptr; char w[96];
+        snprintf(w, sizeof w, "hipHostMalloc %zu MiB (portable)", mb);
+        STEP(w, (void)hipHostMalloc(&p, mb << 20, hipHostMallocPortable));
+        snprintf(w, sizeof w, "hipHostFree %zu MiB", mb);
+        STEP(w, (void)hipHostFree(p));
+    }
+    {
+        void *p = nullptr; (void)posix_memalign(&p, 4096, (size_t)64 << 20); memset(p, 1, (size_t)64 << 20);
+        STEP("hipHostRegister 64 MiB of touched malloc memory", (void)hipHostRegister(p, (size_t)64 << 20, hipHostRegisterPortable));
+        STEP("hipHostUnregister", (void)hipHostUnregister(p));
+        free(p);
+    }
+    hipStream_t s[4] = {};
+    STEP("hipStreamCreateWithFlags (non-blocking) #1", (void)hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
+    STEP("hipStreamCreateWithFlags (non-blocking) #2", (void)hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
+    STEP("kernel on the new stream #1 (queue creation is lazy)", { hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, s[0], d); (void)hipStreamSynchronize(s[0]); });
+    STEP("kernel on the new stream #2", { hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, s[1], d); (void)hipStreamSynchronize(s[1]); });
+    {
+        hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
+        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0);
+        for (int b = 0; b < n_cu - 32; b++) mask[b / 32] |= 1u << (b % 32);
+        STEP("hipExtStreamCreateWithCUMask #1", (void)hipExtStreamCreateWithCUMask(&s[2], (uint32_t)words, mask.data()));
+        STEP("hipExtStreamCreateWithCUMask #2", (void)hipExtStreamCreateWithCUMask(&s[3], (uint32_t)words, mask.data()));
+        STEP("kernel on CU-masked stream #1", { hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, s[2], d); (void)hipStreamSynchronize(s[2]); });
+    }
+    hipEvent_t e;
+    STEP("hipEventCreate", (void)hipEventCreate(&e));
+    if (argc > 1) {
+        void *h = nullptr;
+        STEP("dlopen libmitofilter_hip.so (fat binary registration)", h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL));
+        if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
+        auto dc = (int (*)())dlsym(h, "mf_device_count");
+        STEP("mf_device_count()", if (dc) (void)dc());
+    }
+    printf("%8.4f | done\n", now_s() - T0);
+    return 0;
+}

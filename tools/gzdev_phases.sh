@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-phase cycle counts of the lane-parallel decode kernel (tools/gzdev_check built with -DGZ_PROFILE) and its rate with the chip full
+# (make -C mitoflex_amd/csrc tools builds tools/gzdev_check and tools/gzdev_check_prof before this is sent to the GPU box)
 cd $GRAFT_REPO_ROOT; T=/tmp/gzp; mkdir -p $T gpurun_out
 python tools/make_fastq.py $T/s --pairs ${1:-12000000} --mates 1 --block 2000000 > /dev/null
 python tools/pgzip.py $T/s_1.fq $T/s6.gz --level 6
