@@ -17,6 +17,7 @@
 // read/pair count.  It has no CPU fallback: without the library or a GPU it
 // exits non-zero, which shell_call turns into a RuntimeError (helper.py:82-86).
 #include "../../include/mitofilter.h"
+#include "mf_coldtrace.h"
 
 #include <dlfcn.h>
 #include <limits.h>
@@ -467,6 +468,7 @@ static int bait_main(int argc, char **argv)
     }
     if (k == 0) k = protein ? 9 : 31;
     if (libpath.empty()) libpath = exe_dir() + "/../libmitofilter_hip.so";
+    mf::cold_mark("fastfilter bait: arguments read");
     void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "error: cannot load %s: %s (the bait filter has no CPU fallback)\n", libpath.c_str(), dlerror()); return 2; }
 #define SYM(name) auto p_##name = (decltype(&name))dlsym(h, #name); if (!p_##name) { fprintf(stderr, "error: %s lacks symbol %s\n", libpath.c_str(), #name); return 2; }
@@ -475,11 +477,13 @@ static int bait_main(int argc, char **argv)
 #undef SYM
     if (p_mf_abi_version() != MF_ABI_VERSION) { fprintf(stderr, "error: ABI version mismatch\n"); return 2; }
     for (auto &kv : options) if (p_mf_set_option(kv.first.c_str(), kv.second.c_str()) != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 1; }
+    mf::cold_mark("library loaded");
     mf_kmerset *ks = nullptr;
     const int dev0 = device_list.empty() ? 0 : device_list[0];
     const int brc = protein ? p_mf_kmerset_build_protein_from_fasta(bait.c_str(), k, gcode, dev0, &ks)
                             : p_mf_kmerset_build_from_fasta(bait.c_str(), k, dev0, &ks);
     if (brc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 3; }
+    mf::cold_mark("bait set built");
     uint64_t kept = 0, total = 0;
     setenv("MF_DEVPOOL_GB", "4096", 0);          // (a process that ends with the call gives no device memory back in between: the runtime frees it all at once)
     int rc = device_list.empty()
@@ -490,6 +494,7 @@ static int bait_main(int argc, char **argv)
                                      out2.empty() ? nullptr : out2.c_str(), thr, pair == "both" ? MF_PAIR_BOTH : MF_PAIR_EITHER,
                                      device_list.data(), (int)device_list.size(), &kept, &total);
     if (rc != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); p_mf_kmerset_free(ks); return 3; }
+    mf::cold_mark("files filtered");
     printf("%llu\n", (unsigned long long)kept);      // same stdout contract as the contig filter
     // (the outputs are written and closed; what is left is the GPU runtime's teardown -- queues, code objects, a tenth of a second -- which a
     // process that is about to be gone has no use for; a profiler writes its files in a finaliser, so not under one)

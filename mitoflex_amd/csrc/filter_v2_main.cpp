@@ -5,6 +5,7 @@
 // mf_qualfilter_files of libmitofilter_hip.so: counting and hashing on the GPU, the order-dependent
 // rules on the host.  No CPU fallback: without the library or a gfx950 device it exits non-zero.
 #include "../../include/mitofilter.h"
+#include "mf_coldtrace.h"
 
 #include <dlfcn.h>
 #include <time.h>
@@ -151,6 +152,7 @@ int main(int argc, char **argv)
     const bool timing = getenv("MF_PIPE_TIMING") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
     const double t_load = now();
+    mf::cold_mark("filter_v2: arguments read");
     void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "error: cannot load %s: %s (filter_v2 has no CPU fallback)\n", libpath.c_str(), dlerror()); return 2; }
     auto p_run = (decltype(&mf_qualfilter_files))dlsym(h, "mf_qualfilter_files");
@@ -159,8 +161,10 @@ int main(int argc, char **argv)
     uint64_t kept = 0, total = 0; int panicked = 0;
     setenv("MF_DEVPOOL_GB", "4096", 0);          // (a process that ends with the call gives no device memory back in between: the runtime frees it all at once)
     const double t_call = now();
+    mf::cold_mark("library loaded");
     const int rc = p_run(fq1, fq2, opt['3'].c_str(), out2, start, end, ns, (uint32_t)q64, limit, opt.count('d') ? 1 : 0, trim,
                          opt.count('T') ? 1 : 0, 0, &kept, &total, &panicked);
+    mf::cold_mark("files filtered");
     if (timing) fprintf(stderr, "[filter_v2] loading the library %.3f s, the call %.3f s\n", t_call - t_load, now() - t_call);
     if (rc != MF_OK) { fprintf(stderr, "error: %s\n", p_err()); return 3; }
     if (panicked) rust_panic("called `Result::unwrap()` on an `Err` value / drain out of range");

@@ -8,6 +8,7 @@
 #include "mf_kernels.h"
 #include "mf_pipeline.h"
 #include "mf_synth.h"
+#include "mf_coldtrace.h"
 #include "mf_api_internal.h"
 #include "mf_devingest.h"
 
@@ -65,7 +66,9 @@ int get_ctx(int device, DevCtx **out, int lane)
     auto it = g_ctx.find(device + 4096 * lane);
     if (it != g_ctx.end()) { *out = &it->second; hipError_t e = hipSetDevice(phys(device)); if (e != hipSuccess) return fail(MF_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return MF_OK; }
     int n = 0;
+    mf::cold_mark("get_ctx: a new device context");
     hipError_t e = hipGetDeviceCount(&n);
+    mf::cold_mark("get_ctx: HIP runtime answered (initialised)");
     if (e != hipSuccess || n <= 0) return fail(MF_E_NO_DEVICE, "no HIP device visible (%s); libmitofilter_hip has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
     const int logical = fake_devices() ? fake_devices() : n;
     if (device < 0 || device >= logical) return fail(MF_E_ARG, "device %d out of range (have %d)", device, logical);
@@ -77,15 +80,27 @@ int get_ctx(int device, DevCtx **out, int lane)
     HIPCHK(hipSetDevice(pdev));
     DevCtx c; c.device = device; c.n_cu = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    {   // the second stream carries the short, latency-bound finish kernels that run under the next screen kernel: highest priority
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
-        HIPCHK(hipStreamCreateWithPriority(&c.stream4, hipStreamNonBlocking, hi));
-    }
-    HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
+    mf::cold_mark("get_ctx: stream made");
     g_ctx[device + 4096 * lane] = c;
     *out = &g_ctx[device + 4096 * lane];
+    return MF_OK;
+}
+
+// The streams that only a call of several pipelined passes uses (mf_filter_resident with steps > 1: finish kernels under the next
+// screen, every other screen) are made when such a call first comes.  A stream with a priority is a hardware queue of its own and
+// takes 17-32 ms to make, a plain one 16-30 ms while the process has fewer than four queues (profiles/r05/a_stream_probe.log):
+// a file-level call -- one pass per piece -- through the reference's process-per-call boundary must not pay for three of them per context.
+static int ensure_pipeline_streams(DevCtx *c)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (c->stream2) return MF_OK;
+    int lo = 0, hi = 0;
+    hipStream_t s2 = nullptr, s3 = nullptr, s4 = nullptr;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, hi));          // the short, latency-bound finish kernels that run under the next screen kernel: highest priority
+    HIPCHK(hipStreamCreateWithPriority(&s4, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithFlags(&s3, hipStreamNonBlocking));
+    c->stream3 = s3; c->stream4 = s4; c->stream2 = s2;
     return MF_OK;
 }
 
@@ -781,8 +796,11 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     for (int i = 0; i < 2; i++) if (!r->ev_call[i]) HIPCHK(hipEventCreate(&r->ev_call[i]));
     const hipEvent_t e_begin = r->ev_call[0], e_end = r->ev_call[1];
     lap("events");
+    // (one pass: its three launches follow one another on the one stream -- nothing to overlap with, and no second stream to make)
+    const bool pipelined = steps > 1;
+    if (pipelined) { rc = ensure_pipeline_streams(ctx); if (rc) return rc; }
     HIPCHK(hipEventRecord(e_begin, st));
-    HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
+    if (pipelined) HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
     // every pass's own tally block when the caller wants them all (tests: a buffer-set race that corrupted only the middle passes
     // of a pipelined call would not show in the last pass's tally)
     constexpr size_t TALLY_WORDS = 2 * (size_t)EXACT_MAX_GRID * 2;
@@ -794,7 +812,7 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     struct OverrideReset { mf_reads *r; ~OverrideReset() { r->tally_override = nullptr; } } override_reset{r};
     for (int i = 0; i < steps; i++) {
         if (pass_per_step) r->tally_override = all_tallies.p + (size_t)i * TALLY_WORDS;
-        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, n_sampled && i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, true, i + 1 < steps);
+        rc = enqueue_pass(r, T->view, thr, mode, count_all, ctx, n_sampled && i % stride == 0 ? &ev[(size_t)(i / stride) * 6] : nullptr, pipelined, i + 1 < steps);
         if (rc) return rc;
     }
     lap("enqueued");

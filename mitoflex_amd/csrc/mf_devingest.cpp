@@ -32,6 +32,7 @@
 #include "mf_pinflate.h"
 #include "mf_pipeline.h"
 #include "mf_qualsink.h"
+#include "mf_coldtrace.h"
 
 #include <algorithm>
 #include <atomic>
@@ -61,6 +62,10 @@ uint64_t env_u64(const char *name, uint64_t dflt) { const char *v = getenv(name)
 static const bool g_trace = getenv("MF_DEVINGEST_TRACE") != nullptr;
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define TRACE(...) do { if (g_trace) { const double t_ = now_s(); fprintf(stderr, "[devingest %.3f] ", t_ - (double)((long)t_ / 1000 * 1000)); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
+// a bounded wait on a condition variable (polling loops).  Against the system clock on purpose: that is pthread_cond_timedwait, which
+// ThreadSanitizer knows; wait_for() is pthread_cond_clockwait, which the libtsan of this toolchain does not intercept (it then believes the
+// mutex still held and reports a double lock at the next wait).  A clock step only stretches or cuts one nap of a few hundred microseconds.
+void nap(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, unsigned us) { cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us)); }
 size_t pow2_ceil(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
 // Device memory of this path comes from a pool per device that outlives the call.  Two reasons.  hipFree waits for the whole
@@ -1160,10 +1165,23 @@ struct Ingest {
     bool failed = false; int fail_rc = MF_OK; std::string fail_err;
 
     std::mutex mu_all; std::condition_variable cv_all;          // any producer has something new
+    // The producers use this object's mutexes and condition variables to their last line, and on a failed run they are still running when
+    // the call unwinds: they are stopped and joined before any member goes (the members' own order would destroy cv_all, declared behind
+    // m[], before ~Mate joins its producer -- a notify on a destroyed condition variable; found under ThreadSanitizer by tests/native/ingest_check.cpp)
+    ~Ingest()
+    {
+        for (auto &M : m) { M.stop = true; M.slots.wake(); }
+        for (auto &M : m) {
+            { std::lock_guard<std::mutex> lk(mu); M.batches.clear(); }
+            { std::lock_guard<std::mutex> lk(M.mu); M.ready.clear(); }          // (text buffers give their slots back: a producer waiting for one wakes up and sees stop)
+            if (M.prod.joinable()) M.prod.join();
+        }
+    }
     double t_begin = 0, t_first_piece = 0, t_last_piece = 0, t_consumed = 0;      // when the first / last piece of text was handed over, when the last consumer was done (seconds into the call)
     void publish(Mate &M, TextPiece &&t)
     {
-        { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(std::move(t)); const double now = now_s() - t_begin; if (t_first_piece == 0) t_first_piece = now; t_last_piece = now; }
+        { std::lock_guard<std::mutex> lk(M.mu); M.ready.push_back(std::move(t)); }
+        { std::lock_guard<std::mutex> lk(mu_all); const double now = now_s() - t_begin; if (t_first_piece == 0) { t_first_piece = now; cold_mark("device ingest: first piece of text handed over"); } t_last_piece = now; }          // (two producers)
         M.cv.notify_all(); cv_all.notify_all();
     }
 
@@ -1458,7 +1476,12 @@ struct Ingest {
                     std::lock_guard<std::mutex> lk(mu);
                     if (M.batches.empty() || !M.batches.front()->filtered) break;
                     covered = fin ? total : (nm == 2 ? std::min(m[0].rec_filtered, m[1].rec_filtered) : M.rec_filtered);
-                    if (!fin && M.batches.front()->rec_base + M.batches.front()->n_rec > covered) break;
+                    // Pairs end with the shorter file: once the other mate has been filtered to its end, nothing of this mate at or behind
+                    // that record will ever be written -- such a batch must not wait for the end of the call with its text buffer in hand
+                    // (with the longer mate's buffers all held that way its producer never got another one: found by tests/native/ingest_check.cpp)
+                    uint64_t end = M.batches.front()->rec_base + M.batches.front()->n_rec;
+                    if (!fin && nm == 2 && scans_done(m[1 - i])) end = std::min(end, m[1 - i].rec_indexed);
+                    if (!fin && end > covered) break;
                     B = std::move(M.batches.front()); M.batches.pop_front();
                 }
                 if (B->rec_base < covered) { const int rc = emit(W, M, i, *B, covered - B->rec_base, err); if (rc) return rc; }       // (pairs end with the shorter file)
@@ -1488,6 +1511,10 @@ struct Ingest {
                         M.eof = true; M.stop = true; M.slots.wake();
                         continue;
                     }
+                    if (!qual && nm == 2 && scans_done(m[1 - order[k]]) && M.a_turn == M.taken && M.rec_indexed >= m[1 - order[k]].rec_indexed) {
+                        M.eof = true; M.stop = true; M.slots.wake();          // the other mate has ended in front of this one's next record: pairs end with the shorter file
+                        continue;
+                    }
                     std::unique_lock<std::mutex> plk(M.mu);
                     if (!M.ready.empty()) {
                         P = std::move(M.ready.front()); M.ready.pop_front();
@@ -1505,7 +1532,7 @@ struct Ingest {
                 if (again && round) { *again = true; if (timing) t_wait += now_s() - tw; return false; }
             }
             std::unique_lock<std::mutex> lk(mu_all);
-            cv_all.wait_for(lk, std::chrono::microseconds(300));
+            nap(cv_all, lk, 300);
         }
     }
 
@@ -1730,7 +1757,7 @@ struct Ingest {
         B.reset();
         const size_t chunk = Q.chunks.chunk();
         double tw = 0;
-        { const double w0 = now_s(); if (!Q.sink[mi].wait_turn(part.out_at)) { err = "abandoned"; return MF_E_IO; } tw += now_s() - w0; }      // (standard output, a pipe, a .gz: the parts' chunks are taken in file order)
+        { const double w0 = now_s(); if (!Q.sink[mi].wait_turn(part.out_at)) { err = "abandoned"; return MF_E_IO; } tw += now_s() - w0; }      // (standard output, a pipe, a .gz: the parts' chunks are taken in file order -- tests/native/qualsink_check.cpp hangs without it)      // (standard output, a pipe, a .gz: the parts' chunks are taken in file order)
         for (uint64_t off = 0; off < bytes; off += chunk) {
             const uint64_t len = std::min<uint64_t>(chunk, bytes - off);
             const double w0 = now_s();
@@ -1779,7 +1806,11 @@ struct Ingest {
                             upto = other_done ? limit : std::min(limit, m[1].rec_filtered);     // ... and what can be now: the records mate 2's scanned pieces cover
                             // A part of the piece is decided only when waiting for the rest cannot end: the other mate holds all its text buffers
                             // (its pieces wait for THESE decisions before they are written and their buffers come back)
+#ifdef MF_TEST_WITHOUT_PARTIAL_DECISIONS         // (tests/test_ingest_orchestration.py: the check must hang without this rule, as the path did before it had it)
+                            ready = upto == limit;
+#else
                             ready = upto == limit || (upto > cur && m[1].slots.none_free());
+#endif
                         }
                         if (ready) {
                             whole = upto == limit;
@@ -1866,7 +1897,7 @@ struct Ingest {
             }
             if (rc) { fail_with(rc, err); q_abandon(); return; }
             if (q_all_done()) return;
-            if (!did && !again) { std::unique_lock<std::mutex> lk(mu_all); cv_all.wait_for(lk, std::chrono::microseconds(200)); }
+            if (!did && !again) { std::unique_lock<std::mutex> lk(mu_all); nap(cv_all, lk, 200); }
         }
     }
 
@@ -1881,7 +1912,7 @@ struct Ingest {
         std::string err;
         for (;;) {
             int mi = 0, rc = MF_OK; TextPiece P; uint64_t seq = 0;
-            if (!take_piece(mi, P, seq, err, rc)) { if (rc) fail_with(rc, err); return; }
+            if (!take_piece(mi, P, seq, err, rc)) { if (rc) fail_with(rc, err); TRACE("consumer %d: nothing more to take (rc %d)", W.id, rc); return; }
             Mate &M = m[mi];
             {   // the line index of a mate's pieces is cut in order
                 std::unique_lock<std::mutex> lk(mu);
@@ -1889,6 +1920,7 @@ struct Ingest {
                 if (failed) return;
             }
             const double grow = P.grow;
+            TRACE("consumer %d: piece %llu of mate %d (%llu bytes of text%s)", W.id, (unsigned long long)seq, mi + 1, (unsigned long long)P.len, P.last ? ", the last" : "");
             std::shared_ptr<Batch> B;
             rc = index_piece(W, M, P, B, err);
             Batch *Bp = nullptr;
@@ -1906,6 +1938,7 @@ struct Ingest {
             if (Bp) {
                 rc = filter_piece(W, *Bp, grow, err);
                 if (rc) { fail_with(rc, err); return; }
+                TRACE("consumer %d: piece %llu of mate %d filtered: records %llu .. %llu", W.id, (unsigned long long)seq, mi + 1, (unsigned long long)Bp->rec_base, (unsigned long long)(Bp->rec_base + Bp->n_rec));
                 DevScratch &S = *W.scratch[Bp->ldev];
                 std::lock_guard<std::mutex> lk(mu);
                 append_bits(M.bits, Bp->rec_base, Bp->n_rec, S.h_bits);
@@ -1979,7 +2012,9 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
             if ((d[3] & 4) && M.map.n >= 18 && d[12] == 'B' && d[13] == 'C') return MF_DEVINGEST_DECLINED;   // BGZF: the host reader decodes its members side by side
         }
     }
+    cold_mark("device ingest: inputs mapped");
     for (int d : I.devices) { DevCtx *c = nullptr; const int rc = get_ctx(d, &c, 0); if (rc) { err = mf_thread_error(); return rc; } }
+    cold_mark("device ingest: device contexts ready");
     const double t_begin = now_s();
     I.t_begin = t_begin;
     g_pool.reset_peak();
@@ -2005,7 +2040,9 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     for (int i = 0; i < I.nm; i++)
         if (!(I.qual ? I.qual->sink[i].open(out_path[i], &I.qual->chunks) : I.m[i].out.open(out_path[i]))) { err = std::string("Cannot open file ") + (out_path[i] ? out_path[i] : "<stdout>"); return MF_E_IO; }
     const double t_setup = now_s() - t_begin;
+    cold_mark("device ingest: decoders and outputs open");
     rc = I.run(err);
+    cold_mark("device ingest: consumers done");
     TRACE("run returned %d", rc);
     for (int i = 0; i < I.nm; i++) { I.m[i].stop = true; I.m[i].slots.wake(); }
     bool wrote = true;

@@ -348,6 +348,24 @@ bool inflate_gap(const uint8_t *data, size_t size, uint64_t from_bit, uint64_t t
     return true;
 }
 
+// One speculative chunk, decoded the way fill() decodes the chunks of a group: the CPU stand-in for the device decode kernel in
+// tests/native/ingest_stub.cpp (the orchestration of the device ingest path under ThreadSanitizer) calls this.
+int speculative_chunk(const uint8_t *data, size_t size, uint64_t origin, uint64_t from_bit, uint64_t to_bit, bool exact,
+                      std::vector<uint16_t> &sym, uint64_t &start_bit, uint64_t &end_bit)
+{
+    const uint64_t o = origin * 8;
+    size_t s = (size_t)(from_bit - o);
+    if (!exact) { s = find_block(data, size, (size_t)(from_bit - o), (size_t)std::min<uint64_t>(to_bit - o, (uint64_t)size * 8)); if (s == SIZE_MAX) return 0; }
+    Bits in(data, size); in.seek(s);
+    Tables t; const char *why = nullptr;
+    Out<uint16_t> out; out.v.resize((size_t)1 << 16);
+    const Stop st = decode_until<uint16_t>(in, t, out, (size_t)(to_bit - o), (size_t)1 << 30, why);
+    start_bit = o + s; end_bit = o + in.bitpos();
+    if (st == FAILED) return 3;
+    sym.assign(out.v.begin(), out.v.begin() + (ptrdiff_t)out.n);
+    return st == MEMBER_END ? 2 : 1;
+}
+
 struct ChunkResult { bool valid = false; size_t start = 0, end = 0; Stop stop = FAILED; Out<uint16_t> sym; };
 struct ParallelGzReader::Scratch { std::vector<ChunkResult> res; Out<uint8_t> first; };
 

@@ -33,6 +33,13 @@ void resolve_symbols(const uint16_t *s, size_t n, const uint8_t *window, uint8_t
 bool inflate_gap(const uint8_t *data, size_t size, uint64_t from_bit, uint64_t to_bit, const uint8_t *window, size_t wlen,
                  std::vector<uint8_t> &out, uint64_t &end_bit, bool &member_end, std::string &err);
 
+// (test infrastructure: the stand-in for the device decode kernel in tests/native/ingest_stub.cpp)  One speculative chunk: data[0 .. size) are
+// the bytes of the file from byte `origin` on, bit positions are absolute; exact = decode from from_bit itself, else search [from_bit, to_bit) for
+// a dynamic block header with complete codes; symbols are bytes or 0x8000 | index into the 32 KiB in front of the chunk.
+// Returns 0 nothing found, 1 stopped in front of the first block at or behind to_bit, 2 behind the member's final block, 3 does not decode.
+int speculative_chunk(const uint8_t *data, size_t size, uint64_t origin, uint64_t from_bit, uint64_t to_bit, bool exact,
+                      std::vector<uint16_t> &sym, uint64_t &start_bit, uint64_t &end_bit);
+
 class ParallelGzReader {
     using ByteBuf = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;   // sized without being zero-filled
 public:

@@ -100,10 +100,12 @@ public:
     {
         pool_ = pool;
         bool ok = false;
-        if (path && !has_gz_ext(path)) {
+        // (what the path names is looked at BEFORE it is opened: opening a named pipe only to find out that it is one, and closing it again,
+        // shows its reader an end of file -- the reader leaves, and the second open waits for a reader for ever; tests/native/ingest_check.cpp qual_pipes)
+        struct stat sb;
+        if (path && !has_gz_ext(path) && (stat(path, &sb) != 0 || S_ISREG(sb.st_mode))) {
             fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
             if (fd_ < 0) return false;
-            struct stat sb;
             if (fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) { direct_ = true; ok = true; }
             else { ::close(fd_); fd_ = -1; }
         }

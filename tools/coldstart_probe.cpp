@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -21,7 +23,8 @@ int main(int argc, char **argv)
 {
     T0 = now_s();
     int n = 0;
-    STEP("hipGetDeviceCount (runtime initialisation)", (void)hipGetDeviceCount(&n));
+    STEP("hipInit(0)", (void)hipInit(0));
+    STEP("hipGetDeviceCount", (void)hipGetDeviceCount(&n));
     STEP("hipSetDevice(0) + hipFree(0) (context)", { (void)hipSetDevice(0); (void)hipFree(nullptr); });
     unsigned *d = nullptr;
     STEP("hipMalloc 4 KiB (first allocation)", (void)hipMalloc(&d, 4096));
@@ -53,6 +56,30 @@ int main(int argc, char **argv)
         STEP("hipHostRegister 64 MiB of touched malloc memory", (void)hipHostRegister(p, (size_t)64 << 20, hipHostRegisterPortable));
         STEP("hipHostUnregister", (void)hipHostUnregister(p));
         free(p);
+    }
+    if (getenv("PROBE_STREAMS")) {          // how the cost of a stream depends on how many there are already, and whether making one stalls another thread's launches
+        hipStream_t q[16] = {};
+        for (int i = 0; i < 12; i++) { char w[64]; snprintf(w, sizeof w, "plain non-blocking stream #%d", i + 1); STEP(w, (void)hipStreamCreateWithFlags(&q[i], hipStreamNonBlocking)); }
+        STEP("12 kernels, one per stream, + device sync", { for (int i = 0; i < 12; i++) hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, q[i], d); (void)hipDeviceSynchronize(); });
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        STEP("stream with priority (high)", (void)hipStreamCreateWithPriority(&q[12], hipStreamNonBlocking, hi));
+        STEP("hipStreamDestroy of one", (void)hipStreamDestroy(q[11]));
+        STEP("plain stream again", (void)hipStreamCreateWithFlags(&q[11], hipStreamNonBlocking));
+        std::atomic<bool> stop{false}; double worst = 0, sum = 0; int n_it = 0;
+        std::thread other([&] {
+            (void)hipSetDevice(0);
+            while (!stop) { const double a = now_s(); hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, q[0], d); (void)hipStreamSynchronize(q[0]); const double dt = now_s() - a; worst = dt > worst ? dt : worst; sum += dt; n_it++; }
+        });
+        hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
+        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0);
+        for (int b = 0; b < n_cu - 32; b++) mask[b / 32] |= 1u << (b % 32);
+        hipStream_t m[6];
+        STEP("6 CU-masked streams while another thread launches + syncs in a loop", for (auto &x : m) (void)hipExtStreamCreateWithCUMask(&x, (uint32_t)words, mask.data()));
+        stop = true; other.join();
+        printf("         | the other thread: %d launch+sync rounds, mean %.6f s, worst %.6f s\n", n_it, n_it ? sum / n_it : 0.0, worst);
+        printf("%8.4f | done\n", now_s() - T0);
+        return 0;
     }
     hipStream_t s[4] = {};
     STEP("hipStreamCreateWithFlags (non-blocking) #1", (void)hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
