@@ -45,6 +45,10 @@ int fail(int code, const char *fmt, ...)
 
 // --------------------------------------------------------------- device ctx
 static std::mutex g_ctx_mu;
+// "expect_files" (mf_set_option): this process is going to make a file-level call -- what that call's set-up needs of a device (the ingest
+// path's streams, its pinned staging buffers) is started in the background the moment the device's first context exists, beside whatever
+// the caller does first (the bait set's build).  The CLIs set it: a process per call is the reference's boundary (utility/helper.py:78-86).
+static std::atomic<int> g_expect_files{0};
 static std::map<int, DevCtx> g_ctx;
 
 // MF_FAKE_DEVICES=N: the library reports N logical devices and maps logical device d onto physical device d mod <visible>.
@@ -83,6 +87,7 @@ int get_ctx(int device, DevCtx **out, int lane)
     mf::cold_mark("get_ctx: stream made");
     g_ctx[device + 4096 * lane] = c;
     *out = &g_ctx[device + 4096 * lane];
+    if (g_expect_files && lane == 0) mf::ingest_prefetch(device);
     return MF_OK;
 }
 
@@ -447,7 +452,8 @@ static int set_option(const char *name, const char *value)
     if (n == "pass") { if (v == "" || v == "default") g_opt.pass = 0; else if (v == "split") g_opt.pass = 1; else if (v == "serial") g_opt.pass = 2; else return -1; return 0; }
     char *end = nullptr; const long x = strtol(v.c_str(), &end, 10);
     if (v.empty() || *end) return -1;
-    if (n == "adapt") g_opt.adapt = x != 0;
+    if (n == "expect_files") g_expect_files = x != 0;
+    else if (n == "adapt") g_opt.adapt = x != 0;
     else if (n == "finish_streams") { if (x < 0 || x > 2) return -1; g_opt.finish_streams = (int)x; }
     else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
     else if (n == "split_pipe") g_opt.split_pipe = x != 0;
@@ -1031,7 +1037,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, expect_files=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 

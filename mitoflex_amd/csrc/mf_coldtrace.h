@@ -26,6 +26,6 @@ inline double cold_process_start()
     }();
     return t0;
 }
-inline bool cold_trace_on() { static const bool on = getenv("MF_COLD_TRACE") != nullptr; return on; }
+inline bool cold_trace_on() { static const bool on = [] { const char *v = getenv("MF_COLD_TRACE"); return v && *v; }(); return on; }
 inline void cold_mark(const char *what) { if (cold_trace_on()) fprintf(stderr, "[cold +%.3f] %s\n", cold_now() - cold_process_start(), what); }
 } // namespace mf

@@ -214,7 +214,7 @@ class PinnedCache {
 public:
     hipError_t get(uint8_t **p, size_t bytes)
     {
-        { std::lock_guard<std::mutex> lk(mu_); auto it = free_.lower_bound(bytes); if (it != free_.end() && it->first <= bytes * 2 + 4096) { *p = it->second; size_[*p] = it->first; free_.erase(it); return hipSuccess; } }
+        { std::lock_guard<std::mutex> lk(mu_); auto it = free_.lower_bound(bytes); if (it != free_.end() && it->first <= std::max<size_t>(bytes * 2 + 4096, ((size_t)32 << 20) + 4096)) { *p = it->second; size_[*p] = it->first; free_.erase(it); return hipSuccess; } }
         void *q = nullptr;
         hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocPortable);
         if (e == hipSuccess) { *p = (uint8_t *)q; std::lock_guard<std::mutex> lk(mu_); size_[*p] = bytes; }
@@ -229,128 +229,157 @@ public:
         if ((kb && kb[0] == '0') || free_.size() >= 8) { size_.erase(p); lk.unlock(); (void)hipHostFree(p); return; }
         free_.emplace(n, p);
     }
+    void prefill(int n, size_t bytes)          // n buffers of `bytes` into the cache (a thread of its own does this while a cold call maps its files)
+    {
+        for (int i = 0; i < n; i++) {
+            { std::lock_guard<std::mutex> lk(mu_); if (free_.size() >= 4) return; }
+            void *q = nullptr;
+            if (hipHostMalloc(&q, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
+            std::lock_guard<std::mutex> lk(mu_); size_[(uint8_t *)q] = bytes; free_.emplace(bytes, (uint8_t *)q);
+        }
+    }
     void clear() { std::vector<uint8_t *> v; { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : free_) { v.push_back(kv.second); size_.erase(kv.second); } free_.clear(); } for (uint8_t *q : v) (void)hipHostFree(q); }
 private:
     std::mutex mu_; std::multimap<size_t, uint8_t *> free_; std::map<uint8_t *, size_t> size_;
 };
 PinnedCache g_pinned;
 
+// (the threads are the stager's own and live as long as it does: starting eight threads per 32 MiB piece was a tenth of the time of a read)
 struct Stager {
-    uint8_t *buf[2] = {nullptr, nullptr}; size_t piece = 0; int fd = -1; int nthr = 8;
-    ~Stager() { for (auto &b : buf) g_pinned.put(b); }
-    hipError_t init(size_t piece_bytes, int fd_)
+    std::vector<uint8_t *> buf; size_t piece = 0; int fd = -1; int nthr = 8;
+    ~Stager()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : pool_) t.join();
+        for (auto &b : buf) g_pinned.put(b);
+    }
+    hipError_t init(size_t piece_bytes, int fd_, int n_buf = 2)
     {
         piece = piece_bytes; fd = fd_;
         nthr = (int)std::min<uint64_t>(16, std::max<uint64_t>(1, env_u64("MF_UPLOAD_THREADS", 8)));
+        buf.assign((size_t)n_buf, nullptr);
         for (auto &b : buf) { hipError_t e = g_pinned.get(&b, piece + 256); if (e != hipSuccess) return e; }
+        if (piece >= ((size_t)1 << 20)) for (int t = 1; t < nthr; t++) pool_.emplace_back([this, t] { work(t); });
         return hipSuccess;
     }
     bool read(int b, size_t off, size_t len)          // false: the file could not be read (truncated under us, an I/O error)
     {
-        std::atomic<bool> ok{true};
-        const int nt = len < ((size_t)1 << 20) ? 1 : nthr;
-        auto part = [&](int t) {
-            size_t a = len * t / nt; const size_t e = len * (t + 1) / nt;
-            while (a < e) {
-                const ssize_t got = pread(fd, buf[b] + a, e - a, (off_t)(off + a));
-                if (got < 0 && errno == EINTR) continue;
-                if (got <= 0) { ok = false; return; }
-                a += (size_t)got;
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; t++) th.emplace_back(part, t);
+        const int nt = (len < ((size_t)1 << 20) || pool_.empty()) ? 1 : nthr;
+        ok_ = true;
+        if (nt > 1) {
+            { std::lock_guard<std::mutex> lk(mu_); dst_ = buf[(size_t)b]; off_ = off; len_ = len; nt_ = nt; left_ = nt - 1; gen_++; }
+            cv_.notify_all();
+        } else { dst_ = buf[(size_t)b]; off_ = off; len_ = len; nt_ = 1; }
         part(0);
-        for (auto &x : th) x.join();
-        return ok;
+        if (nt > 1) { std::unique_lock<std::mutex> lk(mu_); done_.wait(lk, [&] { return left_ == 0; }); }
+        return ok_;
     }
+private:
+    void part(int t)
+    {
+        size_t a = len_ * (size_t)t / (size_t)nt_; const size_t e = len_ * (size_t)(t + 1) / (size_t)nt_;
+        while (a < e) {
+            const ssize_t got = pread(fd, dst_ + a, e - a, (off_t)(off_ + a));
+            if (got < 0 && errno == EINTR) continue;
+            if (got <= 0) { ok_ = false; return; }
+            a += (size_t)got;
+        }
+    }
+    void work(int t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (quit_) return; }
+            if (t < nt_) part(t);
+            { std::lock_guard<std::mutex> lk(mu_); if (t < nt_ && --left_ == 0) done_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> pool_; std::mutex mu_; std::condition_variable cv_, done_; uint64_t gen_ = 0; bool quit_ = false;
+    uint8_t *dst_ = nullptr; size_t off_ = 0, len_ = 0; int nt_ = 1, left_ = 0; std::atomic<bool> ok_{true};
 };
 
-// ---- the decoder's streams.  The link step is the decoder's one serial path, and its workgroup wants 64 KiB of LDS -- on a chip
-// whose LDS the decode wavefronts of the slabs ahead have filled it would wait tens of milliseconds for a CU to drain.  So a few
-// CUs (mask bit b is a CU of XCD b mod 8) are kept free of decode work: the decode streams are masked off them, the
-// link stream runs only there.  Where CU masks are not to be had, ordinary streams.  The sets are made once and handed from
-// call to call: destroying a CU-masked stream right after use was seen to hang inside the runtime (ROCm 7.2), and they cost a
-// few milliseconds to make.
-constexpr uint32_t GZ_NSTREAM = 10;
-// The DECODE streams are the CU-masked ones.  Such a stream is a hardware queue of its own and takes 10-15 ms to make (the runtime
-// makes them one after the other, whoever asks), so there is one set of them per device for the whole process, shared by the mates
-// of a call: the first is made when the device is first used, the rest by a thread of the set's while the first slabs are already
-// decoding (n: streams made so far).  Never destroyed (below) -- except under a profiler.
-struct DecodeStreams {
-    int device = -1; hipStream_t sd[GZ_NSTREAM] = {}; std::atomic<uint32_t> n{0};
+// ---- the streams of this path, per device.  What a stream costs to make (profiles/r05/a_stream_probe.log): a CU-masked one is a
+// hardware queue of its own, 16 ms, always; a plain one 16-30 ms while the process has fewer than four queues, 2-3 ms afterwards
+// (it then shares one); the runtime makes them one after the other whoever asks, without holding up launches on the streams that
+// exist.  The reference calls this path a process at a time (utility/helper.py:78-86), so a call starts cold more often than
+// not: the streams are made ONCE per process and device by a maker thread, in the order a cold call needs them, while the call
+// maps its files, pins its staging buffers and reads the first bytes -- whoever needs a stream that is not there yet waits for it.
+//   decode streams (dec[]): CU-masked, so that decode wavefronts leave a few CUs alone (below) and a decode kernel of 10-30 ms never
+//     sits in front of a short kernel in a shared queue; shared by the mates of a call; the first is made first, the rest
+//     behind everything a small file needs;
+//   copy: the uploads of every mate (they share the link to the device anyway);
+//   post[]: per mate, everything behind a slab's decode kernel -- link, marker resolution, CRC, in that order, so one stream;
+//     plain ones, and (made late, for inputs large enough to keep the chip full of decode wavefronts for a long time) ones
+//     masked to the CUs the decode streams leave free: profiles/r04/g_configs4_link_stream_ab.txt.
+// Never destroyed (destroying a CU-masked stream right after use was seen to hang inside the runtime, ROCm 7.2) -- except under a
+// profiler, at exit.
+constexpr uint32_t GZ_NSTREAM = 10, GZ_NPOST = 2;
+struct DeviceStreams {
+    int device = -1;
+    hipStream_t dec[GZ_NSTREAM] = {}, copy = nullptr, post[GZ_NPOST] = {}, post_masked[GZ_NPOST] = {};
+    std::atomic<uint32_t> n_dec{0};
+    std::mutex mu; std::condition_variable cv; int made = 0; bool failed = false, post_busy[GZ_NPOST] = {false, false};
     std::thread maker; std::atomic<bool> stop{false};
-    uint32_t words = 0; int n_cu = 0; std::vector<uint32_t> mask; bool masked = false;
-    bool make(hipStream_t *q) const
+    uint32_t words = 0; int n_cu = 0; std::vector<uint32_t> mask, mask_rest; bool masked = false;
+    // the order of making: what a cold call on a small file waits for comes first
+    enum What { DEC0, COPY, POST0, POST1, DEC1, DEC2, DEC3, POSTM0, POSTM1, DEC_REST, N_WHAT };
+    bool make_masked(hipStream_t *q, const std::vector<uint32_t> &m) const
     {
-        if (masked && hipExtStreamCreateWithCUMask(q, words, mask.data()) == hipSuccess) return true;
+        if (masked && hipExtStreamCreateWithCUMask(q, words, m.data()) == hipSuccess) return true;
         (void)hipGetLastError();
         return hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
     }
-    hipStream_t pick(uint32_t seq) const { return sd[seq % std::max<uint32_t>(1, n.load())]; }
+    void run()
+    {
+        if (hipSetDevice(device) != hipSuccess) { fail_(); return; }
+        for (int w = 0; w < N_WHAT && !stop; w++) {
+            bool ok = true;
+            switch (w) {
+            case DEC0: ok = make_masked(&dec[0], mask); if (ok) n_dec = 1; break;
+            case COPY: ok = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess; break;
+            case POST0: case POST1: ok = hipStreamCreateWithFlags(&post[w - POST0], hipStreamNonBlocking) == hipSuccess; break;
+            case DEC1: case DEC2: case DEC3: ok = make_masked(&dec[1 + w - DEC1], mask); if (ok) n_dec = 2 + (uint32_t)(w - DEC1); break;
+            case POSTM0: case POSTM1: ok = make_masked(&post_masked[w - POSTM0], mask_rest); break;
+            case DEC_REST: for (uint32_t i = 4; i < GZ_NSTREAM && !stop && ok; i++) { ok = make_masked(&dec[i], mask); if (ok) n_dec = i + 1; } break;          // (fewer streams: slabs share them)
+            }
+            if (!ok) { fail_(); return; }
+            { std::lock_guard<std::mutex> lk(mu); made = w + 1; }
+            cv.notify_all();
+            if (w == DEC0) cold_mark("streams: first decode stream made");
+            if (w == POST1) cold_mark("streams: copy and post streams made");
+        }
+    }
+    void fail_() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
+    bool wait_for(What w) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || made > (int)w; }); return made > (int)w; }
+    hipStream_t pick_dec(uint32_t seq) { if (!wait_for(DEC0)) return nullptr; return dec[seq % std::max<uint32_t>(1, n_dec.load())]; }
+    hipStream_t copy_stream() { return wait_for(COPY) ? copy : nullptr; }
+    // a post stream for one mate of one call (given back with give_post); want_masked: a large input
+    hipStream_t take_post(bool want_masked, int *slot)
+    {
+        if (!wait_for(POST1)) return nullptr;
+        int k = -1;
+        { std::lock_guard<std::mutex> lk(mu); for (int i = 0; i < (int)GZ_NPOST; i++) if (!post_busy[i]) { post_busy[i] = true; k = i; break; } }
+        *slot = k;
+        if (k < 0) { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; }      // (more than two mates at a time on one device: concurrent calls)
+        if (want_masked && masked && wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k];
+        return post[k];
+    }
+    void give_post(int slot, hipStream_t q)
+    {
+        if (slot >= 0) { std::lock_guard<std::mutex> lk(mu); post_busy[slot] = false; }
+        else if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    }
 };
-// what a mate's decoder has of its own: the stream of the link step (chain, marker resolution, CRC) -- masked to the CUs the decode
-// streams are masked off (MF_GZDEV_LINK_MASK=0: a plain stream, whose workgroups go wherever there is room) --, one for the rest (small
-// copies, set-up), one for the uploads.
-struct StreamSet { int device = -1; DecodeStreams *dec = nullptr; hipStream_t link = nullptr, rest = nullptr, copy = nullptr; };
 class StreamSets {
 public:
-    StreamSet *take(int device, std::string &err)              // (the caller's current device is `device`)
+    // the streams of physical device `device` (the maker is started on first use and runs on by itself)
+    DeviceStreams *get(int device, std::string &err)
     {
-        DecodeStreams *dec = decode_streams(device, err);
-        if (!dec) return nullptr;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            for (size_t i = 0; i < free_.size(); i++) if (free_[i]->device == device) { StreamSet *s = free_[i]; free_.erase(free_.begin() + (long)i); return s; }
-        }
-        std::unique_ptr<StreamSet> s(new StreamSet());
-        s->device = device; s->dec = dec;
-        bool ok = true;
-        {
-            const char *lm = getenv("MF_GZDEV_LINK_MASK");
-            std::vector<uint32_t> m_link(dec->mask.size());
-            for (size_t i = 0; i < m_link.size(); i++) m_link[i] = ~dec->mask[i];
-            if (dec->n_cu % 32) m_link.back() &= (1u << (dec->n_cu % 32)) - 1;
-            if (!dec->masked || (lm && lm[0] == '0') || hipExtStreamCreateWithCUMask(&s->link, dec->words, m_link.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                ok = hipStreamCreateWithFlags(&s->link, hipStreamNonBlocking) == hipSuccess;
-            }
-        }
-        ok = ok && hipStreamCreateWithFlags(&s->rest, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking) == hipSuccess;
-        if (!ok) { err = "hipStreamCreate failed"; return nullptr; }
-        return s.release();
-    }
-    void give(StreamSet *s) { if (s) { std::lock_guard<std::mutex> lk(mu_); free_.push_back(s); } }
-    // Under rocprofv3 a process that still owns CU-masked streams when it exits dies in the profiler's finaliser (SIGSEGV below
-    // __cxa_finalize, after the profile has been written; without a profiler the exit is clean).  So when a profiler is loaded
-    // the streams are destroyed here, at exit, after a device synchronisation -- not otherwise: destroying such a stream was seen to
-    // hang now and then, and an exit that hangs is worse than one a profiler complains about.
-    ~StreamSets()
-    {
-        for (auto &kv : dec_) { kv.second->stop = true; if (kv.second->maker.joinable()) kv.second->maker.join(); }
-        const char *pre = getenv("LD_PRELOAD");
-        const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
-        if (!profiled) return;
-        for (auto &kv : dec_) {
-            if (hipSetDevice(kv.first) != hipSuccess) continue;
-            (void)hipDeviceSynchronize();
-            for (auto &q : kv.second->sd) if (q) (void)hipStreamDestroy(q);
-        }
-        for (StreamSet *s : free_) {
-            if (hipSetDevice(s->device) != hipSuccess) continue;
-            if (s->link) (void)hipStreamDestroy(s->link);
-            if (s->rest) (void)hipStreamDestroy(s->rest);
-            if (s->copy) (void)hipStreamDestroy(s->copy);
-        }
-    }
-private:
-    DecodeStreams *decode_streams(int device, std::string &err)
-    {
-        std::lock_guard<std::mutex> lk(mu_dec_);
-        auto it = dec_.find(device);
-        if (it != dec_.end()) return it->second;
-        std::unique_ptr<DecodeStreams> d(new DecodeStreams());
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = dev_.find(device);
+        if (it != dev_.end()) return it->second;
+        std::unique_ptr<DeviceStreams> d(new DeviceStreams());
         d->device = device;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
@@ -361,19 +390,47 @@ private:
         reserve = std::max(8, std::min(n_cu / 2, reserve)) & ~7;
         d->mask.assign((size_t)words, 0);
         for (int b = 0; b < n_cu - reserve; b++) d->mask[b / 32] |= 1u << (b % 32);
+        d->mask_rest.resize(d->mask.size());
+        for (size_t i = 0; i < d->mask.size(); i++) d->mask_rest[i] = ~d->mask[i];
+        if (n_cu % 32) d->mask_rest.back() &= (1u << (n_cu % 32)) - 1;
         d->words = (uint32_t)words; d->n_cu = n_cu;
         d->masked = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
-        if (!d->make(&d->sd[0])) { err = "hipStreamCreate failed"; return nullptr; }
-        d->n = 1;
-        DecodeStreams *dp = d.release();
-        dp->maker = std::thread([dp] {
-            if (hipSetDevice(dp->device) != hipSuccess) return;
-            for (uint32_t i = 1; i < GZ_NSTREAM && !dp->stop; i++) { if (!dp->make(&dp->sd[i])) return; dp->n = i + 1; }       // (fewer streams: slabs share them)
-        });
-        dec_[device] = dp;
+        DeviceStreams *dp = d.release();
+        dp->maker = std::thread([dp] { dp->run(); });
+        dev_[device] = dp;
         return dp;
     }
-    std::mutex mu_, mu_dec_; std::vector<StreamSet *> free_; std::map<int, DecodeStreams *> dec_;
+    // Under rocprofv3 a process that still owns CU-masked streams when it exits dies in the profiler's finaliser (SIGSEGV below
+    // __cxa_finalize, after the profile has been written; without a profiler the exit is clean).  So when a profiler is loaded
+    // the streams are destroyed here, at exit, after a device synchronisation -- not otherwise: destroying such a stream was seen to
+    // hang now and then, and an exit that hangs is worse than one a profiler complains about.
+    // two staging buffers of the uploader's usual size, pinned on a thread of their own (7 ms each), once per process
+    void prefill_pinned(int device)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (prefill_started_) return;
+        prefill_started_ = true;
+        prefill_ = std::thread([device] { if (hipSetDevice(device) == hipSuccess) g_pinned.prefill(2, ((size_t)32 << 20) + 256); cold_mark("prefetch: staging buffers pinned"); });
+    }
+    ~StreamSets()
+    {
+        if (prefill_.joinable()) prefill_.join();
+        for (auto &kv : dev_) { kv.second->stop = true; if (kv.second->maker.joinable()) kv.second->maker.join(); }
+        const char *pre = getenv("LD_PRELOAD");
+        const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
+        if (!profiled) return;
+        for (auto &kv : dev_) {
+            if (hipSetDevice(kv.first) != hipSuccess) continue;
+            (void)hipDeviceSynchronize();
+            DeviceStreams &D = *kv.second;
+            for (auto &q : D.dec) if (q) (void)hipStreamDestroy(q);
+            for (auto &q : D.post) if (q) (void)hipStreamDestroy(q);
+            for (auto &q : D.post_masked) if (q) (void)hipStreamDestroy(q);
+            if (D.copy) (void)hipStreamDestroy(D.copy);
+        }
+    }
+private:
+    std::mutex mu_; std::map<int, DeviceStreams *> dev_; std::thread prefill_; bool prefill_started_ = false;
 };
 StreamSets g_streams;
 
@@ -395,7 +452,9 @@ struct TextBuf {
     uint8_t *raw = nullptr; size_t raw_bytes = 0;
     uint8_t *p = nullptr; size_t pad = 0, cap = 0;      // p = raw + pad; cap text bytes fit behind p (and 64 more are readable)
     Slots *slots = nullptr;
-    ~TextBuf() { g_pool.put(dev, raw, raw_bytes); if (slots) slots->give(); }
+    hipEvent_t ready = nullptr; bool ready_recorded = false;      // recorded by the producer behind the last kernel that writes the text: a consumer's stream waits for it
+    hipEvent_t ready_event() { if (!ready) { (void)hipSetDevice(dev); if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) ready = nullptr; } ready_recorded = ready != nullptr; return ready; }
+    ~TextBuf() { if (ready) { (void)hipSetDevice(dev); if (ready_recorded) (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); } g_pool.put(dev, raw, raw_bytes); if (slots) slots->give(); }      // (a piece that is dropped unread: whatever still writes it finishes first)
     static hipError_t make(std::unique_ptr<TextBuf> &out, int dev, int ldev, size_t pad, size_t text_bytes, Slots *slots)
     {
         std::unique_ptr<TextBuf> b(new TextBuf());
@@ -416,9 +475,10 @@ struct TextPiece { std::unique_ptr<TextBuf> buf; uint64_t T0 = 0, len = 0; bool 
 // ---- a .gz file's bytes -> the rings of the devices that decode it, in order, a piece at a time.  The slab layout says which
 // devices want which bytes; the producer moves the low-water mark (everything in front of it has been linked) and the uploader
 // keeps within a ring's length of it.  Decode streams wait for the event of the piece that completes the range they read.
+// The thread pins its staging buffers itself and takes the device's copy stream when it is made: a call's set-up does not wait for either.
 class GzUploader {
 public:
-    struct Lane { int dev = 0; uint8_t *ring = nullptr; hipStream_t st = nullptr; };
+    struct Lane { int dev = 0; uint8_t *ring = nullptr; DeviceStreams *ds = nullptr; hipStream_t st = nullptr; };
     ~GzUploader()
     {
         stop_ = true; cv_.notify_all();
@@ -430,16 +490,14 @@ public:
         }
     }
     // piece_lanes[i]: bit l set = lane l wants piece i
-    int start(int fd, size_t n, size_t ring_bytes, size_t piece, std::vector<Lane> lanes, std::vector<uint64_t> piece_lanes, std::string &err)
+    void start(int fd, size_t n, size_t ring_bytes, size_t piece, std::vector<Lane> lanes, std::vector<uint64_t> piece_lanes)
     {
-        n_ = n; ring_ = ring_bytes; piece_ = piece; lanes_ = std::move(lanes); want_ = std::move(piece_lanes);
-        DCHK(stage_.init(piece_, fd));
+        fd_ = fd; n_ = n; ring_ = ring_bytes; piece_ = piece; lanes_ = std::move(lanes); want_ = std::move(piece_lanes);
         ev_.assign(lanes_.size(), std::vector<hipEvent_t>(want_.size(), nullptr));
         free_ev_.assign(lanes_.size(), std::array<hipEvent_t, 2>{nullptr, nullptr});
         stage_used_[0] = stage_used_[1] = 0;
         low_ = 0;
         th_ = std::thread([this] { run(); });
-        return MF_OK;
     }
     void set_low_water(uint64_t byte) { { std::lock_guard<std::mutex> lk(mu_); if (byte > low_) low_ = byte; } cv_.notify_all(); }
     // the copy of bytes [0, upto) has been issued (so wait_for would not block the host)
@@ -450,7 +508,7 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         return failed_ || enqueued_ > (upto - 1) / piece_;
     }
-    // make `st` (a stream of lane l's device) wait until the bytes [.., upto) that lane l wants are in its ring.  false: the uploader failed
+    // make `st` (a stream of lane l's device) wait until the bytes [.., upto) that lane l wants are in its ring.  false: the uploader failed (failure(): why)
     bool wait_for(size_t l, hipStream_t st, size_t upto)
     {
         if (n_ == 0 || upto == 0) return true;
@@ -462,9 +520,12 @@ public:
         while (!((want_[j] >> l) & 1)) { if (!j) return true; j--; }       // (the copy stream is in order: the last piece of this lane at or in front of j)
         return hipStreamWaitEvent(st, ev_[l][j], 0) == hipSuccess;
     }
+    int failure() { std::lock_guard<std::mutex> lk(mu_); return fail_rc_; }
 private:
     void run()
     {
+        if (!lanes_.empty() && hipSetDevice(lanes_[0].dev) != hipSuccess) { fail_(MF_E_HIP); return; }
+        { const hipError_t e = stage_.init(piece_, fd_); if (e != hipSuccess) { fail_(e == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP); return; } }
         const size_t np = want_.size();
         for (size_t i = 0; i < np && !stop_; i++) {
             const size_t off = i * piece_, len = std::min(piece_, n_ - off);
@@ -478,40 +539,44 @@ private:
             const double t_b = now_s();
             const int b = (int)(i & 1);
             for (size_t l = 0; l < lanes_.size(); l++)          // the copies that read this staging buffer are done
-                if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(); return; } }
+                if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(MF_E_HIP); return; } }
             stage_used_[b] = 0;
             const double t_c = now_s();
-            if (!stage_.read(b, off, len)) { fail_(); return; }
+            if (!stage_.read(b, off, len)) { fail_(MF_E_IO); return; }
             t_ring_ += t_b - t_a; t_copy_wait_ += t_c - t_b; t_read_ += now_s() - t_c;
+            if (i == 0) cold_mark("uploader: first piece of the file read into pinned memory");
             size_t total = len;
             if (off + len == n_) { memset(stage_.buf[b] + len, 0, 256); total += 256; }          // readable and zero behind the last byte
             for (size_t l = 0; l < lanes_.size(); l++) {
                 if (!((want_[i] >> l) & 1)) continue;
-                const Lane &L = lanes_[l];
-                if (hipSetDevice(L.dev) != hipSuccess) { fail_(); return; }
-                if (!ev_[l][i] && hipEventCreateWithFlags(&ev_[l][i], hipEventDisableTiming) != hipSuccess) { fail_(); return; }
-                if (!free_ev_[l][b] && hipEventCreateWithFlags(&free_ev_[l][b], hipEventDisableTiming) != hipSuccess) { fail_(); return; }
+                Lane &L = lanes_[l];
+                if (hipSetDevice(L.dev) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (!L.st && !(L.st = L.ds->copy_stream())) { fail_(MF_E_HIP); return; }
+                if (!ev_[l][i] && hipEventCreateWithFlags(&ev_[l][i], hipEventDisableTiming) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (!free_ev_[l][b] && hipEventCreateWithFlags(&free_ev_[l][b], hipEventDisableTiming) != hipSuccess) { fail_(MF_E_HIP); return; }
                 // (a piece never straddles the end of the ring -- the ring is a multiple of the piece --, the zeros behind the file may)
-                const size_t r0 = off & (ring_ - 1), first = std::min(total, ring_ - r0);
-                if (hipMemcpyAsync(L.ring + r0, stage_.buf[b], first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(); return; }
-                if (first < total && hipMemcpyAsync(L.ring, stage_.buf[b] + first, total - first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(); return; }
-                if (hipEventRecord(ev_[l][i], L.st) != hipSuccess || hipEventRecord(free_ev_[l][b], L.st) != hipSuccess) { fail_(); return; }
+                const size_t r0 = ring_mask_off(off), first = std::min(total, ring_ - r0);
+                if (hipMemcpyAsync(L.ring + r0, stage_.buf[b], first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (first < total && hipMemcpyAsync(L.ring, stage_.buf[b] + first, total - first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (hipEventRecord(ev_[l][i], L.st) != hipSuccess || hipEventRecord(free_ev_[l][b], L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
                 stage_used_[b] |= (uint64_t)1 << l;
             }
             { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; }
             cv_.notify_all();
+            if (i == 0) cold_mark("uploader: first copy to the device issued");
         }
-        for (auto &L : lanes_) { if (hipSetDevice(L.dev) == hipSuccess) (void)hipStreamSynchronize(L.st); }
+        for (auto &L : lanes_) { if (L.st && hipSetDevice(L.dev) == hipSuccess) (void)hipStreamSynchronize(L.st); }
     }
-    void fail_() { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; } cv_.notify_all(); }
+    size_t ring_mask_off(size_t off) const { return off & (ring_ - 1); }
+    void fail_(int rc) { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; fail_rc_ = rc; } cv_.notify_all(); }
 public:
     double t_ring_ = 0, t_copy_wait_ = 0, t_read_ = 0;          // the uploader thread's time: waiting for room in the ring, for the copy out of a staging buffer, reading the file
 private:
-    size_t n_ = 0, ring_ = 0, piece_ = 0;
+    size_t n_ = 0, ring_ = 0, piece_ = 0; int fd_ = -1;
     std::vector<Lane> lanes_; std::vector<uint64_t> want_;
     Stager stage_; uint64_t stage_used_[2] = {0, 0};
     std::vector<std::vector<hipEvent_t>> ev_; std::vector<std::array<hipEvent_t, 2>> free_ev_;
-    std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; uint64_t low_ = 0; bool failed_ = false; std::atomic<bool> stop_{false};
+    std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; uint64_t low_ = 0; bool failed_ = false; int fail_rc_ = MF_OK; std::atomic<bool> stop_{false};
 };
 
 // ---- one gzip file decoded on the device(s) (runs on the mate's producer thread, on its own streams)
@@ -522,35 +587,39 @@ public:
         TRACE("~GzStream");
         up_.reset();                                  // (the uploader's copies go to the rings below)
         for (auto &L : lanes_) {                      // nothing of this decoder may be in flight when its buffers go back to the pool
-            if (!L.streams) continue;
+            if (!L.ds) continue;
             (void)hipSetDevice(L.dev);
-            for (uint32_t i = 0, n = L.streams->dec->n.load(); i < n; i++) (void)hipStreamSynchronize(L.streams->dec->sd[i]);      // (the maker thread may still be writing the handles behind n)
-            (void)hipStreamSynchronize(L.streams->link); (void)hipStreamSynchronize(L.streams->rest); (void)hipStreamSynchronize(L.streams->copy);
-            if (L.ev_link) (void)hipEventDestroy(L.ev_link);
+            for (uint32_t i = 0, n = L.ds->n_dec.load(); i < n; i++) (void)hipStreamSynchronize(L.ds->dec[i]);      // (the maker thread may still be writing the handles behind n)
+            if (L.post) (void)hipStreamSynchronize(L.post);
             if (L.ev_base) (void)hipEventDestroy(L.ev_base);
+            if (L.ev_crc) (void)hipEventDestroy(L.ev_crc);
+            for (auto &e : L.ev_list) if (e) (void)hipEventDestroy(e);
         }
-        for (auto &S : slabs_) { (void)hipSetDevice(lanes_[S->lane].dev); if (S->ev) (void)hipEventDestroy(S->ev); if (S->ev0) (void)hipEventDestroy(S->ev0); }
-        if (pend_slab_) { (void)hipSetDevice(lanes_[pend_slab_->lane].dev); if (pend_slab_->ev) (void)hipEventDestroy(pend_slab_->ev); if (pend_slab_->ev0) (void)hipEventDestroy(pend_slab_->ev0); }
-        slabs_.clear(); pend_slab_.reset(); pend_.buf.reset(); cur_buf_.reset();
+        reap(true);
+        for (auto &S : slabs_) drop_events(*S);
+        slabs_.clear(); pend_.buf.reset(); cur_buf_.reset();
         for (auto &L : lanes_) {
-            L.ring.release(); L.d_chunks.release(); L.d_out_off.release(); L.d_chain.release(); L.d_crc.release();
-            if (L.h_crc) { (void)hipSetDevice(L.dev); (void)hipHostFree(L.h_crc); }
-            g_streams.give(L.streams);
+            L.ring.release(); L.d_chunks.release(); L.d_window.release(); L.d_crc.release(); L.d_acc.release(); L.d_acc_off.release(); L.d_link.release();
+            (void)hipSetDevice(L.dev);
+            if (L.h_crc) (void)hipHostFree(L.h_crc);
+            if (L.h_list) (void)hipHostFree(L.h_list);
+            if (L.ds) L.ds->give_post(L.post_slot, L.post);
         }
-        if (h_chain_) (void)hipHostFree(h_chain_);
+        if (h_win_) (void)hipHostFree(h_win_);
+        if (h_chunks_) (void)hipHostFree(h_chunks_);
         TRACE("~GzStream done");
     }
     // data: the mapped file (what the host looks at: headers, trailers, gaps); devices: the logical devices that decode it
     // nslab: slabs whose decode kernels may be in flight per device (enough wavefronts to fill the chip: twelve for one file, seven each for two mates)
+    // large: an input that keeps the chip full of decode wavefronts for a long time (its link streams are the CU-masked ones)
+    // budget: device bytes this mate's decoder may hold in symbol buffers and code lists (what is in flight follows from it; 0: no bound)
     int open(const uint8_t *data, size_t size, int fd, const std::vector<int> &devices, const std::string &path, Slots *slots, size_t carry_room,
-             uint32_t nslab, std::atomic<bool> *stop, std::string &err)
+             uint32_t nslab, bool large, uint64_t budget, std::atomic<bool> *stop, std::string &err)
     {
         uint32_t NSLAB = std::max<uint32_t>(1, (uint32_t)env_u64("MF_GZDEV_SLABS_IN_FLIGHT", nslab));
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
-        // chunks: large enough that the serial link step (a fixed cost per chunk) stays small, small enough that a file keeps the chip busy
-        // (512 KiB chunks halve the link step's share -- 4.5 us a chunk, one after the other -- and lose as much again in the first slab's decode
-        // and in waiting for decode kernels: measured level or slightly behind, profiles/r04)
+        // chunks: large enough that a slab's fixed costs stay small, small enough that a file keeps the chip busy
         size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)256 << 10) & ~(size_t)4095;
         chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", dflt);
         if (chunk_ < 1024) chunk_ = 1024;
@@ -559,6 +628,18 @@ public:
         // slabs in flight are counted in slabs of 512 chunks (the 256 KiB chunks of a large file): what fills the chip is chunks, and a file
         // of a gigabyte, with its smaller chunks and more of them to a slab, would hold twice the symbol room for nothing
         if (!getenv("MF_GZDEV_SLABS_IN_FLIGHT") && cps_ > 512) NSLAB = std::max<uint32_t>(2, (uint32_t)(((uint64_t)NSLAB * 512 + cps_ - 1) / cps_));
+        // The device memory of the path follows the INPUT: what a chunk in flight holds is ~11 bytes of symbol room per compressed byte (16-bit
+        // symbols, 4.5 : 1, a quarter of slack) and 256 KiB of code lists, and a file of a few hundred megabytes must not hold the 20 GB that
+        // twelve slabs of a 5 GB file do (round 4: 28 GB for a 0.6 GB pair).  So the chunks in flight are what the budget pays for -- in slabs
+        // small enough that four or more of them are in flight, so that upload, decode, link and the consumers still overlap.
+        if (budget && !getenv("MF_GZDEV_SLABS_IN_FLIGHT") && !getenv("MF_GZDEV_SLAB_CHUNKS")) {
+            const uint64_t per_chunk = (uint64_t)chunk_ * 11 + ((uint64_t)384 << 10);
+            const uint64_t fit = std::max<uint64_t>(64, budget / per_chunk);                     // chunks in flight the budget allows
+            if ((uint64_t)NSLAB * cps_ > fit) {
+                cps_ = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(cps_, fit / 4));
+                NSLAB = (uint32_t)std::max<uint64_t>(2, fit / cps_);
+            }
+        }
         // symbols of room per compressed byte: a first guess (FASTQ compresses three- to fivefold; the rule adds a chunk's worth, so
         // 3.5 covers 4.5 : 1), then what the file has shown plus a quarter; a slab that overflows is decoded again with four times the room
         expand_ = getenv("MF_GZDEV_EXPAND") ? (double)env_u64("MF_GZDEV_EXPAND", 4) : 3.5;
@@ -597,11 +678,12 @@ public:
                 n = std::min(cps_, n * 2);
             }
         }
-        h_chunks_.resize(n_chunks_);
         const double ts0 = now_s();
-        DCHK(hipHostMalloc((void **)&h_chain_, sizeof(GzChain), hipHostMallocPortable));
-        memset(h_chain_, 0, sizeof(GzChain));
-        h_chain_->cur_bit = (uint64_t)base_byte_ * 8;
+        DCHK(hipHostMalloc((void **)&h_chunks_, (size_t)n_chunks_ * sizeof(GzChunk) + 64, hipHostMallocPortable));
+        memset(h_chunks_, 0, (size_t)n_chunks_ * sizeof(GzChunk));
+        DCHK(hipHostMalloc((void **)&h_win_, GZ_WINDOW, hipHostMallocPortable));
+        memset(h_win_, 0, GZ_WINDOW);
+        link_ = GzLinkState(); link_.cur_bit = (uint64_t)base_byte_ * 8;
         lanes_.resize(nl);
         std::vector<GzUploader::Lane> ul(nl);
         for (uint32_t l = 0; l < nl; l++) {
@@ -609,23 +691,18 @@ public:
             L.ldev = devices[l]; L.dev = phys(devices[l]);
             DCHK(hipSetDevice(L.dev));
             const double tl0 = now_s();
-            L.streams = g_streams.take(L.dev, err);
-            if (!L.streams) return MF_E_HIP;
+            L.ds = g_streams.get(L.dev, err);          // (starts the maker thread if this is the device's first use; nothing here waits for a stream)
+            if (!L.ds) return MF_E_HIP;
+            L.want_masked_post = large;
             t_open_streams_ += now_s() - tl0;
-            DCHK(hipEventCreateWithFlags(&L.ev_link, hipEventDisableTiming));
-            DCHK(hipEventCreate(&L.ev_base)); DCHK(hipEventRecord(L.ev_base, L.streams->rest));
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
-            DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_out_off.need(L.dev, n_chunks_, false)); DCHK(L.d_chain.need(L.dev, 1, false));
-            // (never the null stream: the CU-masked streams are blocking ones, a copy on the null stream would wait for every decode
-            // kernel in flight -- of the other mate's file too)
-            hipStream_t sr = L.streams->rest;
-            DCHK(hipMemsetAsync(L.d_chunks.p, 0, n_chunks_ * sizeof(GzChunk), sr));
-            DCHK(hipMemsetAsync(L.d_out_off.p, 0xFF, n_chunks_ * sizeof(uint64_t), sr));
-            DCHK(hipMemcpyAsync(L.d_chain.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sr));
-            DCHK(hipStreamSynchronize(sr));
-            ul[l].dev = L.dev; ul[l].ring = L.ring.p; ul[l].st = L.streams->copy;
+            DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_window.need(L.dev, GZ_WINDOW, false));
+            DCHK(L.d_acc.need(L.dev, cps_ + 1, false)); DCHK(L.d_acc_off.need(L.dev, cps_ + 1, false)); DCHK(L.d_link.need(L.dev, gz_link_scratch_bytes(cps_), false));
+            DCHK(hipHostMalloc((void **)&L.h_list, (size_t)LIST_SLOTS * (cps_ + 1) * 12, hipHostMallocPortable));
+            L.ev_list.assign(LIST_SLOTS, nullptr);
+            ul[l].dev = L.dev; ul[l].ring = L.ring.p; ul[l].ds = L.ds;
         }
-        chain_lane_ = 0; chain_dirty_ = false;
+        win_dev_ = -1; win_on_host_ = true;
         // which lanes want which pieces of the file
         const size_t np = (size_ + piece_ - 1) / piece_;
         std::vector<uint64_t> want(np, 0);
@@ -635,20 +712,22 @@ public:
         }
         const double tu0 = now_s();
         up_.reset(new GzUploader());
-        const int rc = up_->start(fd, size_, ring_, piece_, ul, want, err);
-        if (rc) return rc;
+        up_->start(fd, size_, ring_, piece_, ul, want);
         t_open_upload_ = now_s() - tu0; t_open_ = now_s() - ts0;
         in_member_ = true;
         TRACE("gz open: %u chunks of %zu B, %zu slabs (<= %u chunks), ring %zu MiB, pieces of %zu KiB, %u slabs in flight, %u lanes", n_chunks_, chunk_, plan_.size(), cps_,
               ring_ >> 20, piece_ >> 10, max_inflight_, nl);
         return MF_OK;
     }
-    // The next piece of text (possibly nothing: out.buf is null).  Marker resolution and the CRC of piece k run while piece k + 1 is
-    // waited for and linked (they are the link step's only neighbours on the producer's critical path), so the piece this returns
-    // is the one BEFORE the piece it has just linked -- nothing the first time, the last piece in a call of its own.
+    // The next piece of text (possibly nothing: out.buf is null).  Nothing here waits for the link, resolve or CRC kernels of a piece: the
+    // piece is handed over with an event (TextPiece::ready) that the consumer's stream waits for; what the producer does wait for is the
+    // decode kernel of the front slab (it needs the chunks' descriptors) and a text buffer.  The piece a call returns is the one BEFORE the
+    // piece it has just linked -- nothing the first time, the last piece in a call of its own -- so that a buffer's slot is asked for with
+    // the previous piece still in hand exactly once (as before: tests of the slot arithmetic rest on it).
     int next(TextPiece &out, std::string &err)
     {
         out = TextPiece();
+        reap(false);
         if (done_ || (slabs_.empty() && next_plan_ >= plan_.size())) return finish_pending(out, err);
         // decode runs ahead of the text: the front slab (waiting for its bytes if need be) and as many of the following ones as the
         // ring has room and uploaded bytes for
@@ -659,14 +738,14 @@ public:
         Slab &S = *slabs_.front();
         Lane &L = lanes_[S.lane];
         DCHK(hipSetDevice(L.dev));
-        hipStream_t sp = L.streams->link, sr = L.streams->rest;
+        rc = lane_post(L, err); if (rc) return rc;
+        hipStream_t sp = L.post;
         if (!S.read_back) {
             TRACE("slab %u..%u on lane %u: waiting for decode", S.lo, S.hi, S.lane);
             const double tw0 = now_s();
-            DCHK(hipStreamWaitEvent(sp, S.ev, 0));
-            DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sp));
-            DCHK(hipStreamSynchronize(sp));
+            DCHK(hipEventSynchronize(S.ev));          // (the descriptors came down on the slab's own decode stream, behind its kernel)
             t_wait_decode_ += now_s() - tw0;
+            if (!first_decoded_) { first_decoded_ = true; cold_mark("producer: first slab decoded"); }
             for (;;) {
                 bool overflow = false;
                 for (uint32_t c = S.lo; c < S.hi; c++) if (h_chunks_[c].status == GZ_OVERFLOW) overflow = true;
@@ -686,9 +765,9 @@ public:
                 S.cap *= 4;
                 TRACE("slab %u..%u overflowed: again with %zu symbols per chunk", S.lo, S.hi, S.cap);
                 DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
-                hipStream_t sd = L.streams->dec->sd[0];
+                hipStream_t sd = L.ds->pick_dec(0);
                 DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, sd));
-                DCHK(hipMemcpyAsync(h_chunks_.data() + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd));
+                DCHK(hipMemcpyAsync(h_chunks_ + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, sd));
                 DCHK(hipStreamSynchronize(sd));
             }
             uint32_t mx = 0;
@@ -696,111 +775,118 @@ public:
             max_sym_seen_ = std::max(max_sym_seen_, mx);
             {   // when its decode kernel ran, on the lane's clock (for the busy time of the decoder)
                 float a_ms = 0, b_ms = 0;
-                if (L.ev_base && hipEventElapsedTime(&a_ms, L.ev_base, S.ev0) == hipSuccess && hipEventElapsedTime(&b_ms, L.ev_base, S.ev) == hipSuccess) L.spans.emplace_back((double)a_ms, (double)b_ms);
+                if (L.ev_base && hipEventElapsedTime(&a_ms, L.ev_base, S.ev0) == hipSuccess && hipEventElapsedTime(&b_ms, L.ev_base, S.ev1) == hipSuccess) L.spans.emplace_back((double)a_ms, (double)b_ms);
                 else (void)hipGetLastError();
             }
             S.read_back = true; S.cur = S.lo;
         }
         // the chunks of this piece: as many of the slab's as make a text buffer of reasonable size
-        const uint32_t a = S.cur; uint32_t b = a; uint64_t sum = 0; uint32_t max_sym = 0;
+        const uint32_t a = S.cur; uint32_t b = a; uint64_t sum = 0;
         while (b < S.hi) {
             const GzChunk &ch = h_chunks_[b];
             const uint64_t n = (ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END) ? ch.n_sym : 0;
             if (b > a && sum + n > text_piece_max_) break;
-            sum += n; max_sym = std::max<uint32_t>(max_sym, (uint32_t)n); b++;
+            sum += n; b++;
         }
         const bool last_piece = b == n_chunks_;
-        const uint64_t T0 = h_chain_->total;
+        const uint64_t T0 = link_.total;
         const double tl0 = now_s();
         TRACE("piece: chunks %u..%u, %llu symbols, text from %llu", a, b, (unsigned long long)sum, (unsigned long long)T0);
         rc = new_text(L, T0, sum + ((size_t)1 << 20), err);
         if (rc) return rc;
         t_newtext_ += now_s() - tl0;
-        // link; the host steps in where the chain stops
-        const uint16_t *sym_a = S.sym.p;             // (the chain and resolve kernels index the slab's symbols from its first chunk)
+        // link; the host steps in where the walk stops
         for (bool first = true;; first = false) {
             if (!done_ && in_member_) {
-                rc = chain_to(S.lane, sp, err); if (rc) return rc;
-                DCHK(launch_gz_chain(L.d_chain.p, L.d_chunks.p, S.lo, b, sym_a, S.cap, L.d_out_off.p, cur_buf_->p, T0, sp));
-                DCHK(hipMemcpyAsync(h_chain_, L.d_chain.p, lanes_.size() > 1 ? sizeof(GzChain) : offsetof(GzChain, window), hipMemcpyDeviceToHost, sp));
+                // which chunks are accepted: a walk over the descriptors, here; the windows: kernels, on the post stream
+                const uint32_t wlen_before = link_.wlen;
+                gz_link_walk(h_chunks_, b, link_, acc_, acc_off_);
+                TRACE("link: %zu chunks accepted, stop %u next %u cur_bit %llu total %llu linked %u", acc_.size(), link_.stop, link_.next, (unsigned long long)link_.cur_bit, (unsigned long long)link_.total, link_.linked);
+                if (!acc_.empty()) {
+                    uint32_t mx = 0;
+                    for (uint32_t c : acc_) mx = std::max(mx, h_chunks_[c].n_sym);
+                    rc = window_to(S.lane, err); if (rc) return rc;
+                    rc = lists_up(L, err); if (rc) return rc;
+                    DCHK(launch_gz_link(L.d_acc.p, L.d_acc_off.p, (uint32_t)acc_.size(), mx, L.d_chunks.p, S.lo, S.sym.p, S.cap, L.d_window.p, wlen_before, L.d_link.p, cur_buf_->p, T0, acc_off_[0], sp));
+                    win_dev_ = (int)S.lane; win_on_host_ = false;
+                    if (lanes_.size() > 1) { rc = window_down(err); if (rc) return rc; }          // (the next slab is linked on another device)
+                }
             }
-            if (first) { const double tf = now_s(); rc = finish_pending(out, err); if (rc) return rc; DCHK(hipSetDevice(L.dev)); t_finish_ += now_s() - tf; }       // (the piece before: its resolve and CRC kernels ran beside this one's decode wait and link)
-            { const double tc = now_s(); if (!done_ && in_member_) DCHK(hipStreamSynchronize(sp)); t_chain_sync_ += now_s() - tc; }
-            TRACE("chain: stop %u next %u cur_bit %llu total %llu linked %u", h_chain_->stop, h_chain_->next, (unsigned long long)h_chain_->cur_bit, (unsigned long long)h_chain_->total, h_chain_->linked);
+            if (first) { const double tf = now_s(); rc = finish_pending(out, err); if (rc) return rc; DCHK(hipSetDevice(L.dev)); t_finish_ += now_s() - tf; }
             if (done_) break;
             uint64_t to_bit = 0;
-            // (behind a member's end the link step goes on with the rest of the piece's chunks, from the next member's first block)
-            if (h_chain_->stop == GZ_STOP_MEMBER_END) { rc = member_end(S, a, b, max_sym, T0, err); if (rc) return rc; if (done_) break; continue; }
-            if (h_chain_->stop == GZ_STOP_GAP) to_bit = h_chunks_[h_chain_->next].start_bit;
-            else if (h_chain_->stop == GZ_STOP_NONE) {
+            // (behind a member's end the walk goes on with the rest of the piece's chunks, from the next member's first block)
+            if (link_.stop == GZ_STOP_MEMBER_END) { rc = member_end(S, T0, err); if (rc) return rc; if (done_) break; continue; }
+            if (link_.stop == GZ_STOP_GAP) to_bit = h_chunks_[link_.next].start_bit;
+            else if (link_.stop == GZ_STOP_NONE) {
                 if (!last_piece) break;
                 to_bit = (uint64_t)size_ * 8;             // behind the last chunk: the host decodes to the end of the member
             }
-            // ---- decode across the gap on the host, with the window the chain left
-            if (lanes_.size() == 1) { DCHK(hipMemcpyAsync(h_chain_->window, L.d_chain.p->window, GZ_WINDOW, hipMemcpyDeviceToHost, sp)); DCHK(hipStreamSynchronize(sp)); }
+            // ---- decode across the gap on the host, with the window behind the accepted data
+            rc = window_down(err); if (rc) return rc;
             std::vector<uint8_t> bytes; uint64_t end_bit = 0; bool mend = false; std::string why;
-            if (!inflate_gap(data_, size_, h_chain_->cur_bit, to_bit, h_chain_->window, h_chain_->wlen, bytes, end_bit, mend, why)) {
+            if (!inflate_gap(data_, size_, link_.cur_bit, to_bit, h_win_, link_.wlen, bytes, end_bit, mend, why)) {
                 err = "gzip read error in " + path_ + ": " + why; return MF_E_FORMAT;
             }
             gap_bytes_ += bytes.size(); n_gaps_++;
             TRACE("gap: %zu bytes, ends at bit %llu (wanted %llu), member end %d", bytes.size(), (unsigned long long)end_bit, (unsigned long long)to_bit, (int)mend);
-            rc = grow_text(L, T0, h_chain_->total + bytes.size() + sum + ((size_t)1 << 20), err);
+            rc = grow_text(L, T0, link_.total + bytes.size() + sum + ((size_t)1 << 20), err);
             if (rc) return rc;
-            if (!bytes.empty()) { DCHK(hipMemcpyAsync(cur_buf_->p + (h_chain_->total - T0), bytes.data(), bytes.size(), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
-            // the window behind the gap
-            if (bytes.size() >= GZ_WINDOW) { memcpy(h_chain_->window, bytes.data() + bytes.size() - GZ_WINDOW, GZ_WINDOW); h_chain_->wlen = GZ_WINDOW; }
+            if (!bytes.empty()) { DCHK(hipMemcpyAsync(cur_buf_->p + (link_.total - T0), bytes.data(), bytes.size(), hipMemcpyHostToDevice, sp)); DCHK(hipStreamSynchronize(sp)); }
+            // the window behind the gap (on the host now: it goes up again before the next link)
+            if (bytes.size() >= GZ_WINDOW) { memcpy(h_win_, bytes.data() + bytes.size() - GZ_WINDOW, GZ_WINDOW); link_.wlen = GZ_WINDOW; }
             else {
-                const size_t keep = std::min<size_t>(h_chain_->wlen, GZ_WINDOW - bytes.size());
-                memmove(h_chain_->window + GZ_WINDOW - keep - bytes.size(), h_chain_->window + GZ_WINDOW - keep, keep);
-                memcpy(h_chain_->window + GZ_WINDOW - bytes.size(), bytes.data(), bytes.size());
-                h_chain_->wlen = (uint32_t)(keep + bytes.size());
+                const size_t keep = std::min<size_t>(link_.wlen, GZ_WINDOW - bytes.size());
+                memmove(h_win_ + GZ_WINDOW - keep - bytes.size(), h_win_ + GZ_WINDOW - keep, keep);
+                memcpy(h_win_ + GZ_WINDOW - bytes.size(), bytes.data(), bytes.size());
+                link_.wlen = (uint32_t)(keep + bytes.size());
             }
-            h_chain_->cur_bit = end_bit; h_chain_->total += bytes.size();
-            if (h_chain_->stop == GZ_STOP_NONE && last_piece && !mend && bytes.empty()) { err = "gzip read error in " + path_ + ": truncated deflate stream"; return MF_E_FORMAT; }
-            h_chain_->stop = mend ? GZ_STOP_MEMBER_END : GZ_STOP_NONE;
-            chain_dirty_ = true;
-            if (mend) { rc = member_end(S, a, b, max_sym, T0, err); if (rc) return rc; if (done_) break; }
+            win_dev_ = -1; win_on_host_ = true;
+            link_.cur_bit = end_bit; link_.total += bytes.size();
+            if (link_.stop == GZ_STOP_NONE && last_piece && !mend && bytes.empty()) { err = "gzip read error in " + path_ + ": truncated deflate stream"; return MF_E_FORMAT; }
+            link_.stop = mend ? GZ_STOP_MEMBER_END : GZ_STOP_NONE;
+            if (mend) { rc = member_end(S, T0, err); if (rc) return rc; if (done_) break; }
         }
         t_link_ += now_s() - tl0;
-        DCHK(hipEventRecord(L.ev_link, sp)); DCHK(hipStreamWaitEvent(sr, L.ev_link, 0));
-        DCHK(launch_gz_resolve(L.d_chunks.p, a, b, sym_a + (size_t)(a - S.lo) * S.cap, S.cap, L.d_out_off.p, cur_buf_->p, T0, max_sym, sr));
-        // the rest of the member's CRC over this piece: launched here, taken in by finish_pending
-        if (h_chain_->total > crc_done_) { rc = crc_launch(L, crc_done_, h_chain_->total, T0, sr, err); if (rc) return rc; }
+        // the rest of the member's CRC over this piece: launched here, taken in when the next one is launched (or at the member's end)
+        if (link_.total > crc_done_) { rc = crc_launch(L, crc_done_, link_.total, T0, sp, err); if (rc) return rc; }
         S.cur = b;
         const bool slab_done = S.cur == S.hi || done_;
         if (last_piece && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
-        pend_.buf = std::move(cur_buf_); pend_.T0 = T0; pend_.len = h_chain_->total - T0; pend_.last = done_;
+        // the piece is text once everything queued on the post stream up to here has run
+        DCHK(hipEventRecord(cur_buf_->ready_event(), sp));
+        pend_.buf = std::move(cur_buf_); pend_.T0 = T0; pend_.len = link_.total - T0; pend_.last = done_;
         pend_.grow = b > a ? std::max(1.0, (double)cps_ / (double)(b - a)) : 1.0;
-        pending_ = true; pend_lane_ = S.lane;
+        pending_ = true;
         if (slab_done) {
-            pend_slab_ = std::move(slabs_.front()); slabs_.pop_front();      // (its symbols are being resolved: kept until finish_pending)
+            // its symbols are being resolved: the slab is kept until the post stream has passed this point
+            Retired R; R.slab = std::move(slabs_.front()); slabs_.pop_front();
+            DCHK(hipEventCreateWithFlags(&R.done, hipEventDisableTiming)); DCHK(hipEventRecord(R.done, sp));
+            R.dev = L.dev;
+            retired_.push_back(std::move(R));
             // what is in front of the next slab has been linked: the ring may take new bytes there
             const uint32_t lo_next = !slabs_.empty() ? slabs_.front()->lo : (next_plan_ < plan_.size() ? plan_[next_plan_].lo : n_chunks_);
             up_->set_low_water(base_byte_ + (uint64_t)lo_next * chunk_);
         }
         return MF_OK;
     }
-    // the piece whose resolve and CRC kernels are in flight becomes text: it goes to `out`
+    // the piece linked by the call before goes to `out` (its kernels may still be running: TextPiece::ready says when it is text)
     int finish_pending(TextPiece &out, std::string &err)
     {
+        (void)err;
         if (!pending_) return MF_OK;
-        Lane &L = lanes_[pend_lane_];
-        DCHK(hipSetDevice(L.dev));
-        DCHK(hipStreamSynchronize(L.streams->rest));
-        crc_finish(L);
-        if (pend_slab_) { if (pend_slab_->ev) (void)hipEventDestroy(pend_slab_->ev); if (pend_slab_->ev0) (void)hipEventDestroy(pend_slab_->ev0); pend_slab_.reset(); }      // (its symbols are text now)
         out = std::move(pend_); pend_ = TextPiece(); pending_ = false;
         return MF_OK;
     }
     bool finished() const { return !pending_ && (done_ || (slabs_.empty() && next_plan_ >= plan_.size())); }
-    uint64_t text_bytes() const { return h_chain_ ? h_chain_->total : 0; }
+    uint64_t text_bytes() const { return link_.total; }
     double launch_seconds() const { return t_launch_; }
     void open_parts(double &all, double &streams, double &uploader) const { all = t_open_; streams = t_open_streams_; uploader = t_open_upload_; }
-    void link_parts(double &newtext, double &finish, double &chain_sync) const { newtext = t_newtext_; finish = t_finish_; chain_sync = t_chain_sync_; }
+    void link_parts(double &newtext, double &finish, double &post_wait) const { newtext = t_newtext_; finish = t_finish_; post_wait = t_post_wait_; }
     double slot_seconds() const { return t_slot_; }
-    // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer and for the piece before to be resolved); the uploader's
+    // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer); the uploader's
     void producer_times(double &wait_decode, double &link, double &up_ring, double &up_copy, double &up_read) const
-    { wait_decode = t_wait_decode_; link = t_link_ + 1000.0 * 0; (void)t_launch_; up_ring = up_ ? up_->t_ring_ : 0; up_copy = up_ ? up_->t_copy_wait_ : 0; up_read = up_ ? up_->t_read_ : 0; }
+    { wait_decode = t_wait_decode_; link = t_link_; up_ring = up_ ? up_->t_ring_ : 0; up_copy = up_ ? up_->t_copy_wait_ : 0; up_read = up_ ? up_->t_read_ : 0; }
     // seconds during which at least one decode kernel of this stream was running on a device, summed over the devices
     double decode_busy_seconds() const
     {
@@ -816,28 +902,59 @@ public:
     }
     uint64_t gap_bytes() const { return gap_bytes_; }
     uint64_t gaps() const { return n_gaps_; }
-    uint64_t chunks_linked() const { return h_chain_ ? h_chain_->linked : 0; }
+    uint64_t chunks_linked() const { return link_.linked; }
     uint32_t chunks() const { return n_chunks_; }
     size_t chunk_bytes() const { return chunk_; }
     size_t ring_bytes() const { return ring_; }
     uint32_t splits() const { return n_splits_; }
 private:
+    static constexpr uint32_t LIST_SLOTS = 4;          // pinned staging for the accepted-chunk lists on their way up: a few link steps may be queued
     struct Lane {
-        int dev = 0, ldev = 0; StreamSet *streams = nullptr; hipEvent_t ev_link = nullptr, ev_base = nullptr; std::vector<std::pair<double, double>> spans;
-        DevBuf<uint8_t> ring; DevBuf<GzChunk> d_chunks; DevBuf<uint64_t> d_out_off; DevBuf<GzChain> d_chain; DevBuf<uint32_t> d_crc;
+        int dev = 0, ldev = 0; DeviceStreams *ds = nullptr; hipStream_t post = nullptr; int post_slot = -1; bool want_masked_post = false;
+        hipEvent_t ev_base = nullptr, ev_crc = nullptr; std::vector<std::pair<double, double>> spans;
+        DevBuf<uint8_t> ring, d_window, d_link; DevBuf<GzChunk> d_chunks; DevBuf<uint32_t> d_crc, d_acc; DevBuf<uint64_t> d_acc_off;
         uint32_t *h_crc = nullptr; size_t h_crc_cap = 0; uint64_t crc_n = 0;      // h_crc: pinned
+        uint8_t *h_list = nullptr; std::vector<hipEvent_t> ev_list; uint32_t list_seq = 0;      // pinned: LIST_SLOTS x {offsets, chunk numbers}
     };
     struct SlabPlan { uint32_t lo, hi, lane; };
     struct Slab {
-        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; DevBuf<uint32_t> lst; size_t cap = 0, limit = 0; hipEvent_t ev = nullptr, ev0 = nullptr;     // lst: the lane-parallel kernel's code lists; ev0 / ev: in front of and behind the slab's decode kernel     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
+        uint32_t lo = 0, hi = 0, lane = 0, cur = 0; DevBuf<uint16_t> sym; DevBuf<uint32_t> lst; size_t cap = 0, limit = 0;
+        hipEvent_t ev = nullptr, ev0 = nullptr, ev1 = nullptr;     // lst: the lane-parallel kernel's code lists; ev0 / ev1: in front of and behind the slab's decode kernel; ev: behind the descriptors' copy to the host     // cap: symbols of room per chunk; limit: bytes of the file on the device when it was launched
         bool launched = false, read_back = false;
     };
+    struct Retired { std::unique_ptr<Slab> slab; hipEvent_t done = nullptr; int dev = 0; };
+    void drop_events(Slab &S) { (void)hipSetDevice(lanes_[S.lane].dev); for (hipEvent_t *e : {&S.ev, &S.ev0, &S.ev1}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; } }
+    // slabs whose symbols the post stream is done with give their buffers back (all: wait for them)
+    void reap(bool all)
+    {
+        while (!retired_.empty()) {
+            Retired &R = retired_.front();
+            (void)hipSetDevice(R.dev);
+            if (all) (void)hipEventSynchronize(R.done);
+            else if (hipEventQuery(R.done) != hipSuccess) { (void)hipGetLastError(); break; }
+            (void)hipEventDestroy(R.done);
+            drop_events(*R.slab);
+            retired_.pop_front();
+        }
+    }
     size_t sym_cap_now() const
     {
         if (expand_fixed_ || !max_sym_seen_) return (size_t)((double)chunk_ * expand_) + 262144;
         // what the largest chunk so far needed, and a quarter; a chunk reads one block past its range (and up to a chunk's worth of
         // stored blocks), which the maximum has seen as well
         return (size_t)max_sym_seen_ + max_sym_seen_ / 4 + 65536;
+    }
+    // the lane's post stream, taken from the device's set when the lane first links (the set's maker may still be at it)
+    int lane_post(Lane &L, std::string &err)
+    {
+        if (L.post) return MF_OK;
+        const double t0 = now_s();
+        L.post = L.ds->take_post(L.want_masked_post, &L.post_slot);
+        t_post_wait_ += now_s() - t0;
+        if (!L.post) { err = "hipStreamCreate failed"; return MF_E_HIP; }
+        DCHK(hipEventCreate(&L.ev_base)); DCHK(hipEventRecord(L.ev_base, L.post));
+        DCHK(hipEventCreateWithFlags(&L.ev_crc, hipEventDisableTiming));
+        return MF_OK;
     }
     int launch_ahead(std::string &err)
     {
@@ -859,25 +976,62 @@ private:
             if (!S.cap) S.cap = sym_cap_now();
             DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
             if (!gz_decode_serial()) DCHK(S.lst.need(L.dev, gz_decode_scratch_bytes(S.hi - S.lo) / 4, false));
-            if (!S.ev) DCHK(hipEventCreate(&S.ev));
+            if (!S.ev) DCHK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
             if (!S.ev0) DCHK(hipEventCreate(&S.ev0));
-            hipStream_t st = L.streams->dec->pick(launch_seq_++);
-            if (!up_->wait_for(S.lane, st, upto)) { err = "upload of " + path_ + " failed"; return MF_E_IO; }
+            if (!S.ev1) DCHK(hipEventCreate(&S.ev1));
+            hipStream_t st = L.ds->pick_dec(launch_seq_++);
+            if (!st) { err = "hipStreamCreate failed"; return MF_E_HIP; }
+            if (!up_->wait_for(S.lane, st, upto)) {
+                const int why = up_->failure();
+                err = why == MF_E_NOMEM ? "hipHostMalloc failed: no pinned memory for the staging buffers of " + path_ : "upload of " + path_ + " failed";
+                return why ? why : MF_E_IO;
+            }
             S.limit = upto;
             DCHK(hipEventRecord(S.ev0, st));
             DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, st));
+            DCHK(hipEventRecord(S.ev1, st));
+            DCHK(hipMemcpyAsync(h_chunks_ + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, st));
             DCHK(hipEventRecord(S.ev, st));
+            if (!first_launched_) { first_launched_ = true; cold_mark("producer: first decode kernel launched"); }
             S.launched = true;
         }
         return MF_OK;
     }
-    // the chain state is on lane l's device (it travels through the host between lanes, and after the host has changed it)
-    int chain_to(uint32_t l, hipStream_t sp, std::string &err)
+    // the accepted chunks of this link step -> the lane's device lists (through a slot of pinned staging: a few steps may be queued)
+    int lists_up(Lane &L, std::string &err)
     {
-        if (l == chain_lane_ && !chain_dirty_) return MF_OK;
-        DCHK(hipMemcpyAsync(lanes_[l].d_chain.p, h_chain_, sizeof(GzChain), hipMemcpyHostToDevice, sp));
-        DCHK(hipStreamSynchronize(sp));
-        chain_lane_ = l; chain_dirty_ = false;
+        const uint32_t slot = L.list_seq++ % LIST_SLOTS, n = (uint32_t)acc_.size();
+        if (L.ev_list[slot]) DCHK(hipEventSynchronize(L.ev_list[slot])); else DCHK(hipEventCreateWithFlags(&L.ev_list[slot], hipEventDisableTiming));
+        uint8_t *h = L.h_list + (size_t)slot * (cps_ + 1) * 12;
+        memcpy(h, acc_off_.data(), (size_t)n * 8); memcpy(h + (size_t)(cps_ + 1) * 8, acc_.data(), (size_t)n * 4);
+        DCHK(hipMemcpyAsync(L.d_acc_off.p, h, (size_t)n * 8, hipMemcpyHostToDevice, L.post));
+        DCHK(hipMemcpyAsync(L.d_acc.p, h + (size_t)(cps_ + 1) * 8, (size_t)n * 4, hipMemcpyHostToDevice, L.post));
+        DCHK(hipEventRecord(L.ev_list[slot], L.post));
+        return MF_OK;
+    }
+    // the window is on lane l's device (it travels through the host between lanes, and after the host has decoded across a gap)
+    int window_to(uint32_t l, std::string &err)
+    {
+        if (win_dev_ == (int)l) return MF_OK;
+        int rc = window_down(err); if (rc) return rc;
+        Lane &L = lanes_[l];
+        DCHK(hipSetDevice(L.dev));
+        DCHK(hipMemcpyAsync(L.d_window.p, h_win_, GZ_WINDOW, hipMemcpyHostToDevice, L.post));
+        DCHK(hipStreamSynchronize(L.post));          // (h_win_ is the host's to change again)
+        win_dev_ = (int)l;
+        return MF_OK;
+    }
+    // ... and on the host
+    int window_down(std::string &err)
+    {
+        if (win_on_host_) return MF_OK;
+        Lane &W = lanes_[(size_t)win_dev_];
+        int cur = -1; (void)hipGetDevice(&cur);
+        DCHK(hipSetDevice(W.dev));
+        DCHK(hipMemcpyAsync(h_win_, W.d_window.p, GZ_WINDOW, hipMemcpyDeviceToHost, W.post));
+        DCHK(hipStreamSynchronize(W.post));
+        if (cur >= 0 && cur != W.dev) DCHK(hipSetDevice(cur));
+        win_on_host_ = true;
         return MF_OK;
     }
     // a fresh buffer for the piece that begins at text offset T0
@@ -889,7 +1043,7 @@ private:
         t_slot_ += now_s() - ts;
         DCHK(TextBuf::make(cur_buf_, L.dev, L.ldev, pad_, text_bytes, slots_));
         // (a damaged stream may point a full window back from the first byte of the text: zeros there, ahead of the link step on its stream)
-        DCHK(hipMemsetAsync(cur_buf_->p - TEXT_FRONT, 0, TEXT_FRONT, L.streams->link));
+        DCHK(hipMemsetAsync(cur_buf_->p - TEXT_FRONT, 0, TEXT_FRONT, L.post));
         return MF_OK;
     }
     // ... holds at least `need_abs - T0` bytes (what is in it moves along)
@@ -898,9 +1052,8 @@ private:
         if (need_abs - T0 <= cur_buf_->cap) return MF_OK;
         std::unique_ptr<TextBuf> nb;
         DCHK(TextBuf::make(nb, L.dev, L.ldev, pad_, (size_t)((need_abs - T0) + (need_abs - T0) / 2), nullptr));
-        const uint64_t have = h_chain_->total - T0;
-        hipStream_t sr = L.streams->rest;
-        DCHK(hipMemcpyAsync(nb->raw, cur_buf_->raw, cur_buf_->pad + have, hipMemcpyDeviceToDevice, sr)); DCHK(hipStreamSynchronize(sr));
+        const uint64_t have = link_.total - T0;
+        DCHK(hipMemcpyAsync(nb->raw, cur_buf_->raw, cur_buf_->pad + have, hipMemcpyDeviceToDevice, L.post)); DCHK(hipStreamSynchronize(L.post));
         nb->slots = cur_buf_->slots; cur_buf_->slots = nullptr;          // (the slot moves to the new buffer)
         cur_buf_ = std::move(nb);
         return MF_OK;
@@ -924,46 +1077,48 @@ private:
         err = "gzip read error in " + path_ + ": truncated gzip header";
         return false;
     }
-    // the chain stands behind the final block of a member: check the trailer, look for another member
-    int member_end(Slab &S, uint32_t a, uint32_t b, uint32_t max_sym, uint64_t T0, std::string &err)
+    // the accepted data ends behind the final block of a member: check the trailer, look for another member
+    int member_end(Slab &S, uint64_t T0, std::string &err)
     {
         Lane &L = lanes_[S.lane];
-        hipStream_t sp = L.streams->link, sr = L.streams->rest;
-        const size_t pos = (size_t)((h_chain_->cur_bit + 7) >> 3);
+        hipStream_t sp = L.post;
+        const size_t pos = (size_t)((link_.cur_bit + 7) >> 3);
         if (pos + 8 > size_) { err = "gzip read error in " + path_ + ": truncated gzip trailer"; return MF_E_FORMAT; }
         uint32_t want_crc, want_len; memcpy(&want_crc, data_ + pos, 4); memcpy(&want_len, data_ + pos + 4, 4);
-        // CRC of the member's text up to here (the resolve kernel has not run yet for this piece: do it for what is accepted)
-        DCHK(hipEventRecord(L.ev_link, sp)); DCHK(hipStreamWaitEvent(sr, L.ev_link, 0));
-        DCHK(launch_gz_resolve(L.d_chunks.p, a, b, S.sym.p + (size_t)(a - S.lo) * S.cap, S.cap, L.d_out_off.p, cur_buf_->p, T0, max_sym, sr));
-        if (h_chain_->total > crc_done_) { const int rc = crc_launch(L, crc_done_, h_chain_->total, T0, sr, err); if (rc) return rc; }
-        DCHK(hipStreamSynchronize(sr));
+        // CRC of the member's text up to here (everything of it is queued on the post stream: link, resolve, the bytes of a gap)
+        if (link_.total > crc_done_) { const int rc = crc_launch(L, crc_done_, link_.total, T0, sp, err); if (rc) return rc; }
+        if (crc_out_ >= 0 && crc_out_ != (int)S.lane) { Lane &O = lanes_[(size_t)crc_out_]; DCHK(hipSetDevice(O.dev)); DCHK(hipEventSynchronize(O.ev_crc)); crc_finish(O); DCHK(hipSetDevice(L.dev)); }
+        DCHK(hipStreamSynchronize(sp));
         crc_finish(L);
         TRACE("member end: crc %08x want %08x", crc_, want_crc);
         if (crc_ != want_crc) { err = "gzip read error in " + path_ + ": incorrect data check"; return MF_E_FORMAT; }
-        if ((uint32_t)(h_chain_->total - member_T0_) != want_len) { err = "gzip read error in " + path_ + ": incorrect length check"; return MF_E_FORMAT; }
-        crc_ = 0; member_T0_ = h_chain_->total;
+        if ((uint32_t)(link_.total - member_T0_) != want_len) { err = "gzip read error in " + path_ + ": incorrect length check"; return MF_E_FORMAT; }
+        crc_ = 0; member_T0_ = link_.total;
         size_t p = pos + 8;
         if (p >= size_ || size_ - p < 2 || data_[p] != 0x1f || data_[p + 1] != 0x8b) { done_ = true; in_member_ = false; return MF_OK; }   // trailing bytes that are no member: ignored
         if (!member_header(p, err)) return MF_E_FORMAT;
-        h_chain_->cur_bit = (uint64_t)p * 8; h_chain_->wlen = 0; h_chain_->stop = GZ_STOP_NONE;
-        chain_dirty_ = true;
-        return chain_to(S.lane, sp, err);
+        // (a new member begins with an empty window: whatever holds the old one is out of date)
+        link_.cur_bit = (uint64_t)p * 8; link_.wlen = 0; link_.stop = GZ_STOP_NONE;
+        memset(h_win_, 0, GZ_WINDOW); win_dev_ = -1; win_on_host_ = true;
+        return MF_OK;
     }
     // running CRC of the member over the text [from, to) of the current piece: the kernel and the copy of its piece CRCs (crc_launch),
     // the combination on the host (crc_finish)
     int crc_launch(Lane &L, uint64_t from, uint64_t to, uint64_t T0, hipStream_t st, std::string &err)
     {
-        if (L.crc_n) { DCHK(hipStreamSynchronize(st)); crc_finish(L); }        // (an earlier launch on this stream that nobody has taken in)
+        // the launch before this one -- on whichever lane: a member's CRC is combined in text order -- is taken in first (its results have long come down)
+        if (crc_out_ >= 0) { Lane &O = lanes_[(size_t)crc_out_]; if (O.dev != L.dev) DCHK(hipSetDevice(O.dev)); DCHK(hipEventSynchronize(O.ev_crc)); crc_finish(O); if (O.dev != L.dev) DCHK(hipSetDevice(L.dev)); }
         const uint64_t n = to - from;
         const size_t np = (size_t)((n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
         DCHK(L.d_crc.need(L.dev, np));
         if (np > L.h_crc_cap) { if (L.h_crc) (void)hipHostFree(L.h_crc); L.h_crc = nullptr; L.h_crc_cap = 0; DCHK(hipHostMalloc((void **)&L.h_crc, (np + np / 2 + 64) * 4, hipHostMallocDefault)); L.h_crc_cap = np + np / 2 + 64; }
         DCHK(launch_gz_crc(cur_buf_->p + (from - T0), n, L.d_crc.p, st));
         DCHK(hipMemcpyAsync(L.h_crc, L.d_crc.p, np * 4, hipMemcpyDeviceToHost, st));
-        L.crc_n = n; crc_done_ = to;
+        DCHK(hipEventRecord(L.ev_crc, st));
+        L.crc_n = n; crc_done_ = to; crc_out_ = (int)(&L - lanes_.data());
         return MF_OK;
     }
-    void crc_finish(Lane &L) { if (L.crc_n) { crc_ = gz_crc_combine(crc_, gz_crc_finish(L.h_crc, L.crc_n), L.crc_n); L.crc_n = 0; } }      // (the stream of crc_launch has been synchronised)
+    void crc_finish(Lane &L) { if (L.crc_n) { crc_ = gz_crc_combine(crc_, gz_crc_finish(L.h_crc, L.crc_n), L.crc_n); L.crc_n = 0; } crc_out_ = -1; }      // (the copy of crc_launch has completed)
 
     const uint8_t *data_ = nullptr; size_t size_ = 0; std::string path_; Slots *slots_ = nullptr; size_t pad_ = TEXT_FRONT; std::atomic<bool> *stop_ = nullptr;
     size_t chunk_ = 0, base_byte_ = 0, margin_ = 0, ring_ = 0, piece_ = 0; double expand_ = 6; bool expand_fixed_ = false; uint32_t max_sym_seen_ = 0;
@@ -971,15 +1126,17 @@ private:
     uint32_t cps_ = 0, n_chunks_ = 0, max_inflight_ = 1, launch_seq_ = 0, n_splits_ = 0;
     std::vector<Lane> lanes_; std::vector<SlabPlan> plan_; size_t next_plan_ = 0;
     std::deque<std::unique_ptr<Slab>> slabs_;          // launched or waiting, in stream order; front = being linked
+    std::deque<Retired> retired_;                      // linked, their symbols on their way to becoming text
     std::unique_ptr<GzUploader> up_;
-    GzChain *h_chain_ = nullptr; uint32_t chain_lane_ = 0; bool chain_dirty_ = false;      // h_chain_: pinned; the master copy between link steps
-    std::vector<GzChunk> h_chunks_;
+    GzLinkState link_; uint8_t *h_win_ = nullptr; int win_dev_ = -1; bool win_on_host_ = true;      // h_win_: pinned, the window when the host has it; win_dev_: the lane whose d_window is current (-1: none)
+    std::vector<uint32_t> acc_; std::vector<uint64_t> acc_off_;
+    GzChunk *h_chunks_ = nullptr;                      // pinned: every chunk's descriptor, copied down behind its slab's decode kernel
     std::unique_ptr<TextBuf> cur_buf_;
-    TextPiece pend_; bool pending_ = false; uint32_t pend_lane_ = 0; std::unique_ptr<Slab> pend_slab_;
+    TextPiece pend_; bool pending_ = false;
     double t_open_ = 0, t_open_streams_ = 0, t_open_upload_ = 0;
-    bool in_member_ = false, done_ = false;
-    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0;
-    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_finish_ = 0, t_chain_sync_ = 0, t_slot_ = 0;
+    bool in_member_ = false, done_ = false, first_launched_ = false, first_decoded_ = false;
+    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0; int crc_out_ = -1;      // crc_out_: the lane whose CRC launch has not been taken in yet
+    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_finish_ = 0, t_post_wait_ = 0, t_slot_ = 0;
 };
 
 // ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
@@ -1205,18 +1362,22 @@ struct Ingest {
         M.cv.notify_all(); cv_all.notify_all();
     }
 
-    // a plain file is its own text: slabs of it are read straight into text buffers, dealt to the devices round robin
+    // a plain file is its own text: slabs of it are read straight into text buffers, dealt to the devices round robin.  Nothing but the
+    // link to the device should bound this: the file's bytes go through three pinned staging buffers (the stager's own threads read
+    // the next while the copies of the two before are in flight) onto the device's copy stream, and a slab is handed over the moment
+    // its last copy has been ISSUED -- the consumer's stream waits for the copy (TextBuf::ready), the producer does not.
     int plain_producer(Mate &M, std::string &err)
     {
         const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)256 << 20), 64);
         const size_t piece = (size_t)std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>(slab, 4096));
+        constexpr int NBUF = 3;
         Stager stg;
         DCHK(hipSetDevice(phys(devices[0])));
-        DCHK(stg.init(piece, M.map.fd));
-        struct PerDev { hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+        DCHK(stg.init(piece, M.map.fd, NBUF));
+        struct PerDev { DeviceStreams *ds = nullptr; hipStream_t st = nullptr; hipEvent_t ev[NBUF] = {}; };
         std::vector<PerDev> pd(devices.size());
-        struct Cleanup { std::vector<PerDev> &pd; const std::vector<int> &devs; ~Cleanup() { for (size_t i = 0; i < pd.size(); i++) { (void)hipSetDevice(phys(devs[i])); for (auto &e : pd[i].ev) if (e) (void)hipEventDestroy(e); if (pd[i].st) { (void)hipStreamSynchronize(pd[i].st); (void)hipStreamDestroy(pd[i].st); } } } } cleanup{pd, devices};
-        uint64_t n_piece = 0; int used_by[2] = {-1, -1};
+        struct Cleanup { std::vector<PerDev> &pd; const std::vector<int> &devs; ~Cleanup() { for (size_t i = 0; i < pd.size(); i++) { (void)hipSetDevice(phys(devs[i])); if (pd[i].st) (void)hipStreamSynchronize(pd[i].st); for (auto &e : pd[i].ev) if (e) (void)hipEventDestroy(e); } } } cleanup{pd, devices};
+        uint64_t n_piece = 0; int used_by[NBUF]; for (auto &u : used_by) u = -1;
         uint64_t s = 0;
         for (uint64_t T0 = 0; T0 < M.map.n && !M.stop; s++) {
             const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
@@ -1224,20 +1385,24 @@ struct Ingest {
             const int ldev = devices[li], dev = phys(ldev);
             DCHK(hipSetDevice(dev));
             PerDev &P = pd[li];
-            if (!P.st) { DCHK(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking)); for (auto &e : P.ev) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+            if (!P.st) {
+                P.ds = g_streams.get(dev, err); if (!P.ds) return MF_E_HIP;
+                P.st = P.ds->copy_stream(); if (!P.st) { err = "hipStreamCreate failed"; return MF_E_HIP; }
+                for (auto &e : P.ev) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
             if (!M.slots.take()) break;
             TextPiece t;
             DCHK(TextBuf::make(t.buf, dev, ldev, TEXT_FRONT + carry_room, (size_t)(T1 - T0), &M.slots));
             for (uint64_t off = T0; off < T1; off += piece, n_piece++) {
-                const int b = (int)(n_piece & 1);
+                const int b = (int)(n_piece % NBUF);
                 if (used_by[b] >= 0) { const size_t lj = (size_t)used_by[b]; DCHK(hipSetDevice(phys(devices[lj]))); DCHK(hipEventSynchronize(pd[lj].ev[b])); DCHK(hipSetDevice(dev)); }
                 const size_t len = (size_t)std::min<uint64_t>(piece, T1 - off);
                 if (!stg.read(b, (size_t)off, len)) { err = "read error on " + M.path; return MF_E_IO; }
-                DCHK(hipMemcpyAsync(t.buf->p + (off - T0), stg.buf[b], len, hipMemcpyHostToDevice, P.st));
+                DCHK(hipMemcpyAsync(t.buf->p + (off - T0), stg.buf[(size_t)b], len, hipMemcpyHostToDevice, P.st));
                 DCHK(hipEventRecord(P.ev[b], P.st));
                 used_by[b] = (int)li;
             }
-            DCHK(hipStreamSynchronize(P.st));
+            DCHK(hipEventRecord(t.buf->ready_event(), P.st));
             t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n;
             publish(M, std::move(t));
             T0 = T1;
@@ -1275,6 +1440,7 @@ struct Ingest {
         DevScratch &S = *Sp;
         const int dev = S.dev;
         hipStream_t sp = S.ctx->stream;
+        if (P.buf->ready_recorded) DCHK(hipStreamWaitEvent(sp, P.buf->ready, 0));          // (the piece's link, resolve and CRC kernels may still be running)
         // the carry in front of the piece's text.  It fits the room in front of the buffer -- or the piece moves to a buffer that
         // holds both (records longer than the room: tests, mostly)
         if (M.carry > P.buf->pad) {
@@ -1621,7 +1787,11 @@ struct Ingest {
         QualState &Q = *qual;
         const int dev = S.dev; hipStream_t sp = S.ctx->stream;
         if (!Q.dd_slots) {
-            uint64_t lg = env_u64("MF_DEDUP_LOG2_SLOTS", 24);
+            // (as many slots as four times the records the input is likely to hold, at most 2^24 to begin with: the set doubles as it fills)
+            uint64_t text_est = 0;
+            for (int i = 0; i < nm; i++) text_est += m[i].gz ? m[i].map.n * 4 : m[i].map.n;
+            uint64_t lg_est = 16; while (lg_est < 24 && ((uint64_t)1 << lg_est) < text_est / (uint64_t)nm / 300 * 4) lg_est++;
+            uint64_t lg = env_u64("MF_DEDUP_LOG2_SLOTS", lg_est);
             lg = std::min<uint64_t>(std::max<uint64_t>(lg, 4), 34);
             Q.dd_slots = (uint64_t)1 << lg;
             DCHK(Q.dd_keys.need(dev, Q.dd_slots, false)); DCHK(Q.dd_first.need(dev, Q.dd_slots, false));
@@ -1956,7 +2126,12 @@ struct Ingest {
     int run(std::string &err)
     {
         for (int i = 0; i < nm; i++) m[i].prod = std::thread([this, i] { producer(m[i]); });
-        const int nw = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, env_u64("MF_INGEST_CONSUMERS", qual ? 6 : 3)));          // (the quality filter's consumers spend their time writing)
+        // consumers: three (the quality filter's, which spend their time writing: six) -- fewer for an input so small that a second
+        // consumer's set-up (a stream, a read set) would take longer than the first one needs for the whole of it
+        uint64_t text_est = 0;
+        for (int i = 0; i < nm; i++) text_est += m[i].gz ? m[i].map.n * 4 : m[i].map.n;
+        const uint64_t by_size = 1 + text_est / ((uint64_t)192 << 20);
+        const int nw = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, env_u64("MF_INGEST_CONSUMERS", std::min<uint64_t>(qual ? 6 : 3, by_size))));
         for (int w = 0; w < nw; w++) { workers.emplace_back(new Worker()); workers.back()->id = w; }
         for (auto &W : workers) { Worker *wp = W.get(); wp->th = std::thread([this, wp] { if (qual) consume_q(*wp); else consume(*wp); }); }
         for (auto &W : workers) W->th.join();
@@ -1981,14 +2156,16 @@ bool alloc_failure(int rc) { return rc == MF_E_NOMEM; }
 // what the two jobs of this path share: is it an input for the path, set-up, the run, what the caller learns about it
 static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *out1, const char *out2, std::string &err, IngestStats *stats)
 {
-    // (declared first: runs after everything of this call is gone.  What a process keeps between calls: up to MF_DEVPOOL_GB per device, default 24 --
-    // a call on a file of gigabytes holds 17-24 GB, and a process that filters file after file should not give them back and ask for them again)
+    // (declared first: runs after everything of this call is gone.  What a process keeps between calls: up to MF_DEVPOOL_GB per device, default 8
+    // -- enough for a caller that filters file after file of up to a gigabyte or two never to ask the runtime twice; a call on a file of several
+    // gigabytes holds up to 20 GB and gives the rest back: hipMalloc of gigabytes takes a millisecond on this runtime (profiles/r05/a_cold_calls_before.log),
+    // and a process that sits on 24 GB between calls, as round 4's did, is a poor neighbour on a shared GPU.  mf_release_cached() gives back all of it.)
     struct EndOfCall {
         bool timing = false; double t0 = 0;
         ~EndOfCall()
         {
             const char *kb = getenv("MF_KEEP_BUFFERS");
-            g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 24) << 30);
+            g_pool.trim(kb && kb[0] == '0' ? 0 : (size_t)env_u64("MF_DEVPOOL_GB", 8) << 30);
             if (timing) fprintf(stderr, "[mf device ingest] streams, threads and buffers of the call put away in %.3f s\n", now_s() - t0);
         }
     } end_of_call;
@@ -2013,6 +2190,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
         }
     }
     cold_mark("device ingest: inputs mapped");
+    for (int d : I.devices) ingest_prefetch(d);          // (the streams' maker and the staging buffers: started now if nobody has yet)
     for (int d : I.devices) { DevCtx *c = nullptr; const int rc = get_ctx(d, &c, 0); if (rc) { err = mf_thread_error(); return rc; } }
     cold_mark("device ingest: device contexts ready");
     const double t_begin = now_s();
@@ -2022,14 +2200,25 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     // filter's pieces wait longer: their text is written out)
     const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", I.qual ? 8 : 6)) + (int)I.devices.size() - 1;
     int rc = MF_OK;
-    {   // (the two mates' decoders side by side: most of it is making streams and pinning staging buffers)
+    // an input that keeps the chip full of decode wavefronts for a long time gets the CU-masked link streams (they are made late: a small
+    // file must not wait for them)
+    uint64_t gz_bytes = 0;
+    for (int i = 0; i < I.nm; i++) if (I.m[i].gz) gz_bytes += I.m[i].map.n;
+    const bool large = gz_bytes >= ((uint64_t)1 << 30) && !getenv("MF_GZDEV_PLAIN_POST");
+    // Device memory follows the input: 6 bytes per compressed byte of the call, at least 3 GB, at most 20 (MF_INGEST_BUDGET_GB sets it); of
+    // that, 45 % go to the decoders' symbol buffers and code lists (shared by the mates), the rest is rings, text buffers, the
+    // consumers' read sets and line indexes, which follow the slab size the decoders settle on.
+    const uint64_t budget = getenv("MF_INGEST_BUDGET_GB") ? env_u64("MF_INGEST_BUDGET_GB", 20) << 30
+                                                         : std::min<uint64_t>((uint64_t)20 << 30, std::max<uint64_t>((uint64_t)3 << 30, 6 * gz_bytes));
+    const uint64_t gz_budget = budget * 45 / 100 / (uint64_t)I.nm;
+    {   // (the two mates' decoders side by side)
         int rcs[2] = {MF_OK, MF_OK}; std::string errs[2]; std::thread th[2];
         for (int i = 0; i < I.nm; i++) {
             Mate &M = I.m[i];
             M.slots.free_ = text_bufs; M.slots.stop = &M.stop;
             if (!M.gz) continue;
             M.gzs.reset(new GzStream());
-            auto open = [&I, &M, &rcs, &errs, i] { rcs[i] = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, &M.stop, errs[i]); };
+            auto open = [&I, &M, &rcs, &errs, i, large, gz_budget] { rcs[i] = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, large, gz_budget, &M.stop, errs[i]); };
             if (i == 0 && I.nm == 2 && I.m[1].gz == false) open(); else if (i == 0 && I.nm == 2) th[0] = std::thread(open); else open();
         }
         for (auto &t : th) if (t.joinable()) t.join();
@@ -2077,7 +2266,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);
                               { double oa, os, ou; I.m[i].gzs->open_parts(oa, os, ou); fprintf(stderr, "; set-up %.3f (streams %.3f, uploader's buffers and thread %.3f)", oa, os, ou); }
-                              double x, y, z; I.m[i].gzs->link_parts(x, y, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f, waiting for the piece before to be resolved and checked %.3f, waiting for the chain kernel %.3f)", x, I.m[i].gzs->slot_seconds(), y, z); }
+                              double x, y, z; I.m[i].gzs->link_parts(x, y, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f, handing the piece before over %.3f; waiting for the post stream to be made %.3f)", x, I.m[i].gzs->slot_seconds(), y, z); }
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) fprintf(stderr, " | mate %d: inflate kernels busy %.3f s (%.1f GB/s of text), %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, I.m[i].gzs->decode_busy_seconds(), I.m[i].gzs->decode_busy_seconds() > 0 ? (double)I.m[i].gzs->text_bytes() / I.m[i].gzs->decode_busy_seconds() / 1e9 : 0.0, (unsigned long long)I.m[i].gzs->chunks_linked(),
                                     I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes(), I.m[i].gzs->ring_bytes() >> 20, I.m[i].gzs->splits());
@@ -2118,6 +2307,17 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
     if (total) *total = I.total;
     if (panicked) *panicked = Q.panicked;
     return MF_OK;
+}
+
+void ingest_prefetch(int device)
+{
+    const int dev = phys(device);
+    int cur = -1; (void)hipGetDevice(&cur);
+    if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::string err;
+    (void)g_streams.get(dev, err);
+    g_streams.prefill_pinned(dev);
+    if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
 }
 
 size_t release_cached_device_memory(bool all)

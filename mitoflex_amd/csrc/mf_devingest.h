@@ -35,4 +35,9 @@ struct QualParams;
 int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, const char *out2, const QualParams &P, int device, uint64_t *kept,
                           uint64_t *total, bool *panicked, std::string &err, IngestStats *stats = nullptr);
 
+// What a file-level call's set-up needs of (logical) device `device` is started in the background: the maker thread of the device's
+// streams, two pinned staging buffers.  Returns at once; calling it again is free.  (mf_set_option("expect_files", "1") makes the library
+// call it when a device's first context is made.)
+void ingest_prefetch(int device);
+
 } // namespace mf

@@ -6,15 +6,17 @@
 //     64 bit offsets are tested per step, one per lane -- and decodes from there up to the first block boundary at or behind
 //     the start of the next chunk's range, into 16-bit symbols: a byte, or MARK | index where a match reaches back into the
 //     32 KiB the chunk cannot know;
-//   * gz_chain_kernel (one workgroup) walks the chunks in order: a chunk is accepted only if it began exactly where the
-//     accepted data ends -- by induction from chunk 0 every accepted chunk starts at a true block boundary -- gives it its
-//     place in the text and resolves the last 32 KiB of its symbols, which are the window of the chunk behind it;
-//   * gz_resolve_kernel turns every other symbol into a byte, in parallel, reading the windows the chain left in the text.
-// Whatever does not link (a stored or fixed block at a seam, a false candidate, a member boundary) stops the chain with the
-// exact bit position and window; the host decodes across the gap with its serial decoder and restarts the chain.
+//   * the chunks are LINKED in order: a chunk is accepted only if it began exactly where the accepted data ends -- by induction
+//     from chunk 0 every accepted chunk starts at a true block boundary.  That walk reads descriptors only and runs on the host
+//     (gz_link_walk); the windows -- a chunk's markers point into the resolved last 32 KiB of the chunk before it -- are a scan
+//     over the chunks, done on the device in two levels (launch_gz_link), nothing of it one chunk at a time;
+//   * gz_resolve_kernel turns every other symbol into a byte, in parallel, reading the windows the link left in the text.
+// Whatever does not link (a stored or fixed block at a seam, a false candidate, a member boundary) stops the walk with the
+// exact bit position; the host decodes across the gap with its serial decoder (and the window) and the walk goes on.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace mf {
 
@@ -51,32 +53,60 @@ hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t
 size_t gz_decode_scratch_bytes(uint32_t n_chunks);
 bool gz_decode_serial();
 
-// ---- linking the chunks (one workgroup, in stream order) and turning symbols into text
+// ---- linking the chunks and turning symbols into text
 enum GzStop : uint32_t {
     GZ_STOP_NONE = 0,       // every chunk of the range was looked at
     GZ_STOP_GAP = 1,        // chunk `next` does not begin where the accepted data ends (or has no data): the host decodes across the gap
     GZ_STOP_MEMBER_END = 2  // the chunk before `next` ended behind the final block of a member (cur_bit: first bit behind it)
 };
-struct GzChain {
-    uint64_t cur_bit;       // block boundary where the accepted data ends
-    uint64_t total;         // bytes of text accepted so far (offset of the next byte in the member's text)
-    uint32_t next;          // first chunk not yet accepted or discarded
-    uint32_t stop;          // GzStop
-    uint32_t linked, discarded;
-    uint32_t wlen, pad;     // valid bytes in `window` (right-aligned)
-    uint8_t window[GZ_WINDOW];   // the last 32 KiB of accepted text
+// Where the accepted data of a stream ends.  The state lives on the HOST (it is a few scalars; the walk over a slab's descriptors that
+// moves it is gz_link_walk below); the one thing that lives on the device is the window -- the last 32 KiB of accepted text, which the
+// link kernels read and leave behind (d_window of launch_gz_link) and which comes down only when the host has to decode across a gap
+// or the next slab is linked on another device.
+struct GzLinkState {
+    uint64_t cur_bit = 0;   // block boundary where the accepted data ends
+    uint64_t total = 0;     // bytes of text accepted so far (offset of the next byte in the stream's text)
+    uint32_t next = 0;      // first chunk not yet accepted or discarded
+    uint32_t stop = 0;      // GzStop
+    uint32_t linked = 0, discarded = 0;
+    uint32_t wlen = 0;      // valid bytes of the window (right-aligned)
 };
-// Walks chunks [chain->next, chunk_hi) in order.  A chunk is accepted iff its status is GZ_AT_BOUNDARY / GZ_MEMBER_END and it starts
-// at chain->cur_bit; chunks that start inside accepted data are discarded.  For an accepted chunk c: out_off[c] = its text offset,
-// and the last min(n_sym, 32 KiB) of its symbols are written as bytes to text[out_off[c] + ...] (text is addressed by absolute
-// offset minus text_base; the 32 KiB in front of the first accepted chunk are written too, from chain->window).  out_off of
-// chunks that are not accepted is set to ~0.
-hipError_t launch_gz_chain(GzChain *d_chain, const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym,
-                           uint64_t sym_cap, uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, hipStream_t st);
-// Every symbol of the accepted chunks of [chunk_lo, chunk_hi) that the chain did not already write becomes a byte of text.
-// max_sym: the largest n_sym among them (grid sizing).
-hipError_t launch_gz_resolve(const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym, uint64_t sym_cap,
-                             const uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, uint32_t max_sym, hipStream_t st);
+// Walks the descriptors of chunks [st.next, chunk_hi) in order (h_chunks: indexed by chunk number).  A chunk is accepted iff its status is
+// GZ_AT_BOUNDARY / GZ_MEMBER_END and it starts at st.cur_bit -- by induction from the member's first block every accepted chunk starts at
+// a true block boundary --; chunks that start inside accepted data, or hold nothing, are discarded.  acc / acc_off: the accepted chunks
+// and the text offsets of their first bytes.  Stops (st.stop) at a gap, behind a member's end, or at chunk_hi.
+inline void gz_link_walk(const GzChunk *h_chunks, uint32_t chunk_hi, GzLinkState &st, std::vector<uint32_t> &acc, std::vector<uint64_t> &acc_off)
+{
+    acc.clear(); acc_off.clear();
+    st.stop = GZ_STOP_NONE;
+    uint32_t c = st.next;
+    for (; c < chunk_hi; c++) {
+        const GzChunk &ch = h_chunks[c];
+        const bool ok = ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END;
+        if (!ok || ch.start_bit < st.cur_bit) { st.discarded++; continue; }
+        if (ch.start_bit > st.cur_bit) { st.stop = GZ_STOP_GAP; break; }
+        acc.push_back(c); acc_off.push_back(st.total);
+        st.total += ch.n_sym; st.cur_bit = ch.end_bit; st.linked++;
+        st.wlen = st.wlen + ch.n_sym < GZ_WINDOW ? st.wlen + ch.n_sym : GZ_WINDOW;
+        if (ch.status == GZ_MEMBER_END) { c++; st.stop = GZ_STOP_MEMBER_END; break; }
+    }
+    st.next = c;
+}
+// The accepted chunks d_acc[0 .. n_acc) (chunk numbers, ascending; d_acc_off: their text offsets) become text: text is addressed by
+// absolute offset minus text_base.  d_window: 32 KiB, the text in front of the first of them (wlen_before valid bytes, right-aligned;
+// they are written to the text in front of first_off = the first chunk's offset too) -> the last 32 KiB behind the last of them.
+// The symbols' tails are rewritten in place.  max_sym: the largest n_sym among the chunks (grid sizing).  d_scratch:
+// gz_link_scratch_bytes(most chunks ever passed at once) bytes, used in stream order.  See mf_gzdev.hip for the scheme (a two-level scan
+// over the windows: nothing in it is serial per chunk).
+hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t max_sym, const GzChunk *d_chunks, uint32_t chunk_lo, uint16_t *d_sym,
+                          uint64_t sym_cap, uint8_t *d_window, uint32_t wlen_before, uint8_t *d_scratch, uint8_t *d_text, uint64_t text_base, uint64_t first_off, hipStream_t st);
+inline uint32_t gz_link_group(uint32_t n_acc) { return n_acc <= 16 ? 4 : n_acc <= 64 ? 8 : n_acc <= 512 ? 16 : 32; }          // chunks per group of the scan's first level
+inline size_t gz_link_scratch_bytes(uint32_t max_chunks)
+{
+    uint32_t groups = 1;                                           // the most groups any number of accepted chunks up to max_chunks makes
+    for (uint32_t n : {16u, 64u, 512u, max_chunks}) { const uint32_t m = n < max_chunks ? n : max_chunks; if (m) { const uint32_t g = (m + gz_link_group(m) - 1) / gz_link_group(m); if (g > groups) groups = g; } }
+    return (size_t)groups * GZ_WINDOW * 3 + 256;
+}
 // CRC-32 (gzip) of d_text[0 .. n) as 64 KiB pieces: d_piece[i] = the pure polynomial remainder (register starts at 0, no final
 // inversion) of piece i; gz_crc_finish() on the host folds them into zlib's crc32() value.
 constexpr uint32_t GZ_CRC_PIECE = 65536;

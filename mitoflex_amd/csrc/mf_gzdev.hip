@@ -17,6 +17,7 @@
 // times the wavefronts a CU holds: 9.9 KB of LDS and 128 VGPRs per wavefront, sixteen chunks in flight per CU.
 #include "mf_gzdev.h"
 #include "mf_gzlane.h"
+#include <algorithm>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1332,117 +1333,176 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------- chain
-// One workgroup walks the chunks in stream order.  The last 32 KiB of accepted text live in LDS (two buffers: the tail of a
-// chunk is resolved against the window in front of the chunk while the window behind it is being written).  The 64 KiB are why
-// the caller launches it on a stream whose CU mask keeps a few CUs free of decode wavefronts: those fill every CU's LDS, and a
-// workgroup that has to wait for 64 KiB to come free waits for tens of milliseconds -- on the one serial path of the decoder.
-__global__ __launch_bounds__(1024) void gz_chain_kernel(GzChain *chain, const GzChunk *chunks, uint32_t chunk_lo, uint32_t chunk_hi,
-                                                        const uint16_t *sym, uint64_t sym_cap, uint64_t *out_off, uint8_t *text,
-                                                        uint64_t text_base)
+// ---------------------------------------------------------------------------------------------------------- link
+// Which chunks are accepted, and where their text goes, is decided on the HOST (gz_link_walk below: a walk over the slab's 24-byte
+// descriptors).  What is left for the device is the one true data dependency of the scheme: a chunk's markers point into the 32 KiB
+// of text in front of it, i.e. into the resolved TAIL of the chunk before -- whose markers point into the tail before that.  Round 4
+// walked that chain on one workgroup, a chunk at a time (3.3-4.5 us each, 0.07 s of configs[4]).  Now it is a two-level scan:
+//   1. gz_link_tails_kernel, a workgroup per GROUP of consecutive accepted chunks, all groups side by side: the group's chunks in order,
+//      against a SYMBOLIC window in LDS (16 bits an entry: a byte, or MARK | index into the window the group began with); the tails
+//      are rewritten in place to that form and the window the group ends with is written out;
+//   2. gz_link_groups_kernel, one workgroup: the groups in order against the real window (bytes, LDS) -- the only serial part, one step
+//      per GROUP instead of one per chunk; leaves the window every group begins with, and the window behind the last chunk;
+//   3. gz_link_text_kernel, all tails side by side: the rewritten tails become text through their group's window.
+// Everything else of a chunk (its body) is gz_resolve_kernel's, which finds its windows in the text as before.
+constexpr uint32_t LINK_THREADS = 1024, LINK_PER = GZ_WINDOW / LINK_THREADS;          // 32 entries of a window per thread
+
+__global__ __launch_bounds__(LINK_THREADS) void gz_link_tails_kernel(const uint32_t *acc, uint32_t n_acc, uint32_t group, const GzChunk *chunks, uint32_t chunk_lo,
+                                                                     uint16_t *sym, uint64_t sym_cap, uint16_t *gfinal)
 {
-    __shared__ uint8_t win[2][GZ_WINDOW];
-    const uint32_t tid = threadIdx.x;
-    uint64_t cur = chain->cur_bit, total = chain->total;
-    uint32_t c = chain->next, wlen = chain->wlen, linked = chain->linked, discarded = chain->discarded, stop = GZ_STOP_NONE;
-    for (uint32_t i = tid * 16; i < GZ_WINDOW; i += 1024 * 16)
-        *reinterpret_cast<uint4 *>(&win[0][i]) = *reinterpret_cast<const uint4 *>(&chain->window[i]);
+    __shared__ uint16_t win[GZ_WINDOW];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t k0 = g * group, k1 = k0 + group < n_acc ? k0 + group : n_acc;
+    for (uint32_t i = tid; i < GZ_WINDOW; i += LINK_THREADS) win[i] = (uint16_t)(GZ_MARK | i);
     __syncthreads();
-    // the window is text too: a chunk's markers are looked up there by the resolve kernel
-    for (uint32_t i = tid; i < wlen; i += 1024) text[(int64_t)(total - text_base) - (int64_t)wlen + i] = win[0][GZ_WINDOW - wlen + i];
-    uint32_t a = 0;
-    // The descriptor of a chunk is fetched two chunks ahead and the tail of its symbols -- the last 32 Ki, four 16-byte loads a thread --
-    // one chunk ahead, so that a chunk's turn finds both in registers: what is serial per chunk is the look-up of its markers in
-    // the LDS window and a barrier, not three memory latencies.
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const GzChunk none{0, 0, 0, GZ_NONE};
-    auto desc = [&](uint32_t i) -> GzChunk { return i < chunk_hi ? chunks[i] : none; };
-    auto usable = [](const GzChunk &d) { return d.status == GZ_AT_BOUNDARY || d.status == GZ_MEMBER_END; };
-    // thread's j-th piece of a chunk's tail: symbols [tid * 8 + j * 8192, +8) of the tail
-    auto fetch = [&](uint32_t i, const GzChunk &d, u32x4 (&raw)[4]) {
-        if (!usable(d)) return;
-        const uint32_t n = d.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW;
-        const uint16_t *sp = sym + (uint64_t)(i - chunk_lo) * sym_cap + (n - tail);
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t c = acc[k];
+        const uint32_t n = chunks[c].n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW, keep = GZ_WINDOW - tail;
+        uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap + (n - tail);
+        // read: this thread's share of the tail, looked up in the window as it is; and (a chunk shorter than the window) its share of
+        // what slides -- all reads of the window first, then a barrier, then the writes: one window in LDS is enough
+        uint16_t t[LINK_PER], sl[LINK_PER];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t k = tid * 8 + j * 8192;
-            if (k + 8 <= tail) __builtin_memcpy(&raw[j], sp + k, 16);
-            else if (k < tail) { uint16_t v[8] = {}; for (uint32_t q = 0; k + q < tail; q++) v[q] = sp[k + q]; __builtin_memcpy(&raw[j], v, 16); }      // (the last piece: never past the chunk's symbols)
-        }
-    };
-    GzChunk ch = desc(c), nx = desc(c + 1);
-    u32x4 cur_raw[4] = {}, nxt_raw[4] = {};
-    fetch(c, ch, cur_raw);
-    for (; c < chunk_hi; c++) {
-        const GzChunk nx2 = desc(c + 2);
-        fetch(c + 1, nx, nxt_raw);
-        const bool ok = usable(ch);
-        bool take = false;
-        if (!ok || ch.start_bit < cur) { if (tid == 0) out_off[c] = ~0ull; discarded++; }
-        else if (ch.start_bit > cur) { stop = GZ_STOP_GAP; break; }
-        else take = true;
-        if (take) {
-            if (tid == 0) out_off[c] = total;
-            const uint32_t n = ch.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW, keep = GZ_WINDOW - tail;
-            uint8_t *tp = text + (int64_t)(total - text_base) + (n - tail);
-            const uint8_t *wa = win[a]; uint8_t *wb = win[a ^ 1];
-            for (uint32_t i = tid; i < keep; i += 1024) wb[i] = wa[i + tail];          // (a chunk shorter than the window: the rest slides)
+        for (uint32_t j = 0; j < LINK_PER / 8; j++) {
+            const uint32_t i = tid * 8 + j * (LINK_THREADS * 8);
+            uint16_t v[8];
+            if (i + 8 <= tail) __builtin_memcpy(v, sp + i, 16);
+            else {
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t i = tid * 8 + j * 8192;
-                if (i >= tail) continue;
-                uint16_t v[8];
-                __builtin_memcpy(v, &cur_raw[j], 16);
-                const uint32_t m = tail - i < 8 ? tail - i : 8;
-                uint8_t bts[8];
-                for (uint32_t k = 0; k < 8; k++) bts[k] = k < m ? ((v[k] & GZ_MARK) ? wa[v[k] & 0x7FFFu] : (uint8_t)v[k]) : 0;
-                if (m == 8 && ((keep + i) & 7) == 0) {                          // eight bytes at a time to the new window and to the text
-                    uint64_t q; __builtin_memcpy(&q, bts, 8);
-                    *reinterpret_cast<uint64_t *>(wb + keep + i) = q;
-                    __builtin_memcpy(tp + i, &q, 8);
-                } else for (uint32_t k = 0; k < m; k++) { wb[keep + i + k] = bts[k]; tp[i + k] = bts[k]; }
+                for (uint32_t q = 0; q < 8; q++) v[q] = i + q < tail ? sp[i + q] : (uint16_t)0;          // (the tail's last piece: never past the chunk's symbols; constant indices, so v stays in registers)
             }
-            __syncthreads();
-            a ^= 1;
-            total += n; cur = ch.end_bit; linked++;
-            wlen = wlen + n < GZ_WINDOW ? wlen + n : GZ_WINDOW;
-            if (ch.status == GZ_MEMBER_END) { c++; stop = GZ_STOP_MEMBER_END; break; }
-        }
-        ch = nx; nx = nx2;
 #pragma unroll
-        for (int j = 0; j < 4; j++) cur_raw[j] = nxt_raw[j];
+            for (uint32_t q = 0; q < 8; q++) t[j * 8 + q] = (v[q] & GZ_MARK) ? win[v[q] & 0x7FFFu] : v[q];
+        }
+        if (keep) {
+#pragma unroll
+            for (uint32_t j = 0; j < LINK_PER / 8; j++)
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) { const uint32_t i = tid * 8 + j * (LINK_THREADS * 8) + q; sl[j * 8 + q] = i < keep ? win[i + tail] : 0; }
+        }
+        __syncthreads();
+        if (keep) {
+#pragma unroll
+            for (uint32_t j = 0; j < LINK_PER / 8; j++)
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) { const uint32_t i = tid * 8 + j * (LINK_THREADS * 8) + q; if (i < keep) win[i] = sl[j * 8 + q]; }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < LINK_PER / 8; j++) {
+            const uint32_t i = tid * 8 + j * (LINK_THREADS * 8);
+            if (i >= tail) continue;
+            if (i + 8 <= tail) {
+                __builtin_memcpy(sp + i, &t[j * 8], 16);
+                if (((keep + i) & 7) == 0) __builtin_memcpy(&win[keep + i], &t[j * 8], 16);
+                else {
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; q++) win[keep + i + q] = t[j * 8 + q];
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) if (i + q < tail) { sp[i + q] = t[j * 8 + q]; win[keep + i + q] = t[j * 8 + q]; }
+            }
+        }
+        __syncthreads();
     }
-    for (uint32_t i = tid * 16; i < GZ_WINDOW; i += 1024 * 16)
-        *reinterpret_cast<uint4 *>(&chain->window[i]) = *reinterpret_cast<const uint4 *>(&win[a][i]);
-    if (tid == 0) {
-        chain->cur_bit = cur; chain->total = total; chain->next = c; chain->stop = stop;
-        chain->linked = linked; chain->discarded = discarded; chain->wlen = wlen;
+    uint16_t *out = gfinal + (uint64_t)g * GZ_WINDOW;
+    for (uint32_t i = tid * 8; i < GZ_WINDOW; i += LINK_THREADS * 8) *reinterpret_cast<uint4 *>(out + i) = *reinterpret_cast<const uint4 *>(&win[i]);
+}
+
+// window: the last 32 KiB of text in front of the first accepted chunk (wlen valid bytes, right-aligned) -> behind the last one.
+// gwin[g]: the window group g begins with.  The window in front of the first chunk is text too (a body's markers are looked up
+// in the text): written to text_front, which ends where the first accepted chunk's text begins.
+__global__ __launch_bounds__(LINK_THREADS) void gz_link_groups_kernel(uint8_t *window, uint32_t wlen, const uint16_t *gfinal, uint32_t n_groups, uint8_t *gwin, uint8_t *text_front)
+{
+    __shared__ uint8_t R[GZ_WINDOW];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid * 16; i < GZ_WINDOW; i += LINK_THREADS * 16) *reinterpret_cast<uint4 *>(&R[i]) = *reinterpret_cast<const uint4 *>(&window[i]);
+    __syncthreads();
+    for (uint32_t i = tid; i < wlen; i += LINK_THREADS) text_front[(int64_t)i - (int64_t)wlen] = R[GZ_WINDOW - wlen + i];
+    for (uint32_t g = 0; g < n_groups; g++) {
+        uint8_t *gw = gwin + (uint64_t)g * GZ_WINDOW;
+        const uint16_t *F = gfinal + (uint64_t)g * GZ_WINDOW;
+        uint8_t b[LINK_PER];
+#pragma unroll
+        for (uint32_t j = 0; j < LINK_PER / 8; j++) {
+            const uint32_t i = tid * 8 + j * (LINK_THREADS * 8);
+            uint16_t v[8];
+            __builtin_memcpy(v, F + i, 16);
+            uint64_t r; __builtin_memcpy(&r, &R[i], 8);
+            __builtin_memcpy(gw + i, &r, 8);                              // the window this group begins with
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) b[j * 8 + q] = (v[q] & GZ_MARK) ? R[v[q] & 0x7FFFu] : (uint8_t)v[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < LINK_PER / 8; j++) __builtin_memcpy(&R[tid * 8 + j * (LINK_THREADS * 8)], &b[j * 8], 8);
+        __syncthreads();
+    }
+    for (uint32_t i = tid * 16; i < GZ_WINDOW; i += LINK_THREADS * 16) *reinterpret_cast<uint4 *>(&window[i]) = *reinterpret_cast<const uint4 *>(&R[i]);
+}
+
+constexpr uint32_t RESOLVE_SEG = 8192;            // symbols per workgroup
+__global__ __launch_bounds__(256) void gz_link_text_kernel(const uint32_t *acc, const uint64_t *acc_off, uint32_t group, const GzChunk *chunks, uint32_t chunk_lo,
+                                                           const uint16_t *sym, uint64_t sym_cap, const uint8_t *gwin, uint8_t *text, uint64_t text_base)
+{
+    const uint32_t k = blockIdx.y, c = acc[k];
+    const uint32_t n = chunks[c].n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW;
+    const uint32_t s0 = blockIdx.x * RESOLVE_SEG;
+    if (s0 >= tail) return;
+    const uint32_t s1 = s0 + RESOLVE_SEG < tail ? s0 + RESOLVE_SEG : tail;
+    const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap + (n - tail);
+    const uint8_t *wp = gwin + (uint64_t)(k / group) * GZ_WINDOW;
+    uint8_t *tp = text + (int64_t)(acc_off[k] - text_base) + (n - tail);
+    for (uint32_t i = s0 + threadIdx.x * 8; i < s1; i += 256 * 8) {
+        const uint32_t m = s1 - i < 8 ? s1 - i : 8;
+        uint16_t v[8];
+        if (m == 8) __builtin_memcpy(v, sp + i, 16);
+        else {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) v[q] = q < m ? sp[i + q] : (uint16_t)0;
+        }
+        uint8_t b[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) b[q] = (v[q] & GZ_MARK) ? wp[v[q] & 0x7FFFu] : (uint8_t)v[q];
+        if (m == 8) __builtin_memcpy(tp + i, b, 8);
+        else {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) if (q < m) tp[i + q] = b[q];
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------- resolve
-constexpr uint32_t RESOLVE_SEG = 8192;            // symbols per workgroup
-__global__ __launch_bounds__(256) void gz_resolve_kernel(const GzChunk *chunks, uint32_t chunk_lo, const uint16_t *sym, uint64_t sym_cap,
-                                                         const uint64_t *out_off, uint8_t *text, uint64_t text_base)
+// the body of every accepted chunk (everything in front of its last 32 Ki symbols): markers are looked up in the text in front of the chunk
+__global__ __launch_bounds__(256) void gz_resolve_kernel(const uint32_t *acc, const uint64_t *acc_off, const GzChunk *chunks, uint32_t chunk_lo, const uint16_t *sym,
+                                                         uint64_t sym_cap, uint8_t *text, uint64_t text_base)
 {
-    const uint32_t c = chunk_lo + blockIdx.y;
-    const uint64_t off = out_off[c];
-    if (off == ~0ull) return;
+    const uint32_t c = acc[blockIdx.y];
+    const uint64_t off = acc_off[blockIdx.y];
     const uint32_t n = chunks[c].n_sym;
-    const uint32_t body = n > GZ_WINDOW ? n - GZ_WINDOW : 0;      // the chain has written the rest
+    const uint32_t body = n > GZ_WINDOW ? n - GZ_WINDOW : 0;      // the link step has written the rest
     const uint32_t s0 = blockIdx.x * RESOLVE_SEG;
     if (s0 >= body) return;
     const uint32_t s1 = s0 + RESOLVE_SEG < body ? s0 + RESOLVE_SEG : body;
-    const uint16_t *sp = sym + (uint64_t)blockIdx.y * sym_cap;
+    const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap;
     uint8_t *tp = text + (int64_t)(off - text_base);
     const uint8_t *wp = tp - GZ_WINDOW;                            // the 32 KiB in front of the chunk
     for (uint32_t i = s0 + threadIdx.x * 8; i < s1; i += 256 * 8) {
         const uint32_t m = s1 - i < 8 ? s1 - i : 8;
         uint16_t v[8];
-        if (m == 8) __builtin_memcpy(v, sp + i, 16); else for (uint32_t k = 0; k < m; k++) v[k] = sp[i + k];
+        if (m == 8) __builtin_memcpy(v, sp + i, 16);
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) v[k] = k < m ? sp[i + k] : (uint16_t)0;
+        }
         uint8_t b[8];
-        for (uint32_t k = 0; k < m; k++) b[k] = (v[k] & GZ_MARK) ? wp[v[k] & 0x7FFFu] : (uint8_t)v[k];
-        if (m == 8) __builtin_memcpy(tp + i, b, 8); else for (uint32_t k = 0; k < m; k++) tp[i + k] = b[k];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) b[k] = (v[k] & GZ_MARK) ? wp[v[k] & 0x7FFFu] : (uint8_t)v[k];          // (a marker of the last, partial group would read the window at index 0: readable)
+        if (m == 8) __builtin_memcpy(tp + i, b, 8);
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) if (k < m) tp[i + k] = b[k];
+        }
     }
 }
 
@@ -1530,19 +1590,18 @@ hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t
     return hipGetLastError();
 }
 
-hipError_t launch_gz_chain(GzChain *d_chain, const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym,
-                           uint64_t sym_cap, uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, hipStream_t st)
+hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t max_sym, const GzChunk *d_chunks, uint32_t chunk_lo, uint16_t *d_sym,
+                          uint64_t sym_cap, uint8_t *d_window, uint32_t wlen_before, uint8_t *d_scratch, uint8_t *d_text, uint64_t text_base, uint64_t first_off, hipStream_t st)
 {
-    hipLaunchKernelGGL(gz_chain_kernel, dim3(1), dim3(1024), 0, st, d_chain, d_chunks, chunk_lo, chunk_hi, d_sym, sym_cap, d_out_off, d_text, text_base);
-    return hipGetLastError();
-}
-
-hipError_t launch_gz_resolve(const GzChunk *d_chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *d_sym, uint64_t sym_cap,
-                             const uint64_t *d_out_off, uint8_t *d_text, uint64_t text_base, uint32_t max_sym, hipStream_t st)
-{
-    if (chunk_hi <= chunk_lo || max_sym <= GZ_WINDOW) return hipSuccess;
-    const uint32_t gx = (max_sym - GZ_WINDOW + RESOLVE_SEG - 1) / RESOLVE_SEG;
-    hipLaunchKernelGGL(gz_resolve_kernel, dim3(gx, chunk_hi - chunk_lo), dim3(256), 0, st, d_chunks, chunk_lo, d_sym, sym_cap, d_out_off, d_text, text_base);
+    if (!n_acc) return hipSuccess;
+    const uint32_t group = gz_link_group(n_acc), n_groups = (n_acc + group - 1) / group;
+    uint16_t *gfinal = reinterpret_cast<uint16_t *>(d_scratch);
+    uint8_t *gwin = d_scratch + (size_t)n_groups * GZ_WINDOW * 2;
+    hipLaunchKernelGGL(gz_link_tails_kernel, dim3(n_groups), dim3(LINK_THREADS), 0, st, d_acc, n_acc, group, d_chunks, chunk_lo, d_sym, sym_cap, gfinal);
+    hipLaunchKernelGGL(gz_link_groups_kernel, dim3(1), dim3(LINK_THREADS), 0, st, d_window, wlen_before, gfinal, n_groups, gwin, d_text + (int64_t)(first_off - text_base));
+    hipLaunchKernelGGL(gz_link_text_kernel, dim3(GZ_WINDOW / RESOLVE_SEG, n_acc), dim3(256), 0, st, d_acc, d_acc_off, group, d_chunks, chunk_lo, d_sym, sym_cap, gwin, d_text, text_base);
+    if (max_sym > GZ_WINDOW)
+        hipLaunchKernelGGL(gz_resolve_kernel, dim3((max_sym - GZ_WINDOW + RESOLVE_SEG - 1) / RESOLVE_SEG, n_acc), dim3(256), 0, st, d_acc, d_acc_off, d_chunks, chunk_lo, d_sym, sym_cap, d_text, text_base);
     return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <stdlib.h>
@@ -31,11 +32,14 @@ struct StubStream {
     void push(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv.notify_one(); }
     void drain() { std::unique_lock<std::mutex> lk(mu); idle.wait(lk, [&] { return q.empty() && !busy; }); }
 };
-struct StubEvent {
+// (the state of an event is shared with the records and waits that are queued on streams: like the runtime's, an event may be destroyed
+// while a stream still has a wait for it queued)
+struct EventState {
     std::mutex mu; std::condition_variable cv;
     uint64_t recorded = 0, completed = 0;          // generations: record n is complete when completed >= n
     std::chrono::steady_clock::time_point when;
 };
+struct StubEvent { std::shared_ptr<EventState> s = std::make_shared<EventState>(); };
 
 namespace {
 std::mutex g_mu;
@@ -92,30 +96,32 @@ void stub_enqueue(hipStream_t s, std::function<void()> f) { if (!s) { drain_all(
 
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new StubEvent(); return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }
-hipError_t hipEventDestroy(hipEvent_t e) { if (!e) return hipErrorInvalidValue; { std::unique_lock<std::mutex> lk(e->mu); e->cv.wait(lk, [&] { return e->completed >= e->recorded; }); } delete e; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { if (!e) return hipErrorInvalidValue; delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 {
+    std::shared_ptr<EventState> st = e->s;
     uint64_t gen;
-    { std::lock_guard<std::mutex> lk(e->mu); gen = ++e->recorded; }
-    stub_enqueue(s, [e, gen] { std::lock_guard<std::mutex> lk(e->mu); if (gen > e->completed) { e->completed = gen; e->when = std::chrono::steady_clock::now(); } e->cv.notify_all(); });          // (notified under the lock: the event may be destroyed the moment it is complete)
+    { std::lock_guard<std::mutex> lk(st->mu); gen = ++st->recorded; }
+    stub_enqueue(s, [st, gen] { std::lock_guard<std::mutex> lk(st->mu); if (gen > st->completed) { st->completed = gen; st->when = std::chrono::steady_clock::now(); } st->cv.notify_all(); });
     return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
+    std::shared_ptr<EventState> st = e->s;
     uint64_t gen;
-    { std::lock_guard<std::mutex> lk(e->mu); gen = e->recorded; }
+    { std::lock_guard<std::mutex> lk(st->mu); gen = st->recorded; }
     if (!gen) return hipSuccess;                                   // (never recorded: no-op, as in the runtime)
-    stub_enqueue(s, [e, gen] { std::unique_lock<std::mutex> lk(e->mu); e->cv.wait(lk, [&] { return e->completed >= gen; }); });
+    stub_enqueue(s, [st, gen] { std::unique_lock<std::mutex> lk(st->mu); st->cv.wait(lk, [&] { return st->completed >= gen; }); });
     return hipSuccess;
 }
-hipError_t hipEventSynchronize(hipEvent_t e) { std::unique_lock<std::mutex> lk(e->mu); const uint64_t gen = e->recorded; e->cv.wait(lk, [&] { return e->completed >= gen; }); return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t e) { std::lock_guard<std::mutex> lk(e->mu); return e->completed >= e->recorded ? hipSuccess : hipErrorNotReady; }
+hipError_t hipEventSynchronize(hipEvent_t e) { std::shared_ptr<EventState> st = e->s; std::unique_lock<std::mutex> lk(st->mu); const uint64_t gen = st->recorded; st->cv.wait(lk, [&] { return st->completed >= gen; }); return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t e) { std::lock_guard<std::mutex> lk(e->s->mu); return e->s->completed >= e->s->recorded ? hipSuccess : hipErrorNotReady; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
-    std::unique_lock<std::mutex> la(a->mu, std::defer_lock), lb(b->mu, std::defer_lock);
-    if (a == b) la.lock(); else std::lock(la, lb);
-    if (!a->completed || !b->completed) return hipErrorNotReady;
-    *ms = std::chrono::duration<float, std::milli>(b->when - a->when).count();
+    std::unique_lock<std::mutex> la(a->s->mu, std::defer_lock), lb(b->s->mu, std::defer_lock);
+    if (a->s == b->s) la.lock(); else std::lock(la, lb);
+    if (!a->s->completed || !b->s->completed) return hipErrorNotReady;
+    *ms = std::chrono::duration<float, std::milli>(b->s->when - a->s->when).count();
     return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t s) { stub_enqueue(s, [dst, src, n] { if (n) memmove(dst, src, n); }); return hipSuccess; }

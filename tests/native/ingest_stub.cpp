@@ -117,46 +117,24 @@ hipError_t launch_gz_decode(const uint8_t *d_data, uint64_t ring_bytes, uint64_t
     return hipSuccess;
 }
 
-hipError_t launch_gz_chain(GzChain *chain, const GzChunk *chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *sym, uint64_t sym_cap,
-                           uint64_t *out_off, uint8_t *text, uint64_t text_base, hipStream_t st)
+// the accepted chunks become text, in order, the obvious way: a marker points into the 32 KiB of text in front of its chunk (the first chunk's
+// are the window's bytes, written in front of it first); the window behind the last chunk is left in d_window
+hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t, const GzChunk *chunks, uint32_t chunk_lo, uint16_t *sym, uint64_t sym_cap,
+                          uint8_t *d_window, uint32_t wlen_before, uint8_t *, uint8_t *text, uint64_t text_base, uint64_t first_off, hipStream_t st)
 {
+    if (!n_acc) return hipSuccess;
     stub_enqueue(st, [=] {
-        uint64_t cur = chain->cur_bit, total = chain->total; uint32_t c = chain->next, stop = GZ_STOP_NONE;
         uint8_t *tp = text - text_base;                          // (indexed by absolute text offset)
-        for (uint32_t i = 0; i < chain->wlen; i++) tp[total - chain->wlen + i] = chain->window[GZ_WINDOW - chain->wlen + i];
-        for (; c < chunk_hi; c++) {
-            const GzChunk &ch = chunks[c];
-            const bool ok = ch.status == GZ_AT_BOUNDARY || ch.status == GZ_MEMBER_END;
-            if (!ok || ch.start_bit < cur) { out_off[c] = ~0ull; chain->discarded++; continue; }
-            if (ch.start_bit > cur) { stop = GZ_STOP_GAP; break; }
-            out_off[c] = total;
+        for (uint32_t i = 0; i < wlen_before; i++) tp[first_off - wlen_before + i] = d_window[GZ_WINDOW - wlen_before + i];
+        uint64_t end = first_off; uint32_t wlen = wlen_before;
+        for (uint32_t k = 0; k < n_acc; k++) {
+            const uint32_t c = d_acc[k], n = chunks[c].n_sym;
+            const uint64_t off = d_acc_off[k];
             const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap;
-            const uint32_t n = ch.n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW;
-            // (like the kernel: only the last 32 KiB of a chunk are made text here, the rest is the resolve kernel's; a marker points into the
-            // 32 KiB in front of the chunk, which are the tails of the chunks before it)
-            for (uint32_t i = n - tail; i < n; i++) tp[total + i] = (sp[i] & GZ_MARK) ? tp[total - GZ_WINDOW + (sp[i] & 0x7FFFu)] : (uint8_t)sp[i];
-            total += n; cur = ch.end_bit; chain->linked++;
-            chain->wlen = chain->wlen + n < GZ_WINDOW ? chain->wlen + n : GZ_WINDOW;
-            for (uint32_t i = 0; i < chain->wlen; i++) chain->window[GZ_WINDOW - chain->wlen + i] = tp[total - chain->wlen + i];          // (bytes of chunks shorter than the window slide)
-            if (ch.status == GZ_MEMBER_END) { c++; stop = GZ_STOP_MEMBER_END; break; }
+            for (uint32_t i = 0; i < n; i++) tp[off + i] = (sp[i] & GZ_MARK) ? tp[off - GZ_WINDOW + (sp[i] & 0x7FFFu)] : (uint8_t)sp[i];
+            end = off + n; wlen = wlen + n < GZ_WINDOW ? wlen + n : GZ_WINDOW;
         }
-        chain->cur_bit = cur; chain->total = total; chain->next = c; chain->stop = stop;
-    });
-    return hipSuccess;
-}
-
-hipError_t launch_gz_resolve(const GzChunk *chunks, uint32_t chunk_lo, uint32_t chunk_hi, const uint16_t *sym, uint64_t sym_cap, const uint64_t *out_off,
-                             uint8_t *text, uint64_t text_base, uint32_t, hipStream_t st)
-{
-    stub_enqueue(st, [=] {
-        uint8_t *tp = text - text_base;
-        for (uint32_t c = chunk_lo; c < chunk_hi; c++) {
-            const uint64_t off = out_off[c];
-            if (off == ~0ull) continue;
-            const uint32_t n = chunks[c].n_sym, body = n > GZ_WINDOW ? n - GZ_WINDOW : 0;
-            const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap;
-            for (uint32_t i = 0; i < body; i++) tp[off + i] = (sp[i] & GZ_MARK) ? tp[off - GZ_WINDOW + (sp[i] & 0x7FFFu)] : (uint8_t)sp[i];
-        }
+        for (uint32_t i = 0; i < wlen; i++) d_window[GZ_WINDOW - wlen + i] = tp[end - wlen + i];
     });
     return hipSuccess;
 }

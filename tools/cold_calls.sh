@@ -32,7 +32,7 @@ for ing in device host; do
   for rep in 1 2; do
     echo "== filter_v2 -d 2 M pairs .gz, MF_QUAL_INGEST=$ing rep $rep" >> $L
     rm -f $T/o_1.fq $T/o_2.fq
-    MF_QUAL_INGEST=$ing MF_PIPE_TIMING=1 wall $F -1 $T/p_1.fq.gz -2 $T/p_2.fq.gz -3 $T/o_1.fq -4 $T/o_2.fq -d >> $L 2>&1
+    MF_COLD_TRACE=$([ $rep = 1 ] && echo 1) MF_QUAL_INGEST=$ing MF_PIPE_TIMING=1 wall $F -1 $T/p_1.fq.gz -2 $T/p_2.fq.gz -3 $T/o_1.fq -4 $T/o_2.fq -d >> $L 2>&1
   done
 done
 rm -rf $T

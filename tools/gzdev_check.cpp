@@ -1,8 +1,9 @@
 // Stand-alone check and timing of the device DEFLATE decoder (mitoflex_amd/csrc/mf_gzdev.hip) against zlib.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip tools/gzdev_check.cpp mitoflex_amd/csrc/mf_gzdev.hip -lz -o tools/gzdev_check
 //   tools/gzdev_check file.gz [chunk_KiB=256] [expansion=8] [reps=3]
-// Decodes every chunk on the GPU, links the chunks on the host the way gz_chain_kernel does, resolves markers from the
-// reference text and compares every byte with zlib's output.
+// Decodes every chunk on the GPU and checks every chunk's symbols against zlib's output (markers resolved from the reference text);
+// then links the chunks the way the product does -- the walk over the descriptors on the host, the window scan and the marker resolution
+// on the device (launch_gz_link) -- and compares the device's text with zlib's, byte for byte.
 #include "../mitoflex_amd/csrc/mf_gzdev.h"
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -105,7 +106,7 @@ int main(int argc, char **argv)
     }
     for (uint32_t c = 0; c < n_chunks && ok && !ended; c++) {
         const mf::GzChunk &k = ch[c];
-        // the rules of gz_chain_kernel: a chunk that found nothing, failed, or started inside accepted data is passed over; one that
+        // the rules of gz_link_walk: a chunk that found nothing, failed, or started inside accepted data is passed over; one that
         // starts behind the accepted data is a gap, which the product bridges on the host (inflate_gap) -- this check stops there
         if (k.status == mf::GZ_NONE || k.status == mf::GZ_FAILED || k.start_bit < cur) continue;
         if (k.start_bit > cur) {
@@ -135,6 +136,46 @@ int main(int argc, char **argv)
            (unsigned long long)total, ref.size(), ended ? "reached" : "NOT reached");
     printf("kernel %.3f ms: %.2f GB/s of text, %.2f GB/s of compressed input (%llu symbols written)\n", best, sym_total / best / 1e6, size / best / 1e6,
            (unsigned long long)sym_total);
+    // ---- the link step on the device (launch_gz_link: the two-level window scan + marker resolution), the way the product drives it: the walk
+    // over the descriptors on the host (gz_link_walk), slabs of `slab` chunks, the window carried on the device from slab to slab.  The text
+    // the device produces is compared with zlib's byte for byte, and the link kernels are timed (events around every slab's launches).
+    bool link_ok = true; double link_ms = 0; uint64_t link_bytes = 0; uint32_t link_chunks = 0, link_slabs = 0;
+    {
+        const uint32_t slab = (uint32_t)(getenv("GZCHECK_SLAB") ? atoi(getenv("GZCHECK_SLAB")) : 512);
+        uint8_t *d_text, *d_window, *d_link; uint32_t *d_acc; uint64_t *d_acc_off;
+        const size_t front = 32768 + 256;
+        CK(hipMalloc(&d_text, ref.size() + front + 64)); CK(hipMemset(d_text, 0, front));
+        CK(hipMalloc(&d_window, 32768)); CK(hipMemset(d_window, 0, 32768));
+        CK(hipMalloc(&d_link, mf::gz_link_scratch_bytes(slab))); CK(hipMalloc(&d_acc, (size_t)slab * 4)); CK(hipMalloc(&d_acc_off, (size_t)slab * 8));
+        mf::GzLinkState st; st.cur_bit = (uint64_t)base_byte * 8;
+        std::vector<uint32_t> acc; std::vector<uint64_t> acc_off;
+        for (uint32_t lo = 0; lo < n_chunks && st.stop == mf::GZ_STOP_NONE; lo += slab) {
+            const uint32_t hi = lo + slab < n_chunks ? lo + slab : n_chunks;
+            const uint32_t wlen_before = st.wlen;
+            if (st.next < lo) st.next = lo;
+            mf::gz_link_walk(ch.data(), hi, st, acc, acc_off);
+            if (acc.empty()) continue;
+            uint32_t mx = 0; for (uint32_t c : acc) mx = ch[c].n_sym > mx ? ch[c].n_sym : mx;
+            CK(hipMemcpy(d_acc, acc.data(), acc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_acc_off, acc_off.data(), acc_off.size() * 8, hipMemcpyHostToDevice));
+            CK(hipEventRecord(e0, 0));
+            CK(mf::launch_gz_link(d_acc, d_acc_off, (uint32_t)acc.size(), mx, d_chunks, lo, d_sym + (size_t)lo * cap, cap, d_window, wlen_before, d_link, d_text + front, 0, acc_off[0], 0));
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            link_ms += ms; link_chunks += (uint32_t)acc.size(); link_slabs++;
+        }
+        link_bytes = st.total;
+        std::vector<uint8_t> got(link_bytes);
+        if (link_bytes) CK(hipMemcpy(got.data(), d_text + front, link_bytes, hipMemcpyDeviceToHost));
+        if (link_bytes > ref.size()) { printf("device link: more text than the reference holds\n"); link_ok = false; }
+        else for (uint64_t i = 0; i < link_bytes; i++) if (got[i] != ref[i]) { printf("device link: text offset %llu: %02x, expected %02x\n", (unsigned long long)i, got[i], ref[i]); link_ok = false; break; }
+        if (link_bytes != total) { printf("device link: %llu bytes of text, the host's walk over the same descriptors %llu\n", (unsigned long long)link_bytes, (unsigned long long)total); link_ok = false; }
+        std::vector<uint8_t> w(32768);
+        CK(hipMemcpy(w.data(), d_window, 32768, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < st.wlen && link_ok; i++) if (w[32768 - st.wlen + i] != ref[link_bytes - st.wlen + i]) { printf("device link: the window left behind differs at %u\n", i); link_ok = false; }
+        printf("device link (launch_gz_link, slabs of %u chunks): %u chunks in %u slabs, %llu bytes of text %s zlib's; link + resolve kernels %.3f ms in all = %.2f us a chunk, %.1f GB/s of text\n", slab,
+               link_chunks, link_slabs, (unsigned long long)link_bytes, link_ok ? "equal to" : "DIFFER from", link_ms, link_chunks ? link_ms * 1e3 / link_chunks : 0.0, link_ms > 0 ? link_bytes / link_ms / 1e6 : 0.0);
+        ok = ok && link_ok;
+    }
     const bool pass = ok && ended && total == ref.size();
     const bool partial = ok && !pass && (gap || !ended) && total <= ref.size();      // everything the device linked is right; the rest is the host's (stored-only files, a lost candidate)
     printf(pass ? "PASS\n" : partial ? "PASS (as far as the chunks link without the host: %llu of %zu bytes)\n" : "FAIL\n", (unsigned long long)total, ref.size());
