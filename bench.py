@@ -65,6 +65,8 @@ def parse():
                     help="pairs of the .gz pair the reference's quality filter (filter_v2, SURVEY.md 8f next #2) is timed on, device ingest path against host pipeline (0 = skip)")
     ap.add_argument("--real-gz-reads", type=int, default=READS_5GBP // 8,
                     help="reads of the single-end file that gzip / pigz / bgzip compress themselves (default: an eighth of configs[4]; 0 = skip)")
+    ap.add_argument("--plain-pairs", type=int, default=READS_5GBP // 2,
+                    help="pairs of the plain paired files of configs[1] put through the file boundary (device path against host pipeline; 0 = skip)")
     ap.add_argument("--k-sweep", default="21,41", help="other k of configs[2] timed on the same resident reads, a few steps each ('none' = none)")
     ap.add_argument("--rank-file-reads", type=int, default=500_000, help="N > 1: reads of the .gz shard every rank filters file to file on its own GPU (0 = skip)")
     return ap.parse_args()
@@ -177,7 +179,7 @@ def live_counters(counters, k, timeout_s=75.0):
             # (the profiled program comes right after `--`: no shell, no env wrapper in between)
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--k", str(k),
                    "--steps", "2", "--warmup", "0", "--prewarm-ms", "0", "--cpu-sample", "0", "--no-exhaustive", "--e2e-pairs", "0",
-                   "--e2e-full-reads", "0", "--fv2-pairs", "0", "--no-group-a", "--no-live-traffic"]
+                   "--e2e-full-reads", "0", "--fv2-pairs", "0", "--no-group-a", "--no-live-traffic", "--k-sweep", "none", "--real-gz-reads", "0", "--plain-pairs", "0"]
             p = subprocess.Popen(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 p.wait(timeout=timeout_s)
@@ -266,6 +268,11 @@ def prepare_inputs(a, tmp, solo=True):
                 if shutil.which(cmd[0]):
                     out = os.path.join(tmp, "r_1.%s.fq.gz" % name)
                     real.append((name, out, subprocess.Popen(cmd, stdout=open(out, "wb"), env=env)))
+            # the control: the SAME text through this repository's tools/pgzip.py (what the configs[4] leg is compressed with), so that a
+            # difference between the two figures is the compressor's and not the size's
+            out = os.path.join(tmp, "r_1.pgzip-6.fq.gz")
+            real.append(("pgzip-6 (control: tools/pgzip.py, same text)", out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), src, out, "--level", "6"],
+                                                                                                 stdout=subprocess.DEVNULL, env=env)))
         if a.e2e_full_reads > 0 and solo:                 # (configs[4] is a one-GPU configuration: the other ranks of a multi-rank run would only wait for the file)
             need = a.e2e_full_reads * 321 * 1.7
             if shutil.disk_usage(tmp).free < need:
@@ -277,6 +284,33 @@ def prepare_inputs(a, tmp, solo=True):
                 run([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), os.path.join(tmp, "f_1.fq"), os.path.join(tmp, "f_1.fq.gz"), "--level", "6"])
                 files["full"] = os.path.join(tmp, "f")
                 files["full_prep_seconds"] = {"generate": round(t1 - t0, 1), "compress": round(time.time() - t1, 1)}
+        # ---- the path as the reference calls it: a PROCESS per call (utility/helper.py:78-86, assemble_wrapper.py:326-343) -- `fastfilter bait`
+        # from process start to exit, HIP start-up and all, before this process touches the GPU
+        bait_cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
+
+        def cold(bait, fq, out, reps):
+            secs, kept = [], None
+            for _ in range(reps):
+                if os.path.exists(out):
+                    os.unlink(out)
+                t0 = time.perf_counter()
+                kept = int(subprocess.check_output([bait_cli, "bait", "--bait", bait, "--fq1", fq, "--out1", out], env=env, stderr=subprocess.DEVNULL, timeout=300).decode())
+                secs.append(round(time.perf_counter() - t0, 4))
+            return {"seconds_each": secs, "seconds": min(secs), "kept": kept}
+        try:
+            if "small" in files:
+                files["small_cli"] = cold(os.path.join(tmp, "s.bait.fa"), os.path.join(tmp, "s_1.fq.gz"), os.path.join(tmp, "s_cli.fq"), 3)
+            if "full" in files:
+                files["full_cli"] = cold(os.path.join(tmp, "f.bait.fa"), os.path.join(tmp, "f_1.fq.gz"), os.path.join(tmp, "f_cli.fq"), 3)
+        except Exception as e:
+            files["cli_error"] = str(e)[:200]
+        if a.plain_pairs > 0 and solo:
+            # configs[1] through the file boundary: the 5 Gbp PE150 set as two plain FASTQ files
+            if shutil.disk_usage(tmp).free < a.plain_pairs * 2 * 321 * 1.3:
+                files["plain_note"] = "not enough scratch space for the plain configs[1] pair"
+            else:
+                run([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), os.path.join(tmp, "c"), "--pairs", str(a.plain_pairs), "--block", "2000000"])
+                files["plain"] = os.path.join(tmp, "c")
         if a.fv2_pairs > 0 and solo:
           try:          # (a leg of its own: whatever goes wrong here costs the line this leg, not the file-level legs below)
             # the quality filter's drop-in CLI, process start to exit, on a .gz pair: device ingest path (the default) and host pipeline
@@ -315,17 +349,60 @@ def e2e_files(mf, ks, files, a):
     """Files in / files out (mf_filter_fastq_files), reads/s of the whole call, best of three."""
     out = {}
 
-    def run(f1, f2, o1, o2, n_reads, reps=3):
+    first_call = {}
+
+    def run(f1, f2, o1, o2, n_reads, reps=3, tag=None):
         best, res = 1e9, None
-        for _ in range(reps):
+        for i in range(reps):
             t0 = time.perf_counter()
             res = mf.filter_fastq_files(ks, f1, f2, o1, o2)
-            best = min(best, time.perf_counter() - t0)
+            dt = time.perf_counter() - t0
+            if i == 0 and tag:
+                first_call[tag] = round(dt, 4)
+            best = min(best, dt)
         return n_reads / best, best, res
+
+    def with_ingest(which, fn):
+        prev = os.environ.get("MF_INGEST")
+        os.environ["MF_INGEST"] = which
+        try:
+            return fn()
+        finally:
+            if prev is None:
+                del os.environ["MF_INGEST"]
+            else:
+                os.environ["MF_INGEST"] = prev
+
+    def plain_leg(f1, f2, prefix, n_reads, what):
+        """plain FASTQ through the file boundary: the streaming device path (the file's bytes go up as they are) against the host pipeline
+        (parse and pack on the host); roof: the text crosses PCIe once"""
+        text_bytes = os.path.getsize(f1) + (os.path.getsize(f2) if f2 else 0)
+        h_rate, h_secs, h_res = with_ingest("host", lambda: run(f1, f2, prefix + "_h1.fq", prefix + "_h2.fq" if f2 else None, n_reads, reps=2))
+        d_rate, d_secs, d_res = with_ingest("device", lambda: run(f1, f2, prefix + "_d1.fq", prefix + "_d2.fq" if f2 else None, n_reads, reps=3, tag=what))
+        ist = mf.last_ingest_stats()
+        dflt_rate, dflt_secs, _ = run(f1, f2, prefix + "_x1.fq", prefix + "_x2.fq" if f2 else None, n_reads, reps=2)
+        dflt_path = mf.last_ingest_stats()["path"]
+        try:
+            h2d = mf.h2d_bandwidth(0, 1 << 30, 3)
+        except Exception:
+            h2d = None
+        same = md5_of(prefix + "_d1.fq") == md5_of(prefix + "_h1.fq") and (not f2 or md5_of(prefix + "_d2.fq") == md5_of(prefix + "_h2.fq")) and tuple(d_res) == tuple(h_res)
+        return {"reads": n_reads, "text_bytes": text_bytes,
+                "device_path": {"reads_per_s": d_rate, "seconds": round(d_secs, 4), "first_call_seconds": first_call.get(what), "ingest_path": "device" if ist["path"] == 1 else "host",
+                                "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9},
+                "host_pipeline": {"reads_per_s": h_rate, "seconds": round(h_secs, 4)},
+                "library_default": {"reads_per_s": dflt_rate, "seconds": round(dflt_secs, 4), "ingest_path": "device" if dflt_path == 1 else "host"},
+                "roofline": {"bound": "pcie_h2d", "achieved": text_bytes / d_secs / 1e9, "peak": h2d, "unit": "GB/s", "frac": (text_bytes / d_secs / 1e9 / h2d) if h2d else None,
+                             "note": "bytes of FASTQ text / seconds of the whole call on the device path (files in the page cache -> survivors written)"},
+                "outputs_equal": bool(same), "kept": int(d_res[0]), "total": int(d_res[1])}
     if "small" in files:
         t = files["small"]
         out["pe_plain_reads_per_s"] = run(t + "_1.fq", t + "_2.fq", t + "_o1.fq", t + "_o2.fq", 2 * a.e2e_pairs)[0]
-        out["se_gz_reads_per_s"] = run(t + "_1.fq.gz", None, t + "_og.fq", None, a.e2e_pairs)[0]
+        out["se_gz_reads_per_s"] = run(t + "_1.fq.gz", None, t + "_og.fq", None, a.e2e_pairs, tag="se_gz")[0]
+        out["se_gz_seconds"] = round(a.e2e_pairs / out["se_gz_reads_per_s"], 4)
+        out["se_gz_first_call_seconds"] = first_call.get("se_gz")       # the process's first call of the device ingest path (HIP itself is up: the bait set has been built)
+        if "small_cli" in files:
+            out["se_gz_cli_cold"] = dict(files["small_cli"], note="`fastfilter bait` on the same file, process start to exit (HIP start-up included), run before this process touched the GPU")
         out["pairs"] = a.e2e_pairs
         out["note_small"] = "small inputs (the SE .gz has `pairs` reads): a call's fixed latencies dominate; configs4_se_gz is the throughput figure"
     if "full" in files:
@@ -341,7 +418,7 @@ def e2e_files(mf, ks, files, a):
             del os.environ["MF_INGEST"]
         else:
             os.environ["MF_INGEST"] = prev
-        rate, secs, res = run(t + "_1.fq.gz", None, t + "_od.fq", None, n)
+        rate, secs, res = run(t + "_1.fq.gz", None, t + "_od.fq", None, n, tag="configs4")
         ist = mf.last_ingest_stats()                 # (of the last of the three calls)
         md5 = md5_of(t + "_od.fq")
         gz_bytes = os.path.getsize(t + "_1.fq.gz")
@@ -361,15 +438,30 @@ def e2e_files(mf, ks, files, a):
                                          "73.9 GB/s of text (profiles/r04/h_gzdev_check_kernel_stats.csv) = 2.6e11 VALU wave-instructions/s of the chip's 6.1e11"},
             "ingest_path": "device" if ist["path"] == 1 else "host", "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9, "call_buffers_peak_GB": ist["pool_bytes_peak"] / 1e9,
             "chunks": ist["chunks"], "chunks_linked": ist["chunks_linked"], "gaps_bridged_on_host": ist["gaps"],
-            "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), "kept": int(res[0]), "total": int(res[1]),
+            "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), "first_call_seconds": first_call.get("configs4"), "kept": int(res[0]), "total": int(res[1]),
+            # the same file through the boundary the reference has: a process per call (HIP start-up, streams, pinned staging, the bait set's build
+            # and the call), process start to exit, run before this process touched the GPU
+            "cli_cold": dict(files["full_cli"], reads_per_s=n / files["full_cli"]["seconds"], kept_equals_library=bool(files["full_cli"]["kept"] == int(res[0]))) if "full_cli" in files else files.get("cli_error"),
             "gz_bytes": gz_bytes, "text_bytes": os.path.getsize(t + "_1.fq"),
             "input": "synthetic single-end FASTQ (tools/make_fastq.py), ONE gzip member written by tools/pgzip.py at level 6 (8 MiB slices)",
             "ingest": "device: compressed bytes uploaded as they are; inflate, line index, 2-bit pack, filter, survivor copy on the GPU",
             "output_md5": md5, "output_equals_host_pipeline_on_plain_text": bool(md5 == md5_of(t + "_oh.fq") and tuple(res) == tuple(host_res)),
             "host_pipeline_plain_reads_per_s": host_rate, "host_pipeline_gz_reads_per_s": host_gz_rate,
             "prep_seconds": files.get("full_prep_seconds")}
+        try:          # the plain text of the same reads: single-end, 10.7 GB
+            out["configs4_se_plain"] = plain_leg(t + "_1.fq", None, t + "_p", n, "se_plain")
+        except Exception as e:
+            out["configs4_se_plain"] = {"error": str(e)[:200]}
     elif "full_note" in files:
         out["configs4_se_gz"] = {"skipped": files["full_note"]}
+    if "plain" in files:
+        try:
+            c = files["plain"]
+            out["configs1_pe_plain"] = plain_leg(c + "_1.fq", c + "_2.fq", c + "_p", 2 * a.plain_pairs, "pe_plain")
+        except Exception as e:
+            out["configs1_pe_plain"] = {"error": str(e)[:200]}
+    elif "plain_note" in files:
+        out["configs1_pe_plain"] = {"skipped": files["plain_note"]}
     if "real" in files:
         # an eighth of configs[4], compressed by gzip / pigz / bgzip themselves (not by this repository's tools/pgzip.py): the same
         # call, checked against the host pipeline on the plain text of the same reads
@@ -506,6 +598,12 @@ def main():
         live = live_traffic(a.k)
         if a.k < 28 and live[0] is not None:                  # the stride-8 screen is bound by vector issue, not by HBM: count its instructions too
             valu = live_counters(("SQ_INSTS_VALU",), a.k)
+    # configs[2]: the stride-8 legs of the k sweep get their own live instruction count (one more short child run each)
+    sweep_valu = {}
+    if solo and not a.no_live_traffic and default_set and a.k_sweep and a.k_sweep != "none" and live[0] is not None:
+        for kk in [int(x) for x in a.k_sweep.replace('"', "").split(",") if x.strip().isdigit()]:
+            if kk < 28 and kk != a.k:
+                sweep_valu[kk] = live_counters(("SQ_INSTS_VALU",), kk)
 
     # every rank packs its own synthetic shard on the host first: share the host's threads between the ranks of the node
     if local_world > 1 and "MF_HOST_THREADS" not in os.environ:
@@ -612,9 +710,23 @@ def main():
                 os.environ["MF_EVENT_STRIDE"] = "1"
                 sp2 = mf.filter_resident(ks2, reads, THRESHOLD, mf.MODE_SCREENED, n_st)
                 os.environ["MF_EVENT_STRIDE"] = "8"
+                scr_s = sp2.ms_screen / 1e3
+                hbm2 = {"achieved": alg_bytes / scr_s / 1e9 if scr_s > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": alg_bytes / scr_s / 1e9 / HBM_PEAK_GBPS if scr_s > 0 else None}
+                if kk >= 28:
+                    roof2 = {"bound": "hbm", **hbm2, "kernel": "screen_kernel", "avg_kernel_ms": sp2.ms_screen, "kernel_launches_averaged": n_st,
+                             "whole_pass_frac": alg_bytes / (dt / n_st) / 1e9 / HBM_PEAK_GBPS}
+                else:
+                    v, why = sweep_valu.get(kk, (None, "not collected"))
+                    ginst = v["SQ_INSTS_VALU"] / scr_s / 1e9 if (v and scr_s > 0) else None
+                    roof2 = {"bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST if ginst else None,
+                             "kernel": "screen_kernel (stride-8 geometry)", "avg_kernel_ms": sp2.ms_screen, "kernel_launches_averaged": n_st, "hbm": hbm2,
+                             "valu_wave_instructions_per_launch": v["SQ_INSTS_VALU"] if v else None,
+                             "valu_source": "live: rocprofv3 --pmc SQ_INSTS_VALU child run of this script at this k on this box" if v else f"no live reading ({why})",
+                             "whole_pass_frac_of_hbm_peak": alg_bytes / (dt / n_st) / 1e9 / HBM_PEAK_GBPS}
                 sweep[str(kk)] = {"reads_per_s": a.reads * n_st / dt, "ms_per_step": dt / n_st * 1e3, "steps": n_st, "passed": int(s2.n_pass),
                                   "ms_screen_kernel": round(sp2.ms_screen, 4), "whole_pass_frac_of_hbm_peak": round(alg_bytes / (dt / n_st) / 1e9 / HBM_PEAK_GBPS, 4),
-                                  "bound": "valu (stride-8 screen)" if kk < 28 else "hbm"}
+                                  "bound": "valu (stride-8 screen)" if kk < 28 else "hbm", "roofline": roof2}
                 ks2.close()
             except Exception as e:
                 sweep[str(kk)] = {"error": str(e)[:160]}

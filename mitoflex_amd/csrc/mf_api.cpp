@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -937,7 +938,18 @@ static int filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq
     {
         const char *ing = getenv("MF_INGEST");
         const bool force = ing && strcmp(ing, "device") == 0, any_gz = has_gz_ext(fq1) || (fq2 && has_gz_ext(fq2));
-        if (!(ing && strcmp(ing, "host") == 0) && (force || any_gz)) {
+        // Plain files of a gigabyte and more take the device path too (round 5): their bytes go up as they lie and are cut, packed and filtered there
+        // -- 159 M reads/s single-end and 126 M paired at 10.7 GB against the host pipeline's 108 M / 99 M (profiles/r05/bench_shape_default.json:
+        // extra.e2e_files.configs4_se_plain / configs1_pe_plain); below that the host pipeline's single batch is as fast and starts sooner
+        // (MF_INGEST_PLAIN_MIN_MB moves the line).
+        bool big_plain = false;
+        if (!any_gz && fq1) {
+            struct stat sb; uint64_t sum = 0; bool regular = true;
+            for (const char *f : {fq1, fq2}) if (f) { if (stat(f, &sb) == 0 && S_ISREG(sb.st_mode)) sum += (uint64_t)sb.st_size; else regular = false; }
+            const char *mn = getenv("MF_INGEST_PLAIN_MIN_MB");
+            big_plain = regular && sum >= (mn && *mn ? strtoull(mn, nullptr, 10) : 1024) << 20;
+        }
+        if (!(ing && strcmp(ing, "host") == 0) && (force || any_gz || big_plain)) {
             std::string derr; IngestStats is;
             const int drc = run_device_ingest(ks, fq1, fq2, out1, out2, threshold, pair_mode == MF_PAIR_BOTH, devices, n_devices, kept, total, derr, &is);
             if (drc == MF_OK) {

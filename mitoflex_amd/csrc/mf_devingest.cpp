@@ -330,10 +330,17 @@ struct DeviceStreams {
         (void)hipGetLastError();
         return hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
     }
+    // The maker goes as far as somebody has asked for (want): a small file's call asks for the first decode stream, the copy stream and the
+    // post streams and nothing else -- every further decode stream is asked for by the launch that could have used it (which takes an
+    // existing one meanwhile), the masked post streams by a large input.  The runtime makes streams one after the other, whoever asks: a
+    // maker that ran through all sixteen at once held up the consumers' own streams for a tenth of a second (profiles/r05/c_cold_calls_factory.log).
+    int want = POST1 + 1;
+    void ask(int upto) { { std::lock_guard<std::mutex> lk(mu); if (upto > want) want = upto; } cv.notify_all(); }
     void run()
     {
         if (hipSetDevice(device) != hipSuccess) { fail_(); return; }
         for (int w = 0; w < N_WHAT && !stop; w++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || want > w; }); if (stop) return; }
             bool ok = true;
             switch (w) {
             case DEC0: ok = make_masked(&dec[0], mask); if (ok) n_dec = 1; break;
@@ -352,7 +359,13 @@ struct DeviceStreams {
     }
     void fail_() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
     bool wait_for(What w) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || made > (int)w; }); return made > (int)w; }
-    hipStream_t pick_dec(uint32_t seq) { if (!wait_for(DEC0)) return nullptr; return dec[seq % std::max<uint32_t>(1, n_dec.load())]; }
+    hipStream_t pick_dec(uint32_t seq)
+    {
+        if (!wait_for(DEC0)) return nullptr;
+        const uint32_t n = n_dec.load();
+        if (seq >= n && n < GZ_NSTREAM) ask(n < 4 ? DEC1 + (int)n : N_WHAT);          // (one more for the next launch; the last six come together)
+        return dec[seq % std::max<uint32_t>(1, n)];
+    }
     hipStream_t copy_stream() { return wait_for(COPY) ? copy : nullptr; }
     // a post stream for one mate of one call (given back with give_post); want_masked: a large input
     hipStream_t take_post(bool want_masked, int *slot)
@@ -362,7 +375,7 @@ struct DeviceStreams {
         { std::lock_guard<std::mutex> lk(mu); for (int i = 0; i < (int)GZ_NPOST; i++) if (!post_busy[i]) { post_busy[i] = true; k = i; break; } }
         *slot = k;
         if (k < 0) { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; }      // (more than two mates at a time on one device: concurrent calls)
-        if (want_masked && masked && wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k];
+        if (want_masked && masked) { ask(POSTM1 + 1); if (wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k]; }
         return post[k];
     }
     void give_post(int slot, hipStream_t q)
@@ -410,12 +423,16 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         if (prefill_started_) return;
         prefill_started_ = true;
-        prefill_ = std::thread([device] { if (hipSetDevice(device) == hipSuccess) g_pinned.prefill(2, ((size_t)32 << 20) + 256); cold_mark("prefetch: staging buffers pinned"); });
+        prefill_ = std::thread([device] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            g_pinned.prefill(2, ((size_t)32 << 20) + 256); cold_mark("prefetch: staging buffers pinned");
+            gz_preload(); ingest_preload(); cold_mark("prefetch: code objects of the decoder and the line kernels loaded");
+        });
     }
     ~StreamSets()
     {
         if (prefill_.joinable()) prefill_.join();
-        for (auto &kv : dev_) { kv.second->stop = true; if (kv.second->maker.joinable()) kv.second->maker.join(); }
+        for (auto &kv : dev_) { kv.second->stop = true; kv.second->cv.notify_all(); if (kv.second->maker.joinable()) kv.second->maker.join(); }
         const char *pre = getenv("LD_PRELOAD");
         const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
         if (!profiled) return;
@@ -597,7 +614,7 @@ public:
         }
         reap(true);
         for (auto &S : slabs_) drop_events(*S);
-        slabs_.clear(); pend_.buf.reset(); cur_buf_.reset();
+        slabs_.clear(); cur_buf_.reset();
         for (auto &L : lanes_) {
             L.ring.release(); L.d_chunks.release(); L.d_window.release(); L.d_crc.release(); L.d_acc.release(); L.d_acc_off.release(); L.d_link.release();
             (void)hipSetDevice(L.dev);
@@ -694,6 +711,7 @@ public:
             L.ds = g_streams.get(L.dev, err);          // (starts the maker thread if this is the device's first use; nothing here waits for a stream)
             if (!L.ds) return MF_E_HIP;
             L.want_masked_post = large;
+            if (n_chunks_ > 4 * cps_) L.ds->ask(DeviceStreams::N_WHAT);          // a file of many slabs: every decode stream, now -- they are made while the first slabs decode
             t_open_streams_ += now_s() - tl0;
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
             DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_window.need(L.dev, GZ_WINDOW, false));
@@ -720,15 +738,13 @@ public:
         return MF_OK;
     }
     // The next piece of text (possibly nothing: out.buf is null).  Nothing here waits for the link, resolve or CRC kernels of a piece: the
-    // piece is handed over with an event (TextPiece::ready) that the consumer's stream waits for; what the producer does wait for is the
-    // decode kernel of the front slab (it needs the chunks' descriptors) and a text buffer.  The piece a call returns is the one BEFORE the
-    // piece it has just linked -- nothing the first time, the last piece in a call of its own -- so that a buffer's slot is asked for with
-    // the previous piece still in hand exactly once (as before: tests of the slot arithmetic rest on it).
+    // piece is handed over with an event (TextBuf::ready) that the consumer's stream waits for; what the producer does wait for is the
+    // decode kernel of the front slab (it needs the chunks' descriptors) and a text buffer.
     int next(TextPiece &out, std::string &err)
     {
         out = TextPiece();
         reap(false);
-        if (done_ || (slabs_.empty() && next_plan_ >= plan_.size())) return finish_pending(out, err);
+        if (done_ || (slabs_.empty() && next_plan_ >= plan_.size())) return MF_OK;
         // decode runs ahead of the text: the front slab (waiting for its bytes if need be) and as many of the following ones as the
         // ring has room and uploaded bytes for
         const double tla = now_s();
@@ -796,7 +812,7 @@ public:
         if (rc) return rc;
         t_newtext_ += now_s() - tl0;
         // link; the host steps in where the walk stops
-        for (bool first = true;; first = false) {
+        for (;;) {
             if (!done_ && in_member_) {
                 // which chunks are accepted: a walk over the descriptors, here; the windows: kernels, on the post stream
                 const uint32_t wlen_before = link_.wlen;
@@ -812,7 +828,6 @@ public:
                     if (lanes_.size() > 1) { rc = window_down(err); if (rc) return rc; }          // (the next slab is linked on another device)
                 }
             }
-            if (first) { const double tf = now_s(); rc = finish_pending(out, err); if (rc) return rc; DCHK(hipSetDevice(L.dev)); t_finish_ += now_s() - tf; }
             if (done_) break;
             uint64_t to_bit = 0;
             // (behind a member's end the walk goes on with the rest of the piece's chunks, from the next member's first block)
@@ -853,11 +868,10 @@ public:
         S.cur = b;
         const bool slab_done = S.cur == S.hi || done_;
         if (last_piece && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
-        // the piece is text once everything queued on the post stream up to here has run
+        // the piece is text once everything queued on the post stream up to here has run: it is handed over now, with the event that says so
         DCHK(hipEventRecord(cur_buf_->ready_event(), sp));
-        pend_.buf = std::move(cur_buf_); pend_.T0 = T0; pend_.len = link_.total - T0; pend_.last = done_;
-        pend_.grow = b > a ? std::max(1.0, (double)cps_ / (double)(b - a)) : 1.0;
-        pending_ = true;
+        out.buf = std::move(cur_buf_); out.T0 = T0; out.len = link_.total - T0; out.last = done_;
+        out.grow = b > a ? std::max(1.0, (double)cps_ / (double)(b - a)) : 1.0;
         if (slab_done) {
             // its symbols are being resolved: the slab is kept until the post stream has passed this point
             Retired R; R.slab = std::move(slabs_.front()); slabs_.pop_front();
@@ -870,19 +884,11 @@ public:
         }
         return MF_OK;
     }
-    // the piece linked by the call before goes to `out` (its kernels may still be running: TextPiece::ready says when it is text)
-    int finish_pending(TextPiece &out, std::string &err)
-    {
-        (void)err;
-        if (!pending_) return MF_OK;
-        out = std::move(pend_); pend_ = TextPiece(); pending_ = false;
-        return MF_OK;
-    }
-    bool finished() const { return !pending_ && (done_ || (slabs_.empty() && next_plan_ >= plan_.size())); }
+    bool finished() const { return done_ || (slabs_.empty() && next_plan_ >= plan_.size()); }
     uint64_t text_bytes() const { return link_.total; }
     double launch_seconds() const { return t_launch_; }
     void open_parts(double &all, double &streams, double &uploader) const { all = t_open_; streams = t_open_streams_; uploader = t_open_upload_; }
-    void link_parts(double &newtext, double &finish, double &post_wait) const { newtext = t_newtext_; finish = t_finish_; post_wait = t_post_wait_; }
+    void link_parts(double &newtext, double &post_wait) const { newtext = t_newtext_; post_wait = t_post_wait_; }
     double slot_seconds() const { return t_slot_; }
     // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer); the uploader's
     void producer_times(double &wait_decode, double &link, double &up_ring, double &up_copy, double &up_read) const
@@ -972,6 +978,9 @@ private:
             // the chunks read past their own range up to the end of a block, and the reader's ring a little further
             const size_t upto = std::min(size_, base_byte_ + (size_t)S.hi * chunk_ + margin_);
             if (i > 0 && !up_->issued(upto)) break;
+            // (decode kernels on one stream run one after the other, each waiting for the last straggler of the one before: while the
+            // device's decode streams are still being made -- a process's first large file -- no more than two slabs are queued per stream)
+            if (i >= 2 * (size_t)std::max<uint32_t>(1, L.ds->n_dec.load())) break;
             DCHK(hipSetDevice(L.dev));
             if (!S.cap) S.cap = sym_cap_now();
             DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
@@ -1132,11 +1141,10 @@ private:
     std::vector<uint32_t> acc_; std::vector<uint64_t> acc_off_;
     GzChunk *h_chunks_ = nullptr;                      // pinned: every chunk's descriptor, copied down behind its slab's decode kernel
     std::unique_ptr<TextBuf> cur_buf_;
-    TextPiece pend_; bool pending_ = false;
     double t_open_ = 0, t_open_streams_ = 0, t_open_upload_ = 0;
     bool in_member_ = false, done_ = false, first_launched_ = false, first_decoded_ = false;
     uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0; int crc_out_ = -1;      // crc_out_: the lane whose CRC launch has not been taken in yet
-    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_finish_ = 0, t_post_wait_ = 0, t_slot_ = 0;
+    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_post_wait_ = 0, t_slot_ = 0;
 };
 
 // ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
@@ -1307,6 +1315,7 @@ struct Ingest {
     QualState *qual = nullptr;          // set: the job is the quality filter (one device), not the bait filter
     Mate m[2]; int nm = 1;
     uint64_t kept = 0, total = 0;
+    std::atomic<bool> first_indexed_{false}, first_filtered_{false};
     std::atomic<bool> wrote_any{false};          // a byte of the output has been handed to a writer: the call can no longer be given to the host pipeline
     size_t mem_used_max = 0;           // device memory in use (everything on the device, this path's buffers and the rest), the largest seen after a piece
     size_t carry_room = (size_t)1 << 20;
@@ -1350,7 +1359,7 @@ struct Ingest {
                 TextPiece t;
                 rc = M.gzs->next(t, err);
                 if (rc || M.stop) break;
-                if (!t.buf) { if (M.gzs->finished()) break; continue; }   // (the first call: the decoder hands a piece over one call late)
+                if (!t.buf) { if (M.gzs->finished()) break; continue; }
                 const bool last = t.last;
                 publish(M, std::move(t));
                 if (last) break;
@@ -1441,6 +1450,8 @@ struct Ingest {
         const int dev = S.dev;
         hipStream_t sp = S.ctx->stream;
         if (P.buf->ready_recorded) DCHK(hipStreamWaitEvent(sp, P.buf->ready, 0));          // (the piece's link, resolve and CRC kernels may still be running)
+        const bool first_piece = !first_indexed_.exchange(true);
+        if (first_piece) cold_mark("consumer: first piece taken");
         // the carry in front of the piece's text.  It fits the room in front of the buffer -- or the piece moves to a buffer that
         // holds both (records longer than the room: tests, mostly)
         if (M.carry > P.buf->pad) {
@@ -1470,6 +1481,7 @@ struct Ingest {
             DCHK(hipMemcpyAsync(S.h_small + 0, S.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipMemcpyAsync(S.h_small + 1, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
+            if (first_piece) cold_mark("consumer: first piece is text, its newlines counted");
             const uint64_t newlines = hs[0]; const uint8_t last_byte = (uint8_t)hs[1];
             const bool open_line = P.last && last_byte != '\n';      // lines() yields an unterminated last line
             n_lines = newlines + (open_line ? 1 : 0);
@@ -1496,6 +1508,7 @@ struct Ingest {
         M.carry = carry;
         B->buf = std::move(P.buf);
         Bout = std::move(B);
+        if (first_piece) cold_mark("consumer: first piece indexed");
         if (timing) { std::lock_guard<std::mutex> lk(mu); t_index += now_s() - t0; }
         return MF_OK;
     }
@@ -1566,6 +1579,7 @@ struct Ingest {
         if (bw + 2 > S.h_bits_cap) { if (S.h_bits) (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (bw + bw / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = bw + bw / 2 + 1024; }
         rc = filter_common(ks, R, threshold, MF_MODE_SCREENED, S.h_bits, nullptr, 1, nullptr);
         if (rc) { err = mf_thread_error(); return rc; }
+        if (!first_filtered_.exchange(true)) cold_mark("consumer: first piece packed and filtered");
         {
             size_t f = 0, t = 0; const bool got = hipMemGetInfo(&f, &t) == hipSuccess;
             std::lock_guard<std::mutex> lk(mu);
@@ -2266,7 +2280,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);
                               { double oa, os, ou; I.m[i].gzs->open_parts(oa, os, ou); fprintf(stderr, "; set-up %.3f (streams %.3f, uploader's buffers and thread %.3f)", oa, os, ou); }
-                              double x, y, z; I.m[i].gzs->link_parts(x, y, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f, handing the piece before over %.3f; waiting for the post stream to be made %.3f)", x, I.m[i].gzs->slot_seconds(), y, z); }
+                              double x, z; I.m[i].gzs->link_parts(x, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f; waiting for the post stream to be made %.3f)", x, I.m[i].gzs->slot_seconds(), z); }
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) fprintf(stderr, " | mate %d: inflate kernels busy %.3f s (%.1f GB/s of text), %llu of %u chunks of %zu KiB linked, %llu gaps bridged on the host, %llu bytes decoded there, ring %zu MiB, %u slab splits", i + 1, I.m[i].gzs->decode_busy_seconds(), I.m[i].gzs->decode_busy_seconds() > 0 ? (double)I.m[i].gzs->text_bytes() / I.m[i].gzs->decode_busy_seconds() / 1e9 : 0.0, (unsigned long long)I.m[i].gzs->chunks_linked(),
                                     I.m[i].gzs->chunks(), I.m[i].gzs->chunk_bytes() >> 10, (unsigned long long)I.m[i].gzs->gaps(), (unsigned long long)I.m[i].gzs->gap_bytes(), I.m[i].gzs->ring_bytes() >> 20, I.m[i].gzs->splits());

@@ -107,6 +107,8 @@ inline size_t gz_link_scratch_bytes(uint32_t max_chunks)
     for (uint32_t n : {16u, 64u, 512u, max_chunks}) { const uint32_t m = n < max_chunks ? n : max_chunks; if (m) { const uint32_t g = (m + gz_link_group(m) - 1) / gz_link_group(m); if (g > groups) groups = g; } }
     return (size_t)groups * GZ_WINDOW * 3 + 256;
 }
+void gz_preload();          // loads this file's code object now instead of at its first launch (a cold call's prefetch thread)
+
 // CRC-32 (gzip) of d_text[0 .. n) as 64 KiB pieces: d_piece[i] = the pure polynomial remainder (register starts at 0, no final
 // inversion) of piece i; gz_crc_finish() on the host folds them into zlib's crc32() value.
 constexpr uint32_t GZ_CRC_PIECE = 65536;

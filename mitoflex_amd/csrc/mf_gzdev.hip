@@ -388,9 +388,99 @@ __device__ __forceinline__ bool vet_header(const uint32_t *words, uint64_t wmask
     if (nd > 1 && kd != 32768u) return false;
     return c + used <= size_bits;
 }
-// the next candidate that passes vet_header (~0: none in [.., to_bit)); V: the batch in hand
+// V: a batch of vetted candidates in hand
 struct Vetted { uint64_t cand; uint64_t vmask; bool dry; };      // cand: this lane's candidate of the batch; vmask: lanes whose candidate came through and has not been handed out
-__device__ __forceinline__ uint64_t next_vetted(Search &S, Vetted &V, const uint32_t *words, uint64_t wmask, uint64_t max_dw, uint64_t to_bit, uint64_t size_bits, uint32_t lane)
+
+// ---- round 5: the same search with the lanes kept busy.  next_candidate gives every lane ONE bit offset of a window and lets all 64 run the
+// 19-step Kraft sum of the precode whenever any of them got past the type bits -- one lane in nine does, so eight ninths of that work was
+// idle lanes: 35 cycles a bit offset, 6 M of a 256 KiB chunk's 33 M cycles on a gzip -6 file (profiles/r04/c_gzdev_check_phases.log).  Now the
+// survivors of the cheap test (type bits, symbol counts: a dozen instructions a window) are COMPACTED into a list in LDS, and the Kraft sum
+// runs on 64 of them at a time, one per lane; what passes is compacted again into the batch of 64 candidates that vet_header takes, one per
+// lane.  Same candidates in the same (ascending) order.  The search keeps no queues between calls: `pos` is the next bit offset to look at --
+// behind a batch it is the bit after the batch's last candidate (the few survivors that had been collected behind it are found again), and a
+// chunk whose speculative decode failed goes on from the bit behind that start.
+struct Search2 { uint64_t pos; };
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// list1: 128 entries, list2: 64 entries (LDS; free while a chunk searches).  Returns this lane's candidate of the batch (~0: none) and the batch's size in n.
+__device__ __forceinline__ uint64_t collect_candidates(Search2 &S, uint32_t *list1, uint32_t *list2, const uint32_t *words, uint64_t wmask, uint64_t to_bit, uint64_t size_bits,
+                                                       uint32_t lane, uint32_t &n_out, bool &dry)
+{
+    const uint64_t base = S.pos;                    // (offsets in the lists are relative to it: a chunk's range is far below 2^32 bits)
+    uint64_t pos = S.pos;
+    uint32_t n = 0, c1 = 0;
+    for (;;) {
+        // ---- the cheap test, four windows of 64 offsets at a time (their loads in flight together), survivors to list1
+        while (c1 < 64 && pos < to_bit) {
+            uint32_t w0[SEARCH_W], w1[SEARCH_W]; bool in[SEARCH_W];
+            const uint64_t p0 = pos;
+#pragma unroll
+            for (int j = 0; j < SEARCH_W; j++) {
+                const uint64_t bit = p0 + (uint64_t)(64 * j) + lane;
+                in[j] = bit < to_bit && bit + 128 <= size_bits;
+                const uint64_t wi = in[j] ? bit >> 5 : 0;
+                w0[j] = words[wi & wmask]; w1[j] = words[(wi + 1) & wmask];
+            }
+#pragma unroll
+            for (int j = 0; j < SEARCH_W; j++) {
+                const uint64_t bit = p0 + (uint64_t)(64 * j) + lane;
+                const uint32_t h0 = __funnelshift_r(w0[j], w1[j], (uint32_t)bit & 31u);
+                const bool ok = in[j] && (h0 & 7u) == 4u && ((h0 >> 3) & 31u) <= 29u && ((h0 >> 8) & 31u) <= 29u;      // BFINAL = 0, BTYPE = 10b, HLIT, HDIST in range
+                const uint64_t m = __ballot(ok);
+                if (c1 < 64) {                      // (a window that would take the list past its 128 entries is looked at again next time)
+                    if (ok) list1[c1 + lanes_below(m)] = (uint32_t)(bit - base);
+                    c1 += (uint32_t)__popcll(m);
+                    pos += 64;
+                }
+            }
+        }
+        const uint32_t take = c1 < 64 ? c1 : 64;
+        if (!take) { dry = true; S.pos = to_bit; break; }
+        __syncthreads();
+        // ---- the Kraft sum of the precode, on 64 survivors at once
+        bool ok = false; uint32_t off = 0;
+        if (lane < take) {
+            off = list1[lane];
+            const uint64_t bit = base + off, wi = bit >> 5;
+            const uint32_t s = (uint32_t)bit & 31u;
+            const uint32_t x0 = words[wi & wmask], x1 = words[(wi + 1) & wmask], x2 = words[(wi + 2) & wmask], x3 = words[(wi + 3) & wmask];
+            const uint32_t h0 = __funnelshift_r(x0, x1, s), h1 = __funnelshift_r(x1, x2, s), h2 = __funnelshift_r(x2, x3, s);
+            const uint32_t hclen = ((h0 >> 13) & 15u) + 4;
+            const uint64_t a = h0 | ((uint64_t)h1 << 32), b = h1 | ((uint64_t)h2 << 32);
+            uint32_t k = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 19; i++) {
+                const uint32_t p = 17 + 3 * i;
+                const uint32_t l = (uint32_t)(p < 32 ? (a >> p) : (b >> (p - 32))) & 7u;
+                if (i < hclen && l) k += 128u >> l;
+            }
+            ok = k == 128u;
+        }
+        const uint64_t m2 = __ballot(ok);
+        const uint32_t r2 = n + lanes_below(m2), cnt2 = (uint32_t)__popcll(m2);
+        if (ok && r2 < 64) list2[r2] = off;
+        if (n + cnt2 >= 64) {                       // the batch is full: the search goes on behind its last candidate
+            const uint64_t last = __ballot(ok && r2 == 63);
+            const uint32_t last_off = __shfl(off, __ffsll((unsigned long long)last) - 1);
+            S.pos = base + last_off + 1; n = 64;
+            break;
+        }
+        n += cnt2;
+        // what is left of list1 moves to its front
+        __syncthreads();
+        uint32_t mv0 = 0;
+        if (lane + 64 < c1) mv0 = list1[lane + 64];
+        __syncthreads();
+        if (lane + 64 < c1) list1[lane] = mv0;
+        c1 -= take;
+        __syncthreads();
+        if (pos >= to_bit && c1 == 0) { dry = true; S.pos = to_bit; break; }
+    }
+    __syncthreads();
+    n_out = n;
+    return lane < n ? base + list2[lane] : ~0ull;
+}
+__device__ __forceinline__ uint64_t next_vetted2(Search2 &S, Vetted &V, uint32_t *list1, uint32_t *list2, const uint32_t *words, uint64_t wmask, uint64_t max_dw, uint64_t to_bit,
+                                                 uint64_t size_bits, uint32_t lane)
 {
     for (;;) {
         if (V.vmask) {
@@ -399,13 +489,8 @@ __device__ __forceinline__ uint64_t next_vetted(Search &S, Vetted &V, const uint
             return __shfl(V.cand, idx);
         }
         if (V.dry) return ~0ull;
-        uint32_t n = 0; uint64_t mine = ~0ull;
-        while (n < 64) {
-            const uint64_t c = next_candidate(S, words, wmask, to_bit, size_bits, lane);
-            if (c == ~0ull) { V.dry = true; break; }
-            if (lane == n) mine = c;
-            n++;
-        }
+        uint32_t n = 0;
+        const uint64_t mine = collect_candidates(S, list1, list2, words, wmask, to_bit, size_bits, lane, n, V.dry);
         const bool ok = lane < n && vet_header(words, wmask, max_dw, mine, size_bits);
         V.cand = mine; V.vmask = __ballot(ok);
     }
@@ -1230,8 +1315,9 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
     LaneIn in; in.words = reinterpret_cast<const uint32_t *>(data); in.origin_dw = rd.origin_v * 4; in.wmask = ring_mask >> 2; in.max_dw = rd.vmax * 4 + 3;
     const uint64_t origin_bits = rd.origin_v * 128;
     bool searching = c != exact_chunk;
-    Search S; search_init(S, nominal);
+    Search2 S; S.pos = nominal;
     Vetted V; V.cand = ~0ull; V.vmask = 0; V.dry = false;
+    uint32_t *const cand1 = L.stg, *const cand2 = L.stg + 128;          // the search's lists: that part of LDS is the decoder's only once a start has been found
     uint64_t start = exact_bit, opos = 0, blk_pos = exact_bit, blk_opos = 0;
     uint32_t status = GZ_NONE;
     if (!searching) rd.seek(start, lane);
@@ -1249,7 +1335,7 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
         why = 0;
         PROF_T0();
         if (searching) {
-            start = next_vetted(S, V, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, in.max_dw, search_end, size_bits, lane);
+            start = next_vetted2(S, V, cand1, cand2, reinterpret_cast<const uint32_t *>(data), ring_mask >> 2, in.max_dw, search_end, size_bits, lane);
             if (start == ~0ull) { status = GZ_NONE; break; }
             rd.seek(start + 3, lane);
             strict = true; opos = 0; blk_pos = start; blk_opos = 0;
@@ -1310,8 +1396,8 @@ __global__ __launch_bounds__(64) void gz_decode2_kernel(const uint8_t *data, uin
         }
         if (why) {
             // not deflate data.  From a speculative start that only says the candidate was false: the search goes on behind it
-            // (S still holds the rest of the candidates of its step)
-            if (c != exact_chunk && why != 8) { searching = true; continue; }
+            // (from the bit behind the failed start: the search keeps no queue of its own)
+            if (c != exact_chunk && why != 8) { searching = true; S.pos = start + 1; V.vmask = 0; V.dry = S.pos >= search_end; continue; }
             status = GZ_FAILED; break;
         }
         if (final) { status = GZ_MEMBER_END; break; }
@@ -1604,6 +1690,10 @@ hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint
         hipLaunchKernelGGL(gz_resolve_kernel, dim3((max_sym - GZ_WINDOW + RESOLVE_SEG - 1) / RESOLVE_SEG, n_acc), dim3(256), 0, st, d_acc, d_acc_off, d_chunks, chunk_lo, d_sym, sym_cap, d_text, text_base);
     return hipGetLastError();
 }
+
+// The runtime loads a translation unit's code object when the first of its kernels is asked for (20-50 ms): asking for the attributes of one
+// does that too, so a thread can get it out of the way while a cold call is still reading its first bytes (ingest_prefetch, mf_devingest.cpp)
+void gz_preload() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&gz_decode2_kernel)); (void)hipGetLastError(); }
 
 hipError_t launch_gz_crc(const uint8_t *d_text, uint64_t n, uint32_t *d_piece, hipStream_t st)
 {

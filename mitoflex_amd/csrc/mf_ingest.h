@@ -9,6 +9,8 @@
 
 namespace mf {
 
+void ingest_preload();          // loads this file's code object now instead of at its first launch
+
 constexpr uint32_t INGEST_TILE = 4096;          // bytes of text per workgroup of the line kernels
 
 // exclusive prefix sums, u32 -> u64: out[0 .. n] (n + 1 values, out[n] = total).  scratch: (n / 4096 + 2) u64

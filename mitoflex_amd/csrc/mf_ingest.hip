@@ -462,6 +462,8 @@ __global__ __launch_bounds__(256) void qual_gather_kernel(const uint8_t *text, c
 
 } // namespace
 
+void ingest_preload() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&count_newlines_kernel)); (void)hipGetLastError(); }      // (see gz_preload, mf_gzdev.hip)
+
 uint64_t pack_blocks(uint64_t total_bases, uint64_t base)
 {
     if (!total_bases) return 0;

@@ -83,6 +83,8 @@ int filter_common(const mf_kmerset *, const mf_reads *r, uint32_t, int, uint32_t
 namespace mf {
 
 // ------------------------------------------------------------------------------------------------ mf_gzdev.h
+void gz_preload() {}
+void ingest_preload() {}
 size_t gz_decode_scratch_bytes(uint32_t n_chunks) { return (size_t)n_chunks * 16; }
 bool gz_decode_serial() { return false; }
 

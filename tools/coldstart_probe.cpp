@@ -6,6 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,6 +60,42 @@ int main(int argc, char **argv)
         STEP("hipHostRegister 64 MiB of touched malloc memory", (void)hipHostRegister(p, (size_t)64 << 20, hipHostRegisterPortable));
         STEP("hipHostUnregister", (void)hipHostUnregister(p));
         free(p);
+    }
+    if (const char *path = getenv("PROBE_MMAP")) {          // can the copy engine read a file's pages where the page cache holds them?  (register the mapping, copy from it)
+        int fd = open(path, O_RDONLY); struct stat sb; fstat(fd, &sb);
+        const size_t n = (size_t)sb.st_size & ~(size_t)((2 << 20) - 1);
+        void *dev = nullptr; (void)hipMalloc(&dev, n);
+        hipStream_t st; (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int variant = 0; variant < 4; variant++) {
+            const int prot = variant & 1 ? PROT_READ | PROT_WRITE : PROT_READ;
+            const unsigned flags = variant & 2 ? hipHostRegisterPortable : (hipHostRegisterPortable | hipHostRegisterReadOnly);
+            void *m = mmap(nullptr, n, prot, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m == MAP_FAILED) { printf("mmap failed\n"); continue; }
+            char w[160];
+            snprintf(w, sizeof w, "hipHostRegister of %zu MiB of a %s private file mapping, %s", n >> 20, prot & PROT_WRITE ? "read-write" : "read-only", variant & 2 ? "default flags" : "ReadOnly flag");
+            hipError_t e = hipSuccess;
+            STEP(w, e = hipHostRegister(m, n, flags));
+            if (e != hipSuccess) { printf("         | -> %s\n", hipGetErrorString(e)); (void)hipGetLastError(); munmap(m, n); continue; }
+            STEP("  hipMemcpyAsync of all of it from the registered mapping + sync", { (void)hipMemcpyAsync(dev, m, n, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); });
+            STEP("  the same again", { (void)hipMemcpyAsync(dev, m, n, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); });
+            STEP("  hipHostUnregister", (void)hipHostUnregister(m));
+            munmap(m, n);
+        }
+        {   // the reference point: pread into pinned staging (what the uploader does), 8 threads, and the copy
+            void *pin = nullptr; (void)hipHostMalloc(&pin, (size_t)32 << 20, hipHostMallocPortable);
+            const double a = now_s(); size_t done = 0;
+            while (done < n) {
+                const size_t len = n - done < ((size_t)32 << 20) ? n - done : (size_t)32 << 20;
+                std::vector<std::thread> th;
+                for (int t = 0; t < 8; t++) th.emplace_back([&, t] { size_t x = len * t / 8, y = len * (t + 1) / 8; while (x < y) { ssize_t g = pread(fd, (char *)pin + x, y - x, (off_t)(done + x)); if (g <= 0) break; x += (size_t)g; } });
+                for (auto &t : th) t.join();
+                (void)hipMemcpyAsync((char *)dev + done, pin, len, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st);
+                done += len;
+            }
+            printf("%8.4f | %-58s | %8.4f\n", now_s() - T0, "pread (8 threads) into one pinned buffer + copy, serial", now_s() - a);
+        }
+        printf("%8.4f | done (file of %zu MiB)\n", now_s() - T0, n >> 20);
+        return 0;
     }
     if (getenv("PROBE_STREAMS")) {          // how the cost of a stream depends on how many there are already, and whether making one stalls another thread's launches
         hipStream_t q[16] = {};
