@@ -476,7 +476,7 @@ static int bait_main(int argc, char **argv)
     SYM(mf_filter_fastq_files) SYM(mf_filter_fastq_files_on) SYM(mf_kmerset_free) SYM(mf_set_option)
 #undef SYM
     if (p_mf_abi_version() != MF_ABI_VERSION) { fprintf(stderr, "error: ABI version mismatch\n"); return 2; }
-    (void)p_mf_set_option("expect_files", "1");          // (the file-level call's set-up starts beside the bait set's build)
+    (void)p_mf_set_option("expect_files", "1"); (void)p_mf_set_option("short_lived", "1");          // (the file-level call's set-up starts beside the bait set's build)
     for (auto &kv : options) if (p_mf_set_option(kv.first.c_str(), kv.second.c_str()) != MF_OK) { fprintf(stderr, "error: %s\n", p_mf_last_error()); return 1; }
     mf::cold_mark("library loaded");
     mf_kmerset *ks = nullptr;

@@ -158,7 +158,7 @@ int main(int argc, char **argv)
     auto p_run = (decltype(&mf_qualfilter_files))dlsym(h, "mf_qualfilter_files");
     auto p_err = (decltype(&mf_last_error))dlsym(h, "mf_last_error");
     if (!p_run || !p_err) { fprintf(stderr, "error: %s lacks mf_qualfilter_files\n", libpath.c_str()); return 2; }
-    if (auto p_opt = (decltype(&mf_set_option))dlsym(h, "mf_set_option")) (void)p_opt("expect_files", "1");
+    if (auto p_opt = (decltype(&mf_set_option))dlsym(h, "mf_set_option")) { (void)p_opt("expect_files", "1"); (void)p_opt("short_lived", "1"); }
     uint64_t kept = 0, total = 0; int panicked = 0;
     setenv("MF_DEVPOOL_GB", "4096", 0);          // (a process that ends with the call gives no device memory back in between: the runtime frees it all at once)
     const double t_call = now();

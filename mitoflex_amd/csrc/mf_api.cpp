@@ -454,6 +454,7 @@ static int set_option(const char *name, const char *value)
     char *end = nullptr; const long x = strtol(v.c_str(), &end, 10);
     if (v.empty() || *end) return -1;
     if (n == "expect_files") g_expect_files = x != 0;
+    else if (n == "short_lived") mf::ingest_short_lived(x != 0);
     else if (n == "adapt") g_opt.adapt = x != 0;
     else if (n == "finish_streams") { if (x < 0 || x > 2) return -1; g_opt.finish_streams = (int)x; }
     else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
@@ -712,7 +713,9 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // reads and more, seen in the last call's tallies) those of consecutive passes go to two streams and run side by side --
         // 2 %: 0.303 -> 0.280 ms per pass, 10 %: 0.666 -> 0.596; at 0.5 % the same costs 2 % (0.208 -> 0.213).  MF_FINISH_STREAMS=1 / 2 forces.
         const uint32_t fin_streams = (uint32_t)g_opt.finish_streams;
-        const bool fin2 = fin_streams == 2 || (fin_streams == 0 && r->finish_two);
+        // (two-word keys, k >= 33: a finish kernel's probes are twice as long, and one stream's worth of them is not over when the next screen is --
+        // k = 41 0.2369 -> 0.2331 ms a pass, k = 63 0.2960 -> 0.2817: profiles/r05/c_k41_finish_streams_probe.txt)
+        const bool fin2 = fin_streams == 2 || (fin_streams == 0 && (r->finish_two || S.kw == 2));
         hipStream_t sf = two ? ((fin2 && (q & 1)) ? ctx->stream4 : ctx->stream2) : st;
         // consecutive screens go to two streams in turn: nothing orders them against each other (different buffer sets), so the
         // workgroups of the next screen take over the CUs as the last ones of this screen drain (MF_SCREEN_STREAMS=1: one stream)
@@ -938,16 +941,15 @@ static int filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq
     {
         const char *ing = getenv("MF_INGEST");
         const bool force = ing && strcmp(ing, "device") == 0, any_gz = has_gz_ext(fq1) || (fq2 && has_gz_ext(fq2));
-        // Plain files of a gigabyte and more take the device path too (round 5): their bytes go up as they lie and are cut, packed and filtered there
-        // -- 159 M reads/s single-end and 126 M paired at 10.7 GB against the host pipeline's 108 M / 99 M (profiles/r05/bench_shape_default.json:
-        // extra.e2e_files.configs4_se_plain / configs1_pe_plain); below that the host pipeline's single batch is as fast and starts sooner
-        // (MF_INGEST_PLAIN_MIN_MB moves the line).
+        // Plain regular files take the device path too (round 5): their bytes go up as they lie and are cut, packed and filtered there -- ahead of the
+        // host pipeline at every size measured, 0.16 GB (7 ms against 20) to 10.7 GB (profiles/r05/e_masks_ab.txt, bench: extra.e2e_files.configs4_se_plain /
+        // configs1_pe_plain).  MF_INGEST_PLAIN_MIN_MB sets a size below which plain files keep the host pipeline (default 0).
         bool big_plain = false;
         if (!any_gz && fq1) {
             struct stat sb; uint64_t sum = 0; bool regular = true;
             for (const char *f : {fq1, fq2}) if (f) { if (stat(f, &sb) == 0 && S_ISREG(sb.st_mode)) sum += (uint64_t)sb.st_size; else regular = false; }
             const char *mn = getenv("MF_INGEST_PLAIN_MIN_MB");
-            big_plain = regular && sum >= (mn && *mn ? strtoull(mn, nullptr, 10) : 1024) << 20;
+            big_plain = regular && sum > 0 && sum >= (mn && *mn ? strtoull(mn, nullptr, 10) : 0) << 20;
         }
         if (!(ing && strcmp(ing, "host") == 0) && (force || any_gz || big_plain)) {
             std::string derr; IngestStats is;
@@ -1049,7 +1051,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, expect_files=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 

@@ -4,12 +4,17 @@
 // Per mate file one PRODUCER thread turns the file into pieces of text in device buffers, in order:
 //   * a .gz is decoded in slabs of a few hundred speculative chunks (mf_gzdev.h).  Its compressed bytes pass through a RING per
 //     device (a power of two of bytes; byte b of the file lives at ring[b % R]) that an uploader thread fills a piece at a time and
-//     that is recycled as slabs are linked; the decode kernels of up to twelve slabs run ahead on their own streams while slab
-//     k is linked and slab k - 1 is resolved and CRC-checked; symbol room per chunk follows the expansion the file has shown so
-//     far; every slab's text goes to a buffer of its own (the 32 KiB window and the carry in front of it);
-//   * a plain FASTQ file IS the text: it is read straight into such buffers.
+//     that is recycled as slabs are linked; the decode kernels of the slabs ahead run on the device's decode streams, each followed
+//     by the copy of its chunks' descriptors to the host; which chunks are accepted is decided on the host from those (gz_link_walk);
+//     the windows, marker resolution and CRC are kernels on the mate's post stream, and the piece is handed over WITH AN EVENT --
+//     the producer waits for a slab's descriptors and for a text buffer, never for a kernel of its own;
+//     symbol room per chunk follows the expansion the file has shown so far, slabs in flight the call's memory budget;
+//     every slab's text goes to a buffer of its own (the 32 KiB window and the carry in front of it);
+//   * a plain FASTQ file IS the text: it is read straight into such buffers (three staging buffers, the device's copy stream).
 //   With n devices the slabs are dealt to them round robin: the link step of slab k needs the state the link step of slab k - 1
-//   left (bit position, text length, the last 32 KiB: 33 KB through the host), nothing else crosses devices.
+//   left (a few scalars on the host, the last 32 KiB of text through pinned memory), nothing else crosses devices.
+// The streams all of this runs on are made once per process and device by a maker thread, in the order a cold call needs them
+// (StreamSets below): the reference calls this path a process at a time.
 // A few CONSUMER threads take the pieces.  Per piece, on the device that holds it: cut the text into records where it lies
 // (mf_ingest.h; one piece of a mate at a time, in order: what is behind the last complete record of a piece, the carry, goes to the
 // front of the next piece's buffer), then -- several pieces side by side, each consumer on its own streams -- the piece's job:
@@ -299,6 +304,65 @@ private:
     uint8_t *dst_ = nullptr; size_t off_ = 0, len_ = 0; int nt_ = 1, left_ = 0; std::atomic<bool> ok_{true};
 };
 
+// ---- The file's bytes go to the device FROM WHERE THE PAGE CACHE HOLDS THEM (round 5): the read-only mapping of the file is registered with
+// the runtime a window at a time (hipHostRegister, read-only: 4 ms per 2.4 GB, profiles/r05/e_masks_ab.txt), and the copy engine reads the pages
+// themselves -- 57.7 GB/s, the link's own rate, with no host thread touching a byte; pread into pinned staging and a copy from there, which
+// this replaces, was 100 ms for the same 2.4 GB and eight busy threads.  A window is unregistered when the copies that read it have run (an
+// event per device behind the last of them); at most four windows (2 GiB of page cache) are pinned at a time.  Where a mapping cannot be
+// registered (a file system whose pages cannot be pinned) ensure() says no, once, and the caller stages through pinned buffers as before.
+class PinnedMap {
+public:
+    static constexpr size_t WIN = (size_t)512 << 20; static constexpr size_t MAX_WINDOWS = 4;
+    PinnedMap(const uint8_t *p, size_t n) : p_(p), n_(n), w_((n + WIN - 1) / WIN) { static const bool off = getenv("MF_UPLOAD_STAGED") != nullptr; usable_ = !off && p && n; }
+    ~PinnedMap()
+    {
+        for (size_t w = 0; w < w_.size(); w++) retire(w);
+        for (auto &W : w_) for (auto &e : W.ev) { (void)hipSetDevice(e.first); (void)hipEventDestroy(e.second); }
+    }
+    // bytes [off, off + len) can be given to hipMemcpyAsync as they lie in the mapping
+    bool ensure(size_t off, size_t len)
+    {
+        if (!usable_ || !len) return usable_;
+        for (size_t w = off / WIN; w <= (off + len - 1) / WIN; w++) {
+            if (w_[w].reg) continue;
+            while (live_.size() >= MAX_WINDOWS) { retire(live_.front()); }
+            const size_t a = w * WIN, b = std::min(n_, a + WIN), len_w = (b - a + 4095) & ~(size_t)4095;          // (the mapping runs to the end of the file's last page)
+            if (hipHostRegister(const_cast<uint8_t *>(p_) + a, len_w, hipHostRegisterPortable | hipHostRegisterReadOnly) != hipSuccess) {
+                (void)hipGetLastError();
+                usable_ = false;
+                return false;
+            }
+            w_[w].reg = true; live_.push_back(w);
+        }
+        return true;
+    }
+    // a copy that reads [off, off + len) has been issued on stream st of device dev: the windows it touches stay until it has run
+    bool after_copy(size_t off, size_t len, int dev, hipStream_t st)
+    {
+        for (size_t w = off / WIN; len && w <= (off + len - 1) / WIN; w++) {
+            hipEvent_t ev = nullptr;
+            for (auto &e : w_[w].ev) if (e.first == dev) ev = e.second;
+            if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false; w_[w].ev.emplace_back(dev, ev); }
+            if (hipEventRecord(ev, st) != hipSuccess) return false;
+        }
+        return true;
+    }
+    bool usable() const { return usable_; }
+private:
+    void retire(size_t w)
+    {
+        if (!w_[w].reg) return;
+        int cur = -1; (void)hipGetDevice(&cur);
+        for (auto &e : w_[w].ev) { (void)hipSetDevice(e.first); (void)hipEventSynchronize(e.second); }
+        (void)hipHostUnregister(const_cast<uint8_t *>(p_) + w * WIN);
+        if (cur >= 0) (void)hipSetDevice(cur);
+        w_[w].reg = false;
+        for (size_t i = 0; i < live_.size(); i++) if (live_[i] == w) { live_.erase(live_.begin() + (long)i); break; }
+    }
+    struct Window { bool reg = false; std::vector<std::pair<int, hipEvent_t>> ev; };
+    const uint8_t *p_; size_t n_; std::vector<Window> w_; std::deque<size_t> live_; bool usable_ = false;
+};
+
 // ---- the streams of this path, per device.  What a stream costs to make (profiles/r05/a_stream_probe.log): a CU-masked one is a
 // hardware queue of its own, 16 ms, always; a plain one 16-30 ms while the process has fewer than four queues, 2-3 ms afterwards
 // (it then shares one); the runtime makes them one after the other whoever asks, without holding up launches on the streams that
@@ -387,10 +451,16 @@ struct DeviceStreams {
 class StreamSets {
 public:
     // the streams of physical device `device` (the maker is started on first use and runs on by itself)
-    DeviceStreams *get(int device, std::string &err)
+    // Two sets per device: one of plain streams -- what every call on a file of less than a gigabyte uses -- and one whose decode streams are
+    // CU-masked, for large inputs.  A CU-masked stream is a hardware queue of its own: 16 ms to make, and the process's EXIT waits for the
+    // kernel driver to tear each of them down -- 0.2-0.25 s of a process that lived for 0.4 (profiles/r05/d_exit_probe.log: a quality-filter
+    // call on a 2 M-pair .gz pair, caller saw 0.61 / 0.69 s with masks, 0.39 / 0.41 s without).  A process per call is the reference's
+    // boundary, so the masks are worth their price only where the chip is full of decode wavefronts for long.
+    DeviceStreams *get(int device, bool want_masks, std::string &err)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        auto it = dev_.find(device);
+        const int key = device * 2 + (want_masks ? 1 : 0);
+        auto it = dev_.find(key);
         if (it != dev_.end()) return it->second;
         std::unique_ptr<DeviceStreams> d(new DeviceStreams());
         d->device = device;
@@ -407,17 +477,17 @@ public:
         for (size_t i = 0; i < d->mask.size(); i++) d->mask_rest[i] = ~d->mask[i];
         if (n_cu % 32) d->mask_rest.back() &= (1u << (n_cu % 32)) - 1;
         d->words = (uint32_t)words; d->n_cu = n_cu;
-        d->masked = n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
+        d->masked = want_masks && n_cu >= 64 && !getenv("MF_GZDEV_NO_CUMASK");
         DeviceStreams *dp = d.release();
         dp->maker = std::thread([dp] { dp->run(); });
-        dev_[device] = dp;
+        dev_[key] = dp;
         return dp;
     }
     // Under rocprofv3 a process that still owns CU-masked streams when it exits dies in the profiler's finaliser (SIGSEGV below
     // __cxa_finalize, after the profile has been written; without a profiler the exit is clean).  So when a profiler is loaded
     // the streams are destroyed here, at exit, after a device synchronisation -- not otherwise: destroying such a stream was seen to
     // hang now and then, and an exit that hangs is worse than one a profiler complains about.
-    // two staging buffers of the uploader's usual size, pinned on a thread of their own (7 ms each), once per process
+    // the code objects of the decoder and of the line kernels, loaded on a thread of their own, once per process
     void prefill_pinned(int device)
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -425,8 +495,7 @@ public:
         prefill_started_ = true;
         prefill_ = std::thread([device] {
             if (hipSetDevice(device) != hipSuccess) return;
-            g_pinned.prefill(2, ((size_t)32 << 20) + 256); cold_mark("prefetch: staging buffers pinned");
-            gz_preload(); ingest_preload(); cold_mark("prefetch: code objects of the decoder and the line kernels loaded");
+            gz_preload(); ingest_preload(); cold_mark("prefetch: code objects of the decoder and the line kernels loaded");          // (no staging buffers: the uploads read the page cache's pages)
         });
     }
     ~StreamSets()
@@ -437,7 +506,7 @@ public:
         const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
         if (!profiled) return;
         for (auto &kv : dev_) {
-            if (hipSetDevice(kv.first) != hipSuccess) continue;
+            if (hipSetDevice(kv.second->device) != hipSuccess) continue;
             (void)hipDeviceSynchronize();
             DeviceStreams &D = *kv.second;
             for (auto &q : D.dec) if (q) (void)hipStreamDestroy(q);
@@ -450,6 +519,7 @@ private:
     std::mutex mu_; std::map<int, DeviceStreams *> dev_; std::thread prefill_; bool prefill_started_ = false;
 };
 StreamSets g_streams;
+std::atomic<bool> g_short_lived{false};          // the process makes one file-level call and ends (a CLI): mf_set_option("short_lived", "1")
 
 // ---- how many text buffers a mate may hold at a time (the producer waits for one to come back)
 struct Slots {
@@ -507,9 +577,9 @@ public:
         }
     }
     // piece_lanes[i]: bit l set = lane l wants piece i
-    void start(int fd, size_t n, size_t ring_bytes, size_t piece, std::vector<Lane> lanes, std::vector<uint64_t> piece_lanes)
+    void start(const uint8_t *map, int fd, size_t n, size_t ring_bytes, size_t piece, std::vector<Lane> lanes, std::vector<uint64_t> piece_lanes)
     {
-        fd_ = fd; n_ = n; ring_ = ring_bytes; piece_ = piece; lanes_ = std::move(lanes); want_ = std::move(piece_lanes);
+        map_ = map; fd_ = fd; n_ = n; ring_ = ring_bytes; piece_ = piece; lanes_ = std::move(lanes); want_ = std::move(piece_lanes);
         ev_.assign(lanes_.size(), std::vector<hipEvent_t>(want_.size(), nullptr));
         free_ev_.assign(lanes_.size(), std::array<hipEvent_t, 2>{nullptr, nullptr});
         stage_used_[0] = stage_used_[1] = 0;
@@ -542,7 +612,8 @@ private:
     void run()
     {
         if (!lanes_.empty() && hipSetDevice(lanes_[0].dev) != hipSuccess) { fail_(MF_E_HIP); return; }
-        { const hipError_t e = stage_.init(piece_, fd_); if (e != hipSuccess) { fail_(e == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP); return; } }
+        PinnedMap reg(map_, n_);          // the copy engine reads the page cache's own pages; staging buffers only where those cannot be registered
+        bool staged = false;
         const size_t np = want_.size();
         for (size_t i = 0; i < np && !stop_; i++) {
             const size_t off = i * piece_, len = std::min(piece_, n_ - off);
@@ -555,15 +626,21 @@ private:
             }
             const double t_b = now_s();
             const int b = (int)(i & 1);
-            for (size_t l = 0; l < lanes_.size(); l++)          // the copies that read this staging buffer are done
-                if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(MF_E_HIP); return; } }
-            stage_used_[b] = 0;
-            const double t_c = now_s();
-            if (!stage_.read(b, off, len)) { fail_(MF_E_IO); return; }
+            const bool direct = reg.ensure(off, len);
+            const uint8_t *src = map_ + off;
+            double t_c = now_s();
+            if (!direct) {
+                if (!staged) { const hipError_t e = stage_.init(piece_, fd_); if (e != hipSuccess) { fail_(e == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP); return; } staged = true; }
+                for (size_t l = 0; l < lanes_.size(); l++)          // the copies that read this staging buffer are done
+                    if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(MF_E_HIP); return; } }
+                stage_used_[b] = 0;
+                t_c = now_s();
+                if (!stage_.read(b, off, len)) { fail_(MF_E_IO); return; }
+                src = stage_.buf[(size_t)b];
+            }
             t_ring_ += t_b - t_a; t_copy_wait_ += t_c - t_b; t_read_ += now_s() - t_c;
-            if (i == 0) cold_mark("uploader: first piece of the file read into pinned memory");
-            size_t total = len;
-            if (off + len == n_) { memset(stage_.buf[b] + len, 0, 256); total += 256; }          // readable and zero behind the last byte
+            if (i == 0) cold_mark(direct ? "uploader: the file's first window registered" : "uploader: first piece of the file read into pinned memory");
+            const size_t total = len;
             for (size_t l = 0; l < lanes_.size(); l++) {
                 if (!((want_[i] >> l) & 1)) continue;
                 Lane &L = lanes_[l];
@@ -571,25 +648,30 @@ private:
                 if (!L.st && !(L.st = L.ds->copy_stream())) { fail_(MF_E_HIP); return; }
                 if (!ev_[l][i] && hipEventCreateWithFlags(&ev_[l][i], hipEventDisableTiming) != hipSuccess) { fail_(MF_E_HIP); return; }
                 if (!free_ev_[l][b] && hipEventCreateWithFlags(&free_ev_[l][b], hipEventDisableTiming) != hipSuccess) { fail_(MF_E_HIP); return; }
-                // (a piece never straddles the end of the ring -- the ring is a multiple of the piece --, the zeros behind the file may)
+                // (a piece never straddles the end of the ring -- the ring is a multiple of the piece)
                 const size_t r0 = ring_mask_off(off), first = std::min(total, ring_ - r0);
-                if (hipMemcpyAsync(L.ring + r0, stage_.buf[b], first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
-                if (first < total && hipMemcpyAsync(L.ring, stage_.buf[b] + first, total - first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
-                if (hipEventRecord(ev_[l][i], L.st) != hipSuccess || hipEventRecord(free_ev_[l][b], L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
-                stage_used_[b] |= (uint64_t)1 << l;
+                if (hipMemcpyAsync(L.ring + r0, src, first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (first < total && hipMemcpyAsync(L.ring, src + first, total - first, hipMemcpyHostToDevice, L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (off + len == n_) {          // readable and zero behind the last byte (256 bytes: they may straddle the end of the ring)
+                    const size_t z0 = ring_mask_off(off + len), zf = std::min<size_t>(256, ring_ - z0);
+                    if (hipMemsetAsync(L.ring + z0, 0, zf, L.st) != hipSuccess || (zf < 256 && hipMemsetAsync(L.ring, 0, 256 - zf, L.st) != hipSuccess)) { fail_(MF_E_HIP); return; }
+                }
+                if (hipEventRecord(ev_[l][i], L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
+                if (direct) { if (!reg.after_copy(off, len, L.dev, L.st)) { fail_(MF_E_HIP); return; } }
+                else { if (hipEventRecord(free_ev_[l][b], L.st) != hipSuccess) { fail_(MF_E_HIP); return; } stage_used_[b] |= (uint64_t)1 << l; }
             }
             { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; }
             cv_.notify_all();
             if (i == 0) cold_mark("uploader: first copy to the device issued");
         }
-        for (auto &L : lanes_) { if (L.st && hipSetDevice(L.dev) == hipSuccess) (void)hipStreamSynchronize(L.st); }
+        for (auto &L : lanes_) { if (L.st && hipSetDevice(L.dev) == hipSuccess) (void)hipStreamSynchronize(L.st); }          // (before the windows are unregistered)
     }
     size_t ring_mask_off(size_t off) const { return off & (ring_ - 1); }
     void fail_(int rc) { { std::lock_guard<std::mutex> lk(mu_); failed_ = true; fail_rc_ = rc; } cv_.notify_all(); }
 public:
     double t_ring_ = 0, t_copy_wait_ = 0, t_read_ = 0;          // the uploader thread's time: waiting for room in the ring, for the copy out of a staging buffer, reading the file
 private:
-    size_t n_ = 0, ring_ = 0, piece_ = 0; int fd_ = -1;
+    const uint8_t *map_ = nullptr; size_t n_ = 0, ring_ = 0, piece_ = 0; int fd_ = -1;
     std::vector<Lane> lanes_; std::vector<uint64_t> want_;
     Stager stage_; uint64_t stage_used_[2] = {0, 0};
     std::vector<std::vector<hipEvent_t>> ev_; std::vector<std::array<hipEvent_t, 2>> free_ev_;
@@ -708,7 +790,7 @@ public:
             L.ldev = devices[l]; L.dev = phys(devices[l]);
             DCHK(hipSetDevice(L.dev));
             const double tl0 = now_s();
-            L.ds = g_streams.get(L.dev, err);          // (starts the maker thread if this is the device's first use; nothing here waits for a stream)
+            L.ds = g_streams.get(L.dev, large, err);          // (starts the maker thread if this is the set's first use; nothing here waits for a stream)
             if (!L.ds) return MF_E_HIP;
             L.want_masked_post = large;
             if (n_chunks_ > 4 * cps_) L.ds->ask(DeviceStreams::N_WHAT);          // a file of many slabs: every decode stream, now -- they are made while the first slabs decode
@@ -730,7 +812,7 @@ public:
         }
         const double tu0 = now_s();
         up_.reset(new GzUploader());
-        up_->start(fd, size_, ring_, piece_, ul, want);
+        up_->start(data_, fd, size_, ring_, piece_, ul, want);
         t_open_upload_ = now_s() - tu0; t_open_ = now_s() - ts0;
         in_member_ = true;
         TRACE("gz open: %u chunks of %zu B, %zu slabs (<= %u chunks), ring %zu MiB, pieces of %zu KiB, %u slabs in flight, %u lanes", n_chunks_, chunk_, plan_.size(), cps_,
@@ -1371,20 +1453,22 @@ struct Ingest {
         M.cv.notify_all(); cv_all.notify_all();
     }
 
-    // a plain file is its own text: slabs of it are read straight into text buffers, dealt to the devices round robin.  Nothing but the
-    // link to the device should bound this: the file's bytes go through three pinned staging buffers (the stager's own threads read
-    // the next while the copies of the two before are in flight) onto the device's copy stream, and a slab is handed over the moment
-    // its last copy has been ISSUED -- the consumer's stream waits for the copy (TextBuf::ready), the producer does not.
+    // a plain file is its own text: slabs of it go straight into text buffers, dealt to the devices round robin.  Nothing but the link to the
+    // device bounds this: the copy engine reads the file's pages where the page cache holds them (PinnedMap: the mapping registered a
+    // window at a time), onto the device's copy stream, and a slab is handed over the moment its copies have been ISSUED -- the consumer's
+    // stream waits for them (TextBuf::ready), the producer does not.  (Where the mapping cannot be registered: three pinned staging buffers,
+    // the stager's own threads reading the next while the copies of the two before are in flight.)
     int plain_producer(Mate &M, std::string &err)
     {
         const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)256 << 20), 64);
         const size_t piece = (size_t)std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>(slab, 4096));
         constexpr int NBUF = 3;
-        Stager stg;
         DCHK(hipSetDevice(phys(devices[0])));
-        DCHK(stg.init(piece, M.map.fd, NBUF));
+        PinnedMap reg(M.map.p, M.map.n);
+        Stager stg; bool staged = false;
         struct PerDev { DeviceStreams *ds = nullptr; hipStream_t st = nullptr; hipEvent_t ev[NBUF] = {}; };
         std::vector<PerDev> pd(devices.size());
+        // (declared behind `reg`: runs first -- the copies have run when the windows are unregistered)
         struct Cleanup { std::vector<PerDev> &pd; const std::vector<int> &devs; ~Cleanup() { for (size_t i = 0; i < pd.size(); i++) { (void)hipSetDevice(phys(devs[i])); if (pd[i].st) (void)hipStreamSynchronize(pd[i].st); for (auto &e : pd[i].ev) if (e) (void)hipEventDestroy(e); } } } cleanup{pd, devices};
         uint64_t n_piece = 0; int used_by[NBUF]; for (auto &u : used_by) u = -1;
         uint64_t s = 0;
@@ -1395,21 +1479,27 @@ struct Ingest {
             DCHK(hipSetDevice(dev));
             PerDev &P = pd[li];
             if (!P.st) {
-                P.ds = g_streams.get(dev, err); if (!P.ds) return MF_E_HIP;
+                P.ds = g_streams.get(dev, false, err); if (!P.ds) return MF_E_HIP;
                 P.st = P.ds->copy_stream(); if (!P.st) { err = "hipStreamCreate failed"; return MF_E_HIP; }
                 for (auto &e : P.ev) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
             if (!M.slots.take()) break;
             TextPiece t;
             DCHK(TextBuf::make(t.buf, dev, ldev, TEXT_FRONT + carry_room, (size_t)(T1 - T0), &M.slots));
-            for (uint64_t off = T0; off < T1; off += piece, n_piece++) {
-                const int b = (int)(n_piece % NBUF);
-                if (used_by[b] >= 0) { const size_t lj = (size_t)used_by[b]; DCHK(hipSetDevice(phys(devices[lj]))); DCHK(hipEventSynchronize(pd[lj].ev[b])); DCHK(hipSetDevice(dev)); }
-                const size_t len = (size_t)std::min<uint64_t>(piece, T1 - off);
-                if (!stg.read(b, (size_t)off, len)) { err = "read error on " + M.path; return MF_E_IO; }
-                DCHK(hipMemcpyAsync(t.buf->p + (off - T0), stg.buf[(size_t)b], len, hipMemcpyHostToDevice, P.st));
-                DCHK(hipEventRecord(P.ev[b], P.st));
-                used_by[b] = (int)li;
+            if (reg.ensure((size_t)T0, (size_t)(T1 - T0))) {
+                DCHK(hipMemcpyAsync(t.buf->p, M.map.p + T0, (size_t)(T1 - T0), hipMemcpyHostToDevice, P.st));
+                if (!reg.after_copy((size_t)T0, (size_t)(T1 - T0), dev, P.st)) { err = "hipEventRecord failed"; return MF_E_HIP; }
+            } else {
+                if (!staged) { DCHK(stg.init(piece, M.map.fd, NBUF)); staged = true; }
+                for (uint64_t off = T0; off < T1; off += piece, n_piece++) {
+                    const int b = (int)(n_piece % NBUF);
+                    if (used_by[b] >= 0) { const size_t lj = (size_t)used_by[b]; DCHK(hipSetDevice(phys(devices[lj]))); DCHK(hipEventSynchronize(pd[lj].ev[b])); DCHK(hipSetDevice(dev)); }
+                    const size_t len = (size_t)std::min<uint64_t>(piece, T1 - off);
+                    if (!stg.read(b, (size_t)off, len)) { err = "read error on " + M.path; return MF_E_IO; }
+                    DCHK(hipMemcpyAsync(t.buf->p + (off - T0), stg.buf[(size_t)b], len, hipMemcpyHostToDevice, P.st));
+                    DCHK(hipEventRecord(P.ev[b], P.st));
+                    used_by[b] = (int)li;
+                }
             }
             DCHK(hipEventRecord(t.buf->ready_event(), P.st));
             t.T0 = T0; t.len = T1 - T0; t.last = T1 == M.map.n;
@@ -2214,11 +2304,16 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     // filter's pieces wait longer: their text is written out)
     const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", I.qual ? 8 : 6)) + (int)I.devices.size() - 1;
     int rc = MF_OK;
-    // an input that keeps the chip full of decode wavefronts for a long time gets the CU-masked link streams (they are made late: a small
-    // file must not wait for them)
+    // an input that keeps the chip full of decode wavefronts for a long time gets the CU-masked set of streams (16 ms apiece to make and a
+    // quarter of a second of the process's exit: a small file must not pay for them)
     uint64_t gz_bytes = 0;
     for (int i = 0; i < I.nm; i++) if (I.m[i].gz) gz_bytes += I.m[i].map.n;
-    const bool large = gz_bytes >= ((uint64_t)1 << 30) && !getenv("MF_GZDEV_PLAIN_POST");
+    // Which set of streams: the CU-masked set is faster the moment decode kernels fill the chip for more than a few slabs -- a paired 2 x 1.2 GB input
+    // 0.149 s against 0.263 s on plain streams, configs[4] 0.225 against 0.368 (calls of a warm process, profiles/r05/e_masks_ab.txt) -- and costs a
+    // quarter of a second of the process's exit.  A library user's process lives on: masked from 256 MB of compressed input.  A process that
+    // makes one call and ends (the CLIs say so: mf_set_option("short_lived", "1")) pays the exit with every call: masked only where the
+    // difference is larger than that, from 8 GB.  MF_GZDEV_LARGE_MB overrides either.
+    const bool large = gz_bytes >= (env_u64("MF_GZDEV_LARGE_MB", g_short_lived.load() ? 8192 : 256) << 20);
     // Device memory follows the input: 6 bytes per compressed byte of the call, at least 3 GB, at most 20 (MF_INGEST_BUDGET_GB sets it); of
     // that, 45 % go to the decoders' symbol buffers and code lists (shared by the mates), the rest is rings, text buffers, the
     // consumers' read sets and line indexes, which follow the slab size the decoders settle on.
@@ -2323,13 +2418,15 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
     return MF_OK;
 }
 
+void ingest_short_lived(bool yes) { g_short_lived = yes; }
+
 void ingest_prefetch(int device)
 {
     const int dev = phys(device);
     int cur = -1; (void)hipGetDevice(&cur);
     if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
     std::string err;
-    (void)g_streams.get(dev, err);
+    (void)g_streams.get(dev, false, err);
     g_streams.prefill_pinned(dev);
     if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
 }

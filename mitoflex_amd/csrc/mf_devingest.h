@@ -39,5 +39,8 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
 // streams, two pinned staging buffers.  Returns at once; calling it again is free.  (mf_set_option("expect_files", "1") makes the library
 // call it when a device's first context is made.)
 void ingest_prefetch(int device);
+// The process makes one file-level call and ends (the CLIs): what costs the process's exit more than it saves the call is left out -- the
+// CU-masked stream set below 8 GB of compressed input.  (mf_set_option("short_lived", "1"))
+void ingest_short_lived(bool yes);
 
 } // namespace mf

@@ -924,11 +924,15 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const uint8_t *data, uint
 //     loads are issued ahead), every output position of the round finding its entry by binary search in LDS, as before.
 // The tables stay in LDS (the lanes index them on their own); ring, precode and code-length arrays share their bytes with the
 // round's list and staging buffer.
+// SPAN sets the LDS a wavefront holds (a step's staged rows) and with it how many wavefronts fit a CU: 1024 bits = 16.4 KB = 9 wavefronts,
+// 768 = 15.2 KB = 10, 512 = 12.4 KB with 128-entry rounds = 12 (registers bind then).  Same box, the chip full, bytes equal to zlib's each
+// (profiles/r05/e_gzdev_occupancy_variants.txt): 1024: 80.0 GB/s of text (a 1.3 GB gzip -6 file of 2 384 chunks, which 9 x 256 slots do not hold
+// in one go: 54.2), 768: 89.2 (78.6), 512: 82.4 (73.1), 512 with 128-entry rounds: 83.2 (71.8).
 #ifndef GZ_SPAN
-#define GZ_SPAN 1024
+#define GZ_SPAN 768
 #endif
 constexpr uint32_t SPAN = GZ_SPAN;       // bits of the block per lane and step
-constexpr uint32_t LCAP = 512;           // list entries a lane may leave per step (more codes than that in 1024 bits: the lane stops early, the next step goes on from there)
+constexpr uint32_t LCAP = 512;           // list entries a lane may leave per step (more codes than that in a span: the lane stops early, the next step goes on from there)
 #ifndef GZ_RN
 #define GZ_RN 256
 #endif

@@ -17,7 +17,7 @@ enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, 
 struct StubStream; typedef StubStream *hipStream_t;
 struct StubEvent; typedef StubEvent *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostRegisterPortable = 1 };
+enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostRegisterPortable = 1, hipHostRegisterReadOnly = 8 };
 struct hipDeviceProp_t { int multiProcessorCount; char gcnArchName[256]; char name[256]; };
 
 const char *hipGetErrorString(hipError_t e);
@@ -36,6 +36,8 @@ hipError_t hipFree(void *p);                           // like the runtime's: wa
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags);
 template <class T> inline hipError_t hipHostMalloc(T **p, size_t bytes, unsigned flags) { return hipHostMalloc(reinterpret_cast<void **>(p), bytes, flags); }
 hipError_t hipHostFree(void *p);
+hipError_t hipHostRegister(void *p, size_t bytes, unsigned flags);          // (STUB_NO_REGISTER=1: fails, as on a file system whose pages cannot be pinned)
+hipError_t hipHostUnregister(void *p);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int priority);

@@ -86,6 +86,9 @@ hipError_t hipFree(void *p)
 }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { void *q = nullptr; if (posix_memalign(&q, 4096, bytes ? bytes : 1) != 0) return hipErrorOutOfMemory; *p = q; return hipSuccess; }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static std::atomic<long> g_registered{0};
+hipError_t hipHostRegister(void *, size_t, unsigned) { if (getenv("STUB_NO_REGISTER")) return hipErrorInvalidValue; g_registered++; return hipSuccess; }
+hipError_t hipHostUnregister(void *) { drain_all(); g_registered--; return hipSuccess; }          // (like the runtime's: nothing may still read the range)
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new StubStream(); { std::lock_guard<std::mutex> lk(g_mu); g_streams.insert(*s); } g_streams_made++; return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) { return hipStreamCreateWithFlags(s, 0); }
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(autouse=True)
 def device_ingest(monkeypatch):
-    """plain files take the host pipeline by default (only .gz input goes to the device path): here everything is to go the device way"""
+    """(regular files take the device path by default; forced here all the same, so that a test that means this path cannot end up on the other)"""
     monkeypatch.setenv("MF_INGEST", "device")
 
 
@@ -370,11 +370,14 @@ def test_slabs_dealt_to_several_devices(ol, bait_text, tmp_path, n_dev):
         assert open(g2, "rb").read() == open(o2, "rb").read()
 
 
-@pytest.mark.parametrize("knobs", [dict(MF_GZDEV_RESERVED_CUS="8", MF_UPLOAD_THREADS="1"), dict(MF_GZDEV_RESERVED_CUS="64", MF_UPLOAD_THREADS="16"),
-                                   dict(MF_GZDEV_NO_CUMASK="1")], ids=["reserve8-upload1", "reserve64-upload16", "no-cu-masks"])
+@pytest.mark.parametrize("knobs", [dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_RESERVED_CUS="8", MF_UPLOAD_THREADS="1", MF_UPLOAD_STAGED="1"), dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_RESERVED_CUS="64", MF_UPLOAD_THREADS="16"),
+                                   dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_NO_CUMASK="1"), dict(MF_GZDEV_LARGE_MB="0"), dict(MF_UPLOAD_STAGED="1")],
+                         ids=["masked-reserve8-upload1", "masked-reserve64-upload16", "masked-set-without-masks", "masked-set", "uploads-through-staging-buffers"])
 def test_stream_and_upload_knobs(knobs):
     """The CU masks of the decoder's streams and the uploader's thread count are read when a process makes its first stream set, so the
-    variants run in child processes: gzip levels x seams, several members, flush points -- same bytes as the oracle whatever the knobs say."""
+    variants run in child processes: gzip levels x seams, several members, flush points -- same bytes as the oracle whatever the knobs say.
+    (Round 5: files below a gigabyte use the plain stream set by default -- the rest of this file runs on it --; MF_GZDEV_LARGE_MB=0 sends
+    every input through the CU-masked set, the one large inputs get.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -471,3 +474,69 @@ def test_a_failed_allocation_hands_the_call_to_the_host_pipeline(ol, bait_text, 
     assert int(p.stdout.decode().split()[0]) == ok and ot == 6000
     assert open(g1, "rb").read() == open(o1, "rb").read()
     assert open(g2, "rb").read() == open(o2, "rb").read()
+
+
+# ---- round 5: the device memory of the path follows the input; what a process keeps between calls can be given back; big plain files take the path
+
+def test_device_memory_follows_the_input(mf, ol, bait_text, tmp_path, monkeypatch):
+    """A .gz pair of a few hundred megabytes must not hold what a 5 GB file does (round 4: 28 GB for a 0.6 GB pair): at most max(3 GB, 6 x the
+    compressed bytes) of device memory in use, same kept / total as the oracle."""
+    import subprocess
+    import sys
+    monkeypatch.delenv("MF_INGEST", raising=False)
+    pre = str(tmp_path / "q")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_fastq.py"), pre, "--pairs", "1200000"], stdout=subprocess.DEVNULL)
+    for m in "12":
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pgzip.py"), f"{pre}_{m}.fq", f"{pre}_{m}.fq.gz", "--level", "6"], stdout=subprocess.DEVNULL)
+    gz = os.path.getsize(pre + "_1.fq.gz") + os.path.getsize(pre + "_2.fq.gz")
+    ks = mf.KmerSet.from_fasta(pre + ".bait.fa", 31)
+    mf.release_cached()
+    k, t = mf.filter_fastq_files(ks, pre + "_1.fq.gz", pre + "_2.fq.gz", str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq"))
+    st = mf.last_ingest_stats()
+    assert st["path"] == 1 and t == 1200000
+    assert st["device_bytes_peak"] <= max(3 << 30, 6 * gz), (st["device_bytes_peak"] / 1e9, gz / 1e9)
+    ok, ot = ol.filter_fastq_files(pre + ".bait.fa", 31, 1, 0, pre + "_1.fq", pre + "_2.fq", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), threads=8)
+    assert (k, t) == (ok, ot)
+    assert open(tmp_path / "o1.fq", "rb").read() == open(tmp_path / "r1.fq", "rb").read()
+    # what the process keeps for its next call goes back to the runtime on request (ABI 4), and the next call works all the same
+    released = mf.release_cached()
+    assert released > 0
+    assert mf.release_cached() == 0
+    assert mf.filter_fastq_files(ks, pre + "_1.fq.gz", pre + "_2.fq.gz", str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")) == (k, t)
+
+
+def test_plain_files_take_the_device_path_by_default(mf, ol, bait_text, tmp_path, monkeypatch):
+    """Plain regular files take the device path at every size (measured ahead of the host pipeline from 0.16 GB to 10.7 GB, profiles/r05);
+    MF_INGEST_PLAIN_MIN_MB keeps files below that many megabytes on the host pipeline.  Either way the oracle's bytes."""
+    monkeypatch.delenv("MF_INGEST", raising=False)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    fq = str(tmp_path / "p.fq")
+    open(fq, "wb").write(fastq_text(make_reads(bait_text, 30000, seed=91), "p"))
+    run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    assert mf.last_ingest_stats()["path"] == 1
+    monkeypatch.setenv("MF_INGEST_PLAIN_MIN_MB", "100000")
+    run_both(mf, ol, bait, ks, fq, None, tmp_path)
+    assert mf.last_ingest_stats()["path"] == 0
+
+
+def test_the_clis_run_cold(mf, ol, bait_text, tmp_path, monkeypatch):
+    """The path as the reference calls it: a process per call (utility/helper.py:78-86).  `fastfilter bait` on a .gz, twice, as fresh processes:
+    the oracle's count and bytes, and the cold-start timeline (MF_COLD_TRACE) shows the set-up the CLI asks for (expect_files)."""
+    import subprocess
+    monkeypatch.delenv("MF_INGEST", raising=False)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    s = make_reads(bait_text, 40000, seed=92)
+    fq = str(tmp_path / "c.fq.gz")
+    open(fq, "wb").write(gz_bytes(fastq_text(s, "c"), 6))
+    ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq, None, str(tmp_path / "r.fq"), None, threads=2)
+    exe = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
+    for _ in range(2):
+        p = subprocess.run([exe, "bait", "--bait", bait, "--fq1", fq, "--out1", str(tmp_path / "o.fq")], capture_output=True, env=dict(os.environ, MF_COLD_TRACE="1"), timeout=120)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert int(p.stdout.decode()) == ok
+        assert open(tmp_path / "o.fq", "rb").read() == open(tmp_path / "r.fq", "rb").read()
+        err = p.stderr.decode()
+        assert "prefetch: code objects of the decoder and the line kernels loaded" in err and "device ingest: first piece of text handed over" in err

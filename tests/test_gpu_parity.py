@@ -110,9 +110,15 @@ def test_synth_uniform_matches_oracle(mf, ol, bait_text):
 
 @pytest.mark.parametrize("batch", [None, 700, 1])
 @pytest.mark.parametrize("gz", [False, True])
-def test_fastq_files_match_oracle(mf, ol, bait_text, tmp_path, gz, batch, monkeypatch):
-    """File level, through the chunked pipeline; small batch sizes force many batches, carried
-    partial records and out-of-step mate files."""
+@pytest.mark.parametrize("ingest", ["host", "default"])
+def test_fastq_files_match_oracle(mf, ol, bait_text, tmp_path, gz, batch, ingest, monkeypatch):
+    """File level, through the chunked host pipeline (MF_INGEST=host: regular files take the device ingest path by default since round 5,
+    tests/test_gpu_devingest.py) and through whatever the library picks; small batch sizes force many batches, carried partial
+    records and out-of-step mate files."""
+    if ingest == "host":
+        monkeypatch.setenv("MF_INGEST", "host")
+    elif batch is not None:
+        pytest.skip("the batch knobs are the host pipeline's")
     if batch is not None:
         if gz and batch == 1:
             pytest.skip("one-read batches are exercised on the plain files")
@@ -363,7 +369,7 @@ def test_many_logical_devices_match_oracle(ol, bait_text, tmp_path, n_dev):
     ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
     g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
     cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
-    env = dict(os.environ, MF_FAKE_DEVICES=str(n_dev), MF_BATCH_READS="300")
+    env = dict(os.environ, MF_FAKE_DEVICES=str(n_dev), MF_BATCH_READS="300", MF_INGEST="host")          # (the host pipeline over N devices; the device path over N devices: test_gpu_devingest.py)
     p = subprocess.run([cli, "bait", "--bait", bait, "-k", "31", "--fq1", fq1, "--fq2", fq2, "--out1", g1, "--out2", g2,
                         "--devices", str(n_dev)], capture_output=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[:2000]

@@ -45,10 +45,10 @@ def exes(tmp_path_factory):
     return {name: _build(tmp, name, flags) for name, flags in VARIANTS.items()}
 
 
-def _run(exe, case, tmp_path, records, timeout):
-    env = dict(os.environ, INGEST_CHECK_RECORDS=str(records), INGEST_CHECK_TIMEOUT=str(timeout), TSAN_OPTIONS="report_thread_leaks=0 halt_on_error=0")
+def _run(exe, case, tmp_path, records, timeout, **extra):
+    env = dict(os.environ, INGEST_CHECK_RECORDS=str(records), INGEST_CHECK_TIMEOUT=str(timeout), TSAN_OPTIONS="report_thread_leaks=0 halt_on_error=0", **extra)
     for k in list(env):
-        if k.startswith("MF_"):
+        if k.startswith("MF_") and k not in extra:
             del env[k]
     return subprocess.run([exe, case, str(tmp_path)], env=env, capture_output=True, text=True, timeout=timeout + 60)
 
@@ -62,6 +62,15 @@ def test_ingest_orchestration(exes, tmp_path, case):
 @pytest.mark.parametrize("case", CASES)
 def test_ingest_orchestration_under_tsan(exes, tmp_path, case):
     r = _run(exes["tsan"], case, tmp_path, 1500, 240)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[:6000]
+    assert r.returncode == 0 and "all checks of" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("case", ["bait_se_gz", "bait_plain", "bait_two_devices", "qual_pe"])
+def test_uploads_through_staging_buffers(exes, tmp_path, case):
+    """The uploads read the file's pages where the page cache holds them (the mapping registered with the runtime); where that cannot be done
+    (the stand-in runtime refuses under STUB_NO_REGISTER) they go through pinned staging buffers as before -- same bytes, under TSan."""
+    r = _run(exes["tsan"], case, tmp_path, 1500, 240, STUB_NO_REGISTER="1")
     assert "ThreadSanitizer" not in r.stderr, r.stderr[:6000]
     assert r.returncode == 0 and "all checks of" in r.stderr, r.stderr[-3000:]
 

@@ -85,3 +85,25 @@ def test_bench_line_shapes_round4():
     q = x["filter_v2"]
     assert q["cli_outputs_equal"] and q["library_outputs_equal"] and q["library_call"]["device"]["ingest_path"] == "device"
     assert {"device", "host"} <= set(q["cli_process_start_to_exit"])
+
+
+def test_bench_line_shapes_round5():
+    """Round 5's additions to the default line as committed under profiles/r05/: the cold calls through the CLI (a process per call is the
+    reference's boundary), first-call times, plain files through the device path against their PCIe roof, the same-size control beside the
+    real compressors' files, a roofline object in every leg of the k sweep."""
+    import json
+    f = os.path.join(ROOT, "profiles", "r05", "bench_shape_default.json")
+    if not os.path.exists(f):
+        pytest.skip("profiles/r05/bench_shape_default.json not committed yet")
+    x = json.load(open(f))["extra"]
+    e = x["e2e_files"]
+    c4 = e["configs4_se_gz"]
+    assert c4["cli_cold"]["kept_equals_library"] and c4["cli_cold"]["seconds"] > 0 and c4["first_call_seconds"] >= c4["seconds"] > 0
+    assert e["se_gz_first_call_seconds"] > 0 and e["se_gz_cli_cold"]["seconds"] > 0
+    for leg in ("configs4_se_plain", "configs1_pe_plain"):
+        p = e[leg]
+        assert p["outputs_equal"] and p["device_path"]["ingest_path"] == "device" and p["roofline"]["bound"] == "pcie_h2d" and 0 < p["roofline"]["frac"] < 1.05, leg
+    assert any("pgzip" in k for k in e["real_compressors"]["files"]) and "gzip-6" in e["real_compressors"]["files"]
+    for k, leg in x["k_sweep"].items():
+        r = leg["roofline"]
+        assert r["bound"] == ("valu" if int(k) < 28 else "hbm") and r["peak"] > 0 and "frac" in r, k
