@@ -434,10 +434,10 @@ struct DeviceStreams {
     // a post stream for one mate of one call (given back with give_post); want_masked: a large input
     hipStream_t take_post(bool want_masked, int *slot)
     {
-        if (!wait_for(POST1)) return nullptr;
         int k = -1;
         { std::lock_guard<std::mutex> lk(mu); for (int i = 0; i < (int)GZ_NPOST; i++) if (!post_busy[i]) { post_busy[i] = true; k = i; break; } }
         *slot = k;
+        if (!wait_for(k == 1 ? POST1 : POST0)) return nullptr;          // (a single-end call does not wait for the second post stream)
         if (k < 0) { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; }      // (more than two mates at a time on one device: concurrent calls)
         if (want_masked && masked) { ask(POSTM1 + 1); if (wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k]; }
         return post[k];
@@ -711,15 +711,20 @@ public:
     // data: the mapped file (what the host looks at: headers, trailers, gaps); devices: the logical devices that decode it
     // nslab: slabs whose decode kernels may be in flight per device (enough wavefronts to fill the chip: twelve for one file, seven each for two mates)
     // large: an input that keeps the chip full of decode wavefronts for a long time (its link streams are the CU-masked ones)
-    // budget: device bytes this mate's decoder may hold in symbol buffers and code lists (what is in flight follows from it; 0: no bound)
+    // budget: device bytes this mate may hold in all -- ring, symbol buffers, code lists and its text_bufs text buffers; what is in flight follows
+    // from it (0: no bound)
     int open(const uint8_t *data, size_t size, int fd, const std::vector<int> &devices, const std::string &path, Slots *slots, size_t carry_room,
-             uint32_t nslab, bool large, uint64_t budget, std::atomic<bool> *stop, std::string &err)
+             uint32_t nslab, bool large, uint64_t budget, uint32_t text_bufs, bool small_chunks, std::atomic<bool> *stop, std::string &err)
     {
         uint32_t NSLAB = std::max<uint32_t>(1, (uint32_t)env_u64("MF_GZDEV_SLABS_IN_FLIGHT", nslab));
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
-        // chunks: large enough that a slab's fixed costs stay small, small enough that a file keeps the chip busy
-        size_t dflt = size / 8192; dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)256 << 10) & ~(size_t)4095;
+        // chunks: large enough that a slab's fixed costs stay small, small enough that a file keeps the chip busy.  Measured over 0.1 / 0.3 / 1 / 3 GB of
+        // .gz a mate x {64, 96, 128, 192, 256} KiB (profiles/r05/f_chunk_size_probe.txt, tools/chunk_size_probe.sh): 64 KiB is the fastest up to
+        // 0.3 GB, 96 KiB at 1 GB (SE 0.087 s against 0.101 with 64 KiB and 0.123 with 256; PE 0.163 against 0.207), 192 KiB at 3 GB -- the file's
+        // size / 10 923, between 64 and 192 KiB; the quality filter is fastest with 64 KiB at every size (0.44 s against 0.70-0.81 at 1 GB).
+        size_t dflt = small_chunks ? (size_t)64 << 10 : size / 10923;
+        dflt = std::min<size_t>(std::max<size_t>(dflt, (size_t)64 << 10), (size_t)192 << 10) & ~(size_t)4095;
         chunk_ = (size_t)env_u64("MF_GZDEV_CHUNK_BYTES", dflt);
         if (chunk_ < 1024) chunk_ = 1024;
         cps_ = (uint32_t)env_u64("MF_GZDEV_SLAB_CHUNKS", std::max<uint64_t>(256, ((uint64_t)128 << 20) / chunk_));
@@ -727,22 +732,23 @@ public:
         // slabs in flight are counted in slabs of 512 chunks (the 256 KiB chunks of a large file): what fills the chip is chunks, and a file
         // of a gigabyte, with its smaller chunks and more of them to a slab, would hold twice the symbol room for nothing
         if (!getenv("MF_GZDEV_SLABS_IN_FLIGHT") && cps_ > 512) NSLAB = std::max<uint32_t>(2, (uint32_t)(((uint64_t)NSLAB * 512 + cps_ - 1) / cps_));
-        // The device memory of the path follows the INPUT: what a chunk in flight holds is ~11 bytes of symbol room per compressed byte (16-bit
-        // symbols, 4.5 : 1, a quarter of slack) and 256 KiB of code lists, and a file of a few hundred megabytes must not hold the 20 GB that
-        // twelve slabs of a 5 GB file do (round 4: 28 GB for a 0.6 GB pair).  So the chunks in flight are what the budget pays for -- in slabs
-        // small enough that four or more of them are in flight, so that upload, decode, link and the consumers still overlap.
+        // symbols of room per compressed byte: a first guess (FASTQ compresses three- to fivefold: 4.5, and 64 Ki symbols for the block behind the
+        // range), then what the file has shown plus a quarter; a slab that overflows is decoded again with four times the room
+        expand_ = getenv("MF_GZDEV_EXPAND") ? (double)env_u64("MF_GZDEV_EXPAND", 4) : 4.5;
+        expand_fixed_ = getenv("MF_GZDEV_EXPAND") != nullptr;
+        // The device memory of the path follows the INPUT.  What a chunk in flight holds: its symbol room (16-bit symbols, 4.5 : 1 and 64 Ki of
+        // slack at first, then what the file has shown), 256 KiB of code lists, its bytes in the ring (twice: the ring is a power of two), and its share of
+        // the text buffers (a slab's text each, 4.5 bytes per compressed byte, text_bufs of them over the slabs in flight).  The chunks in flight
+        // are what the budget pays for -- in slabs small enough that four of them are in flight, so that upload, decode, link and the
+        // consumers still overlap.  (Round 4 held 28 GB for a 0.6 GB pair: twelve slabs of a 5 GB file's size whatever the file.)
         if (budget && !getenv("MF_GZDEV_SLABS_IN_FLIGHT") && !getenv("MF_GZDEV_SLAB_CHUNKS")) {
-            const uint64_t per_chunk = (uint64_t)chunk_ * 11 + ((uint64_t)384 << 10);
+            const uint64_t per_chunk = (uint64_t)sym_cap_first() * 2 + ((uint64_t)256 << 10) + (uint64_t)chunk_ * 2 + (uint64_t)chunk_ * 45 / 10 * std::max<uint32_t>(text_bufs, 1) / 4;
             const uint64_t fit = std::max<uint64_t>(64, budget / per_chunk);                     // chunks in flight the budget allows
             if ((uint64_t)NSLAB * cps_ > fit) {
                 cps_ = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(cps_, fit / 4));
                 NSLAB = (uint32_t)std::max<uint64_t>(2, fit / cps_);
             }
         }
-        // symbols of room per compressed byte: a first guess (FASTQ compresses three- to fivefold; the rule adds a chunk's worth, so
-        // 3.5 covers 4.5 : 1), then what the file has shown plus a quarter; a slab that overflows is decoded again with four times the room
-        expand_ = getenv("MF_GZDEV_EXPAND") ? (double)env_u64("MF_GZDEV_EXPAND", 4) : 3.5;
-        expand_fixed_ = getenv("MF_GZDEV_EXPAND") != nullptr;
         text_piece_max_ = env_u64("MF_GZDEV_TEXT_PIECE", (uint64_t)1 << 30);
         size_t pos = 0;
         if (!member_header(pos, err)) return MF_E_FORMAT;
@@ -756,7 +762,7 @@ public:
         size_t ring = pow2_ceil(std::max<size_t>(size_ + 512, 4096));
         {
             uint64_t want = env_u64("MF_GZDEV_RING_BYTES", 0);
-            if (!want) want = (uint64_t)NSLAB * nl * slab_bytes + margin_ + ((size_t)96 << 20);
+            if (!want) want = (uint64_t)NSLAB * nl * slab_bytes + margin_ + 3 * std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>(slab_bytes, (uint64_t)4 << 20));      // (the slabs in flight, the read-ahead, three pieces of the uploader)
             want = pow2_ceil(std::max<uint64_t>(want, 4096));
             if (want < ring) ring = (size_t)want;
         }
@@ -1025,9 +1031,12 @@ private:
             retired_.pop_front();
         }
     }
+    // symbols of room per chunk before the file has shown its expansion: 4.5 : 1 and 64 Ki of slack for the block a chunk decodes past its range (the
+    // first slabs are short: one that overflows -- text that expands more -- is decoded again with four times the room, cheaply, and the rule below takes over)
+    size_t sym_cap_first() const { return (size_t)((double)chunk_ * expand_) + (expand_fixed_ ? 262144 : 65536); }
     size_t sym_cap_now() const
     {
-        if (expand_fixed_ || !max_sym_seen_) return (size_t)((double)chunk_ * expand_) + 262144;
+        if (expand_fixed_ || !max_sym_seen_) return sym_cap_first();
         // what the largest chunk so far needed, and a quarter; a chunk reads one block past its range (and up to a chunk's worth of
         // stored blocks), which the maximum has seen as well
         return (size_t)max_sym_seen_ + max_sym_seen_ / 4 + 65536;
@@ -2302,7 +2311,11 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     g_pool.reset_peak();
     // text buffers a mate may hold: the consumers each hold one, the decoder one, the rest wait for the other mate or for a consumer (the quality
     // filter's pieces wait longer: their text is written out)
-    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", I.qual ? 8 : 6)) + (int)I.devices.size() - 1;
+    // (a call that plans for less than 8 GB keeps two fewer in flight: a text buffer is a slab's text, 4.5 times its compressed bytes)
+    uint64_t in_bytes = 0;
+    for (int i = 0; i < I.nm; i++) in_bytes += I.m[i].map.n;
+    const bool small_call = 6 * in_bytes < ((uint64_t)8 << 30) && !getenv("MF_INGEST_BUDGET_GB");
+    const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", (I.qual ? 8 : 6) - (small_call ? 2 : 0))) + (int)I.devices.size() - 1;
     int rc = MF_OK;
     // an input that keeps the chip full of decode wavefronts for a long time gets the CU-masked set of streams (16 ms apiece to make and a
     // quarter of a second of the process's exit: a small file must not pay for them)
@@ -2314,12 +2327,12 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     // makes one call and ends (the CLIs say so: mf_set_option("short_lived", "1")) pays the exit with every call: masked only where the
     // difference is larger than that, from 8 GB.  MF_GZDEV_LARGE_MB overrides either.
     const bool large = gz_bytes >= (env_u64("MF_GZDEV_LARGE_MB", g_short_lived.load() ? 8192 : 256) << 20);
-    // Device memory follows the input: 6 bytes per compressed byte of the call, at least 3 GB, at most 20 (MF_INGEST_BUDGET_GB sets it); of
-    // that, 45 % go to the decoders' symbol buffers and code lists (shared by the mates), the rest is rings, text buffers, the
-    // consumers' read sets and line indexes, which follow the slab size the decoders settle on.
+    // Device memory follows the input: 6 bytes per compressed byte of the call, at least 3 GB, at most 20 (MF_INGEST_BUDGET_GB sets it).  1.5 GB
+    // of it are not this path's to plan (the runtime's own, the bait tables, the consumers' read sets and line indexes); the rest is shared
+    // by the mates, each of which sizes its ring, its slabs in flight and its text buffers from its share (GzStream::open).
     const uint64_t budget = getenv("MF_INGEST_BUDGET_GB") ? env_u64("MF_INGEST_BUDGET_GB", 20) << 30
                                                          : std::min<uint64_t>((uint64_t)20 << 30, std::max<uint64_t>((uint64_t)3 << 30, 6 * gz_bytes));
-    const uint64_t gz_budget = budget * 45 / 100 / (uint64_t)I.nm;
+    const uint64_t gz_budget = (budget > ((uint64_t)5 << 29) ? budget - ((uint64_t)3 << 29) : budget / 3) / (uint64_t)I.nm;
     {   // (the two mates' decoders side by side)
         int rcs[2] = {MF_OK, MF_OK}; std::string errs[2]; std::thread th[2];
         for (int i = 0; i < I.nm; i++) {
@@ -2327,7 +2340,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
             M.slots.free_ = text_bufs; M.slots.stop = &M.stop;
             if (!M.gz) continue;
             M.gzs.reset(new GzStream());
-            auto open = [&I, &M, &rcs, &errs, i, large, gz_budget] { rcs[i] = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, large, gz_budget, &M.stop, errs[i]); };
+            auto open = [&I, &M, &rcs, &errs, i, large, gz_budget, text_bufs] { rcs[i] = M.gzs->open(M.map.p, M.map.n, M.map.fd, I.devices, M.path, &M.slots, I.carry_room, I.nm == 2 ? 7 : 12, large, gz_budget, (uint32_t)text_bufs, I.qual != nullptr, &M.stop, errs[i]); };
             if (i == 0 && I.nm == 2 && I.m[1].gz == false) open(); else if (i == 0 && I.nm == 2) th[0] = std::thread(open); else open();
         }
         for (auto &t : th) if (t.joinable()) t.join();

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; T=/tmp/e2ef; mkdir -p $T
 READS=${1:-33333334}; LEVELS=${2:-"1 6"}
 t0=$(date +%s)
 python tools/make_fastq.py $T/s --pairs $READS --mates 1 --block 2000000 > /dev/null
-for l in $LEVELS; do ( gzip -$l -c $T/s_1.fq > $T/s.l$l.fq.gz ) & done; wait
+for l in $LEVELS; do ( gzip -$l -c $T/s_1.fq > $T/s.l$l.fq.gz ) & done; python tools/pgzip.py $T/s_1.fq $T/s.pgzip6.fq.gz --level 6; wait          # (GNU gzip: minutes, single-threaded; the same text through tools/pgzip.py as the control)
 echo "generated and compressed in $(( $(date +%s) - t0 )) s"; ls -l $T | awk '{print $5, $9}'
 python - <<PY
 import time, os, sys, hashlib
@@ -32,6 +32,9 @@ for l in levels:
     assert r == ref
     os.environ["MF_INGEST"] = "host"
     run(f"SE gz -{l}, host pipeline", T+f"/s.l{l}.fq.gz", T+f"/o_hostgz{l}.fq", reps=1)
+os.environ.pop("MF_INGEST", None)
+r = run("SE pgzip -6 (control), device ingest", T+"/s.pgzip6.fq.gz", T+"/o_devp.fq")
+assert r == ref
 print("cpu cores", os.cpu_count(), "cpu.max", open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "?")
 PY
 rm -rf $T

@@ -17,7 +17,7 @@ print("   caller saw %.3f s | last mark +%s (%s) | HIP answered +%s | rc %d" % (
 PY
 }
 for rep in 1 2; do
-for setting in "" "MF_GZDEV_NO_CUMASK=1" "GPU_MAX_HW_QUEUES=2" "GPU_MAX_HW_QUEUES=2 MF_GZDEV_NO_CUMASK=1" "GPU_MAX_HW_QUEUES=1"; do
+for setting in "" "GPU_MAX_HW_QUEUES=8" "GPU_MAX_HW_QUEUES=12" "MF_GZDEV_LARGE_MB=0"; do
   echo "== [$setting] filter_v2 -d 2 M pairs"; rm -f $T/o_1.fq $T/o_2.fq
   env $setting bash -c "$(declare -f run); run $F -1 $T/p_1.fq.gz -2 $T/p_2.fq.gz -3 $T/o_1.fq -4 $T/o_2.fq -d"
   echo "== [$setting] fastfilter bait 500 k reads"; rm -f $T/o.fq

@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the driver's bench command (pipelined passes) and of the serial form of the pass, plus the
 # FETCH_SIZE / WRITE_SIZE counters of the screen kernel: the numbers `roofline` in the bench line has to agree with
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-Q="--cpu-sample 0 --no-exhaustive --e2e-pairs 0 --e2e-full-reads 0 --no-group-a --no-live-traffic"
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r05}; mkdir -p $OUT; rm -f $OUT/bench_traffic.txt; cd /tmp; export TMPDIR=/tmp
+Q="--cpu-sample 0 --no-exhaustive --e2e-pairs 0 --e2e-full-reads 0 --no-group-a --no-live-traffic --real-gz-reads 0 --fv2-pairs 0 --plain-pairs 0 --k-sweep none"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 $Q > $OUT/bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv; rm -rf $OUT/trace
 MF_ENV_KNOBS=1 MF_PASS=serial timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 $Q > /dev/null 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the decode kernel alone with the chip full: tools/gzdev_check on a 1.85 GB gzip member
 # (12 M reads, 3.85 GB of text, 7 069 chunks of 256 KiB in ONE launch), byte for byte against zlib
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O; T=/tmp/gzp; mkdir -p $T
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r05}; mkdir -p $O; T=/tmp/gzp; mkdir -p $T
 python $R/tools/make_fastq.py $T/s --pairs 12000000 --mates 1 --block 2000000 > /dev/null
 python $R/tools/pgzip.py $T/s_1.fq $T/s6.gz --level 6; rm $T/s_1.fq
 cd /tmp; export TMPDIR=/tmp
