@@ -423,11 +423,14 @@ struct DeviceStreams {
     }
     void fail_() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
     bool wait_for(What w) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || made > (int)w; }); return made > (int)w; }
-    hipStream_t pick_dec(uint32_t seq)
+    // limit: decode streams this call may use.  A CU-masked stream is a hardware queue with its own save area on the device -- 12 of them hold
+    // 2 GB (configs[4]: 15.8 GB in use against 12.7 GB of buffers; on plain streams the difference is 0.9 GB) --, so an input below a gigabyte,
+    // whose memory is to follow its size, gets three.
+    hipStream_t pick_dec(uint32_t seq, uint32_t limit = GZ_NSTREAM)
     {
         if (!wait_for(DEC0)) return nullptr;
-        const uint32_t n = n_dec.load();
-        if (seq >= n && n < GZ_NSTREAM) ask(n < 4 ? DEC1 + (int)n : N_WHAT);          // (one more for the next launch; the last six come together)
+        const uint32_t n = std::min<uint32_t>(n_dec.load(), std::max<uint32_t>(1, limit));
+        if (seq >= n && n < std::min<uint32_t>(GZ_NSTREAM, limit)) ask(n < 4 ? DEC1 + (int)n : N_WHAT);          // (one more for the next launch; the last six come together)
         return dec[seq % std::max<uint32_t>(1, n)];
     }
     hipStream_t copy_stream() { return wait_for(COPY) ? copy : nullptr; }
@@ -719,6 +722,8 @@ public:
         uint32_t NSLAB = std::max<uint32_t>(1, (uint32_t)env_u64("MF_GZDEV_SLABS_IN_FLIGHT", nslab));
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
+        const bool big = budget == 0 || budget >= ((uint64_t)2 << 30);          // (a mate's share of a call that plans for several gigabytes)
+        dec_limit_ = big ? GZ_NSTREAM : 3;
         // chunks: large enough that a slab's fixed costs stay small, small enough that a file keeps the chip busy.  Measured over 0.1 / 0.3 / 1 / 3 GB of
         // .gz a mate x {64, 96, 128, 192, 256} KiB (profiles/r05/f_chunk_size_probe.txt, tools/chunk_size_probe.sh): 64 KiB is the fastest up to
         // 0.3 GB, 96 KiB at 1 GB (SE 0.087 s against 0.101 with 64 KiB and 0.123 with 256; PE 0.163 against 0.207), 192 KiB at 3 GB -- the file's
@@ -798,7 +803,7 @@ public:
             const double tl0 = now_s();
             L.ds = g_streams.get(L.dev, large, err);          // (starts the maker thread if this is the set's first use; nothing here waits for a stream)
             if (!L.ds) return MF_E_HIP;
-            L.want_masked_post = large;
+            L.want_masked_post = large && big;
             if (n_chunks_ > 4 * cps_) L.ds->ask(DeviceStreams::N_WHAT);          // a file of many slabs: every decode stream, now -- they are made while the first slabs decode
             t_open_streams_ += now_s() - tl0;
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
@@ -1071,7 +1076,7 @@ private:
             if (i > 0 && !up_->issued(upto)) break;
             // (decode kernels on one stream run one after the other, each waiting for the last straggler of the one before: while the
             // device's decode streams are still being made -- a process's first large file -- no more than two slabs are queued per stream)
-            if (i >= 2 * (size_t)std::max<uint32_t>(1, L.ds->n_dec.load())) break;
+            if (i >= 2 * (size_t)std::max<uint32_t>(1, std::min(L.ds->n_dec.load(), dec_limit_))) break;
             DCHK(hipSetDevice(L.dev));
             if (!S.cap) S.cap = sym_cap_now();
             DCHK(S.sym.need(L.dev, (size_t)(S.hi - S.lo) * S.cap, false));
@@ -1079,7 +1084,7 @@ private:
             if (!S.ev) DCHK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
             if (!S.ev0) DCHK(hipEventCreate(&S.ev0));
             if (!S.ev1) DCHK(hipEventCreate(&S.ev1));
-            hipStream_t st = L.ds->pick_dec(launch_seq_++);
+            hipStream_t st = L.ds->pick_dec(launch_seq_++, dec_limit_);
             if (!st) { err = "hipStreamCreate failed"; return MF_E_HIP; }
             if (!up_->wait_for(S.lane, st, upto)) {
                 const int why = up_->failure();
@@ -1223,7 +1228,7 @@ private:
     const uint8_t *data_ = nullptr; size_t size_ = 0; std::string path_; Slots *slots_ = nullptr; size_t pad_ = TEXT_FRONT; std::atomic<bool> *stop_ = nullptr;
     size_t chunk_ = 0, base_byte_ = 0, margin_ = 0, ring_ = 0, piece_ = 0; double expand_ = 6; bool expand_fixed_ = false; uint32_t max_sym_seen_ = 0;
     uint64_t text_piece_max_ = 0;
-    uint32_t cps_ = 0, n_chunks_ = 0, max_inflight_ = 1, launch_seq_ = 0, n_splits_ = 0;
+    uint32_t cps_ = 0, n_chunks_ = 0, max_inflight_ = 1, launch_seq_ = 0, n_splits_ = 0, dec_limit_ = GZ_NSTREAM;
     std::vector<Lane> lanes_; std::vector<SlabPlan> plan_; size_t next_plan_ = 0;
     std::deque<std::unique_ptr<Slab>> slabs_;          // launched or waiting, in stream order; front = being linked
     std::deque<Retired> retired_;                      // linked, their symbols on their way to becoming text
