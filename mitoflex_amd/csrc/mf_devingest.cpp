@@ -304,63 +304,70 @@ private:
     uint8_t *dst_ = nullptr; size_t off_ = 0, len_ = 0; int nt_ = 1, left_ = 0; std::atomic<bool> ok_{true};
 };
 
-// ---- The file's bytes go to the device FROM WHERE THE PAGE CACHE HOLDS THEM (round 5): the read-only mapping of the file is registered with
-// the runtime a window at a time (hipHostRegister, read-only: 4 ms per 2.4 GB, profiles/r05/e_masks_ab.txt), and the copy engine reads the pages
-// themselves -- 57.7 GB/s, the link's own rate, with no host thread touching a byte; pread into pinned staging and a copy from there, which
-// this replaces, was 100 ms for the same 2.4 GB and eight busy threads.  A window is unregistered when the copies that read it have run (an
-// event per device behind the last of them); at most four windows (2 GiB of page cache) are pinned at a time.  Where a mapping cannot be
-// registered (a file system whose pages cannot be pinned) ensure() says no, once, and the caller stages through pinned buffers as before.
+// ---- A file of up to 512 MiB goes to the device FROM WHERE THE PAGE CACHE HOLDS IT (round 5): its read-only mapping is registered with the
+// runtime (hipHostRegister, read-only) and the copy engine reads the pages themselves -- no staging buffers to pin (0.2 ms per MiB, which a
+// cold call of a small file pays in full), no host thread touching a byte.  The page tables are filled first (madvise POPULATE_READ, a
+// thread per 64 MiB: the pages are in the page cache, nothing is read) -- registering pages the process has not touched faults them in one
+// by one, 2-8 GB/s.  Larger files go through pinned staging buffers: what registering costs there is host work per page -- page tables
+// 0.7, hipHostRegister 0.4, hipHostUnregister 1.3 and munmap of the filled mapping 0.7 ms per 100 MiB -- and even with all of it on
+// threads of its own, ahead of and behind the copies, configs[4] took 0.30 s against 0.236 s staged, its plain text 0.284 s (0.07 s of it the
+// munmap) against 0.22-0.30 s (profiles/r05/g_upload_registered_vs_staged.txt).  Where a mapping cannot be registered at all (a file
+// system whose pages cannot be pinned) ensure() says no and the caller stages as well.
 class PinnedMap {
 public:
-    static constexpr size_t WIN = (size_t)512 << 20; static constexpr size_t MAX_WINDOWS = 4;
-    PinnedMap(const uint8_t *p, size_t n) : p_(p), n_(n), w_((n + WIN - 1) / WIN) { static const bool off = getenv("MF_UPLOAD_STAGED") != nullptr; usable_ = !off && p && n; }
+    PinnedMap(const uint8_t *p, size_t n) : p_(p), n_(n)
+    {
+        static const bool off = getenv("MF_UPLOAD_STAGED") != nullptr;
+        usable_ = !off && p && n && n <= (size_t)env_u64("MF_UPLOAD_REGISTER_MAX_MB", 512) << 20;
+    }
     ~PinnedMap()
     {
-        for (size_t w = 0; w < w_.size(); w++) retire(w);
-        for (auto &W : w_) for (auto &e : W.ev) { (void)hipSetDevice(e.first); (void)hipEventDestroy(e.second); }
-    }
-    // bytes [off, off + len) can be given to hipMemcpyAsync as they lie in the mapping
-    bool ensure(size_t off, size_t len)
-    {
-        if (!usable_ || !len) return usable_;
-        for (size_t w = off / WIN; w <= (off + len - 1) / WIN; w++) {
-            if (w_[w].reg) continue;
-            while (live_.size() >= MAX_WINDOWS) { retire(live_.front()); }
-            const size_t a = w * WIN, b = std::min(n_, a + WIN), len_w = (b - a + 4095) & ~(size_t)4095;          // (the mapping runs to the end of the file's last page)
-            if (hipHostRegister(const_cast<uint8_t *>(p_) + a, len_w, hipHostRegisterPortable | hipHostRegisterReadOnly) != hipSuccess) {
-                (void)hipGetLastError();
-                usable_ = false;
-                return false;
-            }
-            w_[w].reg = true; live_.push_back(w);
+        if (registered_) {
+            int cur = -1; (void)hipGetDevice(&cur);
+            for (auto &e : ev_) { (void)hipSetDevice(e.first); (void)hipEventSynchronize(e.second); }          // (the copies that read the mapping have run)
+            (void)hipHostUnregister(const_cast<uint8_t *>(p_));
+            if (cur >= 0) (void)hipSetDevice(cur);
         }
-        return true;
+        for (auto &e : ev_) { (void)hipSetDevice(e.first); (void)hipEventDestroy(e.second); }
     }
-    // a copy that reads [off, off + len) has been issued on stream st of device dev: the windows it touches stay until it has run
-    bool after_copy(size_t off, size_t len, int dev, hipStream_t st)
+    // the file's bytes can be given to hipMemcpyAsync as they lie in the mapping
+    bool ensure()
     {
-        for (size_t w = off / WIN; len && w <= (off + len - 1) / WIN; w++) {
-            hipEvent_t ev = nullptr;
-            for (auto &e : w_[w].ev) if (e.first == dev) ev = e.second;
-            if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false; w_[w].ev.emplace_back(dev, ev); }
-            if (hipEventRecord(ev, st) != hipSuccess) return false;
+        if (!usable_ || registered_) return usable_;
+        constexpr size_t PART = (size_t)64 << 20;
+        if (n_ > PART / 2) {
+            std::vector<std::thread> th;
+            for (size_t q = PART; q < n_; q += PART) th.emplace_back([this, q] { fill(q, std::min(n_, q + PART)); });
+            fill(0, std::min(n_, PART));
+            for (auto &x : th) x.join();
         }
-        return true;
+        const size_t len = (n_ + 4095) & ~(size_t)4095;          // (the mapping runs to the end of the file's last page)
+        if (hipHostRegister(const_cast<uint8_t *>(p_), len, hipHostRegisterPortable | hipHostRegisterReadOnly) != hipSuccess) { (void)hipGetLastError(); usable_ = false; }
+        else registered_ = true;
+        return usable_;
     }
-    bool usable() const { return usable_; }
+    // a copy that reads the mapping has been issued on stream st of device dev: the registration stays until it has run
+    bool after_copy(int dev, hipStream_t st)
+    {
+        hipEvent_t ev = nullptr;
+        for (auto &e : ev_) if (e.first == dev) ev = e.second;
+        if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false; ev_.emplace_back(dev, ev); }
+        return hipEventRecord(ev, st) == hipSuccess;
+    }
 private:
-    void retire(size_t w)
+    void fill(size_t a, size_t b) const
     {
-        if (!w_[w].reg) return;
-        int cur = -1; (void)hipGetDevice(&cur);
-        for (auto &e : w_[w].ev) { (void)hipSetDevice(e.first); (void)hipEventSynchronize(e.second); }
-        (void)hipHostUnregister(const_cast<uint8_t *>(p_) + w * WIN);
-        if (cur >= 0) (void)hipSetDevice(cur);
-        w_[w].reg = false;
-        for (size_t i = 0; i < live_.size(); i++) if (live_[i] == w) { live_.erase(live_.begin() + (long)i); break; }
+#ifndef MADV_POPULATE_READ
+        constexpr int MADV_POPULATE_READ = 22;          // Linux 5.14
+#endif
+        static std::atomic<bool> have{true};
+        if (have.load(std::memory_order_relaxed) && madvise(const_cast<uint8_t *>(p_) + a, b - a, MADV_POPULATE_READ) == 0) return;
+        have.store(false, std::memory_order_relaxed);
+        unsigned acc = 0;
+        for (size_t q = a; q < b; q += 4096) acc += *(const volatile uint8_t *)(p_ + q);
+        (void)acc;
     }
-    struct Window { bool reg = false; std::vector<std::pair<int, hipEvent_t>> ev; };
-    const uint8_t *p_; size_t n_; std::vector<Window> w_; std::deque<size_t> live_; bool usable_ = false;
+    const uint8_t *p_; size_t n_; bool usable_ = false, registered_ = false; std::vector<std::pair<int, hipEvent_t>> ev_;
 };
 
 // ---- the streams of this path, per device.  What a stream costs to make (profiles/r05/a_stream_probe.log): a CU-masked one is a
@@ -615,7 +622,7 @@ private:
     void run()
     {
         if (!lanes_.empty() && hipSetDevice(lanes_[0].dev) != hipSuccess) { fail_(MF_E_HIP); return; }
-        PinnedMap reg(map_, n_);          // the copy engine reads the page cache's own pages; staging buffers only where those cannot be registered
+        PinnedMap reg(map_, n_);          // a file of up to 512 MiB: the copy engine reads the page cache's own pages; otherwise staging buffers
         bool staged = false;
         const size_t np = want_.size();
         for (size_t i = 0; i < np && !stop_; i++) {
@@ -629,7 +636,7 @@ private:
             }
             const double t_b = now_s();
             const int b = (int)(i & 1);
-            const bool direct = reg.ensure(off, len);
+            const bool direct = reg.ensure();
             const uint8_t *src = map_ + off;
             double t_c = now_s();
             if (!direct) {
@@ -642,7 +649,7 @@ private:
                 src = stage_.buf[(size_t)b];
             }
             t_ring_ += t_b - t_a; t_copy_wait_ += t_c - t_b; t_read_ += now_s() - t_c;
-            if (i == 0) cold_mark(direct ? "uploader: the file's first window registered" : "uploader: first piece of the file read into pinned memory");
+            if (i == 0) cold_mark(direct ? "uploader: the file's mapping registered" : "uploader: first piece of the file read into pinned memory");
             const size_t total = len;
             for (size_t l = 0; l < lanes_.size(); l++) {
                 if (!((want_[i] >> l) & 1)) continue;
@@ -660,7 +667,7 @@ private:
                     if (hipMemsetAsync(L.ring + z0, 0, zf, L.st) != hipSuccess || (zf < 256 && hipMemsetAsync(L.ring, 0, 256 - zf, L.st) != hipSuccess)) { fail_(MF_E_HIP); return; }
                 }
                 if (hipEventRecord(ev_[l][i], L.st) != hipSuccess) { fail_(MF_E_HIP); return; }
-                if (direct) { if (!reg.after_copy(off, len, L.dev, L.st)) { fail_(MF_E_HIP); return; } }
+                if (direct) { if (!reg.after_copy(L.dev, L.st)) { fail_(MF_E_HIP); return; } }
                 else { if (hipEventRecord(free_ev_[l][b], L.st) != hipSuccess) { fail_(MF_E_HIP); return; } stage_used_[b] |= (uint64_t)1 << l; }
             }
             { std::lock_guard<std::mutex> lk(mu_); enqueued_ = i + 1; }
@@ -1467,11 +1474,10 @@ struct Ingest {
         M.cv.notify_all(); cv_all.notify_all();
     }
 
-    // a plain file is its own text: slabs of it go straight into text buffers, dealt to the devices round robin.  Nothing but the link to the
-    // device bounds this: the copy engine reads the file's pages where the page cache holds them (PinnedMap: the mapping registered a
-    // window at a time), onto the device's copy stream, and a slab is handed over the moment its copies have been ISSUED -- the consumer's
-    // stream waits for them (TextBuf::ready), the producer does not.  (Where the mapping cannot be registered: three pinned staging buffers,
-    // the stager's own threads reading the next while the copies of the two before are in flight.)
+    // a plain file is its own text: slabs of it go straight into text buffers, dealt to the devices round robin.  A file of up to 512 MiB is
+    // read by the copy engine where the page cache holds it (PinnedMap); a larger one goes through three pinned staging buffers, the stager's
+    // own threads reading the next while the copies of the two before are in flight.  Either way a slab is handed over the moment its copies
+    // have been ISSUED -- the consumer's stream waits for them (TextBuf::ready), the producer does not.
     int plain_producer(Mate &M, std::string &err)
     {
         const uint64_t slab = std::max<uint64_t>(env_u64("MF_INGEST_SLAB_BYTES", (uint64_t)256 << 20), 64);
@@ -1485,7 +1491,7 @@ struct Ingest {
         // (declared behind `reg`: runs first -- the copies have run when the windows are unregistered)
         struct Cleanup { std::vector<PerDev> &pd; const std::vector<int> &devs; ~Cleanup() { for (size_t i = 0; i < pd.size(); i++) { (void)hipSetDevice(phys(devs[i])); if (pd[i].st) (void)hipStreamSynchronize(pd[i].st); for (auto &e : pd[i].ev) if (e) (void)hipEventDestroy(e); } } } cleanup{pd, devices};
         uint64_t n_piece = 0; int used_by[NBUF]; for (auto &u : used_by) u = -1;
-        uint64_t s = 0;
+        uint64_t s = 0; double t_slot = 0; const double t_begin = now_s();
         for (uint64_t T0 = 0; T0 < M.map.n && !M.stop; s++) {
             const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
             const size_t li = (size_t)(s % devices.size());
@@ -1497,12 +1503,14 @@ struct Ingest {
                 P.st = P.ds->copy_stream(); if (!P.st) { err = "hipStreamCreate failed"; return MF_E_HIP; }
                 for (auto &e : P.ev) DCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
+            const double ts = now_s();
             if (!M.slots.take()) break;
+            t_slot += now_s() - ts;
             TextPiece t;
             DCHK(TextBuf::make(t.buf, dev, ldev, TEXT_FRONT + carry_room, (size_t)(T1 - T0), &M.slots));
-            if (reg.ensure((size_t)T0, (size_t)(T1 - T0))) {
+            if (reg.ensure()) {
                 DCHK(hipMemcpyAsync(t.buf->p, M.map.p + T0, (size_t)(T1 - T0), hipMemcpyHostToDevice, P.st));
-                if (!reg.after_copy((size_t)T0, (size_t)(T1 - T0), dev, P.st)) { err = "hipEventRecord failed"; return MF_E_HIP; }
+                if (!reg.after_copy(dev, P.st)) { err = "hipEventRecord failed"; return MF_E_HIP; }
             } else {
                 if (!staged) { DCHK(stg.init(piece, M.map.fd, NBUF)); staged = true; }
                 for (uint64_t off = T0; off < T1; off += piece, n_piece++) {
@@ -1520,6 +1528,7 @@ struct Ingest {
             publish(M, std::move(t));
             T0 = T1;
         }
+        TRACE("plain producer: %llu slabs in %.4f s, of which waiting for the consumers to hand a text buffer back %.4f s", (unsigned long long)s, now_s() - t_begin, t_slot);
         return MF_OK;
     }
 
@@ -2314,12 +2323,13 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     const double t_begin = now_s();
     I.t_begin = t_begin;
     g_pool.reset_peak();
+    if (g_trace) { size_t f = 0, t = 0; (void)hipMemGetInfo(&f, &t); TRACE("device memory in use as the call starts %.3f GB, of which idle buffers of earlier calls %.3f GB", (double)(t - f) / 1e9, (double)g_pool.held(phys(I.devices[0])) / 1e9); }
     // text buffers a mate may hold: the consumers each hold one, the decoder one, the rest wait for the other mate or for a consumer (the quality
     // filter's pieces wait longer: their text is written out)
     // (a call that plans for less than 8 GB keeps two fewer in flight: a text buffer is a slab's text, 4.5 times its compressed bytes)
     uint64_t in_bytes = 0;
     for (int i = 0; i < I.nm; i++) in_bytes += I.m[i].map.n;
-    const bool small_call = 6 * in_bytes < ((uint64_t)8 << 30) && !getenv("MF_INGEST_BUDGET_GB");
+    const bool small_call = 8 * in_bytes < ((uint64_t)8 << 30) && !getenv("MF_INGEST_BUDGET_GB");
     const int text_bufs = (int)std::max<uint64_t>(2, env_u64("MF_INGEST_TEXT_BUFS", (I.qual ? 8 : 6) - (small_call ? 2 : 0))) + (int)I.devices.size() - 1;
     int rc = MF_OK;
     // an input that keeps the chip full of decode wavefronts for a long time gets the CU-masked set of streams (16 ms apiece to make and a
@@ -2332,12 +2342,16 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     // makes one call and ends (the CLIs say so: mf_set_option("short_lived", "1")) pays the exit with every call: masked only where the
     // difference is larger than that, from 8 GB.  MF_GZDEV_LARGE_MB overrides either.
     const bool large = gz_bytes >= (env_u64("MF_GZDEV_LARGE_MB", g_short_lived.load() ? 8192 : 256) << 20);
-    // Device memory follows the input: 6 bytes per compressed byte of the call, at least 3 GB, at most 20 (MF_INGEST_BUDGET_GB sets it).  1.5 GB
-    // of it are not this path's to plan (the runtime's own, the bait tables, the consumers' read sets and line indexes); the rest is shared
-    // by the mates, each of which sizes its ring, its slabs in flight and its text buffers from its share (GzStream::open).
-    const uint64_t budget = getenv("MF_INGEST_BUDGET_GB") ? env_u64("MF_INGEST_BUDGET_GB", 20) << 30
-                                                         : std::min<uint64_t>((uint64_t)20 << 30, std::max<uint64_t>((uint64_t)3 << 30, 6 * gz_bytes));
-    const uint64_t gz_budget = (budget > ((uint64_t)5 << 29) ? budget - ((uint64_t)3 << 29) : budget / 3) / (uint64_t)I.nm;
+    // Device memory follows the input: everything in use on the device stays within 8 bytes per compressed byte of the call, at least 3 GB,
+    // at most 24 (MF_INGEST_BUDGET_GB sets it).  Of that, 1.2 GB are not this path's (the runtime's own 0.83 GB as a process starts, the
+    // streams' queues, the bait tables); and for every byte the mates plan for their rings, symbol rooms, code lists and text buffers
+    // (GzStream::open) the call holds 0.5-0.7 more -- the consumers' read sets and line indexes, which grow with the text pieces, and
+    // buffers of one size idle in the pool while another size is asked for (profiles/r05/g_mem_probe.txt: planned 1.61 GB -> 2.35 GB of
+    // buffers, 3.49-3.70 GB in use; planned 5.8 -> 7.7, 9.4-10.0 in use).  The mates share what is left.
+    const uint64_t budget = getenv("MF_INGEST_BUDGET_GB") ? env_u64("MF_INGEST_BUDGET_GB", 24) << 30
+                                                         : std::min<uint64_t>((uint64_t)24 << 30, std::max<uint64_t>((uint64_t)3 << 30, 8 * gz_bytes));
+    const uint64_t not_ours = (uint64_t)1200 << 20;
+    const uint64_t gz_budget = (budget > 2 * not_ours ? (budget - not_ours) * 10 / 17 : budget / 4) / (uint64_t)I.nm;
     {   // (the two mates' decoders side by side)
         int rcs[2] = {MF_OK, MF_OK}; std::string errs[2]; std::thread th[2];
         for (int i = 0; i < I.nm; i++) {
@@ -2388,7 +2402,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
         else
             fprintf(stderr, "[mf device ingest] wall %.3f s | set-up %.3f | waiting for text (upload, inflate, link, CRC on the producer threads) %.3f | line index %.3f | pack %.3f | filter %.3f | survivors %.3f | buffers of this call at most %.2f GB on a device, device memory in use at most %.2f GB, %zu device(s)",
                     now_s() - t_begin, t_setup, I.t_wait, I.t_index, I.t_pack, I.t_filter, I.t_emit, (double)g_pool.peak() / 1e9, (double)I.mem_used_max / 1e9, I.devices.size());
-        { double tm; uint64_t nm; g_pool.malloc_time(tm, nm); fprintf(stderr, " | %llu new device allocations took %.3f s (summed over the threads that asked)", (unsigned long long)nm, tm); }
+        { double tm; uint64_t nm; g_pool.malloc_time(tm, nm); fprintf(stderr, " | %llu new device allocations took %.3f s (summed over the threads that asked); idle buffers now %.2f GB", (unsigned long long)nm, tm, (double)g_pool.held(phys(I.devices[0])) / 1e9); }
         fprintf(stderr, " | first text after %.3f s, last after %.3f, consumers done after %.3f", I.t_first_piece, I.t_last_piece, I.t_consumed);
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);

@@ -479,8 +479,8 @@ def test_a_failed_allocation_hands_the_call_to_the_host_pipeline(ol, bait_text, 
 # ---- round 5: the device memory of the path follows the input; what a process keeps between calls can be given back; big plain files take the path
 
 def test_device_memory_follows_the_input(mf, ol, bait_text, tmp_path, monkeypatch):
-    """A .gz pair of a few hundred megabytes must not hold what a 5 GB file does (round 4: 28 GB for a 0.6 GB pair): at most max(3 GB, 6 x the
-    compressed bytes) of device memory in use, same kept / total as the oracle."""
+    """A .gz pair of a few hundred megabytes must not hold what a 5 GB file does (round 4: 28 GB for a 0.6 GB pair): at most max(3 GB, 8 x the
+    compressed bytes) of device memory in use -- everything on the device, the runtime's own included -- same kept / total as the oracle."""
     import subprocess
     import sys
     monkeypatch.delenv("MF_INGEST", raising=False)
@@ -494,7 +494,7 @@ def test_device_memory_follows_the_input(mf, ol, bait_text, tmp_path, monkeypatc
     k, t = mf.filter_fastq_files(ks, pre + "_1.fq.gz", pre + "_2.fq.gz", str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq"))
     st = mf.last_ingest_stats()
     assert st["path"] == 1 and t == 1200000
-    assert st["device_bytes_peak"] <= max(3 << 30, 6 * gz), (st["device_bytes_peak"] / 1e9, gz / 1e9)
+    assert st["device_bytes_peak"] <= max(3 << 30, 8 * gz), (st["device_bytes_peak"] / 1e9, gz / 1e9)
     ok, ot = ol.filter_fastq_files(pre + ".bait.fa", 31, 1, 0, pre + "_1.fq", pre + "_2.fq", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), threads=8)
     assert (k, t) == (ok, ot)
     assert open(tmp_path / "o1.fq", "rb").read() == open(tmp_path / "r1.fq", "rb").read()

@@ -81,6 +81,31 @@ int main(int argc, char **argv)
             STEP("  hipHostUnregister", (void)hipHostUnregister(m));
             munmap(m, n);
         }
+        for (int variant = 0; variant < 3; variant++) {          // the way the product does it: no MAP_POPULATE, a window of 512 MiB at a time; variant 0: register cold, 1: madvise POPULATE_READ (8 threads) first, 2: the same, populate one window ahead in the background
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            const size_t WIN = (size_t)512 << 20; const size_t nw = (n + WIN - 1) / WIN;
+            double t_pop = 0, t_reg = 0, t_copy = 0, t_unreg = 0; const double a0 = now_s();
+            auto populate = [&](size_t w) { const size_t a = w * WIN, b = a + WIN < n ? a + WIN : n; std::vector<std::thread> th; const size_t part = (b - a + 7) / 8 + 4095 & ~(size_t)4095;
+                for (size_t q = a; q < b; q += part) th.emplace_back([=] { madvise((char *)m + q, (q + part < b ? q + part : b) - q, 22); }); for (auto &t : th) t.join(); };
+            std::thread ahead;
+            for (size_t w = 0; w < nw; w++) {
+                const size_t a = w * WIN, len = a + WIN < n ? WIN : n - a;
+                double t = now_s();
+                if (variant == 1) populate(w);
+                if (variant == 2) { if (ahead.joinable()) ahead.join(); else populate(w); if (w + 1 < nw) ahead = std::thread([&, w] { populate(w + 1); }); }
+                t_pop += now_s() - t; t = now_s();
+                (void)hipHostRegister((char *)m + a, len, hipHostRegisterPortable | hipHostRegisterReadOnly);
+                t_reg += now_s() - t; t = now_s();
+                (void)hipMemcpyAsync((char *)dev + a, (char *)m + a, len, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st);
+                t_copy += now_s() - t; t = now_s();
+                (void)hipHostUnregister((char *)m + a);
+                t_unreg += now_s() - t;
+            }
+            if (ahead.joinable()) ahead.join();
+            printf("%8.4f | windows of 512 MiB, %s: populate %.4f register %.4f copy+sync %.4f unregister %.4f | %8.4f\n", now_s() - T0,
+                   variant == 0 ? "registered cold" : variant == 1 ? "populated first (8 threads)" : "populated one window ahead", t_pop, t_reg, t_copy, t_unreg, now_s() - a0);
+            munmap(m, n);
+        }
         {   // the reference point: pread into pinned staging (what the uploader does), 8 threads, and the copy
             void *pin = nullptr; (void)hipHostMalloc(&pin, (size_t)32 << 20, hipHostMallocPortable);
             const double a = now_s(); size_t done = 0;
