@@ -243,11 +243,13 @@ public:
             std::lock_guard<std::mutex> lk(mu_); size_[(uint8_t *)q] = bytes; free_.emplace(bytes, (uint8_t *)q);
         }
     }
+    size_t idle() { std::lock_guard<std::mutex> lk(mu_); return free_.size(); }          // staging buffers waiting for the next call
     void clear() { std::vector<uint8_t *> v; { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : free_) { v.push_back(kv.second); size_.erase(kv.second); } free_.clear(); } for (uint8_t *q : v) (void)hipHostFree(q); }
 private:
     std::mutex mu_; std::multimap<size_t, uint8_t *> free_; std::map<uint8_t *, size_t> size_;
 };
 PinnedCache g_pinned;
+std::atomic<bool> g_short_lived{false};          // the process makes one file-level call and ends (a CLI): mf_set_option("short_lived", "1")
 
 // (the threads are the stager's own and live as long as it does: starting eight threads per 32 MiB piece was a tenth of the time of a read)
 struct Stager {
@@ -313,12 +315,16 @@ private:
 // threads of its own, ahead of and behind the copies, configs[4] took 0.30 s against 0.236 s staged, its plain text 0.284 s (0.07 s of it the
 // munmap) against 0.22-0.30 s (profiles/r05/g_upload_registered_vs_staged.txt).  Where a mapping cannot be registered at all (a file
 // system whose pages cannot be pinned) ensure() says no and the caller stages as well.
+// This is the COLD call's way.  Registering is host work with every call (2.4 ms per 100 MiB, and the munmap), staging buffers are pinned once and
+// kept: a warm call of a 0.16 GB plain file took 7.1 ms staged and 16.1 ms registered (profiles/r05/e_masks_ab.txt, g_masks_ab_after.txt).  So
+// a file is registered only while the process holds no idle staging buffers; a process that lives on (not "short_lived") pins a set behind its
+// first call (StreamSets::stage_later), and the calls after that stage.
 class PinnedMap {
 public:
     PinnedMap(const uint8_t *p, size_t n) : p_(p), n_(n)
     {
         static const bool off = getenv("MF_UPLOAD_STAGED") != nullptr;
-        usable_ = !off && p && n && n <= (size_t)env_u64("MF_UPLOAD_REGISTER_MAX_MB", 512) << 20;
+        usable_ = !off && p && n && n <= (size_t)env_u64("MF_UPLOAD_REGISTER_MAX_MB", 512) << 20 && g_pinned.idle() == 0;
     }
     ~PinnedMap()
     {
@@ -508,9 +514,19 @@ public:
             gz_preload(); ingest_preload(); cold_mark("prefetch: code objects of the decoder and the line kernels loaded");          // (no staging buffers: the uploads read the page cache's pages)
         });
     }
+    // staging buffers for the calls to come, pinned on a thread of their own behind a process's first call (not for a process that makes one call and ends)
+    void stage_later()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (stage_started_ || g_short_lived.load() || g_pinned.idle()) return;
+        stage_started_ = true;
+        stage_ = std::thread([] { g_pinned.prefill(4, (size_t)32 << 20); });
+    }
+    void forget_staging() { std::lock_guard<std::mutex> lk(mu_); if (stage_.joinable()) stage_.join(); stage_started_ = false; }          // (the cache has been emptied on request: the next call is a cold one again)
     ~StreamSets()
     {
         if (prefill_.joinable()) prefill_.join();
+        if (stage_.joinable()) stage_.join();
         for (auto &kv : dev_) { kv.second->stop = true; kv.second->cv.notify_all(); if (kv.second->maker.joinable()) kv.second->maker.join(); }
         const char *pre = getenv("LD_PRELOAD");
         const bool profiled = (pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("MF_GZDEV_DESTROY_STREAMS_AT_EXIT");
@@ -526,10 +542,9 @@ public:
         }
     }
 private:
-    std::mutex mu_; std::map<int, DeviceStreams *> dev_; std::thread prefill_; bool prefill_started_ = false;
+    std::mutex mu_; std::map<int, DeviceStreams *> dev_; std::thread prefill_, stage_; bool prefill_started_ = false, stage_started_ = false;
 };
 StreamSets g_streams;
-std::atomic<bool> g_short_lived{false};          // the process makes one file-level call and ends (a CLI): mf_set_option("short_lived", "1")
 
 // ---- how many text buffers a mate may hold at a time (the producer waits for one to come back)
 struct Slots {
@@ -730,7 +745,7 @@ public:
         data_ = data; size_ = size; path_ = path; slots_ = slots; pad_ = TEXT_FRONT + carry_room; stop_ = stop;
         const uint32_t nl = (uint32_t)devices.size();
         const bool big = budget == 0 || budget >= ((uint64_t)2 << 30);          // (a mate's share of a call that plans for several gigabytes)
-        dec_limit_ = big ? GZ_NSTREAM : 3;
+        dec_limit_ = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(GZ_NSTREAM, env_u64("MF_GZDEV_DEC_STREAMS", big ? GZ_NSTREAM : 3)));
         // chunks: large enough that a slab's fixed costs stay small, small enough that a file keeps the chip busy.  Measured over 0.1 / 0.3 / 1 / 3 GB of
         // .gz a mate x {64, 96, 128, 192, 256} KiB (profiles/r05/f_chunk_size_probe.txt, tools/chunk_size_probe.sh): 64 KiB is the fastest up to
         // 0.3 GB, 96 KiB at 1 GB (SE 0.087 s against 0.101 with 64 KiB and 0.123 with 256; PE 0.163 against 0.207), 192 KiB at 3 GB -- the file's
@@ -1492,8 +1507,15 @@ struct Ingest {
         struct Cleanup { std::vector<PerDev> &pd; const std::vector<int> &devs; ~Cleanup() { for (size_t i = 0; i < pd.size(); i++) { (void)hipSetDevice(phys(devs[i])); if (pd[i].st) (void)hipStreamSynchronize(pd[i].st); for (auto &e : pd[i].ev) if (e) (void)hipEventDestroy(e); } } } cleanup{pd, devices};
         uint64_t n_piece = 0; int used_by[NBUF]; for (auto &u : used_by) u = -1;
         uint64_t s = 0; double t_slot = 0; const double t_begin = now_s();
+        // (slabs grow from 32 MiB at the front of the file -- the consumers start on the first after 0.6 ms of copying, not 4.5 -- and shrink
+        // again towards its end: what is left when the last copy has run is one consumer's work on a small piece)
+        const uint64_t small_slab = std::min<uint64_t>(slab, (uint64_t)32 << 20);
         for (uint64_t T0 = 0; T0 < M.map.n && !M.stop; s++) {
-            const uint64_t T1 = std::min<uint64_t>(M.map.n, T0 + slab);
+            const uint64_t left = M.map.n - T0;
+            uint64_t want = std::min<uint64_t>(slab, small_slab << std::min<uint64_t>(s, 8));
+            if (left < 3 * want) want = std::max<uint64_t>(small_slab, left / 3);
+            if (left < want + small_slab / 2) want = left;
+            const uint64_t T1 = T0 + want;
             const size_t li = (size_t)(s % devices.size());
             const int ldev = devices[li], dev = phys(ldev);
             DCHK(hipSetDevice(dev));
@@ -2394,6 +2416,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
             } else stats->text_bytes += M.map.n;
         }
     }
+    if (rc == MF_OK) g_streams.stage_later();
     if (I.timing) {
         if (I.qual)
             fprintf(stderr, "[mf device ingest] quality filter: wall %.3f s | set-up %.3f | consumers (summed over %zu): waiting for text %.3f, line index %.3f, scan %.3f, decisions %.3f, gather + copy down %.3f, waiting for the writers %.3f; writers busy %.3f %.3f | %llu + %llu bytes written | buffers of this call at most %.2f GB, device memory in use at most %.2f GB",
@@ -2465,7 +2488,7 @@ void ingest_prefetch(int device)
 
 size_t release_cached_device_memory(bool all)
 {
-    if (all) { g_scratch.clear(); g_pinned.clear(); return g_pool.release_all(); }
+    if (all) { g_scratch.clear(); g_streams.forget_staging(); g_pinned.clear(); return g_pool.release_all(); }
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return g_pool.release(dev);
