@@ -394,13 +394,13 @@ private:
 constexpr uint32_t GZ_NSTREAM = 10, GZ_NPOST = 2;
 struct DeviceStreams {
     int device = -1;
-    hipStream_t dec[GZ_NSTREAM] = {}, copy = nullptr, post[GZ_NPOST] = {}, post_masked[GZ_NPOST] = {};
+    hipStream_t dec[GZ_NSTREAM] = {}, copy = nullptr, post[GZ_NPOST] = {}, post_masked[GZ_NPOST] = {}, post_b[GZ_NPOST] = {};
     std::atomic<uint32_t> n_dec{0};
     std::mutex mu; std::condition_variable cv; int made = 0; bool failed = false, post_busy[GZ_NPOST] = {false, false};
     std::thread maker; std::atomic<bool> stop{false};
     uint32_t words = 0; int n_cu = 0; std::vector<uint32_t> mask, mask_rest; bool masked = false;
     // the order of making: what a cold call on a small file waits for comes first
-    enum What { DEC0, COPY, POST0, POST1, DEC1, DEC2, DEC3, POSTM0, POSTM1, DEC_REST, N_WHAT };
+    enum What { DEC0, COPY, POST0, POST1, DEC1, DEC2, DEC3, POSTM0, POSTM1, POSTB0, POSTB1, DEC_REST, N_WHAT };
     bool make_masked(hipStream_t *q, const std::vector<uint32_t> &m) const
     {
         if (masked && hipExtStreamCreateWithCUMask(q, words, m.data()) == hipSuccess) return true;
@@ -425,6 +425,7 @@ struct DeviceStreams {
             case POST0: case POST1: ok = hipStreamCreateWithFlags(&post[w - POST0], hipStreamNonBlocking) == hipSuccess; break;
             case DEC1: case DEC2: case DEC3: ok = make_masked(&dec[1 + w - DEC1], mask); if (ok) n_dec = 2 + (uint32_t)(w - DEC1); break;
             case POSTM0: case POSTM1: ok = make_masked(&post_masked[w - POSTM0], mask_rest); break;
+            case POSTB0: case POSTB1: ok = hipStreamCreateWithFlags(&post_b[w - POSTB0], hipStreamNonBlocking) == hipSuccess; break;
             case DEC_REST: for (uint32_t i = 4; i < GZ_NSTREAM && !stop && ok; i++) { ok = make_masked(&dec[i], mask); if (ok) n_dec = i + 1; } break;          // (fewer streams: slabs share them)
             }
             if (!ok) { fail_(); return; }
@@ -457,6 +458,13 @@ struct DeviceStreams {
         if (k < 0) { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; }      // (more than two mates at a time on one device: concurrent calls)
         if (want_masked && masked) { ask(POSTM1 + 1); if (wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k]; }
         return post[k];
+    }
+    // the second stream of a mate's post work (marker resolution of the chunks' bodies and the CRC, behind the link step they belong to): a plain one
+    hipStream_t take_post_b(int slot)
+    {
+        if (slot < 0 || slot >= (int)GZ_NPOST) return nullptr;
+        ask(POSTB1 + 1);
+        return wait_for(slot == 0 ? POSTB0 : POSTB1) ? post_b[slot] : nullptr;
     }
     void give_post(int slot, hipStream_t q)
     {
@@ -538,6 +546,7 @@ public:
             for (auto &q : D.dec) if (q) (void)hipStreamDestroy(q);
             for (auto &q : D.post) if (q) (void)hipStreamDestroy(q);
             for (auto &q : D.post_masked) if (q) (void)hipStreamDestroy(q);
+            for (auto &q : D.post_b) if (q) (void)hipStreamDestroy(q);
             if (D.copy) (void)hipStreamDestroy(D.copy);
         }
     }
@@ -598,7 +607,7 @@ public:
         for (size_t l = 0; l < lanes_.size(); l++) {
             (void)hipSetDevice(lanes_[l].dev);
             for (auto &e : ev_[l]) if (e) (void)hipEventDestroy(e);
-            for (int b = 0; b < 2; b++) if (free_ev_[l][b]) (void)hipEventDestroy(free_ev_[l][b]);
+            for (int b = 0; b < UP_BUFS_MAX; b++) if (free_ev_[l][b]) (void)hipEventDestroy(free_ev_[l][b]);
         }
     }
     // piece_lanes[i]: bit l set = lane l wants piece i
@@ -606,8 +615,9 @@ public:
     {
         map_ = map; fd_ = fd; n_ = n; ring_ = ring_bytes; piece_ = piece; lanes_ = std::move(lanes); want_ = std::move(piece_lanes);
         ev_.assign(lanes_.size(), std::vector<hipEvent_t>(want_.size(), nullptr));
-        free_ev_.assign(lanes_.size(), std::array<hipEvent_t, 2>{nullptr, nullptr});
-        stage_used_[0] = stage_used_[1] = 0;
+        free_ev_.assign(lanes_.size(), std::array<hipEvent_t, UP_BUFS_MAX>{});
+        for (auto &u : stage_used_) u = 0;
+        n_bufs_ = (int)std::max<uint64_t>(2, std::min<uint64_t>(UP_BUFS_MAX, env_u64("MF_GZDEV_UPLOAD_BUFS", 2)));
         low_ = 0;
         th_ = std::thread([this] { run(); });
     }
@@ -650,12 +660,12 @@ private:
                 if (stop_) return;
             }
             const double t_b = now_s();
-            const int b = (int)(i & 1);
+            const int b = (int)(i % (size_t)n_bufs_);
             const bool direct = reg.ensure();
             const uint8_t *src = map_ + off;
             double t_c = now_s();
             if (!direct) {
-                if (!staged) { const hipError_t e = stage_.init(piece_, fd_); if (e != hipSuccess) { fail_(e == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP); return; } staged = true; }
+                if (!staged) { const hipError_t e = stage_.init(piece_, fd_, n_bufs_); if (e != hipSuccess) { fail_(e == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP); return; } staged = true; }
                 for (size_t l = 0; l < lanes_.size(); l++)          // the copies that read this staging buffer are done
                     if ((stage_used_[b] >> l) & 1) { if (hipSetDevice(lanes_[l].dev) != hipSuccess || hipEventSynchronize(free_ev_[l][b]) != hipSuccess) { fail_(MF_E_HIP); return; } }
                 stage_used_[b] = 0;
@@ -698,8 +708,9 @@ public:
 private:
     const uint8_t *map_ = nullptr; size_t n_ = 0, ring_ = 0, piece_ = 0; int fd_ = -1;
     std::vector<Lane> lanes_; std::vector<uint64_t> want_;
-    Stager stage_; uint64_t stage_used_[2] = {0, 0};
-    std::vector<std::vector<hipEvent_t>> ev_; std::vector<std::array<hipEvent_t, 2>> free_ev_;
+    static constexpr int UP_BUFS_MAX = 4;
+    Stager stage_; uint64_t stage_used_[UP_BUFS_MAX] = {}; int n_bufs_ = 2;
+    std::vector<std::vector<hipEvent_t>> ev_; std::vector<std::array<hipEvent_t, UP_BUFS_MAX>> free_ev_;
     std::thread th_; std::mutex mu_; std::condition_variable cv_; size_t enqueued_ = 0; uint64_t low_ = 0; bool failed_ = false; int fail_rc_ = MF_OK; std::atomic<bool> stop_{false};
 };
 
@@ -715,17 +726,19 @@ public:
             (void)hipSetDevice(L.dev);
             for (uint32_t i = 0, n = L.ds->n_dec.load(); i < n; i++) (void)hipStreamSynchronize(L.ds->dec[i]);      // (the maker thread may still be writing the handles behind n)
             if (L.post) (void)hipStreamSynchronize(L.post);
+            if (L.post_b && L.post_b != L.post) (void)hipStreamSynchronize(L.post_b);
             if (L.ev_base) (void)hipEventDestroy(L.ev_base);
-            if (L.ev_crc) (void)hipEventDestroy(L.ev_crc);
+            if (L.ev_a) (void)hipEventDestroy(L.ev_a);
+            for (auto &C : L.crc) if (C.ev) (void)hipEventDestroy(C.ev);
             for (auto &e : L.ev_list) if (e) (void)hipEventDestroy(e);
         }
         reap(true);
         for (auto &S : slabs_) drop_events(*S);
         slabs_.clear(); cur_buf_.reset();
         for (auto &L : lanes_) {
-            L.ring.release(); L.d_chunks.release(); L.d_window.release(); L.d_crc.release(); L.d_acc.release(); L.d_acc_off.release(); L.d_link.release();
+            L.ring.release(); L.d_chunks.release(); L.d_window.release(); for (auto &C : L.crc) C.d.release(); L.d_acc.release(); L.d_acc_off.release(); L.d_link.release();
             (void)hipSetDevice(L.dev);
-            if (L.h_crc) (void)hipHostFree(L.h_crc);
+            for (auto &C : L.crc) if (C.h) (void)hipHostFree(C.h);
             if (L.h_list) (void)hipHostFree(L.h_list);
             if (L.ds) L.ds->give_post(L.post_slot, L.post);
         }
@@ -793,7 +806,7 @@ public:
             want = pow2_ceil(std::max<uint64_t>(want, 4096));
             if (want < ring) ring = (size_t)want;
         }
-        piece_ = std::min<size_t>((size_t)32 << 20, std::max<size_t>(ring / 8, 512));
+        piece_ = std::min<size_t>(pow2_ceil((size_t)env_u64("MF_GZDEV_UPLOAD_PIECE_MB", 32)) << 20, std::max<size_t>(ring / 8, 512));
         for (;;) {          // slabs in flight: what the ring holds beside the margin and three pieces of the uploader
             const size_t fixed = margin_ + 3 * piece_ + 512;
             if (ring > fixed + slab_bytes) { max_inflight_ = (uint32_t)std::min<size_t>((size_t)NSLAB * nl, (ring - fixed) / slab_bytes); break; }
@@ -830,7 +843,7 @@ public:
             t_open_streams_ += now_s() - tl0;
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
             DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_window.need(L.dev, GZ_WINDOW, false));
-            DCHK(L.d_acc.need(L.dev, cps_ + 1, false)); DCHK(L.d_acc_off.need(L.dev, cps_ + 1, false)); DCHK(L.d_link.need(L.dev, gz_link_scratch_bytes(cps_), false));
+            DCHK(L.d_acc.need(L.dev, (size_t)LIST_SLOTS * (cps_ + 1), false)); DCHK(L.d_acc_off.need(L.dev, (size_t)LIST_SLOTS * (cps_ + 1), false)); DCHK(L.d_link.need(L.dev, gz_link_scratch_bytes(cps_), false));
             DCHK(hipHostMalloc((void **)&L.h_list, (size_t)LIST_SLOTS * (cps_ + 1) * 12, hipHostMallocPortable));
             L.ev_list.assign(LIST_SLOTS, nullptr);
             ul[l].dev = L.dev; ul[l].ring = L.ring.p; ul[l].ds = L.ds;
@@ -857,8 +870,9 @@ public:
     // decode kernel of the front slab (it needs the chunks' descriptors) and a text buffer.
     int next(TextPiece &out, std::string &err)
     {
+        struct Timed { double &acc, t0; ~Timed() { acc += now_s() - t0; } } timed{t_next_, now_s()};
         out = TextPiece();
-        reap(false);
+        { const double t = now_s(); reap(false); t_reap_ += now_s() - t; }
         if (done_ || (slabs_.empty() && next_plan_ >= plan_.size())) return MF_OK;
         // decode runs ahead of the text: the front slab (waiting for its bytes if need be) and as many of the following ones as the
         // ring has room and uploaded bytes for
@@ -937,8 +951,14 @@ public:
                     uint32_t mx = 0;
                     for (uint32_t c : acc_) mx = std::max(mx, h_chunks_[c].n_sym);
                     rc = window_to(S.lane, err); if (rc) return rc;
-                    rc = lists_up(L, err); if (rc) return rc;
-                    DCHK(launch_gz_link(L.d_acc.p, L.d_acc_off.p, (uint32_t)acc_.size(), mx, L.d_chunks.p, S.lo, S.sym.p, S.cap, L.d_window.p, wlen_before, L.d_link.p, cur_buf_->p, T0, acc_off_[0], sp));
+                    uint32_t slot = 0;
+                    rc = lists_up(L, slot, err); if (rc) return rc;
+                    const uint32_t *da = L.d_acc.p + (size_t)slot * (cps_ + 1); const uint64_t *dao = L.d_acc_off.p + (size_t)slot * (cps_ + 1);
+                    // the tails and the window on the post stream -- the next link step waits for nothing else --, the bodies behind them on post_b
+                    DCHK(launch_gz_link(da, dao, (uint32_t)acc_.size(), mx, L.d_chunks.p, S.lo, S.sym.p, S.cap, L.d_window.p, wlen_before, L.d_link.p, cur_buf_->p, T0, acc_off_[0], sp));
+                    rc = b_behind_a(L, err); if (rc) return rc;
+                    DCHK(launch_gz_resolve(da, dao, (uint32_t)acc_.size(), mx, L.d_chunks.p, S.lo, S.sym.p, S.cap, cur_buf_->p, T0, L.post_b));
+                    DCHK(hipEventRecord(L.ev_list[slot], L.post_b));
                     win_dev_ = (int)S.lane; win_on_host_ = false;
                     if (lanes_.size() > 1) { rc = window_down(err); if (rc) return rc; }          // (the next slab is linked on another device)
                 }
@@ -978,19 +998,22 @@ public:
             if (mend) { rc = member_end(S, T0, err); if (rc) return rc; if (done_) break; }
         }
         t_link_ += now_s() - tl0;
-        // the rest of the member's CRC over this piece: launched here, taken in when the next one is launched (or at the member's end)
-        if (link_.total > crc_done_) { rc = crc_launch(L, crc_done_, link_.total, T0, sp, err); if (rc) return rc; }
+        // the rest of the member's CRC over this piece: launched here, taken in when it has come down (or at the member's end)
+        const double tc0 = now_s();
+        rc = b_behind_a(L, err); if (rc) return rc;          // (the bytes of a gap, the zeros in front of the text: whatever post has been given for this piece)
+        if (link_.total > crc_done_) { rc = crc_launch(L, crc_done_, link_.total, T0, L.post_b, err); if (rc) return rc; }
+        t_crc_ += now_s() - tc0;
         S.cur = b;
         const bool slab_done = S.cur == S.hi || done_;
         if (last_piece && !done_) { err = "gzip read error in " + path_ + ": unexpected end of file"; return MF_E_FORMAT; }   // the data ran out inside a member
-        // the piece is text once everything queued on the post stream up to here has run: it is handed over now, with the event that says so
-        DCHK(hipEventRecord(cur_buf_->ready_event(), sp));
+        // the piece is text once everything queued on the post streams up to here has run: it is handed over now, with the event that says so
+        DCHK(hipEventRecord(cur_buf_->ready_event(), L.post_b));
         out.buf = std::move(cur_buf_); out.T0 = T0; out.len = link_.total - T0; out.last = done_;
         out.grow = b > a ? std::max(1.0, (double)cps_ / (double)(b - a)) : 1.0;
         if (slab_done) {
             // its symbols are being resolved: the slab is kept until the post stream has passed this point
             Retired R; R.slab = std::move(slabs_.front()); slabs_.pop_front();
-            DCHK(hipEventCreateWithFlags(&R.done, hipEventDisableTiming)); DCHK(hipEventRecord(R.done, sp));
+            DCHK(hipEventCreateWithFlags(&R.done, hipEventDisableTiming)); DCHK(hipEventRecord(R.done, L.post_b));
             R.dev = L.dev;
             retired_.push_back(std::move(R));
             // what is in front of the next slab has been linked: the ring may take new bytes there
@@ -1006,6 +1029,7 @@ public:
     void link_parts(double &newtext, double &post_wait) const { newtext = t_newtext_; post_wait = t_post_wait_; }
     double slot_seconds() const { return t_slot_; }
     // where the producer thread's time went: waiting for decode kernels, the link step (incl. the wait for a text buffer); the uploader's
+    void other_times(double &reap, double &crc, double &all) const { reap = t_reap_; crc = t_crc_; all = t_next_; }
     void producer_times(double &wait_decode, double &link, double &up_ring, double &up_copy, double &up_read) const
     { wait_decode = t_wait_decode_; link = t_link_; up_ring = up_ ? up_->t_ring_ : 0; up_copy = up_ ? up_->t_copy_wait_ : 0; up_read = up_ ? up_->t_read_ : 0; }
     // seconds during which at least one decode kernel of this stream was running on a device, summed over the devices
@@ -1030,11 +1054,17 @@ public:
     uint32_t splits() const { return n_splits_; }
 private:
     static constexpr uint32_t LIST_SLOTS = 4;          // pinned staging for the accepted-chunk lists on their way up: a few link steps may be queued
+    // A piece's CRC launch leaves its results in one of a few slots, taken in -- in text order -- when they have come down: the producer
+    // does not wait for the post stream piece by piece (it did, for the launch before: every piece then cost the producer the whole of the
+    // previous piece's link, resolve and CRC kernels, 4-5 ms a slab of configs[4], and the decode launches behind it came that much later).
+    static constexpr uint32_t CRC_SLOTS = 4;
+    struct CrcSlot { DevBuf<uint32_t> d; uint32_t *h = nullptr; size_t h_cap = 0; hipEvent_t ev = nullptr; uint64_t n = 0; bool out = false; };      // h: pinned
     struct Lane {
-        int dev = 0, ldev = 0; DeviceStreams *ds = nullptr; hipStream_t post = nullptr; int post_slot = -1; bool want_masked_post = false;
-        hipEvent_t ev_base = nullptr, ev_crc = nullptr; std::vector<std::pair<double, double>> spans;
-        DevBuf<uint8_t> ring, d_window, d_link; DevBuf<GzChunk> d_chunks; DevBuf<uint32_t> d_crc, d_acc; DevBuf<uint64_t> d_acc_off;
-        uint32_t *h_crc = nullptr; size_t h_crc_cap = 0; uint64_t crc_n = 0;      // h_crc: pinned
+        int dev = 0, ldev = 0; DeviceStreams *ds = nullptr; hipStream_t post = nullptr, post_b = nullptr; int post_slot = -1; bool want_masked_post = false;          // post_b: see lane_post
+        hipEvent_t ev_a = nullptr;          // on post, behind a link step: post_b's kernels of the same chunks wait for it
+        hipEvent_t ev_base = nullptr; std::vector<std::pair<double, double>> spans;
+        DevBuf<uint8_t> ring, d_window, d_link; DevBuf<GzChunk> d_chunks; DevBuf<uint32_t> d_acc; DevBuf<uint64_t> d_acc_off;
+        CrcSlot crc[CRC_SLOTS]; uint32_t crc_seq = 0;
         uint8_t *h_list = nullptr; std::vector<hipEvent_t> ev_list; uint32_t list_seq = 0;      // pinned: LIST_SLOTS x {offsets, chunk numbers}
     };
     struct SlabPlan { uint32_t lo, hi, lane; };
@@ -1076,8 +1106,14 @@ private:
         L.post = L.ds->take_post(L.want_masked_post, &L.post_slot);
         t_post_wait_ += now_s() - t0;
         if (!L.post) { err = "hipStreamCreate failed"; return MF_E_HIP; }
+        // A link step waits for the one before through the window, and for nothing else; the bodies of its chunks and the CRC of its text are
+        // three quarters of a piece's post work (2.0 + 1.0 of 3.6 ms a slab of configs[4], profiles/r05/devingest_kernel_stats.txt) and nothing
+        // of the next piece waits for them: on an input of many slabs they go to a stream of their own, behind the link step (b_behind_a).
+        // (one stream for it all paced the whole pipeline at the sum: profiles/r05/g_configs4_timing_crc_ring.txt)
+        const char *two = getenv("MF_GZDEV_RESOLVE_STREAM");
+        L.post_b = (two ? two[0] == '1' : L.want_masked_post) ? L.ds->take_post_b(L.post_slot) : nullptr;
+        if (!L.post_b) L.post_b = L.post;
         DCHK(hipEventCreate(&L.ev_base)); DCHK(hipEventRecord(L.ev_base, L.post));
-        DCHK(hipEventCreateWithFlags(&L.ev_crc, hipEventDisableTiming));
         return MF_OK;
     }
     int launch_ahead(std::string &err)
@@ -1124,16 +1160,26 @@ private:
         }
         return MF_OK;
     }
-    // the accepted chunks of this link step -> the lane's device lists (through a slot of pinned staging: a few steps may be queued)
-    int lists_up(Lane &L, std::string &err)
+    // the accepted chunks of this link step -> one of the lane's device lists (through a slot of pinned staging: a few steps may be queued; a slot
+    // is free again when the resolve kernel that read it has run)
+    int lists_up(Lane &L, uint32_t &slot, std::string &err)
     {
-        const uint32_t slot = L.list_seq++ % LIST_SLOTS, n = (uint32_t)acc_.size();
+        slot = L.list_seq++ % LIST_SLOTS;
+        const uint32_t n = (uint32_t)acc_.size();
         if (L.ev_list[slot]) DCHK(hipEventSynchronize(L.ev_list[slot])); else DCHK(hipEventCreateWithFlags(&L.ev_list[slot], hipEventDisableTiming));
         uint8_t *h = L.h_list + (size_t)slot * (cps_ + 1) * 12;
         memcpy(h, acc_off_.data(), (size_t)n * 8); memcpy(h + (size_t)(cps_ + 1) * 8, acc_.data(), (size_t)n * 4);
-        DCHK(hipMemcpyAsync(L.d_acc_off.p, h, (size_t)n * 8, hipMemcpyHostToDevice, L.post));
-        DCHK(hipMemcpyAsync(L.d_acc.p, h + (size_t)(cps_ + 1) * 8, (size_t)n * 4, hipMemcpyHostToDevice, L.post));
-        DCHK(hipEventRecord(L.ev_list[slot], L.post));
+        DCHK(hipMemcpyAsync(L.d_acc_off.p + (size_t)slot * (cps_ + 1), h, (size_t)n * 8, hipMemcpyHostToDevice, L.post));
+        DCHK(hipMemcpyAsync(L.d_acc.p + (size_t)slot * (cps_ + 1), h + (size_t)(cps_ + 1) * 8, (size_t)n * 4, hipMemcpyHostToDevice, L.post));
+        return MF_OK;
+    }
+    // what post has been given up to here, post_b runs behind
+    int b_behind_a(Lane &L, std::string &err)
+    {
+        if (L.post_b == L.post) return MF_OK;
+        if (!L.ev_a) DCHK(hipEventCreateWithFlags(&L.ev_a, hipEventDisableTiming));
+        DCHK(hipEventRecord(L.ev_a, L.post));
+        DCHK(hipStreamWaitEvent(L.post_b, L.ev_a, 0));
         return MF_OK;
     }
     // the window is on lane l's device (it travels through the host between lanes, and after the host has decoded across a gap)
@@ -1180,6 +1226,7 @@ private:
         std::unique_ptr<TextBuf> nb;
         DCHK(TextBuf::make(nb, L.dev, L.ldev, pad_, (size_t)((need_abs - T0) + (need_abs - T0) / 2), nullptr));
         const uint64_t have = link_.total - T0;
+        if (L.post_b != L.post) DCHK(hipStreamSynchronize(L.post_b));          // (bodies on their way into the old buffer)
         DCHK(hipMemcpyAsync(nb->raw, cur_buf_->raw, cur_buf_->pad + have, hipMemcpyDeviceToDevice, L.post)); DCHK(hipStreamSynchronize(L.post));
         nb->slots = cur_buf_->slots; cur_buf_->slots = nullptr;          // (the slot moves to the new buffer)
         cur_buf_ = std::move(nb);
@@ -1213,10 +1260,11 @@ private:
         if (pos + 8 > size_) { err = "gzip read error in " + path_ + ": truncated gzip trailer"; return MF_E_FORMAT; }
         uint32_t want_crc, want_len; memcpy(&want_crc, data_ + pos, 4); memcpy(&want_len, data_ + pos + 4, 4);
         // CRC of the member's text up to here (everything of it is queued on the post stream: link, resolve, the bytes of a gap)
-        if (link_.total > crc_done_) { const int rc = crc_launch(L, crc_done_, link_.total, T0, sp, err); if (rc) return rc; }
-        if (crc_out_ >= 0 && crc_out_ != (int)S.lane) { Lane &O = lanes_[(size_t)crc_out_]; DCHK(hipSetDevice(O.dev)); DCHK(hipEventSynchronize(O.ev_crc)); crc_finish(O); DCHK(hipSetDevice(L.dev)); }
+        { const int rc = b_behind_a(L, err); if (rc) return rc; }
+        if (link_.total > crc_done_) { const int rc = crc_launch(L, crc_done_, link_.total, T0, L.post_b, err); if (rc) return rc; }
+        { const int rc = crc_take(L, nullptr, true, err); if (rc) return rc; }
         DCHK(hipStreamSynchronize(sp));
-        crc_finish(L);
+        if (L.post_b != sp) DCHK(hipStreamSynchronize(L.post_b));
         TRACE("member end: crc %08x want %08x", crc_, want_crc);
         if (crc_ != want_crc) { err = "gzip read error in " + path_ + ": incorrect data check"; return MF_E_FORMAT; }
         if ((uint32_t)(link_.total - member_T0_) != want_len) { err = "gzip read error in " + path_ + ": incorrect length check"; return MF_E_FORMAT; }
@@ -1230,22 +1278,41 @@ private:
         return MF_OK;
     }
     // running CRC of the member over the text [from, to) of the current piece: the kernel and the copy of its piece CRCs (crc_launch),
-    // the combination on the host (crc_finish)
+    // the combination on the host (crc_take)
     int crc_launch(Lane &L, uint64_t from, uint64_t to, uint64_t T0, hipStream_t st, std::string &err)
     {
-        // the launch before this one -- on whichever lane: a member's CRC is combined in text order -- is taken in first (its results have long come down)
-        if (crc_out_ >= 0) { Lane &O = lanes_[(size_t)crc_out_]; if (O.dev != L.dev) DCHK(hipSetDevice(O.dev)); DCHK(hipEventSynchronize(O.ev_crc)); crc_finish(O); if (O.dev != L.dev) DCHK(hipSetDevice(L.dev)); }
+        CrcSlot &C = L.crc[L.crc_seq++ % CRC_SLOTS];
+        // the slot's last launch (four pieces ago on this lane) is taken in first if it has not been, and whatever else has come down
+        { const int rc = crc_take(L, &C, false, err); if (rc) return rc; }
         const uint64_t n = to - from;
         const size_t np = (size_t)((n + GZ_CRC_PIECE - 1) / GZ_CRC_PIECE);
-        DCHK(L.d_crc.need(L.dev, np));
-        if (np > L.h_crc_cap) { if (L.h_crc) (void)hipHostFree(L.h_crc); L.h_crc = nullptr; L.h_crc_cap = 0; DCHK(hipHostMalloc((void **)&L.h_crc, (np + np / 2 + 64) * 4, hipHostMallocDefault)); L.h_crc_cap = np + np / 2 + 64; }
-        DCHK(launch_gz_crc(cur_buf_->p + (from - T0), n, L.d_crc.p, st));
-        DCHK(hipMemcpyAsync(L.h_crc, L.d_crc.p, np * 4, hipMemcpyDeviceToHost, st));
-        DCHK(hipEventRecord(L.ev_crc, st));
-        L.crc_n = n; crc_done_ = to; crc_out_ = (int)(&L - lanes_.data());
+        DCHK(C.d.need(L.dev, np));
+        if (np > C.h_cap) { if (C.h) (void)hipHostFree(C.h); C.h = nullptr; C.h_cap = 0; DCHK(hipHostMalloc((void **)&C.h, (np + np / 2 + 64) * 4, hipHostMallocDefault)); C.h_cap = np + np / 2 + 64; }
+        if (!C.ev) DCHK(hipEventCreateWithFlags(&C.ev, hipEventDisableTiming));
+        DCHK(launch_gz_crc(cur_buf_->p + (from - T0), n, C.d.p, st));
+        DCHK(hipMemcpyAsync(C.h, C.d.p, np * 4, hipMemcpyDeviceToHost, st));
+        DCHK(hipEventRecord(C.ev, st));
+        C.n = n; C.out = true; crc_done_ = to;
+        crc_q_.emplace_back((uint32_t)(&L - lanes_.data()), (uint32_t)(&C - L.crc));
         return MF_OK;
     }
-    void crc_finish(Lane &L) { if (L.crc_n) { crc_ = gz_crc_combine(crc_, gz_crc_finish(L.h_crc, L.crc_n), L.crc_n); L.crc_n = 0; } crc_out_ = -1; }      // (the copy of crc_launch has completed)
+    // CRC launches taken in, oldest first (a member's CRC is combined in text order, whichever lane a piece was on): all of them (waiting), or
+    // up to and including slot `until` if that is still out (waiting), and then those that have come down already.  `cur`: the lane whose device is current.
+    int crc_take(Lane &cur, const CrcSlot *until, bool all, std::string &err)
+    {
+        int dev = cur.dev;
+        while (!crc_q_.empty()) {
+            Lane &O = lanes_[crc_q_.front().first]; CrcSlot &C = O.crc[crc_q_.front().second];
+            if (O.dev != dev) { DCHK(hipSetDevice(O.dev)); dev = O.dev; }
+            if (all || (until && until->out)) DCHK(hipEventSynchronize(C.ev));
+            else if (hipEventQuery(C.ev) != hipSuccess) { (void)hipGetLastError(); break; }
+            crc_ = gz_crc_combine(crc_, gz_crc_finish(C.h, C.n), C.n);
+            C.n = 0; C.out = false;
+            crc_q_.pop_front();
+        }
+        if (dev != cur.dev) DCHK(hipSetDevice(cur.dev));
+        return MF_OK;
+    }
 
     const uint8_t *data_ = nullptr; size_t size_ = 0; std::string path_; Slots *slots_ = nullptr; size_t pad_ = TEXT_FRONT; std::atomic<bool> *stop_ = nullptr;
     size_t chunk_ = 0, base_byte_ = 0, margin_ = 0, ring_ = 0, piece_ = 0; double expand_ = 6; bool expand_fixed_ = false; uint32_t max_sym_seen_ = 0;
@@ -1261,8 +1328,8 @@ private:
     std::unique_ptr<TextBuf> cur_buf_;
     double t_open_ = 0, t_open_streams_ = 0, t_open_upload_ = 0;
     bool in_member_ = false, done_ = false, first_launched_ = false, first_decoded_ = false;
-    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0; int crc_out_ = -1;      // crc_out_: the lane whose CRC launch has not been taken in yet
-    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_post_wait_ = 0, t_slot_ = 0;
+    uint32_t crc_ = 0; uint64_t crc_done_ = 0, member_T0_ = 0, gap_bytes_ = 0, n_gaps_ = 0; std::deque<std::pair<uint32_t, uint32_t>> crc_q_;      // crc_q_: (lane, slot) of the CRC launches not taken in yet, in text order
+    double t_wait_decode_ = 0, t_link_ = 0, t_launch_ = 0, t_newtext_ = 0, t_post_wait_ = 0, t_slot_ = 0, t_reap_ = 0, t_crc_ = 0, t_next_ = 0;
 };
 
 // ---- survivors on their way to the output file (one writer thread per mate; pieces arrive in order)
@@ -2429,6 +2496,7 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
         fprintf(stderr, " | first text after %.3f s, last after %.3f, consumers done after %.3f", I.t_first_piece, I.t_last_piece, I.t_consumed);
         for (int i = 0; i < I.nm; i++)
             if (I.m[i].gzs) { double a, b, c, d, e; I.m[i].gzs->producer_times(a, b, c, d, e); fprintf(stderr, " | mate %d producer: launching (incl. waiting for the upload) %.3f, waiting for decode %.3f, link %.3f; uploader: ring full %.3f, copy wait %.3f, file read %.3f", i + 1, I.m[i].gzs->launch_seconds(), a, b, c, d, e);
+                              { double r, k, n; I.m[i].gzs->other_times(r, k, n); fprintf(stderr, "; giving back the buffers of linked slabs %.3f, CRC launch and results %.3f, all of the producer's steps %.3f", r, k, n); }
                               { double oa, os, ou; I.m[i].gzs->open_parts(oa, os, ou); fprintf(stderr, "; set-up %.3f (streams %.3f, uploader's buffers and thread %.3f)", oa, os, ou); }
                               double x, z; I.m[i].gzs->link_parts(x, z); fprintf(stderr, " (of the link time: text buffer %.3f of which waiting for the consumers to hand one back %.3f; waiting for the post stream to be made %.3f)", x, I.m[i].gzs->slot_seconds(), z); }
         for (int i = 0; i < I.nm; i++)

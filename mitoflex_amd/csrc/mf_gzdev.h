@@ -92,14 +92,20 @@ inline void gz_link_walk(const GzChunk *h_chunks, uint32_t chunk_hi, GzLinkState
     }
     st.next = c;
 }
-// The accepted chunks d_acc[0 .. n_acc) (chunk numbers, ascending; d_acc_off: their text offsets) become text: text is addressed by
-// absolute offset minus text_base.  d_window: 32 KiB, the text in front of the first of them (wlen_before valid bytes, right-aligned;
-// they are written to the text in front of first_off = the first chunk's offset too) -> the last 32 KiB behind the last of them.
-// The symbols' tails are rewritten in place.  max_sym: the largest n_sym among the chunks (grid sizing).  d_scratch:
+// The accepted chunks d_acc[0 .. n_acc) (chunk numbers, ascending; d_acc_off: their text offsets) become text, in two steps: text is addressed
+// by absolute offset minus text_base.
+// launch_gz_link -- the part that depends on the chunks in front: every chunk's TAIL (its last 32 Ki symbols) becomes text.  d_window: 32 KiB,
+// the text in front of the first chunk (wlen_before valid bytes, right-aligned; they are written to the text in front of first_off = the first
+// chunk's offset too) -> the last 32 KiB behind the last chunk.  The symbols' tails are rewritten in place.  d_scratch:
 // gz_link_scratch_bytes(most chunks ever passed at once) bytes, used in stream order.  See mf_gzdev.hip for the scheme (a two-level scan
-// over the windows: nothing in it is serial per chunk).
+// over the windows: nothing in it is serial per chunk).  This is what one link step waits for the one before with.
+// launch_gz_resolve -- the rest, every chunk's BODY: markers looked up in the 32 KiB of text in front of the chunk, which the link step of
+// the same chunks has written.  Any stream that runs behind that link step; nothing later waits for it but the text's readers.
+// max_sym: the largest n_sym among the chunks (grid sizing).
 hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t max_sym, const GzChunk *d_chunks, uint32_t chunk_lo, uint16_t *d_sym,
                           uint64_t sym_cap, uint8_t *d_window, uint32_t wlen_before, uint8_t *d_scratch, uint8_t *d_text, uint64_t text_base, uint64_t first_off, hipStream_t st);
+hipError_t launch_gz_resolve(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t max_sym, const GzChunk *d_chunks, uint32_t chunk_lo, const uint16_t *d_sym,
+                             uint64_t sym_cap, uint8_t *d_text, uint64_t text_base, hipStream_t st);
 inline uint32_t gz_link_group(uint32_t n_acc) { return n_acc <= 16 ? 4 : n_acc <= 64 ? 8 : n_acc <= 512 ? 16 : 32; }          // chunks per group of the scan's first level
 inline size_t gz_link_scratch_bytes(uint32_t max_chunks)
 {

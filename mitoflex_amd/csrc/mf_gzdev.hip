@@ -1690,8 +1690,14 @@ hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint
     hipLaunchKernelGGL(gz_link_tails_kernel, dim3(n_groups), dim3(LINK_THREADS), 0, st, d_acc, n_acc, group, d_chunks, chunk_lo, d_sym, sym_cap, gfinal);
     hipLaunchKernelGGL(gz_link_groups_kernel, dim3(1), dim3(LINK_THREADS), 0, st, d_window, wlen_before, gfinal, n_groups, gwin, d_text + (int64_t)(first_off - text_base));
     hipLaunchKernelGGL(gz_link_text_kernel, dim3(GZ_WINDOW / RESOLVE_SEG, n_acc), dim3(256), 0, st, d_acc, d_acc_off, group, d_chunks, chunk_lo, d_sym, sym_cap, gwin, d_text, text_base);
-    if (max_sym > GZ_WINDOW)
-        hipLaunchKernelGGL(gz_resolve_kernel, dim3((max_sym - GZ_WINDOW + RESOLVE_SEG - 1) / RESOLVE_SEG, n_acc), dim3(256), 0, st, d_acc, d_acc_off, d_chunks, chunk_lo, d_sym, sym_cap, d_text, text_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_gz_resolve(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t max_sym, const GzChunk *d_chunks, uint32_t chunk_lo, const uint16_t *d_sym,
+                             uint64_t sym_cap, uint8_t *d_text, uint64_t text_base, hipStream_t st)
+{
+    if (!n_acc || max_sym <= GZ_WINDOW) return hipSuccess;
+    hipLaunchKernelGGL(gz_resolve_kernel, dim3((max_sym - GZ_WINDOW + RESOLVE_SEG - 1) / RESOLVE_SEG, n_acc), dim3(256), 0, st, d_acc, d_acc_off, d_chunks, chunk_lo, d_sym, sym_cap, d_text, text_base);
     return hipGetLastError();
 }
 

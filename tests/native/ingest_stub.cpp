@@ -125,18 +125,33 @@ hipError_t launch_gz_link(const uint32_t *d_acc, const uint64_t *d_acc_off, uint
                           uint8_t *d_window, uint32_t wlen_before, uint8_t *, uint8_t *text, uint64_t text_base, uint64_t first_off, hipStream_t st)
 {
     if (!n_acc) return hipSuccess;
-    stub_enqueue(st, [=] {
+    stub_enqueue(st, [=] {          // every chunk's tail (its last 32 Ki symbols): the markers in it point into the tails in front, which are text by now
         uint8_t *tp = text - text_base;                          // (indexed by absolute text offset)
         for (uint32_t i = 0; i < wlen_before; i++) tp[first_off - wlen_before + i] = d_window[GZ_WINDOW - wlen_before + i];
         uint64_t end = first_off; uint32_t wlen = wlen_before;
         for (uint32_t k = 0; k < n_acc; k++) {
-            const uint32_t c = d_acc[k], n = chunks[c].n_sym;
+            const uint32_t c = d_acc[k], n = chunks[c].n_sym, tail = n < GZ_WINDOW ? n : GZ_WINDOW;
             const uint64_t off = d_acc_off[k];
             const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap;
-            for (uint32_t i = 0; i < n; i++) tp[off + i] = (sp[i] & GZ_MARK) ? tp[off - GZ_WINDOW + (sp[i] & 0x7FFFu)] : (uint8_t)sp[i];
+            for (uint32_t i = n - tail; i < n; i++) tp[off + i] = (sp[i] & GZ_MARK) ? tp[off - GZ_WINDOW + (sp[i] & 0x7FFFu)] : (uint8_t)sp[i];
             end = off + n; wlen = wlen + n < GZ_WINDOW ? wlen + n : GZ_WINDOW;
         }
         for (uint32_t i = 0; i < wlen; i++) d_window[GZ_WINDOW - wlen + i] = tp[end - wlen + i];
+    });
+    return hipSuccess;
+}
+hipError_t launch_gz_resolve(const uint32_t *d_acc, const uint64_t *d_acc_off, uint32_t n_acc, uint32_t, const GzChunk *chunks, uint32_t chunk_lo, const uint16_t *sym, uint64_t sym_cap,
+                             uint8_t *text, uint64_t text_base, hipStream_t st)
+{
+    if (!n_acc) return hipSuccess;
+    stub_enqueue(st, [=] {          // every chunk's body: its window is the tail(s) in front of it
+        uint8_t *tp = text - text_base;
+        for (uint32_t k = 0; k < n_acc; k++) {
+            const uint32_t c = d_acc[k], n = chunks[c].n_sym, body = n > GZ_WINDOW ? n - GZ_WINDOW : 0;
+            const uint64_t off = d_acc_off[k];
+            const uint16_t *sp = sym + (uint64_t)(c - chunk_lo) * sym_cap;
+            for (uint32_t i = 0; i < body; i++) tp[off + i] = (sp[i] & GZ_MARK) ? tp[off - GZ_WINDOW + (sp[i] & 0x7FFFu)] : (uint8_t)sp[i];
+        }
     });
     return hipSuccess;
 }

@@ -75,6 +75,15 @@ def test_uploads_through_staging_buffers(exes, tmp_path, case):
     assert r.returncode == 0 and "all checks of" in r.stderr, r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("case", ["bait_se_gz", "bait_pe_gz", "bait_two_devices", "qual_pe"])
+def test_bodies_and_crc_on_a_stream_of_their_own(exes, tmp_path, case):
+    """On an input of many slabs the chunks' bodies and the CRC run on a second stream behind the link step they belong to (GzStream::lane_post,
+    b_behind_a); MF_GZDEV_RESOLVE_STREAM=1 asks for that on the small files of this check -- same bytes, same CRC verdicts, nothing for TSan."""
+    r = _run(exes["tsan"], case, tmp_path, 1500, 240, MF_GZDEV_RESOLVE_STREAM="1")
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[:6000]
+    assert r.returncode == 0 and "all checks of" in r.stderr, r.stderr[-3000:]
+
+
 def test_the_check_hangs_without_partial_decisions(exes, tmp_path):
     """Round 4 fixed a hang of the paired quality filter: a piece of mate 1 waited for decisions that waited for text buffers the other mate
     held (mf_devingest.cpp, q_progress: `ready`).  With that rule compiled out the check must hang (its watchdog exits with 3) -- i.e. this

@@ -3,7 +3,7 @@
 //   tools/gzdev_check file.gz [chunk_KiB=256] [expansion=8] [reps=3]
 // Decodes every chunk on the GPU and checks every chunk's symbols against zlib's output (markers resolved from the reference text);
 // then links the chunks the way the product does -- the walk over the descriptors on the host, the window scan and the marker resolution
-// on the device (launch_gz_link) -- and compares the device's text with zlib's, byte for byte.
+// on the device (launch_gz_link, launch_gz_resolve) -- and compares the device's text with zlib's, byte for byte.
 #include "../mitoflex_amd/csrc/mf_gzdev.h"
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -159,6 +159,7 @@ int main(int argc, char **argv)
             CK(hipMemcpy(d_acc, acc.data(), acc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_acc_off, acc_off.data(), acc_off.size() * 8, hipMemcpyHostToDevice));
             CK(hipEventRecord(e0, 0));
             CK(mf::launch_gz_link(d_acc, d_acc_off, (uint32_t)acc.size(), mx, d_chunks, lo, d_sym + (size_t)lo * cap, cap, d_window, wlen_before, d_link, d_text + front, 0, acc_off[0], 0));
+            CK(mf::launch_gz_resolve(d_acc, d_acc_off, (uint32_t)acc.size(), mx, d_chunks, lo, d_sym + (size_t)lo * cap, cap, d_text + front, 0, 0));
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             link_ms += ms; link_chunks += (uint32_t)acc.size(); link_slabs++;
