@@ -1111,7 +1111,7 @@ private:
         // of the next piece waits for them: on an input of many slabs they go to a stream of their own, behind the link step (b_behind_a).
         // (one stream for it all paced the whole pipeline at the sum: profiles/r05/g_configs4_timing_crc_ring.txt)
         const char *two = getenv("MF_GZDEV_RESOLVE_STREAM");
-        L.post_b = (two ? two[0] == '1' : L.want_masked_post) ? L.ds->take_post_b(L.post_slot) : nullptr;
+        L.post_b = (two ? two[0] == '1' : (L.want_masked_post || n_chunks_ > 4 * cps_)) ? L.ds->take_post_b(L.post_slot) : nullptr;
         if (!L.post_b) L.post_b = L.post;
         DCHK(hipEventCreate(&L.ev_base)); DCHK(hipEventRecord(L.ev_base, L.post));
         return MF_OK;
