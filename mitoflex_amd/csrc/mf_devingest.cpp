@@ -391,7 +391,7 @@ private:
 //     masked to the CUs the decode streams leave free: profiles/r04/g_configs4_link_stream_ab.txt.
 // Never destroyed (destroying a CU-masked stream right after use was seen to hang inside the runtime, ROCm 7.2) -- except under a
 // profiler, at exit.
-constexpr uint32_t GZ_NSTREAM = 10, GZ_NPOST = 2;
+constexpr uint32_t GZ_NSTREAM = 4, GZ_NPOST = 2;          // (four decode streams do what ten did, profiles/r05/g_dec_streams_ab.txt: six hardware queues fewer to make, to hold and to tear down at exit)
 struct DeviceStreams {
     int device = -1;
     hipStream_t dec[GZ_NSTREAM] = {}, copy = nullptr, post[GZ_NPOST] = {}, post_masked[GZ_NPOST] = {}, post_b[GZ_NPOST] = {};
@@ -400,7 +400,7 @@ struct DeviceStreams {
     std::thread maker; std::atomic<bool> stop{false};
     uint32_t words = 0; int n_cu = 0; std::vector<uint32_t> mask, mask_rest; bool masked = false;
     // the order of making: what a cold call on a small file waits for comes first
-    enum What { DEC0, COPY, POST0, POST1, DEC1, DEC2, DEC3, POSTM0, POSTM1, POSTB0, POSTB1, DEC_REST, N_WHAT };
+    enum What { DEC0, COPY, POST0, POST1, POSTM0, POSTB0, DEC1, DEC2, DEC3, POSTM1, POSTB1, N_WHAT };          // (a large input's first link step waits for POSTM0: in front of the further decode streams)
     bool make_masked(hipStream_t *q, const std::vector<uint32_t> &m) const
     {
         if (masked && hipExtStreamCreateWithCUMask(q, words, m.data()) == hipSuccess) return true;
@@ -410,7 +410,7 @@ struct DeviceStreams {
     // The maker goes as far as somebody has asked for (want): a small file's call asks for the first decode stream, the copy stream and the
     // post streams and nothing else -- every further decode stream is asked for by the launch that could have used it (which takes an
     // existing one meanwhile), the masked post streams by a large input.  The runtime makes streams one after the other, whoever asks: a
-    // maker that ran through all sixteen at once held up the consumers' own streams for a tenth of a second (profiles/r05/c_cold_calls_factory.log).
+    // maker that ran through all of them (sixteen then) at once held up the consumers' own streams for a tenth of a second (profiles/r05/c_cold_calls_factory.log).
     int want = POST1 + 1;
     void ask(int upto) { { std::lock_guard<std::mutex> lk(mu); if (upto > want) want = upto; } cv.notify_all(); }
     void run()
@@ -424,9 +424,8 @@ struct DeviceStreams {
             case COPY: ok = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess; break;
             case POST0: case POST1: ok = hipStreamCreateWithFlags(&post[w - POST0], hipStreamNonBlocking) == hipSuccess; break;
             case DEC1: case DEC2: case DEC3: ok = make_masked(&dec[1 + w - DEC1], mask); if (ok) n_dec = 2 + (uint32_t)(w - DEC1); break;
-            case POSTM0: case POSTM1: ok = make_masked(&post_masked[w - POSTM0], mask_rest); break;
-            case POSTB0: case POSTB1: ok = hipStreamCreateWithFlags(&post_b[w - POSTB0], hipStreamNonBlocking) == hipSuccess; break;
-            case DEC_REST: for (uint32_t i = 4; i < GZ_NSTREAM && !stop && ok; i++) { ok = make_masked(&dec[i], mask); if (ok) n_dec = i + 1; } break;          // (fewer streams: slabs share them)
+            case POSTM0: case POSTM1: ok = make_masked(&post_masked[w == POSTM0 ? 0 : 1], mask_rest); break;
+            case POSTB0: case POSTB1: ok = hipStreamCreateWithFlags(&post_b[w == POSTB0 ? 0 : 1], hipStreamNonBlocking) == hipSuccess; break;
             }
             if (!ok) { fail_(); return; }
             { std::lock_guard<std::mutex> lk(mu); made = w + 1; }
@@ -444,7 +443,7 @@ struct DeviceStreams {
     {
         if (!wait_for(DEC0)) return nullptr;
         const uint32_t n = std::min<uint32_t>(n_dec.load(), std::max<uint32_t>(1, limit));
-        if (seq >= n && n < std::min<uint32_t>(GZ_NSTREAM, limit)) ask(n < 4 ? DEC1 + (int)n : N_WHAT);          // (one more for the next launch; the last six come together)
+        if (seq >= n && n < std::min<uint32_t>(GZ_NSTREAM, limit)) ask(DEC1 + (int)n);          // (one more for the next launch)
         return dec[seq % std::max<uint32_t>(1, n)];
     }
     hipStream_t copy_stream() { return wait_for(COPY) ? copy : nullptr; }
@@ -456,14 +455,14 @@ struct DeviceStreams {
         *slot = k;
         if (!wait_for(k == 1 ? POST1 : POST0)) return nullptr;          // (a single-end call does not wait for the second post stream)
         if (k < 0) { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; }      // (more than two mates at a time on one device: concurrent calls)
-        if (want_masked && masked) { ask(POSTM1 + 1); if (wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k]; }
+        if (want_masked && masked) { ask((k == 0 ? POSTM0 : POSTM1) + 1); if (wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k]; }
         return post[k];
     }
     // the second stream of a mate's post work (marker resolution of the chunks' bodies and the CRC, behind the link step they belong to): a plain one
     hipStream_t take_post_b(int slot)
     {
         if (slot < 0 || slot >= (int)GZ_NPOST) return nullptr;
-        ask(POSTB1 + 1);
+        ask((slot == 0 ? POSTB0 : POSTB1) + 1);
         return wait_for(slot == 0 ? POSTB0 : POSTB1) ? post_b[slot] : nullptr;
     }
     void give_post(int slot, hipStream_t q)
@@ -839,7 +838,7 @@ public:
             L.ds = g_streams.get(L.dev, large, err);          // (starts the maker thread if this is the set's first use; nothing here waits for a stream)
             if (!L.ds) return MF_E_HIP;
             L.want_masked_post = large && big;
-            if (n_chunks_ > 4 * cps_) L.ds->ask(DeviceStreams::N_WHAT);          // a file of many slabs: every decode stream, now -- they are made while the first slabs decode
+            if (n_chunks_ > 4 * cps_) L.ds->ask(DeviceStreams::N_WHAT);          // a file of many slabs: every stream of the set, now -- they are made while the first slabs decode
             t_open_streams_ += now_s() - tl0;
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
             DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_window.need(L.dev, GZ_WINDOW, false));
