@@ -143,6 +143,19 @@ int main(int argc, char **argv)
         STEP("6 CU-masked streams while another thread launches + syncs in a loop", for (auto &x : m) (void)hipExtStreamCreateWithCUMask(&x, (uint32_t)words, mask.data()));
         stop = true; other.join();
         printf("         | the other thread: %d launch+sync rounds, mean %.6f s, worst %.6f s\n", n_it, n_it ? sum / n_it : 0.0, worst);
+        {   // ... and copies?  a thread that copies 32 MiB pieces from pinned memory to the device on its own stream, while this one makes six more masked streams
+            void *pin = nullptr, *dv = nullptr; (void)hipHostMalloc(&pin, (size_t)32 << 20, hipHostMallocPortable); (void)hipMalloc(&dv, (size_t)32 << 20);
+            std::atomic<bool> stop2{false}; double worst2 = 0, sum2 = 0; int n2 = 0; double quiet = 0; int nq = 0;
+            for (int i = 0; i < 20; i++) { const double a = now_s(); (void)hipMemcpyAsync(dv, pin, (size_t)32 << 20, hipMemcpyHostToDevice, q[1]); (void)hipStreamSynchronize(q[1]); quiet += now_s() - a; nq++; }
+            std::thread copier([&] {
+                (void)hipSetDevice(0);
+                while (!stop2) { const double a = now_s(); (void)hipMemcpyAsync(dv, pin, (size_t)32 << 20, hipMemcpyHostToDevice, q[1]); (void)hipStreamSynchronize(q[1]); const double dt = now_s() - a; worst2 = dt > worst2 ? dt : worst2; sum2 += dt; n2++; }
+            });
+            hipStream_t m2[6];
+            STEP("6 more CU-masked streams while another thread copies 32 MiB pieces H2D + syncs in a loop", for (auto &x : m2) (void)hipExtStreamCreateWithCUMask(&x, (uint32_t)words, mask.data()));
+            stop2 = true; copier.join();
+            printf("         | the copying thread: alone %.6f s a piece (%.1f GB/s); beside the stream maker %d pieces, mean %.6f s, worst %.6f s\n", quiet / nq, 0.0335544 / (quiet / nq), n2, n2 ? sum2 / n2 : 0.0, worst2);
+        }
         printf("%8.4f | done\n", now_s() - T0);
         return 0;
     }
