@@ -1168,8 +1168,8 @@ private:
         if (L.ev_list[slot]) DCHK(hipEventSynchronize(L.ev_list[slot])); else DCHK(hipEventCreateWithFlags(&L.ev_list[slot], hipEventDisableTiming));
         uint8_t *h = L.h_list + (size_t)slot * (cps_ + 1) * 12;
         memcpy(h, acc_off_.data(), (size_t)n * 8); memcpy(h + (size_t)(cps_ + 1) * 8, acc_.data(), (size_t)n * 4);
-        DCHK(hipMemcpyAsync(L.d_acc_off.p + (size_t)slot * (cps_ + 1), h, (size_t)n * 8, hipMemcpyHostToDevice, L.post));
-        DCHK(hipMemcpyAsync(L.d_acc.p + (size_t)slot * (cps_ + 1), h + (size_t)(cps_ + 1) * 8, (size_t)n * 4, hipMemcpyHostToDevice, L.post));
+        DCHK(launch_bytes_from_host(L.d_acc_off.p + (size_t)slot * (cps_ + 1), h, (size_t)n * 8, L.post));          // (not the copy engine: mf_ingest.h)
+        DCHK(launch_bytes_from_host(L.d_acc.p + (size_t)slot * (cps_ + 1), h + (size_t)(cps_ + 1) * 8, (size_t)n * 4, L.post));
         return MF_OK;
     }
     // what post has been given up to here, post_b runs behind
@@ -1188,7 +1188,7 @@ private:
         int rc = window_down(err); if (rc) return rc;
         Lane &L = lanes_[l];
         DCHK(hipSetDevice(L.dev));
-        DCHK(hipMemcpyAsync(L.d_window.p, h_win_, GZ_WINDOW, hipMemcpyHostToDevice, L.post));
+        DCHK(launch_bytes_from_host(L.d_window.p, h_win_, GZ_WINDOW, L.post));
         DCHK(hipStreamSynchronize(L.post));          // (h_win_ is the host's to change again)
         win_dev_ = (int)l;
         return MF_OK;
@@ -1663,7 +1663,7 @@ struct Ingest {
             nb->slots = P.buf->slots; P.buf->slots = nullptr;
             P.buf = std::move(nb);
         }
-        if (M.carry) DCHK(hipMemcpyAsync(P.buf->p - M.carry, M.h_carry, M.carry, hipMemcpyHostToDevice, sp));
+        if (M.carry) DCHK(launch_bytes_from_host(P.buf->p - M.carry, M.h_carry, M.carry, sp));          // (not the copy engine: mf_ingest.h)
         std::shared_ptr<Batch> B(new Batch());
         B->ldev = S.ldev;
         B->text = P.buf->p - M.carry;
@@ -1688,7 +1688,7 @@ struct Ingest {
             n_lines = newlines + (open_line ? 1 : 0);
             DCHK(B->line_start.need(dev, n_lines + 2, false));
             DCHK(launch_line_starts(text, n, S.tile_base.p, B->line_start.p, sp));
-            if (open_line) { S.h_small[7] = n + 1; DCHK(hipMemcpyAsync(B->line_start.p + n_lines, S.h_small + 7, 8, hipMemcpyHostToDevice, sp)); }
+            if (open_line) { S.h_small[7] = n + 1; DCHK(launch_bytes_from_host(B->line_start.p + n_lines, S.h_small + 7, 8, sp)); }
             B->n_rec = n_lines / 4; B->n_lines = n_lines;
             DCHK(hipMemcpyAsync(S.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
@@ -1733,7 +1733,7 @@ struct Ingest {
         // sequence lengths, the piece's own base offsets
         DCHK(S.seq_len.need(dev, n_rec)); DCHK(S.minmax.need(dev, 2)); DCHK(S.offsets_tmp.need(dev, n_rec + 1)); DCHK(S.scan_tmp.need(dev, n_rec / 4096 + 4));
         S.h_small[8] = (uint64_t)0xFFFFFFFFull;                   // {~0u, 0u}
-        DCHK(hipMemcpyAsync(S.minmax.p, S.h_small + 8, 8, hipMemcpyHostToDevice, sp));
+        DCHK(launch_bytes_from_host(S.minmax.p, S.h_small + 8, 8, sp));
         DCHK(launch_seq_lens(text, Bt.line_start.p, n_rec, S.seq_len.p, S.minmax.p, sp));
         DCHK(launch_scan_u32(S.seq_len.p, n_rec, S.offsets_tmp.p, S.scan_tmp.p, sp));
         DCHK(hipMemcpyAsync(S.h_small + 3, S.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
@@ -1824,16 +1824,19 @@ struct Ingest {
             if (keep_n > S.h_bits_cap) { (void)hipHostFree(S.h_bits); S.h_bits = nullptr; S.h_bits_cap = 0; DCHK(hipHostMalloc((void **)&S.h_bits, (keep_n + keep_n / 2 + 1024) * 4, hipHostMallocDefault)); S.h_bits_cap = keep_n + keep_n / 2 + 1024; }
             memcpy(S.h_bits, idx.data(), keep_n * 4);
         }
-        DCHK(S.mask.need(dev, keep_n)); DCHK(S.out_len.need(dev, keep_n)); DCHK(S.out_off.need(dev, keep_n + 1)); DCHK(S.scan_tmp.need(dev, keep_n / 4096 + 4));
-        DCHK(hipMemcpyAsync(S.mask.p, S.h_bits, keep_n * 4, hipMemcpyHostToDevice, sp));
-        DCHK(launch_sel_lens(B.text, B.line_start.p, S.mask.p, keep_n, S.out_len.p, sp));
+        DCHK(S.out_len.need(dev, keep_n)); DCHK(S.out_off.need(dev, keep_n + 1)); DCHK(S.scan_tmp.need(dev, keep_n / 4096 + 4));
+        // The kernels read the list where it lies, in pinned host memory (a few thousand numbers a piece).  As a copy to the device it went
+        // through the engine that carries the uploads, BEHIND them: with a plain pair's twelve 256 MiB slabs queued that was 40-50 ms a time
+        // during which no text buffer came back and the link to the device ran dry (profiles/r05/g_pe_plain_trace_before.txt).
+        const uint32_t *list = S.h_bits;
+        DCHK(launch_sel_lens(B.text, B.line_start.p, list, keep_n, S.out_len.p, sp));
         DCHK(launch_scan_u32(S.out_len.p, keep_n, S.out_off.p, S.scan_tmp.p, sp));
         DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + keep_n, 8, hipMemcpyDeviceToHost, sp));
         DCHK(hipStreamSynchronize(sp));
         const uint64_t bytes = ((volatile uint64_t *)S.h_small)[6];
         if (bytes) {
             DCHK(S.d_out.need(dev, bytes));
-            DCHK(launch_sel_gather(B.text, B.line_start.p, S.mask.p, keep_n, S.out_off.p, S.d_out.p, sp));
+            DCHK(launch_sel_gather(B.text, B.line_start.p, list, keep_n, S.out_off.p, S.d_out.p, sp));
             if (bytes > S.h_out_cap) { if (S.h_out) (void)hipHostFree(S.h_out); S.h_out = nullptr; S.h_out_cap = 0; DCHK(hipHostMalloc((void **)&S.h_out, bytes + bytes / 2 + 65536, hipHostMallocDefault)); S.h_out_cap = bytes + bytes / 2 + 65536; }
             DCHK(hipMemcpyAsync(S.h_out, S.d_out.p, bytes, hipMemcpyDeviceToHost, sp));
             DCHK(hipStreamSynchronize(sp));
@@ -1948,7 +1951,7 @@ struct Ingest {
         DCHK(B.q_bad.need(dev, n, false)); DCHK(B.q_sl.need(dev, n, false)); DCHK(B.q_ql.need(dev, n, false)); DCHK(B.q_olen.need(dev, n, false)); DCHK(B.q_fl.need(dev, n, false));
         DCHK(S.minmax.need(dev, 2));
         S.h_small[8] = ~0ull;
-        DCHK(hipMemcpyAsync(S.minmax.p, S.h_small + 8, 8, hipMemcpyHostToDevice, sp));
+        DCHK(launch_bytes_from_host(S.minmax.p, S.h_small + 8, 8, sp));
         DCHK(launch_qual_scan(B.text, B.line_start.p, n, Q.P.start, Q.cap, Q.P.quality, Q.P.ns, B.q_bad.p, B.q_fl.p, B.q_sl.p, B.q_ql.p, B.q_olen.p, S.minmax.p, sp));
         if (mi == 0 && Q.P.dedup && !Q.P.trunc) { DCHK(B.q_hash.need(dev, n, false)); DCHK(launch_qual_hash(B.text, B.line_start.p, n, Q.P.start, B.q_sl.p, B.q_hash.p, sp)); }
         DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 4, hipMemcpyDeviceToHost, sp));
@@ -2045,8 +2048,8 @@ struct Ingest {
             if (Q.pe) {
                 DCHK(S.q_bad2.need(dev, n)); DCHK(S.q_fl2.need(dev, n));
                 Q.bad2.get(g0, n, (uint32_t *)S.h_stage); Q.fl2.get(g0, n, S.h_stage + n * 4);
-                DCHK(hipMemcpyAsync(S.q_bad2.p, S.h_stage, n * 4, hipMemcpyHostToDevice, sp));
-                DCHK(hipMemcpyAsync(S.q_fl2.p, S.h_stage + n * 4, n, hipMemcpyHostToDevice, sp));
+                DCHK(launch_bytes_from_host(S.q_bad2.p, S.h_stage, n * 4, sp));
+                DCHK(launch_bytes_from_host(S.q_fl2.p, S.h_stage + n * 4, n, sp));
             }
             DCHK(launch_qual_decide(n, Q.pe, Q.P.trunc, Q.P.limit, B.q_bad.p + r0, B.q_fl.p + r0, B.q_sl.p + r0, B.q_ql.p + r0, S.q_bad2.p, S.q_fl2.p, S.q_alive.p, sp));
             const bool dd = Q.P.dedup && !Q.P.trunc;
@@ -2109,7 +2112,7 @@ struct Ingest {
             DCHK(S.q_keep.need(dev, n)); DCHK(S.out_len.need(dev, n)); DCHK(S.out_off.need(dev, n + 1)); DCHK(S.scan_tmp.need(dev, n / 4096 + 4));
             DCHK(S.stage(n + 16));
             Q.keep.get(B.rec_base, n, S.h_stage);
-            DCHK(hipMemcpyAsync(S.q_keep.p, S.h_stage, n, hipMemcpyHostToDevice, sp));
+            DCHK(launch_bytes_from_host(S.q_keep.p, S.h_stage, n, sp));
             DCHK(launch_qual_keep(n, S.q_keep.p, nullptr, B.q_olen.p, nullptr, S.out_len.p, nullptr, sp));
             DCHK(launch_scan_u32(S.out_len.p, n, S.out_off.p, S.scan_tmp.p, sp));
             DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n, 8, hipMemcpyDeviceToHost, sp));

@@ -513,6 +513,26 @@ hipError_t launch_pack(const uint8_t *text, const uint64_t *line_start, const ui
     return hipGetLastError();
 }
 
+// A few bytes to a few megabytes from PINNED host memory to the device, read by a kernel over the link instead of queued on the copy engine:
+// the engine carries the uploads, and whatever small copy a consumer or a link step asks for in the same direction waits behind all of
+// them (a plain pair's twelve 256 MiB slabs: 40-50 ms for a 300-byte carry, profiles/r05/g_pe_plain_trace_before.txt).
+__global__ __launch_bounds__(256) void bytes_from_host_kernel(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256, t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src | n) & 15) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src); uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (uint64_t i = t; i < n / 16; i += stride) d4[i] = s4[i];
+    } else
+        for (uint64_t i = t; i < n; i += stride) dst[i] = src[i];
+}
+hipError_t launch_bytes_from_host(void *dst, const void *pinned_src, uint64_t n, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    const uint64_t items = ((((uintptr_t)dst | (uintptr_t)pinned_src | n) & 15) == 0) ? n / 16 : n;
+    hipLaunchKernelGGL(bytes_from_host_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (items + 255) / 256)), dim3(256), 0, st, (uint8_t *)dst, (const uint8_t *)pinned_src, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_add_base(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t st)
 {
     if (!n) return hipSuccess;

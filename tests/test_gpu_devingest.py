@@ -371,8 +371,11 @@ def test_slabs_dealt_to_several_devices(ol, bait_text, tmp_path, n_dev):
 
 
 @pytest.mark.parametrize("knobs", [dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_RESERVED_CUS="8", MF_UPLOAD_THREADS="1", MF_UPLOAD_STAGED="1"), dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_RESERVED_CUS="64", MF_UPLOAD_THREADS="16"),
-                                   dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_NO_CUMASK="1"), dict(MF_GZDEV_LARGE_MB="0"), dict(MF_UPLOAD_STAGED="1")],
-                         ids=["masked-reserve8-upload1", "masked-reserve64-upload16", "masked-set-without-masks", "masked-set", "uploads-through-staging-buffers"])
+                                   dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_NO_CUMASK="1"), dict(MF_GZDEV_LARGE_MB="0"), dict(MF_UPLOAD_STAGED="1"),
+                                   dict(MF_GZDEV_LARGE_MB="0", MF_GZDEV_RESOLVE_STREAM="1", MF_GZDEV_DEC_STREAMS="2", MF_GZDEV_UPLOAD_BUFS="4", MF_GZDEV_UPLOAD_PIECE_MB="1"),
+                                   dict(MF_GZDEV_RESOLVE_STREAM="1", MF_GZDEV_DEC_STREAMS="1", MF_UPLOAD_REGISTER_MAX_MB="0")],
+                         ids=["masked-reserve8-upload1", "masked-reserve64-upload16", "masked-set-without-masks", "masked-set", "uploads-through-staging-buffers",
+                              "masked-two-post-streams-2-decode-streams-4-upload-buffers", "plain-two-post-streams-1-decode-stream-nothing-registered"])
 def test_stream_and_upload_knobs(knobs):
     """The CU masks of the decoder's streams and the uploader's thread count are read when a process makes its first stream set, so the
     variants run in child processes: gzip levels x seams, several members, flush points -- same bytes as the oracle whatever the knobs say.
