@@ -1152,7 +1152,7 @@ private:
             DCHK(hipEventRecord(S.ev0, st));
             DCHK(launch_gz_decode(L.ring.p, ring_, size_, S.limit, base_byte_, chunk_, S.lo, S.hi - S.lo, 0, (uint64_t)base_byte_ * 8, S.sym.p, S.cap, L.d_chunks.p, S.lst.p, st));
             DCHK(hipEventRecord(S.ev1, st));
-            DCHK(hipMemcpyAsync(h_chunks_ + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), hipMemcpyDeviceToHost, st));
+            DCHK(launch_bytes_to_host(h_chunks_ + S.lo, L.d_chunks.p + S.lo, (S.hi - S.lo) * sizeof(GzChunk), st));
             DCHK(hipEventRecord(S.ev, st));
             if (!first_launched_) { first_launched_ = true; cold_mark("producer: first decode kernel launched"); }
             S.launched = true;
@@ -1289,7 +1289,7 @@ private:
         if (np > C.h_cap) { if (C.h) (void)hipHostFree(C.h); C.h = nullptr; C.h_cap = 0; DCHK(hipHostMalloc((void **)&C.h, (np + np / 2 + 64) * 4, hipHostMallocDefault)); C.h_cap = np + np / 2 + 64; }
         if (!C.ev) DCHK(hipEventCreateWithFlags(&C.ev, hipEventDisableTiming));
         DCHK(launch_gz_crc(cur_buf_->p + (from - T0), n, C.d.p, st));
-        DCHK(hipMemcpyAsync(C.h, C.d.p, np * 4, hipMemcpyDeviceToHost, st));
+        DCHK(launch_bytes_to_host(C.h, C.d.p, np * 4, st));
         DCHK(hipEventRecord(C.ev, st));
         C.n = n; C.out = true; crc_done_ = to;
         crc_q_.emplace_back((uint32_t)(&L - lanes_.data()), (uint32_t)(&C - L.crc));
@@ -1679,8 +1679,8 @@ struct Ingest {
             DCHK(launch_count_newlines(text, n, S.tile_cnt.p, sp));
             DCHK(launch_scan_u32(S.tile_cnt.p, tiles, S.tile_base.p, S.scan_tmp.p, sp));
             hs[1] = 0;
-            DCHK(hipMemcpyAsync(S.h_small + 0, S.tile_base.p + tiles, 8, hipMemcpyDeviceToHost, sp));
-            DCHK(hipMemcpyAsync(S.h_small + 1, text + n - 1, 1, hipMemcpyDeviceToHost, sp));
+            DCHK(launch_bytes_to_host(S.h_small + 0, S.tile_base.p + tiles, 8, sp));
+            DCHK(launch_bytes_to_host(S.h_small + 1, text + n - 1, 1, sp));
             DCHK(hipStreamSynchronize(sp));
             if (first_piece) cold_mark("consumer: first piece is text, its newlines counted");
             const uint64_t newlines = hs[0]; const uint8_t last_byte = (uint8_t)hs[1];
@@ -1690,7 +1690,7 @@ struct Ingest {
             DCHK(launch_line_starts(text, n, S.tile_base.p, B->line_start.p, sp));
             if (open_line) { S.h_small[7] = n + 1; DCHK(launch_bytes_from_host(B->line_start.p + n_lines, S.h_small + 7, 8, sp)); }
             B->n_rec = n_lines / 4; B->n_lines = n_lines;
-            DCHK(hipMemcpyAsync(S.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(launch_bytes_to_host(S.h_small + 2, B->line_start.p + 4 * B->n_rec, 8, sp));
             DCHK(hipStreamSynchronize(sp));
         }
         used = hs[2];
@@ -1703,7 +1703,7 @@ struct Ingest {
                 if (M.h_carry) (void)hipHostFree(M.h_carry);
                 M.h_carry = q; M.h_carry_cap = carry + carry / 2 + 4096;
             }
-            DCHK(hipMemcpyAsync(M.h_carry, text + used, carry, hipMemcpyDeviceToHost, sp));
+            DCHK(launch_bytes_to_host(M.h_carry, text + used, carry, sp));
             DCHK(hipStreamSynchronize(sp));
         }
         M.carry = carry;
@@ -1736,8 +1736,8 @@ struct Ingest {
         DCHK(launch_bytes_from_host(S.minmax.p, S.h_small + 8, 8, sp));
         DCHK(launch_seq_lens(text, Bt.line_start.p, n_rec, S.seq_len.p, S.minmax.p, sp));
         DCHK(launch_scan_u32(S.seq_len.p, n_rec, S.offsets_tmp.p, S.scan_tmp.p, sp));
-        DCHK(hipMemcpyAsync(S.h_small + 3, S.offsets_tmp.p + n_rec, 8, hipMemcpyDeviceToHost, sp));
-        DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 8, hipMemcpyDeviceToHost, sp));
+        DCHK(launch_bytes_to_host(S.h_small + 3, S.offsets_tmp.p + n_rec, 8, sp));
+        DCHK(launch_bytes_to_host(S.h_small + 4, S.minmax.p, 8, sp));
         DCHK(hipStreamSynchronize(sp));
         const uint64_t nb = hs[3]; const uint32_t mm[2] = {(uint32_t)hs[4], (uint32_t)(hs[4] >> 32)};
         const uint32_t uniform = (mm[0] == mm[1] && mm[0] > 0) ? mm[0] : 0;
@@ -1765,7 +1765,7 @@ struct Ingest {
             DCHK(S.inv_cnt.need(dev, pb)); DCHK(S.inv_base.need(dev, pb + 1)); DCHK(S.scan_tmp.need(dev, pb / 4096 + 4));
             DCHK(launch_pack(text, Bt.line_start.p, uniform ? nullptr : S.offsets_tmp.p, uniform, n_rec, nb, 0, R->d_words, S.inv_cnt.p, nullptr, nullptr, sp));
             DCHK(launch_scan_u32(S.inv_cnt.p, pb, S.inv_base.p, S.scan_tmp.p, sp));
-            DCHK(hipMemcpyAsync(S.h_small + 5, S.inv_base.p + pb, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(launch_bytes_to_host(S.h_small + 5, S.inv_base.p + pb, 8, sp));
             DCHK(hipStreamSynchronize(sp));
             inv = hs[5];
             if (inv) {
@@ -1831,7 +1831,7 @@ struct Ingest {
         const uint32_t *list = S.h_bits;
         DCHK(launch_sel_lens(B.text, B.line_start.p, list, keep_n, S.out_len.p, sp));
         DCHK(launch_scan_u32(S.out_len.p, keep_n, S.out_off.p, S.scan_tmp.p, sp));
-        DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + keep_n, 8, hipMemcpyDeviceToHost, sp));
+        DCHK(launch_bytes_to_host(S.h_small + 6, S.out_off.p + keep_n, 8, sp));
         DCHK(hipStreamSynchronize(sp));
         const uint64_t bytes = ((volatile uint64_t *)S.h_small)[6];
         if (bytes) {
@@ -1954,7 +1954,7 @@ struct Ingest {
         DCHK(launch_bytes_from_host(S.minmax.p, S.h_small + 8, 8, sp));
         DCHK(launch_qual_scan(B.text, B.line_start.p, n, Q.P.start, Q.cap, Q.P.quality, Q.P.ns, B.q_bad.p, B.q_fl.p, B.q_sl.p, B.q_ql.p, B.q_olen.p, S.minmax.p, sp));
         if (mi == 0 && Q.P.dedup && !Q.P.trunc) { DCHK(B.q_hash.need(dev, n, false)); DCHK(launch_qual_hash(B.text, B.line_start.p, n, Q.P.start, B.q_sl.p, B.q_hash.p, sp)); }
-        DCHK(hipMemcpyAsync(S.h_small + 4, S.minmax.p, 4, hipMemcpyDeviceToHost, sp));
+        DCHK(launch_bytes_to_host(S.h_small + 4, S.minmax.p, 4, sp));
         uint32_t *h_bad = nullptr; uint8_t *h_fl = nullptr;
         if (mi == 1) {
             DCHK(S.stage(n * 5 + 16));
@@ -2082,8 +2082,8 @@ struct Ingest {
             }
             if (n) {
                 DCHK(launch_scan_u32(S.out_len.p, n, S.out_off.p, S.scan_tmp.p, sp));
-                DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n, 8, hipMemcpyDeviceToHost, sp));
-                DCHK(hipMemcpyAsync(S.h_small + 3, Q.dd_small.p + 1, 16, hipMemcpyDeviceToHost, sp));       // keys of the set, kept of the piece
+                DCHK(launch_bytes_to_host(S.h_small + 6, S.out_off.p + n, 8, sp));
+                DCHK(launch_bytes_to_host(S.h_small + 3, Q.dd_small.p + 1, 16, sp));       // keys of the set, kept of the piece
                 if (Q.pe && !Q.P.trim) DCHK(hipMemcpyAsync(h_keep, S.q_keep.p, n, hipMemcpyDeviceToHost, sp));
                 DCHK(hipStreamSynchronize(sp));
                 bytes = hs[6]; if (dd) Q.dd_n = hs[3];
@@ -2115,7 +2115,7 @@ struct Ingest {
             DCHK(launch_bytes_from_host(S.q_keep.p, S.h_stage, n, sp));
             DCHK(launch_qual_keep(n, S.q_keep.p, nullptr, B.q_olen.p, nullptr, S.out_len.p, nullptr, sp));
             DCHK(launch_scan_u32(S.out_len.p, n, S.out_off.p, S.scan_tmp.p, sp));
-            DCHK(hipMemcpyAsync(S.h_small + 6, S.out_off.p + n, 8, hipMemcpyDeviceToHost, sp));
+            DCHK(launch_bytes_to_host(S.h_small + 6, S.out_off.p + n, 8, sp));
             DCHK(hipStreamSynchronize(sp));
             bytes = ((volatile uint64_t *)S.h_small)[6];
         }

@@ -34,6 +34,7 @@ uint64_t pack_blocks(uint64_t total_bases, uint64_t base);
 hipError_t launch_pack(const uint8_t *text, const uint64_t *line_start, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_rec,
                        uint64_t total_bases, uint64_t base, uint32_t *words, uint32_t *inv_cnt, const uint64_t *inv_base, uint64_t *npos, hipStream_t st);
 hipError_t launch_bytes_from_host(void *dst, const void *pinned_src, uint64_t n, hipStream_t st);      // dst[0..n) = pinned host memory, read by a kernel (not the copy engine: that one carries the uploads)
+hipError_t launch_bytes_to_host(void *pinned_dst, const void *src, uint64_t n, hipStream_t st);        // pinned host memory [0..n) = src, written by a kernel; read it after waiting for the stream
 hipError_t launch_add_base(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t st);       // dst[i] = src[i] + base
 // pass bits of one batch (bit i = record i of the batch) into the file-wide bitmap at record index rec_base
 hipError_t launch_store_bits(const uint32_t *batch_bits, uint64_t n_rec, uint32_t *file_bits, uint64_t rec_base, hipStream_t st);

@@ -528,8 +528,22 @@ __global__ __launch_bounds__(256) void bytes_from_host_kernel(uint8_t *dst, cons
 hipError_t launch_bytes_from_host(void *dst, const void *pinned_src, uint64_t n, hipStream_t st)
 {
     if (!n) return hipSuccess;
+    static const bool on_engine = getenv("MF_SMALL_H2D_ON_ENGINE") != nullptr;          // (A/B runs)
+    if (on_engine) return hipMemcpyAsync(dst, pinned_src, n, hipMemcpyHostToDevice, st);
     const uint64_t items = ((((uintptr_t)dst | (uintptr_t)pinned_src | n) & 15) == 0) ? n / 16 : n;
     hipLaunchKernelGGL(bytes_from_host_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (items + 255) / 256)), dim3(256), 0, st, (uint8_t *)dst, (const uint8_t *)pinned_src, n);
+    return hipGetLastError();
+}
+
+// ... and the other way: a few bytes to a few hundred kilobytes written by a kernel into pinned (coherent) host memory; the host reads them
+// after it has waited for the stream.  The quality filter's output goes down through the copy engine a gigabyte at a time.
+static const bool g_small_d2h_on_engine = getenv("MF_SMALL_D2H_ON_ENGINE") != nullptr;          // (A/B runs)
+hipError_t launch_bytes_to_host(void *pinned_dst, const void *src, uint64_t n, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    if (g_small_d2h_on_engine) return hipMemcpyAsync(pinned_dst, src, n, hipMemcpyDeviceToHost, st);
+    const uint64_t items = ((((uintptr_t)pinned_dst | (uintptr_t)src | n) & 15) == 0) ? n / 16 : n;
+    hipLaunchKernelGGL(bytes_from_host_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (items + 255) / 256)), dim3(256), 0, st, (uint8_t *)pinned_dst, (const uint8_t *)src, n);
     return hipGetLastError();
 }
 

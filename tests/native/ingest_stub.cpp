@@ -172,6 +172,7 @@ uint32_t gz_crc_finish(const uint32_t *piece, uint64_t n)
 
 // ------------------------------------------------------------------------------------------------ mf_ingest.h
 hipError_t launch_bytes_from_host(void *dst, const void *src, uint64_t n, hipStream_t st) { stub_enqueue(st, [=] { if (n) memmove(dst, src, n); }); return hipSuccess; }
+hipError_t launch_bytes_to_host(void *dst, const void *src, uint64_t n, hipStream_t st) { stub_enqueue(st, [=] { if (n) memmove(dst, src, n); }); return hipSuccess; }
 hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *, hipStream_t st)
 {
     stub_enqueue(st, [=] { uint64_t s = 0; for (uint64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; });
