@@ -37,3 +37,21 @@ def test_make_fastq_blocks_and_mates(tmp_path):
     assert len(lines) == 4 * 5000 + 1 and lines[-1] == b"" and not os.path.exists(base + "_2.fq")
     assert all(lines[4 * i].startswith(b"@") and lines[4 * i + 2].startswith(b"+") and len(lines[4 * i + 1]) == len(lines[4 * i + 3]) == 150 for i in range(0, 5000, 97))
     assert os.path.getsize(base + ".bait.fa") > 10000
+
+
+def test_scripts_the_documents_name_exist_and_parse():
+    """Every tools/ script DESIGN.md, README.md, INTEGRATION.md and round 5's part of profiles/README.md name is in the tree (records must be
+    reproducible from the scripts that made them), and every shell script under tools/ parses."""
+    import re
+    named = set()
+    for doc, start in (("DESIGN.md", None), ("README.md", None), ("INTEGRATION.md", None), (os.path.join("profiles", "README.md"), "`r05/`")):
+        text = open(os.path.join(ROOT, doc)).read()
+        if start:
+            text = text[text.index(start):]
+        named |= set(re.findall(r"tools/[A-Za-z0-9_]+\.(?:sh|py|cpp)", text))
+    missing = sorted(n for n in named if not os.path.exists(os.path.join(ROOT, n)))
+    assert not missing, missing
+    assert len(named) > 10
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        if f.endswith(".sh"):
+            assert subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", f)]).returncode == 0, f
