@@ -63,6 +63,10 @@ namespace {
 
 #define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + " failed: " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? MF_E_NOMEM : MF_E_HIP; } } while (0)
 
+// Pinned host memory that KERNELS read or write (launch_bytes_from_host / _to_host, the survivors' list): coherent (fine-grained), so that
+// nothing of it sits in the device's L2 from one kernel to the next while the host rewrites it.  hipHostMallocDefault is coherent by itself;
+// hipHostMallocPortable alone is not (it follows HIP_HOST_COHERENT, 0 by default).  Staging buffers only the copy engine reads stay as they were.
+constexpr unsigned PINNED_FOR_KERNELS = hipHostMallocPortable | hipHostMallocCoherent;
 uint64_t env_u64(const char *name, uint64_t dflt) { const char *v = getenv(name); return v && *v ? strtoull(v, nullptr, 10) : dflt; }
 static const bool g_trace = getenv("MF_DEVINGEST_TRACE") != nullptr;
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -823,9 +827,9 @@ public:
             }
         }
         const double ts0 = now_s();
-        DCHK(hipHostMalloc((void **)&h_chunks_, (size_t)n_chunks_ * sizeof(GzChunk) + 64, hipHostMallocPortable));
+        DCHK(hipHostMalloc((void **)&h_chunks_, (size_t)n_chunks_ * sizeof(GzChunk) + 64, PINNED_FOR_KERNELS));
         memset(h_chunks_, 0, (size_t)n_chunks_ * sizeof(GzChunk));
-        DCHK(hipHostMalloc((void **)&h_win_, GZ_WINDOW, hipHostMallocPortable));
+        DCHK(hipHostMalloc((void **)&h_win_, GZ_WINDOW, PINNED_FOR_KERNELS));
         memset(h_win_, 0, GZ_WINDOW);
         link_ = GzLinkState(); link_.cur_bit = (uint64_t)base_byte_ * 8;
         lanes_.resize(nl);
@@ -843,7 +847,7 @@ public:
             DCHK(L.ring.need(L.dev, ring_ + 4096, false));
             DCHK(L.d_chunks.need(L.dev, n_chunks_, false)); DCHK(L.d_window.need(L.dev, GZ_WINDOW, false));
             DCHK(L.d_acc.need(L.dev, (size_t)LIST_SLOTS * (cps_ + 1), false)); DCHK(L.d_acc_off.need(L.dev, (size_t)LIST_SLOTS * (cps_ + 1), false)); DCHK(L.d_link.need(L.dev, gz_link_scratch_bytes(cps_), false));
-            DCHK(hipHostMalloc((void **)&L.h_list, (size_t)LIST_SLOTS * (cps_ + 1) * 12, hipHostMallocPortable));
+            DCHK(hipHostMalloc((void **)&L.h_list, (size_t)LIST_SLOTS * (cps_ + 1) * 12, PINNED_FOR_KERNELS));
             L.ev_list.assign(LIST_SLOTS, nullptr);
             ul[l].dev = L.dev; ul[l].ring = L.ring.p; ul[l].ds = L.ds;
         }
@@ -1699,7 +1703,7 @@ struct Ingest {
         if (carry) {
             if (carry > M.h_carry_cap) {
                 uint8_t *q = nullptr;
-                DCHK(hipHostMalloc((void **)&q, carry + carry / 2 + 4096, hipHostMallocPortable));
+                DCHK(hipHostMalloc((void **)&q, carry + carry / 2 + 4096, PINNED_FOR_KERNELS));
                 if (M.h_carry) (void)hipHostFree(M.h_carry);
                 M.h_carry = q; M.h_carry_cap = carry + carry / 2 + 4096;
             }

@@ -17,7 +17,7 @@ enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, 
 struct StubStream; typedef StubStream *hipStream_t;
 struct StubEvent; typedef StubEvent *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostRegisterPortable = 1, hipHostRegisterReadOnly = 8 };
+enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostMallocCoherent = 0x40000000, hipHostRegisterPortable = 1, hipHostRegisterReadOnly = 8 };
 struct hipDeviceProp_t { int multiProcessorCount; char gcnArchName[256]; char name[256]; };
 
 const char *hipGetErrorString(hipError_t e);
