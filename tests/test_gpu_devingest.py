@@ -543,3 +543,44 @@ def test_the_clis_run_cold(mf, ol, bait_text, tmp_path, monkeypatch):
         assert open(tmp_path / "o.fq", "rb").read() == open(tmp_path / "r.fq", "rb").read()
         err = p.stderr.decode()
         assert "prefetch: code objects of the decoder and the line kernels loaded" in err and "device ingest: first piece of text handed over" in err
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MF_INGEST_FUZZ_SEEDS", "10"))))
+def test_random_files_under_random_knobs(mf, ol, bait_text, tmp_path, monkeypatch, seed):
+    """Random inputs (single-end or paired, 1-3 gzip members or plain text, level 0-9, CRLF or not, mates of different length, an unterminated
+    last line) under random sizes of everything that puts a seam somewhere -- chunk, slab, ring, margin, text piece, text buffers, consumers,
+    the uploader's buffers and pieces, the bodies and CRC on their own stream or not, one or several decode streams: the oracle's bytes and
+    counts every time (the seeds are fixed, the message carries the configuration)."""
+    rng = random.Random(9000 + seed)
+    knobs = {
+        "MF_GZDEV_CHUNK_BYTES": str(rng.choice([1024, 4096, 9000, 32768])), "MF_GZDEV_SLAB_CHUNKS": str(rng.choice([1, 3, 7, 64])),
+        "MF_GZDEV_RING_BYTES": str(rng.choice([65536, 262144, 1 << 22])), "MF_GZDEV_MARGIN": str(rng.choice([1024, 8192, 1 << 20])),
+        "MF_GZDEV_TEXT_PIECE": str(rng.choice([20000, 300000, 1 << 30])), "MF_INGEST_TEXT_BUFS": str(rng.choice([2, 3, 6])),
+        "MF_INGEST_CONSUMERS": str(rng.choice([1, 2, 3, 5])), "MF_INGEST_SLAB_BYTES": str(rng.choice([50001, 400000, 1 << 28])),
+        "MF_GZDEV_UPLOAD_BUFS": str(rng.choice([2, 3, 4])), "MF_GZDEV_UPLOAD_PIECE_MB": str(rng.choice([1, 32])),
+        "MF_GZDEV_RESOLVE_STREAM": rng.choice(["0", "1"]), "MF_GZDEV_DEC_STREAMS": str(rng.choice([1, 2, 4])),
+        "MF_GZDEV_SLABS_IN_FLIGHT": str(rng.choice([1, 2, 5])), "MF_INGEST_CARRY_ROOM": rng.choice(["0", "1048576"]),
+    }
+    if rng.random() < 0.3:
+        knobs["MF_UPLOAD_STAGED"] = "1"
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    ks = mf.KmerSet.from_fasta(bait, 31)
+    paired, plain = rng.random() < 0.5, rng.random() < 0.25
+    level, members, crlf = rng.choice([0, 1, 6, 9]), rng.choice([1, 1, 2, 3]), rng.random() < 0.2
+    n1 = rng.randint(1, 6000)
+    n2 = n1 + rng.choice([0, 0, 0, 5, -1 if n1 > 1 else 0])
+    names = []
+    for m, n in ((1, n1), (2, n2)) if paired else ((1, n1),):
+        t = fastq_text(make_reads(bait_text, n, seed=1000 * seed + m), "f%d" % m, crlf=crlf, last_newline=rng.random() < 0.8, seed=seed)
+        p = str(tmp_path / ("r_%d.fq" % m)) + ("" if plain else ".gz")
+        open(p, "wb").write(t if plain else gz_bytes(t, level, members))
+        names.append(p)
+    cfg = dict(seed=seed, paired=paired, plain=plain, level=level, members=members, crlf=crlf, n=(n1, n2), **knobs)
+    try:
+        run_both(mf, ol, bait, ks, names[0], names[1] if paired else None, tmp_path, thr=rng.choice([1, 1, 2]), pair_mode=rng.choice([0, 1]) if paired else 0)
+    except AssertionError as e:
+        raise AssertionError("%s under %r" % (e, cfg))
+    assert mf.last_ingest_stats()["path"] == 1, cfg
