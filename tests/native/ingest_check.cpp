@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <initializer_list>
 #include <string>
 #include <sys/stat.h>
 #include <thread>
@@ -182,6 +183,20 @@ static void tiny_knobs(bool carry_room)
     setenv("MF_INGEST_TEXT_BUFS", "2", 1); setenv("MF_GZDEV_TEXT_PIECE", "20000", 1); setenv("MF_INGEST_SLAB_BYTES", "50001", 1);
     setenv("MF_INGEST_CARRY_ROOM", carry_room ? "1048576" : "0", 1);
     setenv("MF_QUAL_OUT_CHUNK", "4096", 1); setenv("MF_QUAL_OUT_CHUNKS", "6", 1); setenv("MF_DEDUP_LOG2_SLOTS", "4", 1);
+    // INGEST_CHECK_KNOB_SEED: other sizes of everything, picked by a small generator from the seed (a case's own settings behind this call stay)
+    if (const char *sd = getenv("INGEST_CHECK_KNOB_SEED")) {
+        uint64_t x = 0x9E3779B97F4A7C15ull * (uint64_t)(atoi(sd) + 1);
+        auto pick = [&](std::initializer_list<const char *> v) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return *(v.begin() + (size_t)(x % v.size())); };
+        setenv("MF_GZDEV_CHUNK_BYTES", pick({"1024", "4096", "9000", "32768"}), 1); setenv("MF_GZDEV_SLAB_CHUNKS", pick({"1", "3", "7", "64"}), 1);
+        setenv("MF_GZDEV_RING_BYTES", pick({"65536", "262144", "4194304"}), 1); setenv("MF_GZDEV_MARGIN", pick({"2048", "8192", "1048576"}), 1);
+        setenv("MF_INGEST_TEXT_BUFS", pick({"2", "3", "6"}), 1); setenv("MF_GZDEV_TEXT_PIECE", pick({"20000", "300000", "1073741824"}), 1);
+        setenv("MF_INGEST_SLAB_BYTES", pick({"50001", "400000", "268435456"}), 1); setenv("MF_INGEST_CONSUMERS", pick({"1", "2", "3", "5"}), 1);
+        setenv("MF_GZDEV_UPLOAD_BUFS", pick({"2", "3", "4"}), 1); setenv("MF_GZDEV_RESOLVE_STREAM", pick({"0", "1"}), 1);
+        setenv("MF_GZDEV_DEC_STREAMS", pick({"1", "2", "4"}), 1); setenv("MF_GZDEV_SLABS_IN_FLIGHT", pick({"1", "2", "5"}), 1);
+        fprintf(stderr, "knobs of seed %s: chunk %s slab %s ring %s margin %s text bufs %s piece %s plain slab %s consumers %s upload bufs %s two post streams %s decode streams %s slabs in flight %s\n", sd,
+                getenv("MF_GZDEV_CHUNK_BYTES"), getenv("MF_GZDEV_SLAB_CHUNKS"), getenv("MF_GZDEV_RING_BYTES"), getenv("MF_GZDEV_MARGIN"), getenv("MF_INGEST_TEXT_BUFS"), getenv("MF_GZDEV_TEXT_PIECE"),
+                getenv("MF_INGEST_SLAB_BYTES"), getenv("MF_INGEST_CONSUMERS"), getenv("MF_GZDEV_UPLOAD_BUFS"), getenv("MF_GZDEV_RESOLVE_STREAM"), getenv("MF_GZDEV_DEC_STREAMS"), getenv("MF_GZDEV_SLABS_IN_FLIGHT"));
+    }
 }
 
 int main(int argc, char **argv)

@@ -84,6 +84,16 @@ def test_bodies_and_crc_on_a_stream_of_their_own(exes, tmp_path, case):
     assert r.returncode == 0 and "all checks of" in r.stderr, r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("case", ["bait_pe_gz", "bait_two_devices", "qual_pe"])
+def test_other_sizes_of_everything_under_tsan(exes, tmp_path, case, seed):
+    """The cases run with one set of tiny sizes; INGEST_CHECK_KNOB_SEED picks others (chunk, slab, ring, margin, text piece and buffers, consumers,
+    upload buffers, one or two post streams, decode streams, slabs in flight) from a small generator: same bytes, nothing for TSan."""
+    r = _run(exes["tsan"], case, tmp_path, 1200, 240, INGEST_CHECK_KNOB_SEED=str(seed))
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[:6000]
+    assert r.returncode == 0 and "all checks of" in r.stderr, r.stderr[-3000:]
+
+
 def test_the_check_hangs_without_partial_decisions(exes, tmp_path):
     """Round 4 fixed a hang of the paired quality filter: a piece of mate 1 waited for decisions that waited for text buffers the other mate
     held (mf_devingest.cpp, q_progress: `ready`).  With that rule compiled out the check must hang (its watchdog exits with 3) -- i.e. this
