@@ -297,6 +297,8 @@ def prepare_inputs(a, tmp, solo=True):
                 kept = int(subprocess.check_output([bait_cli, "bait", "--bait", bait, "--fq1", fq, "--out1", out], env=env, stderr=subprocess.DEVNULL, timeout=300).decode())
                 secs.append(round(time.perf_counter() - t0, 4))
             return {"seconds_each": secs, "seconds": min(secs), "kept": kept}
+        for name, out, proc in real:          # (the compressors started above have had the time of the steps in between; nothing of ours runs beside the cold calls)
+            proc.wait()
         try:
             if "small" in files:
                 files["small_cli"] = cold(os.path.join(tmp, "s.bait.fa"), os.path.join(tmp, "s_1.fq.gz"), os.path.join(tmp, "s_cli.fq"), 3)
@@ -338,7 +340,7 @@ def prepare_inputs(a, tmp, solo=True):
             run([sys.executable, "-c", G20_GENERATOR, os.path.join(tmp, "g20.fa")])
             files["g20"] = os.path.join(tmp, "g20.fa")
         for name, out, proc in real:
-            if proc.wait() == 0:
+            if proc.returncode == 0:
                 files.setdefault("real", {"plain": os.path.join(tmp, "r_1.fq"), "bait": os.path.join(tmp, "r.bait.fa"), "gz": {}})["gz"][name] = out
     except Exception as e:
         files["error"] = str(e)[:200]
