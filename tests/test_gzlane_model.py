@@ -50,3 +50,14 @@ def test_lane_walk_equals_zlib(model, tmp_path, kind, text):
     for span_bits, cells in (("768", "1"), ("768", "0"), ("1024", "1"), ("2048", "1"), ("256", "1")):          # (768: the kernel's span since round 5)          # cells = 1: the kernel's expansion rounds restated, 0: a plain LZ77 copy
         p = subprocess.run([model, path, span_bits, "6", cells], capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout.decode().strip().endswith("PASS"), (kind, text, span_bits, cells, p.stdout[-600:], p.stderr[-600:])
+
+
+def test_link_walk_against_a_model(tmp_path):
+    """gz_link_walk (mf_gzdev.h) -- which chunks of a slab are accepted, where their text goes, where the walk stops -- is host code since round 5
+    (the device does the windows).  tests/native/linkwalk_check.cpp holds it to an obviously right model on 20 000 random descriptor sequences
+    (honest chunks, chunks that found nothing, false starts inside accepted data, gaps, members' ends), walked a slab at a time; under ASan + UBSan."""
+    exe = str(tmp_path / "linkwalk_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "tests", "native", "hipstub"),
+                           "-I", os.path.join(ROOT, "mitoflex_amd", "csrc"), os.path.join(ROOT, "tests", "native", "linkwalk_check.cpp"), "-o", exe])
+    r = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "equal to the model" in r.stdout, r.stderr[-2000:]
