@@ -98,15 +98,23 @@ int get_ctx(int device, DevCtx **out, int lane)
 // a file-level call -- one pass per piece -- through the reference's process-per-call boundary must not pay for three of them per context.
 static int ensure_pipeline_streams(DevCtx *c)
 {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (c->stream2) return MF_OK;
+    // (made outside g_ctx_mu -- every other thread's get_ctx() would wait 50-100 ms behind them -- and published under it; a thread
+    // that loses the race, or a creation that fails half way, destroys what it has made)
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); if (c->stream2) return MF_OK; }
     int lo = 0, hi = 0;
     hipStream_t s2 = nullptr, s3 = nullptr, s4 = nullptr;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, hi));          // the short, latency-bound finish kernels that run under the next screen kernel: highest priority
-    HIPCHK(hipStreamCreateWithPriority(&s4, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithFlags(&s3, hipStreamNonBlocking));
-    c->stream3 = s3; c->stream4 = s4; c->stream2 = s2;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, hi);          // the short, latency-bound finish kernels that run under the next screen kernel: highest priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s4, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s3, hipStreamNonBlocking);
+    bool publish = e == hipSuccess;
+    if (publish) {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (c->stream2) publish = false;
+        else { c->stream3 = s3; c->stream4 = s4; c->stream2 = s2; }
+    }
+    if (!publish) { for (hipStream_t s : {s2, s4, s3}) if (s) (void)hipStreamDestroy(s); }
+    if (e != hipSuccess) return fail(MF_E_HIP, "creating the streams of a pipelined call failed: %s", hipGetErrorString(e));
     return MF_OK;
 }
 
@@ -114,6 +122,7 @@ static int ensure_pipeline_streams(DevCtx *c)
 struct DevTables {
     uint64_t *keys = nullptr;
     uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr, *kbloom_co = nullptr, *plut = nullptr;    // kbloom_co: own allocation only when it differs from kbloom
+    uint32_t *front2 = nullptr, *front3 = nullptr;      // bait-sized fronts of the large-bait screen (front_mode 1, 2)
     KmerSetView view{};
     uint64_t n_keys = 0, n_smers = 0;
 };
@@ -127,6 +136,7 @@ struct mf_kmerset {
     uint64_t n_windows = 0, slots = 0;
     ScreenGeom geom{0, 0};
     uint32_t bloom_log2w = 0, stage2_log2w = 0, stab_slots = 0, kb_log2w = 0;
+    uint32_t front_mode = 0, f2_log2b = 0, f3_log2b = 0;
     size_t screen_words() const { return ((size_t)1 << bloom_log2w) + ((size_t)1 << stage2_log2w); }
     std::mutex mu;
     std::map<int, DevTables> dev;
@@ -141,7 +151,7 @@ struct DevScratch {
 // tables under construction: released unless the build commits them
 struct TablesGuard {
     DevTables *t;
-    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->kbloom_co); hipFree(t->plut); } }
+    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->kbloom_co); hipFree(t->plut); hipFree(t->front2); hipFree(t->front3); } }
 };
 // events of one timing loop
 struct EventList {
@@ -164,6 +174,61 @@ static uint32_t env_u32(const char *name, uint32_t dflt)
     const char *v = getenv(name);
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
+
+// ----------------------------------------------------------------- options
+// How a screened pass is run.  Default: screen_kernel, then finish_kernel when the threshold is 1 and no hit counts are wanted
+// (mark_kernel + exact_kernel otherwise).  MF_PASS=split: always screen, mark, exact.  MF_PASS=serial: screen + finish
+// without overlapping consecutive passes (for comparison).
+// The switches that select WHICH KERNELS a pass runs live in one options block.  A production process never reads them from the
+// environment: they are set through mf_set_option (the CLI's --option name=value), or -- for the test suite, bench.py and the profiling
+// scripts -- taken from the MF_* variables when MF_ENV_KNOBS=1 says so.  Every variant is parity-tested (tests/test_gpu_parity.py).
+struct PassOptions {
+    std::atomic<int> pass{0};             // 0 default (screen + finish, pipelined) | 1 split | 2 serial            "pass"            MF_PASS
+    std::atomic<int> adapt{1};            // switch the pass kind from the previous call's tallies                   "adapt"           MF_ADAPT
+    std::atomic<int> finish_streams{0};   // 0 by tallies | 1 | 2                                                    "finish_streams"  MF_FINISH_STREAMS
+    std::atomic<int> screen_streams{2};   // consecutive screens on one stream or on two in turn                     "screen_streams"  MF_SCREEN_STREAMS
+    std::atomic<int> split_pipe{1};       // the candidate-bitmap pass pipelined                                     "split_pipe"      MF_SPLIT_PIPE
+    std::atomic<int> exact_co{0};         // the co-resident exact kernel behind every screen (tests)                "exact_co"        MF_EXACT_CO
+    // the large-bait screen (read when a k-mer set is BUILT; tests force every form on small baits)
+    std::atomic<int> front{-1};           // -1 by the bait's size | 0 LDS table only | 1 LDS table + front2 | 2 front2 (+ front3) only   "front"   MF_FRONT
+    std::atomic<int> front2_log2b{0};     // 0 by the bait's size | log2 of front2's 128-bit blocks (6..18)                         "front2_log2b"   MF_FRONT2_LOG2B
+    std::atomic<int> front3_log2b{-1};    // -1 by the bait's size | 0 none | log2 of front3's blocks (6..27)                       "front3_log2b"   MF_FRONT3_LOG2B
+};
+static PassOptions g_opt;
+static int set_option(const char *name, const char *value)
+{
+    const std::string n = name ? name : "", v = value ? value : "";
+    if (n == "pass") { if (v == "" || v == "default") g_opt.pass = 0; else if (v == "split") g_opt.pass = 1; else if (v == "serial") g_opt.pass = 2; else return -1; return 0; }
+    char *end = nullptr; const long x = strtol(v.c_str(), &end, 10);
+    if (v.empty() || *end) return -1;
+    if (n == "expect_files") g_expect_files = x != 0;
+    else if (n == "short_lived") mf::ingest_short_lived(x != 0);
+    else if (n == "adapt") g_opt.adapt = x != 0;
+    else if (n == "finish_streams") { if (x < 0 || x > 2) return -1; g_opt.finish_streams = (int)x; }
+    else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
+    else if (n == "split_pipe") g_opt.split_pipe = x != 0;
+    else if (n == "exact_co") g_opt.exact_co = x != 0;
+    else if (n == "front") { if (x < -1 || x > 2) return -1; g_opt.front = (int)x; }
+    else if (n == "front2_log2b") { if (x != 0 && (x < 6 || x > 24)) return -1; g_opt.front2_log2b = (int)x; }
+    else if (n == "front3_log2b") { if (x < -1 || (x > 0 && x < 6) || x > 27) return -1; g_opt.front3_log2b = (int)x; }
+    else return -1;
+    return 0;
+}
+static void options_from_env_once()
+{
+    static const bool done = [] {
+        const char *k = getenv("MF_ENV_KNOBS");
+        if (k && k[0] == '1') {
+            static const char *const pairs[][2] = {{"pass", "MF_PASS"}, {"adapt", "MF_ADAPT"}, {"finish_streams", "MF_FINISH_STREAMS"}, {"screen_streams", "MF_SCREEN_STREAMS"},
+                                                   {"split_pipe", "MF_SPLIT_PIPE"}, {"exact_co", "MF_EXACT_CO"},
+                                                   {"front", "MF_FRONT"}, {"front2_log2b", "MF_FRONT2_LOG2B"}, {"front3_log2b", "MF_FRONT3_LOG2B"}};
+            for (auto &p : pairs) { const char *v = getenv(p[1]); if (v && *v && set_option(p[0], v) != 0) fprintf(stderr, "libmitofilter_hip: %s=%s is not a value of option '%s' (ignored)\n", p[1], v, p[0]); }
+        }
+        return true;
+    }();
+    (void)done;
+}
+static int pass_kind() { options_from_env_once(); return g_opt.pass; }          // (looked up on every pass: bench.py times the serial form next to the default one in one process)
 
 static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
 {
@@ -226,7 +291,16 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
         HIPCHK(hipMemsetAsync(T.bloom, 0, ks->screen_words() * 4, st));
         HIPCHK(dev_malloc(&T.stab, (size_t)ks->stab_slots * 4));
         HIPCHK(hipMemsetAsync(T.stab, 0xFF, (size_t)ks->stab_slots * 4, st));
-        HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag, st));
+        if (ks->front_mode) {
+            HIPCHK(dev_malloc(&T.front2, (size_t)16 << ks->f2_log2b));
+            HIPCHK(hipMemsetAsync(T.front2, 0, (size_t)16 << ks->f2_log2b, st));
+            if (ks->f3_log2b) {
+                HIPCHK(dev_malloc(&T.front3, (size_t)16 << ks->f3_log2b));
+                HIPCHK(hipMemsetAsync(T.front3, 0, (size_t)16 << ks->f3_log2b, st));
+            }
+        }
+        HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag,
+                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, st));
     }
     HIPCHK(dev_malloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
     HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
@@ -250,6 +324,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.smask = ks->geom.s >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ks->geom.s)) - 1);
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
+    V.front_mode = ks->front_mode; V.f2_log2b = ks->f2_log2b; V.f3_log2b = ks->f3_log2b; V.front2 = T.front2; V.front3 = T.front3;
     // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
     V.use_stab = (T.n_smers / 2 * STAGE2_K > ((uint64_t)32 << ks->stage2_log2w) * 7 / 10) ? 1u : 0u;
 #ifdef MF_DEBUG_KNOBS              // (experiment builds only: `make variant VARFLAGS=-DMF_DEBUG_KNOBS`)
@@ -299,6 +374,29 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         uint64_t ss = 1024; while (ss < 2 * bound) ss <<= 1;
         if (ss > (1ull << 31)) { delete ks; return fail(MF_E_ARG, "bait too large for the s-mer screen table"); }
         ks->stab_slots = (uint32_t)ss;
+        // Which screen (mf_kernels.hip, screen2_kernel), by the s-mers a 128-bit block of the LDS table holds.  Up to 9 (a bait of ~37 kbp:
+        // the table passes up to 0.5 % of the samples) the records go straight to the finish kernels, as ever (mode 0).  Up to 26 (9 % of
+        // the samples at 100 kbp: some 46 positives per wave and chunk of a queue's 64) the positives are looked up in a bait-sized table in
+        // L2 before anything is recorded (mode 1).  Beyond that the LDS table passes so much that it is left out and every sample is looked
+        // up (mode 2).  Measured where the forms meet (profiles/r06/e_front_variants3.txt, ms a pass): 25 kbp 0.261 (mode 0) against
+        // 0.306 (mode 1), 33 kbp 0.306 / 0.320, 50 kbp 0.441 / 0.340; 100 kbp 0.396 (mode 1) against 1.34 (mode 2).
+        // front2: about four s-mers a block (0.02 % false positives), at most 2 MiB; front3 behind it where front2 holds more than twelve
+        // a block (from ~800 kbp).
+        const uint64_t per_lds_block = bound >> (ks->bloom_log2w - 2);
+        int mode = per_lds_block <= 9 ? 0 : per_lds_block <= 26 ? 1 : 2;
+        options_from_env_once();
+        if (g_opt.front >= 0) mode = g_opt.front;
+        ks->front_mode = (uint32_t)mode;
+        if (mode) {
+            uint32_t lg = 10;
+            while (lg < FRONT2_MAX_LOG2B && (4ull << lg) < bound) lg++;
+            if (g_opt.front2_log2b > 0) lg = (uint32_t)g_opt.front2_log2b;
+            ks->f2_log2b = lg;
+            uint32_t lg3 = 0;
+            if ((bound >> lg) > 12) { lg3 = lg + 1; while (lg3 < 27 && (4ull << lg3) < bound) lg3++; }
+            if (g_opt.front3_log2b >= 0) lg3 = (uint32_t)g_opt.front3_log2b;
+            ks->f3_log2b = mode == 2 ? lg3 : 0;          // (mode 1 keeps its LDS table and never sees a bait that overloads front2)
+        }
     }
     DevTables *T; int rc = build_on_device(ks, device, &T);
     if (rc) { delete ks; return rc; }
@@ -423,7 +521,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 {
     if (!ks) return MF_OK;
     for (auto &kv : ks->dev) {
-        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.kbloom_co); hipFree(kv.second.plut); }
+        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.kbloom_co); hipFree(kv.second.plut); hipFree(kv.second.front2); hipFree(kv.second.front3); }
     }
     delete ks;
     return MF_OK;
@@ -432,52 +530,6 @@ int mf_kmerset_free(mf_kmerset *ks)
 } // extern "C"
 
 // -------------------------------------------------------------------- reads
-// How a screened pass is run.  Default: screen_kernel, then finish_kernel when the threshold is 1 and no hit counts are wanted
-// (mark_kernel + exact_kernel otherwise).  MF_PASS=split: always screen, mark, exact.  MF_PASS=serial: screen + finish
-// without overlapping consecutive passes (for comparison).
-// The switches that select WHICH KERNELS a pass runs live in one options block.  A production process never reads them from the
-// environment: they are set through mf_set_option (the CLI's --option name=value), or -- for the test suite, bench.py and the profiling
-// scripts -- taken from the MF_* variables when MF_ENV_KNOBS=1 says so.  Every variant is parity-tested (tests/test_gpu_parity.py).
-struct PassOptions {
-    std::atomic<int> pass{0};             // 0 default (screen + finish, pipelined) | 1 split | 2 serial            "pass"            MF_PASS
-    std::atomic<int> adapt{1};            // switch the pass kind from the previous call's tallies                   "adapt"           MF_ADAPT
-    std::atomic<int> finish_streams{0};   // 0 by tallies | 1 | 2                                                    "finish_streams"  MF_FINISH_STREAMS
-    std::atomic<int> screen_streams{2};   // consecutive screens on one stream or on two in turn                     "screen_streams"  MF_SCREEN_STREAMS
-    std::atomic<int> split_pipe{1};       // the candidate-bitmap pass pipelined                                     "split_pipe"      MF_SPLIT_PIPE
-    std::atomic<int> exact_co{0};         // the co-resident exact kernel behind every screen (tests)                "exact_co"        MF_EXACT_CO
-};
-static PassOptions g_opt;
-static int set_option(const char *name, const char *value)
-{
-    const std::string n = name ? name : "", v = value ? value : "";
-    if (n == "pass") { if (v == "" || v == "default") g_opt.pass = 0; else if (v == "split") g_opt.pass = 1; else if (v == "serial") g_opt.pass = 2; else return -1; return 0; }
-    char *end = nullptr; const long x = strtol(v.c_str(), &end, 10);
-    if (v.empty() || *end) return -1;
-    if (n == "expect_files") g_expect_files = x != 0;
-    else if (n == "short_lived") mf::ingest_short_lived(x != 0);
-    else if (n == "adapt") g_opt.adapt = x != 0;
-    else if (n == "finish_streams") { if (x < 0 || x > 2) return -1; g_opt.finish_streams = (int)x; }
-    else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
-    else if (n == "split_pipe") g_opt.split_pipe = x != 0;
-    else if (n == "exact_co") g_opt.exact_co = x != 0;
-    else return -1;
-    return 0;
-}
-static void options_from_env_once()
-{
-    static const bool done = [] {
-        const char *k = getenv("MF_ENV_KNOBS");
-        if (k && k[0] == '1') {
-            static const char *const pairs[][2] = {{"pass", "MF_PASS"}, {"adapt", "MF_ADAPT"}, {"finish_streams", "MF_FINISH_STREAMS"}, {"screen_streams", "MF_SCREEN_STREAMS"},
-                                                   {"split_pipe", "MF_SPLIT_PIPE"}, {"exact_co", "MF_EXACT_CO"}};
-            for (auto &p : pairs) { const char *v = getenv(p[1]); if (v && *v && set_option(p[0], v) != 0) fprintf(stderr, "libmitofilter_hip: %s=%s is not a value of option '%s' (ignored)\n", p[1], v, p[0]); }
-        }
-        return true;
-    }();
-    (void)done;
-}
-static int pass_kind() { options_from_env_once(); return g_opt.pass; }          // (looked up on every pass: bench.py times the serial form next to the default one in one process)
-
 void reads_release(mf_reads *r)
 {
     if (!r) return;
@@ -550,8 +602,9 @@ int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, ui
     {   // worst case one 16-byte record per lane per chunk (a quarter of the packed stream); typical use is ~0.2 %.  The second
         // list is only needed by pipelined threshold-1 passes and is allocated on first use (enqueue_pass).
         // (the stride-16 and the stride-8 screens deal the chunks to different numbers of lists: room for either)
-        uint64_t grid = screen_grid_for(V, ctx->n_cu, 8), cap = screen_rec_cap_for(V, ctx->n_cu, 8);
-        { const uint64_t g2 = screen_grid_for(V, ctx->n_cu, 16), c2 = screen_rec_cap_for(V, ctx->n_cu, 16); if (g2 * c2 > grid * cap) cap = (g2 * c2 + grid - 1) / (grid ? grid : 1); }
+        // (key 4: two workgroups a CU -- the most lists, so its grid sizes the count array; room for the records of any of the three)
+        uint64_t grid = screen_grid_for(V, ctx->n_cu, 4), cap = screen_rec_cap_for(V, ctx->n_cu, 4);
+        for (int key : {8, 16}) { const uint64_t g2 = screen_grid_for(V, ctx->n_cu, key), c2 = screen_rec_cap_for(V, ctx->n_cu, key); if (g2 * c2 > grid * cap) cap = (g2 * c2 + grid - 1) / (grid ? grid : 1); }
         size_t c0 = r->cap_recs, c1 = r->cap_rec_counts;
         RCHK(dev_reserve(r->d_recs[0], c0, (grid * cap ? grid * cap : 1) * 16, reuse));
         RCHK(dev_reserve(r->d_rec_counts[0], c1, (grid ? grid : 1) * 4, reuse));
@@ -1051,7 +1104,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 

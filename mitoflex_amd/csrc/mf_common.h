@@ -69,6 +69,13 @@ MF_HD uint32_t bloom_hash(uint32_t smer) { return (smer & 0xFFFFFFu) * 0x9E3779u
 MF_HD uint32_t stage1_index_lo(int s, uint32_t log2w) { const uint32_t ib = log2w - 2; return (uint32_t)(2 * s) >= ib ? (uint32_t)(2 * s) - ib : 0u; }
 MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return ((i < 3 ? smer >> (8 * i) : h >> 8)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
+// the grid / record-list geometry a set's screen uses: the HBM-bound stride-16 screen leaves one CU in eight free (screen_grid_for);
+// every other screen -- stride 8, and the gather- and issue-bound screens of large baits -- takes every CU
+// (key 4: two workgroups a CU -- the front2-only screen of large baits holds few registers and no LDS table, and twice the gathers in flight)
+MF_HD int screen_grid_key(int stride, uint32_t front_mode) { return front_mode == 2 ? 4 : (stride == 16 && front_mode == 0) ? 16 : 8; }
+// front2 at most 2 MiB: an XCD's L2 is 4 MiB and the read stream passes through it too -- a 4 MiB table is looked up at 150-180 G/s,
+// a 2 MiB one at 205 (profiles/r06/c_front_variants.txt; the part's roof, nothing else running, is 265 G/s: tools/gather_roof.hip)
+constexpr uint32_t FRONT2_MAX_LOG2B = 17;
 constexpr int STAGE2_K = 4;
 MF_HD uint32_t stage2_hash_a(uint32_t canon) { uint32_t h = canon * 0x85EBCA6Bu; return h ^ (h >> 13); }
 MF_HD uint32_t stage2_hash_b(uint32_t canon) { uint32_t h = canon * 0xC2B2AE35u; return (h ^ (h >> 16)) | 1u; }
@@ -185,6 +192,12 @@ struct KmerSetView {
     const uint32_t *stab;       // s-mer exact table (ordered linear probing, EMPTY32)
     uint32_t  stab_has_ones;    // the all-ones s-mer (poly-T, only possible for s == 16) is present
     uint32_t  use_stab;         // stage 3 on: stage 2 is too full to be trusted alone (large baits)
+    // bait-sized fronts behind (or instead of) the LDS table, for baits the 128 KiB of LDS cannot screen (screen2_kernel): blocked bit
+    // tables of the stage-1 kind (128-bit blocks, one bit per dword, both strands inserted) in global memory.  front2 stays within
+    // an XCD's L2 (<= 4 MiB); front3 (only where front2 itself is overloaded: baits of several Mbp) is as large as the bait asks.
+    uint32_t  front_mode;       // 0: LDS table only (screen_kernel) | 1: LDS table, its positives through front2 | 2: every sample through front2 (no LDS table)
+    uint32_t  f2_log2b, f3_log2b;   // blocks = 1 << log2b; f3_log2b == 0: no front3
+    const uint32_t *front2, *front3;
     // protein-space set (peptide k-mers, 5 bits per residue; k = residues per key, kw = 1, no screen)
     uint32_t  prot;             // 1: keys are peptide k-mers and reads are translated in six frames
     uint32_t  kb_in_lds;        // the k-mer bit table is small enough to be staged in LDS

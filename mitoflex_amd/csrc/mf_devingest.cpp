@@ -457,7 +457,11 @@ struct DeviceStreams {
         int k = -1;
         { std::lock_guard<std::mutex> lk(mu); for (int i = 0; i < (int)GZ_NPOST; i++) if (!post_busy[i]) { post_busy[i] = true; k = i; break; } }
         *slot = k;
-        if (!wait_for(k == 1 ? POST1 : POST0)) return nullptr;          // (a single-end call does not wait for the second post stream)
+        if (!wait_for(k == 1 ? POST1 : POST0)) {          // (a single-end call does not wait for the second post stream)
+            if (k >= 0) { std::lock_guard<std::mutex> lk(mu); post_busy[k] = false; }          // the maker has failed: the slot is not taken
+            *slot = -1;
+            return nullptr;
+        }
         if (k < 0) { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; }      // (more than two mates at a time on one device: concurrent calls)
         if (want_masked && masked) { ask((k == 0 ? POSTM0 : POSTM1) + 1); if (wait_for(k == 0 ? POSTM0 : POSTM1)) return post_masked[k]; }
         return post[k];
@@ -609,6 +613,10 @@ public:
         if (th_.joinable()) th_.join();
         for (size_t l = 0; l < lanes_.size(); l++) {
             (void)hipSetDevice(lanes_[l].dev);
+            // run() leaves early when it is stopped (the longer mate of a pair, a failed call) or fails: copies it has queued on the
+            // device's shared copy stream may still be on their way into the ring and out of the staging buffers, and both go back to
+            // their pools right after this destructor -- nothing of this uploader may be in flight then
+            if (lanes_[l].st) (void)hipStreamSynchronize(lanes_[l].st);
             for (auto &e : ev_[l]) if (e) (void)hipEventDestroy(e);
             for (int b = 0; b < UP_BUFS_MAX; b++) if (free_ev_[l][b]) (void)hipEventDestroy(free_ev_[l][b]);
         }
@@ -2514,9 +2522,15 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     return MF_OK;
 }
 
+// file-level calls running in this process right now: what they hold in the caches (consumers' scratch and read sets, pinned staging) is in
+// use, so a release of everything (mf_release_cached, an allocation elsewhere that found the device full) leaves those alone meanwhile
+static std::atomic<int> g_calls_running{0};
+struct CallRunning { CallRunning() { g_calls_running++; } ~CallRunning() { g_calls_running--; } };
+
 int run_device_ingest(mf_kmerset *ks, const char *fq1, const char *fq2, const char *out1, const char *out2, uint32_t threshold,
                       bool pair_both, const int *devices, int n_devices, uint64_t *kept, uint64_t *total, std::string &err, IngestStats *stats)
 {
+    CallRunning running;
     Ingest I;
     I.ks = ks; I.threshold = threshold; I.pair_both = pair_both;
     for (int i = 0; i < n_devices; i++) I.devices.push_back(devices[i]);
@@ -2536,6 +2550,7 @@ int run_device_qualfilter(const char *fq1, const char *fq2, const char *out1, co
     Q.P = P; Q.pe = fq2 != nullptr; Q.cap = P.end ? P.end - P.start : ~0ull;
     Q.chunks.init((size_t)std::max<uint64_t>(env_u64("MF_QUAL_OUT_CHUNK", (uint64_t)4 << 20), 4096), (int)std::max<uint64_t>(2, env_u64("MF_QUAL_OUT_CHUNKS", 24)),
                   [](size_t n) -> void * { void *q = nullptr; return hipHostMalloc(&q, n, hipHostMallocPortable) == hipSuccess ? q : nullptr; }, [](void *q) { (void)hipHostFree(q); });
+    CallRunning running;
     Ingest I;
     I.qual = &Q;
     I.devices.push_back(device);
@@ -2562,7 +2577,9 @@ void ingest_prefetch(int device)
 
 size_t release_cached_device_memory(bool all)
 {
-    if (all) { g_scratch.clear(); g_streams.forget_staging(); g_pinned.clear(); return g_pool.release_all(); }
+    // (the pool's free lists hold idle buffers only -- giving those back is always safe, if slow beside a running call: hipFree waits for the
+    // device --; the scratch, read-set and pinned caches are taken apart only when no file-level call of this process is running)
+    if (all) { if (g_calls_running.load() == 0) { g_scratch.clear(); g_streams.forget_staging(); g_pinned.clear(); } return g_pool.release_all(); }
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return g_pool.release(dev);

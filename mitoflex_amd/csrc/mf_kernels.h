@@ -36,8 +36,10 @@ hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand
 hipError_t launch_build_kbloom(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, uint64_t slots, uint32_t *postab_scratch,
                               hipStream_t st);
+// front2 / front3 (optional): the bait-sized fronts of the large-bait screen, 1 << log2b blocks of 128 bits each, zeroed
 hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
-                               uint32_t stab_slots, uint32_t *has_ones, hipStream_t st);
+                               uint32_t stab_slots, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b,
+                               hipStream_t st);
 hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,
                              unsigned long long *out2, hipStream_t st);
 // FASTQ quality filter: a record's (cut) sequence and quality strings as offsets into the uploaded text

@@ -208,6 +208,222 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
 }
 
+// ------------------------------------------------- screen for baits the LDS table cannot hold
+// The 128 KiB stage-1 table screens a bait of one mitogenome (33 k s-mers on both strands: 0.06 % false positives); at two mitogenomes it
+// passes 0.4 % of the samples, at 100 kbp 9 %, at 350 kbp three quarters -- and every positive used to become a record for the finish
+// kernels (a pass fell from 0.24 ms to 1.3 ms at 100 kbp and 29 ms at 350 kbp, profiles/r06/a_bait_sweep_before.txt).  The s-mer test
+// itself stays selective far beyond that (2 M s-mers of 4^16 at 1 Mbp); what is missing is a table of the bait's size to ask.  That table
+// (front2: blocked bits of the stage-1 kind, <= 4 MiB so that it stays in every XCD's L2; front3 behind it for baits of several Mbp) is
+// asked from INSIDE the screen, before anything is recorded:
+//   front_mode 1 (LDS table still selective, baits of ~40 .. ~105 kbp): stage 1 as before; the positives of a wave's chunk are compacted
+//     into a queue in LDS (ballot / mbcnt, one sample slot of the wave at a time) and looked up by ONE dense wave-wide 16-byte gather a
+//     turn: issued at the top of the next turn, in front of the stream's loads, tested behind that chunk's stage 1.  Verified positives go
+//     back to their lane through an LDS word per lane (ds_or), and a lane records its chunk's verified mask one turn late: the record
+//     format, and everything behind it, is unchanged.  Bound by instruction issue (~185 vector instructions a wave and chunk at 100 kbp
+//     against 80 of screen_kernel): 0.40 ms a pass at 100 kbp, where the records of screen_kernel cost 1.3 ms.
+//   front_mode 2 (LDS table useless, larger baits): no LDS table; every sample is looked up in front2 (two workgroups a CU, four 16-byte
+//     gathers in flight per lane), the survivors in front3 where the bait has one.  Bound by the part's random-gather rate
+//     (tools/gather_roof.hip: 265 G lookups/s from a table of <= 4 MiB with nothing else running, 217 G/s beside a 16-byte read stream,
+//     55-80 G/s beyond L2), not by HBM: 312.5 M samples a 5 Gbp pass = 1.4-1.5 ms.
+// Conservative at every step (a table never loses an inserted s-mer; what a round cannot take is passed on unverified), so the records
+// hold every true s-mer match and the emitted bits stay the brute-force oracle's.
+constexpr int S2_QCAP = 64;           // queue entries per wave and chunk: ONE round of gathers a turn, issued and tested at fixed places of the turn (no load sits in a
+                                      // branch or an inner loop, so the compiler's vmcnt counts are exact); more positives than that are passed on unverified.  A bait whose
+                                      // LDS table passes more than ~10 % of the samples (46 a wave and chunk) takes front_mode 2 instead.
+constexpr size_t S2_LDS_EXTRA = 16 + (size_t)(SCREEN_BLOCK / 64) * (64 * 4 + S2_QCAP * 8);          // record counter | verified masks | queues
+
+__device__ __forceinline__ uint32_t lds_or(lds_u32 *p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_xchg(lds_u32 *p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// sign bit of the result: the s-mer's four bits are all set in its 128-bit block (stage1_field)
+__device__ __forceinline__ uint32_t block_test(uint32_t sm, uint32_t h, const uint4 blk)
+{
+    return lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);
+}
+
+template <int SPW, int U, bool LDSF, int G = 8>
+__global__ void __launch_bounds__(1024, G == 8 ? 4 : 8)          // (G = 4, no LDS table: two workgroups share a CU)
+screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
+               uint4 *__restrict__ clear, uint64_t clear_vec4)
+{
+    extern __shared__ uint4 s_tab4[];                                       // [stage-1 table] record counter | verified masks | queues
+    constexpr int NS = U * 4 * SPW;
+    const uint32_t nb4 = LDSF ? (1u << S.bloom_log2w) >> 2 : 0u;
+    uint32_t &s_nrec = *reinterpret_cast<uint32_t *>(s_tab4 + nb4);
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    lds_u32 *s_ver = (lds_u32 *)(reinterpret_cast<uint32_t *>(s_tab4 + nb4 + 1)) + wid * 64;
+    // the queue as two arrays (s-mers, ids): one 8-byte store per entry wants its two halves in a register pair, and the register allocator
+    // then keeps the chunk's words in pair positions of their own -- copied there from the stream loads' registers at the end of every
+    // turn, behind a wait for loads issued a moment before (one chunk in flight instead of two)
+    lds_u32 *s_qsm = (lds_u32 *)(reinterpret_cast<uint32_t *>(s_tab4 + nb4 + 1 + (SCREEN_BLOCK / 64) * 16)) + wid * (2 * S2_QCAP);
+    lds_u32 *s_qid = s_qsm + S2_QCAP;
+    const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
+    const uint4 *__restrict__ f2 = reinterpret_cast<const uint4 *>(S.front2);
+    const uint4 *__restrict__ f3 = reinterpret_cast<const uint4 *>(S.front3);
+    const uint64_t chunk = (uint64_t)blockDim.x * U;
+    const uint64_t n_chunks = R.n_vec / chunk;
+    const uint32_t idx_lo = LDSF ? stage1_index_lo(S.s, S.bloom_log2w) : 0u, idx_bits = LDSF ? S.bloom_log2w - 2 : 0u;
+    const uint32_t lo2 = stage1_index_lo(S.s, S.f2_log2b + 2), b2 = S.f2_log2b;
+    const uint32_t lo3 = stage1_index_lo(S.s, S.f3_log2b + 2), b3 = S.f3_log2b;
+    const uint64_t cstep = gridDim.x;
+    ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
+
+    auto load = [&](uint64_t c, u32x4 (&d)[U], uint32_t (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t v = c * chunk + (uint64_t)u * blockDim.x + threadIdx.x;
+            d[u] = __builtin_nontemporal_load(&w4[v]);
+            if (SPW == 2) x[u] = R.words[4 * v + 4];
+        }
+    };
+    auto record = [&](uint64_t c, uint32_t mask) {
+        const uint32_t slot = atomicAdd(&s_nrec, 1u);
+        ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = mask; rec.pad = 0;
+        my_recs[slot] = rec;
+    };
+    // the samples of a chunk slice as they lie in the stream; sample i is bit NS-1-i of a mask (ScreenRec)
+    auto samples = [&](const u32x4 (&d)[U], const uint32_t (&x)[U], uint32_t (&sm)[NS]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int j = 0; j < SPW; j++) sm[(u * 4 + q) * SPW + j] = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
+        }
+    };
+
+    // ---- front_mode 1: the first round of the LAST chunk's queue is issued at the top of a turn (in front of the next chunk's stream
+    // loads, so that the wait for it does not include those), tested behind this chunk's stage 1, and the last chunk's verified masks are
+    // recorded before this chunk's positives go into the queue.  Nothing a load returns lives across a turn: with two copies of the
+    // loop body (the stream's two register sets) a loop-carried load result ends in register copies that wait for the load at once.
+    uint32_t p_n = 0, p_sm = 0, p_id = 0; uint4 p_blk = make_uint4(0, 0, 0, 0);
+    uint64_t prev_c = 0;
+    auto issue_prev = [&] {
+        // UNCONDITIONAL gather (a lane without an entry asks for block 0, one request for all of them): a load the compiler cannot count
+        // makes its vmcnt waits conservative, and this chunk's stage 1 would wait for the gather instead of only for its own data
+        p_sm = lds_ld(&s_qsm[lane]); p_id = lds_ld(&s_qid[lane]);       // (beyond the queue's fill: stale bytes, never used)
+        const uint32_t bi = __builtin_amdgcn_ubfe(bloom_hash(p_sm), lo2, b2);
+        p_blk = f2[lane < p_n ? bi : 0u];
+    };
+    auto settle_prev = [&] {          // test the round, then every lane takes (and clears) the verified mask of its slice of the last chunk
+        // (the test itself is unconditional: a load whose only use sits in a branch is sunk into that branch by the compiler -- issued where it is waited for)
+        const uint32_t pt = block_test(p_sm, bloom_hash(p_sm), p_blk);
+        if (lane < p_n && (int32_t)pt < 0) lds_or(&s_ver[p_id & 63u], 1u << (p_id >> 8));
+        MF_COMPILER_FENCE();          // (a wave's LDS operations execute in the order they were issued)
+        const uint32_t v = lds_xchg(&s_ver[lane], 0u);
+        if (v) record(prev_c, v);
+    };
+
+    auto process = [&](uint64_t c, const u32x4 (&d)[U], const uint32_t (&x)[U]) {
+        uint32_t sm[NS];
+        samples(d, x, sm);
+        if (LDSF) {
+            // stage 1 and the compaction of its positives into the wave's queue, eight samples at a time (one sample slot of the wave per ballot)
+            uint32_t base = 0;
+            uint32_t hms[NS / 8];
+#pragma unroll
+            for (int g0 = 0; g0 < NS; g0 += 8) {
+                uint32_t hm = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t h = bloom_hash(sm[g0 + i]);
+                    const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];
+                    hm = alignbit(hm, block_test(sm[g0 + i], h, blk), 31);          // sample g0 + i: bit 7-i
+                }
+                hms[g0 / 8] = hm;
+            }
+            settle_prev();                                              // the last chunk's first round (issued at the top of this turn)
+            constexpr int GL = 8;
+#pragma unroll
+            for (int g0 = 0; g0 < NS; g0 += GL) {
+                const uint32_t hm = hms[g0 / GL];
+#pragma unroll
+                for (int i = 0; i < GL; i++) {
+                    const bool hit = (hm >> (GL - 1 - i)) & 1u;
+                    const uint64_t bm = __builtin_amdgcn_ballot_w64(hit);
+                    if (bm) {
+                        const uint32_t off = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        const uint32_t bit = (uint32_t)(NS - 1 - (g0 + i));
+                        if (hit) {
+                            if (off < (uint32_t)S2_QCAP) { lds_st(&s_qsm[off], sm[g0 + i]); lds_st(&s_qid[off], lane | (bit << 8)); }
+                            else lds_or(&s_ver[lane], 1u << bit);          // no room: passed on unverified
+                        }
+                        base += (uint32_t)__popcll(bm);
+                    }
+                }
+            }
+            MF_COMPILER_FENCE();
+            p_n = base < (uint32_t)S2_QCAP ? base : (uint32_t)S2_QCAP;      // the round is issued at the top of the next turn
+            prev_c = c;
+        } else {
+            uint32_t mask = 0;                                          // G: gathers in flight per lane
+#pragma unroll
+            for (int g0 = 0; g0 < NS; g0 += G) {
+                uint4 blk[G];                                               // (the hash is computed again where it is needed: a register each would cost the second workgroup of the CU)
+#pragma unroll
+                for (int i = 0; i < G; i++) blk[i] = f2[__builtin_amdgcn_ubfe(bloom_hash(sm[g0 + i]), lo2, b2)];
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < G; i++) m = alignbit(m, block_test(sm[g0 + i], bloom_hash(sm[g0 + i]), blk[i]), 31);      // sample g0 + i: bit G-1-i
+                if (b3 && __ballot(m != 0)) {                           // the survivors through front3
+#pragma unroll
+                    for (int i = 0; i < G; i++) if ((m >> (G - 1 - i)) & 1u) blk[i] = f3[__builtin_amdgcn_ubfe(bloom_hash(sm[g0 + i]), lo3, b3)];
+                    uint32_t m3 = 0;
+#pragma unroll
+                    for (int i = 0; i < G; i++) {
+                        const uint32_t t = ((m >> (G - 1 - i)) & 1u) ? block_test(sm[g0 + i], bloom_hash(sm[g0 + i]), blk[i]) : 0u;
+                        m3 = alignbit(m3, t, 31);
+                    }
+                    m = m3;
+                }
+                mask = (mask << G) | m;
+            }
+            if (mask) record(c, mask);
+        }
+    };
+
+    u32x4 a[U], b[U]; uint32_t ax[U], bx[U];
+    uint64_t c = blockIdx.x;
+    if (c < n_chunks) load(c, a, ax);
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < clear_vec4; i += cstep * blockDim.x) clear[i] = z;
+        if (LDSF) {
+            const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
+            for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
+        }
+        lds_st(&s_ver[lane], 0u); lds_st(&s_qsm[lane], 0u); lds_st(&s_qid[lane], 0u);
+        if (threadIdx.x == 0) s_nrec = 0;
+    }
+    __syncthreads();
+    // Two register sets in turn, as in screen_kernel (a single set that is copied at the end of a turn waits there for the loads it
+    // has just issued: the copy needs the data).  The next chunk's loads are unconditional -- the last turn reads its own chunk again --
+    // so the compiler's vmcnt counts stay exact without peeling the last chunk (two copies of this long body instead of four).
+    if (c < n_chunks) for (;;) {
+        {
+            const bool last = c + cstep >= n_chunks;
+            const uint64_t cn = last ? c : c + cstep;
+            if (LDSF) issue_prev();
+            load(cn, b, bx);
+            process(c, a, ax);
+            if (last) break;
+            c = cn;
+        }
+        {
+            const bool last = c + cstep >= n_chunks;
+            const uint64_t cn = last ? c : c + cstep;
+            if (LDSF) issue_prev();
+            load(cn, a, ax);
+            process(c, b, bx);
+            if (last) break;
+            c = cn;
+        }
+    }
+    if (LDSF) { issue_prev(); settle_prev(); }                          // the last chunk's first round
+    __syncthreads();
+    if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
+}
+
 // Finishes the screen: for every recorded positive, stage 2 (canonical s-mer, Bloom probes),
 // optional stage 3 (exact s-mer table, large baits), then the candidate bit of the read that holds
 // the s-mer.  Dense: one record per lane, a few hundred thousand records per 5 Gbp.
@@ -1112,7 +1328,7 @@ __device__ __forceinline__ void stab_insert(uint32_t sm, uint32_t *stab, uint32_
 }
 
 __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
-                                    uint32_t stab_mask, uint32_t *has_ones)
+                                    uint32_t stab_mask, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B.total || B.runlen[p] < s) return;
@@ -1121,6 +1337,8 @@ __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t
     if (s < 16) fwd &= (1u << (2 * s)) - 1;
     const uint32_t rc = revcomp_s(fwd, s);
     stage1_insert(fwd, s, bloom, log2w); stage1_insert(rc, s, bloom, log2w);
+    if (front2) { stage1_insert(fwd, s, front2, f2_log2b + 2); stage1_insert(rc, s, front2, f2_log2b + 2); }      // the bait-sized fronts: the same blocks, more of them
+    if (front3) { stage1_insert(fwd, s, front3, f3_log2b + 2); stage1_insert(rc, s, front3, f3_log2b + 2); }
     stab_insert(fwd, stab, stab_mask, has_ones); stab_insert(rc, stab, stab_mask, has_ones);
     const uint32_t cn = fwd < rc ? fwd : rc;
     const uint32_t ha = stage2_hash_a(cn), hb = stage2_hash_b(cn);
@@ -1400,6 +1618,7 @@ uint64_t screen_grid_for(const ReadsView &R, int n_cu, int stride)
     const uint64_t n_chunks = R.n_vec / ((uint64_t)SCREEN_BLOCK * SCREEN_U);
     uint64_t wg = (uint64_t)n_cu;
     if (stride == 16 && n_cu >= 16) wg = (uint64_t)n_cu * SCREEN_CU_NUM / SCREEN_CU_DEN;
+    if (stride == 4) wg = (uint64_t)n_cu * 2;          // (key 4: the front2-only screen of large baits, two workgroups a CU)
     return n_chunks < wg ? n_chunks : wg;
 }
 uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu, int stride)
@@ -1433,9 +1652,22 @@ template <int SPW>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
-    const uint64_t grid = screen_grid_for(R, n_cu, S.stride);
+    const int key = screen_grid_key(S.stride, S.front_mode);
+    const uint64_t grid = screen_grid_for(R, n_cu, key);
     if (grid == 0) return;
-    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, S.stride);
+    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
+    if (S.front_mode == 1) {          // LDS table, its positives through front2 (screen2_kernel)
+        const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + S2_LDS_EXTRA;
+        raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, true>>(128 * 1024 + S2_LDS_EXTRA);
+        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, true>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
+                  static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
+        return;
+    }
+    if (S.front_mode == 2) {          // every sample through front2 (and front3): two workgroups a CU (its grid key says so), four gathers in flight per lane
+        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 4>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), S2_LDS_EXTRA, st, tm, R, S,
+                  static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
+        return;
+    }
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
     raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U>>(128 * 1024 + 16);
     MF_LAUNCH((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
@@ -1446,9 +1678,10 @@ template <int SPW>
 static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
                             hipStream_t st, const KernelTiming *tm)
 {
-    const uint64_t grid = screen_grid_for(R, n_cu, S.stride);
+    const int key = screen_grid_key(S.stride, S.front_mode);
+    const uint64_t grid = screen_grid_for(R, n_cu, key);
     if (grid == 0) return;
-    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, S.stride);
+    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
     static const uint32_t split = getenv("MF_MARK_SPLIT") ? (uint32_t)atoi(getenv("MF_MARK_SPLIT")) : (uint32_t)MARK_SPLIT;
     static const uint32_t mblock = getenv("MF_MARK_BLOCK") ? (uint32_t)atoi(getenv("MF_MARK_BLOCK")) : (uint32_t)MARK_BLOCK;
     MF_LAUNCH((mark_kernel<SPW, SCREEN_U>), dim3((unsigned)grid * split), dim3(mblock), 0, st, tm, R, S,
@@ -1466,13 +1699,14 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, u
 hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
                          unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm, hipEvent_t done)
 {
-    const uint64_t lists = screen_grid_for(R, n_cu, S.stride);
+    const int key = screen_grid_key(S.stride, S.front_mode);
+    const uint64_t lists = screen_grid_for(R, n_cu, key);
     if (lists == 0) {               // (an empty read set) nothing to settle: the tallies read zero and `done` still completes, as in launch_exact
         (void)hipMemsetAsync(partials, 0, 2 * EXACT_MAX_GRID * 16, st);
         if (done) (void)hipEventRecord(done, st);
         return hipGetLastError();
     }
-    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, S.stride);
+    const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
     const ScreenRec *rc = static_cast<const ScreenRec *>(recs);
     static const bool time_phase1 = getenv("MF_TIME_PHASE1") != nullptr;          // the one event pair goes to phase 0 unless asked otherwise
     const KernelTiming *none = nullptr, *tm0 = time_phase1 ? none : tm, *tm1 = time_phase1 ? tm : none;
@@ -1552,10 +1786,11 @@ hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, 
 }
 
 hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
-                               uint32_t stab_slots, uint32_t *has_ones, hipStream_t st)
+                               uint32_t stab_slots, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b, hipStream_t st)
 {
     if (B.total == 0) return hipSuccess;
-    hipLaunchKernelGGL(build_screen_kernel, dim3(grid_for(B.total, 256)), dim3(256), 0, st, B, s, bloom, log2w, log2w2, stab, stab_slots - 1, has_ones);
+    hipLaunchKernelGGL(build_screen_kernel, dim3(grid_for(B.total, 256)), dim3(256), 0, st, B, s, bloom, log2w, log2w2, stab, stab_slots - 1, has_ones,
+                       front2, f2_log2b, front3, f3_log2b);
     return hipGetLastError();
 }
 

@@ -35,3 +35,24 @@ def bait_records(bait_text: str) -> List[str]:
         elif cur is not None:
             cur.append("".join(ln.split()))
     return ["".join(r) for r in recs]
+
+
+def random_bait(length: int, seed: int = 1, n_records: int = 0, line: int = 70) -> str:
+    """A seeded random nucleotide bait of `length` bases in all (the bait-size axis of bench.py / tools/bait_sweep.py: 33 kbp =
+    two mitogenomes ... 8.5 Mbp = the reference's profile/MT_database read as nucleotides), cut into records of about
+    16.5 kbp (a clade-wide bait is many mitogenomes, not one long sequence) unless n_records says otherwise."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, size=length, dtype=np.uint8)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes().decode()
+    if n_records <= 0:
+        n_records = max(1, round(length / 16569))
+    per = (length + n_records - 1) // n_records
+    out = []
+    for r in range(n_records):
+        rec = seq[r * per:(r + 1) * per]
+        if not rec:
+            break
+        out.append(">random_bait_%d len=%d" % (r, len(rec)))
+        out.extend(rec[i:i + line] for i in range(0, len(rec), line))
+    return "\n".join(out) + "\n"

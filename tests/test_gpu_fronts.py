@@ -1,0 +1,124 @@
+"""GPU parity of the large-bait screen (screen2_kernel: front_mode 1 = LDS table + bait-sized front2 in L2, front_mode 2 = front2 (+ front3)
+only): every form is forced onto small inputs through mf_set_option and held bit-exact to the CPU oracle, through the threshold-1
+pass (screen + finish), the candidate-bitmap pass (mark + exact, hit counts) and at every screen geometry; then baits that really
+are large (100 kbp .. 2 Mbp), where the library picks the form itself.
+
+PARITY UNPINNED BY THE REFERENCE (SURVEY.md 8a group B): the oracle is this repository's own.  Bar: bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util_data import bits_to_bool, make_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mf(built_lib):
+    from mitoflex_amd import mitofilter
+    if mitofilter.device_count() < 1:
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    return mitofilter
+
+
+@pytest.fixture(scope="module")
+def ol():
+    from oracle import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture()
+def front(mf):
+    """set the front options for the sets built inside a test; back to automatic afterwards"""
+    def set_(mode, f2=0, f3=-1):
+        mf.set_option("front", mode)
+        mf.set_option("front2_log2b", f2)
+        mf.set_option("front3_log2b", f3)
+    yield set_
+    set_(-1, 0, -1)
+
+
+# (mode, front2 log2 blocks, front3 log2 blocks): roomy tables, overloaded front2 (nearly everything passes: what a round cannot
+# verify is passed on), a front3 behind an overloaded front2, the smallest tables there are
+FORMS = [(1, 0, -1), (1, 6, -1), (2, 0, -1), (2, 6, 0), (2, 6, 12), (2, 8, 6)]
+
+
+@pytest.mark.parametrize("k", [19, 21, 25, 28, 31, 32, 33, 41, 63])
+@pytest.mark.parametrize("form", FORMS)
+def test_forced_forms_match_oracle(mf, ol, bait_text, front, k, form):
+    front(*form)
+    ks = mf.KmerSet.from_text(bait_text, k)
+    t = ol.OracleTable(bait_text, k)
+    for uniform in (True, False):
+        seqs = make_reads(bait_text, 5000, seed=300 + k, uniform=uniform)
+        R = ol.OracleReads.from_seqs(seqs)
+        reads = mf.Reads.from_packed(R.words, R.offsets, R.npos)
+        for thr in (1, 2):
+            obits, ohits = ol.filter_reads(t, R, thr, threads=4)
+            bits, hits, _ = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED, want_hits=True)
+            assert np.array_equal(hits, ohits), (k, form, uniform, thr)
+            assert np.array_equal(bits, obits), (k, form, uniform, thr)
+            bits2, _, st = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED)
+            assert np.array_equal(bits2, obits), (k, form, uniform, thr)
+            assert st.n_pass == int(bits_to_bool(obits, len(seqs)).sum())
+        reads.close()
+    ks.close()
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_forced_forms_pipelined_passes(mf, ol, bait_text, front, form):
+    """several pipelined passes of a 300 k-read synthetic set: every pass's tally equals the oracle's count (buffer sets, streams)"""
+    front(*form)
+    n, L = 300_000, 150
+    ks = mf.KmerSet.from_text(bait_text, 31)
+    reads = mf.Reads.synth(n, L, seed=9, bait_text=bait_text, keep_host=True)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    R = ol.OracleReads.from_arrays(reads.host_words, off, reads.host_npos)
+    obits, _ = ol.filter_reads(ol.OracleTable(bait_text, 31), R, 1, threads=os.cpu_count() or 1)
+    want = int(bits_to_bool(obits, n).sum())
+    per, _ = mf.filter_resident_passes(ks, reads, 1, mf.MODE_SCREENED, 6)
+    assert [int(x) for x in per] == [want] * 6
+    bits, _, _ = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
+    assert np.array_equal(bits, obits)
+
+
+@pytest.mark.parametrize("size,k", [(40_000, 31), (100_000, 31), (100_000, 21), (350_000, 31), (350_000, 41), (2_000_000, 31)])
+def test_large_baits_pick_their_screen(mf, ol, size, k):
+    """baits that are large for real: the library picks the form (LDS + front2 up to ~250 kbp, front2 alone beyond); bits and hit counts
+    equal the oracle's on 200 k reads (0.5 % bait reads, N), and the screened pass equals the exhaustive one"""
+    from mitoflex_amd.utility.synth_bait import random_bait
+    bait = random_bait(size, seed=size + k)
+    ks = mf.KmerSet.from_text(bait, k)
+    n, L = 200_000, 150
+    reads = mf.Reads.synth(n, L, seed=size, bait_text=bait, keep_host=True)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    R = ol.OracleReads.from_arrays(reads.host_words, off, reads.host_npos)
+    t = ol.OracleTable(bait, k)
+    for thr in (1, 3):
+        obits, ohits = ol.filter_reads(t, R, thr, threads=os.cpu_count() or 1)
+        bits, hits, _ = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED, want_hits=True)
+        assert np.array_equal(hits, ohits), (size, k, thr)
+        assert np.array_equal(bits, obits), (size, k, thr)
+        b2, _, _ = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED)
+        assert np.array_equal(b2, obits), (size, k, thr)
+        b3, _, _ = mf.filter_reads(ks, reads, thr, mf.MODE_EXHAUSTIVE)
+        assert np.array_equal(b3, obits), (size, k, thr)
+    assert 0.003 * n < int(bits_to_bool(obits, n).sum())
+
+
+def test_bait_rich_input_through_the_fronts(mf, ol, bait_text, front):
+    """every read a bait read: all of a wave's samples are positives, far more than its queue holds -- the overflow is passed on unverified"""
+    for form in [(1, 0, -1), (2, 0, -1)]:
+        front(*form)
+        ks = mf.KmerSet.from_text(bait_text, 31)
+        n, L = 100_000, 150
+        reads = mf.Reads.synth(n, L, seed=3, bait_text=bait_text, mito_ppm=1_000_000, keep_host=True)
+        off = np.arange(n + 1, dtype=np.uint64) * L
+        R = ol.OracleReads.from_arrays(reads.host_words, off, reads.host_npos)
+        obits, _ = ol.filter_reads(ol.OracleTable(bait_text, 31), R, 1, threads=os.cpu_count() or 1)
+        for _ in range(3):                      # (the pass kind adapts to what the last call saw)
+            bits, _, _ = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
+            assert np.array_equal(bits, obits), form
