@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--plain-pairs", type=int, default=READS_5GBP // 2,
                     help="pairs of the plain paired files of configs[1] put through the file boundary (device path against host pipeline; 0 = skip)")
     ap.add_argument("--k-sweep", default="21,41", help="other k of configs[2] timed on the same resident reads, a few steps each ('none' = none)")
+    ap.add_argument("--no-axes", action="store_true", help="skip extra.bait_sweep / threshold_sweep / ragged / realistic (the resident path off the headline's one point)")
     ap.add_argument("--rank-file-reads", type=int, default=500_000, help="N > 1: reads of the .gz shard every rank filters file to file on its own GPU (0 = skip)")
     return ap.parse_args()
 
@@ -179,7 +180,7 @@ def live_counters(counters, k, timeout_s=75.0):
             # (the profiled program comes right after `--`: no shell, no env wrapper in between)
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--k", str(k),
                    "--steps", "2", "--warmup", "0", "--prewarm-ms", "0", "--cpu-sample", "0", "--no-exhaustive", "--e2e-pairs", "0",
-                   "--e2e-full-reads", "0", "--fv2-pairs", "0", "--no-group-a", "--no-live-traffic", "--k-sweep", "none", "--real-gz-reads", "0", "--plain-pairs", "0"]
+                   "--e2e-full-reads", "0", "--fv2-pairs", "0", "--no-group-a", "--no-live-traffic", "--k-sweep", "none", "--real-gz-reads", "0", "--plain-pairs", "0", "--no-axes"]
             p = subprocess.Popen(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 p.wait(timeout=timeout_s)
@@ -353,16 +354,26 @@ def e2e_files(mf, ks, files, a):
 
     first_call = {}
 
+    each = {}          # every call's seconds of the last run() (the legs print them all: a minimum alone hides the call-to-call spread)
+
     def run(f1, f2, o1, o2, n_reads, reps=3, tag=None):
-        best, res = 1e9, None
+        best, res, secs = 1e9, None, []
         for i in range(reps):
             t0 = time.perf_counter()
             res = mf.filter_fastq_files(ks, f1, f2, o1, o2)
             dt = time.perf_counter() - t0
             if i == 0 and tag:
                 first_call[tag] = round(dt, 4)
+            secs.append(round(dt, 4))
             best = min(best, dt)
+        each["last"] = secs
         return n_reads / best, best, res
+
+    def spread():
+        """seconds of every call of the last run(), their median and max / min"""
+        v = sorted(each.get("last", []))
+        return {"seconds_each": list(each.get("last", [])), "seconds_median": v[len(v) // 2] if v else None,
+                "max_over_min": round(v[-1] / v[0], 3) if v and v[0] > 0 else None}
 
     def with_ingest(which, fn):
         prev = os.environ.get("MF_INGEST")
@@ -380,9 +391,12 @@ def e2e_files(mf, ks, files, a):
         (parse and pack on the host); roof: the text crosses PCIe once"""
         text_bytes = os.path.getsize(f1) + (os.path.getsize(f2) if f2 else 0)
         h_rate, h_secs, h_res = with_ingest("host", lambda: run(f1, f2, prefix + "_h1.fq", prefix + "_h2.fq" if f2 else None, n_reads, reps=2))
-        d_rate, d_secs, d_res = with_ingest("device", lambda: run(f1, f2, prefix + "_d1.fq", prefix + "_d2.fq" if f2 else None, n_reads, reps=3, tag=what))
+        h_spread = spread()
+        d_rate, d_secs, d_res = with_ingest("device", lambda: run(f1, f2, prefix + "_d1.fq", prefix + "_d2.fq" if f2 else None, n_reads, reps=5, tag=what))
+        d_spread = spread()
         ist = mf.last_ingest_stats()
-        dflt_rate, dflt_secs, _ = run(f1, f2, prefix + "_x1.fq", prefix + "_x2.fq" if f2 else None, n_reads, reps=2)
+        dflt_rate, dflt_secs, _ = run(f1, f2, prefix + "_x1.fq", prefix + "_x2.fq" if f2 else None, n_reads, reps=5)
+        x_spread = spread()
         dflt_path = mf.last_ingest_stats()["path"]
         try:
             h2d = mf.h2d_bandwidth(0, 1 << 30, 3)
@@ -390,10 +404,10 @@ def e2e_files(mf, ks, files, a):
             h2d = None
         same = md5_of(prefix + "_d1.fq") == md5_of(prefix + "_h1.fq") and (not f2 or md5_of(prefix + "_d2.fq") == md5_of(prefix + "_h2.fq")) and tuple(d_res) == tuple(h_res)
         return {"reads": n_reads, "text_bytes": text_bytes,
-                "device_path": {"reads_per_s": d_rate, "seconds": round(d_secs, 4), "first_call_seconds": first_call.get(what), "ingest_path": "device" if ist["path"] == 1 else "host",
-                                "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9},
-                "host_pipeline": {"reads_per_s": h_rate, "seconds": round(h_secs, 4)},
-                "library_default": {"reads_per_s": dflt_rate, "seconds": round(dflt_secs, 4), "ingest_path": "device" if dflt_path == 1 else "host"},
+                "device_path": {"reads_per_s": d_rate, "seconds": round(d_secs, 4), **d_spread, "first_of_these_calls_seconds": first_call.get(what),
+                                "ingest_path": "device" if ist["path"] == 1 else "host", "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9},
+                "host_pipeline": {"reads_per_s": h_rate, "seconds": round(h_secs, 4), **h_spread},
+                "library_default": {"reads_per_s": dflt_rate, "seconds": round(dflt_secs, 4), **x_spread, "ingest_path": "device" if dflt_path == 1 else "host"},
                 "roofline": {"bound": "pcie_h2d", "achieved": text_bytes / d_secs / 1e9, "peak": h2d, "unit": "GB/s", "frac": (text_bytes / d_secs / 1e9 / h2d) if h2d else None,
                              "note": "bytes of FASTQ text / seconds of the whole call on the device path (files in the page cache -> survivors written)"},
                 "outputs_equal": bool(same), "kept": int(d_res[0]), "total": int(d_res[1])}
@@ -420,8 +434,11 @@ def e2e_files(mf, ks, files, a):
             del os.environ["MF_INGEST"]
         else:
             os.environ["MF_INGEST"] = prev
-        rate, secs, res = run(t + "_1.fq.gz", None, t + "_od.fq", None, n, reps=5, tag="configs4")          # (the first is the process's first call at this size; best of the other four)
-        ist = mf.last_ingest_stats()                 # (of the last of the three calls)
+        rate, secs, res = run(t + "_1.fq.gz", None, t + "_od.fq", None, n, reps=6, tag="configs4")          # (the first is the process's first call at this size)
+        c4_spread = spread()
+        warm = sorted(c4_spread["seconds_each"][1:])
+        c4_spread["warm_calls_max_over_min"] = round(warm[-1] / warm[0], 3) if warm and warm[0] > 0 else None
+        ist = mf.last_ingest_stats()                 # (of the last of the calls)
         md5 = md5_of(t + "_od.fq")
         gz_bytes = os.path.getsize(t + "_1.fq.gz")
         try:
@@ -437,10 +454,10 @@ def e2e_files(mf, ks, files, a):
                                 "note": "time with at least one gz_decode kernel running (HIP events around every launch), while upload, link step and the consumers' kernels share the device",
                                 "bound": "instruction issue and latency of divergent lane code, not memory: 6.6 wave-instructions per byte of text (VALU 3.5, scalar 2.7, LDS 0.26), wavefronts on "
                                          "s_waitcnt 56 % of their cycles, ~2.7 B of HBM traffic per byte of text (profiles/r04/c_gzdev_pmc.txt); alone with the chip full the kernel does "
-                                         "73.9 GB/s of text (profiles/r04/h_gzdev_check_kernel_stats.csv) = 2.6e11 VALU wave-instructions/s of the chip's 6.1e11"},
+                                         "88.5 GB/s of text (profiles/r05/h_gzdev_check_kernel_stats.csv: 43.5 ms for 3.85 GB)"},
             "ingest_path": "device" if ist["path"] == 1 else "host", "device_memory_in_use_peak_GB": ist["device_bytes_peak"] / 1e9, "call_buffers_peak_GB": ist["pool_bytes_peak"] / 1e9,
             "chunks": ist["chunks"], "chunks_linked": ist["chunks_linked"], "gaps_bridged_on_host": ist["gaps"],
-            "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), "first_call_seconds": first_call.get("configs4"), "kept": int(res[0]), "total": int(res[1]),
+            "reads": n, "reads_per_s": rate, "seconds": round(secs, 4), **c4_spread, "first_call_seconds": first_call.get("configs4"), "kept": int(res[0]), "total": int(res[1]),
             # the same file through the boundary the reference has: a process per call (HIP start-up, streams, pinned staging, the bait set's build
             # and the call), process start to exit, run before this process touched the GPU
             "cli_cold": dict(files["full_cli"], reads_per_s=n / files["full_cli"]["seconds"], kept_equals_library=bool(files["full_cli"]["kept"] == int(res[0]))) if "full_cli" in files else files.get("cli_error"),
@@ -558,6 +575,201 @@ def group_a(files):
 
 
 VALU_PEAK_GINST = 1024 * 2.4 / 4        # wave-instructions per ns the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles per wave stream at 2.4 GHz
+
+GATHER_PEAK_GLOOKUPS = 265.0     # G lookups/s: independent random 16-byte gathers from a table of <= 4 MiB (an XCD's L2), every CU issuing, nothing else
+                                 # running -- measured by tools/gather_roof.hip (profiles/r06/a_gather_roof.txt); 217 G/s beside a 16-byte read stream
+
+
+def committed_valu(kernel_tag, profile):
+    """SQ_INSTS_VALU per launch of a kernel from a committed PMC profile of this round (profiles/r06/pmc_<profile>.txt, tools/pmc_any.sh):
+    the count is a property of the code and the input, so the committed figure prices a live duration.  None when absent."""
+    import ast
+    import re
+    try:
+        for ln in open(os.path.join(ROOT, "profiles", "r06", "pmc_%s.txt" % profile)):
+            if kernel_tag in ln and "SQ_INSTS_VALU" in ln:
+                d = ast.literal_eval(re.search(r"\{.*\}", ln).group(0))
+                return float(d["SQ_INSTS_VALU"])
+    except Exception:
+        pass
+    return None
+
+
+def oracle_window(bait, k, thr, host_words, host_npos, n_win, offsets=None):
+    """pass bits of the first n_win reads from the CPU oracle (all host threads)"""
+    import numpy as np
+    from oracle import oracle_lib as ol
+    off = np.arange(n_win + 1, dtype=np.uint64) * READ_LEN if offsets is None else offsets[:n_win + 1]
+    lim = int(off[n_win])
+    R = ol.OracleReads.from_arrays(host_words[:(lim + 15) // 16 + 8], off, host_npos[host_npos < lim])
+    return ol.filter_reads(ol.OracleTable(bait, k), R, thr, threads=os.cpu_count() or 1)[0]
+
+
+def timed_passes(mf, ks, reads, thr, dev, n_st, mode=None):
+    """(seconds per pipelined pass over n_st passes, stats of the timed call, stats of a fully sampled loop)"""
+    mode = mf.MODE_SCREENED if mode is None else mode
+    os.environ["MF_EVENT_STRIDE"] = "1000000000"
+    for _ in range(3):                                   # (the pass kind follows what the last calls of this read set saw)
+        mf.filter_resident(ks, reads, thr, mode, 3)
+    mf.device_synchronize(dev)
+    c0 = time.perf_counter()
+    st = mf.filter_resident(ks, reads, thr, mode, n_st)
+    mf.device_synchronize(dev)
+    dt = (time.perf_counter() - c0) / n_st
+    os.environ["MF_EVENT_STRIDE"] = "1"
+    sp = mf.filter_resident(ks, reads, thr, mode, n_st)
+    os.environ["MF_EVENT_STRIDE"] = "8"
+    return dt, st, sp
+
+
+def superset_bait(base, size, seed):
+    """the benchmark's bait plus random records up to `size` bases in all: the reads planted from the benchmark's bait stay bait reads"""
+    from mitoflex_amd.utility.synth_bait import bait_records, random_bait
+    have = sum(len(r) for r in bait_records(base))
+    return base if size <= have else base + random_bait(size - have, seed=seed)
+
+
+def bait_sweep_leg(mf, reads, base_bait, a, dev, alg_bytes, n_words):
+    """extra.bait_sweep: the same resident reads against baits of 33 kbp .. 8.5 Mbp (the benchmark's bait plus random genomes; the last is
+    the size of the reference's profile/MT_database read as nucleotides).  Which screen a bait takes follows its size (front_mode); every
+    leg carries the roofline of what actually bounds it and a check of its first 1.5 M pass bits against the CPU oracle."""
+    import numpy as np
+    out = {}
+    n_win = min(1_500_000, a.reads) // 32 * 32
+    for size in (33_000, 100_000, 350_000, 1_000_000, 8_500_000):
+        bait = superset_bait(base_bait, size, seed=size)
+        t0 = time.perf_counter()
+        ks = mf.KmerSet.from_text(bait, a.k, dev)
+        t_build = time.perf_counter() - t0
+        inf = ks.info
+        n_st = 10
+        dt, st, sp = timed_passes(mf, ks, reads, THRESHOLD, dev, n_st)
+        scr_s = sp.ms_screen / 1e3
+        whole = alg_bytes / dt / 1e9 / HBM_PEAK_GBPS
+        hbm = {"achieved": alg_bytes / scr_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / scr_s / 1e9 / HBM_PEAK_GBPS}
+        if inf.front_mode == 2:
+            look = n_words / scr_s / 1e9              # one 16-base sample per 32-bit word of the stream, each looked up in front2
+            roof = {"bound": "l2_gather", "achieved": look, "peak": GATHER_PEAK_GLOOKUPS, "unit": "G lookups/s", "frac": look / GATHER_PEAK_GLOOKUPS,
+                    "kernel": "screen2_kernel (front2 only)", "lookups_per_launch": int(n_words), "hbm": hbm,
+                    "peak_source": "tools/gather_roof.hip, profiles/r06/a_gather_roof.txt: random 16-byte gathers from <= 4 MiB, nothing else running (217 G/s beside a read stream)",
+                    "note": "front3 look-ups of front2's survivors (baits of several Mbp: a table beyond L2, 55-80 G lookups/s) are not counted in `achieved`"}
+        elif inf.front_mode == 1:
+            v = committed_valu("screen2_kernel", "s2_100k")
+            g = v / scr_s / 1e9 if v else None
+            roof = {"bound": "valu", "achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST if g else None,
+                    "kernel": "screen2_kernel (LDS table + front2)", "hbm": hbm,
+                    "valu_source": "profiles/r06/pmc_s2_100k.txt (SQ_INSTS_VALU per launch at 100 kbp; the count moves with the bait's size)"}
+        else:
+            roof = {"bound": "hbm", **hbm, "kernel": "screen3_kernel" if inf.front_mode == 3 else "screen_kernel"}
+        roof.update({"avg_kernel_ms": sp.ms_screen, "kernel_launches_averaged": n_st, "whole_pass_frac_of_hbm_peak": whole})
+        leg = {"bait_bases": size, "front_mode": int(inf.front_mode), "front2_MiB": (16 << inf.front2_log2_blocks) / 2**20 if inf.front2_log2_blocks else 0,
+               "front3_MiB": (16 << inf.front3_log2_blocks) / 2**20 if inf.front3_log2_blocks else 0, "n_keys": int(inf.n_keys), "n_smers": int(inf.n_smers),
+               "set_build_seconds": round(t_build, 3), "reads_per_s": a.reads / dt, "ms_per_step": dt * 1e3, "steps": n_st,
+               "ms_screen_kernel": round(sp.ms_screen, 4), "work_items_per_read": st.n_candidates / a.reads, "passed": int(st.n_pass),
+               "whole_pass_frac_of_hbm_peak": round(whole, 4), "roofline": roof}
+        if reads.host_words is not None and n_win:
+            gbits, _, _ = mf.filter_reads(ks, reads, THRESHOLD, mf.MODE_SCREENED)
+            obits = oracle_window(bait, a.k, THRESHOLD, reads.host_words, reads.host_npos, n_win)
+            leg["window_bits_match_oracle"] = bool(np.array_equal(gbits[:n_win // 32], obits[:n_win // 32]))
+            leg["window_reads_checked"] = n_win
+        out[str(size)] = leg
+        ks.close()
+    return out
+
+
+def threshold_leg(mf, ks, reads, bait, a, dev, alg_bytes):
+    """extra.threshold_sweep: the passes the headline does not take -- threshold 2 and 7 (screen + mark + exact on the candidates) and the
+    hit-count form (every k-mer of every candidate verified) -- on the same resident reads; the exhaustive pass (the literal north-star
+    kernel on every read) priced against the vector issue rate."""
+    import numpy as np
+    out = {}
+    n_win = min(1_500_000, a.reads) // 32 * 32
+    for thr in (1, 2, 7):
+        dt, st, sp = timed_passes(mf, ks, reads, thr, dev, 10)
+        leg = {"ms_per_step": dt * 1e3, "reads_per_s": a.reads / dt, "passed": int(st.n_pass), "candidates_or_work_items": int(st.n_candidates),
+               "ms_screen_kernel": round(sp.ms_screen, 4), "ms_mark_kernel": round(sp.ms_mark, 4), "ms_last_kernel": round(sp.ms_exact, 4),
+               "whole_pass_frac_of_hbm_peak": round(alg_bytes / dt / 1e9 / HBM_PEAK_GBPS, 4)}
+        _, hits, sh = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED, want_hits=True)          # hit counts: the count-all exact kernel
+        _, _, sh = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED, want_hits=True)
+        leg["with_hit_counts"] = {"ms_per_step": sh.ms_total, "reads_per_s": a.reads / (sh.ms_total / 1e3), "ms_exact_kernel": round(sh.ms_exact, 4)}
+        if reads.host_words is not None and n_win and thr > 1:
+            gbits, _, _ = mf.filter_reads(ks, reads, thr, mf.MODE_SCREENED)
+            obits = oracle_window(bait, a.k, thr, reads.host_words, reads.host_npos, n_win)
+            leg["window_bits_match_oracle"] = bool(np.array_equal(gbits[:n_win // 32], obits[:n_win // 32]))
+        del hits
+        out[str(thr)] = leg
+    ex = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_EXHAUSTIVE, 1)
+    os.environ["MF_EVENT_STRIDE"] = "1"
+    ex = mf.filter_resident(ks, reads, THRESHOLD, mf.MODE_EXHAUSTIVE, 2)
+    os.environ["MF_EVENT_STRIDE"] = "8"
+    v = committed_valu("exact_kernel", "exhaustive")
+    ex_s = ex.ms_exact / 1e3
+    g = v / ex_s / 1e9 if (v and ex_s > 0) else None
+    out["exhaustive"] = {"ms_per_step": ex.ms_total, "reads_per_s": a.reads / (ex.ms_total / 1e3), "ms_exact_kernel": round(ex.ms_exact, 4),
+                         "roofline": {"bound": "valu", "achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST if g else None,
+                                      "kernel": "exact_kernel (every read: extract -> canonicalise -> LDS bit table -> open-address probe -> threshold)",
+                                      "valu_wave_instructions_per_launch": v, "valu_source": "profiles/r06/pmc_exhaustive.txt (SQ_INSTS_VALU per launch, same reads, same bait)",
+                                      "hbm_frac": alg_bytes / ex_s / 1e9 / HBM_PEAK_GBPS if ex_s > 0 else None}}
+    return out
+
+
+def ragged_leg(mf, ks, reads, bait, a, dev, uniform_ms):
+    """extra.ragged: the same dense stream cut into reads of 60..150 bases (what the quality filter's cuts leave,
+    filter/filter_bin/src/main.rs:239-268): the offsets path (a read is found by binary search instead of a multiplication)."""
+    import numpy as np
+    from mitoflex_amd.utility.synth_bait import ragged_offsets
+    total = a.reads * READ_LEN
+    off = ragged_offsets(total)
+    n = len(off) - 1
+    rr = mf.Reads.from_packed(reads.host_words, off, reads.host_npos, dev)
+    try:
+        dt, st, sp = timed_passes(mf, ks, rr, THRESHOLD, dev, 10)
+        alg = st.algorithmic_bytes
+        leg = {"reads": n, "mean_length": total / n, "ms_per_step": dt * 1e3, "reads_per_s": n / dt, "bases_per_s": total / dt, "passed": int(st.n_pass),
+               "ms_screen_kernel": round(sp.ms_screen, 4), "ms_last_kernel": round(sp.ms_exact, 4), "work_items": int(st.n_candidates),
+               "whole_pass_frac_of_hbm_peak": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4), "ms_per_step_over_uniform": round(dt * 1e3 / uniform_ms, 3),
+               "roofline": {"bound": "hbm", "achieved": alg / (sp.ms_screen / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": alg / (sp.ms_screen / 1e3) / 1e9 / HBM_PEAK_GBPS, "kernel": "screen_kernel", "avg_kernel_ms": sp.ms_screen}}
+        n_win = min(1_500_000, n) // 32 * 32
+        gbits, _, _ = mf.filter_reads(ks, rr, THRESHOLD, mf.MODE_SCREENED)
+        obits = oracle_window(bait, a.k, THRESHOLD, reads.host_words, reads.host_npos, n_win, offsets=off)
+        leg["window_bits_match_oracle"] = bool(np.array_equal(gbits[:n_win // 32], obits[:n_win // 32]))
+        leg["window_reads_checked"] = n_win
+        return leg
+    finally:
+        rr.close()
+
+
+def realistic_leg(mf, a, dev, uniform_ms):
+    """extra.realistic: an AT-rich bait with poly-T / poly-A runs and a (TA)n stretch, a background with 2 % microsatellite reads and
+    0.1 % NUMT-like reads (bait fragments at 15 % divergence) beside the 0.5 % bait reads: what low-complexity s-mers shared between bait and
+    background cost (every one of them is a true stage-1 positive that the finish kernels settle exactly)."""
+    import numpy as np
+    from mitoflex_amd.utility.synth_bait import realistic_bait
+    bait = realistic_bait()
+    ks = mf.KmerSet.from_text(bait, a.k, dev)
+    rd = mf.Reads.synth(a.reads, READ_LEN, seed=20261004, bait_text=bait, mito_ppm=5000, sub_ppm=10000, n_read_ppm=10000, n_base_ppm=1000,
+                        device=dev, keep_host=True, msat_ppm=20000, numt_ppm=1000, numt_div_ppm=150000)
+    try:
+        dt, st, sp = timed_passes(mf, ks, rd, THRESHOLD, dev, 10)
+        alg = st.algorithmic_bytes
+        leg = {"bait": "16 569 bp, 68 % AT, poly-T(40) / poly-A(35) runs, (TA)60 (mitoflex_amd/utility/synth_bait.realistic_bait)",
+               "background": "2 % microsatellite reads (motif of 1..6 bases), 0.1 % NUMT-like reads (15 % divergence), 0.5 % bait reads, N in 1 % of reads",
+               "ms_per_step": dt * 1e3, "reads_per_s": a.reads / dt, "passed": int(st.n_pass), "work_items_per_read": st.n_candidates / a.reads,
+               "ms_screen_kernel": round(sp.ms_screen, 4), "ms_last_kernel": round(sp.ms_exact, 4),
+               "whole_pass_frac_of_hbm_peak": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4), "ms_per_step_over_iid": round(dt * 1e3 / uniform_ms, 3),
+               "roofline": {"bound": "hbm", "achieved": alg / (sp.ms_screen / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": alg / (sp.ms_screen / 1e3) / 1e9 / HBM_PEAK_GBPS, "kernel": "screen_kernel", "avg_kernel_ms": sp.ms_screen}}
+        n_win = min(1_500_000, a.reads) // 32 * 32
+        gbits, _, _ = mf.filter_reads(ks, rd, THRESHOLD, mf.MODE_SCREENED)
+        obits = oracle_window(bait, a.k, THRESHOLD, rd.host_words, rd.host_npos, n_win)
+        leg["window_bits_match_oracle"] = bool(np.array_equal(gbits[:n_win // 32], obits[:n_win // 32]))
+        leg["window_reads_checked"] = n_win
+        return leg
+    finally:
+        rd.close()
+        ks.close()
+
 
 
 def main():
@@ -734,6 +946,22 @@ def main():
                 sweep[str(kk)] = {"error": str(e)[:160]}
         extra["k_sweep"] = sweep
 
+    # ---- the axes the headline does not move along (one bait size, threshold 1, uniform reads, iid background): a leg that raises ends the
+    # run with a non-zero exit instead of hiding in `extra`
+    def leg(name, fn):
+        try:
+            extra[name] = fn()
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            extra[name] = {"error": str(e)[:200]}
+    if solo and default_set and not a.no_axes:
+        n_words_stream = (a.reads * READ_LEN + 15) // 16
+        leg("bait_sweep", lambda: bait_sweep_leg(mf, reads, bait, a, dev, alg_bytes, n_words_stream))
+        leg("threshold_sweep", lambda: threshold_leg(mf, ks, reads, bait, a, dev, alg_bytes))
+        if reads.host_words is not None:
+            leg("ragged", lambda: ragged_leg(mf, ks, reads, bait, a, dev, elapsed / a.steps * 1e3))
+
     cpu = None
     if want_cpu:
         import numpy as np
@@ -759,6 +987,8 @@ def main():
         extra["sample_reads_checked"] = nw * 32
     if solo:
         reads.close()                                    # (the file-level runs want the device memory)
+        if default_set and not a.no_axes:
+            leg("realistic", lambda: realistic_leg(mf, a, dev, elapsed / a.steps * 1e3))
         if "skipped" in files or "error" in files:
             extra["e2e_files"] = {k: v for k, v in files.items() if k in ("skipped", "error")}
         else:
@@ -869,6 +1099,18 @@ def main():
         print(json.dumps(out))
     if rdv is not None:
         rdv.close()
+    # a leg that raised is in `extra` as {"error": ...} (the line is still printed: the other legs' figures stand) -- and the run fails
+    def find_errors(d, path):
+        found = []
+        if isinstance(d, dict):
+            if "error" in d:
+                found.append(path)
+            for k2, v2 in d.items():
+                found += find_errors(v2, path + "." + str(k2) if path else str(k2))
+        return found
+    bad = find_errors(extra, "extra") if rank == 0 else []
+    if bad:
+        sys.exit("bench.py: legs that raised: " + ", ".join(bad))
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 4
+#define MF_ABI_VERSION 5
 
 enum {
     MF_OK = 0,
@@ -70,6 +70,12 @@ typedef struct {
     uint64_t n_smers;      /* distinct s-mers (both strands) */
     int32_t  kind;         /* MF_KIND_*; for MF_KIND_PROTEIN k is the peptide k-mer length (ABI 2) */
     int32_t  genetic_code; /* NCBI translation table of a protein set, else 0 (ABI 2) */
+    /* ABI 5: which screen a set of this size takes (the bait-size axis) */
+    uint32_t front_mode;         /* 0 LDS table only | 1 LDS table, positives looked up in front2 turn by turn | 2 every sample through
+                                    front2 (+ front3), no LDS table | 3 LDS table, lone positives through front2 sixty-four at a time */
+    uint32_t front2_log2_blocks; /* log2 of front2's 128-bit blocks (0: none) */
+    uint32_t front3_log2_blocks; /* log2 of front3's 128-bit blocks (0: none) */
+    uint32_t reserved;
 } mf_kmerset_info_t;
 
 typedef struct {
@@ -149,6 +155,16 @@ int mf_reads_synth(uint64_t n_reads, uint32_t read_len, uint64_t seed,
                    int device, mf_reads **out,
                    uint32_t **host_words_out, uint64_t *host_n_words_out,
                    uint64_t **host_npos_out, uint64_t *host_n_npos_out);
+/* ABI 5: the same with "real-data-shaped" extras for the low-complexity leg of bench.py: msat_ppm / 1e6 of the reads are
+ * microsatellites (a random motif of 1..6 bases repeated: poly-A, (TA)n, ...), numt_ppm / 1e6 are NUMT-like reads (sampled from
+ * the bait, numt_div_ppm / 1e6 substitutions per base). */
+int mf_reads_synth_ex(uint64_t n_reads, uint32_t read_len, uint64_t seed,
+                      const char *bait_fasta_text, size_t bait_len,
+                      uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm,
+                      uint32_t msat_ppm, uint32_t numt_ppm, uint32_t numt_div_ppm,
+                      int device, mf_reads **out,
+                      uint32_t **host_words_out, uint64_t *host_n_words_out,
+                      uint64_t **host_npos_out, uint64_t *host_n_npos_out);
 void mf_free_host(void *p);
 int mf_reads_info(const mf_reads *r, mf_reads_info_t *info);
 int mf_reads_free(mf_reads *r);

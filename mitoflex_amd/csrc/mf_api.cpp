@@ -190,7 +190,7 @@ struct PassOptions {
     std::atomic<int> split_pipe{1};       // the candidate-bitmap pass pipelined                                     "split_pipe"      MF_SPLIT_PIPE
     std::atomic<int> exact_co{0};         // the co-resident exact kernel behind every screen (tests)                "exact_co"        MF_EXACT_CO
     // the large-bait screen (read when a k-mer set is BUILT; tests force every form on small baits)
-    std::atomic<int> front{-1};           // -1 by the bait's size | 0 LDS table only | 1 LDS table + front2 | 2 front2 (+ front3) only   "front"   MF_FRONT
+    std::atomic<int> front{-1};           // -1 by the bait's size | 0 LDS table only | 1 LDS table + front2 | 2 front2 (+ front3) only | 3 LDS table, lone positives through front2   "front"   MF_FRONT
     std::atomic<int> front2_log2b{0};     // 0 by the bait's size | log2 of front2's 128-bit blocks (6..18)                         "front2_log2b"   MF_FRONT2_LOG2B
     std::atomic<int> front3_log2b{-1};    // -1 by the bait's size | 0 none | log2 of front3's blocks (6..27)                       "front3_log2b"   MF_FRONT3_LOG2B
 };
@@ -208,7 +208,7 @@ static int set_option(const char *name, const char *value)
     else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
     else if (n == "split_pipe") g_opt.split_pipe = x != 0;
     else if (n == "exact_co") g_opt.exact_co = x != 0;
-    else if (n == "front") { if (x < -1 || x > 2) return -1; g_opt.front = (int)x; }
+    else if (n == "front") { if (x < -1 || x > 3) return -1; g_opt.front = (int)x; }
     else if (n == "front2_log2b") { if (x != 0 && (x < 6 || x > 24)) return -1; g_opt.front2_log2b = (int)x; }
     else if (n == "front3_log2b") { if (x < -1 || (x > 0 && x < 6) || x > 27) return -1; g_opt.front3_log2b = (int)x; }
     else return -1;
@@ -384,6 +384,7 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         // a block (from ~800 kbp).
         const uint64_t per_lds_block = bound >> (ks->bloom_log2w - 2);
         int mode = per_lds_block <= 9 ? 0 : per_lds_block <= 26 ? 1 : 2;
+        if (ks->geom.stride == 16 && per_lds_block > 5 && per_lds_block <= 14) mode = 3;
         options_from_env_once();
         if (g_opt.front >= 0) mode = g_opt.front;
         ks->front_mode = (uint32_t)mode;
@@ -395,7 +396,7 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
             uint32_t lg3 = 0;
             if ((bound >> lg) > 12) { lg3 = lg + 1; while (lg3 < 27 && (4ull << lg3) < bound) lg3++; }
             if (g_opt.front3_log2b >= 0) lg3 = (uint32_t)g_opt.front3_log2b;
-            ks->f3_log2b = mode == 2 ? lg3 : 0;          // (mode 1 keeps its LDS table and never sees a bait that overloads front2)
+            ks->f3_log2b = mode == 2 ? lg3 : 0;          // (modes 1 and 3 keep their LDS table and never see a bait that overloads front2)
         }
     }
     DevTables *T; int rc = build_on_device(ks, device, &T);
@@ -504,6 +505,7 @@ int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info)
     info->bloom_words = ks->geom.s ? (uint32_t)ks->screen_words() : 0; info->smer_slots = ks->stab_slots;
     if (!ks->dev.empty()) { info->n_keys = ks->dev.begin()->second.n_keys; info->n_smers = ks->dev.begin()->second.n_smers; }
     info->kind = ks->kind; info->genetic_code = ks->genetic_code;
+    info->front_mode = ks->front_mode; info->front2_log2_blocks = ks->front_mode ? ks->f2_log2b : 0; info->front3_log2_blocks = ks->f3_log2b;
     return MF_OK;
 }
 
@@ -683,14 +685,24 @@ int mf_reads_synth(uint64_t n_reads, uint32_t read_len, uint64_t seed, const cha
                    uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm, int device, mf_reads **out,
                    uint32_t **host_words_out, uint64_t *host_n_words_out, uint64_t **host_npos_out, uint64_t *host_n_npos_out)
 {
+    return mf_reads_synth_ex(n_reads, read_len, seed, bait_text, bait_len, mito_ppm, sub_ppm, n_read_ppm, n_base_ppm, 0, 0, 0, device, out,
+                             host_words_out, host_n_words_out, host_npos_out, host_n_npos_out);
+}
+
+int mf_reads_synth_ex(uint64_t n_reads, uint32_t read_len, uint64_t seed, const char *bait_text, size_t bait_len,
+                      uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm,
+                      uint32_t msat_ppm, uint32_t numt_ppm, uint32_t numt_div_ppm, int device, mf_reads **out,
+                      uint32_t **host_words_out, uint64_t *host_n_words_out, uint64_t **host_npos_out, uint64_t *host_n_npos_out)
+{
     if (!out) return fail(MF_E_ARG, "out is NULL");
     *out = nullptr;
     if (read_len == 0) return fail(MF_E_ARG, "read_len must be > 0");
     BaitHost B; parse_bait_fasta(bait_text ? bait_text : "", bait_text ? bait_len : 0, B);
     SynthOut S;
     std::string err;
+    SynthExtra extra; extra.msat_ppm = msat_ppm; extra.numt_ppm = numt_ppm; extra.numt_div_ppm = numt_div_ppm;
     if (!synth_reads(n_reads, read_len, seed, B, mito_ppm, sub_ppm, n_read_ppm, n_base_ppm,
-                     host_threads(), S, err)) return fail(MF_E_ARG, "%s", err.c_str());
+                     host_threads(), S, err, extra)) return fail(MF_E_ARG, "%s", err.c_str());
     int rc = reads_upload(S.words.data(), S.n_words, true, nullptr, n_reads, n_reads * (uint64_t)read_len, read_len,
                           S.npos.data(), S.npos.size(), device, out);
     if (rc) return rc;
@@ -1104,7 +1116,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 

@@ -72,7 +72,8 @@ MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage
 // the grid / record-list geometry a set's screen uses: the HBM-bound stride-16 screen leaves one CU in eight free (screen_grid_for);
 // every other screen -- stride 8, and the gather- and issue-bound screens of large baits -- takes every CU
 // (key 4: two workgroups a CU -- the front2-only screen of large baits holds few registers and no LDS table, and twice the gathers in flight)
-MF_HD int screen_grid_key(int stride, uint32_t front_mode) { return front_mode == 2 ? 4 : (stride == 16 && front_mode == 0) ? 16 : 8; }
+// (mode 3 with stride 16 is screen_kernel's loop and keeps its HBM-bound grid)
+MF_HD int screen_grid_key(int stride, uint32_t front_mode) { return front_mode == 2 ? 4 : (stride == 16 && (front_mode == 0 || front_mode == 3)) ? 16 : 8; }
 // front2 at most 2 MiB: an XCD's L2 is 4 MiB and the read stream passes through it too -- a 4 MiB table is looked up at 150-180 G/s,
 // a 2 MiB one at 205 (profiles/r06/c_front_variants.txt; the part's roof, nothing else running, is 265 G/s: tools/gather_roof.hip)
 constexpr uint32_t FRONT2_MAX_LOG2B = 17;
@@ -195,7 +196,8 @@ struct KmerSetView {
     // bait-sized fronts behind (or instead of) the LDS table, for baits the 128 KiB of LDS cannot screen (screen2_kernel): blocked bit
     // tables of the stage-1 kind (128-bit blocks, one bit per dword, both strands inserted) in global memory.  front2 stays within
     // an XCD's L2 (<= 4 MiB); front3 (only where front2 itself is overloaded: baits of several Mbp) is as large as the bait asks.
-    uint32_t  front_mode;       // 0: LDS table only (screen_kernel) | 1: LDS table, its positives through front2 | 2: every sample through front2 (no LDS table)
+    uint32_t  front_mode;       // 0: LDS table only (screen_kernel) | 1: LDS table, its positives through front2 turn by turn | 2: every sample through front2
+                                // (no LDS table) | 3: LDS table, lone positives queued and looked up in front2 sixty-four at a time (screen3_kernel)
     uint32_t  f2_log2b, f3_log2b;   // blocks = 1 << log2b; f3_log2b == 0: no front3
     const uint32_t *front2, *front3;
     // protein-space set (peptide k-mers, 5 bits per residue; k = residues per key, kw = 1, no screen)

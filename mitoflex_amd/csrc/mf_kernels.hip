@@ -156,6 +156,34 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     // no returning global atomic, no division in the streaming loop -- mark_kernel finishes them.
     auto stage1 = [&](uint64_t c, const u32x4 (&d)[U], const uint32_t (&x)[U]) {
         uint32_t hitmask = 0;
+#ifdef MF_STAGE1_BATCH
+        // The table blocks of MF_STAGE1_BATCH samples are asked for together and tested behind a scheduling barrier: left to itself the
+        // compiler asks for two, waits for both, tests them, and a wave pays the LDS round trip eight times a chunk at the stride-8 geometries
+        // (four waves a SIMD do not cover it: 0.58 of the issue rate at k = 21).
+        constexpr int NS = U * 4 * SPW, B = MF_STAGE1_BATCH < NS ? MF_STAGE1_BATCH : NS;
+        uint32_t sm[NS];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int j = 0; j < SPW; j++) sm[(u * 4 + q) * SPW + j] = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
+        }
+#pragma unroll
+        for (int g0 = 0; g0 < NS; g0 += B) {
+            uint4 blk[B]; uint32_t h[B];
+#pragma unroll
+            for (int i = 0; i < B; i++) { h[i] = bloom_hash(sm[g0 + i]); blk[i] = s_tab4[__builtin_amdgcn_ubfe(h[i], idx_lo, idx_bits)]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const uint32_t t = lshl_by_byte<0>(sm[g0 + i], blk[i].x) & lshl_by_byte<1>(sm[g0 + i], blk[i].y) & lshl_by_byte<2>(sm[g0 + i], blk[i].z) & lshl_by_byte<1>(h[i], blk[i].w);
+                hitmask = alignbit(hitmask, t, 31);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
@@ -172,6 +200,7 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                 }
             }
         }
+#endif
         if (hitmask) {
             const uint32_t slot = atomicAdd(&s_nrec, 1u);
             ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = hitmask; rec.pad = 0;
@@ -420,6 +449,115 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
         }
     }
     if (LDSF) { issue_prev(); settle_prev(); }                          // the last chunk's first round
+    __syncthreads();
+    if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
+}
+
+// ----------------------------------------------- screen for baits a little too large for the LDS table
+// front_mode 3 (stride-16 geometries, baits of ~20 .. ~60 kbp: the LDS table passes 0.1 .. 2 % of the samples).  screen_kernel's loop with
+// one change: a lane whose chunk slice holds exactly ONE positive does not record it -- the sample goes into a queue of the wave in LDS
+// (ballot / mbcnt; what is selective here is the LDS table, so a wave sees a handful a chunk), and when 64 have gathered they are looked up
+// in front2 by one dense 16-byte gather and only the survivors are recorded, each on behalf of the lane that queued it.  A slice with two or
+// more positives is recorded as ever: that is a bait read (two independent false positives in eight samples: 1e-4 at 0.4 %).  The per-chunk
+// cost over screen_kernel is a dozen vector instructions; the look-ups cost one synchronous gather every tens of chunks.  The records, the
+// finish kernels and the emitted bits are what they were -- minus the false positives that cost a 33 kbp bait 0.306 ms a pass instead of 0.24.
+constexpr int S3_QN = 128;                 // queue entries per wave: fewer than 64 wait, a chunk adds at most 64
+constexpr size_t S3_LDS_EXTRA = 16 + (size_t)(SCREEN_BLOCK / 64) * (3 * S3_QN * 4);
+
+template <int U>
+__global__ void __launch_bounds__(1024)
+screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
+               uint4 *__restrict__ clear, uint64_t clear_vec4)
+{
+    extern __shared__ uint4 s_tab4[];                                       // stage-1 table | record counter | per wave: queued s-mers, chunks, ids
+    constexpr int NS = U * 4;
+    static_assert(NS == 8, "the sample select below is written for eight samples a slice");
+    const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
+    uint32_t &s_nrec = *reinterpret_cast<uint32_t *>(s_tab4 + nb4);
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    lds_u32 *s_qsm = (lds_u32 *)(reinterpret_cast<uint32_t *>(s_tab4 + nb4 + 1)) + wid * (3 * S3_QN);
+    lds_u32 *s_qch = s_qsm + S3_QN, *s_qid = s_qch + S3_QN;
+    const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
+    const uint4 *__restrict__ f2 = reinterpret_cast<const uint4 *>(S.front2);
+    const uint64_t chunk = (uint64_t)blockDim.x * U;
+    const uint64_t n_chunks = R.n_vec / chunk;
+    const uint32_t idx_lo = stage1_index_lo(S.s, S.bloom_log2w), idx_bits = S.bloom_log2w - 2;
+    const uint32_t lo2 = stage1_index_lo(S.s, S.f2_log2b + 2), b2 = S.f2_log2b;
+    const uint64_t cstep = gridDim.x;
+    ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
+    uint32_t q_n = 0;                                                       // entries in this wave's queue (wave-uniform)
+
+    auto load = [&](uint64_t c, u32x4 (&d)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = __builtin_nontemporal_load(&w4[c * chunk + (uint64_t)u * blockDim.x + threadIdx.x]);
+    };
+    auto record = [&](uint32_t c32, uint32_t tid, uint32_t mask) {
+        const uint32_t slot = atomicAdd(&s_nrec, 1u);
+        ScreenRec rec; rec.chunk = c32; rec.tid = tid; rec.hitmask = mask; rec.pad = 0;
+        my_recs[slot] = rec;
+    };
+    // the first 64 entries of the queue through front2; the rest moves to the front
+    auto drain = [&] {
+        const uint32_t cnt = q_n < 64u ? q_n : 64u;
+        const uint32_t esm = lds_ld(&s_qsm[lane]), ech = lds_ld(&s_qch[lane]), eid = lds_ld(&s_qid[lane]);
+        const uint32_t tsm = lds_ld(&s_qsm[64 + lane]), tch = lds_ld(&s_qch[64 + lane]), tid2 = lds_ld(&s_qid[64 + lane]);
+        if (lane < cnt) {
+            const uint32_t hh = bloom_hash(esm);
+            const uint4 blk = f2[__builtin_amdgcn_ubfe(hh, lo2, b2)];
+            if ((int32_t)block_test(esm, hh, blk) < 0) record(ech, eid & 0xFFFFu, 1u << (eid >> 16));
+        }
+        MF_COMPILER_FENCE();
+        lds_st(&s_qsm[lane], tsm); lds_st(&s_qch[lane], tch); lds_st(&s_qid[lane], tid2);
+        q_n -= cnt;
+    };
+    auto stage1 = [&](uint64_t c, const u32x4 (&d)[U]) {
+        uint32_t hitmask = 0;
+        const uint32_t sm[NS] = {d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, d[1].y, d[1].z, d[1].w};
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const uint32_t h = bloom_hash(sm[i]);
+            const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];
+            hitmask = alignbit(hitmask, block_test(sm[i], h, blk), 31);          // sample i: bit NS-1-i
+        }
+        const bool single = hitmask != 0 && (hitmask & (hitmask - 1u)) == 0;
+        const uint64_t bm = __builtin_amdgcn_ballot_w64(single);
+        if (hitmask != 0 && !single) record((uint32_t)c, threadIdx.x, hitmask);          // two or more positives in one slice: a bait read, as ever
+        if (bm) {
+            const uint32_t off = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (single) {
+                const uint32_t bit = 31u - (uint32_t)__clz(hitmask), i = (uint32_t)(NS - 1) - bit;          // the one positive sample
+                const uint32_t lo = (i & 1u) ? ((i & 2u) ? sm[3] : sm[1]) : ((i & 2u) ? sm[2] : sm[0]);
+                const uint32_t hi = (i & 1u) ? ((i & 2u) ? sm[7] : sm[5]) : ((i & 2u) ? sm[6] : sm[4]);
+                lds_st(&s_qsm[off], (i & 4u) ? hi : lo); lds_st(&s_qch[off], (uint32_t)c); lds_st(&s_qid[off], threadIdx.x | (bit << 16));
+            }
+            q_n += (uint32_t)__popcll(bm);
+            MF_COMPILER_FENCE();
+            if (q_n >= 64u) drain();
+        }
+    };
+
+    u32x4 a[U], b[U];
+    uint64_t c = blockIdx.x;
+    if (c < n_chunks) load(c, a);
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < clear_vec4; i += cstep * blockDim.x) clear[i] = z;
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
+        if (threadIdx.x == 0) s_nrec = 0;
+    }
+    __syncthreads();
+    if (c < n_chunks) for (;;) {
+        if (c + cstep >= n_chunks) { stage1(c, a); break; }
+        load(c + cstep, b);
+        stage1(c, a);
+        c += cstep;
+        if (c + cstep >= n_chunks) { stage1(c, b); break; }
+        load(c + cstep, a);
+        stage1(c, b);
+        c += cstep;
+    }
+    while (q_n) drain();                                                    // what is left in the queue
     __syncthreads();
     if (threadIdx.x == 0) rec_counts[blockIdx.x] = s_nrec;
 }
@@ -1656,7 +1794,14 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     const uint64_t grid = screen_grid_for(R, n_cu, key);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
-    if (S.front_mode == 1) {          // LDS table, its positives through front2 (screen2_kernel)
+    if (S.front_mode == 3 && SPW == 1) {          // LDS table; lone positives queued and looked up in front2 sixty-four at a time (screen3_kernel)
+        const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + S3_LDS_EXTRA;
+        raise_lds_limit_once<&screen3_kernel<SCREEN_U>>(128 * 1024 + S3_LDS_EXTRA);
+        MF_LAUNCH((screen3_kernel<SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
+                  static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
+        return;
+    }
+    if (S.front_mode == 1 || S.front_mode == 3) {          // LDS table, its positives through front2 turn by turn (screen2_kernel; mode 3 falls here for the stride-8 geometries)
         const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + S2_LDS_EXTRA;
         raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, true>>(128 * 1024 + S2_LDS_EXTRA);
         MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, true>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,

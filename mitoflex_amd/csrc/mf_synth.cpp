@@ -20,7 +20,7 @@ static inline uint32_t get_base(const uint32_t *words, uint64_t g) { return (wor
 
 bool synth_reads(uint64_t n_reads, uint32_t L, uint64_t seed, const BaitHost &bait,
                  uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm,
-                 int threads, SynthOut &out, std::string &err)
+                 int threads, SynthOut &out, std::string &err, const SynthExtra &extra)
 {
     out = SynthOut();
     const uint64_t total = n_reads * (uint64_t)L;
@@ -50,11 +50,18 @@ bool synth_reads(uint64_t n_reads, uint32_t L, uint64_t seed, const BaitHost &ba
     // bait records usable as read sources
     std::vector<uint64_t> rstart, rlen; uint64_t s0 = 0;
     for (uint64_t l : bait.rec_len) { if (l >= L) { rstart.push_back(s0); rlen.push_back(l); } s0 += l; }
-    if (mito_ppm && rstart.empty()) { err = "no bait record is as long as read_len"; return false; }
+    if ((mito_ppm || extra.numt_ppm) && rstart.empty()) { err = "no bait record is as long as read_len"; return false; }
 
     for (uint64_t r = 0; r < n_reads; r++) {
         const uint64_t g0 = r * (uint64_t)L;
-        if (mito_ppm && h64(seed, 0xA5A5A5A5ULL, r) % 1000000ULL < mito_ppm) {
+        const bool numt = extra.numt_ppm && h64(seed, 0x5EED0010ULL, r) % 1000000ULL < extra.numt_ppm;
+        const uint32_t sub_here = numt ? extra.numt_div_ppm : sub_ppm;
+        if (extra.msat_ppm && !numt && h64(seed, 0x5EED0011ULL, r) % 1000000ULL < extra.msat_ppm) {
+            const uint64_t hm = h64(seed, 0x5EED0012ULL, r);
+            const uint32_t mlen = 1 + (uint32_t)(hm % 6);                     // motif of 1..6 bases, repeated
+            for (uint32_t j = 0; j < L; j++) set_base(W, g0 + j, (uint32_t)(hm >> (8 + 2 * (j % mlen))) & 3u);
+        } else
+        if (numt || (mito_ppm && h64(seed, 0xA5A5A5A5ULL, r) % 1000000ULL < mito_ppm)) {
             const uint64_t hr = h64(seed, 0x5EED0001ULL, r);
             const size_t rec = (size_t)(hr % rstart.size());
             const uint64_t pos = (hr >> 20) % (rlen[rec] - L + 1);
@@ -65,10 +72,10 @@ bool synth_reads(uint64_t n_reads, uint32_t L, uint64_t seed, const BaitHost &ba
                 if (bait.runlen[src] == 0) c = (uint32_t)(h64(seed, 0x5EED0002ULL, g0 + j) & 3);   // invalid bait base: random
                 else { c = get_base(bait.words.data(), src); if (rc) c = 3 - c; }
                 const uint64_t hs = h64(seed, 0x5EED0003ULL, g0 + j);
-                if (sub_ppm && hs % 1000000ULL < sub_ppm) c = (c + 1 + (uint32_t)((hs >> 32) % 3)) & 3;
+                if (sub_here && hs % 1000000ULL < sub_here) c = (c + 1 + (uint32_t)((hs >> 32) % 3)) & 3;
                 set_base(W, g0 + j, c);
             }
-            out.n_mito++;
+            if (!numt) out.n_mito++;
         }
         if (n_read_ppm && h64(seed, 0x5EED0004ULL, r) % 1000000ULL < n_read_ppm) {
             for (uint32_t j = 0; j < L; j++) {

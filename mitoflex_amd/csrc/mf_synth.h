@@ -20,8 +20,12 @@ struct SynthOut {
 // per-base substitution probability sub_ppm/1e6.  Read r carries invalid
 // bases iff a third hash % 1e6 < n_read_ppm, each base then invalid with
 // probability n_base_ppm/1e6.
+// "Real-data-shaped" extras (bench.py extra.realistic): msat_ppm of the reads are microsatellites (a random motif of 1..6 bases
+// repeated over the whole read: poly-A/T, (TA)n, ...), numt_ppm are NUMT-like (sampled from the bait like a bait read, but with
+// numt_div_ppm / 1e6 substitutions per base instead of sub_ppm).
+struct SynthExtra { uint32_t msat_ppm = 0, numt_ppm = 0, numt_div_ppm = 150000; };
 bool synth_reads(uint64_t n_reads, uint32_t read_len, uint64_t seed, const BaitHost &bait,
                  uint32_t mito_ppm, uint32_t sub_ppm, uint32_t n_read_ppm, uint32_t n_base_ppm,
-                 int threads, SynthOut &out, std::string &err);
+                 int threads, SynthOut &out, std::string &err, const SynthExtra &extra = SynthExtra());
 
 } // namespace mf

@@ -27,7 +27,7 @@ EXPORTS = (
     "mf_abi_version", "mf_last_error", "mf_device_count", "mf_device_name", "mf_device_synchronize",
     "mf_kmerset_build_from_fasta", "mf_kmerset_build_from_text", "mf_kmerset_build_protein_from_fasta",
     "mf_kmerset_build_protein_from_text", "mf_kmerset_info", "mf_kmerset_export",
-    "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_free_host",
+    "mf_kmerset_free", "mf_reads_from_packed", "mf_reads_from_fastq", "mf_reads_synth", "mf_reads_synth_ex", "mf_free_host",
     "mf_reads_info", "mf_reads_free", "mf_filter", "mf_filter_resident", "mf_filter_resident_passes", "mf_filter_packed",
     "mf_filter_fastq_files", "mf_filter_fastq_files_on", "mf_last_ingest_stats", "mf_h2d_bandwidth", "mf_set_option", "mf_qualfilter_files", "mf_release_cached",
 )
@@ -41,7 +41,8 @@ class KmerSetInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("key_words", C.c_int32), ("slots", C.c_uint64), ("n_keys", C.c_uint64),
                 ("n_windows", C.c_uint64), ("screen_s", C.c_int32), ("screen_stride", C.c_int32),
                 ("bloom_words", C.c_uint32), ("smer_slots", C.c_uint32), ("n_smers", C.c_uint64),
-                ("kind", C.c_int32), ("genetic_code", C.c_int32)]
+                ("kind", C.c_int32), ("genetic_code", C.c_int32),
+                ("front_mode", C.c_uint32), ("front2_log2_blocks", C.c_uint32), ("front3_log2_blocks", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ReadsInfo(C.Structure):
@@ -100,6 +101,9 @@ def load(path: Optional[str] = None):
     L.mf_reads_synth.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p, C.c_size_t,
                                  C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp),
                                  C.POINTER(u32p), u64p, C.POINTER(u64p), u64p]
+    L.mf_reads_synth_ex.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p, C.c_size_t,
+                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp),
+                                    C.POINTER(u32p), u64p, C.POINTER(u64p), u64p]
     L.mf_free_host.argtypes = [vp]
     L.mf_free_host.restype = None
     L.mf_reads_info.argtypes = [vp, C.POINTER(ReadsInfo)]
@@ -119,7 +123,7 @@ def load(path: Optional[str] = None):
     L.mf_qualfilter_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                       C.c_uint32, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
                                       C.POINTER(C.c_int)]
-    if L.mf_abi_version() != 4:
+    if L.mf_abi_version() != 5:
         raise MitoFilterError("libmitofilter_hip ABI version mismatch")
     _lib = L
     return L
@@ -233,7 +237,8 @@ class Reads:
 
     @classmethod
     def synth(cls, n_reads: int, read_len: int, seed: int, bait_text, mito_ppm=5000, sub_ppm=10000,
-              n_read_ppm=10000, n_base_ppm=1000, device: int = 0, keep_host: bool = False) -> "Reads":
+              n_read_ppm=10000, n_base_ppm=1000, device: int = 0, keep_host: bool = False,
+              msat_ppm: int = 0, numt_ppm: int = 0, numt_div_ppm: int = 150000) -> "Reads":
         if isinstance(bait_text, str):
             bait_text = bait_text.encode()
         h = C.c_void_p()
@@ -241,8 +246,8 @@ class Reads:
         if keep_host:
             wp, np_ = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)()
             nw, nn = C.c_uint64(), C.c_uint64()
-            _chk(L.mf_reads_synth(n_reads, read_len, seed, bait_text, len(bait_text), mito_ppm, sub_ppm, n_read_ppm,
-                                  n_base_ppm, device, C.byref(h), C.byref(wp), C.byref(nw), C.byref(np_), C.byref(nn)))
+            _chk(L.mf_reads_synth_ex(n_reads, read_len, seed, bait_text, len(bait_text), mito_ppm, sub_ppm, n_read_ppm,
+                                     n_base_ppm, msat_ppm, numt_ppm, numt_div_ppm, device, C.byref(h), C.byref(wp), C.byref(nw), C.byref(np_), C.byref(nn)))
             self = cls(h)
             self.host_words = np.ctypeslib.as_array(wp, shape=(nw.value + 8,)).copy()
             self.host_npos = (np.ctypeslib.as_array(np_, shape=(nn.value,)).copy() if nn.value
@@ -250,8 +255,8 @@ class Reads:
             L.mf_free_host(wp)
             L.mf_free_host(np_)
             return self
-        _chk(L.mf_reads_synth(n_reads, read_len, seed, bait_text, len(bait_text), mito_ppm, sub_ppm, n_read_ppm,
-                              n_base_ppm, device, C.byref(h), None, None, None, None))
+        _chk(L.mf_reads_synth_ex(n_reads, read_len, seed, bait_text, len(bait_text), mito_ppm, sub_ppm, n_read_ppm,
+                                 n_base_ppm, msat_ppm, numt_ppm, numt_div_ppm, device, C.byref(h), None, None, None, None))
         return cls(h)
 
     @property

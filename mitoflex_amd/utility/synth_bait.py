@@ -56,3 +56,29 @@ def random_bait(length: int, seed: int = 1, n_records: int = 0, line: int = 70) 
         out.append(">random_bait_%d len=%d" % (r, len(rec)))
         out.extend(rec[i:i + line] for i in range(0, len(rec), line))
     return "\n".join(out) + "\n"
+
+
+def ragged_offsets(total_bases: int, lo: int = 60, hi: int = 150, seed: int = 7):
+    """base offsets that cut a dense stream of `total_bases` into reads of lo..hi bases (what `filter_v2 -s/-e` and its quality
+    cuts leave of 150-base reads, /root/reference filter/filter_bin/src/main.rs:239-268 in spirit): u64[n + 1], offsets[0] = 0,
+    offsets[n] = total_bases"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_est = int(total_bases / ((lo + hi) / 2) * 1.02) + 16
+    lens = rng.integers(lo, hi + 1, size=n_est, dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(lens)))
+    n = int(np.searchsorted(off, total_bases, side="left"))
+    off = off[:n + 1].copy()
+    off[n] = total_bases                       # (the last read takes what is left: it may be shorter than lo)
+    return off.astype(np.uint64)
+
+
+def realistic_bait(seed: int = 20261004, length: int = 16569) -> str:
+    """A mitogenome-shaped bait for the low-complexity leg of bench.py: 68 % A+T (animal mitogenomes run 60-80 %), poly-T and poly-A runs
+    and a (TA)n stretch of the kind the control region carries; one record."""
+    rng = random.Random(seed)
+    g = "".join(rng.choices("ACGT", weights=[34, 16, 16, 34], k=length))
+    g = g[:3000] + "T" * 40 + g[3040:7000] + "A" * 35 + g[7035:15500] + "TA" * 60 + g[15620:]
+    g = g[:16000] + "T" * 18 + "C" + "T" * 14 + g[16033:]
+    lines = [">realistic_mito len=%d" % len(g)] + [g[i:i + 70] for i in range(0, len(g), 70)]
+    return "\n".join(lines) + "\n"

@@ -17,7 +17,7 @@ def test_exports_match_header(built_lib):
     assert declared == set(mitofilter.EXPORTS)
     for name in declared:
         assert hasattr(built_lib, name), name
-    assert built_lib.mf_abi_version() == 4
+    assert built_lib.mf_abi_version() == 5
 
 
 def test_no_cpu_fallback(built_lib):

@@ -85,3 +85,101 @@ def test_filter_v2_leg_builds_its_dictionary(bench, tmp_path):
     assert out["cli_outputs_equal"] and out["library_outputs_equal"]
     assert out["library_call"]["device"]["ingest_path"] == "device" and set(out["cli_process_start_to_exit"]) == {"device", "host"}
     assert [c[3] for c in lib.calls if c[0] == "qual"] == [None, None, None, "host"] and os.environ.get("MF_QUAL_INGEST") is None
+
+
+class FakeResident:
+    """stand-in for the resident-path API the axis legs of bench.py use: the 'GPU' bits come from the oracle itself, the timings are made up"""
+    MODE_SCREENED, MODE_EXHAUSTIVE = 0, 1
+
+    def __init__(self, ol):
+        self.ol = ol
+        outer = self
+
+        class KS:
+            def __init__(self, bait, k):
+                from mitoflex_amd.utility.synth_bait import bait_records
+                self.bait, self.k = bait, k
+                size = sum(len(r) for r in bait_records(bait))
+                mode = 0 if size < 20_000 else 3 if size < 60_000 else 1 if size < 105_000 else 2
+                self.info = types.SimpleNamespace(front_mode=mode, front2_log2_blocks=0 if mode == 0 else 15, front3_log2_blocks=20 if size > 2_000_000 else 0,
+                                                  n_keys=size, n_smers=2 * size)
+
+            @classmethod
+            def from_text(cls, bait, k, dev=0):
+                return cls(bait, k)
+
+            def close(self):
+                pass
+
+        class Reads:
+            def __init__(self, words, off, npos):
+                self.host_words, self.off, self.host_npos = words, off, npos
+                self.info = types.SimpleNamespace(n_reads=len(off) - 1)
+
+            @classmethod
+            def from_packed(cls, words, off, npos, dev=0):
+                return cls(words, off, npos)
+
+            @classmethod
+            def synth(cls, n, L, seed, bait_text, **kw):
+                import numpy as np
+                rng = np.random.default_rng(seed)
+                nw = (n * L + 15) // 16
+                return cls(rng.integers(0, 2**32, size=nw + 8, dtype=np.uint32), np.arange(n + 1, dtype=np.uint64) * L, np.zeros(0, np.uint64))
+
+            def close(self):
+                pass
+        self.KmerSet, self.Reads = KS, Reads
+
+    def _stats(self, reads):
+        n = reads.info.n_reads
+        return types.SimpleNamespace(n_reads=n, n_pass=3, n_candidates=n // 10, ms_total=0.25, ms_screen=0.24, ms_mark=0.0, ms_exact=0.05,
+                                     algorithmic_bytes=int(reads.off[-1]) // 4 + n // 8)
+
+    def filter_resident(self, ks, reads, thr, mode, steps):
+        return self._stats(reads)
+
+    def filter_reads(self, ks, reads, thr, mode, want_hits=False):
+        import numpy as np
+        n = reads.info.n_reads
+        R = self.ol.OracleReads.from_arrays(reads.host_words, reads.off, reads.host_npos)
+        bits, hits = self.ol.filter_reads(self.ol.OracleTable(ks.bait, ks.k), R, thr, threads=2)
+        return bits, (hits if want_hits else None), self._stats(reads)
+
+    def device_synchronize(self, dev):
+        pass
+
+
+def test_resident_axis_legs_build_their_dictionaries(bench):
+    """extra.bait_sweep / threshold_sweep / ragged / realistic: every key the legs read exists, the window checks run against the real
+    oracle, the dictionaries are JSON -- with a stand-in for the device"""
+    import numpy as np
+    from oracle import oracle_lib as ol
+    ol.lib()
+    from mitoflex_amd.utility.synth_bait import make_bait
+    lib = FakeResident(ol)
+    bait = make_bait()
+    a = types.SimpleNamespace(reads=3200, k=31)
+    reads = lib.Reads.synth(a.reads, 150, 5, bait)
+    ks = lib.KmerSet.from_text(bait, 31)
+    alg = 3200 * 150 // 4 + 400
+    out = bench.bait_sweep_leg(lib, reads, bait, a, 0, alg, (3200 * 150 + 15) // 16)
+    json.dumps(out)
+    assert set(out) == {"33000", "100000", "350000", "1000000", "8500000"}
+    assert [out[k]["roofline"]["bound"] for k in ("33000", "100000", "350000", "8500000")] == ["hbm", "valu", "l2_gather", "l2_gather"]
+    assert all(v["window_bits_match_oracle"] and v["window_reads_checked"] == 3200 for v in out.values())
+    assert out["8500000"]["front3_MiB"] == 16.0 and out["350000"]["roofline"]["peak"] == bench.GATHER_PEAK_GLOOKUPS
+    t = bench.threshold_leg(lib, ks, reads, bait, a, 0, alg)
+    json.dumps(t)
+    assert set(t) == {"1", "2", "7", "exhaustive"} and t["2"]["window_bits_match_oracle"] and t["exhaustive"]["roofline"]["bound"] == "valu"
+    r = bench.ragged_leg(lib, ks, reads, bait, a, 0, 0.22)
+    json.dumps(r)
+    assert 3200 * 150 / 150 <= r["reads"] <= 3200 * 150 / 60 and r["window_bits_match_oracle"]
+    z = bench.realistic_leg(lib, a, 0, 0.22)
+    json.dumps(z)
+    assert z["window_bits_match_oracle"] and z["roofline"]["bound"] == "hbm"
+
+
+def test_a_leg_that_raised_is_found(bench):
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "find_errors(extra" in src and "sys.exit(\"bench.py: legs that raised" in src
