@@ -156,34 +156,6 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
     // no returning global atomic, no division in the streaming loop -- mark_kernel finishes them.
     auto stage1 = [&](uint64_t c, const u32x4 (&d)[U], const uint32_t (&x)[U]) {
         uint32_t hitmask = 0;
-#ifdef MF_STAGE1_BATCH
-        // The table blocks of MF_STAGE1_BATCH samples are asked for together and tested behind a scheduling barrier: left to itself the
-        // compiler asks for two, waits for both, tests them, and a wave pays the LDS round trip eight times a chunk at the stride-8 geometries
-        // (four waves a SIMD do not cover it: 0.58 of the issue rate at k = 21).
-        constexpr int NS = U * 4 * SPW, B = MF_STAGE1_BATCH < NS ? MF_STAGE1_BATCH : NS;
-        uint32_t sm[NS];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int j = 0; j < SPW; j++) sm[(u * 4 + q) * SPW + j] = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
-        }
-#pragma unroll
-        for (int g0 = 0; g0 < NS; g0 += B) {
-            uint4 blk[B]; uint32_t h[B];
-#pragma unroll
-            for (int i = 0; i < B; i++) { h[i] = bloom_hash(sm[g0 + i]); blk[i] = s_tab4[__builtin_amdgcn_ubfe(h[i], idx_lo, idx_bits)]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < B; i++) {
-                const uint32_t t = lshl_by_byte<0>(sm[g0 + i], blk[i].x) & lshl_by_byte<1>(sm[g0 + i], blk[i].y) & lshl_by_byte<2>(sm[g0 + i], blk[i].z) & lshl_by_byte<1>(h[i], blk[i].w);
-                hitmask = alignbit(hitmask, t, 31);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t wv[5] = {d[u].x, d[u].y, d[u].z, d[u].w, SPW == 2 ? x[u] : 0u};
@@ -200,7 +172,6 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
                 }
             }
         }
-#endif
         if (hitmask) {
             const uint32_t slot = atomicAdd(&s_nrec, 1u);
             ScreenRec rec; rec.chunk = (uint32_t)c; rec.tid = threadIdx.x; rec.hitmask = hitmask; rec.pad = 0;
@@ -325,14 +296,16 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     // loads, so that the wait for it does not include those), tested behind this chunk's stage 1, and the last chunk's verified masks are
     // recorded before this chunk's positives go into the queue.  Nothing a load returns lives across a turn: with two copies of the
     // loop body (the stream's two register sets) a loop-carried load result ends in register copies that wait for the load at once.
-    uint32_t p_n = 0, p_sm = 0, p_id = 0; uint4 p_blk = make_uint4(0, 0, 0, 0);
+    uint32_t p_n = 0, p_sm = 0, p_id = 0, p_off = 0; uint4 p_blk = make_uint4(0, 0, 0, 0);
     uint64_t prev_c = 0;
+    const char *__restrict__ f2_bytes = reinterpret_cast<const char *>(S.front2);
     auto issue_prev = [&] {
         // UNCONDITIONAL gather (a lane without an entry asks for block 0, one request for all of them): a load the compiler cannot count
-        // makes its vmcnt waits conservative, and this chunk's stage 1 would wait for the gather instead of only for its own data
-        p_sm = lds_ld(&s_qsm[lane]); p_id = lds_ld(&s_qid[lane]);       // (beyond the queue's fill: stale bytes, never used)
-        const uint32_t bi = __builtin_amdgcn_ubfe(bloom_hash(p_sm), lo2, b2);
-        p_blk = f2[lane < p_n ? bi : 0u];
+        // makes its vmcnt waits conservative, and this chunk's stage 1 would wait for the gather instead of only for its own data.
+        // Nothing is computed here: the byte offset was made at the end of the last turn, and the load takes it as it is (scalar base +
+        // 32-bit vector offset).  A vector instruction at this spot got a register of the stream's next loads for its result and, in front
+        // of it, a wait for every load in flight -- one chunk in flight instead of two, 0.36 ms a pass instead of 0.29.
+        p_blk = *reinterpret_cast<const uint4 *>(f2_bytes + p_off);
     };
     auto settle_prev = [&] {          // test the round, then every lane takes (and clears) the verified mask of its slice of the last chunk
         // (the test itself is unconditional: a load whose only use sits in a branch is sunk into that branch by the compiler -- issued where it is waited for)
@@ -384,6 +357,8 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
             MF_COMPILER_FENCE();
             p_n = base < (uint32_t)S2_QCAP ? base : (uint32_t)S2_QCAP;      // the round is issued at the top of the next turn
             prev_c = c;
+            p_sm = lds_ld(&s_qsm[lane]); p_id = lds_ld(&s_qid[lane]);       // (beyond the queue's fill: stale values, never used)
+            p_off = lane < p_n ? __builtin_amdgcn_ubfe(bloom_hash(p_sm), lo2, b2) << 4 : 0u;
         } else {
             uint32_t mask = 0;                                          // G: gathers in flight per lane
 #pragma unroll
