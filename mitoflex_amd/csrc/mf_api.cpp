@@ -55,10 +55,15 @@ static std::map<int, DevCtx> g_ctx;
 // MF_FAKE_DEVICES=N: the library reports N logical devices and maps logical device d onto physical device d mod <visible>.
 // Every logical device has its own context (streams), bait tables and read sets, so the multi-device code paths -- batch
 // dealing in the file pipeline, one worker per device -- run for real on a single-GPU box (tests; not a performance mode).
+// A TEST HOOK: compiled into libmitofilter_hip_hooks.so (-DMF_TEST_HOOKS, what the multi-device tests load) and not into the shipped library.
 static int fake_devices()
 {
+#ifdef MF_TEST_HOOKS
     static const int n = [] { const char *v = getenv("MF_FAKE_DEVICES"); const int k = v ? atoi(v) : 0; return k > 0 && k <= 64 ? k : 0; }();
     return n;
+#else
+    return 0;
+#endif
 }
 static int physical_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 int phys(int device) { const int n = physical_count(); return fake_devices() && n > 0 ? device % n : device; }

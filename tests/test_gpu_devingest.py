@@ -15,6 +15,8 @@ import pytest
 from tests.util_data import make_reads, write_fastq
 
 pytestmark = pytest.mark.gpu
+# the library with the test hooks compiled in (MF_FAKE_DEVICES, MF_DEVPOOL_FAIL_AT): the shipped one carries neither
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mitoflex_amd", "libmitofilter_hip_hooks.so")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -355,7 +357,7 @@ def test_slabs_dealt_to_several_devices(ol, bait_text, tmp_path, n_dev):
     ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
     g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
     cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
-    env = dict(os.environ, MF_FAKE_DEVICES=str(n_dev), MF_PIPE_TIMING="1", MF_GZDEV_CHUNK_BYTES="8192", MF_GZDEV_SLAB_CHUNKS="5",
+    env = dict(os.environ, MITOFILTER_LIB=HOOKS_LIB, MF_FAKE_DEVICES=str(n_dev), MF_PIPE_TIMING="1", MF_GZDEV_CHUNK_BYTES="8192", MF_GZDEV_SLAB_CHUNKS="5",
                MF_GZDEV_TEXT_PIECE="200000")
     env.pop("MF_INGEST", None)
     for args in (["--devices", str(n_dev)], ["--device-list", ",".join(str(d) for d in reversed(range(1, n_dev)))]):
@@ -468,7 +470,7 @@ def test_a_failed_allocation_hands_the_call_to_the_host_pipeline(ol, bait_text, 
     ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
     g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
     cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
-    env = dict(os.environ, MF_PIPE_TIMING="1", MF_DEVPOOL_FAIL_AT=str(fail_at), MF_GZDEV_CHUNK_BYTES="16384", MF_GZDEV_SLAB_CHUNKS="8")
+    env = dict(os.environ, MITOFILTER_LIB=HOOKS_LIB, MF_PIPE_TIMING="1", MF_DEVPOOL_FAIL_AT=str(fail_at), MF_GZDEV_CHUNK_BYTES="16384", MF_GZDEV_SLAB_CHUNKS="8")
     env.pop("MF_INGEST", None)
     p = subprocess.run([cli, "bait", "--bait", bait, "-k", "31", "--fq1", fq1, "--fq2", fq2, "--out1", g1, "--out2", g2], capture_output=True, env=env, timeout=300)
     err = p.stderr.decode()

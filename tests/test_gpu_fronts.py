@@ -125,3 +125,27 @@ def test_bait_rich_input_through_the_fronts(mf, ol, bait_text, front):
         for _ in range(3):                      # (the pass kind adapts to what the last call saw)
             bits, _, _ = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
             assert np.array_equal(bits, obits), form
+
+
+def test_full_size_set_through_a_saturated_lds_table(mf, ol):
+    """configs[1]'s 33.3 M reads against a 350 kbp bait (the 128 KiB LDS table would pass three quarters of the samples: the library leaves it
+    out and looks every sample up in front2): the screened pass equals the exhaustive one on every one of the 33.3 M bits, both equal the
+    oracle on a 1.5 M-read window, and consecutive pipelined passes tally the same."""
+    from mitoflex_amd.utility.synth_bait import random_bait
+    bait = random_bait(350_000, seed=350_000)
+    ks = mf.KmerSet.from_text(bait, 31)
+    assert ks.info.front_mode == 2
+    n, L = 33_333_334, 150
+    reads = mf.Reads.synth(n, L, seed=20261003, bait_text=bait, keep_host=True)
+    b1, _, s1 = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
+    b2, _, s2 = mf.filter_reads(ks, reads, 1, mf.MODE_EXHAUSTIVE)
+    assert np.array_equal(b1, b2) and s1.n_pass == s2.n_pass
+    per, _ = mf.filter_resident_passes(ks, reads, 1, mf.MODE_SCREENED, 5)
+    assert [int(x) for x in per] == [int(s1.n_pass)] * 5
+    n_win = 1_500_000 // 32 * 32
+    off = np.arange(n_win + 1, dtype=np.uint64) * L
+    lim = n_win * L
+    R = ol.OracleReads.from_arrays(reads.host_words[:lim // 16 + 8], off, reads.host_npos[reads.host_npos < lim])
+    obits, _ = ol.filter_reads(ol.OracleTable(bait, 31), R, 1, threads=os.cpu_count() or 1)
+    assert np.array_equal(b1[:n_win // 32], obits[:n_win // 32])
+    assert 0.003 * n < int(s1.n_pass) < 0.008 * n

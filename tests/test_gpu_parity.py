@@ -12,6 +12,8 @@ import pytest
 from tests.util_data import bits_to_bool, make_reads, write_fastq
 
 pytestmark = pytest.mark.gpu
+# the library with the test hooks compiled in (MF_FAKE_DEVICES, MF_DEVPOOL_FAIL_AT): the shipped one carries neither
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mitoflex_amd", "libmitofilter_hip_hooks.so")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -369,7 +371,7 @@ def test_many_logical_devices_match_oracle(ol, bait_text, tmp_path, n_dev):
     ok, ot = ol.filter_fastq_files(bait, 31, 1, 0, fq1, fq2, o1, o2, threads=2)
     g1, g2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
     cli = os.path.join(ROOT, "mitoflex_amd", "assemble", "fastfilter")
-    env = dict(os.environ, MF_FAKE_DEVICES=str(n_dev), MF_BATCH_READS="300", MF_INGEST="host")          # (the host pipeline over N devices; the device path over N devices: test_gpu_devingest.py)
+    env = dict(os.environ, MITOFILTER_LIB=HOOKS_LIB, MF_FAKE_DEVICES=str(n_dev), MF_BATCH_READS="300", MF_INGEST="host")          # (the host pipeline over N devices; the device path over N devices: test_gpu_devingest.py)
     p = subprocess.run([cli, "bait", "--bait", bait, "-k", "31", "--fq1", fq1, "--fq2", fq2, "--out1", g1, "--out2", g2,
                         "--devices", str(n_dev)], capture_output=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[:2000]
