@@ -549,7 +549,7 @@ void reads_release(mf_reads *r)
             if (i < 2 && r->ev_call[i]) hipEventDestroy(r->ev_call[i]);
             if (r->ev_finish[i]) hipEventDestroy(r->ev_finish[i]);
         }
-        hipFree(r->d_hits); hipFree(r->d_npos_blk);
+        hipFree(r->d_hits); hipFree(r->d_npos_blk); hipFree(r->d_off_blk);
     }
     delete r;
 }
@@ -573,6 +573,12 @@ int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, ui
     const uint64_t n_blk = (total_bases >> NPOS_BLK_SHIFT) + 3;
     RCHK(dev_reserve(r->d_npos_blk, r->cap_npos_blk, n_blk * 4, reuse));
     RCHK(launch_build_npos_blk(r->d_npos, n_npos, n_blk, r->d_npos_blk, st));
+    if (!uniform_len) {                        // ragged reads: the block index over the offsets (a read per 1024 bases of the stream)
+        if (n_reads >= 0xFFFFFFFFull) return fail(MF_E_ARG, "more than 2^32 reads in one ragged read set");
+        const uint64_t n_oblk = (total_bases >> OFF_BLK_SHIFT) + 2;
+        RCHK(dev_reserve(r->d_off_blk, r->cap_off_blk, n_oblk * 4, reuse));
+        RCHK(launch_build_off_blk(r->d_offsets, n_reads, n_oblk, r->d_off_blk, st));
+    }
     r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;
     if (r->bitmap_bytes > r->cap_bitmap || !r->d_has_n) {     // the four bitmaps share one capacity
         size_t c[2 + NSETS] = {};
@@ -602,7 +608,7 @@ int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, ui
     ReadsView &V = r->v;
     V = ReadsView{};
     V.words = r->d_words; V.n_words = n_words; V.n_vec = (padded - 16) / 4;
-    V.offsets = uniform_len ? nullptr : r->d_offsets; V.uniform_len = uniform_len; V.n_reads = n_reads; V.total_bases = total_bases;
+    V.offsets = uniform_len ? nullptr : r->d_offsets; V.off_blk = uniform_len ? nullptr : r->d_off_blk; V.uniform_len = uniform_len; V.n_reads = n_reads; V.total_bases = total_bases;
     V.len_magic = uniform_len > 1 ? ~0ULL / uniform_len + 1 : 0;
     V.len_magic32 = (uniform_len > 1 && uniform_len <= 4096) ? 0xFFFFFFFFu / uniform_len + 1 : 0;
     V.npos = r->d_npos; V.n_npos = n_npos; V.npos_blk = r->d_npos_blk; V.has_n = r->d_has_n;

@@ -157,11 +157,14 @@ MF_HD void revcomp2(uint64_t lo, uint64_t hi, int k, uint64_t &rlo, uint64_t &rh
 
 // ---- plain-data views passed to kernels ------------------------------------
 constexpr int NPOS_BLK_SHIFT = 12;
+constexpr int OFF_BLK_SHIFT = 10;          // ragged read sets: one entry of the block index over `offsets` per 1024 bases
 struct ReadsView {
     const uint32_t *words;      // padded with zero words past n_words
     uint64_t        n_words;    // words holding bases
     uint64_t        n_vec;      // uint4 count the screen kernel walks (padded, zero tail)
     const uint64_t *offsets;    // n_reads+1 base offsets, nullptr when uniform_len > 0
+    const uint32_t *off_blk;    // ragged sets: off_blk[b] = the read that holds base b << OFF_BLK_SHIFT ((total_bases >> OFF_BLK_SHIFT) + 2 entries): the read
+                                // of a base is then a search over the few reads of a block instead of ~26 dependent loads over all offsets
     uint32_t        uniform_len;
     uint64_t        len_magic;  // ceil(2^64 / uniform_len): g / uniform_len == umulhi64(g, len_magic) while g * len < 2^64
     uint32_t        len_magic32;// ceil(2^32 / uniform_len), used for 32-bit offsets when uniform_len <= 4096 (else 0)

@@ -104,6 +104,13 @@ static int run_ingest(Ingest &I, const char *fq1, const char *fq2, const char *o
     const uint64_t budget = g_knobs.is_set(KN_INGEST_BUDGET_GB) ? g_knobs.u64(KN_INGEST_BUDGET_GB, 24) << 30
                                                          : std::min<uint64_t>((uint64_t)24 << 30, std::max<uint64_t>((uint64_t)3 << 30, 8 * gz_bytes));
     const uint64_t not_ours = (uint64_t)1200 << 20;
+    // (what the pool may hold on a device while this call runs, in use and idle together: idle buffers of an earlier call's shapes that this call
+    // cannot use go back to the runtime when its own would not fit beside them)
+    // (a plain file's text is what its buffers hold: two bytes per byte of it, where a .gz plans eight per compressed byte)
+    const uint64_t hold = g_knobs.is_set(KN_INGEST_BUDGET_GB) ? budget
+                        : std::min<uint64_t>((uint64_t)24 << 30, std::max<uint64_t>((uint64_t)3 << 30, 8 * gz_bytes + 2 * (in_bytes - gz_bytes)));
+    for (int d : I.devices) g_pool.set_limit(phys(d), hold - not_ours);
+    struct LimitOff { Ingest &I; ~LimitOff() { for (int d : I.devices) g_pool.set_limit(phys(d), 0); } } limit_off{I};
     const uint64_t gz_budget = (budget > 2 * not_ours ? (budget - not_ours) * 10 / 17 : budget / 4) / (uint64_t)I.nm;
     {   // (the two mates' decoders side by side)
         int rcs[2] = {MF_OK, MF_OK}; std::string errs[2]; std::thread th[2];

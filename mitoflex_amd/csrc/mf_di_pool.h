@@ -35,6 +35,18 @@ public:
                 return hipSuccess;
             }
         }
+        // Nothing idle fits.  A call's buffers and what idles beside them stay within the call's limit (run_ingest: what the call may hold on the
+        // device, which follows its input): a process that filters inputs of very different sizes in turn would otherwise carry the last call's
+        // 8 GB of idle buffers beside this call's own (14.8 GB in use for a 0.6 GB pair behind a 5 GB file) -- the idle ones go first, largest first.
+        {
+            size_t keep = ~(size_t)0;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                PerDev &D = dev_[dev];
+                if (D.limit && D.used + D.held + want > D.limit) { const size_t over = D.used + D.held + want - D.limit; keep = D.held > over ? D.held - over : 0; }
+            }
+            if (keep != ~(size_t)0) trim_dev(dev, keep, true);
+        }
         const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 #ifdef MF_TEST_HOOKS
         // (test hook, libmitofilter_hip_hooks.so only: MF_DEVPOOL_FAIL_AT=n makes the n-th new allocation of the process fail as if the device were full -- the
@@ -64,6 +76,7 @@ public:
         account(dev, -(long long)bytes);
     }
     size_t held(int dev) { std::lock_guard<std::mutex> lk(mu_); return dev_[dev].held; }          // bytes waiting for the next call
+    void set_limit(int dev, size_t bytes) { std::lock_guard<std::mutex> lk(mu_); dev_[dev].limit = bytes; }      // in use + idle on `dev` while a call runs (0: no limit)
     size_t release(int dev) { const size_t h = held(dev); trim_dev(dev, 0); return h; }          // the idle buffers of one device back to the runtime; returns their bytes
     size_t release_all() { size_t h = 0; std::vector<int> devs; { std::lock_guard<std::mutex> lk(mu_); for (auto &kv : dev_) { devs.push_back(kv.first); h += kv.second.held; } } for (int d : devs) trim_dev(d, 0); return h; }
     // high-water mark of the bytes in use (handed out and not yet returned) on any one device since reset_peak()
@@ -77,15 +90,15 @@ public:
         for (int d : devs) trim_dev(d, keep_per_dev);
     }
 private:
-    struct PerDev { std::multimap<size_t, void *> free_; size_t held = 0, used = 0, peak = 0; };
+    struct PerDev { std::multimap<size_t, void *> free_; size_t held = 0, used = 0, peak = 0, limit = 0; };
     void account(int dev, long long delta) { PerDev &D = dev_[dev]; D.used = (size_t)((long long)D.used + delta); if (D.used > D.peak) D.peak = D.used; }     // (mu_ held)
-    void trim_dev(int dev, size_t keep)
+    void trim_dev(int dev, size_t keep, bool largest_first = false)
     {
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lk(mu_);
             PerDev &D = dev_[dev];
-            while (D.held > keep && !D.free_.empty()) { auto it = D.free_.begin(); drop.push_back(it->second); D.held -= it->first; D.free_.erase(it); }
+            while (D.held > keep && !D.free_.empty()) { auto it = largest_first ? std::prev(D.free_.end()) : D.free_.begin(); drop.push_back(it->second); D.held -= it->first; D.free_.erase(it); }
         }
         if (drop.empty()) return;
         int cur = -1; (void)hipGetDevice(&cur);

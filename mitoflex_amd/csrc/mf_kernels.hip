@@ -67,8 +67,10 @@ __device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g,
         uint64_t off = g - r * R.uniform_len;
         return off + s <= R.uniform_len ? r : ~0ULL;
     }
-    // first offset > g, minus one
-    uint64_t lo = 0, hi = R.n_reads + 1;
+    // first offset > g, minus one -- searched inside the block of the index that holds g (a read of a 150-base set is found in three or
+    // four steps; over all offsets of a 5 Gbp set it took twenty-six dependent loads per positive: 0.49 ms a pass against 0.22 for uniform reads)
+    const uint64_t b = g >> OFF_BLK_SHIFT;
+    uint64_t lo = (uint64_t)R.off_blk[b] + 1, hi = (uint64_t)R.off_blk[b + 1] + 1;
     while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (R.offsets[mid] <= g) lo = mid + 1; else hi = mid; }
     uint64_t r = lo - 1;
     return g + s <= R.offsets[r + 1] ? r : ~0ULL;
@@ -1228,7 +1230,8 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
         uint64_t rq = 0; uint32_t rrem = 0;
         if (fast) { rq = __umul64hi(cb, R.len_magic); rrem = (uint32_t)(cb - rq * R.uniform_len); }
         uint32_t m = rec.hitmask;
-        uint32_t runs = fast ? m & run_ok : 0u;       // bit B (sample i) starts a run iff bits B, B-1, ..., B-(n_adj-1) are set
+        uint32_t runs = m & run_ok;                   // bit B (sample i) starts a run iff bits B, B-1, ..., B-(n_adj-1) are set (ragged reads too: whether a run lies
+                                                      // inside one read is looked up through the offsets' block index where it is taken up)
         for (uint32_t j = 1; j < n_adj; j++) runs &= m << j;
         if (PHASE == 0 && SPW == 1 && KW == 2 && fast) {
             // Runs across the lane border (k > 32; for shorter k a run is two samples and the extra arithmetic does not pay): the records of a list are in lane order, so the next record is usually the next lane
@@ -1496,6 +1499,17 @@ __global__ void build_npos_blk_kernel(const uint64_t *__restrict__ npos, uint64_
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
     blk[b] = (uint32_t)lower_bound_u64(npos, n_npos, b << NPOS_BLK_SHIFT);
+}
+
+// block index over the offsets of a ragged read set (one thread per block of 1024 bases): the read that holds the block's first base
+__global__ void build_off_blk_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_blk, uint32_t *__restrict__ blk)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blk) return;
+    const uint64_t v = b << OFF_BLK_SHIFT;
+    uint64_t lo = 0, hi = n_reads + 1;                 // first index with offsets[i] > v (n_reads + 1: none)
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= v) lo = mid + 1; else hi = mid; }
+    blk[b] = (uint32_t)(lo - 1);                       // (offsets[0] == 0 <= v: lo >= 1)
 }
 
 // mark reads that hold an invalid base (one thread per invalid position)
@@ -1925,6 +1939,12 @@ hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const
 hipError_t launch_build_npos_blk(const uint64_t *npos, uint64_t n_npos, uint64_t n_blk, uint32_t *blk, hipStream_t st)
 {
     hipLaunchKernelGGL(build_npos_blk_kernel, dim3(grid_for(n_blk, 256)), dim3(256), 0, st, npos, n_npos, n_blk, blk);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_off_blk(const uint64_t *offsets, uint64_t n_reads, uint64_t n_blk, uint32_t *blk, hipStream_t st)
+{
+    hipLaunchKernelGGL(build_off_blk_kernel, dim3(grid_for(n_blk, 256)), dim3(256), 0, st, offsets, n_reads, n_blk, blk);
     return hipGetLastError();
 }
 
