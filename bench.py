@@ -213,6 +213,17 @@ def live_traffic(k):
         "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script on this box (FETCH_SIZE x 2 on gfx950, KiB counters)"
 
 
+def cpu_throttled_usec():
+    """microseconds the container's cgroup has been throttled by its CPU quota so far (cgroup v2 cpu.stat), or None"""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_quota():
     """CPUs the container may actually use (cgroup v2 cpu.max), or None when unlimited / unknown: the oracle runs on
     every visible hardware thread, but a quota caps what those threads get."""
@@ -357,23 +368,28 @@ def e2e_files(mf, ks, files, a):
     each = {}          # every call's seconds of the last run() (the legs print them all: a minimum alone hides the call-to-call spread)
 
     def run(f1, f2, o1, o2, n_reads, reps=3, tag=None):
-        best, res, secs = 1e9, None, []
+        best, res, secs, thr = 1e9, None, [], []
         for i in range(reps):
+            th0 = cpu_throttled_usec()
             t0 = time.perf_counter()
             res = mf.filter_fastq_files(ks, f1, f2, o1, o2)
             dt = time.perf_counter() - t0
+            th1 = cpu_throttled_usec()
             if i == 0 and tag:
                 first_call[tag] = round(dt, 4)
             secs.append(round(dt, 4))
+            thr.append(round((th1 - th0) / 1e3, 1) if th0 is not None and th1 is not None else None)
             best = min(best, dt)
-        each["last"] = secs
+        each["last"], each["throttled"] = secs, thr
         return n_reads / best, best, res
 
     def spread():
         """seconds of every call of the last run(), their median and max / min"""
         v = sorted(each.get("last", []))
         return {"seconds_each": list(each.get("last", [])), "seconds_median": v[len(v) // 2] if v else None,
-                "max_over_min": round(v[-1] / v[0], 3) if v and v[0] > 0 else None}
+                "max_over_min": round(v[-1] / v[0], 3) if v and v[0] > 0 else None,
+                # the container's CPU quota at work: milliseconds (summed over its threads) this cgroup was throttled during each call
+                "cpu_throttled_ms_each": list(each.get("throttled", []))}
 
     def with_ingest(which, fn):
         prev = os.environ.get("MF_INGEST")

@@ -467,6 +467,7 @@ static int bait_main(int argc, char **argv)
         return 1;
     }
     if (k == 0) k = protein ? 9 : 31;
+    if (libpath.empty()) { const char *e = getenv("MITOFILTER_LIB"); if (e && *e) libpath = e; }          // (as the Python wrapper and filter_v2 do)
     if (libpath.empty()) libpath = exe_dir() + "/../libmitofilter_hip.so";
     mf::cold_mark("fastfilter bait: arguments read");
     void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);

@@ -396,6 +396,10 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         if (mode) {
             uint32_t lg = 10;
             while (lg < FRONT2_MAX_LOG2B && (4ull << lg) < bound) lg++;
+            // (baits of several Mbp: a 2 MiB front2 with more than ~32 s-mers a block passes nearly everything on to front3, a table beyond L2 that
+            // answers at a fifth of the rate -- a front2 of 4 or 8 MiB, slower per look-up, saves more of those than it costs:
+            // 4 Mbp 3.87 -> 2.59 ms a pass, 8.5 Mbp 6.88 -> 4.64, profiles/r06/d_front_variants2.txt)
+            while (lg < FRONT2_MAX_LOG2B + 2 && (bound >> lg) > 32) lg++;
             if (g_opt.front2_log2b > 0) lg = (uint32_t)g_opt.front2_log2b;
             ks->f2_log2b = lg;
             uint32_t lg3 = 0;

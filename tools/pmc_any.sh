@@ -31,6 +31,7 @@ PY
   rm -rf $D/p
 }
 ARGS=("$@")
+[ -n "$STATS_ONLY" ] && { rm -rf $D $D.err; cat $T; exit 0; }          # STATS_ONLY=1: the kernel statistics alone (a PMC pass of a 33 M-read set takes minutes)
 echo "# counters (per launch averages; rocprofv3 --pmc, one group a run)" >> $T
 pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS
