@@ -976,7 +976,9 @@ def main():
         leg("bait_sweep", lambda: bait_sweep_leg(mf, reads, bait, a, dev, alg_bytes, n_words_stream))
         leg("threshold_sweep", lambda: threshold_leg(mf, ks, reads, bait, a, dev, alg_bytes))
         if reads.host_words is not None:
-            leg("ragged", lambda: ragged_leg(mf, ks, reads, bait, a, dev, elapsed / a.steps * 1e3))
+            # (against the uniform set timed the same way: ten pipelined passes behind three warm-up calls -- threshold_sweep's T = 1 leg)
+            uni = extra.get("threshold_sweep", {}).get("1", {}).get("ms_per_step") or elapsed / a.steps * 1e3
+            leg("ragged", lambda: ragged_leg(mf, ks, reads, bait, a, dev, uni))
 
     cpu = None
     if want_cpu:
@@ -1004,7 +1006,7 @@ def main():
     if solo:
         reads.close()                                    # (the file-level runs want the device memory)
         if default_set and not a.no_axes:
-            leg("realistic", lambda: realistic_leg(mf, a, dev, elapsed / a.steps * 1e3))
+            leg("realistic", lambda: realistic_leg(mf, a, dev, extra.get("threshold_sweep", {}).get("1", {}).get("ms_per_step") or elapsed / a.steps * 1e3))
         if "skipped" in files or "error" in files:
             extra["e2e_files"] = {k: v for k, v in files.items() if k in ("skipped", "error")}
         else:

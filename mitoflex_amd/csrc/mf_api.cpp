@@ -577,7 +577,7 @@ int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, ui
     const uint64_t n_blk = (total_bases >> NPOS_BLK_SHIFT) + 3;
     RCHK(dev_reserve(r->d_npos_blk, r->cap_npos_blk, n_blk * 4, reuse));
     RCHK(launch_build_npos_blk(r->d_npos, n_npos, n_blk, r->d_npos_blk, st));
-    if (!uniform_len) {                        // ragged reads: the block index over the offsets (a read per 1024 bases of the stream)
+    if (!uniform_len) {                        // ragged reads: the block index over the offsets (a read per 128 bases of the stream)
         if (n_reads >= 0xFFFFFFFFull) return fail(MF_E_ARG, "more than 2^32 reads in one ragged read set");
         const uint64_t n_oblk = (total_bases >> OFF_BLK_SHIFT) + 2;
         RCHK(dev_reserve(r->d_off_blk, r->cap_off_blk, n_oblk * 4, reuse));

@@ -157,7 +157,7 @@ MF_HD void revcomp2(uint64_t lo, uint64_t hi, int k, uint64_t &rlo, uint64_t &rh
 
 // ---- plain-data views passed to kernels ------------------------------------
 constexpr int NPOS_BLK_SHIFT = 12;
-constexpr int OFF_BLK_SHIFT = 10;          // ragged read sets: one entry of the block index over `offsets` per 1024 bases
+constexpr int OFF_BLK_SHIFT = 7;           // ragged read sets: one entry of the block index over `offsets` per 128 bases (4 bytes per 32 bytes of stream)
 struct ReadsView {
     const uint32_t *words;      // padded with zero words past n_words
     uint64_t        n_words;    // words holding bases

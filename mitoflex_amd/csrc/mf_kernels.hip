@@ -57,23 +57,45 @@ __device__ __forceinline__ uint64_t npos_lower_bound(const ReadsView &R, uint64_
     return lo;
 }
 
-// read index holding global base g, or ~0 if the s bases from g do not lie in one read
-__device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g, uint32_t s)
+// read index holding global base g, or ~0 if the s bases from g do not lie in one read; *start (optional) = the read's first base
+__device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g, uint32_t s, uint64_t *start = nullptr)
 {
     if (g + s > R.total_bases) return ~0ULL;
     if (R.uniform_len) {
         // exact floor division by multiplication (g * uniform_len < 2^64 always holds here)
         uint64_t r = R.uniform_len > 1 ? __umul64hi(g, R.len_magic) : g;
         uint64_t off = g - r * R.uniform_len;
+        if (start) *start = g - off;
         return off + s <= R.uniform_len ? r : ~0ULL;
     }
-    // first offset > g, minus one -- searched inside the block of the index that holds g (a read of a 150-base set is found in three or
-    // four steps; over all offsets of a 5 Gbp set it took twenty-six dependent loads per positive: 0.49 ms a pass against 0.22 for uniform reads)
+    // Ragged reads: first offset > g, minus one.  The block index says which reads begin inside g's block of 128 bases -- rarely more than
+    // three -- and their offsets, the one in front and the one behind are asked for TOGETHER: two round trips (index, offsets) where a binary
+    // search over all offsets of a 5 Gbp set took twenty-six (0.49 ms a pass against 0.22 for uniform reads) and one inside a block of 1024
+    // bases five or six (0.355 ms).
     const uint64_t b = g >> OFF_BLK_SHIFT;
-    uint64_t lo = (uint64_t)R.off_blk[b] + 1, hi = (uint64_t)R.off_blk[b + 1] + 1;
-    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (R.offsets[mid] <= g) lo = mid + 1; else hi = mid; }
-    uint64_t r = lo - 1;
-    return g + s <= R.offsets[r + 1] ? r : ~0ULL;
+    const uint64_t lo = (uint64_t)R.off_blk[b] + 1;
+    uint64_t hi = (uint64_t)R.off_blk[b + 1] + 1;                                                  // the answer's index + 1 lies in [lo, hi]
+    if (hi > R.n_reads) hi = R.n_reads;                                                            // (g < total_bases = offsets[n_reads]: never beyond the last entry)
+    uint64_t first;                                                                                // first index with offsets[index] > g
+    uint64_t o_prev, o_first;                                                                      // offsets[first - 1], offsets[first]
+    if (hi - lo <= 3) {
+        const uint64_t om = R.offsets[lo - 1];
+        uint64_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = R.offsets[lo + j <= hi ? lo + j : hi];                 // (offsets[hi] exists: hi <= n_reads)
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) cnt += (lo + j < hi && o[j] <= g) ? 1u : 0u;                 // (monotone: the ones <= g come first)
+        first = lo + cnt;
+        o_prev = cnt == 0 ? om : cnt == 1 ? o[0] : cnt == 2 ? o[1] : o[2];
+        o_first = cnt == 0 ? o[0] : cnt == 1 ? o[1] : cnt == 2 ? o[2] : o[3];
+    } else {
+        uint64_t l = lo, h = hi;
+        while (l < h) { const uint64_t mid = (l + h) >> 1; if (R.offsets[mid] <= g) l = mid + 1; else h = mid; }
+        first = l; o_prev = R.offsets[first - 1]; o_first = R.offsets[first];
+    }
+    if (start) *start = o_prev;
+    return g + s <= o_first ? first - 1 : ~0ULL;
 }
 
 __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
@@ -1255,7 +1277,7 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
         // run start of its own inside the same read.  (Should that one fail -- rare: its two samples are bait s-mers -- the read
         // goes to phase 1, which looks at every positive.)
         uint32_t lf_runs = 0; bool lf = false;
-        if (PHASE == 0 && SPW == 1 && fast) {
+        if (PHASE == 0 && SPW == 1) {
             const uint32_t lc = __shfl_up(rec.chunk, 1), lt = __shfl_up(rec.tid, 1);
             lf_runs = __shfl_up(runs, 1);
             lf = (threadIdx.x & 63) != 0 && lc == rec.chunk && lt + 1 == rec.tid;
@@ -1291,8 +1313,16 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
                         }
                     }
                 } else {
-                    r = read_holding(R, g0, span);
+                    uint64_t r_start;
+                    r = read_holding(R, g0, span, &r_start);
                     if (r == ~0ULL) continue;
+                    if (PHASE == 0 && SPW == 1 && lf) {                                          // (as above, with the sample's offset inside its read looked up)
+                        const uint32_t nib = (lf_runs >> (4 * (U - 1 - su))) & 15u;
+                        if (nib) {
+                            const int qn = 3 - (__ffs(nib) - 1);
+                            if ((uint64_t)(64 + 16 * (sq - qn)) <= g0 - r_start) continue;
+                        }
+                    }
                 }
                 if (r == passed_r || r == passed_r2) continue;
                 got = true;
@@ -1501,7 +1531,7 @@ __global__ void build_npos_blk_kernel(const uint64_t *__restrict__ npos, uint64_
     blk[b] = (uint32_t)lower_bound_u64(npos, n_npos, b << NPOS_BLK_SHIFT);
 }
 
-// block index over the offsets of a ragged read set (one thread per block of 1024 bases): the read that holds the block's first base
+// block index over the offsets of a ragged read set (one thread per block of 128 bases): the read that holds the block's first base
 __global__ void build_off_blk_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_blk, uint32_t *__restrict__ blk)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
