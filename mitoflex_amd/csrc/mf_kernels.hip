@@ -58,7 +58,7 @@ __device__ __forceinline__ uint64_t npos_lower_bound(const ReadsView &R, uint64_
 }
 
 // read index holding global base g, or ~0 if the s bases from g do not lie in one read; *start (optional) = the read's first base
-__device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g, uint32_t s, uint64_t *start = nullptr)
+__device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g, uint32_t s, uint64_t *start = nullptr, uint64_t *end = nullptr)
 {
     if (g + s > R.total_bases) return ~0ULL;
     if (R.uniform_len) {
@@ -66,6 +66,7 @@ __device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g,
         uint64_t r = R.uniform_len > 1 ? __umul64hi(g, R.len_magic) : g;
         uint64_t off = g - r * R.uniform_len;
         if (start) *start = g - off;
+        if (end) *end = g - off + R.uniform_len;
         return off + s <= R.uniform_len ? r : ~0ULL;
     }
     // Ragged reads: first offset > g, minus one.  The block index says which reads begin inside g's block of 128 bases -- rarely more than
@@ -95,6 +96,7 @@ __device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g,
         first = l; o_prev = R.offsets[first - 1]; o_first = R.offsets[first];
     }
     if (start) *start = o_prev;
+    if (end) *end = o_first;
     return g + s <= o_first ? first - 1 : ~0ULL;
 }
 
@@ -636,8 +638,31 @@ mark_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint
             if (r == ~0ULL) { r = read_holding(R, g0, (uint32_t)S.s); if (r == ~0ULL) return; }
             mark(r);
         };
-        if (!fast) {                                  // ragged reads: every positive is looked up on its own
-            while (m) { const int bit = 31 - __clz(m); m &= ~(1u << bit); verify(NS - 1 - bit, ~0ULL); }
+        if (!fast) {
+            // Ragged reads: the positives of a lane are walked in stream order; the read of the first is looked up (block index over the
+            // offsets), the ones behind it inside the same read need no look-up, and -- as for uniform reads below -- two or more in one
+            // read mark it without fetching anything, a lone one goes through stage 2.  (One look-up and one verification per positive,
+            // nine for a bait read, made the mark kernel of a ragged 5 Gbp set 242 us against 76 for uniform reads.)
+            uint64_t cur_r = ~0ULL, cur_lo = 0, cur_hi = 0; int cur_idx = 0; uint32_t cur_n = 0;
+            auto flush = [&] {
+                if (cur_n >= 2) mark(cur_r);
+                else if (cur_n == 1) verify(cur_idx, cur_r);
+            };
+            while (m) {
+                const int bit = 31 - __clz(m);
+                m &= ~(1u << bit);
+                const int idx = NS - 1 - bit;
+                const uint64_t g0 = cb + off_of(idx);
+                if (cur_r != ~0ULL && g0 >= cur_lo && g0 + (uint64_t)S.s <= cur_hi) { cur_n++; continue; }
+                flush();
+                cur_n = 0; cur_r = ~0ULL;
+                if (g0 < cur_hi && cur_hi != 0 && g0 >= cur_lo) continue;                      // straddles the end of the read just left: not a sample of any read
+                uint64_t lo_, hi_;
+                const uint64_t r = read_holding(R, g0, (uint32_t)S.s, &lo_, &hi_);
+                if (r == ~0ULL) continue;
+                cur_r = r; cur_lo = lo_; cur_hi = hi_; cur_idx = idx; cur_n = 1;
+            }
+            flush();
         } else {
         // Uniform read length: the positives of a lane are walked in stream order and grouped by the read
         // they fall into (a division by multiplication each).  Two or more stage-1 positives of one lane
