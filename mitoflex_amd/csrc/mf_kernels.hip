@@ -463,7 +463,9 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
 // cost over screen_kernel is a dozen vector instructions; the look-ups cost one synchronous gather every tens of chunks.  The records, the
 // finish kernels and the emitted bits are what they were -- minus the false positives that cost a 33 kbp bait 0.306 ms a pass instead of 0.24.
 constexpr int S3_QN = 128;                 // queue entries per wave: fewer than 64 wait, a chunk adds at most 64
-constexpr size_t S3_LDS_EXTRA = 16 + (size_t)(SCREEN_BLOCK / 64) * (3 * S3_QN * 4);
+// (10 bytes an entry -- s-mer, chunk, 16-bit id -- and not 12: with 24 KiB of queues beside the 128 KiB table a finish workgroup's 8 KiB no longer
+// fit on the CU, and the finish kernels of pass i, which run under the screen of pass i + 1, were left the one CU in eight that screen does not take)
+constexpr size_t S3_LDS_EXTRA = 16 + (size_t)(SCREEN_BLOCK / 64) * (S3_QN * 10);
 
 template <int U>
 __global__ void __launch_bounds__(1024)
@@ -476,8 +478,10 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     const uint32_t nb4 = (1u << S.bloom_log2w) >> 2;
     uint32_t &s_nrec = *reinterpret_cast<uint32_t *>(s_tab4 + nb4);
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    lds_u32 *s_qsm = (lds_u32 *)(reinterpret_cast<uint32_t *>(s_tab4 + nb4 + 1)) + wid * (3 * S3_QN);
-    lds_u32 *s_qch = s_qsm + S3_QN, *s_qid = s_qch + S3_QN;
+    typedef __attribute__((address_space(3))) unsigned short lds_u16;
+    lds_u32 *s_qsm = (lds_u32 *)(reinterpret_cast<uint32_t *>(s_tab4 + nb4 + 1)) + wid * (S3_QN * 10 / 4);
+    lds_u32 *s_qch = s_qsm + S3_QN;
+    lds_u16 *s_qid = (lds_u16 *)(s_qch + S3_QN);          // lane-in-workgroup (10 bits) | bit of the hit mask (3 bits) << 10
     const u32x4 *__restrict__ w4 = reinterpret_cast<const u32x4 *>(R.words);
     const uint4 *__restrict__ f2 = reinterpret_cast<const uint4 *>(S.front2);
     const uint64_t chunk = (uint64_t)blockDim.x * U;
@@ -500,15 +504,15 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     // the first 64 entries of the queue through front2; the rest moves to the front
     auto drain = [&] {
         const uint32_t cnt = q_n < 64u ? q_n : 64u;
-        const uint32_t esm = lds_ld(&s_qsm[lane]), ech = lds_ld(&s_qch[lane]), eid = lds_ld(&s_qid[lane]);
-        const uint32_t tsm = lds_ld(&s_qsm[64 + lane]), tch = lds_ld(&s_qch[64 + lane]), tid2 = lds_ld(&s_qid[64 + lane]);
+        const uint32_t esm = lds_ld(&s_qsm[lane]), ech = lds_ld(&s_qch[lane]), eid = s_qid[lane];
+        const uint32_t tsm = lds_ld(&s_qsm[64 + lane]), tch = lds_ld(&s_qch[64 + lane]), tid2 = s_qid[64 + lane];
         if (lane < cnt) {
             const uint32_t hh = bloom_hash(esm);
             const uint4 blk = f2[__builtin_amdgcn_ubfe(hh, lo2, b2)];
-            if ((int32_t)block_test(esm, hh, blk) < 0) record(ech, eid & 0xFFFFu, 1u << (eid >> 16));
+            if ((int32_t)block_test(esm, hh, blk) < 0) record(ech, eid & 1023u, 1u << (eid >> 10));
         }
         MF_COMPILER_FENCE();
-        lds_st(&s_qsm[lane], tsm); lds_st(&s_qch[lane], tch); lds_st(&s_qid[lane], tid2);
+        lds_st(&s_qsm[lane], tsm); lds_st(&s_qch[lane], tch); s_qid[lane] = (unsigned short)tid2;
         q_n -= cnt;
     };
     auto stage1 = [&](uint64_t c, const u32x4 (&d)[U]) {
@@ -529,7 +533,7 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
                 const uint32_t bit = 31u - (uint32_t)__clz(hitmask), i = (uint32_t)(NS - 1) - bit;          // the one positive sample
                 const uint32_t lo = (i & 1u) ? ((i & 2u) ? sm[3] : sm[1]) : ((i & 2u) ? sm[2] : sm[0]);
                 const uint32_t hi = (i & 1u) ? ((i & 2u) ? sm[7] : sm[5]) : ((i & 2u) ? sm[6] : sm[4]);
-                lds_st(&s_qsm[off], (i & 4u) ? hi : lo); lds_st(&s_qch[off], (uint32_t)c); lds_st(&s_qid[off], threadIdx.x | (bit << 16));
+                lds_st(&s_qsm[off], (i & 4u) ? hi : lo); lds_st(&s_qch[off], (uint32_t)c); s_qid[off] = (unsigned short)(threadIdx.x | (bit << 10));
             }
             q_n += (uint32_t)__popcll(bm);
             MF_COMPILER_FENCE();

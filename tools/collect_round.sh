@@ -13,6 +13,9 @@ bash tools/prof_bench.sh $TAG > $O/prof_bench.log 2>&1; tail -4 $O/prof_bench.lo
 tools/prof_devingest.sh 33333334 p6 > $O/devingest_kernel_stats.txt 2>&1; head -14 $O/devingest_kernel_stats.txt | cut -c1-160
 bash tools/prof_gzdev_check.sh $TAG > /dev/null 2>&1; tail -3 $O/h_gzdev_check_under_rocprof.log; head -3 $O/h_gzdev_check_kernel_stats.csv | cut -c1-60,400-520
 bash tools/cold_calls.sh $TAG > /dev/null 2>&1; grep -E "^==|wall " $O/cold_calls.log | cut -c1-160
+# round 6: the bait-size axis with the screened == exhaustive check per size, and rocprofv3 kernel statistics of the 350 kbp leg
+SWEEP_CHECK=1 timeout 600 python tools/bait_sweep.py > $O/bait_sweep_final.txt 2>&1; cat $O/bait_sweep_final.txt | cut -c1-200
+STATS_ONLY=1 bash tools/pmc_any.sh s2_350k_stats --bait-size 350000 > /dev/null 2>&1; cp gpurun_out/r06/pmc_s2_350k_stats.txt $O/ 2>/dev/null
 python - <<PY
 import json
 d = json.load(open("$O/bench_shape_default.json"))
@@ -21,7 +24,11 @@ e = d["extra"]["e2e_files"]
 for k in ("se_gz_seconds", "se_gz_first_call_seconds", "se_gz_cli_cold"): print(k, e.get(k))
 c = e.get("configs4_se_gz", {})
 print("configs4", {k: c.get(k) for k in ("seconds", "first_call_seconds", "reads_per_s", "cli_cold", "device_memory_in_use_peak_GB", "output_equals_host_pipeline_on_plain_text")}, c.get("roofline", {}).get("frac"), c.get("inflate_kernels", {}).get("text_GB_per_s"))
-for k in ("configs4_se_plain", "configs1_pe_plain"): print(k, json.dumps(e.get(k))[:700])
+for k in ("configs4_se_plain", "configs1_pe_plain"): print(k, json.dumps(e.get(k))[:900])
+x = d["extra"]
+print("bait_sweep", {k: (round(v["ms_per_step"], 4), v["whole_pass_frac_of_hbm_peak"], v["roofline"]["bound"], v["roofline"]["frac"], v.get("window_bits_match_oracle")) for k, v in x.get("bait_sweep", {}).items() if "ms_per_step" in v})
+print("thresholds", {k: (round(v["ms_per_step"], 4), v.get("with_hit_counts", {}).get("ms_per_step"), v.get("roofline", {}).get("frac")) for k, v in x.get("threshold_sweep", {}).items() if "ms_per_step" in v})
+print("ragged", {k: x.get("ragged", {}).get(k) for k in ("ms_per_step", "ms_per_step_over_uniform", "window_bits_match_oracle")}, "realistic", {k: x.get("realistic", {}).get(k) for k in ("ms_per_step", "ms_per_step_over_iid", "whole_pass_frac_of_hbm_peak", "window_bits_match_oracle")})
 print("real", json.dumps(e.get("real_compressors"))[:900])
 print("fv2", json.dumps(d["extra"].get("filter_v2"))[:1200])
 print("k_sweep", {k: (v.get("reads_per_s"), v.get("whole_pass_frac_of_hbm_peak"), v.get("roofline", {}).get("frac")) for k, v in d["extra"].get("k_sweep", {}).items()})

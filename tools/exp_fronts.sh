@@ -1,8 +1,9 @@
 mkdir -p gpurun_out/r06
-O=gpurun_out/r06/g_front_k21.txt
+O=gpurun_out/r06/i_mode3_at_16k.txt
 : > $O
-run() { echo "## $*" >> $O; env "$@" SWEEP_CHECK=0 timeout 300 python tools/bait_sweep.py 33333334 $SIZES 21 >> $O 2>&1; }
-SIZES=16569,33000,50000,100000,350000 run X=default
-SIZES=33000,50000,100000 run SWEEP_OPTS=front=0
-SIZES=50000,100000 run SWEEP_OPTS=front=2
+run() { echo "## $*" >> $O; env "$@" SWEEP_CHECK=0 timeout 300 python tools/bait_sweep.py 33333334 $SIZES >> $O 2>&1; }
+for rep in 1 2 3; do
+SIZES=16569 run X=default
+SIZES=16569 run SWEEP_OPTS=front=3
+done
 cat $O
