@@ -602,8 +602,8 @@ int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, ui
     r->cand_clean[0] = true;
     for (int i = 1; i < NSETS; i++) r->cand_clean[i] = false;          // (the twins are allocated and cleared on first use)
     for (int i = 0; i < NSETS; i++) {
-        if (!r->d_counters[i]) RCHK(hipHostMalloc(reinterpret_cast<void **>(&r->d_counters[i]), 2 * EXACT_MAX_GRID * 16, hipHostMallocDefault));
-        memset(r->d_counters[i], 0, 2 * EXACT_MAX_GRID * 16);             // (no kernel of this handle is in flight: every call ends synchronised)
+        if (!r->d_counters[i]) RCHK(hipHostMalloc(reinterpret_cast<void **>(&r->d_counters[i]), 3 * EXACT_MAX_GRID * 16, hipHostMallocDefault));
+        memset(r->d_counters[i], 0, 3 * EXACT_MAX_GRID * 16);             // (no kernel of this handle is in flight: every call ends synchronised)
         RCHK(hipMemsetAsync(r->d_bits[i], 0, r->bitmap_bytes, st));
         if (!r->ev_screen[i]) RCHK(hipEventCreate(&r->ev_screen[i]));         // (attached to dispatches as completion events)
         if (!r->ev_finish[i]) RCHK(hipEventCreate(&r->ev_finish[i]));
@@ -812,7 +812,24 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         static const uint32_t nofin = env_u32("MF_NO_FINISH", 0);
         if (nofin) { if (two) HIPCHK(hipEventRecord(r->ev_finish[q], sf)); } else
 #endif
-        HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], tally_of(r, q), n_cu, sf, t2, two ? r->ev_finish[q] : nullptr));
+        {
+            // For k >= 48 (runs of four and more samples: fewer reads are settled by a run) phase 1 hands the reads that hold a bait s-mer outside
+            // any run to an exact kernel behind it, which deals a read's windows to eight lanes, instead of counting them on the one lane that met
+            // the s-mer: k = 63 0.283 -> 0.257 ms a pass.  Below that the third launch costs more than the tail it removes (k = 31 0.219 -> 0.226,
+            // k = 41 0.235 -> 0.248, 33 kbp bait 0.228 -> 0.262: profiles/r06/j_finish_exact_ab.txt).  The candidate bitmap of set q is clean
+            // (cleared when made, and the exact kernel clears what it consumes).
+#ifndef MF_FINISH_EXACT
+#define MF_FINISH_EXACT (S.k >= 48)
+#endif
+            uint32_t *cand = nullptr;
+            if (MF_FINISH_EXACT) {
+                if (!r->d_cand[q]) { size_t c = 0; HIPCHK(dev_reserve(r->d_cand[q], c, r->cap_bitmap, false)); r->cand_clean[q] = false; }
+                if (!r->cand_clean[q]) { HIPCHK(hipMemsetAsync(r->d_cand[q], 0, r->bitmap_bytes, sf)); r->cand_clean[q] = true; }
+                cand = r->d_cand[q];
+            }
+            HIPCHK(launch_finish(r->v, S, r->d_recs[q], r->d_rec_counts[q], r->d_bits[q], tally_of(r, q), n_cu, sf, t2, (two && !cand) ? r->ev_finish[q] : nullptr, cand));
+            if (cand) HIPCHK(launch_exact(r->v, S, cand, 1, false, r->d_bits[q], nullptr, tally_of(r, q) + 4 * (size_t)EXACT_MAX_GRID, n_cu, sf, nullptr, more, two ? r->ev_finish[q] : nullptr, true));
+        }
         r->sample_pass = true;
         r->cur = q;
         return MF_OK;
@@ -893,7 +910,7 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     if (pipelined) HIPCHK(hipStreamWaitEvent(ctx->stream3, e_begin, 0));
     // every pass's own tally block when the caller wants them all (tests: a buffer-set race that corrupted only the middle passes
     // of a pipelined call would not show in the last pass's tally)
-    constexpr size_t TALLY_WORDS = 2 * (size_t)EXACT_MAX_GRID * 2;
+    constexpr size_t TALLY_WORDS = 3 * (size_t)EXACT_MAX_GRID * 2;
     struct PinnedTmp { unsigned long long *p = nullptr; ~PinnedTmp() { if (p) (void)hipHostFree(p); } } all_tallies;
     if (pass_per_step) {
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&all_tallies.p), (size_t)steps * TALLY_WORDS * 8, hipHostMallocDefault));
@@ -917,12 +934,12 @@ int filter_common(const mf_kmerset *ks_, const mf_reads *reads_, uint32_t thr, i
     HIPCHK(hipStreamSynchronize(st));
     lap("synced");
     unsigned long long cnt[2] = {0, 0};
-    for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }
+    for (int i = 0; i < (two_halves ? 3 : 1) * EXACT_MAX_GRID; i++) { cnt[0] += part[2 * i]; cnt[1] += part[2 * i + 1]; }          // (a screen + finish pass: phase 0, phase 1, the exact kernel behind them)
     if (pass_per_step)
         for (int s = 0; s < steps; s++) {
             const unsigned long long *q = all_tallies.p + (size_t)s * TALLY_WORDS;
             uint64_t n = 0;
-            for (int i = 0; i < (two_halves ? 2 : 1) * EXACT_MAX_GRID; i++) n += q[2 * i];
+            for (int i = 0; i < (two_halves ? 3 : 1) * EXACT_MAX_GRID; i++) n += q[2 * i];
             pass_per_step[s] = n;
         }
     const bool adapt = g_opt.adapt != 0;          // (adapt = 0: measurements of the sample pass on bait-rich input)

@@ -24,15 +24,17 @@ uint64_t screen_rec_cap_for(const ReadsView &R, int n_cu, int stride);          
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                          const KernelTiming *tm = nullptr, uint32_t *clear = nullptr, uint64_t clear_vec4 = 0);
 // threshold 1, no hit counts: two launches of finish_kernel (runs, then the rest) settle every stage-1 record and set the pass
-// bits (bits must be clean).  partials: 2 * EXACT_MAX_GRID tally pairs (first half phase 0, second half phase 1).
+// bits (bits must be clean).  partials: 3 * EXACT_MAX_GRID tally pairs (phase 0, phase 1, the exact kernel behind them).
 // done (optional): an event that completes with the last finish kernel
+// cand (optional): a clean candidate bitmap -- phase 1 then marks the reads that hold a bait s-mer outside any run instead of counting their windows itself, and
+// the caller runs launch_exact(cand, thr = 1, merge = true) behind it (third tally region)
 hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
-                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr, hipEvent_t done = nullptr);
+                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm = nullptr, hipEvent_t done = nullptr, uint32_t *cand = nullptr);
 hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
                        hipStream_t st, const KernelTiming *tm = nullptr);
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *counters, int n_cu, hipStream_t st,
-                        const KernelTiming *tm = nullptr, bool coresident = false, hipEvent_t done = nullptr);
+                        const KernelTiming *tm = nullptr, bool coresident = false, hipEvent_t done = nullptr, bool merge = false);
 hipError_t launch_build_kbloom(const uint64_t *keys, uint64_t slots, int kw, uint32_t *kbloom, uint32_t kb_log2w, hipStream_t st);
 hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, uint64_t slots, uint32_t *postab_scratch,
                               hipStream_t st);

@@ -974,7 +974,7 @@ constexpr int WC_WORDS = 64 * WC_PER_LANE;         // ... per wave-chunk (8192 r
 template <int KW, bool COUNT_ALL, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t thr,
-             uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out, unsigned long long *__restrict__ partials)
+             uint32_t *__restrict__ out_bits, uint32_t *__restrict__ hits_out, unsigned long long *__restrict__ partials, uint32_t merge)
 {
     extern __shared__ uint4 s_mem4[];
     constexpr int WAVES = BLOCK / 64;
@@ -1074,7 +1074,7 @@ exact_kernel(ReadsView R, KmerSetView S, uint32_t *__restrict__ cand, uint32_t t
         for (int j = 0; j < WC_PER_LANE; j++) {
             const uint64_t wi = wbase + (uint64_t)lane * WC_PER_LANE + j;
             const uint32_t res = my_res[lane * WC_PER_LANE + j];
-            if (wi < n_bw) out_bits[wi] = res;
+            if (wi < n_bw) { if (!merge) out_bits[wi] = res; else if (res) atomicOr(&out_bits[wi], res); }      // merge: behind the finish kernels, whose bits stay
             tot_pass += __popc(res);
         }
     }
@@ -1226,7 +1226,7 @@ static_assert(FINISH_GRID <= EXACT_MAX_GRID, "tally buffer");          // phase 
 template <int SPW, int U, int KW, int PHASE>
 __global__ void __launch_bounds__(FINISH_BLOCK)
 finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, uint32_t rec_cap, const uint32_t *__restrict__ rec_counts,
-              uint32_t n_lists, uint32_t screen_block, uint32_t *__restrict__ bits, unsigned long long *__restrict__ partials)
+              uint32_t n_lists, uint32_t screen_block, uint32_t *__restrict__ bits, unsigned long long *__restrict__ partials, uint32_t *__restrict__ cand)
 {
     __shared__ uint32_t s_pre[EXACT_MAX_GRID + 1];           // exclusive prefix of the record counts
     __shared__ uint32_t s_tot[2];
@@ -1401,6 +1401,11 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
                     pend_old = atomicOr(&bits[r >> 5], bitm);              // the first setter of the bit counts the pass
                 }
             } else if (stab_contains(S, alignbit(raw[1], raw[0], sh) & smask)) {   // a true bait s-mer (either strand) outside any run
+                // With a candidate bitmap (the default): the read is handed to an exact kernel behind this launch, which deals its windows to
+                // eight lanes.  Counting a sample's sixteen windows right here, on this one lane, made the reads that have a bait s-mer but NO
+                // matching window -- a bait read with a substitution in every window: 1-2 % of them at k = 41 -- the tail of the launch: eight
+                // positives, eight serial sample_items, ~100 us (k = 41: phase 1 167 us against 105 without substitutions, profiles/r06/k41_phase_probe.txt).
+                if (cand) { atomicOr(&cand[r >> 5], bitm); passed_r2 = passed_r; passed_r = r; continue; }
                 // the windows this sample owns start at g0 - stride + 1 .. g0; the item tests 16 positions from the first of them
                 // that lies inside the read (positions past g0 belong to the next sample: harmless for threshold 1)
                 uint64_t b0, len;
@@ -1890,12 +1895,12 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, u
 }
 
 hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
-                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm, hipEvent_t done)
+                         unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm, hipEvent_t done, uint32_t *cand)
 {
     const int key = screen_grid_key(S.stride, S.front_mode);
     const uint64_t lists = screen_grid_for(R, n_cu, key);
     if (lists == 0) {               // (an empty read set) nothing to settle: the tallies read zero and `done` still completes, as in launch_exact
-        (void)hipMemsetAsync(partials, 0, 2 * EXACT_MAX_GRID * 16, st);
+        (void)hipMemsetAsync(partials, 0, 3 * EXACT_MAX_GRID * 16, st);
         if (done) (void)hipEventRecord(done, st);
         return hipGetLastError();
     }
@@ -1910,9 +1915,9 @@ hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *r
     static const unsigned fgrid = std::min<unsigned>(EXACT_MAX_GRID, std::max<unsigned>(64, getenv("MF_FINISH_GRID") ? (unsigned)atoi(getenv("MF_FINISH_GRID")) : FINISH_GRID));
 #define MF_LAUNCH_FINISH(SPW, KW) do { \
         MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 0>), dim3(fgrid), dim3(FINISH_BLOCK), 0, st, tm0, R, S, rc, cap, rec_counts, \
-                  (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); \
+                  (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials, cand); \
         MF_LAUNCH((finish_kernel<SPW, SCREEN_U, KW, 1>), dim3(fgrid), dim3(FINISH_BLOCK), 0, st, tm1, R, S, rc, cap, rec_counts, \
-                  (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials); } while (0)
+                  (uint32_t)lists, (uint32_t)SCREEN_BLOCK, bits, partials, cand); } while (0)
     if (S.stride == 16) { if (S.kw == 1) MF_LAUNCH_FINISH(1, 1); else MF_LAUNCH_FINISH(1, 2); }
     else                { if (S.kw == 1) MF_LAUNCH_FINISH(2, 1); else MF_LAUNCH_FINISH(2, 2); }
 #undef MF_LAUNCH_FINISH
@@ -1930,7 +1935,7 @@ hipError_t launch_mark(const ReadsView &R, const KmerSetView &S, const void *rec
 
 hipError_t launch_exact(const ReadsView &R, const KmerSetView &S_, uint32_t *cand, uint32_t thr, bool count_all,
                         uint32_t *out_bits, uint32_t *hits_out, unsigned long long *partials, int n_cu, hipStream_t st,
-                        const KernelTiming *tm, bool coresident, hipEvent_t done)
+                        const KernelTiming *tm, bool coresident, hipEvent_t done, bool merge)
 {
     const uint64_t n_bw = (R.n_reads + 31) >> 5;
     const uint64_t n_wc = (n_bw + WC_WORDS - 1) / WC_WORDS;
@@ -1950,7 +1955,7 @@ hipError_t launch_exact(const ReadsView &R, const KmerSetView &S_, uint32_t *can
     const KernelTiming *tmx = tm ? tm : (done ? &with_done : nullptr);
 #define MF_LAUNCH_EXACT(KW, CA, BLK) do { \
         raise_lds_limit_once<&exact_kernel<KW, CA, BLK>>(160 * 1024); \
-        MF_LAUNCH((exact_kernel<KW, CA, BLK>), dim3((unsigned)grid), dim3(BLK), lds, st, tmx, R, S, cand, thr, out_bits, hits_out, partials); } while (0)
+        MF_LAUNCH((exact_kernel<KW, CA, BLK>), dim3((unsigned)grid), dim3(BLK), lds, st, tmx, R, S, cand, thr, out_bits, hits_out, partials, merge ? 1u : 0u); } while (0)
     if (coresident) { if (S.kw == 1) MF_LAUNCH_EXACT(1, false, EXACT_BLOCK_CO); else MF_LAUNCH_EXACT(2, false, EXACT_BLOCK_CO); }
     else if (S.kw == 1) { if (count_all) MF_LAUNCH_EXACT(1, true, EXACT_BLOCK); else MF_LAUNCH_EXACT(1, false, EXACT_BLOCK); }
     else                { if (count_all) MF_LAUNCH_EXACT(2, true, EXACT_BLOCK); else MF_LAUNCH_EXACT(2, false, EXACT_BLOCK); }
