@@ -663,10 +663,11 @@ def bait_sweep_leg(mf, reads, base_bait, a, dev, alg_bytes, n_words):
         scr_s = sp.ms_screen / 1e3
         whole = alg_bytes / dt / 1e9 / HBM_PEAK_GBPS
         hbm = {"achieved": alg_bytes / scr_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / scr_s / 1e9 / HBM_PEAK_GBPS}
-        if inf.front_mode == 2:
-            look = n_words / scr_s / 1e9              # one 16-base sample per 32-bit word of the stream, each looked up in front2
-            roof = {"bound": "l2_gather", "achieved": look, "peak": GATHER_PEAK_GLOOKUPS, "unit": "G lookups/s", "frac": look / GATHER_PEAK_GLOOKUPS,
-                    "kernel": "screen2_kernel (front2 only)", "lookups_per_launch": int(n_words), "hbm": hbm,
+        if inf.front_mode in (2, 4):
+            look = n_words / scr_s / 1e9              # one 16-base sample per 32-bit word of the stream, each looked up in front2 (mode 4: or answered by the one-bit LDS table)
+            roof = {"bound": "l2_gather", "achieved": look, "peak": GATHER_PEAK_GLOOKUPS, "unit": "G samples/s against G lookups/s", "frac": look / GATHER_PEAK_GLOOKUPS,
+                    "kernel": "screen2_kernel (front2 only)" if inf.front_mode == 2 else "screen2_kernel (one-bit LDS table, then front2: the LDS table answers 1/2 - 2/3 of the samples itself, so `frac` can pass the look-up rate's share)",
+                    "lookups_per_launch": int(n_words), "hbm": hbm,
                     "peak_source": "tools/gather_roof.hip, profiles/r06/a_gather_roof.txt: random 16-byte gathers from <= 4 MiB, nothing else running (217 G/s beside a read stream)",
                     "note": "front3 look-ups of front2's survivors (baits of several Mbp: a table beyond L2, 55-80 G lookups/s) are not counted in `achieved`"}
         elif inf.front_mode == 1:

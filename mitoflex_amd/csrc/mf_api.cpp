@@ -127,7 +127,7 @@ static int ensure_pipeline_streams(DevCtx *c)
 struct DevTables {
     uint64_t *keys = nullptr;
     uint32_t *bloom = nullptr, *stab = nullptr, *kbloom = nullptr, *kbloom_co = nullptr, *plut = nullptr;    // kbloom_co: own allocation only when it differs from kbloom
-    uint32_t *front2 = nullptr, *front3 = nullptr;      // bait-sized fronts of the large-bait screen (front_mode 1, 2)
+    uint32_t *front2 = nullptr, *front3 = nullptr, *pre = nullptr;      // bait-sized fronts of the large-bait screen (front_mode 1 .. 4); mode 4's one-bit LDS table
     KmerSetView view{};
     uint64_t n_keys = 0, n_smers = 0;
 };
@@ -141,7 +141,7 @@ struct mf_kmerset {
     uint64_t n_windows = 0, slots = 0;
     ScreenGeom geom{0, 0};
     uint32_t bloom_log2w = 0, stage2_log2w = 0, stab_slots = 0, kb_log2w = 0;
-    uint32_t front_mode = 0, f2_log2b = 0, f3_log2b = 0;
+    uint32_t front_mode = 0, f2_log2b = 0, f3_log2b = 0, pre_log2w = 0;
     size_t screen_words() const { return ((size_t)1 << bloom_log2w) + ((size_t)1 << stage2_log2w); }
     std::mutex mu;
     std::map<int, DevTables> dev;
@@ -156,7 +156,7 @@ struct DevScratch {
 // tables under construction: released unless the build commits them
 struct TablesGuard {
     DevTables *t;
-    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->kbloom_co); hipFree(t->plut); hipFree(t->front2); hipFree(t->front3); } }
+    ~TablesGuard() { if (t) { hipFree(t->keys); hipFree(t->bloom); hipFree(t->stab); hipFree(t->kbloom); hipFree(t->kbloom_co); hipFree(t->plut); hipFree(t->front2); hipFree(t->front3); hipFree(t->pre); } }
 };
 // events of one timing loop
 struct EventList {
@@ -213,7 +213,7 @@ static int set_option(const char *name, const char *value)
     else if (n == "screen_streams") { if (x < 1 || x > 2) return -1; g_opt.screen_streams = (int)x; }
     else if (n == "split_pipe") g_opt.split_pipe = x != 0;
     else if (n == "exact_co") g_opt.exact_co = x != 0;
-    else if (n == "front") { if (x < -1 || x > 3) return -1; g_opt.front = (int)x; }
+    else if (n == "front") { if (x < -1 || x > 4) return -1; g_opt.front = (int)x; }
     else if (n == "front2_log2b") { if (x != 0 && (x < 6 || x > 24)) return -1; g_opt.front2_log2b = (int)x; }
     else if (n == "front3_log2b") { if (x < -1 || (x > 0 && x < 6) || x > 27) return -1; g_opt.front3_log2b = (int)x; }
     else return -1;
@@ -304,8 +304,12 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
                 HIPCHK(hipMemsetAsync(T.front3, 0, (size_t)16 << ks->f3_log2b, st));
             }
         }
+        if (ks->front_mode == 4) {
+            HIPCHK(dev_malloc(&T.pre, sizeof(uint32_t) << ks->pre_log2w));
+            HIPCHK(hipMemsetAsync(T.pre, 0, sizeof(uint32_t) << ks->pre_log2w, st));
+        }
         HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag,
-                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, st));
+                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, T.pre, ks->pre_log2w, st));
     }
     HIPCHK(dev_malloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
     HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
@@ -330,6 +334,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
     V.front_mode = ks->front_mode; V.f2_log2b = ks->f2_log2b; V.f3_log2b = ks->f3_log2b; V.front2 = T.front2; V.front3 = T.front3;
+    V.pre_log2w = ks->pre_log2w; V.pre = T.pre;
     // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
     V.use_stab = (T.n_smers / 2 * STAGE2_K > ((uint64_t)32 << ks->stage2_log2w) * 7 / 10) ? 1u : 0u;
 #ifdef MF_DEBUG_KNOBS              // (experiment builds only: `make variant VARFLAGS=-DMF_DEBUG_KNOBS`)
@@ -390,9 +395,14 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         const uint64_t per_lds_block = bound >> (ks->bloom_log2w - 2);
         int mode = per_lds_block <= 9 ? 0 : per_lds_block <= 26 ? 1 : 2;
         if (ks->geom.stride == 16 && per_lds_block > 5 && per_lds_block <= 14) mode = 3;
+        // mode 2's range up to ~1 Mbp: a ONE-bit table of the LDS's size still answers e^(-s-mers / 2^20) of the samples itself -- 67 % at 200 kbp, 51 % at
+        // 350 kbp, 14 % at 1 Mbp -- and only the rest is looked up (mode 4): 0.57 / 0.64 / 0.86 / 1.06 ms a pass at 150 / 200 / 350 / 500 kbp against 1.4-1.5,
+        // 1.28 against 1.59 at 700 kbp, 1.42 against 1.63 at 1 Mbp (profiles/r06/k_mode4.txt); beyond two million s-mers it passes everything and is left out
+        if (mode == 2 && bound <= (1u << 21)) mode = 4;
         options_from_env_once();
         if (g_opt.front >= 0) mode = g_opt.front;
         ks->front_mode = (uint32_t)mode;
+        ks->pre_log2w = mode == 4 ? 15 : 0;
         if (mode) {
             uint32_t lg = 10;
             while (lg < FRONT2_MAX_LOG2B && (4ull << lg) < bound) lg++;
@@ -405,7 +415,7 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
             uint32_t lg3 = 0;
             if ((bound >> lg) > 12) { lg3 = lg + 1; while (lg3 < 27 && (4ull << lg3) < bound) lg3++; }
             if (g_opt.front3_log2b >= 0) lg3 = (uint32_t)g_opt.front3_log2b;
-            ks->f3_log2b = mode == 2 ? lg3 : 0;          // (modes 1 and 3 keep their LDS table and never see a bait that overloads front2)
+            ks->f3_log2b = (mode == 2 || mode == 4) ? lg3 : 0;          // (modes 1 and 3 keep their LDS table and never see a bait that overloads front2)
         }
     }
     DevTables *T; int rc = build_on_device(ks, device, &T);
@@ -532,7 +542,7 @@ int mf_kmerset_free(mf_kmerset *ks)
 {
     if (!ks) return MF_OK;
     for (auto &kv : ks->dev) {
-        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.kbloom_co); hipFree(kv.second.plut); hipFree(kv.second.front2); hipFree(kv.second.front3); }
+        if (hipSetDevice(phys(kv.first)) == hipSuccess) { hipFree(kv.second.keys); hipFree(kv.second.bloom); hipFree(kv.second.stab); hipFree(kv.second.kbloom); hipFree(kv.second.kbloom_co); hipFree(kv.second.plut); hipFree(kv.second.front2); hipFree(kv.second.front3); hipFree(kv.second.pre); }
     }
     delete ks;
     return MF_OK;
@@ -1148,7 +1158,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3|4, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 

@@ -69,6 +69,8 @@ MF_HD uint32_t bloom_hash(uint32_t smer) { return (smer & 0xFFFFFFu) * 0x9E3779u
 MF_HD uint32_t stage1_index_lo(int s, uint32_t log2w) { const uint32_t ib = log2w - 2; return (uint32_t)(2 * s) >= ib ? (uint32_t)(2 * s) - ib : 0u; }
 MF_HD uint32_t stage1_field(uint32_t smer, uint32_t h, int i) { return ((i < 3 ? smer >> (8 * i) : h >> 8)) & 31u; }
 MF_HD uint32_t stage1_bit(uint32_t smer, uint32_t h, int i) { return 31u - stage1_field(smer, h, i); }
+// one-bit LDS table of mode 4: bit number among 1 << (log2w + 5), taken like a stage-1 block index (the bits of h that end just below bit 2s)
+MF_HD uint32_t pre_index_lo(int s, uint32_t log2w) { const uint32_t ib = log2w + 5; return (uint32_t)(2 * s) >= ib ? (uint32_t)(2 * s) - ib : 0u; }
 // the grid / record-list geometry a set's screen uses: the HBM-bound stride-16 screen leaves one CU in eight free (screen_grid_for);
 // every other screen -- stride 8, and the gather- and issue-bound screens of large baits -- takes every CU
 // (key 4: two workgroups a CU -- the front2-only screen of large baits holds few registers and no LDS table, and twice the gathers in flight)
@@ -201,8 +203,13 @@ struct KmerSetView {
     // an XCD's L2 (<= 4 MiB); front3 (only where front2 itself is overloaded: baits of several Mbp) is as large as the bait asks.
     uint32_t  front_mode;       // 0: LDS table only (screen_kernel) | 1: LDS table, its positives through front2 turn by turn | 2: every sample through front2
                                 // (no LDS table) | 3: LDS table, lone positives queued and looked up in front2 sixty-four at a time (screen3_kernel)
+                                // | 4: a one-bit LDS table in front of mode 2's look-ups
     uint32_t  f2_log2b, f3_log2b;   // blocks = 1 << log2b; f3_log2b == 0: no front3
     const uint32_t *front2, *front3;
+    // mode 4: a ONE-bit table for the LDS (1 << pre_log2w words, both strands inserted, bit = pre_bit(h)): at 100-500 kbp it still answers half to
+    // two thirds of the samples itself, and only the rest is looked up in front2
+    uint32_t  pre_log2w;
+    const uint32_t *pre;
     // protein-space set (peptide k-mers, 5 bits per residue; k = residues per key, kw = 1, no screen)
     uint32_t  prot;             // 1: keys are peptide k-mers and reads are translated in six frames
     uint32_t  kb_in_lds;        // the k-mer bit table is small enough to be staged in LDS

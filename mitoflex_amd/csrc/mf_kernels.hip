@@ -266,16 +266,18 @@ __device__ __forceinline__ uint32_t block_test(uint32_t sm, uint32_t h, const ui
     return lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);
 }
 
-template <int SPW, int U, bool LDSF, int G = 8>
+template <int SPW, int U, bool LDSF, int G = 8, bool PRE = false>
 __global__ void __launch_bounds__(1024, G == 8 ? 4 : 8)          // (G = 4, no LDS table: two workgroups share a CU)
 screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
                uint4 *__restrict__ clear, uint64_t clear_vec4)
 {
     extern __shared__ uint4 s_tab4[];                                       // [stage-1 table] record counter | verified masks | queues
     constexpr int NS = U * 4 * SPW;
-    const uint32_t nb4 = LDSF ? (1u << S.bloom_log2w) >> 2 : 0u;
+    const uint32_t nb4 = LDSF ? (1u << S.bloom_log2w) >> 2 : PRE ? (1u << S.pre_log2w) >> 2 : 0u;          // the stage-1 table, or mode 4's one-bit table
     uint32_t &s_nrec = *reinterpret_cast<uint32_t *>(s_tab4 + nb4);
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const lds_u32 *s_pre = (const lds_u32 *)reinterpret_cast<const uint32_t *>(s_tab4);
+    const uint32_t pre_lo = PRE ? pre_index_lo(S.s, S.pre_log2w) : 0u, pre_bits = PRE ? S.pre_log2w + 5 : 0u;
     lds_u32 *s_ver = (lds_u32 *)(reinterpret_cast<uint32_t *>(s_tab4 + nb4 + 1)) + wid * 64;
     // the queue as two arrays (s-mers, ids): one 8-byte store per entry wants its two halves in a register pair, and the register allocator
     // then keeps the chunk's words in pair positions of their own -- copied there from the stream loads' registers at the end of every
@@ -390,11 +392,24 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
 #pragma unroll
             for (int g0 = 0; g0 < NS; g0 += G) {
                 uint4 blk[G];                                               // (the hash is computed again where it is needed: a register each would cost the second workgroup of the CU)
+                uint32_t pre = (1u << G) - 1u;                              // sample g0 + i: bit G-1-i
+                if (PRE) {                                                  // mode 4: the one-bit LDS table first; only its positives are looked up
+                    pre = 0;
 #pragma unroll
-                for (int i = 0; i < G; i++) blk[i] = f2[__builtin_amdgcn_ubfe(bloom_hash(sm[g0 + i]), lo2, b2)];
+                    for (int i = 0; i < G; i++) {
+                        const uint32_t bi = __builtin_amdgcn_ubfe(bloom_hash(sm[g0 + i]), pre_lo, pre_bits);
+                        const uint32_t w = lds_ld(&s_pre[bi >> 5]);
+                        pre = alignbit(pre, w << (~bi & 31u), 31);          // the bit in the sign position
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < G; i++) if (!PRE || ((pre >> (G - 1 - i)) & 1u)) blk[i] = f2[__builtin_amdgcn_ubfe(bloom_hash(sm[g0 + i]), lo2, b2)];
                 uint32_t m = 0;
 #pragma unroll
-                for (int i = 0; i < G; i++) m = alignbit(m, block_test(sm[g0 + i], bloom_hash(sm[g0 + i]), blk[i]), 31);      // sample g0 + i: bit G-1-i
+                for (int i = 0; i < G; i++) {
+                    const uint32_t t = (!PRE || ((pre >> (G - 1 - i)) & 1u)) ? block_test(sm[g0 + i], bloom_hash(sm[g0 + i]), blk[i]) : 0u;
+                    m = alignbit(m, t, 31);
+                }
                 if (b3 && __ballot(m != 0)) {                           // the survivors through front3
 #pragma unroll
                     for (int i = 0; i < G; i++) if ((m >> (G - 1 - i)) & 1u) blk[i] = f3[__builtin_amdgcn_ubfe(bloom_hash(sm[g0 + i]), lo3, b3)];
@@ -418,8 +433,8 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < clear_vec4; i += cstep * blockDim.x) clear[i] = z;
-        if (LDSF) {
-            const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(S.bloom);
+        if (LDSF || PRE) {
+            const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(LDSF ? S.bloom : S.pre);
             for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) s_tab4[i] = src[i];
         }
         lds_st(&s_ver[lane], 0u); lds_st(&s_qsm[lane], 0u); lds_st(&s_qid[lane], 0u);
@@ -1508,7 +1523,8 @@ __device__ __forceinline__ void stab_insert(uint32_t sm, uint32_t *stab, uint32_
 }
 
 __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
-                                    uint32_t stab_mask, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b)
+                                    uint32_t stab_mask, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b,
+                                    uint32_t *pre, uint32_t pre_log2w)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B.total || B.runlen[p] < s) return;
@@ -1519,6 +1535,10 @@ __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t
     stage1_insert(fwd, s, bloom, log2w); stage1_insert(rc, s, bloom, log2w);
     if (front2) { stage1_insert(fwd, s, front2, f2_log2b + 2); stage1_insert(rc, s, front2, f2_log2b + 2); }      // the bait-sized fronts: the same blocks, more of them
     if (front3) { stage1_insert(fwd, s, front3, f3_log2b + 2); stage1_insert(rc, s, front3, f3_log2b + 2); }
+    if (pre) {                                          // mode 4's one-bit table
+        const uint32_t lo = pre_index_lo(s, pre_log2w), nb = pre_log2w + 5;
+        for (uint32_t v : {fwd, rc}) { const uint32_t bi = (bloom_hash(v) >> lo) & ((1u << nb) - 1u); atomicOr(&pre[bi >> 5], 1u << (bi & 31u)); }
+    }
     stab_insert(fwd, stab, stab_mask, has_ones); stab_insert(rc, stab, stab_mask, has_ones);
     const uint32_t cn = fwd < rc ? fwd : rc;
     const uint32_t ha = stage2_hash_a(cn), hb = stage2_hash_b(cn);
@@ -1861,6 +1881,13 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
                   static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
         return;
     }
+    if (S.front_mode == 4) {          // a one-bit LDS table, its positives through front2 (and front3): one workgroup a CU, eight gathers in flight per lane
+        const size_t lds = (sizeof(uint32_t) << S.pre_log2w) + S2_LDS_EXTRA;
+        raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, false, 8, true>>(128 * 1024 + S2_LDS_EXTRA);
+        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 8, true>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
+                  static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
+        return;
+    }
     if (S.front_mode == 2) {          // every sample through front2 (and front3): two workgroups a CU (its grid key says so), four gathers in flight per lane
         MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 4>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), S2_LDS_EXTRA, st, tm, R, S,
                   static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
@@ -1984,11 +2011,12 @@ hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, 
 }
 
 hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
-                               uint32_t stab_slots, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b, hipStream_t st)
+                               uint32_t stab_slots, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b,
+                               uint32_t *pre, uint32_t pre_log2w, hipStream_t st)
 {
     if (B.total == 0) return hipSuccess;
     hipLaunchKernelGGL(build_screen_kernel, dim3(grid_for(B.total, 256)), dim3(256), 0, st, B, s, bloom, log2w, log2w2, stab, stab_slots - 1, has_ones,
-                       front2, f2_log2b, front3, f3_log2b);
+                       front2, f2_log2b, front3, f3_log2b, pre, pre_log2w);
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 """GPU parity of the large-bait screens (screen2_kernel: front_mode 1 = LDS table + bait-sized front2 in L2 asked turn by turn, front_mode 2 =
-front2 (+ front3) only; screen3_kernel: front_mode 3 = LDS table, lone positives queued and asked sixty-four at a time): every form is forced onto small inputs through mf_set_option and held bit-exact to the CPU oracle, through the threshold-1
+front2 (+ front3) only, front_mode 4 = a one-bit LDS table in front of mode 2's look-ups; screen3_kernel: front_mode 3 = LDS table, lone positives queued and asked sixty-four at a time): every form is forced onto small inputs through mf_set_option and held bit-exact to the CPU oracle, through the threshold-1
 pass (screen + finish), the candidate-bitmap pass (mark + exact, hit counts) and at every screen geometry; then baits that really
 are large (100 kbp .. 2 Mbp), where the library picks the form itself.
 
@@ -43,7 +43,7 @@ def front(mf):
 
 # (mode, front2 log2 blocks, front3 log2 blocks): roomy tables, overloaded front2 (nearly everything passes: what a round cannot
 # verify is passed on), a front3 behind an overloaded front2, the smallest tables there are
-FORMS = [(1, 0, -1), (1, 6, -1), (2, 0, -1), (2, 6, 0), (2, 6, 12), (2, 8, 6), (3, 0, -1), (3, 6, -1)]
+FORMS = [(1, 0, -1), (1, 6, -1), (2, 0, -1), (2, 6, 0), (2, 6, 12), (2, 8, 6), (3, 0, -1), (3, 6, -1), (4, 0, -1), (4, 6, 8)]
 
 
 @pytest.mark.parametrize("k", [19, 21, 25, 28, 31, 32, 33, 41, 63])
@@ -85,16 +85,16 @@ def test_forced_forms_pipelined_passes(mf, ol, bait_text, front, form):
     assert np.array_equal(bits, obits)
 
 
-@pytest.mark.parametrize("size,k", [(30_000, 31), (30_000, 21), (50_000, 31), (100_000, 31), (100_000, 21), (350_000, 31), (350_000, 41), (2_000_000, 31)])
+@pytest.mark.parametrize("size,k", [(30_000, 31), (30_000, 21), (50_000, 31), (100_000, 31), (100_000, 21), (350_000, 31), (350_000, 41), (1_000_000, 31), (2_000_000, 31)])
 def test_large_baits_pick_their_screen(mf, ol, size, k):
-    """baits that are large for real: the library picks the form (LDS + front2 up to ~250 kbp, front2 alone beyond); bits and hit counts
+    """baits that are large for real: the library picks the form (LDS table + front2 up to ~105 kbp, a one-bit LDS table + front2 up to ~1 Mbp, front2 + front3 alone beyond); bits and hit counts
     equal the oracle's on 200 k reads (0.5 % bait reads, N), and the screened pass equals the exhaustive one"""
     from mitoflex_amd.utility.synth_bait import random_bait
     bait = random_bait(size, seed=size + k)
     ks = mf.KmerSet.from_text(bait, k)
-    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 100_000: 1, 350_000: 2, 2_000_000: 2}[size]
+    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 100_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 2}[size]
     assert ks.info.front_mode == want_mode, (size, k, ks.info.front_mode)
-    assert (ks.info.front3_log2_blocks > 0) == (size >= 2_000_000)
+    assert (ks.info.front3_log2_blocks > 0) == (size >= 1_000_000)
     n, L = 200_000, 150
     reads = mf.Reads.synth(n, L, seed=size, bait_text=bait, keep_host=True)
     off = np.arange(n + 1, dtype=np.uint64) * L
@@ -114,7 +114,7 @@ def test_large_baits_pick_their_screen(mf, ol, size, k):
 
 def test_bait_rich_input_through_the_fronts(mf, ol, bait_text, front):
     """every read a bait read: all of a wave's samples are positives, far more than its queue holds -- the overflow is passed on unverified"""
-    for form in [(1, 0, -1), (2, 0, -1), (3, 0, -1)]:
+    for form in [(1, 0, -1), (2, 0, -1), (3, 0, -1), (4, 0, -1)]:
         front(*form)
         ks = mf.KmerSet.from_text(bait_text, 31)
         n, L = 100_000, 150
@@ -134,7 +134,7 @@ def test_full_size_set_through_a_saturated_lds_table(mf, ol):
     from mitoflex_amd.utility.synth_bait import random_bait
     bait = random_bait(350_000, seed=350_000)
     ks = mf.KmerSet.from_text(bait, 31)
-    assert ks.info.front_mode == 2
+    assert ks.info.front_mode == 4          # (a one-bit LDS table in front of the look-ups; 2 Mbp and beyond take mode 2: test_large_baits_pick_their_screen)
     n, L = 33_333_334, 150
     reads = mf.Reads.synth(n, L, seed=20261003, bait_text=bait, keep_host=True)
     b1, _, s1 = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)

@@ -1,9 +1,8 @@
 mkdir -p gpurun_out/r06
-O=gpurun_out/r06/i_mode3_at_16k.txt
+O=gpurun_out/r06/k_mode4.txt
 : > $O
-run() { echo "## $*" >> $O; env "$@" SWEEP_CHECK=0 timeout 300 python tools/bait_sweep.py 33333334 $SIZES >> $O 2>&1; }
-for rep in 1 2 3; do
-SIZES=16569 run X=default
-SIZES=16569 run SWEEP_OPTS=front=3
-done
+run() { echo "## $*" >> $O; env "$@" SWEEP_CHECK=${CHECK:-0} timeout 400 python tools/bait_sweep.py 33333334 $SIZES >> $O 2>&1; }
+CHECK=1 SIZES=100000,150000,200000,350000,500000,700000,1000000 run X=default
+SIZES=60000,100000,700000,1000000 run SWEEP_OPTS=front=4
+SIZES=200000,350000,500000 run SWEEP_OPTS=front=2
 cat $O
