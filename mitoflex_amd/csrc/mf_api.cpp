@@ -588,9 +588,9 @@ int reads_finish(mf_reads *r, bool reuse, uint64_t n_words, uint64_t n_reads, ui
     RCHK(dev_reserve(r->d_npos_blk, r->cap_npos_blk, n_blk * 4, reuse));
     RCHK(launch_build_npos_blk(r->d_npos, n_npos, n_blk, r->d_npos_blk, st));
     if (!uniform_len) {                        // ragged reads: the block index over the offsets (a read per 128 bases of the stream)
-        if (n_reads >= 0xFFFFFFFFull) return fail(MF_E_ARG, "more than 2^32 reads in one ragged read set");
+        if (n_reads >= 0x7FFFFFFFull) return fail(MF_E_ARG, "more than 2^31 reads in one ragged read set");
         const uint64_t n_oblk = (total_bases >> OFF_BLK_SHIFT) + 2;
-        RCHK(dev_reserve(r->d_off_blk, r->cap_off_blk, n_oblk * 4, reuse));
+        RCHK(dev_reserve(r->d_off_blk, r->cap_off_blk, n_oblk * 8, reuse));
         RCHK(launch_build_off_blk(r->d_offsets, n_reads, n_oblk, r->d_off_blk, st));
     }
     r->bitmap_bytes = ((n_reads + 31) / 32 + 64) * 4;

@@ -50,7 +50,7 @@ struct mf_reads {
     int device = 0, lane = 0;     // lane: which of the device's contexts (streams) this read set works on
     mf::ReadsView v{};
     uint32_t *d_words = nullptr; uint64_t *d_offsets = nullptr, *d_npos = nullptr;
-    uint32_t *d_has_n = nullptr, *d_hits = nullptr, *d_npos_blk = nullptr, *d_off_blk = nullptr;
+    uint32_t *d_has_n = nullptr, *d_hits = nullptr, *d_npos_blk = nullptr; uint64_t *d_off_blk = nullptr;
     // Threshold-1 passes (screen_kernel + finish_kernel) are pipelined: the finish kernel of pass i runs on a second stream
     // under the screen kernel of pass i + 1, the way consecutive batches of a file do.  What a pass writes therefore
     // exists NSETS times and rotates: record lists, result bitmap, tally buffer.  `cur` holds the latest result.

@@ -157,6 +157,20 @@ MF_HD void revcomp2(uint64_t lo, uint64_t hi, int k, uint64_t &rlo, uint64_t &rh
     rhi = yhi >> sh;
 }
 
+// ---- block index over the offsets of a ragged read set -----------------------
+// entry of block b (bases B0 = b << 7 .. B0 + 127):
+//   bits  0..30  r0    the read that holds base B0 (the last read that begins at or before it)
+//   bits 31..38  back  B0 - (first base of r0), capped at 255
+//   bits 39..46  fwd   (first read start at or behind B0 + 128) - (B0 + 128), capped at 255
+//   bits 47..48  n     reads that begin inside the block behind B0 (1 .. 127): 0, 1, 2; 3 = more than two (the look-up falls back to a search)
+//   bits 49..55  p1    where the first of them begins (offset inside the block)
+//   bits 56..62  p2    ... the second
+struct OffBlk {
+    uint32_t r0, back, fwd, n, p1, p2;
+    MF_HD static OffBlk unpack(uint64_t e) { return OffBlk{(uint32_t)(e & 0x7FFFFFFFu), (uint32_t)(e >> 31) & 255u, (uint32_t)(e >> 39) & 255u, (uint32_t)(e >> 47) & 3u, (uint32_t)(e >> 49) & 127u, (uint32_t)(e >> 56) & 127u}; }
+    MF_HD uint64_t pack() const { return (uint64_t)r0 | ((uint64_t)back << 31) | ((uint64_t)fwd << 39) | ((uint64_t)n << 47) | ((uint64_t)p1 << 49) | ((uint64_t)p2 << 56); }
+};
+
 // ---- plain-data views passed to kernels ------------------------------------
 constexpr int NPOS_BLK_SHIFT = 12;
 constexpr int OFF_BLK_SHIFT = 7;           // ragged read sets: one entry of the block index over `offsets` per 128 bases (4 bytes per 32 bytes of stream)
@@ -165,8 +179,9 @@ struct ReadsView {
     uint64_t        n_words;    // words holding bases
     uint64_t        n_vec;      // uint4 count the screen kernel walks (padded, zero tail)
     const uint64_t *offsets;    // n_reads+1 base offsets, nullptr when uniform_len > 0
-    const uint32_t *off_blk;    // ragged sets: off_blk[b] = the read that holds base b << OFF_BLK_SHIFT ((total_bases >> OFF_BLK_SHIFT) + 2 entries): the read
-                                // of a base is then a search over the few reads of a block instead of ~26 dependent loads over all offsets
+    const uint64_t *off_blk;    // ragged sets: one 8-byte entry per block of 128 bases ((total_bases >> OFF_BLK_SHIFT) + 2 entries) that says which reads
+                                // the block holds and where they begin (OffBlk below): the read of a base is ONE load, where a binary search over
+                                // all offsets of a 5 Gbp set took twenty-six dependent ones
     uint32_t        uniform_len;
     uint64_t        len_magic;  // ceil(2^64 / uniform_len): g / uniform_len == umulhi64(g, len_magic) while g * len < 2^64
     uint32_t        len_magic32;// ceil(2^32 / uniform_len), used for 32-bit offsets when uniform_len <= 4096 (else 0)

@@ -65,7 +65,7 @@ hipError_t launch_pfilter(const ReadsView &R, const KmerSetView &S, uint32_t thr
 // npos_blk: n_blk = (total_bases >> NPOS_BLK_SHIFT) + 3 entries
 hipError_t launch_build_npos_blk(const uint64_t *npos, uint64_t n_npos, uint64_t n_blk, uint32_t *blk, hipStream_t st);
 // off_blk: n_blk = (total_bases >> OFF_BLK_SHIFT) + 2 entries (ragged read sets)
-hipError_t launch_build_off_blk(const uint64_t *offsets, uint64_t n_reads, uint64_t n_blk, uint32_t *blk, hipStream_t st);
+hipError_t launch_build_off_blk(const uint64_t *offsets, uint64_t n_reads, uint64_t n_blk, uint64_t *blk, hipStream_t st);
 hipError_t launch_mark_has_n(const ReadsView &R, uint32_t *has_n, hipStream_t st);
 
 } // namespace mf

@@ -69,35 +69,31 @@ __device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g,
         if (end) *end = g - off + R.uniform_len;
         return off + s <= R.uniform_len ? r : ~0ULL;
     }
-    // Ragged reads: first offset > g, minus one.  The block index says which reads begin inside g's block of 128 bases -- rarely more than
-    // three -- and their offsets, the one in front and the one behind are asked for TOGETHER: two round trips (index, offsets) where a binary
-    // search over all offsets of a 5 Gbp set took twenty-six (0.49 ms a pass against 0.22 for uniform reads) and one inside a block of 1024
-    // bases five or six (0.355 ms).
-    const uint64_t b = g >> OFF_BLK_SHIFT;
-    const uint64_t lo = (uint64_t)R.off_blk[b] + 1;
-    uint64_t hi = (uint64_t)R.off_blk[b + 1] + 1;                                                  // the answer's index + 1 lies in [lo, hi]
-    if (hi > R.n_reads) hi = R.n_reads;                                                            // (g < total_bases = offsets[n_reads]: never beyond the last entry)
-    uint64_t first;                                                                                // first index with offsets[index] > g
-    uint64_t o_prev, o_first;                                                                      // offsets[first - 1], offsets[first]
-    if (hi - lo <= 3) {
-        const uint64_t om = R.offsets[lo - 1];
-        uint64_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = R.offsets[lo + j <= hi ? lo + j : hi];                 // (offsets[hi] exists: hi <= n_reads)
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 3; j++) cnt += (lo + j < hi && o[j] <= g) ? 1u : 0u;                 // (monotone: the ones <= g come first)
-        first = lo + cnt;
-        o_prev = cnt == 0 ? om : cnt == 1 ? o[0] : cnt == 2 ? o[1] : o[2];
-        o_first = cnt == 0 ? o[0] : cnt == 1 ? o[1] : cnt == 2 ? o[2] : o[3];
-    } else {
-        uint64_t l = lo, h = hi;
-        while (l < h) { const uint64_t mid = (l + h) >> 1; if (R.offsets[mid] <= g) l = mid + 1; else h = mid; }
-        first = l; o_prev = R.offsets[first - 1]; o_first = R.offsets[first];
+    // Ragged reads: the block index says which reads g's block of 128 bases holds and where they begin -- ONE 8-byte load (OffBlk,
+    // mf_common.h) where a binary search over all offsets of a 5 Gbp set took twenty-six dependent ones (0.49 ms a pass against 0.22 for
+    // uniform reads), and an index of read numbers plus the candidates' offsets two round trips to tables far beyond the caches (0.32 ms).
+    const uint64_t b = g >> OFF_BLK_SHIFT, B0 = b << OFF_BLK_SHIFT;
+    const OffBlk e = OffBlk::unpack(R.off_blk[b]);
+    const uint32_t rel = (uint32_t)(g - B0);
+    if (e.n <= 2) {
+        const uint32_t cnt = (e.n >= 1 && e.p1 <= rel ? 1u : 0u) + (e.n >= 2 && e.p2 <= rel ? 1u : 0u);
+        const uint64_t r = (uint64_t)e.r0 + cnt;
+        // where the read begins (exact, or "255 bases or more in front of the block") and ends (exact, or "255 or more behind it")
+        const uint64_t r_lo = cnt == 0 ? B0 - e.back : B0 + (cnt == 1 ? e.p1 : e.p2);
+        uint64_t r_hi = cnt < e.n ? B0 + (cnt == 0 ? e.p1 : e.p2) : B0 + 128 + e.fwd;
+        if (end && cnt == e.n && e.fwd == 255u) r_hi = R.offsets[r + 1];          // (a caller that wants the exact end of a long read)
+        if (start) *start = r_lo;
+        if (end) *end = r_hi;
+        return g + s <= r_hi ? r : ~0ULL;                                          // (s <= 255: a capped end is far enough)
     }
+    // more than two reads begin inside the block (reads of a few bases): first offset > g, minus one, searched between this block's and the next one's read
+    uint64_t l = (uint64_t)e.r0 + 1, h = (uint64_t)(R.off_blk[b + 1] & 0x7FFFFFFFu) + 1;
+    if (h > R.n_reads) h = R.n_reads;                                              // (g < total_bases = offsets[n_reads]: never beyond the last entry)
+    while (l < h) { const uint64_t mid = (l + h) >> 1; if (R.offsets[mid] <= g) l = mid + 1; else h = mid; }
+    const uint64_t o_prev = R.offsets[l - 1], o_first = R.offsets[l];
     if (start) *start = o_prev;
     if (end) *end = o_first;
-    return g + s <= o_first ? first - 1 : ~0ULL;
+    return g + s <= o_first ? l - 1 : ~0ULL;
 }
 
 __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
@@ -1333,6 +1329,8 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
             // memory access for uniform read lengths, so positives that need nothing (outside any read, read already passed)
             // are skipped right here instead of costing the wave a turn of round trips.
             bool is_run = false, got = false; uint64_t g0 = 0, r = 0;
+            constexpr int NKW = KW == 1 ? 3 : 5;
+            uint32_t raw[NKW];                        // the words at the sample (ragged sets, phase 0: asked for beside the read's look-up)
             while (m) {
                 is_run = PHASE == 0;                                             // (phase 0: m holds the run starts only)
                 const int bit = 31 - __clz(m);
@@ -1357,6 +1355,11 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
                         }
                     }
                 } else {
+                    if (PHASE == 0) {                 // the run's words do not wait for its read: one round trip less per run start (four -> three)
+                        const uint32_t *__restrict__ wp = R.words + ((2 * g0) >> 5);
+#pragma unroll
+                        for (int i = 0; i < NKW; i++) raw[i] = wp[i];
+                    }
                     uint64_t r_start;
                     r = read_holding(R, g0, span, &r_start);
                     if (r == ~0ULL) continue;
@@ -1379,8 +1382,38 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
             const uint64_t wbit = 2 * g0;
             const uint32_t *__restrict__ w = R.words + (wbit >> 5);
             const uint32_t sh = (uint32_t)wbit & 31;
-            constexpr int NKW = KW == 1 ? 3 : 5;
-            uint32_t raw[NKW];
+            // the canonical k-mer at the sample, and whether it is a bait k-mer (phase 0: a run's window)
+            auto run_hit = [&]() -> bool {
+                uint64_t klo, khi = 0;
+                const uint64_t lo = (uint64_t)alignbit(raw[1], raw[0], sh) | ((uint64_t)alignbit(raw[2], raw[1], sh) << 32);
+                if (KW == 1) {
+                    const uint64_t fwd = lo & mask_lo, rc = revcomp1(fwd, k);
+                    klo = fwd < rc ? fwd : rc;
+                } else {
+                    const uint64_t hi = ((uint64_t)alignbit(raw[NKW - 2], raw[2], sh) | ((uint64_t)alignbit(raw[NKW - 1], raw[NKW - 2], sh) << 32)) & mask_hi;
+                    uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
+                    const bool fl = (hi < rhi) || (hi == rhi && lo < rlo);
+                    klo = fl ? lo : rlo; khi = fl ? hi : rhi;
+                }
+                return table_has<KW>(S, klo, khi, (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi)));
+            };
+            if (PHASE == 0 && !fast) {
+                // Ragged reads: the words are here (asked for beside the read's look-up), so the probe goes out TOGETHER with the read's has-N and
+                // pass bits instead of behind them -- a probe for a read that has passed meanwhile is wasted, a round trip per run start is not.
+                const uint32_t hn_w = R.has_n[r >> 5];
+                const uint32_t bw = __hip_atomic_load(&bits[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool hit = run_hit();
+                if (pend_bit && !(pend_old & pend_bit)) n_pass++;
+                pend_bit = 0;
+                if (bw & bitm) { passed_r2 = passed_r; passed_r = r; continue; }
+                if ((hn_w >> (r & 31)) & 1u) continue;
+                if (hit) {
+                    passed_r2 = passed_r; passed_r = r;
+                    pend_bit = bitm;
+                    pend_old = atomicOr(&bits[r >> 5], bitm);
+                }
+                continue;
+            }
             if (PHASE == 1) {          // nearly every record left over belongs to a read phase 0 has passed: look at its bit before fetching anything else
                 // (an ordinary cached load: phase 0 ended at a kernel boundary, so what it passed is visible; a read that another record
                 // of this launch passes meanwhile may be missed -- that costs the work below, not correctness)
@@ -1399,18 +1432,7 @@ finish_kernel(ReadsView R, KmerSetView S, const ScreenRec *__restrict__ recs, ui
             if (is_run && ((hn_w >> (r & 31)) & 1u)) continue;                   // invalid bases in the read: its positives come back as isolated ones
             // ---- round trip 2: one probe -- the k-mer table for a run, the exact s-mer table for an isolated positive
             if (PHASE == 0) {
-                uint64_t klo, khi = 0;
-                const uint64_t lo = (uint64_t)alignbit(raw[1], raw[0], sh) | ((uint64_t)alignbit(raw[2], raw[1], sh) << 32);
-                if (KW == 1) {
-                    const uint64_t fwd = lo & mask_lo, rc = revcomp1(fwd, k);
-                    klo = fwd < rc ? fwd : rc;
-                } else {
-                    const uint64_t hi = ((uint64_t)alignbit(raw[NKW - 2], raw[2], sh) | ((uint64_t)alignbit(raw[NKW - 1], raw[NKW - 2], sh) << 32)) & mask_hi;
-                    uint64_t rlo, rhi; revcomp2(lo, hi, k, rlo, rhi);
-                    const bool fl = (hi < rhi) || (hi == rhi && lo < rlo);
-                    klo = fl ? lo : rlo; khi = fl ? hi : rhi;
-                }
-                if (table_has<KW>(S, klo, khi, (uint32_t)(KW == 1 ? hash_key1(klo) : hash_key2(klo, khi)))) {
+                if (run_hit()) {
                     passed_r2 = passed_r; passed_r = r;
                     pend_bit = bitm;
                     pend_old = atomicOr(&bits[r >> 5], bitm);              // the first setter of the bit counts the pass
@@ -1585,15 +1607,33 @@ __global__ void build_npos_blk_kernel(const uint64_t *__restrict__ npos, uint64_
     blk[b] = (uint32_t)lower_bound_u64(npos, n_npos, b << NPOS_BLK_SHIFT);
 }
 
-// block index over the offsets of a ragged read set (one thread per block of 128 bases): the read that holds the block's first base
-__global__ void build_off_blk_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_blk, uint32_t *__restrict__ blk)
+// block index over the offsets of a ragged read set (one thread per block of 128 bases): OffBlk, mf_common.h
+__global__ void build_off_blk_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_blk, uint64_t *__restrict__ blk)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
-    const uint64_t v = b << OFF_BLK_SHIFT;
-    uint64_t lo = 0, hi = n_reads + 1;                 // first index with offsets[i] > v (n_reads + 1: none)
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= v) lo = mid + 1; else hi = mid; }
-    blk[b] = (uint32_t)(lo - 1);                       // (offsets[0] == 0 <= v: lo >= 1)
+    const uint64_t B0 = b << OFF_BLK_SHIFT, B1 = B0 + ((uint64_t)1 << OFF_BLK_SHIFT);
+    uint64_t lo = 0, hi = n_reads + 1;                 // first index with offsets[i] > B0 (n_reads + 1: none)
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= B0) lo = mid + 1; else hi = mid; }
+    OffBlk e{};
+    const uint64_t r0 = lo - 1;                        // (offsets[0] == 0 <= B0: lo >= 1)
+    e.r0 = (uint32_t)r0;
+    const uint64_t back = B0 - offsets[r0 <= n_reads ? r0 : n_reads];
+    e.back = back > 255 ? 255u : (uint32_t)back;
+    // the reads that begin inside the block behind its first base, and the first one that begins at or behind its end
+    uint32_t n = 0; uint64_t pos[3] = {0, 0, 0}; uint64_t next = ~0ULL;
+    for (uint64_t i = r0 + 1; i <= n_reads; i++) {
+        const uint64_t o = offsets[i];
+        if (o >= B1) { next = o; break; }
+        if (n < 3) pos[n] = o - B0;
+        n++;
+        if (n > 2) break;
+    }
+    e.n = n > 2 ? 3u : n;
+    e.p1 = (uint32_t)pos[0]; e.p2 = (uint32_t)pos[1];
+    const uint64_t fwd = next == ~0ULL ? 255 : next - B1;          // (no read start behind the block: the last read's end is offsets[n_reads], handled by the caller's total_bases check)
+    e.fwd = fwd > 255 ? 255u : (uint32_t)fwd;
+    blk[b] = e.pack();
 }
 
 // mark reads that hold an invalid base (one thread per invalid position)
@@ -2034,7 +2074,7 @@ hipError_t launch_build_npos_blk(const uint64_t *npos, uint64_t n_npos, uint64_t
     return hipGetLastError();
 }
 
-hipError_t launch_build_off_blk(const uint64_t *offsets, uint64_t n_reads, uint64_t n_blk, uint32_t *blk, hipStream_t st)
+hipError_t launch_build_off_blk(const uint64_t *offsets, uint64_t n_reads, uint64_t n_blk, uint64_t *blk, hipStream_t st)
 {
     hipLaunchKernelGGL(build_off_blk_kernel, dim3(grid_for(n_blk, 256)), dim3(256), 0, st, offsets, n_reads, n_blk, blk);
     return hipGetLastError();
