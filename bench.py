@@ -668,6 +668,8 @@ def bait_sweep_leg(mf, reads, base_bait, a, dev, alg_bytes, n_words):
             roof = {"bound": "l2_gather", "achieved": look, "peak": GATHER_PEAK_GLOOKUPS, "unit": "G samples/s against G lookups/s", "frac": look / GATHER_PEAK_GLOOKUPS,
                     "kernel": "screen2_kernel (front2 only)" if inf.front_mode == 2 else "screen2_kernel (one-bit LDS table, then front2: the LDS table answers 1/2 - 2/3 of the samples itself, so `frac` can pass the look-up rate's share)",
                     "lookups_per_launch": int(n_words), "hbm": hbm,
+                    "whole_pass_frac": n_words / dt / 1e9 / GATHER_PEAK_GLOOKUPS,
+                    "whole_pass_note": "samples a second of wall time over the gather roof: consecutive screens run on two streams in turn and overlap, so a launch lasts longer than a pass takes",
                     "peak_source": "tools/gather_roof.hip, profiles/r06/a_gather_roof.txt: random 16-byte gathers from <= 4 MiB, nothing else running (217 G/s beside a read stream)",
                     "note": "front3 look-ups of front2's survivors (baits of several Mbp: a table beyond L2, 55-80 G lookups/s) are not counted in `achieved`"}
         elif inf.front_mode == 1:
