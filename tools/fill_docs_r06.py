@@ -9,7 +9,11 @@ T = "%s passed, %s skipped" % (m.group(1), m.group(2)) if m else "?"
 bs=e['bait_sweep']
 def leg(k):
     v=bs[k]; r=v['roofline']
-    roof = {"hbm": "HBM %.2f" % r['frac'], "valu": "issue %.2f" % (r['frac'] or 0), "l2_gather": "%.2f of the gather roof" % r['frac']}[r['bound']]
+    if r['bound'] == 'l2_gather':
+        wp = r.get('whole_pass_frac') or r['lookups_per_launch'] / (v['ms_per_step'] * 1e-3) / 1e9 / r['peak']
+        roof = "samples/s over the gather roof %.2f a pass, %.2f a launch" % (wp, r['frac'])
+    else:
+        roof = {"hbm": "HBM %.2f" % r['frac'], "valu": "issue %.2f" % (r['frac'] or 0)}[r['bound']]
     return "%s (%.3f; %s)" % (ms(v['ms_per_step']), v['whole_pass_frac_of_hbm_peak'], roof)
 bait = " / ".join(leg(k) for k in ("33000","100000","350000","1000000","8500000"))
 bait_short = " / ".join("%s (%.3f)" % (ms(bs[k]['ms_per_step']), bs[k]['whole_pass_frac_of_hbm_peak']) for k in ("33000","100000","350000","1000000","8500000"))
