@@ -72,10 +72,11 @@ typedef struct {
     int32_t  genetic_code; /* NCBI translation table of a protein set, else 0 (ABI 2) */
     /* ABI 5: which screen a set of this size takes (the bait-size axis) */
     uint32_t front_mode;         /* 0 LDS table only | 1 LDS table, positives looked up in front2 turn by turn | 2 every sample through
-                                    front2 (+ front3), no LDS table | 3 LDS table, lone positives through front2 sixty-four at a time */
+                                    front2 (+ front3), no LDS table | 3 LDS table, lone positives through front2 sixty-four at a time |
+                                    4 a one-bit LDS table in front of mode 2's look-ups */
     uint32_t front2_log2_blocks; /* log2 of front2's 128-bit blocks (0: none) */
     uint32_t front3_log2_blocks; /* log2 of front3's 128-bit blocks (0: none) */
-    uint32_t reserved;
+    uint32_t canonical_screen;      /* 1: the screen's tables hold one canonical key per bait s-mer (16-base samples, larger baits) instead of one per strand */
 } mf_kmerset_info_t;
 
 typedef struct {

@@ -142,6 +142,7 @@ struct mf_kmerset {
     ScreenGeom geom{0, 0};
     uint32_t bloom_log2w = 0, stage2_log2w = 0, stab_slots = 0, kb_log2w = 0;
     uint32_t front_mode = 0, f2_log2b = 0, f3_log2b = 0, pre_log2w = 0;
+    bool canon = false;         // the screen's tables hold one canonical key per bait s-mer (KmerSetView::canon)
     size_t screen_words() const { return ((size_t)1 << bloom_log2w) + ((size_t)1 << stage2_log2w); }
     std::mutex mu;
     std::map<int, DevTables> dev;
@@ -197,6 +198,7 @@ struct PassOptions {
     // the large-bait screen (read when a k-mer set is BUILT; tests force every form on small baits)
     std::atomic<int> front{-1};           // -1 by the bait's size | 0 LDS table only | 1 LDS table + front2 | 2 front2 (+ front3) only | 3 LDS table, lone positives through front2   "front"   MF_FRONT
     std::atomic<int> front2_log2b{0};     // 0 by the bait's size | log2 of front2's 128-bit blocks (6..18)                         "front2_log2b"   MF_FRONT2_LOG2B
+    std::atomic<int> canon{-1};           // -1 by the bait's size | 0 both strands in the screen's tables | 1 one canonical key per s-mer (16-base samples only)             "canon"          MF_CANON
     std::atomic<int> front3_log2b{-1};    // -1 by the bait's size | 0 none | log2 of front3's blocks (6..27)                       "front3_log2b"   MF_FRONT3_LOG2B
 };
 static PassOptions g_opt;
@@ -215,6 +217,7 @@ static int set_option(const char *name, const char *value)
     else if (n == "exact_co") g_opt.exact_co = x != 0;
     else if (n == "front") { if (x < -1 || x > 4) return -1; g_opt.front = (int)x; }
     else if (n == "front2_log2b") { if (x != 0 && (x < 6 || x > 24)) return -1; g_opt.front2_log2b = (int)x; }
+    else if (n == "canon") { if (x < -1 || x > 1) return -1; g_opt.canon = (int)x; }
     else if (n == "front3_log2b") { if (x < -1 || (x > 0 && x < 6) || x > 27) return -1; g_opt.front3_log2b = (int)x; }
     else return -1;
     return 0;
@@ -226,7 +229,7 @@ static void options_from_env_once()
         if (k && k[0] == '1') {
             static const char *const pairs[][2] = {{"pass", "MF_PASS"}, {"adapt", "MF_ADAPT"}, {"finish_streams", "MF_FINISH_STREAMS"}, {"screen_streams", "MF_SCREEN_STREAMS"},
                                                    {"split_pipe", "MF_SPLIT_PIPE"}, {"exact_co", "MF_EXACT_CO"},
-                                                   {"front", "MF_FRONT"}, {"front2_log2b", "MF_FRONT2_LOG2B"}, {"front3_log2b", "MF_FRONT3_LOG2B"}};
+                                                   {"front", "MF_FRONT"}, {"front2_log2b", "MF_FRONT2_LOG2B"}, {"front3_log2b", "MF_FRONT3_LOG2B"}, {"canon", "MF_CANON"}};
             for (auto &p : pairs) { const char *v = getenv(p[1]); if (v && *v && set_option(p[0], v) != 0) fprintf(stderr, "libmitofilter_hip: %s=%s is not a value of option '%s' (ignored)\n", p[1], v, p[0]); }
         }
         return true;
@@ -309,7 +312,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
             HIPCHK(hipMemsetAsync(T.pre, 0, sizeof(uint32_t) << ks->pre_log2w, st));
         }
         HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag,
-                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, T.pre, ks->pre_log2w, st));
+                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, T.pre, ks->pre_log2w, ks->canon, st));
     }
     HIPCHK(dev_malloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
     HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
@@ -333,6 +336,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.smask = ks->geom.s >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ks->geom.s)) - 1);
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
+    V.canon = ks->canon ? 1u : 0u;
     V.front_mode = ks->front_mode; V.f2_log2b = ks->f2_log2b; V.f3_log2b = ks->f3_log2b; V.front2 = T.front2; V.front3 = T.front3;
     V.pre_log2w = ks->pre_log2w; V.pre = T.pre;
     // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
@@ -392,28 +396,37 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         // 0.306 (mode 1), 33 kbp 0.306 / 0.320, 50 kbp 0.441 / 0.340; 100 kbp 0.396 (mode 1) against 1.34 (mode 2).
         // front2: about four s-mers a block (0.02 % false positives), at most 2 MiB; front3 behind it where front2 holds more than twelve
         // a block (from ~800 kbp).
-        const uint64_t per_lds_block = bound >> (ks->bloom_log2w - 2);
-        int mode = per_lds_block <= 9 ? 0 : per_lds_block <= 26 ? 1 : 2;
-        if (ks->geom.stride == 16 && per_lds_block > 5 && per_lds_block <= 14) mode = 3;
-        // mode 2's range up to ~1 Mbp: a ONE-bit table of the LDS's size still answers e^(-s-mers / 2^20) of the samples itself -- 67 % at 200 kbp, 51 % at
-        // 350 kbp, 14 % at 1 Mbp -- and only the rest is looked up (mode 4): 0.57 / 0.64 / 0.86 / 1.06 ms a pass at 150 / 200 / 350 / 500 kbp against 1.4-1.5,
-        // 1.28 against 1.59 at 700 kbp, 1.42 against 1.63 at 1 Mbp (profiles/r06/k_mode4.txt); beyond two million s-mers it passes everything and is left out
-        if (mode == 2 && bound <= (1u << 21)) mode = 4;
         options_from_env_once();
+        uint64_t per_lds_block = bound >> (ks->bloom_log2w - 2);
+        // Canonical keys (16-base samples, i.e. k >= 31): from the size at which the LDS table stops screening a bait by itself, the screen's tables
+        // hold one key per bait s-mer instead of one per strand and every sample is made canonical before it is looked up (six vector
+        // instructions a sample, canon16) -- half the load on every table, so each form below reaches twice as far.  The six instructions cost the
+        // LDS-table screens 0.03-0.04 ms a pass (16.5 kbp: 0.231 -> 0.266; 50 kbp, queued form: 0.295 -> 0.32), so the keys turn canonical where the
+        // queued form with both strands ends (~61 kbp): 70 kbp 0.37 -> 0.32 ms a pass, 100 kbp 0.39 -> 0.36, 150 kbp 0.57 -> 0.40, 200 kbp 0.64 -> 0.45,
+        // 350 kbp 0.86 -> 0.62, 1 Mbp 1.42 -> 1.09, 8.5 Mbp 4.6 -> 3.4 (profiles/r06/m_canon.txt).
+        ks->canon = ks->geom.s == 16 && ks->geom.stride == 16 && (g_opt.canon < 0 ? per_lds_block > 14 : g_opt.canon == 1);
+        const uint64_t keys_bound = ks->canon ? bound / 2 : bound;          // keys the screen's tables hold
+        per_lds_block = keys_bound >> (ks->bloom_log2w - 2);
+        int mode = per_lds_block <= 9 ? 0 : per_lds_block <= 26 ? 1 : 2;
+        if (ks->geom.stride == 16 && per_lds_block > 5 && per_lds_block <= (ks->canon ? 12u : 14u)) mode = 3;          // (canonical keys: 100 kbp 0.36 queued against 0.37 turn by turn, 150 kbp 0.51 against 0.40)
+        // mode 2's range up to ~1 Mbp: a ONE-bit table of the LDS's size still answers e^(-keys / 2^20) of the samples itself -- 67 % at 200 kbp, 51 % at
+        // 350 kbp, 14 % at 1 Mbp (both strands) -- and only the rest is looked up (mode 4): 0.57 / 0.64 / 0.86 / 1.06 ms a pass at 150 / 200 / 350 / 500 kbp against 1.4-1.5,
+        // 1.28 against 1.59 at 700 kbp, 1.42 against 1.63 at 1 Mbp (profiles/r06/k_mode4.txt); beyond two million keys it passes everything and is left out
+        if (mode == 2 && keys_bound <= (1u << 21)) mode = 4;
         if (g_opt.front >= 0) mode = g_opt.front;
         ks->front_mode = (uint32_t)mode;
         ks->pre_log2w = mode == 4 ? 15 : 0;
         if (mode) {
             uint32_t lg = 10;
-            while (lg < FRONT2_MAX_LOG2B && (4ull << lg) < bound) lg++;
+            while (lg < FRONT2_MAX_LOG2B && (4ull << lg) < keys_bound) lg++;
             // (baits of several Mbp: a 2 MiB front2 with more than ~32 s-mers a block passes nearly everything on to front3, a table beyond L2 that
             // answers at a fifth of the rate -- a front2 of 4 or 8 MiB, slower per look-up, saves more of those than it costs:
             // 4 Mbp 3.87 -> 2.59 ms a pass, 8.5 Mbp 6.88 -> 4.64, profiles/r06/d_front_variants2.txt)
-            while (lg < FRONT2_MAX_LOG2B + 2 && (bound >> lg) > 32) lg++;
+            while (lg < FRONT2_MAX_LOG2B + 2 && (keys_bound >> lg) > 32) lg++;
             if (g_opt.front2_log2b > 0) lg = (uint32_t)g_opt.front2_log2b;
             ks->f2_log2b = lg;
             uint32_t lg3 = 0;
-            if ((bound >> lg) > 12) { lg3 = lg + 1; while (lg3 < 27 && (4ull << lg3) < bound) lg3++; }
+            if ((keys_bound >> lg) > 12) { lg3 = lg + 1; while (lg3 < 27 && (4ull << lg3) < keys_bound) lg3++; }
             if (g_opt.front3_log2b >= 0) lg3 = (uint32_t)g_opt.front3_log2b;
             ks->f3_log2b = (mode == 2 || mode == 4) ? lg3 : 0;          // (modes 1 and 3 keep their LDS table and never see a bait that overloads front2)
         }
@@ -524,7 +537,7 @@ int mf_kmerset_info(const mf_kmerset *ks, mf_kmerset_info_t *info)
     info->bloom_words = ks->geom.s ? (uint32_t)ks->screen_words() : 0; info->smer_slots = ks->stab_slots;
     if (!ks->dev.empty()) { info->n_keys = ks->dev.begin()->second.n_keys; info->n_smers = ks->dev.begin()->second.n_smers; }
     info->kind = ks->kind; info->genetic_code = ks->genetic_code;
-    info->front_mode = ks->front_mode; info->front2_log2_blocks = ks->front_mode ? ks->f2_log2b : 0; info->front3_log2_blocks = ks->f3_log2b;
+    info->front_mode = ks->front_mode; info->front2_log2_blocks = ks->front_mode ? ks->f2_log2b : 0; info->front3_log2_blocks = ks->f3_log2b; info->canonical_screen = ks->canon ? 1u : 0u;
     return MF_OK;
 }
 
@@ -1158,7 +1171,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3|4, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3|4, canon=-1|0|1, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 

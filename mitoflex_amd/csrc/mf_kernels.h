@@ -41,7 +41,7 @@ hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, 
 // front2 / front3 (optional): the bait-sized fronts of the large-bait screen, 1 << log2b blocks of 128 bits each, zeroed
 hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
                                uint32_t stab_slots, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b,
-                               uint32_t *pre, uint32_t pre_log2w, hipStream_t st);          // pre (optional): mode 4's one-bit LDS table, zeroed
+                               uint32_t *pre, uint32_t pre_log2w, bool canon, hipStream_t st);          // pre (optional): mode 4's one-bit LDS table, zeroed
 hipError_t launch_count_keys(const uint64_t *keys, uint64_t slots, int kw, const uint32_t *stab, uint64_t stab_slots,
                              unsigned long long *out2, hipStream_t st);
 // FASTQ quality filter: a record's (cut) sequence and quality strings as offsets into the uploaded text

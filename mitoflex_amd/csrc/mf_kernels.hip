@@ -140,6 +140,16 @@ __device__ __forceinline__ uint32_t lshl_by_byte(uint32_t amt, uint32_t data)
     return r;
 }
 
+// A 16-base sample or its reverse complement, whichever is smaller (revcomp_s(x, 16) in six vector instructions).  A set built CANONICAL
+// (KmerSetView::canon) inserts one key per bait s-mer into its screen tables instead of one per strand: half the load on the 128 KiB LDS table --
+// at 100 kbp it passes 1 % of the samples instead of 9 % -- for six instructions a sample.  What a screen kernel records is positions,
+// so nothing behind the screen knows.
+__device__ __forceinline__ uint32_t canon16(uint32_t x)
+{
+    const uint32_t y = __brev(~x);
+    const uint32_t rc = (0xAAAAAAAAu & (y << 1)) | (0x55555555u & (y >> 1));
+    return x < rc ? x : rc;
+}
 // A stage-1 positive record: everything mark_kernel needs to finish the job later.
 // One per (lane, chunk) that saw at least one positive.  Sample i of the lane's chunk slice
 // (i = (u*4+q)*SPW+j) is bit NS-1-i of hitmask, NS = U*4*SPW.
@@ -147,7 +157,7 @@ struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pa
 
 // SPW: samples per word (stride 16 -> 1, stride 8 -> 2).  For s < 16 a sample is the low 2s bits of what is hashed; the bits
 // above them ride along (stage1_index_lo in mf_common.h).
-template <int SPW, int U>
+template <int SPW, int U, bool CANON = false>
 __global__ void __launch_bounds__(1024)
 screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
               uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -186,7 +196,9 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
 #pragma unroll
                 for (int j = 0; j < SPW; j++) {
                     // the sample as it lies in the stream: for s < 16 the bases behind it ride along in the bits above 2s (stage1_index_lo)
-                    const uint32_t sm = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
+                    static_assert(!CANON || SPW == 1, "canonical keys are for 16-base samples");
+                    const uint32_t raw = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
+                    const uint32_t sm = CANON ? canon16(raw) : raw;
                     const uint32_t h = bloom_hash(sm);
                     const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];        // one v_bfe_u32
                     const uint32_t t = lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);   // stage1_field
@@ -262,7 +274,7 @@ __device__ __forceinline__ uint32_t block_test(uint32_t sm, uint32_t h, const ui
     return lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);
 }
 
-template <int SPW, int U, bool LDSF, int G = 8, bool PRE = false>
+template <int SPW, int U, bool LDSF, int G = 8, bool PRE = false, bool CANON = false>
 __global__ void __launch_bounds__(1024, G == 8 ? 4 : 8)          // (G = 4, no LDS table: two workgroups share a CU)
 screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
                uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -312,7 +324,11 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int j = 0; j < SPW; j++) sm[(u * 4 + q) * SPW + j] = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
+                for (int j = 0; j < SPW; j++) {
+                    static_assert(!CANON || SPW == 1, "canonical keys are for 16-base samples");
+                    const uint32_t raw = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
+                    sm[(u * 4 + q) * SPW + j] = CANON ? canon16(raw) : raw;          // (the key every table of the screen is asked with)
+                }
         }
     };
 
@@ -478,7 +494,7 @@ constexpr int S3_QN = 128;                 // queue entries per wave: fewer than
 // fit on the CU, and the finish kernels of pass i, which run under the screen of pass i + 1, were left the one CU in eight that screen does not take)
 constexpr size_t S3_LDS_EXTRA = 16 + (size_t)(SCREEN_BLOCK / 64) * (S3_QN * 10);
 
-template <int U>
+template <int U, bool CANON = false>
 __global__ void __launch_bounds__(1024)
 screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
                uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -502,6 +518,7 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     const uint64_t cstep = gridDim.x;
     ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
     uint32_t q_n = 0;                                                       // entries in this wave's queue (wave-uniform)
+    uint32_t e_w = 0, t_w = 0;                                              // canonical keys: what this wave has recorded and queued, and its turns (wave-uniform)
 
     auto load = [&](uint64_t c, u32x4 (&d)[U]) {
 #pragma unroll
@@ -528,27 +545,55 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     };
     auto stage1 = [&](uint64_t c, const u32x4 (&d)[U]) {
         uint32_t hitmask = 0;
-        const uint32_t sm[NS] = {d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, d[1].y, d[1].z, d[1].w};
+        uint32_t sm[NS] = {d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, d[1].y, d[1].z, d[1].w};
+        if (CANON) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) sm[i] = canon16(sm[i]);          // (the key the LDS table and front2 are asked with, and what is queued)
+        }
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             const uint32_t h = bloom_hash(sm[i]);
             const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];
             hitmask = alignbit(hitmask, block_test(sm[i], h, blk), 31);          // sample i: bit NS-1-i
         }
-        const bool single = hitmask != 0 && (hitmask & (hitmask - 1u)) == 0;
-        const uint64_t bm = __builtin_amdgcn_ballot_w64(single);
-        if (hitmask != 0 && !single) record((uint32_t)c, threadIdx.x, hitmask);          // two or more positives in one slice: a bait read, as ever
-        if (bm) {
+        // Both strands in the table: a slice with two or more positives is a bait read (two independent false positives in eight samples: 1e-4 at
+        // 0.4 %) and is recorded as ever; only lone positives are queued.  Canonical keys: the form serves baits whose table passes 1 % and more,
+        // where two false positives in a slice are no longer rare (0.3 % of the slices at 100 kbp: 0.6 M of a pass's 1.3 M work items) -- a slice
+        // is recorded as it is only when two NEIGHBOURING samples are positive (what a bait read shows, and what the finish kernel's run detection
+        // needs in one record: 7e-4 of the slices by chance at 1 %); every other positive is queued, one per lane and round.
+        // (A workgroup's record list holds one record per lane and chunk, and a slice whose positives are queued one by one may come back as
+        // several.  A wave keeps count: what it has recorded and queued so far, e_w, never exceeds 64 a turn -- slices with several positives
+        // are queued only while the wave is 256 entries under that line, which at 1 % positives it is from its fifth turn on; on bait-rich
+        // input it is not, and such slices are recorded as they are.)
+        uint32_t todo = hitmask;
+        if (!CANON) {
+            const bool single = hitmask != 0 && (hitmask & (hitmask - 1u)) == 0;
+            if (hitmask != 0 && !single) record((uint32_t)c, threadIdx.x, hitmask);
+            if (!single) todo = 0;
+        } else {
+            t_w++;
+            const bool roomy = e_w + 256u <= 64u * t_w;
+            const bool single = (hitmask & (hitmask - 1u)) == 0;
+            const bool direct = hitmask != 0 && ((hitmask & (hitmask << 1)) != 0 || (!single && !roomy));
+            if (direct) { record((uint32_t)c, threadIdx.x, hitmask); todo = 0; }
+            e_w += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(direct));
+        }
+        for (;;) {
+            const uint64_t bm = __builtin_amdgcn_ballot_w64(todo != 0);
+            if (!bm) break;
             const uint32_t off = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-            if (single) {
-                const uint32_t bit = 31u - (uint32_t)__clz(hitmask), i = (uint32_t)(NS - 1) - bit;          // the one positive sample
+            if (todo) {
+                const uint32_t bit = 31u - (uint32_t)__clz(todo), i = (uint32_t)(NS - 1) - bit;          // the (next) positive sample
                 const uint32_t lo = (i & 1u) ? ((i & 2u) ? sm[3] : sm[1]) : ((i & 2u) ? sm[2] : sm[0]);
                 const uint32_t hi = (i & 1u) ? ((i & 2u) ? sm[7] : sm[5]) : ((i & 2u) ? sm[6] : sm[4]);
                 lds_st(&s_qsm[off], (i & 4u) ? hi : lo); lds_st(&s_qch[off], (uint32_t)c); s_qid[off] = (unsigned short)(threadIdx.x | (bit << 10));
+                todo &= ~(1u << bit);
             }
             q_n += (uint32_t)__popcll(bm);
+            if (CANON) e_w += (uint32_t)__popcll(bm);
             MF_COMPILER_FENCE();
             if (q_n >= 64u) drain();
+            if (!CANON) break;
         }
     };
 
@@ -1546,7 +1591,7 @@ __device__ __forceinline__ void stab_insert(uint32_t sm, uint32_t *stab, uint32_
 
 __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
                                     uint32_t stab_mask, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b,
-                                    uint32_t *pre, uint32_t pre_log2w)
+                                    uint32_t *pre, uint32_t pre_log2w, bool canon)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B.total || B.runlen[p] < s) return;
@@ -1554,15 +1599,18 @@ __global__ void build_screen_kernel(BaitView B, int s, uint32_t *bloom, uint32_t
     uint32_t fwd = alignbit(B.words[wi + 1], B.words[wi], sh);
     if (s < 16) fwd &= (1u << (2 * s)) - 1;
     const uint32_t rc = revcomp_s(fwd, s);
-    stage1_insert(fwd, s, bloom, log2w); stage1_insert(rc, s, bloom, log2w);
-    if (front2) { stage1_insert(fwd, s, front2, f2_log2b + 2); stage1_insert(rc, s, front2, f2_log2b + 2); }      // the bait-sized fronts: the same blocks, more of them
-    if (front3) { stage1_insert(fwd, s, front3, f3_log2b + 2); stage1_insert(rc, s, front3, f3_log2b + 2); }
+    const uint32_t cn = fwd < rc ? fwd : rc;
+    // the screen's tables: both strands as they lie in a read -- or, for a set built canonical (s == 16, larger baits), the smaller of the two only,
+    // which the screen kernels then make of every sample (canon16)
+    const uint32_t k0 = canon ? cn : fwd, k1 = canon ? cn : rc;
+    stage1_insert(k0, s, bloom, log2w); if (!canon) stage1_insert(k1, s, bloom, log2w);
+    if (front2) { stage1_insert(k0, s, front2, f2_log2b + 2); if (!canon) stage1_insert(k1, s, front2, f2_log2b + 2); }      // the bait-sized fronts: the same blocks, more of them
+    if (front3) { stage1_insert(k0, s, front3, f3_log2b + 2); if (!canon) stage1_insert(k1, s, front3, f3_log2b + 2); }
     if (pre) {                                          // mode 4's one-bit table
         const uint32_t lo = pre_index_lo(s, pre_log2w), nb = pre_log2w + 5;
-        for (uint32_t v : {fwd, rc}) { const uint32_t bi = (bloom_hash(v) >> lo) & ((1u << nb) - 1u); atomicOr(&pre[bi >> 5], 1u << (bi & 31u)); }
+        for (uint32_t v : {k0, k1}) { const uint32_t bi = (bloom_hash(v) >> lo) & ((1u << nb) - 1u); atomicOr(&pre[bi >> 5], 1u << (bi & 31u)); }
     }
     stab_insert(fwd, stab, stab_mask, has_ones); stab_insert(rc, stab, stab_mask, has_ones);
-    const uint32_t cn = fwd < rc ? fwd : rc;
     const uint32_t ha = stage2_hash_a(cn), hb = stage2_hash_b(cn);
     uint32_t *st2 = bloom + ((size_t)1 << log2w);
 #pragma unroll
@@ -1899,7 +1947,7 @@ template <auto Kernel> static void raise_lds_limit_once(size_t max_bytes)
     done.fetch_or(bit, std::memory_order_release);
 }
 
-template <int SPW>
+template <int SPW, bool CANON>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
@@ -1907,35 +1955,35 @@ static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *re
     const uint64_t grid = screen_grid_for(R, n_cu, key);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
-    if (S.front_mode == 3 && SPW == 1) {          // LDS table; lone positives queued and looked up in front2 sixty-four at a time (screen3_kernel)
+    if constexpr (SPW == 1) if (S.front_mode == 3) {          // LDS table; lone positives queued and looked up in front2 sixty-four at a time (screen3_kernel)
         const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + S3_LDS_EXTRA;
-        raise_lds_limit_once<&screen3_kernel<SCREEN_U>>(128 * 1024 + S3_LDS_EXTRA);
-        MF_LAUNCH((screen3_kernel<SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
+        raise_lds_limit_once<&screen3_kernel<SCREEN_U, CANON>>(128 * 1024 + S3_LDS_EXTRA);
+        MF_LAUNCH((screen3_kernel<SCREEN_U, CANON>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
                   static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
         return;
     }
     if (S.front_mode == 1 || S.front_mode == 3) {          // LDS table, its positives through front2 turn by turn (screen2_kernel; mode 3 falls here for the stride-8 geometries)
         const size_t lds = (sizeof(uint32_t) << S.bloom_log2w) + S2_LDS_EXTRA;
-        raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, true>>(128 * 1024 + S2_LDS_EXTRA);
-        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, true>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
+        raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, true, 8, false, CANON>>(128 * 1024 + S2_LDS_EXTRA);
+        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, true, 8, false, CANON>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
                   static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
         return;
     }
     if (S.front_mode == 4) {          // a one-bit LDS table, its positives through front2 (and front3): one workgroup a CU, eight gathers in flight per lane
         const size_t lds = (sizeof(uint32_t) << S.pre_log2w) + S2_LDS_EXTRA;
-        raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, false, 8, true>>(128 * 1024 + S2_LDS_EXTRA);
-        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 8, true>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
+        raise_lds_limit_once<&screen2_kernel<SPW, SCREEN_U, false, 8, true, CANON>>(128 * 1024 + S2_LDS_EXTRA);
+        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 8, true, CANON>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds, st, tm, R, S,
                   static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
         return;
     }
     if (S.front_mode == 2) {          // every sample through front2 (and front3): two workgroups a CU (its grid key says so), four gathers in flight per lane
-        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 4>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), S2_LDS_EXTRA, st, tm, R, S,
+        MF_LAUNCH((screen2_kernel<SPW, SCREEN_U, false, 4, false, CANON>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), S2_LDS_EXTRA, st, tm, R, S,
                   static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
         return;
     }
     const size_t lds1 = (sizeof(uint32_t) << S.bloom_log2w) + 16;
-    raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U>>(128 * 1024 + 16);
-    MF_LAUNCH((screen_kernel<SPW, SCREEN_U>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
+    raise_lds_limit_once<&screen_kernel<SPW, SCREEN_U, CANON>>(128 * 1024 + 16);
+    MF_LAUNCH((screen_kernel<SPW, SCREEN_U, CANON>), dim3((unsigned)grid), dim3(SCREEN_BLOCK), lds1, st, tm, R, S,
               static_cast<ScreenRec *>(recs), cap, rec_counts, reinterpret_cast<uint4 *>(clear), clear ? clear_vec4 : (uint64_t)0);
 }
 
@@ -1956,8 +2004,9 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                          const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
-    if (S.stride == 16) launch_screen_spw<1>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
-    else launch_screen_spw<2>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    if (S.stride == 16 && S.canon) launch_screen_spw<1, true>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);          // (canonical keys: 16-base samples only)
+    else if (S.stride == 16) launch_screen_spw<1, false>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else launch_screen_spw<2, false>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
     return hipGetLastError();
 }
 
@@ -2052,11 +2101,11 @@ hipError_t launch_build_table(const BaitView &B, int k, int kw, uint64_t *keys, 
 
 hipError_t launch_build_screen(const BaitView &B, int s, uint32_t *bloom, uint32_t log2w, uint32_t log2w2, uint32_t *stab,
                                uint32_t stab_slots, uint32_t *has_ones, uint32_t *front2, uint32_t f2_log2b, uint32_t *front3, uint32_t f3_log2b,
-                               uint32_t *pre, uint32_t pre_log2w, hipStream_t st)
+                               uint32_t *pre, uint32_t pre_log2w, bool canon, hipStream_t st)
 {
     if (B.total == 0) return hipSuccess;
     hipLaunchKernelGGL(build_screen_kernel, dim3(grid_for(B.total, 256)), dim3(256), 0, st, B, s, bloom, log2w, log2w2, stab, stab_slots - 1, has_ones,
-                       front2, f2_log2b, front3, f3_log2b, pre, pre_log2w);
+                       front2, f2_log2b, front3, f3_log2b, pre, pre_log2w, canon);
     return hipGetLastError();
 }
 

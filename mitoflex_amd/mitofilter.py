@@ -42,7 +42,7 @@ class KmerSetInfo(C.Structure):
                 ("n_windows", C.c_uint64), ("screen_s", C.c_int32), ("screen_stride", C.c_int32),
                 ("bloom_words", C.c_uint32), ("smer_slots", C.c_uint32), ("n_smers", C.c_uint64),
                 ("kind", C.c_int32), ("genetic_code", C.c_int32),
-                ("front_mode", C.c_uint32), ("front2_log2_blocks", C.c_uint32), ("front3_log2_blocks", C.c_uint32), ("reserved", C.c_uint32)]
+                ("front_mode", C.c_uint32), ("front2_log2_blocks", C.c_uint32), ("front3_log2_blocks", C.c_uint32), ("canonical_screen", C.c_uint32)]
 
 
 class ReadsInfo(C.Structure):

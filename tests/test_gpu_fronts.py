@@ -33,17 +33,21 @@ def ol():
 @pytest.fixture()
 def front(mf):
     """set the front options for the sets built inside a test; back to automatic afterwards"""
-    def set_(mode, f2=0, f3=-1):
+    def set_(mode, f2=0, f3=-1, canon=-1):
         mf.set_option("front", mode)
         mf.set_option("front2_log2b", f2)
         mf.set_option("front3_log2b", f3)
+        mf.set_option("canon", canon)
     yield set_
-    set_(-1, 0, -1)
+    set_(-1, 0, -1, -1)
 
 
 # (mode, front2 log2 blocks, front3 log2 blocks): roomy tables, overloaded front2 (nearly everything passes: what a round cannot
 # verify is passed on), a front3 behind an overloaded front2, the smallest tables there are
 FORMS = [(1, 0, -1), (1, 6, -1), (2, 0, -1), (2, 6, 0), (2, 6, 12), (2, 8, 6), (3, 0, -1), (3, 6, -1), (4, 0, -1), (4, 6, 8)]
+# ... and with the screen's tables built canonical (one key per bait s-mer, the samples made canonical in the screen: 16-base samples,
+# k >= 31; the option is ignored for shorter k), the plain LDS-table screen included
+FORMS += [(0, 0, -1, 1), (1, 0, -1, 1), (1, 6, -1, 1), (2, 0, -1, 1), (2, 6, 12, 1), (3, 0, -1, 1), (3, 6, -1, 1), (4, 0, -1, 1), (4, 6, 8, 1)]
 
 
 @pytest.mark.parametrize("k", [19, 21, 25, 28, 31, 32, 33, 41, 63])
@@ -51,6 +55,7 @@ FORMS = [(1, 0, -1), (1, 6, -1), (2, 0, -1), (2, 6, 0), (2, 6, 12), (2, 8, 6), (
 def test_forced_forms_match_oracle(mf, ol, bait_text, front, k, form):
     front(*form)
     ks = mf.KmerSet.from_text(bait_text, k)
+    assert ks.info.canonical_screen == (1 if len(form) > 3 and form[3] == 1 and k >= 31 else 0)
     t = ol.OracleTable(bait_text, k)
     for uniform in (True, False):
         seqs = make_reads(bait_text, 5000, seed=300 + k, uniform=uniform)
@@ -85,16 +90,19 @@ def test_forced_forms_pipelined_passes(mf, ol, bait_text, front, form):
     assert np.array_equal(bits, obits)
 
 
-@pytest.mark.parametrize("size,k", [(30_000, 31), (30_000, 21), (50_000, 31), (100_000, 31), (100_000, 21), (350_000, 31), (350_000, 41), (1_000_000, 31), (2_000_000, 31)])
+@pytest.mark.parametrize("size,k", [(30_000, 31), (30_000, 21), (50_000, 31), (70_000, 31), (100_000, 31), (100_000, 21), (200_000, 31), (350_000, 31), (350_000, 41), (1_000_000, 31), (2_000_000, 31),
+                                    (4_500_000, 31)])
 def test_large_baits_pick_their_screen(mf, ol, size, k):
-    """baits that are large for real: the library picks the form (LDS table + front2 up to ~105 kbp, a one-bit LDS table + front2 up to ~1 Mbp, front2 + front3 alone beyond); bits and hit counts
-    equal the oracle's on 200 k reads (0.5 % bait reads, N), and the screened pass equals the exhaustive one"""
+    """baits that are large for real: the library picks the form -- for 16-base samples (k >= 31) canonical keys from ~40 kbp, with them the LDS table and a
+    queue of lone positives up to ~120 kbp, LDS table + front2 turn by turn up to ~210 kbp, a one-bit LDS table + front2 up to ~2 Mbp, front2 + front3
+    alone beyond; bits and hit counts equal the oracle's on 200 k reads (0.5 % bait reads, N), and the screened pass equals the exhaustive one"""
     from mitoflex_amd.utility.synth_bait import random_bait
     bait = random_bait(size, seed=size + k)
     ks = mf.KmerSet.from_text(bait, k)
-    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 100_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 2}[size]
+    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 70_000: 3, 100_000: 3 if k >= 31 else 1, 200_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 4, 4_500_000: 2}[size]
     assert ks.info.front_mode == want_mode, (size, k, ks.info.front_mode)
-    assert (ks.info.front3_log2_blocks > 0) == (size >= 1_000_000)
+    assert ks.info.canonical_screen == (1 if k >= 31 and size >= 70_000 else 0)
+    assert (ks.info.front3_log2_blocks > 0) == (size >= 2_000_000)
     n, L = 200_000, 150
     reads = mf.Reads.synth(n, L, seed=size, bait_text=bait, keep_host=True)
     off = np.arange(n + 1, dtype=np.uint64) * L
@@ -114,7 +122,7 @@ def test_large_baits_pick_their_screen(mf, ol, size, k):
 
 def test_bait_rich_input_through_the_fronts(mf, ol, bait_text, front):
     """every read a bait read: all of a wave's samples are positives, far more than its queue holds -- the overflow is passed on unverified"""
-    for form in [(1, 0, -1), (2, 0, -1), (3, 0, -1), (4, 0, -1)]:
+    for form in [(1, 0, -1), (2, 0, -1), (3, 0, -1), (4, 0, -1), (0, 0, -1, 1), (1, 0, -1, 1), (3, 0, -1, 1), (4, 0, -1, 1)]:
         front(*form)
         ks = mf.KmerSet.from_text(bait_text, 31)
         n, L = 100_000, 150
@@ -125,6 +133,30 @@ def test_bait_rich_input_through_the_fronts(mf, ol, bait_text, front):
         for _ in range(3):                      # (the pass kind adapts to what the last call saw)
             bits, _, _ = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
             assert np.array_equal(bits, obits), form
+
+
+@pytest.mark.parametrize("ppm", [30_000, 200_000, 600_000])
+def test_canonical_queue_keeps_within_the_record_lists(mf, ol, bait_text, front, ppm):
+    """canonical keys, the queued form: a slice's positives are queued one by one while the wave is well under one record per lane and
+    chunk, and recorded as a slice when it is not -- inputs between sparse and bait-rich, small LDS table and front2 (many false positives
+    of both), bits equal to the oracle on every pass"""
+    front(3, 6, -1, 1)
+    mf.set_option("adapt", 0)
+    try:
+        ks = mf.KmerSet.from_text(bait_text, 31)
+        assert ks.info.canonical_screen == 1 and ks.info.front_mode == 3
+        n, L = 400_000, 150
+        reads = mf.Reads.synth(n, L, seed=ppm, bait_text=bait_text, mito_ppm=ppm, sub_ppm=30_000, keep_host=True)
+        off = np.arange(n + 1, dtype=np.uint64) * L
+        R = ol.OracleReads.from_arrays(reads.host_words, off, reads.host_npos)
+        obits, _ = ol.filter_reads(ol.OracleTable(bait_text, 31), R, 1, threads=os.cpu_count() or 1)
+        want = int(bits_to_bool(obits, n).sum())
+        bits, _, _ = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
+        assert np.array_equal(bits, obits)
+        per, _ = mf.filter_resident_passes(ks, reads, 1, mf.MODE_SCREENED, 4)
+        assert [int(x) for x in per] == [want] * 4
+    finally:
+        mf.set_option("adapt", 1)
 
 
 def test_full_size_set_through_a_saturated_lds_table(mf, ol):
