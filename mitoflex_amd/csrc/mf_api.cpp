@@ -804,13 +804,16 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
-        const int q = (p + 1) % NSETS;
+        // (three buffer sets for pipelined passes: the screen of pass i + 3 waits for the finish kernels of pass i, not of pass i + 1 -- with two sets a
+        // finish chain that outlasts the next screen, as the two-word keys' does, held the screen after that: k = 41 0.243 -> 0.234 ms a pass, k = 31
+        // 0.224 -> 0.222, 33 kbp 0.243 -> 0.237, profiles/r06/n_three_sets.txt.  A call of one pass -- a file-level call's batches -- keeps to two.)
+        const bool two = overlap && pass_kind() == 0;
+        const int q = (p + 1) % (two ? NSETS : 2);
         if (!r->d_recs[q]) {
             size_t c0 = 0, c1 = 0;
             HIPCHK(dev_reserve(r->d_recs[q], c0, r->cap_recs, false));
             HIPCHK(dev_reserve(r->d_rec_counts[q], c1, r->cap_rec_counts, false));
         }
-        const bool two = overlap && pass_kind() == 0;
         // The finish kernels are chains of memory latencies.  With few records (the benchmark's 0.5 % bait reads) they are over long
         // before the next screen is and one stream carries them all; when they are what a pass waits for (bait-rich input: 2 % bait
         // reads and more, seen in the last call's tallies) those of consecutive passes go to two streams and run side by side --
@@ -819,11 +822,12 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // (two-word keys, k >= 33: a finish kernel's probes are twice as long, and one stream's worth of them is not over when the next screen is --
         // k = 41 0.2369 -> 0.2331 ms a pass, k = 63 0.2960 -> 0.2817: profiles/r05/c_k41_finish_streams_probe.txt)
         const bool fin2 = fin_streams == 2 || (fin_streams == 0 && (r->finish_two || S.kw == 2));
-        hipStream_t sf = two ? ((fin2 && (q & 1)) ? ctx->stream4 : ctx->stream2) : st;
+        const int odd = (r->flip ^= 1);
+        hipStream_t sf = two ? ((fin2 && odd) ? ctx->stream4 : ctx->stream2) : st;
         // consecutive screens go to two streams in turn: nothing orders them against each other (different buffer sets), so the
         // workgroups of the next screen take over the CUs as the last ones of this screen drain (MF_SCREEN_STREAMS=1: one stream)
         const bool alt = g_opt.screen_streams == 2;
-        hipStream_t ss = (two && alt && (q & 1)) ? ctx->stream3 : st;
+        hipStream_t ss = (two && alt && odd) ? ctx->stream3 : st;
         if (two) HIPCHK(hipStreamWaitEvent(ss, r->ev_finish[q], 0));           // the finish kernels of NSETS passes ago read this set
         // cross-stream order without marker packets in the screen's stream: the events ride on the dispatches themselves
         // (hipExtLaunchKernelGGL completion events); a separately recorded event costs the next dispatch ~5 us
@@ -874,7 +878,8 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         }
         if (!r->d_cand[q]) { size_t c = 0; HIPCHK(dev_reserve(r->d_cand[q], c, r->cap_bitmap, false)); r->cand_clean[q] = false; }
         const bool alt = g_opt.screen_streams == 2;
-        hipStream_t ss = (alt && (q & 1)) ? ctx->stream3 : st, sf = ctx->stream2;
+        const int odd = (r->flip ^= 1);
+        hipStream_t ss = (alt && odd) ? ctx->stream3 : st, sf = ctx->stream2;
         HIPCHK(hipStreamWaitEvent(ss, r->ev_finish[q], 0));                    // the exact kernel of NSETS passes ago worked on this set
         if (!r->cand_clean[q]) { HIPCHK(hipMemsetAsync(r->d_cand[q], 0, r->bitmap_bytes, ss)); r->cand_clean[q] = true; }
         KernelTiming scr_done{nullptr, r->ev_screen[q]};

@@ -44,8 +44,12 @@ template <class T> inline hipError_t dev_reserve(T *&p, size_t &cap, size_t byte
 }
 
 
-// Buffer sets a pipelined pass rotates through (a third set, or a second finish stream, changed nothing measurable).
-constexpr int NSETS = 2;
+// Buffer sets a pipelined pass rotates through.  (Round 2 measured nothing from a third; since the finish kernels of two-word keys run on two streams and
+// outlast a screen, it is worth 1-4 % of a pass: profiles/r06/n_three_sets.txt.  A fourth adds nothing.)
+#ifndef MF_NSETS
+#define MF_NSETS 3
+#endif
+constexpr int NSETS = MF_NSETS;
 struct mf_reads {
     int device = 0, lane = 0;     // lane: which of the device's contexts (streams) this read set works on
     mf::ReadsView v{};
@@ -68,6 +72,7 @@ struct mf_reads {
     bool finish_two = false;          // bait-rich input (from the last call's tallies): the finish kernels of consecutive passes go to two streams
     bool split_serial = false;      // ... and with very many candidates (> 5 % of the reads) its kernels do not fit beside the next screen: one stream
     int cur = 0;
+    int flip = 0;               // parity of the pipelined passes enqueued so far (which of two streams a pass's screen / finish kernels take)
     unsigned long long *tally_override = nullptr;       // set per pass by filter_common when every pass's tally is wanted
     size_t bitmap_bytes = 0;
     // capacities (bytes), so that a handle can be refilled batch after batch without touching the allocator
