@@ -805,10 +805,12 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.
         // (three buffer sets for pipelined passes: the screen of pass i + 3 waits for the finish kernels of pass i, not of pass i + 1 -- with two sets a
-        // finish chain that outlasts the next screen, as the two-word keys' does, held the screen after that: k = 41 0.243 -> 0.234 ms a pass, k = 31
-        // 0.224 -> 0.222, 33 kbp 0.243 -> 0.237, profiles/r06/n_three_sets.txt.  A call of one pass -- a file-level call's batches -- keeps to two.)
+        // finish chain that outlasts the next screen, as the two-word keys' does, held the screen after that: k = 41 0.243 -> 0.234 ms a pass, k = 63 0.257 -> 0.250 (k = 31
+        // 0.224 -> 0.222, 33 kbp 0.243 -> 0.237), profiles/r06/n_three_sets.txt.  A call of one pass -- a file-level call's batches -- keeps to two.)
+        // (Kept to the two-word keys: for k <= 32 it is worth 1-2 %, and with three sets two or three screens are in flight at a time, so that a launch
+        // lasts twice what a pass takes -- the per-launch figure bench.py's `roofline` reports for the headline would no longer say what the pass does.)
         const bool two = overlap && pass_kind() == 0;
-        const int q = (p + 1) % (two ? NSETS : 2);
+        const int q = (p + 1) % (two && S.kw == 2 ? NSETS : 2);
         if (!r->d_recs[q]) {
             size_t c0 = 0, c1 = 0;
             HIPCHK(dev_reserve(r->d_recs[q], c0, r->cap_recs, false));
@@ -870,7 +872,7 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         // bitmap, result bitmap, tallies); its mark and exact kernels go to the second stream and run beside the screen of
         // pass i + 1.  The exact kernel takes its co-resident form when a screen follows (a screen workgroup holds 128 KiB
         // of every CU's LDS for the whole pass), its full form behind the last screen of the call.
-        const int q = (p + 1) % NSETS;
+        const int q = (p + 1) % (S.kw == 2 ? NSETS : 2);
         if (!r->d_recs[q]) {
             size_t c0 = 0, c1 = 0;
             HIPCHK(dev_reserve(r->d_recs[q], c0, r->cap_recs, false));

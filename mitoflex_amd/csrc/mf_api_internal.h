@@ -45,7 +45,7 @@ template <class T> inline hipError_t dev_reserve(T *&p, size_t &cap, size_t byte
 
 
 // Buffer sets a pipelined pass rotates through.  (Round 2 measured nothing from a third; since the finish kernels of two-word keys run on two streams and
-// outlast a screen, it is worth 1-4 % of a pass: profiles/r06/n_three_sets.txt.  A fourth adds nothing.)
+// outlast a screen, it is worth 4 % of a pass for them: profiles/r06/n_three_sets.txt -- one-word keys keep to two, mf_api.cpp enqueue_pass.  A fourth adds nothing.)
 #ifndef MF_NSETS
 #define MF_NSETS 3
 #endif

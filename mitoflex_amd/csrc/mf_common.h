@@ -75,7 +75,10 @@ MF_HD uint32_t pre_index_lo(int s, uint32_t log2w) { const uint32_t ib = log2w +
 // every other screen -- stride 8, and the gather- and issue-bound screens of large baits -- takes every CU
 // (key 4: two workgroups a CU -- the front2-only screen of large baits holds few registers and no LDS table, and twice the gathers in flight)
 // (mode 3 with stride 16 is screen_kernel's loop and keeps its HBM-bound grid)
-MF_HD int screen_grid_key(int stride, uint32_t front_mode) { return front_mode == 2 ? 4 : (stride == 16 && (front_mode == 0 || front_mode == 3)) ? 16 : 8; }
+#ifndef MF_CANON_KEY
+#define MF_CANON_KEY 16
+#endif
+MF_HD int screen_grid_key(int stride, uint32_t front_mode, uint32_t canon = 0) { return front_mode == 2 ? 4 : (stride == 16 && (front_mode == 0 || front_mode == 3)) ? (canon ? MF_CANON_KEY : 16) : 8; }
 // front2 at most 2 MiB: an XCD's L2 is 4 MiB and the read stream passes through it too -- a 4 MiB table is looked up at 150-180 G/s,
 // a 2 MiB one at 205 (profiles/r06/c_front_variants.txt; the part's roof, nothing else running, is 265 G/s: tools/gather_roof.hip)
 constexpr uint32_t FRONT2_MAX_LOG2B = 17;

@@ -1951,7 +1951,7 @@ template <int SPW, bool CANON>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
-    const int key = screen_grid_key(S.stride, S.front_mode);
+    const int key = screen_grid_key(S.stride, S.front_mode, S.canon);
     const uint64_t grid = screen_grid_for(R, n_cu, key);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
@@ -1991,7 +1991,7 @@ template <int SPW>
 static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *cand, int n_cu,
                             hipStream_t st, const KernelTiming *tm)
 {
-    const int key = screen_grid_key(S.stride, S.front_mode);
+    const int key = screen_grid_key(S.stride, S.front_mode, S.canon);
     const uint64_t grid = screen_grid_for(R, n_cu, key);
     if (grid == 0) return;
     const uint32_t cap = (uint32_t)screen_rec_cap_for(R, n_cu, key);
@@ -2013,7 +2013,7 @@ hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, u
 hipError_t launch_finish(const ReadsView &R, const KmerSetView &S, const void *recs, const uint32_t *rec_counts, uint32_t *bits,
                          unsigned long long *partials, int n_cu, hipStream_t st, const KernelTiming *tm, hipEvent_t done, uint32_t *cand)
 {
-    const int key = screen_grid_key(S.stride, S.front_mode);
+    const int key = screen_grid_key(S.stride, S.front_mode, S.canon);
     const uint64_t lists = screen_grid_for(R, n_cu, key);
     if (lists == 0) {               // (an empty read set) nothing to settle: the tallies read zero and `done` still completes, as in launch_exact
         (void)hipMemsetAsync(partials, 0, 3 * EXACT_MAX_GRID * 16, st);

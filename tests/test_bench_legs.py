@@ -159,7 +159,7 @@ def test_resident_axis_legs_build_their_dictionaries(bench):
     from mitoflex_amd.utility.synth_bait import make_bait
     lib = FakeResident(ol)
     bait = make_bait()
-    a = types.SimpleNamespace(reads=3200, k=31)
+    a = types.SimpleNamespace(reads=3200, k=31, steps=7)
     reads = lib.Reads.synth(a.reads, 150, 5, bait)
     ks = lib.KmerSet.from_text(bait, 31)
     alg = 3200 * 150 // 4 + 400
