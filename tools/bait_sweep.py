@@ -16,6 +16,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 33_333_334
 sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16569, 33000, 100000, 350000, 1000000, 8500000]
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
 check = os.environ.get("SWEEP_CHECK", "1") == "1"
+STEPS = int(os.environ.get("SWEEP_STEPS", "50"))          # passes a timed call, as bench.py's default K (a call pays ~0.3 ms of ramp and tail whatever K is)
+print(f"# {STEPS} pipelined passes a timed call")
 for kv in [x for x in os.environ.get("SWEEP_OPTS", "").split(",") if x]:          # e.g. SWEEP_OPTS=front=2,front2_log2b=17
     name, val = kv.split("=")
     mf.set_option(name, val)
@@ -32,11 +34,11 @@ for size in sizes:
         mf.filter_resident(ks, reads, 1, mf.MODE_SCREENED, 3)
     mf.device_synchronize(0)
     t0 = time.perf_counter()
-    st = mf.filter_resident(ks, reads, 1, mf.MODE_SCREENED, 10)
+    st = mf.filter_resident(ks, reads, 1, mf.MODE_SCREENED, STEPS)
     mf.device_synchronize(0)
-    dt = (time.perf_counter() - t0) / 10
+    dt = (time.perf_counter() - t0) / STEPS
     os.environ["MF_EVENT_STRIDE"] = "1"
-    sp = mf.filter_resident(ks, reads, 1, mf.MODE_SCREENED, 10)
+    sp = mf.filter_resident(ks, reads, 1, mf.MODE_SCREENED, STEPS)
     frac = st.algorithmic_bytes / dt / 1e9 / HBM
     line = (f"bait {size:>8d} bp: build {t_build:6.3f} s, keys {inf.n_keys:>9d}, s-mers {inf.n_smers:>9d}, stage-1 words {inf.bloom_words:>7d} | "
             f"{dt * 1e3:8.4f} ms/pass = {n / dt / 1e9:7.2f} G reads/s = {frac:5.3f} of HBM | screen {sp.ms_screen * 1e3:7.1f} us, mark {sp.ms_mark * 1e3:7.1f}, last {sp.ms_exact * 1e3:7.1f} | "
