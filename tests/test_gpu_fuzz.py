@@ -58,6 +58,25 @@ def _reads_from(rng, recs, n, max_len, junk):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MF_FUZZ_SEEDS", "40"))))
 def test_fuzz_nucleotide(mf, ol, seed):
+    _fuzz_nucleotide(mf, ol, seed)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MF_FUZZ_SEEDS", "40"))))
+def test_fuzz_nucleotide_forced_screens(mf, ol, seed):
+    """the same configurations with a form of the large-bait screen forced on them (LDS table + front2 turn by turn / queued, front2 alone, a
+    one-bit LDS table in front of it; small and overloaded tables; canonical keys on and off)"""
+    r2 = random.Random(11000 + seed)
+    opts = {"front": r2.choice([0, 1, 2, 3, 4]), "canon": r2.choice([0, 1, 1]), "front2_log2b": r2.choice([0, 6, 7, 10]), "front3_log2b": r2.choice([-1, 0, 6, 9])}
+    for n, v in opts.items():
+        mf.set_option(n, v)
+    try:
+        _fuzz_nucleotide(mf, ol, seed, opts)
+    finally:
+        for n, v in (("front", -1), ("canon", -1), ("front2_log2b", 0), ("front3_log2b", -1)):
+            mf.set_option(n, v)
+
+
+def _fuzz_nucleotide(mf, ol, seed, opts=None):
     rng = random.Random(7000 + seed)
     k = rng.choice([11, 12, 15, 16, 17, 19, 20, 21, 22, 23, 24, 26, 27, 28, 29, 30, 31, 32, 33, 34, 40, 47, 48, 55, 62, 63])
     recs = [_rand_dna(rng, rng.choice([0, 5, k - 1, k, k + 1, 200, 1500, 6000]), junk=rng.choice([0.0, 0.0, 0.1]))
@@ -73,7 +92,7 @@ def test_fuzz_nucleotide(mf, ol, seed):
     t = ol.OracleTable(bait, k)
     obits, ohits = ol.filter_reads(t, R, thr, threads=4)
     ks = mf.KmerSet.from_text(bait, k)
-    cfg = dict(seed=seed, k=k, n_reads=len(seqs), thr=thr, recs=[len(r) for r in recs])
+    cfg = dict(seed=seed, k=k, n_reads=len(seqs), thr=thr, recs=[len(r) for r in recs], opts=opts)
     assert np.array_equal(ks.export_table(), t.keys), cfg
     reads = mf.Reads.from_packed(R.words, R.offsets, R.npos)
     for mode in (mf.MODE_SCREENED, mf.MODE_EXHAUSTIVE):

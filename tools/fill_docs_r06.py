@@ -33,7 +33,7 @@ sub = {
  'R6_CPU': "%.2f M reads/s, C oracle, %d threads (16-CPU quota), all 33.3 M bits equal: %s" % (d['cpu_baseline']['value']/1e6, d['cpu_baseline']['cores'], e.get('sample_bits_match_oracle')),
  'R6_BAIT_SHORT': bait_short,
  'R6_BAIT': "**" + bait + "**; every leg's 1.5 M-read window equal to the oracle: %s" % all(bs[k].get('window_bits_match_oracle') for k in bs),
- 'R6_K': "%.3f (%.3f of vector issue) / %.3f (%.3f)" % (ks['21']['whole_pass_frac_of_hbm_peak'], ks['21']['roofline'].get('frac') or 0, ks['41']['whole_pass_frac_of_hbm_peak'], ks['41']['roofline'].get('frac') or 0),
+ 'R6_K': "%.3f (%.3f of vector issue) / **%.3f** (a launch: %.3f -- with three buffer sets two or three screens are in flight)" % (ks['21']['whole_pass_frac_of_hbm_peak'], ks['21']['roofline'].get('frac') or 0, ks['41']['whole_pass_frac_of_hbm_peak'], ks['41']['roofline'].get('frac') or 0),
  'R6_T': "%s / %s / %s–%s ms; exhaustive %.2f ms = **%.3f of the vector issue rate**" % (ms(th['2']['ms_per_step']), ms(th['7']['ms_per_step']), ms(min(th[k]['with_hit_counts']['ms_per_step'] for k in '127')), ms(max(th[k]['with_hit_counts']['ms_per_step'] for k in '127')), th['exhaustive']['ms_per_step'], th['exhaustive']['roofline']['frac']),
  'R6_RAGGED': "%s ms a pass = **%.2f ×** uniform (%.3f of HBM), window equal to the oracle: %s" % (ms(e['ragged']['ms_per_step']), e['ragged']['ms_per_step_over_uniform'], e['ragged']['whole_pass_frac_of_hbm_peak'], e['ragged']['window_bits_match_oracle']),
  'R6_REAL': "%s ms a pass = %.2f × the iid set, **%.3f of HBM**, %.3f work items a read, window equal to the oracle: %s" % (ms(e['realistic']['ms_per_step']), e['realistic']['ms_per_step_over_iid'], e['realistic']['whole_pass_frac_of_hbm_peak'], e['realistic']['work_items_per_read'], e['realistic']['window_bits_match_oracle']),
