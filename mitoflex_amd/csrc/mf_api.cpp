@@ -143,6 +143,7 @@ struct mf_kmerset {
     uint32_t bloom_log2w = 0, stage2_log2w = 0, stab_slots = 0, kb_log2w = 0;
     uint32_t front_mode = 0, f2_log2b = 0, f3_log2b = 0, pre_log2w = 0;
     bool canon = false;         // the screen's tables hold one canonical key per bait s-mer (KmerSetView::canon)
+    bool s8_finish = false;     // a stride-8 set whose threshold-1 passes go through screen + finish (baits beyond ~20 kbp)
     size_t screen_words() const { return ((size_t)1 << bloom_log2w) + ((size_t)1 << stage2_log2w); }
     std::mutex mu;
     std::map<int, DevTables> dev;
@@ -198,6 +199,7 @@ struct PassOptions {
     // the large-bait screen (read when a k-mer set is BUILT; tests force every form on small baits)
     std::atomic<int> front{-1};           // -1 by the bait's size | 0 LDS table only | 1 LDS table + front2 | 2 front2 (+ front3) only | 3 LDS table, lone positives through front2   "front"   MF_FRONT
     std::atomic<int> front2_log2b{0};     // 0 by the bait's size | log2 of front2's 128-bit blocks (6..18)                         "front2_log2b"   MF_FRONT2_LOG2B
+    std::atomic<int> s8_finish{-1};       // the stride-8 geometries (k < 28) through screen + finish instead of the candidate bitmap: -1 by the bait's size | 0 | 1   "s8_finish"   MF_S8_FINISH
     std::atomic<int> canon{-1};           // -1 by the bait's size | 0 both strands in the screen's tables | 1 one canonical key per s-mer (16-base samples only)             "canon"          MF_CANON
     std::atomic<int> front3_log2b{-1};    // -1 by the bait's size | 0 none | log2 of front3's blocks (6..27)                       "front3_log2b"   MF_FRONT3_LOG2B
 };
@@ -217,6 +219,7 @@ static int set_option(const char *name, const char *value)
     else if (n == "exact_co") g_opt.exact_co = x != 0;
     else if (n == "front") { if (x < -1 || x > 4) return -1; g_opt.front = (int)x; }
     else if (n == "front2_log2b") { if (x != 0 && (x < 6 || x > 24)) return -1; g_opt.front2_log2b = (int)x; }
+    else if (n == "s8_finish") { if (x < -1 || x > 1) return -1; g_opt.s8_finish = (int)x; }
     else if (n == "canon") { if (x < -1 || x > 1) return -1; g_opt.canon = (int)x; }
     else if (n == "front3_log2b") { if (x < -1 || (x > 0 && x < 6) || x > 27) return -1; g_opt.front3_log2b = (int)x; }
     else return -1;
@@ -229,7 +232,7 @@ static void options_from_env_once()
         if (k && k[0] == '1') {
             static const char *const pairs[][2] = {{"pass", "MF_PASS"}, {"adapt", "MF_ADAPT"}, {"finish_streams", "MF_FINISH_STREAMS"}, {"screen_streams", "MF_SCREEN_STREAMS"},
                                                    {"split_pipe", "MF_SPLIT_PIPE"}, {"exact_co", "MF_EXACT_CO"},
-                                                   {"front", "MF_FRONT"}, {"front2_log2b", "MF_FRONT2_LOG2B"}, {"front3_log2b", "MF_FRONT3_LOG2B"}, {"canon", "MF_CANON"}};
+                                                   {"front", "MF_FRONT"}, {"front2_log2b", "MF_FRONT2_LOG2B"}, {"front3_log2b", "MF_FRONT3_LOG2B"}, {"canon", "MF_CANON"}, {"s8_finish", "MF_S8_FINISH"}};
             for (auto &p : pairs) { const char *v = getenv(p[1]); if (v && *v && set_option(p[0], v) != 0) fprintf(stderr, "libmitofilter_hip: %s=%s is not a value of option '%s' (ignored)\n", p[1], v, p[0]); }
         }
         return true;
@@ -337,6 +340,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
     V.canon = ks->canon ? 1u : 0u;
+    V.s8_finish = ks->s8_finish ? 1u : 0u;
     V.front_mode = ks->front_mode; V.f2_log2b = ks->f2_log2b; V.f3_log2b = ks->f3_log2b; V.front2 = T.front2; V.front3 = T.front3;
     V.pre_log2w = ks->pre_log2w; V.pre = T.pre;
     // stage 2 holds STAGE2_K bits per canonical s-mer; past ~50 % fill its false-positive rate climbs fast
@@ -404,10 +408,14 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         // LDS-table screens 0.03-0.04 ms a pass (16.5 kbp: 0.231 -> 0.266; 50 kbp, queued form: 0.295 -> 0.32), so the keys turn canonical where the
         // queued form with both strands ends (~61 kbp): 70 kbp 0.37 -> 0.32 ms a pass, 100 kbp 0.39 -> 0.36, 150 kbp 0.57 -> 0.40, 200 kbp 0.64 -> 0.45,
         // 350 kbp 0.86 -> 0.62, 1 Mbp 1.42 -> 1.09, 8.5 Mbp 4.6 -> 3.4 (profiles/r06/m_canon.txt).
+        ks->s8_finish = ks->geom.stride == 8 && per_lds_block > 5;
         ks->canon = ks->geom.s == 16 && ks->geom.stride == 16 && (g_opt.canon < 0 ? per_lds_block > 14 : g_opt.canon == 1);
         const uint64_t keys_bound = ks->canon ? bound / 2 : bound;          // keys the screen's tables hold
         per_lds_block = keys_bound >> (ks->bloom_log2w - 2);
-        int mode = per_lds_block <= 9 ? 0 : per_lds_block <= 26 ? 1 : 2;
+        // (stride 8: sixteen samples a lane and chunk, so the per-turn form's queue of 64 overflows from ~5 % positives -- 18 keys a block, ~75 kbp -- and what
+        // overflows is passed on unverified: k = 21 at 100 kbp 1.51 ms a pass with 20 M work items against 0.85 through the one-bit table, profiles/r06/o_stride8_finish.txt)
+        const uint64_t mode1_max = ks->geom.stride == 8 ? 18 : 26;
+        int mode = per_lds_block <= 9 ? 0 : per_lds_block <= mode1_max ? 1 : 2;
         if (ks->geom.stride == 16 && per_lds_block > 5 && per_lds_block <= (ks->canon ? 12u : 14u)) mode = 3;          // (canonical keys: 100 kbp 0.36 queued against 0.37 turn by turn, 150 kbp 0.51 against 0.40)
         // mode 2's range up to ~1 Mbp: a ONE-bit table of the LDS's size still answers e^(-keys / 2^20) of the samples itself -- 67 % at 200 kbp, 51 % at
         // 350 kbp, 14 % at 1 Mbp (both strands) -- and only the rest is looked up (mode 4): 0.57 / 0.64 / 0.86 / 1.06 ms a pass at 150 / 200 / 350 / 500 kbp against 1.4-1.5,
@@ -798,9 +806,12 @@ static int enqueue_pass(mf_reads *r, const KmerSetView &S, uint32_t thr, int mod
         return MF_OK;
     }
     const bool screened = (mode == MF_MODE_SCREENED) && S.s > 0;
-    // (stride-8 geometries, k < 28: twice the samples, several times the records -- measured faster through the candidate bitmap)
+    // (stride-8 geometries, k < 28: twice the samples, several times the records -- measured faster through the candidate bitmap for a bait the LDS table
+    // screens well, 16.5 kbp: k = 21 0.314 against 0.319 ms a pass, k = 25 / 27 0.292 against 0.298.  Beyond ~20 kbp the candidate bitmap's exact kernel is
+    // what a pass waits for -- its LDS k-mer table fills up -- and screen + finish is faster: k = 21 33 kbp 0.50 -> 0.45, 50 kbp 0.74 -> 0.55, 100 kbp
+    // 1.88 -> 1.51, 350 kbp 3.03 -> 1.98, k = 25 100 kbp 1.68 -> 1.21: KmerSetView::s8_finish, profiles/r06/o_stride8_finish.txt)
     // (round 3, after the stage-1 fields were fixed for 14-base samples: still the faster pass for stride 8 -- k = 21 0.299 vs 0.302-0.309 ms, k = 25 0.278-0.280 vs 0.281-0.283)
-    if (screened && pass_kind() != 1 && !r->prefer_split && thr == 1 && !count_all && (S.stride == 16 || pass_kind() == 2)) {
+    if (screened && pass_kind() != 1 && !r->prefer_split && thr == 1 && !count_all && (S.stride == 16 || pass_kind() == 2 || (g_opt.s8_finish < 0 ? S.s8_finish != 0 : g_opt.s8_finish == 1))) {
         // Two launches: the screen records its stage-1 positives (and clears this pass's result bitmap on the side), the
         // finish kernel settles them and sets the pass bits with atomics.  Pass i works on buffer set i mod 2; its finish
         // kernel goes to the second stream and runs under the screen of pass i + 1, which uses the other set.

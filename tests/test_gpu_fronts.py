@@ -73,6 +73,33 @@ def test_forced_forms_match_oracle(mf, ol, bait_text, front, k, form):
     ks.close()
 
 
+@pytest.mark.parametrize("k", [17, 19, 21, 25, 27])
+@pytest.mark.parametrize("form", [(0, 0, -1), (1, 6, -1), (3, 0, -1), (4, 6, 8), (2, 6, 12)])
+def test_stride8_sets_through_the_finish_kernels(mf, ol, bait_text, front, k, form):
+    """k < 28 (a sample every 8 bases): the threshold-1 pass through screen + finish -- what sets of baits beyond ~20 kbp take -- forced on small inputs,
+    every screen form, uniform and ragged reads, single and pipelined passes: bits equal the oracle's"""
+    front(*form)
+    mf.set_option("s8_finish", 1)
+    try:
+        ks = mf.KmerSet.from_text(bait_text, k)
+        t = ol.OracleTable(bait_text, k)
+        for uniform in (True, False):
+            seqs = make_reads(bait_text, 6000, seed=500 + k, uniform=uniform)
+            R = ol.OracleReads.from_seqs(seqs)
+            reads = mf.Reads.from_packed(R.words, R.offsets, R.npos)
+            obits, _ = ol.filter_reads(t, R, 1, threads=4)
+            want = int(bits_to_bool(obits, len(seqs)).sum())
+            bits, _, st = mf.filter_reads(ks, reads, 1, mf.MODE_SCREENED)
+            assert np.array_equal(bits, obits), (k, form, uniform)
+            assert st.n_pass == want
+            per, _ = mf.filter_resident_passes(ks, reads, 1, mf.MODE_SCREENED, 5)
+            assert [int(x) for x in per] == [want] * 5, (k, form, uniform)
+            reads.close()
+        ks.close()
+    finally:
+        mf.set_option("s8_finish", -1)
+
+
 @pytest.mark.parametrize("form", FORMS)
 def test_forced_forms_pipelined_passes(mf, ol, bait_text, front, form):
     """several pipelined passes of a 300 k-read synthetic set: every pass's tally equals the oracle's count (buffer sets, streams)"""
@@ -99,7 +126,7 @@ def test_large_baits_pick_their_screen(mf, ol, size, k):
     from mitoflex_amd.utility.synth_bait import random_bait
     bait = random_bait(size, seed=size + k)
     ks = mf.KmerSet.from_text(bait, k)
-    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 70_000: 3, 100_000: 3 if k >= 31 else 1, 200_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 4, 4_500_000: 2}[size]
+    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 70_000: 3, 100_000: 3 if k >= 31 else 4, 200_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 4, 4_500_000: 2}[size]
     assert ks.info.front_mode == want_mode, (size, k, ks.info.front_mode)
     assert ks.info.canonical_screen == (1 if k >= 31 and size >= 70_000 else 0)
     assert (ks.info.front3_log2_blocks > 0) == (size >= 2_000_000)
