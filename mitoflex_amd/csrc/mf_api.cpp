@@ -1189,7 +1189,7 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2, c
 int mf_set_option(const char *name, const char *value)
 {
     options_from_env_once();          // (so that a later first pass does not overwrite what is set here)
-    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3|4, canon=-1|0|1, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
+    if (set_option(name, value) != 0) return fail(MF_E_ARG, "unknown option or value: %s=%s (options: pass=default|split|serial, adapt=0|1, finish_streams=0|1|2, screen_streams=1|2, split_pipe=0|1, exact_co=0|1, front=-1|0|1|2|3|4, canon=-1|0|1, s8_finish=-1|0|1, front2_log2b=0|6..24, front3_log2b=-1|0|6..27, expect_files=0|1, short_lived=0|1)", name ? name : "(null)", value ? value : "(null)");
     return MF_OK;
 }
 
