@@ -76,7 +76,7 @@ typedef struct {
                                     4 a one-bit LDS table in front of mode 2's look-ups */
     uint32_t front2_log2_blocks; /* log2 of front2's 128-bit blocks (0: none) */
     uint32_t front3_log2_blocks; /* log2 of front3's 128-bit blocks (0: none) */
-    uint32_t canonical_screen;      /* 1: the screen's tables hold one canonical key per bait s-mer (16-base samples, larger baits) instead of one per strand */
+    uint32_t canonical_screen;      /* 1: the screen's tables hold one canonical key per bait s-mer (larger baits) instead of one per strand */
 } mf_kmerset_info_t;
 
 typedef struct {

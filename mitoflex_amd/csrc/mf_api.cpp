@@ -142,7 +142,7 @@ struct mf_kmerset {
     ScreenGeom geom{0, 0};
     uint32_t bloom_log2w = 0, stage2_log2w = 0, stab_slots = 0, kb_log2w = 0;
     uint32_t front_mode = 0, f2_log2b = 0, f3_log2b = 0, pre_log2w = 0;
-    bool canon = false;         // the screen's tables hold one canonical key per bait s-mer (KmerSetView::canon)
+    int canon = 0;              // != 0: the screen's tables hold one canonical key per bait s-mer (KmerSetView::canon: 1 sixteen-base samples, 2 shorter)
     bool s8_finish = false;     // a stride-8 set whose threshold-1 passes go through screen + finish (baits beyond ~20 kbp)
     size_t screen_words() const { return ((size_t)1 << bloom_log2w) + ((size_t)1 << stage2_log2w); }
     std::mutex mu;
@@ -315,7 +315,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
             HIPCHK(hipMemsetAsync(T.pre, 0, sizeof(uint32_t) << ks->pre_log2w, st));
         }
         HIPCHK(launch_build_screen(bv, ks->geom.s, T.bloom, ks->bloom_log2w, ks->stage2_log2w, T.stab, ks->stab_slots, d_flag,
-                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, T.pre, ks->pre_log2w, ks->canon, st));
+                                   T.front2, ks->f2_log2b, T.front3, ks->f3_log2b, T.pre, ks->pre_log2w, ks->canon != 0, st));
     }
     HIPCHK(dev_malloc(&T.kbloom, sizeof(uint32_t) << ks->kb_log2w));
     HIPCHK(hipMemsetAsync(T.kbloom, 0, sizeof(uint32_t) << ks->kb_log2w, st));
@@ -339,7 +339,7 @@ static int build_on_device(mf_kmerset *ks, int device, DevTables **out)
     V.smask = ks->geom.s >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ks->geom.s)) - 1);
     V.bloom_log2w = ks->bloom_log2w; V.stage2_log2w = ks->stage2_log2w; V.bloom = T.bloom;
     V.stab_mask = ks->stab_slots ? ks->stab_slots - 1 : 0; V.stab = T.stab; V.stab_has_ones = flag;
-    V.canon = ks->canon ? 1u : 0u;
+    V.canon = (uint32_t)ks->canon;
     V.s8_finish = ks->s8_finish ? 1u : 0u;
     V.front_mode = ks->front_mode; V.f2_log2b = ks->f2_log2b; V.f3_log2b = ks->f3_log2b; V.front2 = T.front2; V.front3 = T.front3;
     V.pre_log2w = ks->pre_log2w; V.pre = T.pre;
@@ -409,7 +409,12 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         // queued form with both strands ends (~61 kbp): 70 kbp 0.37 -> 0.32 ms a pass, 100 kbp 0.39 -> 0.36, 150 kbp 0.57 -> 0.40, 200 kbp 0.64 -> 0.45,
         // 350 kbp 0.86 -> 0.62, 1 Mbp 1.42 -> 1.09, 8.5 Mbp 4.6 -> 3.4 (profiles/r06/m_canon.txt).
         ks->s8_finish = ks->geom.stride == 8 && per_lds_block > 5;
-        ks->canon = ks->geom.s == 16 && ks->geom.stride == 16 && (g_opt.canon < 0 ? per_lds_block > 14 : g_opt.canon == 1);
+        // Shorter samples (k < 31) take eight instructions; the stride-16 ones (k = 28 .. 30) turn canonical at the same size, the stride-8 ones (k < 28: twice the
+        // samples to make canonical) where their both-strand per-turn form ends (~75 kbp): k = 21 at 100 kbp 0.85 -> 0.6 ms a pass (profiles/r06/p_canon_short.txt).
+        {
+            const bool want = g_opt.canon < 0 ? per_lds_block > (ks->geom.stride == 8 ? 18u : 14u) : g_opt.canon == 1;
+            ks->canon = !want ? 0 : ks->geom.s == 16 ? 1 : 2;
+        }
         const uint64_t keys_bound = ks->canon ? bound / 2 : bound;          // keys the screen's tables hold
         per_lds_block = keys_bound >> (ks->bloom_log2w - 2);
         // (stride 8: sixteen samples a lane and chunk, so the per-turn form's queue of 64 overflows from ~5 % positives -- 18 keys a block, ~75 kbp -- and what

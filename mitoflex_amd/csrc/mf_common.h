@@ -210,8 +210,8 @@ struct KmerSetView {
     int32_t   s, stride;        // s == 0: disabled
     uint32_t  smask;            // (1 << 2s) - 1
     uint32_t  bloom_log2w;      // stage 1: 1 << bloom_log2w words (= 1 << (bloom_log2w-2) blocks of 128 bit)
-    uint32_t  canon;            // the screen's tables (stage 1, front2, front3, the one-bit table) hold ONE key per bait s-mer -- the smaller of the s-mer and its
-                                // reverse complement -- and the screen kernels ask them with canon16(sample): s == 16 and stride == 16 only
+    uint32_t  canon;            // != 0: the screen's tables (stage 1, front2, front3, the one-bit table) hold ONE key per bait s-mer -- the smaller of the s-mer and its
+                                // reverse complement -- and the screen kernels ask them with the canonical sample: 1 sixteen-base samples (canon16), 2 shorter ones
     uint32_t  s8_finish;        // stride-8 set (k < 28) of a bait beyond ~20 kbp: threshold-1 passes take screen + finish instead of the candidate bitmap
     uint32_t  stage2_log2w;     // stage 2: 1 << stage2_log2w words, stored right behind stage 1
     const uint32_t *bloom;      // (1 << bloom_log2w) + (1 << stage2_log2w) words

@@ -150,6 +150,19 @@ __device__ __forceinline__ uint32_t canon16(uint32_t x)
     const uint32_t rc = (0xAAAAAAAAu & (y << 1)) | (0x55555555u & (y >> 1));
     return x < rc ? x : rc;
 }
+// The same for samples of fewer than sixteen bases (k < 31): the sample is the low 2s bits of `x` (what lies above rides along and falls out of the
+// reverse complement with the shift), eight vector instructions.  CANON: 0 the sample as it lies in the stream | 1 sixteen bases | 2 fewer.
+template <int CANON>
+__device__ __forceinline__ uint32_t canon_key(uint32_t x, uint32_t smask, uint32_t rc_shift)
+{
+    if (CANON == 0) return x;
+    if (CANON == 1) return canon16(x);
+    const uint32_t y = __brev(~x);
+    const uint32_t rc = ((0xAAAAAAAAu & (y << 1)) | (0x55555555u & (y >> 1))) >> rc_shift;
+    const uint32_t xm = x & smask;
+    return xm < rc ? xm : rc;
+}
+
 // A stage-1 positive record: everything mark_kernel needs to finish the job later.
 // One per (lane, chunk) that saw at least one positive.  Sample i of the lane's chunk slice
 // (i = (u*4+q)*SPW+j) is bit NS-1-i of hitmask, NS = U*4*SPW.
@@ -157,7 +170,7 @@ struct __attribute__((aligned(16))) ScreenRec { uint32_t chunk, tid, hitmask, pa
 
 // SPW: samples per word (stride 16 -> 1, stride 8 -> 2).  For s < 16 a sample is the low 2s bits of what is hashed; the bits
 // above them ride along (stage1_index_lo in mf_common.h).
-template <int SPW, int U, bool CANON = false>
+template <int SPW, int U, int CANON = 0>
 __global__ void __launch_bounds__(1024)
 screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
               uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -196,9 +209,9 @@ screen_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t
 #pragma unroll
                 for (int j = 0; j < SPW; j++) {
                     // the sample as it lies in the stream: for s < 16 the bases behind it ride along in the bits above 2s (stage1_index_lo)
-                    static_assert(!CANON || SPW == 1, "canonical keys are for 16-base samples");
+                    static_assert(CANON != 1 || SPW == 1, "sixteen-base samples come with stride 16");
                     const uint32_t raw = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
-                    const uint32_t sm = CANON ? canon16(raw) : raw;
+                    const uint32_t sm = canon_key<CANON>(raw, S.smask, 32u - 2u * (uint32_t)S.s);
                     const uint32_t h = bloom_hash(sm);
                     const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];        // one v_bfe_u32
                     const uint32_t t = lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);   // stage1_field
@@ -274,7 +287,7 @@ __device__ __forceinline__ uint32_t block_test(uint32_t sm, uint32_t h, const ui
     return lshl_by_byte<0>(sm, blk.x) & lshl_by_byte<1>(sm, blk.y) & lshl_by_byte<2>(sm, blk.z) & lshl_by_byte<1>(h, blk.w);
 }
 
-template <int SPW, int U, bool LDSF, int G = 8, bool PRE = false, bool CANON = false>
+template <int SPW, int U, bool LDSF, int G = 8, bool PRE = false, int CANON = 0>
 __global__ void __launch_bounds__(1024, G == 8 ? 4 : 8)          // (G = 4, no LDS table: two workgroups share a CU)
 screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
                uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -325,9 +338,9 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
             for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int j = 0; j < SPW; j++) {
-                    static_assert(!CANON || SPW == 1, "canonical keys are for 16-base samples");
+                    static_assert(CANON != 1 || SPW == 1, "sixteen-base samples come with stride 16");
                     const uint32_t raw = (SPW == 1 || j == 0) ? wv[q] : alignbit(wv[q + 1], wv[q], 16u);
-                    sm[(u * 4 + q) * SPW + j] = CANON ? canon16(raw) : raw;          // (the key every table of the screen is asked with)
+                    sm[(u * 4 + q) * SPW + j] = canon_key<CANON>(raw, S.smask, 32u - 2u * (uint32_t)S.s);          // (the key every table of the screen is asked with)
                 }
         }
     };
@@ -494,7 +507,7 @@ constexpr int S3_QN = 128;                 // queue entries per wave: fewer than
 // fit on the CU, and the finish kernels of pass i, which run under the screen of pass i + 1, were left the one CU in eight that screen does not take)
 constexpr size_t S3_LDS_EXTRA = 16 + (size_t)(SCREEN_BLOCK / 64) * (S3_QN * 10);
 
-template <int U, bool CANON = false>
+template <int U, int CANON = 0>
 __global__ void __launch_bounds__(1024)
 screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ rec_counts,
                uint4 *__restrict__ clear, uint64_t clear_vec4)
@@ -548,7 +561,7 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
         uint32_t sm[NS] = {d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, d[1].y, d[1].z, d[1].w};
         if (CANON) {
 #pragma unroll
-            for (int i = 0; i < NS; i++) sm[i] = canon16(sm[i]);          // (the key the LDS table and front2 are asked with, and what is queued)
+            for (int i = 0; i < NS; i++) sm[i] = canon_key<CANON>(sm[i], S.smask, 32u - 2u * (uint32_t)S.s);          // (the key the LDS table and front2 are asked with, and what is queued)
         }
 #pragma unroll
         for (int i = 0; i < NS; i++) {
@@ -1947,7 +1960,7 @@ template <auto Kernel> static void raise_lds_limit_once(size_t max_bytes)
     done.fetch_or(bit, std::memory_order_release);
 }
 
-template <int SPW, bool CANON>
+template <int SPW, int CANON>
 static void launch_screen_spw(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                               const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
@@ -2004,9 +2017,12 @@ static void launch_mark_spw(const ReadsView &R, const KmerSetView &S, const void
 hipError_t launch_screen(const ReadsView &R, const KmerSetView &S, void *recs, uint32_t *rec_counts, int n_cu, hipStream_t st,
                          const KernelTiming *tm, uint32_t *clear, uint64_t clear_vec4)
 {
-    if (S.stride == 16 && S.canon) launch_screen_spw<1, true>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);          // (canonical keys: 16-base samples only)
-    else if (S.stride == 16) launch_screen_spw<1, false>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
-    else launch_screen_spw<2, false>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    // (canonical keys: KmerSetView::canon is 1 for sixteen-base samples, 2 for shorter ones)
+    if (S.stride == 16 && S.canon == 1) launch_screen_spw<1, 1>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else if (S.stride == 16 && S.canon) launch_screen_spw<1, 2>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else if (S.stride == 16) launch_screen_spw<1, 0>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else if (S.canon) launch_screen_spw<2, 2>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
+    else launch_screen_spw<2, 0>(R, S, recs, rec_counts, n_cu, st, tm, clear, clear_vec4);
     return hipGetLastError();
 }
 

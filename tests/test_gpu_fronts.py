@@ -45,8 +45,8 @@ def front(mf):
 # (mode, front2 log2 blocks, front3 log2 blocks): roomy tables, overloaded front2 (nearly everything passes: what a round cannot
 # verify is passed on), a front3 behind an overloaded front2, the smallest tables there are
 FORMS = [(1, 0, -1), (1, 6, -1), (2, 0, -1), (2, 6, 0), (2, 6, 12), (2, 8, 6), (3, 0, -1), (3, 6, -1), (4, 0, -1), (4, 6, 8)]
-# ... and with the screen's tables built canonical (one key per bait s-mer, the samples made canonical in the screen: 16-base samples,
-# k >= 31; the option is ignored for shorter k), the plain LDS-table screen included
+# ... and with the screen's tables built canonical (one key per bait s-mer, the samples made canonical in the screen: six instructions for the
+# 16-base samples of k >= 31, eight for the shorter ones below), the plain LDS-table screen included
 FORMS += [(0, 0, -1, 1), (1, 0, -1, 1), (1, 6, -1, 1), (2, 0, -1, 1), (2, 6, 12, 1), (3, 0, -1, 1), (3, 6, -1, 1), (4, 0, -1, 1), (4, 6, 8, 1)]
 
 
@@ -55,7 +55,7 @@ FORMS += [(0, 0, -1, 1), (1, 0, -1, 1), (1, 6, -1, 1), (2, 0, -1, 1), (2, 6, 12,
 def test_forced_forms_match_oracle(mf, ol, bait_text, front, k, form):
     front(*form)
     ks = mf.KmerSet.from_text(bait_text, k)
-    assert ks.info.canonical_screen == (1 if len(form) > 3 and form[3] == 1 and k >= 31 else 0)
+    assert ks.info.canonical_screen == (1 if len(form) > 3 and form[3] == 1 else 0)          # (sixteen-base samples for k >= 31, shorter ones below)
     t = ol.OracleTable(bait_text, k)
     for uniform in (True, False):
         seqs = make_reads(bait_text, 5000, seed=300 + k, uniform=uniform)
@@ -74,7 +74,7 @@ def test_forced_forms_match_oracle(mf, ol, bait_text, front, k, form):
 
 
 @pytest.mark.parametrize("k", [17, 19, 21, 25, 27])
-@pytest.mark.parametrize("form", [(0, 0, -1), (1, 6, -1), (3, 0, -1), (4, 6, 8), (2, 6, 12)])
+@pytest.mark.parametrize("form", [(0, 0, -1), (1, 6, -1), (3, 0, -1), (4, 6, 8), (2, 6, 12), (0, 0, -1, 1), (1, 6, -1, 1), (4, 6, 8, 1), (2, 6, 12, 1)])
 def test_stride8_sets_through_the_finish_kernels(mf, ol, bait_text, front, k, form):
     """k < 28 (a sample every 8 bases): the threshold-1 pass through screen + finish -- what sets of baits beyond ~20 kbp take -- forced on small inputs,
     every screen form, uniform and ragged reads, single and pipelined passes: bits equal the oracle's"""
@@ -117,7 +117,7 @@ def test_forced_forms_pipelined_passes(mf, ol, bait_text, front, form):
     assert np.array_equal(bits, obits)
 
 
-@pytest.mark.parametrize("size,k", [(30_000, 31), (30_000, 21), (50_000, 31), (70_000, 31), (100_000, 31), (100_000, 21), (200_000, 31), (350_000, 31), (350_000, 41), (1_000_000, 31), (2_000_000, 31),
+@pytest.mark.parametrize("size,k", [(30_000, 31), (30_000, 21), (50_000, 31), (70_000, 31), (100_000, 31), (100_000, 21), (100_000, 29), (200_000, 31), (350_000, 21), (350_000, 31), (350_000, 41), (1_000_000, 31), (2_000_000, 31),
                                     (4_500_000, 31)])
 def test_large_baits_pick_their_screen(mf, ol, size, k):
     """baits that are large for real: the library picks the form -- for 16-base samples (k >= 31) canonical keys from ~40 kbp, with them the LDS table and a
@@ -126,9 +126,9 @@ def test_large_baits_pick_their_screen(mf, ol, size, k):
     from mitoflex_amd.utility.synth_bait import random_bait
     bait = random_bait(size, seed=size + k)
     ks = mf.KmerSet.from_text(bait, k)
-    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 70_000: 3, 100_000: 3 if k >= 31 else 4, 200_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 4, 4_500_000: 2}[size]
+    want_mode = {30_000: 3 if k >= 28 else 0, 50_000: 3 if k >= 28 else 1, 70_000: 3, 100_000: 3 if k >= 28 else 1, 200_000: 1, 350_000: 4, 1_000_000: 4, 2_000_000: 4, 4_500_000: 2}[size]
     assert ks.info.front_mode == want_mode, (size, k, ks.info.front_mode)
-    assert ks.info.canonical_screen == (1 if k >= 31 and size >= 70_000 else 0)
+    assert ks.info.canonical_screen == (1 if size >= (70_000 if k >= 28 else 100_000) else 0)
     assert (ks.info.front3_log2_blocks > 0) == (size >= 2_000_000)
     n, L = 200_000, 150
     reads = mf.Reads.synth(n, L, seed=size, bait_text=bait, keep_host=True)
