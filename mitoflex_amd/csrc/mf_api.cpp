@@ -402,15 +402,15 @@ static int kmerset_new(const char *text, size_t len, int k, int device, mf_kmers
         // a block (from ~800 kbp).
         options_from_env_once();
         uint64_t per_lds_block = bound >> (ks->bloom_log2w - 2);
+        ks->s8_finish = ks->geom.stride == 8 && per_lds_block > 5;          // (stride-8 sets beyond ~20 kbp: threshold-1 passes through screen + finish, enqueue_pass)
         // Canonical keys (16-base samples, i.e. k >= 31): from the size at which the LDS table stops screening a bait by itself, the screen's tables
         // hold one key per bait s-mer instead of one per strand and every sample is made canonical before it is looked up (six vector
         // instructions a sample, canon16) -- half the load on every table, so each form below reaches twice as far.  The six instructions cost the
         // LDS-table screens 0.03-0.04 ms a pass (16.5 kbp: 0.231 -> 0.266; 50 kbp, queued form: 0.295 -> 0.32), so the keys turn canonical where the
         // queued form with both strands ends (~61 kbp): 70 kbp 0.37 -> 0.32 ms a pass, 100 kbp 0.39 -> 0.36, 150 kbp 0.57 -> 0.40, 200 kbp 0.64 -> 0.45,
         // 350 kbp 0.86 -> 0.62, 1 Mbp 1.42 -> 1.09, 8.5 Mbp 4.6 -> 3.4 (profiles/r06/m_canon.txt).
-        ks->s8_finish = ks->geom.stride == 8 && per_lds_block > 5;
         // Shorter samples (k < 31) take eight instructions; the stride-16 ones (k = 28 .. 30) turn canonical at the same size, the stride-8 ones (k < 28: twice the
-        // samples to make canonical) where their both-strand per-turn form ends (~75 kbp): k = 21 at 100 kbp 0.85 -> 0.6 ms a pass (profiles/r06/p_canon_short.txt).
+        // samples to make canonical) where their both-strand per-turn form ends (~75 kbp): k = 21 at 100 kbp 0.85 -> 0.70 ms a pass, k = 29 0.45 -> 0.375 (profiles/r06/p_canon_short.txt).
         {
             const bool want = g_opt.canon < 0 ? per_lds_block > (ks->geom.stride == 8 ? 18u : 14u) : g_opt.canon == 1;
             ks->canon = !want ? 0 : ks->geom.s == 16 ? 1 : 2;
