@@ -69,31 +69,8 @@ __device__ __forceinline__ uint64_t read_holding(const ReadsView &R, uint64_t g,
         if (end) *end = g - off + R.uniform_len;
         return off + s <= R.uniform_len ? r : ~0ULL;
     }
-    // Ragged reads: the block index says which reads g's block of 128 bases holds and where they begin -- ONE 8-byte load (OffBlk,
-    // mf_common.h) where a binary search over all offsets of a 5 Gbp set took twenty-six dependent ones (0.49 ms a pass against 0.22 for
-    // uniform reads), and an index of read numbers plus the candidates' offsets two round trips to tables far beyond the caches (0.32 ms).
-    const uint64_t b = g >> OFF_BLK_SHIFT, B0 = b << OFF_BLK_SHIFT;
-    const OffBlk e = OffBlk::unpack(R.off_blk[b]);
-    const uint32_t rel = (uint32_t)(g - B0);
-    if (e.n <= 2) {
-        const uint32_t cnt = (e.n >= 1 && e.p1 <= rel ? 1u : 0u) + (e.n >= 2 && e.p2 <= rel ? 1u : 0u);
-        const uint64_t r = (uint64_t)e.r0 + cnt;
-        // where the read begins (exact, or "255 bases or more in front of the block") and ends (exact, or "255 or more behind it")
-        const uint64_t r_lo = cnt == 0 ? B0 - e.back : B0 + (cnt == 1 ? e.p1 : e.p2);
-        uint64_t r_hi = cnt < e.n ? B0 + (cnt == 0 ? e.p1 : e.p2) : B0 + 128 + e.fwd;
-        if (end && cnt == e.n && e.fwd == 255u) r_hi = R.offsets[r + 1];          // (a caller that wants the exact end of a long read)
-        if (start) *start = r_lo;
-        if (end) *end = r_hi;
-        return g + s <= r_hi ? r : ~0ULL;                                          // (s <= 255: a capped end is far enough)
-    }
-    // more than two reads begin inside the block (reads of a few bases): first offset > g, minus one, searched between this block's and the next one's read
-    uint64_t l = (uint64_t)e.r0 + 1, h = (uint64_t)(R.off_blk[b + 1] & 0x7FFFFFFFu) + 1;
-    if (h > R.n_reads) h = R.n_reads;                                              // (g < total_bases = offsets[n_reads]: never beyond the last entry)
-    while (l < h) { const uint64_t mid = (l + h) >> 1; if (R.offsets[mid] <= g) l = mid + 1; else h = mid; }
-    const uint64_t o_prev = R.offsets[l - 1], o_first = R.offsets[l];
-    if (start) *start = o_prev;
-    if (end) *end = o_first;
-    return g + s <= o_first ? l - 1 : ~0ULL;
+    // Ragged reads: the block index over the offsets (offblk_lookup, mf_common.h): one 8-byte load
+    return offblk_lookup(R.off_blk, R.offsets, R.n_reads, g, s, start, end);
 }
 
 __device__ __forceinline__ bool stab_contains(const KmerSetView &S, uint32_t sm)
@@ -1673,28 +1650,7 @@ __global__ void build_off_blk_kernel(const uint64_t *__restrict__ offsets, uint6
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
-    const uint64_t B0 = b << OFF_BLK_SHIFT, B1 = B0 + ((uint64_t)1 << OFF_BLK_SHIFT);
-    uint64_t lo = 0, hi = n_reads + 1;                 // first index with offsets[i] > B0 (n_reads + 1: none)
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= B0) lo = mid + 1; else hi = mid; }
-    OffBlk e{};
-    const uint64_t r0 = lo - 1;                        // (offsets[0] == 0 <= B0: lo >= 1)
-    e.r0 = (uint32_t)r0;
-    const uint64_t back = B0 - offsets[r0 <= n_reads ? r0 : n_reads];
-    e.back = back > 255 ? 255u : (uint32_t)back;
-    // the reads that begin inside the block behind its first base, and the first one that begins at or behind its end
-    uint32_t n = 0; uint64_t pos[3] = {0, 0, 0}; uint64_t next = ~0ULL;
-    for (uint64_t i = r0 + 1; i <= n_reads; i++) {
-        const uint64_t o = offsets[i];
-        if (o >= B1) { next = o; break; }
-        if (n < 3) pos[n] = o - B0;
-        n++;
-        if (n > 2) break;
-    }
-    e.n = n > 2 ? 3u : n;
-    e.p1 = (uint32_t)pos[0]; e.p2 = (uint32_t)pos[1];
-    const uint64_t fwd = next == ~0ULL ? 255 : next - B1;          // (no read start behind the block: the last read's end is offsets[n_reads], handled by the caller's total_bases check)
-    e.fwd = fwd > 255 ? 255u : (uint32_t)fwd;
-    blk[b] = e.pack();
+    blk[b] = offblk_make(offsets, n_reads, b).pack();
 }
 
 // mark reads that hold an invalid base (one thread per invalid position)
