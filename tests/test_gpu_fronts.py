@@ -186,6 +186,33 @@ def test_canonical_queue_keeps_within_the_record_lists(mf, ol, bait_text, front,
         mf.set_option("adapt", 1)
 
 
+@pytest.mark.parametrize("size,k", [(100_000, 31), (350_000, 31), (100_000, 21), (2_500_000, 31)])
+def test_large_baits_through_the_file_level_call(mf, ol, tmp_path, monkeypatch, size, k):
+    """the drop-in boundary with a large bait: mf_filter_fastq_files on a .gz pair (device ingest path: one pass a batch) and on the host pipeline,
+    kept / total and the output bytes equal to the oracle's"""
+    from mitoflex_amd.utility.synth_bait import random_bait
+    from tests.util_data import write_fastq
+    bait_text = random_bait(size, seed=size + k)
+    bait = str(tmp_path / "bait.fa")
+    open(bait, "w").write(bait_text)
+    s1 = make_reads(bait_text[:400_000], 30_000, seed=41)
+    s2 = make_reads(bait_text[:400_000], 30_000, seed=42)
+    fq1, fq2 = str(tmp_path / "a_1.fq.gz"), str(tmp_path / "a_2.fq.gz")
+    write_fastq(fq1, s1, "a", gz=True)
+    write_fastq(fq2, s2, "b", gz=True)
+    o1, o2 = str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq")
+    ok, ot = ol.filter_fastq_files(bait, k, 1, mf.PAIR_EITHER, fq1, fq2, o1, o2, threads=os.cpu_count() or 1)
+    assert ot == 30_000 and 0 < ok < ot
+    ks = mf.KmerSet.from_fasta(bait, k)
+    assert ks.info.front_mode != 0
+    for path in ("device", "host"):
+        monkeypatch.setenv("MF_INGEST", path)
+        g1, g2 = str(tmp_path / f"g1_{path}.fq"), str(tmp_path / f"g2_{path}.fq")
+        gk, gt = mf.filter_fastq_files(ks, fq1, fq2, g1, g2, 1, mf.PAIR_EITHER)
+        assert (gk, gt) == (ok, ot), (size, k, path)
+        assert open(g1, "rb").read() == open(o1, "rb").read() and open(g2, "rb").read() == open(o2, "rb").read(), (size, k, path)
+
+
 def test_full_size_set_through_a_saturated_lds_table(mf, ol):
     """configs[1]'s 33.3 M reads against a 350 kbp bait (the 128 KiB LDS table would pass three quarters of the samples: the library leaves it
     out and looks every sample up in front2): the screened pass equals the exhaustive one on every one of the 33.3 M bits, both equal the
