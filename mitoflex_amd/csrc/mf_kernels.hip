@@ -473,10 +473,10 @@ screen2_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
 
 // ----------------------------------------------- screen for baits a little too large for the LDS table
 // front_mode 3 (stride-16 geometries, baits of ~20 .. ~60 kbp: the LDS table passes 0.1 .. 2 % of the samples).  screen_kernel's loop with
-// one change: a lane whose chunk slice holds exactly ONE positive does not record it -- the sample goes into a queue of the wave in LDS
+// one change: a positive of a lane's chunk slice is not recorded at once -- the sample goes into a queue of the wave in LDS
 // (ballot / mbcnt; what is selective here is the LDS table, so a wave sees a handful a chunk), and when 64 have gathered they are looked up
-// in front2 by one dense 16-byte gather and only the survivors are recorded, each on behalf of the lane that queued it.  A slice with two or
-// more positives is recorded as ever: that is a bait read (two independent false positives in eight samples: 1e-4 at 0.4 %).  The per-chunk
+// in front2 by one dense 16-byte gather and only the survivors are recorded, each on behalf of the lane that queued it.  A slice with two
+// NEIGHBOURING positives is recorded as ever: that is a bait read, and the finish kernel's run detection wants it in one record.  The per-chunk
 // cost over screen_kernel is a dozen vector instructions; the look-ups cost one synchronous gather every tens of chunks.  The records, the
 // finish kernels and the emitted bits are what they were -- minus the false positives that cost a 33 kbp bait 0.306 ms a pass instead of 0.24.
 constexpr int S3_QN = 128;                 // queue entries per wave: fewer than 64 wait, a chunk adds at most 64
@@ -508,7 +508,7 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
     const uint64_t cstep = gridDim.x;
     ScreenRec *__restrict__ my_recs = recs + (size_t)blockIdx.x * rec_cap;
     uint32_t q_n = 0;                                                       // entries in this wave's queue (wave-uniform)
-    uint32_t e_w = 0, t_w = 0;                                              // canonical keys: what this wave has recorded and queued, and its turns (wave-uniform)
+    uint32_t e_w = 0, t_w = 0;                                              // what this wave has recorded and queued, and its turns (wave-uniform)
 
     auto load = [&](uint64_t c, u32x4 (&d)[U]) {
 #pragma unroll
@@ -546,21 +546,16 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
             const uint4 blk = s_tab4[__builtin_amdgcn_ubfe(h, idx_lo, idx_bits)];
             hitmask = alignbit(hitmask, block_test(sm[i], h, blk), 31);          // sample i: bit NS-1-i
         }
-        // Both strands in the table: a slice with two or more positives is a bait read (two independent false positives in eight samples: 1e-4 at
-        // 0.4 %) and is recorded as ever; only lone positives are queued.  Canonical keys: the form serves baits whose table passes 1 % and more,
-        // where two false positives in a slice are no longer rare (0.3 % of the slices at 100 kbp: 0.6 M of a pass's 1.3 M work items) -- a slice
-        // is recorded as it is only when two NEIGHBOURING samples are positive (what a bait read shows, and what the finish kernel's run detection
-        // needs in one record: 7e-4 of the slices by chance at 1 %); every other positive is queued, one per lane and round.
+        // A slice is recorded as it is only when two NEIGHBOURING samples are positive: what a bait read shows, and what the finish kernel's run detection
+        // needs in one record (by chance: 7e-4 of the slices at a table that passes 1 %).  Every other positive -- the lone ones, and since the canonical
+        // tables took the form to baits whose table passes 1 % and more, also two or three apart in one slice (0.3 % of the slices at 100 kbp: 0.6 M of a
+        // pass's 1.3 M work items; 60 kbp with both strands: 1.86 M work items -> 1.19 M) -- is queued, one per lane and round.
         // (A workgroup's record list holds one record per lane and chunk, and a slice whose positives are queued one by one may come back as
         // several.  A wave keeps count: what it has recorded and queued so far, e_w, never exceeds 64 a turn -- slices with several positives
         // are queued only while the wave is 256 entries under that line, which at 1 % positives it is from its fifth turn on; on bait-rich
         // input it is not, and such slices are recorded as they are.)
         uint32_t todo = hitmask;
-        if (!CANON) {
-            const bool single = hitmask != 0 && (hitmask & (hitmask - 1u)) == 0;
-            if (hitmask != 0 && !single) record((uint32_t)c, threadIdx.x, hitmask);
-            if (!single) todo = 0;
-        } else {
+        {
             t_w++;
             const bool roomy = e_w + 256u <= 64u * t_w;
             const bool single = (hitmask & (hitmask - 1u)) == 0;
@@ -580,10 +575,9 @@ screen3_kernel(ReadsView R, KmerSetView S, ScreenRec *__restrict__ recs, uint32_
                 todo &= ~(1u << bit);
             }
             q_n += (uint32_t)__popcll(bm);
-            if (CANON) e_w += (uint32_t)__popcll(bm);
+            e_w += (uint32_t)__popcll(bm);
             MF_COMPILER_FENCE();
             if (q_n >= 64u) drain();
-            if (!CANON) break;
         }
     };
 
