@@ -278,14 +278,14 @@ struct KmerSetView {
     uint32_t  stab_has_ones;    // the all-ones s-mer (poly-T, only possible for s == 16) is present
     uint32_t  use_stab;         // stage 3 on: stage 2 is too full to be trusted alone (large baits)
     // bait-sized fronts behind (or instead of) the LDS table, for baits the 128 KiB of LDS cannot screen (screen2_kernel): blocked bit
-    // tables of the stage-1 kind (128-bit blocks, one bit per dword, both strands inserted) in global memory.  front2 stays within
+    // tables of the stage-1 kind (128-bit blocks, one bit per dword; both strands inserted, or one canonical key per s-mer: `canon`) in global memory.  front2 stays within
     // an XCD's L2 (<= 4 MiB); front3 (only where front2 itself is overloaded: baits of several Mbp) is as large as the bait asks.
     uint32_t  front_mode;       // 0: LDS table only (screen_kernel) | 1: LDS table, its positives through front2 turn by turn | 2: every sample through front2
                                 // (no LDS table) | 3: LDS table, lone positives queued and looked up in front2 sixty-four at a time (screen3_kernel)
                                 // | 4: a one-bit LDS table in front of mode 2's look-ups
     uint32_t  f2_log2b, f3_log2b;   // blocks = 1 << log2b; f3_log2b == 0: no front3
     const uint32_t *front2, *front3;
-    // mode 4: a ONE-bit table for the LDS (1 << pre_log2w words, both strands inserted, bit = pre_bit(h)): at 100-500 kbp it still answers half to
+    // mode 4: a ONE-bit table for the LDS (1 << pre_log2w words, keys as in the other tables, bit = pre_bit(h)): at 100-500 kbp it still answers half to
     // two thirds of the samples itself, and only the rest is looked up in front2
     uint32_t  pre_log2w;
     const uint32_t *pre;
