@@ -229,6 +229,10 @@ int mf_filter_fastq_files_on(mf_kmerset *ks, const char *fq1, const char *fq2,
 
 /* Options that select which kernels a filter pass runs (process-wide; every variant gives the same bits and is parity-tested):
  *   pass=default|split|serial   adapt=0|1   finish_streams=0|1|2   screen_streams=1|2   split_pipe=0|1   exact_co=0|1
+ * and, read when a k-mer set is BUILT (ABI 5; every form gives the same bits -- tests force them on small baits):
+ *   front=-1|0|1|2|3|4 (which screen; -1: by the bait's size)   canon=-1|0|1 (one canonical key per bait s-mer in the screen's tables)
+ *   s8_finish=-1|0|1 (k < 28: threshold-1 passes through screen + finish)   front2_log2b=0|6..24   front3_log2b=-1|0|6..27
+ *   (MF_FRONT, MF_CANON, MF_S8_FINISH, MF_FRONT2_LOG2B, MF_FRONT3_LOG2B under MF_ENV_KNOBS=1); expect_files=0|1, short_lived=0|1 (ABI 4).
  * The library does NOT take these from the environment in a production process: the MF_PASS, MF_ADAPT, MF_FINISH_STREAMS,
  * MF_SCREEN_STREAMS, MF_SPLIT_PIPE and MF_EXACT_CO variables only count when MF_ENV_KNOBS=1 is set beside them (tests, bench.py,
  * profiling scripts).  ABI 3. */
